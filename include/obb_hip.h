@@ -1,0 +1,113 @@
+/*
+ * obb_hip.h -- C ABI of libobb_hip.so, the MI355X (gfx950) oriented-box hot path.
+ *
+ * Drop-in boundary for hukaixuan19970627/yolov5_obb: every entry point names the
+ * reference interface it replaces (file:line, relative to the reference root).
+ * Conventions shared by all functions:
+ *   - plain C: raw pointers + sizes, no torch / ATen types;
+ *   - every pointer is a DEVICE pointer unless its name ends in `_host`;
+ *   - buffers are caller-owned; inputs are never modified;
+ *   - work is enqueued on `stream` (a hipStream_t passed as void*; NULL = the
+ *     default stream) and is stream-ordered: no hidden host synchronisation, no
+ *     allocation, no device->host copy.  Scratch memory comes from `ws`
+ *     (size from the matching *_workspace_bytes query; 256-byte aligned);
+ *   - return value: OBB_OK (0) or a negative OBB_ERR_* code; nothing throws.
+ *     The Python host layer turns codes into RuntimeError, mirroring the
+ *     reference's AT_ASSERTM / AT_ERROR -> RuntimeError behaviour
+ *     (utils/nms_rotated/src/nms_rotated_ext.cpp:29-54).
+ *   - floating point: IEEE fp32, no FMA contraction; results are defined by the
+ *     CPU oracle in oracle/ (pinned to the reference's own sources).
+ */
+#ifndef OBB_HIP_H
+#define OBB_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OBB_OK 0
+#define OBB_ERR_BAD_ARG (-1)
+#define OBB_ERR_WORKSPACE (-2)   /* ws == NULL or ws_bytes too small */
+#define OBB_ERR_LAUNCH (-3)      /* a kernel launch failed (see hipGetLastError) */
+#define OBB_ERR_INTERNAL (-4)
+#define OBB_ERR_NO_DEVICE (-5)
+
+/* flags for obb_nms_rotated_* */
+#define OBB_NMS_DROP_SMALL 1 /* ignore boxes with min(w,h) < 0.001 (utils/nms_rotated/nms_rotated_wrapper.py:32-39) */
+
+/* Library / device identification: returns OBB_OK and fills the fields when a gfx950-class device is usable. */
+const char* obb_version(void);
+int obb_device_info(int* cu_count, int* wave_size, char* arch_name, int arch_name_len);
+
+/* ------------------------------------------------------------------ NMS ------------------------------ */
+
+/* Scratch bytes for n boxes in nseg segments.  kind: 0 = rotated boxes, 1 = quads. */
+size_t obb_nms_workspace_bytes(int64_t n, int64_t nseg, int kind);
+
+/*
+ * Rotated-box NMS.  Replaces nms_rotated_ext.nms_rotated on CUDA tensors
+ * (utils/nms_rotated/src/nms_rotated_ext.cpp:25-39 -> nms_rotated_cuda,
+ *  utils/nms_rotated/src/nms_rotated_cuda.cu:71-134: sort, N x N/64 mask kernel,
+ *  device->host mask copy, host greedy scan).
+ *   dets5    [n,5] fp32 contiguous  (cx, cy, w, h, angle in RADIANS)
+ *   scores   [n]   fp32
+ *   iou_thr  a box is dropped iff an earlier kept box has IoU > iou_thr (strict, cu:60)
+ *   max_keep 0 = unlimited; otherwise stop after this many kept boxes (the caller's max_det,
+ *            utils/general.py:854-855 truncates the same prefix)
+ *   keep_out [n] int64: original indices of kept boxes in descending-score order
+ *            (ties: ascending index; NaN scores first -- torch.sort's order)
+ *   num_keep [1] int64 (device)
+ */
+int obb_nms_rotated_f32(const float* dets5, const float* scores, int64_t n, float iou_thr, int flags, int64_t max_keep,
+                        int64_t* keep_out, int64_t* num_keep, void* ws, size_t ws_bytes, void* stream);
+
+/*
+ * The same for a batch of independent segments (images) in one call: what the per-image loop of
+ * non_max_suppression_obb (utils/general.py:801-857) does with bs separate obb_nms calls.
+ *   seg_id   [n] int32 in [0, nseg)          tie / tie_bits: optional explicit tie-break word (ascending)
+ *   max_seg  host-side upper bound on the size of any segment (<= 0: n)
+ *   keep_out [n]: segment g's kept indices start at seg_begin_out[g]
+ *   num_keep [nseg], seg_begin_out [nseg+1] (may be NULL)
+ */
+int obb_nms_rotated_batched_f32(const float* dets5, const float* scores, const int32_t* seg_id, const uint32_t* tie,
+                                int tie_bits, int64_t n, int64_t nseg, int64_t max_seg, float iou_thr, int flags,
+                                int64_t max_keep, int64_t* keep_out, int64_t* num_keep, int64_t* seg_begin_out, void* ws,
+                                size_t ws_bytes, void* stream);
+
+/*
+ * Quadrilateral NMS.  Replaces nms_rotated_ext.nms_poly (nms_rotated_ext.cpp:42-55 -> poly_nms_cuda,
+ * utils/nms_rotated/src/poly_nms_cuda.cu:197-261).  Rows are x1 y1 x2 y2 x3 y3 x4 y4 score (+ ignored extra
+ * columns): row_stride >= 9 floats.
+ */
+int obb_nms_poly_f32(const float* polys, int64_t row_stride, int64_t n, float iou_thr, int64_t max_keep, int64_t* keep_out,
+                     int64_t* num_keep, void* ws, size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------ pairwise IoU --------------------- */
+
+/* out[i] = IoU(a5[i], b5[i]); the device function behind the NMS
+ * (single_box_iou_rotated<float>, utils/nms_rotated/src/box_iou_rotated_utils.h:333-360). */
+int obb_rotated_iou_pairs_f32(const float* a5, const float* b5, int64_t n, float* out, void* stream);
+/* out[i*k + j] = IoU(a5[i], b5[j]) */
+int obb_rotated_iou_matrix_f32(const float* a5, int64_t n, const float* b5, int64_t k, float* out, void* stream);
+/* out[i*k + j] = quad IoU of rows (first 8 floats used) -- devPolyIoU, utils/nms_rotated/src/poly_nms_cuda.cu:122-142 */
+int obb_quad_iou_matrix_f32(const float* a, int64_t a_stride, int64_t n, const float* b, int64_t b_stride, int64_t k,
+                            float* out, void* stream);
+/* Dense IoU matrix of rboxes through RotBox2Poly + devPolyIoU: the overlaps_kernel of
+ * DOTA_devkit/poly_nms_gpu/poly_overlaps_kernel.cu:280-353 on device pointers. */
+int obb_rbox_overlaps_f32(const float* boxes5, int64_t n, const float* query5, int64_t k, float* out, void* stream);
+
+/* ------------------------------------------------------------------ devkit host-pointer API ---------- */
+
+/* Same symbols, argument order and host-pointer convention as the reference's devkit
+ * (DOTA_devkit/poly_nms_gpu/poly_nms.hpp:9-10, poly_overlaps.hpp:1); synchronous. */
+void _poly_nms(int* keep_out_host, int* num_out_host, const float* polys_host, int polys_num, int polys_dim,
+               float nms_overlap_thresh, int device_id);
+void _overlaps(float* overlaps_host, const float* boxes_host, const float* query_boxes_host, int n, int k, int device_id);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OBB_HIP_H */

@@ -1,0 +1,195 @@
+"""GPU parity: rotated / quad NMS and pairwise IoU through the C ABI vs the CPU oracle.
+
+Bar: kept-index sequences bit-exact (same indices, same order); IoU values bit-exact
+for the rotated/quad kernels (same IEEE fp32 operations as the oracle), except the
+devkit overlaps where fp32 cosf/sinf differ between ocml and glibc (<= 1e-5 abs).
+"""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from tests import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _gpu_keep(dets, scores, thr, dev):
+    from yolov5_obb_amd import nms_rotated_ext
+    k = nms_rotated_ext.nms_rotated(dets.to(dev), scores.to(dev), thr)
+    return k.cpu().numpy()
+
+
+@pytest.mark.parametrize("n,seed", [(1, 0), (2, 0), (63, 1), (64, 1), (65, 2), (1000, 0), (2048, 3), (2049, 3), (5000, 1)])
+@pytest.mark.parametrize("thr", [0.1, 0.4])
+def test_nms_rotated_uniform(dev, oracle_lib, n, seed, thr):
+    dets, scores = synth.s_uniform(n, seed)
+    scores = synth.tie_free(scores)
+    ref = oracle.nms_rotated(dets.numpy(), scores.numpy(), thr)
+    got = _gpu_keep(dets, scores, thr, dev)
+    assert np.array_equal(ref, got)
+
+
+@pytest.mark.parametrize("n,k,seed", [(1000, 30, 0), (10000, 300, 1), (30000, 300, 2)])
+@pytest.mark.parametrize("thr", [0.2, 0.45])
+def test_nms_rotated_clustered(dev, oracle_lib, n, k, seed, thr):
+    dets, scores = synth.s_clustered(n, k, seed)
+    scores = synth.tie_free(scores)
+    ref = oracle.nms_rotated(dets.numpy(), scores.numpy(), thr)
+    got = _gpu_keep(dets, scores, thr, dev)
+    assert np.array_equal(ref, got)
+
+
+def test_nms_rotated_class_offsets(dev, oracle_lib):
+    dets, scores = synth.s_clustered(6000, 100, 5)
+    dets, _ = synth.with_classes(dets, 16, 5)
+    scores = synth.tie_free(scores)
+    ref = oracle.nms_rotated(dets.numpy(), scores.numpy(), 0.4)
+    got = _gpu_keep(dets, scores, 0.4, dev)
+    assert np.array_equal(ref, got)
+
+
+def test_nms_rotated_ties_stable(dev, oracle_lib):
+    """fp16-rounded scores: many ties; documented rule = ascending original index among equals."""
+    dets, scores = synth.s_clustered(4000, 60, 11)
+    scores = scores.half().float()
+    assert scores.unique().numel() < scores.numel()
+    ref = oracle.nms_rotated(dets.numpy(), scores.numpy(), 0.3)
+    got = _gpu_keep(dets, scores, 0.3, dev)
+    assert np.array_equal(ref, got)
+
+
+def test_nms_rotated_thresholds_edge(dev, oracle_lib):
+    dets, scores = synth.s_clustered(1500, 40, 3)
+    scores = synth.tie_free(scores)
+    for thr in (0.0, 1.0, -0.5):
+        ref = oracle.nms_rotated(dets.numpy(), scores.numpy(), thr)
+        got = _gpu_keep(dets, scores, thr, dev)
+        assert np.array_equal(ref, got), thr
+
+
+def test_nms_rotated_degenerate_boxes(dev, oracle_lib):
+    dets, scores = synth.s_uniform(500, 4)
+    dets[::7, 2] = 0.0            # zero width: area < 1e-14 -> IoU 0 with everything
+    dets[::11, 3] = 1e-9
+    dets[5:200:13] = dets[4:199:13]   # exact duplicates
+    scores = synth.tie_free(scores)
+    ref = oracle.nms_rotated(dets.numpy(), scores.numpy(), 0.3)
+    got = _gpu_keep(dets, scores, 0.3, dev)
+    assert np.array_equal(ref, got)
+
+
+def test_obb_nms_wrapper_small_box_filter(dev, oracle_lib):
+    """obb_nms drops boxes with min(w,h) < 0.001 before NMS (nms_rotated_wrapper.py:32-39)."""
+    from yolov5_obb_amd.utils.nms_rotated import obb_nms
+    dets, scores = synth.s_clustered(3000, 50, 8)
+    dets[::5, 2] = 0.0005
+    scores = synth.tie_free(scores)
+    valid = (dets[:, 2:4].min(1)[0] >= 0.001).numpy()
+    idx = np.nonzero(valid)[0]
+    ref = idx[oracle.nms_rotated(dets.numpy()[valid], scores.numpy()[valid], 0.4)]
+    kept, inds = obb_nms(dets.to(dev), scores.to(dev), 0.4)
+    assert inds.device.type == "cuda" and inds.dtype == torch.int64
+    assert np.array_equal(ref, inds.cpu().numpy())
+    assert torch.equal(kept.cpu(), dets[inds.cpu()])
+    # all too small -> nothing
+    d2 = dets.clone(); d2[:, 3] = 0.0
+    _, inds2 = obb_nms(d2.to(dev), scores.to(dev), 0.4)
+    assert inds2.numel() == 0
+    # empty input
+    _, inds3 = obb_nms(dets[:0].to(dev), scores[:0].to(dev), 0.4)
+    assert inds3.numel() == 0 and inds3.dtype == torch.int64
+    # numpy in -> numpy indices out
+    k4, inds4 = obb_nms(dets.numpy(), scores.numpy(), 0.4, device_id=0)
+    assert isinstance(inds4, np.ndarray) and np.array_equal(inds4, ref)
+
+
+def test_nms_rotated_errors(dev):
+    from yolov5_obb_amd import nms_rotated_ext
+    from yolov5_obb_amd.utils.nms_rotated import obb_nms, poly_nms
+    dets, scores = synth.s_uniform(10, 0)
+    with pytest.raises(RuntimeError):
+        nms_rotated_ext.nms_rotated(dets, scores, 0.5)            # CPU tensors: no CPU path in this build
+    with pytest.raises(TypeError):
+        obb_nms([1, 2, 3], scores, 0.5)
+    with pytest.raises(NotImplementedError):
+        poly_nms(torch.zeros(3, 9), 0.5)                          # reference: CPU poly_nms not implemented
+    with pytest.raises(RuntimeError):
+        nms_rotated_ext.nms_poly(torch.zeros(3, 9), 0.5)
+
+
+@pytest.mark.parametrize("n,seed,thr", [(1, 0, 0.3), (300, 1, 0.1), (2500, 2, 0.3)])
+def test_nms_poly(dev, oracle_lib, n, seed, thr):
+    from yolov5_obb_amd import nms_rotated_ext
+    from yolov5_obb_amd.utils.nms_rotated import poly_nms
+    dets, scores = synth.s_clustered(n, max(1, n // 12), seed, extent=300.0)
+    scores = synth.tie_free(scores)
+    polys = torch.cat([synth.rbox_to_quad(dets), scores[:, None]], 1).contiguous()
+    polys[::9, :8] = polys[::9, :8].reshape(-1, 4, 2).flip(1).reshape(-1, 8)   # some clockwise rings
+    ref = oracle.nms_poly(polys.numpy(), thr)
+    got = nms_rotated_ext.nms_poly(polys.to(dev), thr).cpu().numpy()
+    assert np.array_equal(ref, got)
+    kept, inds = poly_nms(polys.to(dev), thr)
+    assert np.array_equal(inds.cpu().numpy(), ref) and torch.equal(kept.cpu(), polys[ref])
+
+
+def test_rotated_iou_pairs_bit_exact(dev, oracle_lib):
+    from yolov5_obb_amd import ops
+    a, _ = synth.s_uniform(200000, 1, extent=120.0)
+    b, _ = synth.s_uniform(200000, 2, extent=120.0)
+    a[:1000] = b[:1000]
+    a[1000:2000, 4] = 0; b[1000:2000, 4] = 0
+    a[2000:3000, :4] = a[2000:3000, :4].round(); b[2000:3000, :4] = b[2000:3000, :4].round()
+    a[2000:3000, 4] = 0; b[2000:3000, 4] = 0
+    got = ops.rotated_iou_pairs(a.to(dev), b.to(dev)).cpu().numpy()
+    ref = oracle.riou_pairs(a.numpy(), b.numpy())
+    bad = got.view(np.uint32) != ref.view(np.uint32)
+    # double-precision cos/sin come from ocml on the GPU and glibc on the host: a last-ulp difference in the
+    # double result can flip the float rounding of cos/sin once in ~1e8 evaluations; allow <= 2 such pairs
+    assert bad.sum() <= 2, (bad.sum(), np.abs(got - ref).max())
+    assert np.abs(got - ref).max() <= 1e-5
+    assert (ref > 0).mean() > 0.2
+
+
+def test_rotated_iou_matrix(dev, oracle_lib):
+    from yolov5_obb_amd import ops
+    a, _ = synth.s_uniform(300, 3, extent=200.0)
+    b, _ = synth.s_uniform(257, 4, extent=200.0)
+    got = ops.rotated_iou_matrix(a.to(dev), b.to(dev)).cpu().numpy()
+    ref = oracle.riou_matrix(a.numpy(), b.numpy())
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+
+
+def test_quad_iou_matrix_bit_exact(dev, oracle_lib):
+    from yolov5_obb_amd import ops
+    a, _ = synth.s_uniform(260, 5, extent=150.0)
+    b, _ = synth.s_uniform(190, 6, extent=150.0)
+    qa, qb = synth.rbox_to_quad(a), synth.rbox_to_quad(b)
+    qb[::5] = qb[::5].reshape(-1, 4, 2).flip(1).reshape(-1, 8)
+    qa[3] = qa[3, :2].repeat(4)        # degenerate point
+    qb[7] = qb[7, :2].repeat(4)
+    got = ops.quad_iou_matrix(qa.to(dev), qb.to(dev)).cpu().numpy()
+    ref = oracle.piou_matrix(qa.numpy(), qb.numpy())
+    same = (got.view(np.uint32) == ref.view(np.uint32)) | (np.isnan(got) & np.isnan(ref))
+    assert same.all(), (np.count_nonzero(~same), np.nanmax(np.abs(got - ref)))
+    assert got[3, 7] == 1.0            # both degenerate: union == 0 -> (0+1)/(0+1)  (poly_nms_cuda.cu:136-137)
+
+
+def test_devkit_overlaps_and_poly_gpu_nms(dev, oracle_lib):
+    from yolov5_obb_amd.DOTA_devkit.poly_nms_gpu import poly_overlaps
+    from yolov5_obb_amd.DOTA_devkit.poly_nms_gpu.nms_wrapper import poly_nms_gpu
+    from yolov5_obb_amd.DOTA_devkit.poly_nms_gpu.poly_nms import poly_gpu_nms
+    a, _ = synth.s_uniform(150, 7, extent=150.0)
+    b, _ = synth.s_uniform(70, 8, extent=150.0)
+    got = poly_overlaps(a.numpy(), b.numpy())
+    ref = oracle.devkit_overlaps(a.numpy(), b.numpy())
+    assert got.shape == (150, 70) and got.dtype == np.float32
+    assert np.abs(got - ref).max() <= 1e-5        # fp32 cosf/sinf: ocml vs glibc
+    dets, scores = synth.s_clustered(1200, 80, 9, extent=300.0)
+    scores = synth.tie_free(scores)
+    polys = torch.cat([synth.rbox_to_quad(dets), scores[:, None]], 1).numpy()
+    order = polys[:, 8].argsort()[::-1]            # poly_nms.pyx:18-19
+    ref_keep = order[oracle.devkit_poly_nms(np.ascontiguousarray(polys[order]), 0.3)]
+    got_keep = poly_gpu_nms(polys, 0.3)
+    assert isinstance(got_keep, list) and np.array_equal(np.asarray(got_keep), ref_keep)
+    assert poly_nms_gpu(polys[:0], 0.3) == []

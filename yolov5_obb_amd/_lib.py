@@ -1,0 +1,102 @@
+"""ctypes binding of libobb_hip.so (C ABI in include/obb_hip.h).
+
+PyTorch is used here only as plumbing: device memory (caching allocator),
+the current HIP stream, and tensors as typed views of device pointers.
+The library is loaded eagerly on first use and its absence is a hard error:
+there is no CPU / eager fallback anywhere in this package.
+"""
+import ctypes as C
+import os
+import threading
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libobb_hip.so")
+
+OBB_OK = 0
+OBB_NMS_DROP_SMALL = 1
+_ERR = {-1: "bad argument", -2: "workspace missing or too small", -3: "kernel launch failed",
+        -4: "internal error", -5: "no usable HIP device"}
+
+_lib = None
+_lock = threading.Lock()
+
+_vp, _i64, _i32, _f32, _sz = C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_size_t
+
+# name -> (restype, argtypes); must list every symbol include/obb_hip.h declares
+SIGNATURES = {
+    "obb_version": (C.c_char_p, []),
+    "obb_device_info": (_i32, [C.POINTER(_i32), C.POINTER(_i32), C.c_char_p, _i32]),
+    "obb_nms_workspace_bytes": (_sz, [_i64, _i64, _i32]),
+    "obb_nms_rotated_f32": (_i32, [_vp, _vp, _i64, _f32, _i32, _i64, _vp, _vp, _vp, _sz, _vp]),
+    "obb_nms_rotated_batched_f32": (_i32, [_vp, _vp, _vp, _vp, _i32, _i64, _i64, _i64, _f32, _i32, _i64, _vp, _vp, _vp,
+                                           _vp, _sz, _vp]),
+    "obb_nms_poly_f32": (_i32, [_vp, _i64, _i64, _f32, _i64, _vp, _vp, _vp, _sz, _vp]),
+    "obb_rotated_iou_pairs_f32": (_i32, [_vp, _vp, _i64, _vp, _vp]),
+    "obb_rotated_iou_matrix_f32": (_i32, [_vp, _i64, _vp, _i64, _vp, _vp]),
+    "obb_quad_iou_matrix_f32": (_i32, [_vp, _i64, _i64, _vp, _i64, _i64, _vp, _vp]),
+    "obb_rbox_overlaps_f32": (_i32, [_vp, _i64, _vp, _i64, _vp, _vp]),
+    "_poly_nms": (None, [_vp, _vp, _vp, _i32, _i32, _f32, _i32]),
+    "_overlaps": (None, [_vp, _vp, _vp, _i32, _i32, _i32]),
+}
+
+
+def lib():
+    """Load libobb_hip.so (once).  Raises ImportError with build instructions when it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} not found: the HIP extension is not built. Run `python -c 'import __graft_entry__ as g; "
+                f"g.build()'` (or `make -C yolov5_obb_amd/csrc`). yolov5_obb_amd has no CPU fallback.")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)  # AttributeError here == library/header mismatch
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc, what):
+    if rc != OBB_OK:
+        raise RuntimeError(f"{what} failed: {_ERR.get(rc, 'error')} (code {rc})")
+
+
+def stream_ptr(device):
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def require_cuda(t, name):
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name} must be a torch.Tensor, got {type(t)}")
+    if not t.is_cuda:
+        # the reference dispatches CPU tensors to nms_rotated_cpu (nms_rotated_ext.cpp:38); this build is GPU-only
+        raise RuntimeError(f"{name} must be a CUDA/HIP tensor: yolov5_obb_amd is compiled for MI355X only "
+                           f"(no CPU path, by design)")
+
+
+_ws_cache = {}
+
+
+def workspace(nbytes, device):
+    """A reusable scratch buffer per (device, stream); grown geometrically, never shrunk."""
+    key = (device.index if device.index is not None else torch.cuda.current_device(),
+           torch.cuda.current_stream(device).cuda_stream)
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < nbytes:
+        size = max(int(nbytes), 1 << 20)
+        if buf is not None:
+            size = max(size, 2 * buf.numel())
+        buf = torch.empty(size, dtype=torch.uint8, device=device)
+        _ws_cache[key] = buf
+    return buf

@@ -1,0 +1,190 @@
+// Pairwise IoU entry points: element-wise pairs, dense matrices, and the devkit's
+// rbox overlaps (DOTA_devkit/poly_nms_gpu/poly_overlaps_kernel.cu:280-353).
+//
+// Layout: one wave-sized workgroup per 64 x 64 output tile.  Lanes own COLUMNS
+// (so each store instruction writes 64 consecutive floats of one output row),
+// the row box is wave-uniform and read from LDS as a broadcast.  The <=24/20
+// clip points of each lane live in an LDS column (bank == lane).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "geom.h"
+#include "obb_hip.h"
+
+namespace obb {
+
+__device__ __forceinline__ void store_rot_feat(float* t, int i, const RBoxFeat& f) {
+  t[0 * 64 + i] = f.x; t[1 * 64 + i] = f.y; t[2 * 64 + i] = f.w; t[3 * 64 + i] = f.h;
+  t[4 * 64 + i] = f.sh; t[5 * 64 + i] = f.cw; t[6 * 64 + i] = f.ch; t[7 * 64 + i] = f.sw;
+  t[8 * 64 + i] = f.r; t[9 * 64 + i] = f.c; t[10 * 64 + i] = f.s; t[11 * 64 + i] = f.area;
+}
+
+__global__ __launch_bounds__(64) void k_riou_pairs(const float* __restrict__ a5, const float* __restrict__ b5, long long n,
+                                                   float* __restrict__ out) {
+  __shared__ float scr[RotGeom::SCR * 64];
+  long long i = (long long)blockIdx.x * 64 + threadIdx.x;
+  if (i >= n) return;
+  const float* a = a5 + i * 5; const float* b = b5 + i * 5;
+  RBoxFeat A = rbox_make_feat(a[0], a[1], a[2], a[3], a[4]);
+  RBoxFeat B = rbox_make_feat(b[0], b[1], b[2], b[3], b[4]);
+  out[i] = RotGeom::iou(A, B, scr + threadIdx.x);
+}
+
+__global__ __launch_bounds__(64) void k_riou_matrix(const float* __restrict__ a5, long long n, const float* __restrict__ b5,
+                                                    long long k, float* __restrict__ out) {
+  __shared__ float rowf[RotGeom::NF * 64];
+  __shared__ float scr[RotGeom::SCR * 64];
+  const int lane = threadIdx.x;
+  const long long i0 = (long long)blockIdx.y * 64, j = (long long)blockIdx.x * 64 + lane;
+  {
+    long long i = i0 + lane;
+    RBoxFeat f = {};
+    if (i < n) { const float* a = a5 + i * 5; f = rbox_make_feat(a[0], a[1], a[2], a[3], a[4]); }
+    store_rot_feat(rowf, lane, f);
+  }
+  RBoxFeat B = {};
+  if (j < k) { const float* b = b5 + j * 5; B = rbox_make_feat(b[0], b[1], b[2], b[3], b[4]); }
+  __syncthreads();
+  const int nr = (int)((n - i0) < 64 ? (n - i0) : 64);
+  for (int r = 0; r < nr; r++) {
+    RBoxFeat A = RotGeom::load(rowf, r);
+    if (j < k) {
+      // the reject only fires where the reference provably returns exactly 0
+      float v = rbox_certainly_disjoint(A, B) ? 0.f : RotGeom::iou(A, B, scr + lane);
+      out[(i0 + r) * k + j] = v;
+    }
+  }
+}
+
+__global__ __launch_bounds__(64) void k_quad_matrix(const float* __restrict__ a, long long sa, long long n,
+                                                    const float* __restrict__ b, long long sb, long long k,
+                                                    float* __restrict__ out) {
+  __shared__ float rowf[QuadGeom::NF * 64];
+  __shared__ float scr[QuadGeom::SCR * 64];
+  const int lane = threadIdx.x;
+  const long long i0 = (long long)blockIdx.y * 64, j = (long long)blockIdx.x * 64 + lane;
+  {
+    long long i = i0 + lane;
+#pragma unroll
+    for (int c = 0; c < 8; c++) rowf[c * 64 + lane] = (i < n) ? a[i * sa + c] : 0.f;
+  }
+  QuadFeat B = {};
+  if (j < k) {
+#pragma unroll
+    for (int c = 0; c < 4; c++) { B.x[c] = b[j * sb + 2 * c]; B.y[c] = b[j * sb + 2 * c + 1]; }
+  }
+  __syncthreads();
+  const int nr = (int)((n - i0) < 64 ? (n - i0) : 64);
+  for (int r = 0; r < nr; r++) {
+    QuadFeat A = QuadGeom::load(rowf, r);
+    if (j < k) out[(i0 + r) * k + j] = QuadGeom::iou(A, B, scr + lane);
+  }
+}
+
+// RotBox2Poly (poly_overlaps_kernel.cu:280-297): fp32 cos/sin, corner arithmetic in double
+// (the "/ 2.0" literals promote), one rounding to float per coordinate.
+__device__ __forceinline__ void rbox_to_quad_devkit(const float* d, float* qx, float* qy) {
+  float cs = cosf(d[4]), ss = sinf(d[4]);
+  double w = d[2], h = d[3], x = d[0], y = d[1];
+  qx[0] = (float)(x + cs * (w / 2.0) - ss * (-h / 2.0));
+  qx[1] = (float)(x + cs * (w / 2.0) - ss * (h / 2.0));
+  qx[2] = (float)(x + cs * (-w / 2.0) - ss * (h / 2.0));
+  qx[3] = (float)(x + cs * (-w / 2.0) - ss * (-h / 2.0));
+  qy[0] = (float)(y + ss * (w / 2.0) + cs * (-h / 2.0));
+  qy[1] = (float)(y + ss * (w / 2.0) + cs * (h / 2.0));
+  qy[2] = (float)(y + ss * (-w / 2.0) + cs * (h / 2.0));
+  qy[3] = (float)(y + ss * (-w / 2.0) + cs * (-h / 2.0));
+}
+
+__global__ __launch_bounds__(64) void k_rbox_overlaps(const float* __restrict__ boxes, long long n,
+                                                      const float* __restrict__ query, long long k, float* __restrict__ out) {
+  __shared__ float rowf[QuadGeom::NF * 64];
+  __shared__ float scr[QuadGeom::SCR * 64];
+  const int lane = threadIdx.x;
+  const long long i0 = (long long)blockIdx.y * 64, j = (long long)blockIdx.x * 64 + lane;
+  {
+    long long i = i0 + lane;
+    float qx[4] = {0, 0, 0, 0}, qy[4] = {0, 0, 0, 0};
+    if (i < n) rbox_to_quad_devkit(boxes + i * 5, qx, qy);
+#pragma unroll
+    for (int c = 0; c < 4; c++) { rowf[(2 * c) * 64 + lane] = qx[c]; rowf[(2 * c + 1) * 64 + lane] = qy[c]; }
+  }
+  QuadFeat B = {};
+  if (j < k) rbox_to_quad_devkit(query + j * 5, B.x, B.y);
+  __syncthreads();
+  const int nr = (int)((n - i0) < 64 ? (n - i0) : 64);
+  for (int r = 0; r < nr; r++) {
+    QuadFeat A = QuadGeom::load(rowf, r);
+    if (j < k) out[(i0 + r) * k + j] = QuadGeom::iou(A, B, scr + lane);
+  }
+}
+
+}  // namespace obb
+
+using namespace obb;
+
+#define OBB_CHECK_LAUNCH() (hipGetLastError() == hipSuccess ? OBB_OK : OBB_ERR_LAUNCH)
+
+extern "C" {
+
+int obb_rotated_iou_pairs_f32(const float* a5, const float* b5, int64_t n, float* out, void* stream) {
+  if (n < 0 || (n > 0 && (!a5 || !b5 || !out))) return OBB_ERR_BAD_ARG;
+  if (n == 0) return OBB_OK;
+  k_riou_pairs<<<(unsigned)((n + 63) / 64), 64, 0, (hipStream_t)stream>>>(a5, b5, n, out);
+  return OBB_CHECK_LAUNCH();
+}
+
+int obb_rotated_iou_matrix_f32(const float* a5, int64_t n, const float* b5, int64_t k, float* out, void* stream) {
+  if (n < 0 || k < 0 || (n > 0 && k > 0 && (!a5 || !b5 || !out))) return OBB_ERR_BAD_ARG;
+  if (n == 0 || k == 0) return OBB_OK;
+  dim3 g((unsigned)((k + 63) / 64), (unsigned)((n + 63) / 64));
+  if (g.y > 65535) return OBB_ERR_BAD_ARG;
+  k_riou_matrix<<<g, 64, 0, (hipStream_t)stream>>>(a5, n, b5, k, out);
+  return OBB_CHECK_LAUNCH();
+}
+
+int obb_quad_iou_matrix_f32(const float* a, int64_t a_stride, int64_t n, const float* b, int64_t b_stride, int64_t k,
+                            float* out, void* stream) {
+  if (n < 0 || k < 0 || a_stride < 8 || b_stride < 8 || (n > 0 && k > 0 && (!a || !b || !out))) return OBB_ERR_BAD_ARG;
+  if (n == 0 || k == 0) return OBB_OK;
+  dim3 g((unsigned)((k + 63) / 64), (unsigned)((n + 63) / 64));
+  if (g.y > 65535) return OBB_ERR_BAD_ARG;
+  k_quad_matrix<<<g, 64, 0, (hipStream_t)stream>>>(a, a_stride, n, b, b_stride, k, out);
+  return OBB_CHECK_LAUNCH();
+}
+
+int obb_rbox_overlaps_f32(const float* boxes5, int64_t n, const float* query5, int64_t k, float* out, void* stream) {
+  if (n < 0 || k < 0 || (n > 0 && k > 0 && (!boxes5 || !query5 || !out))) return OBB_ERR_BAD_ARG;
+  if (n == 0 || k == 0) return OBB_OK;
+  dim3 g((unsigned)((k + 63) / 64), (unsigned)((n + 63) / 64));
+  if (g.y > 65535) return OBB_ERR_BAD_ARG;
+  k_rbox_overlaps<<<g, 64, 0, (hipStream_t)stream>>>(boxes5, n, query5, k, out);
+  return OBB_CHECK_LAUNCH();
+}
+
+
+// Devkit host-pointer API (DOTA_devkit/poly_nms_gpu/poly_overlaps.hpp:1, poly_overlaps_kernel.cu:368-427):
+// allocate, upload, run, download, free; synchronous; errors are printed, not raised (CUDA_CHECK there
+// prints and continues, poly_nms_kernel.cu:20-27).
+void _overlaps(float* overlaps_host, const float* boxes_host, const float* query_boxes_host, int n, int k, int device_id) {
+  if (n <= 0 || k <= 0) return;
+  int cur = 0;
+  if (hipGetDevice(&cur) != hipSuccess) { fprintf(stderr, "_overlaps: no HIP device\n"); return; }
+  if (device_id >= 0 && device_id != cur) hipSetDevice(device_id);
+  float *db = nullptr, *dq = nullptr, *dout = nullptr;
+  hipError_t e = hipMalloc(&db, (size_t)n * 5 * 4);
+  if (e == hipSuccess) e = hipMalloc(&dq, (size_t)k * 5 * 4);
+  if (e == hipSuccess) e = hipMalloc(&dout, (size_t)n * k * 4);
+  if (e == hipSuccess) e = hipMemcpy(db, boxes_host, (size_t)n * 5 * 4, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(dq, query_boxes_host, (size_t)k * 5 * 4, hipMemcpyHostToDevice);
+  if (e == hipSuccess) {
+    int rc = obb_rbox_overlaps_f32(db, n, dq, k, dout, nullptr);
+    if (rc) fprintf(stderr, "_overlaps: launch failed (%d)\n", rc);
+    e = hipMemcpy(overlaps_host, dout, (size_t)n * k * 4, hipMemcpyDeviceToHost);
+  }
+  if (e != hipSuccess) fprintf(stderr, "_overlaps: %s\n", hipGetErrorString(e));
+  hipFree(db); hipFree(dq); hipFree(dout);
+  if (device_id >= 0 && device_id != cur) hipSetDevice(cur);
+}
+
+}  // extern "C"

@@ -1,0 +1,228 @@
+// Rotated-rectangle IoU for gfx950 -- written from scratch for this project.
+//
+// Behavioural contract (what the result bits must equal):
+//   reference  utils/nms_rotated/src/box_iou_rotated_utils.h:333-360
+//   (single_box_iou_rotated<float>, *device* hull branch :195-218), evaluated
+//   in IEEE fp32 without FMA contraction -- the same contract the CPU oracle
+//   (oracle/riou_impl.inc) is pinned to.  Compile with -ffp-contract=off.
+//
+// What is different from the reference's formulation (and why it is legal):
+//   * the double-precision cos/sin depend on one box only, so they are hoisted
+//     into a per-box feature record computed once per NMS call (N evaluations
+//     instead of N^2) -- rbox_make_feat(); the four products s2*h, c2*w, c2*h,
+//     s2*w are hoisted with them (each is a single rounded fp32 product in the
+//     reference, so the hoisted value is the same bits);
+//   * a conservative reject (rbox_certainly_disjoint) answers "IoU == 0"
+//     without running the clip when the rectangles are separated by a clear
+//     margin: in that case the reference finds no edge crossing and no contained
+//     corner (num <= 2, :322-324) and returns exactly 0;
+//   * the <=24 candidate points live in a caller-provided scratch with a
+//     compile-time lane stride (LDS column per lane on the GPU: bank = lane, no
+//     conflicts; stride 1 on the host check) instead of per-thread local arrays
+//     that would spill to scratch memory;
+//   * the hull is built in place (p and q of the reference alias) and the
+//     squared distances are recomputed instead of being swapped along.
+#pragma once
+#include "obb_device.h"
+
+namespace obb {
+
+struct RBoxFeat {
+  float x, y, w, h;      // raw box (centre, size)
+  float sh, cw, ch, sw;  // (float)sin(a)*0.5f*h, (float)cos(a)*0.5f*w, ...*h, ...*w
+  float r;               // inflated circumradius (cull)
+  float c, s;            // cos(a), sin(a) in fp32 (cull only)
+  float area;            // w*h
+};
+
+OBB_HD RBoxFeat rbox_make_feat(float x, float y, float w, float h, float a) {
+  RBoxFeat f;
+  double th = (double)a;
+  float c2 = (float)cos(th) * 0.5f;  // box_iou_rotated_utils.h:63-65
+  float s2 = (float)sin(th) * 0.5f;
+  f.x = x; f.y = y; f.w = w; f.h = h;
+  f.sh = s2 * h; f.cw = c2 * w; f.ch = c2 * h; f.sw = s2 * w;
+  f.c = c2 * 2.0f; f.s = s2 * 2.0f;
+  f.r = sqrtf(w * w + h * h) * 0.5005f;  // half diagonal, +0.1 %
+  f.area = w * h;                         // :351-352
+  return f;
+}
+
+// True only when the reference provably returns IoU == 0 for this pair:
+// separation by >= 0.1 % of the involved extents on the centre line or on one
+// of the four edge normals.  NaN anywhere makes every test false (not culled).
+OBB_HD bool rbox_certainly_disjoint(const RBoxFeat& A, const RBoxFeat& B) {
+  float dx = B.x - A.x, dy = B.y - A.y;
+  float rs = A.r + B.r;
+  if (dx * dx + dy * dy > rs * rs) return true;
+  const float m = 1.001f;
+  float hwA = fabsf(A.w) * 0.5f, hhA = fabsf(A.h) * 0.5f;
+  float hwB = fabsf(B.w) * 0.5f, hhB = fabsf(B.h) * 0.5f;
+  // corner = centre +- w/2 * (c, -s) +- h/2 * (s, c)
+  float cc = fabsf(A.c * B.c + A.s * B.s);  // |cos(dtheta)|
+  float ss = fabsf(B.s * A.c - B.c * A.s);  // |sin(dtheta)|
+  if (fabsf(dx * A.c - dy * A.s) > (hwA + hwB * cc + hhB * ss) * m) return true;
+  if (fabsf(dx * A.s + dy * A.c) > (hhA + hwB * ss + hhB * cc) * m) return true;
+  if (fabsf(dx * B.c - dy * B.s) > (hwB + hwA * cc + hhA * ss) * m) return true;
+  if (fabsf(dx * B.s + dy * B.c) > (hhB + hwA * ss + hhA * cc) * m) return true;
+  return false;
+}
+
+// Upper bound on any IoU the reference can return for the pair (area ratio,
+// +0.1 %): IoU = I/(a1+a2-I) with I <= min(a1,a2).  Used to skip the clip when
+// the bound is already <= the NMS threshold.  Returns +inf when not applicable.
+OBB_HD float rbox_iou_upper_bound(const RBoxFeat& A, const RBoxFeat& B) {
+  float lo = fminf(A.area, B.area), hi = fmaxf(A.area, B.area);
+  if (!(lo > 1e-6f) || !(hi < 1e30f)) return __builtin_inff();
+  return lo / hi * 1.001f;
+}
+
+// Full clip.  A = higher-scored ("row") box, B = lower-scored ("column") box:
+// the argument order is part of the contract (nms_rotated_cuda.cu:60).
+// px/py: scratch for 24 points, element i at [i * STRIDE].
+template <int STRIDE>
+OBB_HD float rbox_iou(const RBoxFeat& A, const RBoxFeat& B, float* px, float* py) {
+  constexpr float kDetLe = f32_floor(1e-14);   // fabs(det) <= 1e-14
+  constexpr float kAreaLt = f32_ceil(1e-14);   // area < 1e-14
+  constexpr float kCpLtNeg = f32_ceil(-1e-6);  // cp < -1e-6
+  constexpr float kCpLt = f32_ceil(1e-6);      // fabs(cp) < 1e-6
+  constexpr float kD2Gt = f32_floor(1e-8);     // dist > 1e-8
+
+  if (A.area < kAreaLt || B.area < kAreaLt) return 0.f;  // :353
+
+  // centre shift, evaluated in double like the reference (:338-346)
+  double mx = (double)(A.x + B.x) * 0.5, my = (double)(A.y + B.y) * 0.5;
+  float ax = (float)((double)A.x - mx), ay = (float)((double)A.y - my);
+  float bx = (float)((double)B.x - mx), by = (float)((double)B.y - my);
+
+  float v1x[4], v1y[4], v2x[4], v2y[4];
+  v1x[0] = ax + A.sh + A.cw; v1y[0] = ay + A.ch - A.sw;
+  v1x[1] = ax - A.sh + A.cw; v1y[1] = ay - A.ch - A.sw;
+  v1x[2] = 2 * ax - v1x[0];  v1y[2] = 2 * ay - v1y[0];
+  v1x[3] = 2 * ax - v1x[1];  v1y[3] = 2 * ay - v1y[1];
+  v2x[0] = bx + B.sh + B.cw; v2y[0] = by + B.ch - B.sw;
+  v2x[1] = bx - B.sh + B.cw; v2y[1] = by - B.ch - B.sw;
+  v2x[2] = 2 * bx - v2x[0];  v2y[2] = 2 * by - v2y[0];
+  v2x[3] = 2 * bx - v2x[1];  v2y[3] = 2 * by - v2y[1];
+
+  float e1x[4], e1y[4], e2x[4], e2y[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    e1x[i] = v1x[(i + 1) & 3] - v1x[i]; e1y[i] = v1y[(i + 1) & 3] - v1y[i];
+    e2x[i] = v2x[(i + 1) & 3] - v2x[i]; e2y[i] = v2y[(i + 1) & 3] - v2y[i];
+  }
+
+  int n = 0;
+  // 16 edge/edge crossings (:93-112)
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      float det = e2x[j] * e1y[i] - e1x[i] * e2y[j];
+      if (fabsf(det) <= kDetLe) continue;
+      float dx = v2x[j] - v1x[i], dy = v2y[j] - v1y[i];
+      float t1 = (e2x[j] * dy - dx * e2y[j]) / det;
+      float t2 = (e1x[i] * dy - dx * e1y[i]) / det;
+      if (t1 >= 0.0f && t1 <= 1.0f && t2 >= 0.0f && t2 <= 1.0f) {
+        px[n * STRIDE] = v1x[i] + e1x[i] * t1;
+        py[n * STRIDE] = v1y[i] + e1y[i] * t1;
+        n++;
+      }
+    }
+  }
+  // corners of A inside B (:115-135)
+  {
+    float abab = e2x[0] * e2x[0] + e2y[0] * e2y[0];
+    float adad = e2x[3] * e2x[3] + e2y[3] * e2y[3];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      float apx = v1x[i] - v2x[0], apy = v1y[i] - v2y[0];
+      float apab = apx * e2x[0] + apy * e2y[0];
+      float apad = -(apx * e2x[3] + apy * e2y[3]);
+      if (apab >= 0 && apad >= 0 && apab <= abab && apad <= adad) {
+        px[n * STRIDE] = v1x[i]; py[n * STRIDE] = v1y[i]; n++;
+      }
+    }
+  }
+  // corners of B inside A (:138-154)
+  {
+    float abab = e1x[0] * e1x[0] + e1y[0] * e1y[0];
+    float adad = e1x[3] * e1x[3] + e1y[3] * e1y[3];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      float apx = v2x[i] - v1x[0], apy = v2y[i] - v1y[0];
+      float apab = apx * e1x[0] + apy * e1y[0];
+      float apad = -(apx * e1x[3] + apy * e1y[3]);
+      if (apab >= 0 && apad >= 0 && apab <= abab && apad <= adad) {
+        px[n * STRIDE] = v2x[i]; py[n * STRIDE] = v2y[i]; n++;
+      }
+    }
+  }
+
+  float inter = 0.f;
+  if (n > 2) {
+    // ---- Graham scan in place (:159-291) ----
+    int t = 0;
+    float tx = px[0], ty = py[0];
+    for (int i = 1; i < n; i++) {
+      float x = px[i * STRIDE], y = py[i * STRIDE];
+      if (y < ty || (y == ty && x < tx)) { t = i; tx = x; ty = y; }
+    }
+    for (int i = 0; i < n; i++) { px[i * STRIDE] -= tx; py[i * STRIDE] -= ty; }
+    {
+      float x0 = px[0], y0 = py[0];
+      px[0] = px[t * STRIDE]; py[0] = py[t * STRIDE];
+      px[t * STRIDE] = x0; py[t * STRIDE] = y0;
+    }
+    // exchange sort by polar angle around the pivot, ties by distance (:205-218)
+    for (int i = 1; i < n - 1; i++) {
+      float qix = px[i * STRIDE], qiy = py[i * STRIDE];
+      for (int j = i + 1; j < n; j++) {
+        float qjx = px[j * STRIDE], qjy = py[j * STRIDE];
+        float cp = qix * qjy - qjx * qiy;
+        bool sw = cp < kCpLtNeg;
+        if (!sw && fabsf(cp) < kCpLt) sw = (qix * qix + qiy * qiy) > (qjx * qjx + qjy * qjy);
+        if (sw) {
+          px[j * STRIDE] = qix; py[j * STRIDE] = qiy;
+          qix = qjx; qiy = qjy;
+        }
+      }
+      px[i * STRIDE] = qix; py[i * STRIDE] = qiy;
+    }
+    // first point that is not a duplicate of the pivot (:239-249)
+    int k = 1;
+    for (; k < n; k++) {
+      float x = px[k * STRIDE], y = py[k * STRIDE];
+      if (x * x + y * y > kD2Gt) break;
+    }
+    if (k < n) {
+      px[1 * STRIDE] = px[k * STRIDE]; py[1 * STRIDE] = py[k * STRIDE];
+      int m = 2;
+      for (int i = k + 1; i < n; i++) {
+        float qx = px[i * STRIDE], qy = py[i * STRIDE];
+        while (m > 1) {
+          float bx2 = px[(m - 2) * STRIDE], by2 = py[(m - 2) * STRIDE];
+          float q1x = qx - bx2, q1y = qy - by2;
+          float q2x = px[(m - 1) * STRIDE] - bx2, q2y = py[(m - 1) * STRIDE] - by2;
+          if (q1x * q2y >= q2x * q1y) m--; else break;  // two rounded products (:266)
+        }
+        px[m * STRIDE] = qx; py[m * STRIDE] = qy; m++;
+      }
+      // fan area (:293-305)
+      if (m > 2) {
+        float q0x = px[0], q0y = py[0];
+        float acc = 0.f;
+        float pxx = px[1 * STRIDE] - q0x, pyy = py[1 * STRIDE] - q0y;
+        for (int i = 1; i < m - 1; i++) {
+          float nx = px[(i + 1) * STRIDE] - q0x, ny = py[(i + 1) * STRIDE] - q0y;
+          acc += fabsf(pxx * ny - nx * pyy);
+          pxx = nx; pyy = ny;
+        }
+        inter = acc * 0.5f;  // area / 2.0 (exact scaling either way)
+      }
+    }
+  }
+  return inter / (A.area + B.area - inter);  // :358
+}
+
+}  // namespace obb

@@ -1,0 +1,75 @@
+"""Mirror of the reference's compiled module ``nms_rotated_ext``
+(utils/nms_rotated/src/nms_rotated_ext.cpp:57-60): ``nms_rotated`` and ``nms_poly``.
+
+Same signatures, return conventions and error types; the work is done by
+``obb_nms_rotated_f32`` / ``obb_nms_poly_f32`` of libobb_hip.so.
+"""
+import torch
+
+from . import _lib
+
+__all__ = ["nms_rotated", "nms_poly"]
+
+
+def _run_rotated(dets, scores, iou_threshold, flags=0, max_keep=0):
+    L = _lib.lib()
+    n = dets.shape[0]
+    dev = dets.device
+    keep = torch.empty(n, dtype=torch.int64, device=dev)
+    cnt = torch.empty(1, dtype=torch.int64, device=dev)
+    with torch.cuda.device(dev):
+        nbytes = L.obb_nms_workspace_bytes(n, 1, 0)
+        ws = _lib.workspace(nbytes, dev)
+        rc = L.obb_nms_rotated_f32(_lib.ptr(dets), _lib.ptr(scores), n, float(iou_threshold), int(flags), int(max_keep),
+                                   _lib.ptr(keep), _lib.ptr(cnt), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev))
+    _lib.check(rc, "obb_nms_rotated_f32")
+    return keep[: int(cnt.item())]
+
+
+def nms_rotated(dets, scores, iou_threshold):
+    """nms_rotated_ext.cpp:25-39.  dets (N,5) [cx,cy,w,h,theta_rad], scores (N) -> LongTensor of kept
+    original indices in descending-score order, on dets' device.  A box is dropped iff an earlier kept box
+    has IoU > iou_threshold (the CUDA path's strict compare, nms_rotated_cuda.cu:60)."""
+    _lib.require_cuda(dets, "dets")
+    _lib.require_cuda(scores, "scores")
+    if dets.device != scores.device:
+        raise RuntimeError("dets and scores must be on the same device")  # bare assert in the reference (:29)
+    if dets.dtype != scores.dtype:
+        raise RuntimeError("dets should have the same type as scores")  # nms_rotated_cpu.cpp:19-21
+    if dets.dtype != torch.float32:
+        # the reference dispatches float and double (nms_rotated_cuda.cu:96); every caller in the repository
+        # passes float32 (utils/general.py:849-853), which is what the HIP kernels implement
+        raise RuntimeError(f"nms_rotated: only float32 is implemented on MI355X, got {dets.dtype}")
+    if dets.dim() != 2 or dets.shape[1] != 5 or scores.dim() != 1 or scores.shape[0] != dets.shape[0]:
+        raise RuntimeError(f"nms_rotated: expected dets (N,5) and scores (N), got {tuple(dets.shape)} {tuple(scores.shape)}")
+    if dets.numel() == 0:
+        return torch.empty(0, dtype=torch.int64, device=dets.device)
+    return _run_rotated(dets.contiguous(), scores.contiguous(), iou_threshold)
+
+
+def nms_poly(dets, iou_threshold):
+    """nms_rotated_ext.cpp:42-55.  dets (N,9) [x1 y1 .. x4 y4 score] float32 on the GPU -> LongTensor of kept
+    original indices in descending-score order.  CPU input raises like the reference (AT_ERROR, :54)."""
+    if not isinstance(dets, torch.Tensor):
+        raise TypeError(f"dets must be a torch.Tensor, got {type(dets)}")
+    if not dets.is_cuda:
+        raise RuntimeError("POLY_NMS is not implemented on CPU")
+    if dets.numel() == 0:
+        # the reference returns a CPU tensor here (:47-48)
+        return torch.empty(0, dtype=torch.int64, device="cpu")
+    if dets.dtype != torch.float32:
+        raise RuntimeError(f"nms_poly: float32 expected (the reference wrapper casts with .float()), got {dets.dtype}")
+    if dets.dim() != 2 or dets.shape[1] < 9:
+        raise RuntimeError(f"nms_poly: expected dets (N,9), got {tuple(dets.shape)}")
+    dets = dets.contiguous()
+    L = _lib.lib()
+    n, stride = dets.shape[0], dets.shape[1]
+    dev = dets.device
+    keep = torch.empty(n, dtype=torch.int64, device=dev)
+    cnt = torch.empty(1, dtype=torch.int64, device=dev)
+    with torch.cuda.device(dev):
+        ws = _lib.workspace(L.obb_nms_workspace_bytes(n, 1, 1), dev)
+        rc = L.obb_nms_poly_f32(_lib.ptr(dets), stride, n, float(iou_threshold), 0, _lib.ptr(keep), _lib.ptr(cnt),
+                                _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev))
+    _lib.check(rc, "obb_nms_poly_f32")
+    return keep[: int(cnt.item())]
