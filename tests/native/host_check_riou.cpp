@@ -19,7 +19,7 @@ int main(int argc, char** argv) {
   float px[24], py[24];
   for (long i = 0; i < n; i++) {
     float a[5], b[5];
-    int mode = i % 8;
+    int mode = i % 10;
     float spread = (mode < 4) ? 100.f : 30.f;
     a[0] = U(g) * spread; a[1] = U(g) * spread; a[2] = U(g) * 60 + 4; a[3] = U(g) * 60 + 4; a[4] = (U(g) - 0.5f) * 3.14159265f;
     b[0] = U(g) * spread; b[1] = U(g) * spread; b[2] = U(g) * 60 + 4; b[3] = U(g) * 60 + 4; b[4] = (U(g) - 0.5f) * 3.14159265f;
@@ -28,6 +28,8 @@ int main(int argc, char** argv) {
     if (mode == 3) { b[0] = a[0] + 4096.f * 3; a[0] += 4096.f * 3; }   // class-offset magnitudes, same class
     if (mode == 5) { b[2] = a[2]; b[3] = a[3]; b[4] = a[4] + 1.57079633f; b[0] = a[0]; b[1] = a[1]; }  // crossed
     if (mode == 6) { a[2] = 200; a[3] = 3; b[2] = 150; b[3] = 2; }     // thin
+    if (mode == 8) { a[3] = 1e-9f; a[0] += 300.f; }                     // thin box far away: reference gives garbage IoU ~ 1
+    if (mode == 9) { b[2] = 3e-6f; b[1] += 150.f; a[0] += 4096.f * 7; b[0] += 4096.f * 7; }
     if (mode == 7) { b[0] = a[0] + a[2]; b[1] = a[1]; b[4] = a[4] = 0; b[2] = a[2]; } // edge-touching
     obb::RBoxFeat A = obb::rbox_make_feat(a[0], a[1], a[2], a[3], a[4]);
     obb::RBoxFeat B = obb::rbox_make_feat(b[0], b[1], b[2], b[3], b[4]);

@@ -48,10 +48,29 @@ OBB_HD RBoxFeat rbox_make_feat(float x, float y, float w, float h, float a) {
   return f;
 }
 
-// True only when the reference provably returns IoU == 0 for this pair:
+// Locality guard for the two shortcuts below.  The reference rounds the four
+// corners of each box AFTER shifting both centres to the pair's midpoint, so a
+// corner carries an absolute error of about ulp(M), M = |centre distance|/2 +
+// size.  A box whose short side is not far above that error degenerates: an edge
+// vector rounds to (nearly) zero, the "corner inside rectangle" test (:115-154)
+// turns the box into an unbounded strip, and the reference reports IoU ~ 1 for
+// boxes that are hundreds of pixels apart (reproduced in tests/).  The shortcuts
+// are therefore only taken when both short sides are >= 2e-5 * M (relative edge
+// error <= ~1 %), where the usual geometric reasoning holds; everything else
+// goes through the full clip and inherits the reference's behaviour bit for bit.
+OBB_HD bool rbox_pair_well_conditioned(const RBoxFeat& A, const RBoxFeat& B) {
+  float dx = B.x - A.x, dy = B.y - A.y;
+  float M = fabsf(dx) + fabsf(dy) + A.r + B.r;
+  float ms = fminf(fminf(fabsf(A.w), fabsf(A.h)), fminf(fabsf(B.w), fabsf(B.h)));
+  return ms >= 2e-5f * M;   // false on NaN
+}
+
+// True only when the reference returns IoU == 0 for this (well-conditioned) pair:
 // separation by >= 0.1 % of the involved extents on the centre line or on one
-// of the four edge normals.  NaN anywhere makes every test false (not culled).
+// of the four edge normals -> no edge crossing, no contained corner (num <= 2,
+// :322-324).  NaN anywhere makes every test false (not culled).
 OBB_HD bool rbox_certainly_disjoint(const RBoxFeat& A, const RBoxFeat& B) {
+  if (!rbox_pair_well_conditioned(A, B)) return false;
   float dx = B.x - A.x, dy = B.y - A.y;
   float rs = A.r + B.r;
   if (dx * dx + dy * dy > rs * rs) return true;
@@ -68,12 +87,13 @@ OBB_HD bool rbox_certainly_disjoint(const RBoxFeat& A, const RBoxFeat& B) {
   return false;
 }
 
-// Upper bound on any IoU the reference can return for the pair (area ratio,
-// +0.1 %): IoU = I/(a1+a2-I) with I <= min(a1,a2).  Used to skip the clip when
-// the bound is already <= the NMS threshold.  Returns +inf when not applicable.
+// Upper bound on the IoU the reference returns for a well-conditioned pair (area
+// ratio, +0.1 %): IoU = I/(a1+a2-I) with I <= min(a1,a2).  Used to skip the clip
+// when the bound is already <= the NMS threshold.  +inf when not applicable.
 OBB_HD float rbox_iou_upper_bound(const RBoxFeat& A, const RBoxFeat& B) {
+  if (!rbox_pair_well_conditioned(A, B)) return __builtin_inff();
   float lo = fminf(A.area, B.area), hi = fmaxf(A.area, B.area);
-  if (!(lo > 1e-6f) || !(hi < 1e30f)) return __builtin_inff();
+  if (!(lo > 0.f) || !(hi < 1e30f)) return __builtin_inff();
   return lo / hi * 1.001f;
 }
 
