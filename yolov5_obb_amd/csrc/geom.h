@@ -1,6 +1,10 @@
-// Geometry policies shared by the NMS and pairwise kernels: how a box is laid
-// out in an LDS tile (SoA, [field][64 lanes]), its conservative reject and its
-// exact IoU with the per-lane clip scratch in an LDS column.
+// Geometry policies shared by the NMS and pairwise kernels.
+//
+// A box travels through the NMS as an AoS record of RECQ float4 (16-byte) quads,
+// stored in score order.  Quad 0 is everything the hot pair loop needs
+// (x, y, inflated circumradius, short side): one 16-byte load per box, read as a
+// wave-uniform LDS broadcast on the row side.  The remaining quads are only
+// gathered for the few pairs that survive the cheap test.
 #pragma once
 #include <hip/hip_runtime.h>
 #include "obb_device.h"
@@ -10,43 +14,71 @@
 namespace obb {
 
 struct RotGeom {
-  static constexpr int NF = 12;
-  static constexpr int SCR = 48;  // 24 points x (x,y)
-  using Feat = RBoxFeat;
-  static __device__ __forceinline__ Feat load(const float* t, int i) {
-    Feat f;
-    f.x = t[0 * 64 + i]; f.y = t[1 * 64 + i]; f.w = t[2 * 64 + i]; f.h = t[3 * 64 + i];
-    f.sh = t[4 * 64 + i]; f.cw = t[5 * 64 + i]; f.ch = t[6 * 64 + i]; f.sw = t[7 * 64 + i];
-    f.r = t[8 * 64 + i]; f.c = t[9 * 64 + i]; f.s = t[10 * 64 + i]; f.area = t[11 * 64 + i];
+  static constexpr int RECQ = 4;
+  static constexpr int SCR = 48;  // 24 clip points x (x,y) per lane
+  // q0 = {x, y, r, ms}  q1 = {w, h, c, s}  q2 = {sh, cw, ch, sw}  q3 = {area, 0, 0, 0}
+  static OBB_HD void pack(const RBoxFeat& f, float4* q) {
+    float ms = fminf(fabsf(f.w), fabsf(f.h));
+    q[0] = make_float4(f.x, f.y, f.r, ms);
+    q[1] = make_float4(f.w, f.h, f.c, f.s);
+    q[2] = make_float4(f.sh, f.cw, f.ch, f.sw);
+    q[3] = make_float4(f.area, 0.f, 0.f, 0.f);
+  }
+  static OBB_HD RBoxFeat unpack(const float4& q0, const float4& q1, const float4& q2, const float4& q3) {
+    RBoxFeat f;
+    f.x = q0.x; f.y = q0.y; f.r = q0.z;
+    f.w = q1.x; f.h = q1.y; f.c = q1.z; f.s = q1.w;
+    f.sh = q2.x; f.cw = q2.y; f.ch = q2.z; f.sw = q2.w;
+    f.area = q3.x;
     return f;
   }
-  static __device__ __forceinline__ bool reject(const Feat& A, const Feat& B, float thr) {
-    if (rbox_certainly_disjoint(A, B)) return true;
-    return rbox_iou_upper_bound(A, B) <= thr;
+  // Hot-loop test on quad 0 only: circumscribed circles clearly apart AND the pair is well
+  // conditioned (riou_device.h) -> the reference returns exactly 0.  ~13 VALU ops.
+  static __device__ __forceinline__ bool cheap_reject(const float4& a, const float4& b) {
+    float dx = b.x - a.x, dy = b.y - a.y;
+    float rs = a.z + b.z;
+    float M = fabsf(dx) + fabsf(dy) + rs;
+    bool wc = fminf(a.w, b.w) >= 2e-5f * M;
+    return wc && (dx * dx + dy * dy > rs * rs);
   }
-  static __device__ __forceinline__ float iou(const Feat& A, const Feat& B, float* scr) {
-    return rbox_iou<64>(A, B, scr, scr + 24 * 64);
+  // Survivors: separating-axis reject, area-ratio bound, then the exact clip.  Returns IoU > thr.
+  static __device__ __forceinline__ bool hit(const float4* ra, const float4* rb, float thr, bool cull, float* scr) {
+    RBoxFeat A = unpack(ra[0], ra[1], ra[2], ra[3]);
+    RBoxFeat B = unpack(rb[0], rb[1], rb[2], rb[3]);
+    if (cull) {
+      if (rbox_certainly_disjoint(A, B)) return false;
+      if (rbox_iou_upper_bound(A, B) <= thr) return false;
+    }
+    return rbox_iou<64>(A, B, scr, scr + 24 * 64) > thr;
   }
 };
 
 struct QuadGeom {
-  static constexpr int NF = 8;
-  static constexpr int SCR = 40;  // 2 x 10 points x (x,y)
-  using Feat = QuadFeat;
-  static __device__ __forceinline__ Feat load(const float* t, int i) {
-    Feat f;
-#pragma unroll
-    for (int k = 0; k < 4; k++) { f.x[k] = t[(2 * k) * 64 + i]; f.y[k] = t[(2 * k + 1) * 64 + i]; }
+  static constexpr int RECQ = 2;
+  static constexpr int SCR = 40;  // 2 x 10 points x (x,y) per lane
+  // q0 = {x0, y0, x1, y1}  q1 = {x2, y2, x3, y3}
+  // The reference's quad IoU sums signed triangle areas taken from the coordinate origin; for
+  // disjoint quads the terms cancel only up to rounding (measured up to 0.06 at |coord| ~ 5000),
+  // so "IoU == 0" cannot be predicted from a bounding-box test.  No reject: every pair is clipped.
+  static __device__ __forceinline__ bool cheap_reject(const float4&, const float4&) { return false; }
+  static OBB_HD QuadFeat unpack(const float4& q0, const float4& q1) {
+    QuadFeat f;
+    f.x[0] = q0.x; f.y[0] = q0.y; f.x[1] = q0.z; f.y[1] = q0.w;
+    f.x[2] = q1.x; f.y[2] = q1.y; f.x[3] = q1.z; f.y[3] = q1.w;
     f.minx = f.maxx = f.miny = f.maxy = 0.f;
     return f;
   }
-  // The reference's quad IoU sums signed triangle areas taken from the coordinate
-  // origin; for disjoint quads the terms cancel only up to rounding, so "IoU == 0"
-  // cannot be predicted cheaply (measured up to 0.06 at |coord| ~ 5000).  No reject.
-  static __device__ __forceinline__ bool reject(const Feat&, const Feat&, float) { return false; }
-  static __device__ __forceinline__ float iou(const Feat& A, const Feat& B, float* scr) {
+  static __device__ __forceinline__ float iou(const QuadFeat& A, const QuadFeat& B, float* scr) {
     return quad_iou<64>(A, B, scr, scr + 10 * 64, scr + 20 * 64, scr + 30 * 64);
   }
+  static __device__ __forceinline__ bool hit(const float4* ra, const float4* rb, float thr, bool, float* scr) {
+    return iou(unpack(ra[0], ra[1]), unpack(rb[0], rb[1]), scr) > thr;
+  }
 };
+
+// exact rotated IoU value with the per-lane scratch column (pairwise kernels)
+__device__ __forceinline__ float rot_iou_value(const RBoxFeat& A, const RBoxFeat& B, float* scr) {
+  return rbox_iou<64>(A, B, scr, scr + 24 * 64);
+}
 
 }  // namespace obb

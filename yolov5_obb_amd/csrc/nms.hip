@@ -53,52 +53,59 @@ __global__ void k_make_keys(const float* __restrict__ scores, int score_stride, 
   vals[i] = (uint32_t)i;
 }
 
-__global__ void k_seg_bounds(const uint64_t* __restrict__ keys, int n, int nseg, int shift, int* __restrict__ seg_begin,
-                             int* keep_cnt, int* nrows, int* nedges) {
-  int g = blockIdx.x * blockDim.x + threadIdx.x;
-  if (g > nseg) return;
-  if (g == nseg) { seg_begin[g] = n; return; }
-  // lower_bound of (g << shift)
-  uint64_t target = (uint64_t)g << shift;
+__device__ __forceinline__ int key_lower_bound(const uint64_t* keys, int n, uint64_t target) {
   int lo = 0, hi = n;
   while (lo < hi) {
     int mid = (lo + hi) >> 1;
     if (keys[mid] < target) lo = mid + 1; else hi = mid;
   }
-  seg_begin[g] = lo;
-  keep_cnt[g] = 0; nrows[g] = 0; nedges[g] = 0;
+  return lo;
+}
+
+// segment g = sorted positions [seg_begin[g], seg_begin[g+1]); only the first `topk` of them take part
+// (utils/general.py:845-846: x = x[x[:, 5].argsort(descending=True)[:max_nms]])
+__global__ void k_seg_bounds(const uint64_t* __restrict__ keys, int n, int nseg, int shift, long long topk,
+                             int* __restrict__ seg_begin, int* __restrict__ seg_end, int* cursor, int* keep_cnt, int* ccount,
+                             int* nrows, int* nedges) {
+  int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= nseg) return;
+  int lo = key_lower_bound(keys, n, (uint64_t)g << shift);
+  int hi = (g + 1 == nseg) ? n : key_lower_bound(keys, n, (uint64_t)(g + 1) << shift);
+  if (topk > 0 && hi - lo > topk) hi = lo + (int)topk;
+  seg_begin[g] = lo; seg_end[g] = hi; cursor[g] = lo;
+  keep_cnt[g] = 0; ccount[g] = 0; nrows[g] = 0; nedges[g] = 0;
 }
 
 __global__ void k_prep_rot(const float* __restrict__ dets5, const uint32_t* __restrict__ order, int drop_small, int n,
-                           float* __restrict__ feat, uint8_t* __restrict__ dead) {
+                           float4* __restrict__ rec, uint8_t* __restrict__ dead) {
   int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= n) return;
   const float* d = dets5 + (size_t)order[p] * 5;
   float x = d[0], y = d[1], w = d[2], h = d[3], a = d[4];
   RBoxFeat f = rbox_make_feat(x, y, w, h, a);
-  feat[(size_t)0 * n + p] = f.x;  feat[(size_t)1 * n + p] = f.y;  feat[(size_t)2 * n + p] = f.w;   feat[(size_t)3 * n + p] = f.h;
-  feat[(size_t)4 * n + p] = f.sh; feat[(size_t)5 * n + p] = f.cw; feat[(size_t)6 * n + p] = f.ch;  feat[(size_t)7 * n + p] = f.sw;
-  feat[(size_t)8 * n + p] = f.r;  feat[(size_t)9 * n + p] = f.c;  feat[(size_t)10 * n + p] = f.s;  feat[(size_t)11 * n + p] = f.area;
+  float4 q[4];
+  RotGeom::pack(f, q);
+#pragma unroll
+  for (int k = 0; k < 4; k++) rec[(size_t)p * 4 + k] = q[k];
   float mn = (h < w) ? h : w;
   dead[p] = (drop_small && mn < 0.001f) ? 1 : 0;
 }
 
 __global__ void k_prep_quad(const float* __restrict__ polys, int stride, const uint32_t* __restrict__ order, int n,
-                            float* __restrict__ feat, uint8_t* __restrict__ dead) {
+                            float4* __restrict__ rec, uint8_t* __restrict__ dead) {
   int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= n) return;
   const float* d = polys + (size_t)order[p] * stride;
-#pragma unroll
-  for (int k = 0; k < 8; k++) feat[(size_t)k * n + p] = d[k];
+  rec[(size_t)p * 2 + 0] = make_float4(d[0], d[1], d[2], d[3]);
+  rec[(size_t)p * 2 + 1] = make_float4(d[4], d[5], d[6], d[7]);
   dead[p] = 0;
 }
 
 __global__ void k_finalize(const int* __restrict__ keep_cnt, const int* __restrict__ seg_begin, int nseg, long long max_keep,
                            int64_t* __restrict__ num_keep, int64_t* __restrict__ seg_begin_out) {
   int g = blockIdx.x * blockDim.x + threadIdx.x;
-  if (g > nseg) return;
+  if (g >= nseg) return;
   if (seg_begin_out) seg_begin_out[g] = seg_begin[g];
-  if (g == nseg) return;
   long long c = keep_cnt[g];
   if (max_keep > 0 && c > max_keep) c = max_keep;
   num_keep[g] = c;
@@ -107,26 +114,31 @@ __global__ void k_finalize(const int* __restrict__ keep_cnt, const int* __restri
 // ---------------------------------------------------------------- workspace
 static inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
 
-static int chunk_size() {
-  static int c = 0;
-  if (!c) {
-    const char* e = getenv("OBB_NMS_CHUNK");
-    int v = e ? atoi(e) : 2048;
-    if (v < 64) v = 64;
-    if (v > 4096) v = 4096;
-    v = (v + 63) / 64 * 64;
-    c = v;
-  }
-  return c;
+// Chunk capacities: the first chunk has OBB_NMS_CHUNK boxes (default 2048), later chunks double up to
+// OBB_NMS_CHUNK_MAX (default 8192 for a single list, 2048 per segment for batches: the edge list is sized for
+// the worst case cap*(cap-1)/2 per segment).
+static int env_int(const char* name, int dflt, int lo, int hi) {
+  const char* e = getenv(name);
+  int v = e ? atoi(e) : dflt;
+  if (v < lo) v = lo;
+  if (v > hi) v = hi;
+  return (v + 63) / 64 * 64;
+}
+static int cap_first() { static int c = 0; if (!c) c = env_int("OBB_NMS_CHUNK", 2048, 64, 8192); return c; }
+static int cap_max(int64_t nseg) {
+  static int c1 = 0, cb = 0;
+  if (!c1) { c1 = env_int("OBB_NMS_CHUNK_MAX", 8192, 64, 16384); cb = env_int("OBB_NMS_CHUNK_MAX_BATCHED", 2048, 64, 16384); }
+  int c = nseg > 1 ? cb : c1;
+  return c < cap_first() ? cap_first() : c;
 }
 
 struct Carve {
   uint64_t *keys_a, *keys_b;
   uint32_t *vals_a, *vals_b;
   void* sort_tmp; size_t sort_tmp_bytes;
-  float* feat; uint8_t* dead;
-  int *seg_begin, *keep_cnt, *nrows, *nedges;
-  uint32_t *rows, *edges;
+  float4* rec; uint8_t* dead;
+  int *seg_begin, *seg_end, *cursor, *keep_cnt, *ccount, *nrows, *nedges;
+  uint32_t *cidx, *rows, *edges;
   long long ecap;
   size_t total;
 };
@@ -137,7 +149,7 @@ static hipError_t sort_tmp_query(size_t n, size_t* bytes) {
                                    (uint32_t*)nullptr, n, 0, 64, (hipStream_t)0, false);
 }
 
-static int carve(void* base, int64_t n, int64_t nseg, int nf, int C, Carve* cv) {
+static int carve(void* base, int64_t n, int64_t nseg, int recq, int C, Carve* cv) {
   size_t off = 0;
   auto take = [&](size_t bytes) { size_t o = off; off += align_up(bytes); return base ? (char*)base + o : (char*)nullptr; };
   size_t nn = (size_t)(n > 0 ? n : 1), ns = (size_t)(nseg > 0 ? nseg : 1);
@@ -145,15 +157,44 @@ static int carve(void* base, int64_t n, int64_t nseg, int nf, int C, Carve* cv) 
   cv->vals_a = (uint32_t*)take(nn * 4); cv->vals_b = (uint32_t*)take(nn * 4);
   if (sort_tmp_query(nn, &cv->sort_tmp_bytes) != hipSuccess) return OBB_ERR_INTERNAL;
   cv->sort_tmp = take(cv->sort_tmp_bytes ? cv->sort_tmp_bytes : 16);
-  cv->feat = (float*)take(nn * nf * 4);
-  cv->dead = (uint8_t*)take(nn);
-  cv->seg_begin = (int*)take((ns + 1) * 4); cv->keep_cnt = (int*)take(ns * 4);
+  cv->rec = (float4*)take(nn * recq * 16);
+  cv->dead = (uint8_t*)take(nn + 64);
+  cv->seg_begin = (int*)take(ns * 4); cv->seg_end = (int*)take(ns * 4); cv->cursor = (int*)take(ns * 4);
+  cv->keep_cnt = (int*)take(ns * 4); cv->ccount = (int*)take(ns * 4);
   cv->nrows = (int*)take(ns * 4); cv->nedges = (int*)take(ns * 4);
+  cv->cidx = (uint32_t*)take(ns * (size_t)C * 4);
   cv->rows = (uint32_t*)take(ns * (size_t)C * 4);
   cv->ecap = (long long)C * (C - 1) / 2; if (cv->ecap < 1) cv->ecap = 1;
   cv->edges = (uint32_t*)take(ns * (size_t)cv->ecap * 4);
   cv->total = off;
   return OBB_OK;
+}
+
+// The step loop shared by every entry point.  max_seg: host-side upper bound on the number of boxes of any
+// segment that take part (bounds the number of steps and the grid sizes; kernels read the true sizes on device).
+static void nms_steps(int kind, NmsArgs& a, int64_t nseg, int64_t max_seg, hipStream_t st) {
+  int cap = cap_first();
+  if (cap > a.capmax) cap = a.capmax;
+  int64_t covered = 0;
+  while (covered < max_seg) {
+    k_select_chunk<<<(unsigned)nseg, 1024, 0, st>>>(a, cap);
+    const int64_t cn = (max_seg - covered) < cap ? (max_seg - covered) : cap;   // bound on this step's chunk size
+    const int64_t nb = (cn + 63) / 64;
+    int64_t g1 = nb * nb; if (g1 > 4096) g1 = 4096; if (g1 < 1) g1 = 1;
+    dim3 ga((unsigned)g1, (unsigned)nseg);
+    if (kind == 0) k_chunk_pairs<RotGeom><<<ga, 64, 0, st>>>(a);
+    else k_chunk_pairs<QuadGeom><<<ga, 64, 0, st>>>(a);
+    k_chunk_resolve<<<(unsigned)nseg, 1024, (size_t)2 * a.capmax, st>>>(a);
+    covered += cap;
+    const int64_t rest = max_seg - covered;
+    if (rest > 0) {
+      int64_t g2 = ((rest + 63) / 64) * nb; if (g2 > 4096) g2 = 4096; if (g2 < 1) g2 = 1;
+      dim3 gc((unsigned)g2, (unsigned)nseg);
+      if (kind == 0) k_cross<RotGeom><<<gc, 64, 0, st>>>(a);
+      else k_cross<QuadGeom><<<gc, 64, 0, st>>>(a);
+    }
+    if (cap < a.capmax) { cap *= 2; if (cap > a.capmax) cap = a.capmax; }
+  }
 }
 
 // kind: 0 rotated (5 floats + score array), 1 quad (rows of `stride` floats, score in column 8)
@@ -163,10 +204,10 @@ static int run_nms(int kind, const float* boxes, int stride, const float* scores
                    hipStream_t st) {
   if (n < 0 || nseg < 1 || n > 0x7fffffffLL) return OBB_ERR_BAD_ARG;
   if (!num_keep || (n > 0 && (!boxes || !scores || !keep_out))) return OBB_ERR_BAD_ARG;
-  const int C = chunk_size();
-  const int nf = kind == 0 ? RotGeom::NF : QuadGeom::NF;
+  const int C = cap_max(nseg);
+  const int recq = kind == 0 ? RotGeom::RECQ : QuadGeom::RECQ;
   Carve cv;
-  int rc = carve(ws, n, nseg, nf, C, &cv);
+  int rc = carve(ws, n, nseg, recq, C, &cv);
   if (rc) return rc;
   if (!ws || ws_bytes < cv.total) return OBB_ERR_WORKSPACE;
   int seg_bits = 0;
@@ -174,11 +215,12 @@ static int run_nms(int kind, const float* boxes, int stride, const float* scores
   if (32 + tie_bits + seg_bits > 64) return OBB_ERR_BAD_ARG;
   const int T = 256;
   const int drop_small = (flags & OBB_NMS_DROP_SMALL) ? 1 : 0;
+  const unsigned gseg = (unsigned)((nseg + T - 1) / T);
 
   if (n == 0) {
     hipMemsetAsync(cv.keep_cnt, 0, nseg * 4, st);
-    hipMemsetAsync(cv.seg_begin, 0, (nseg + 1) * 4, st);
-    k_finalize<<<(unsigned)((nseg + 1 + T - 1) / T), T, 0, st>>>(cv.keep_cnt, cv.seg_begin, (int)nseg, max_keep, num_keep, seg_begin_out);
+    hipMemsetAsync(cv.seg_begin, 0, nseg * 4, st);
+    k_finalize<<<gseg, T, 0, st>>>(cv.keep_cnt, cv.seg_begin, (int)nseg, max_keep, num_keep, seg_begin_out);
     return hipGetLastError() == hipSuccess ? OBB_OK : OBB_ERR_LAUNCH;
   }
 
@@ -189,35 +231,23 @@ static int run_nms(int kind, const float* boxes, int stride, const float* scores
   if (rocprim::radix_sort_pairs(cv.sort_tmp, tmp, cv.keys_a, cv.keys_b, cv.vals_a, cv.vals_b, (size_t)n, 0,
                                 (unsigned)(32 + tie_bits + seg_bits), st, false) != hipSuccess)
     return OBB_ERR_LAUNCH;
-  k_seg_bounds<<<(unsigned)((nseg + 1 + T - 1) / T), T, 0, st>>>(cv.keys_b, (int)n, (int)nseg, 32 + tie_bits, cv.seg_begin,
-                                                                cv.keep_cnt, cv.nrows, cv.nedges);
-  if (kind == 0) k_prep_rot<<<gb, T, 0, st>>>(boxes, cv.vals_b, drop_small, (int)n, cv.feat, cv.dead);
-  else k_prep_quad<<<gb, T, 0, st>>>(boxes, stride, cv.vals_b, (int)n, cv.feat, cv.dead);
+  k_seg_bounds<<<gseg, T, 0, st>>>(cv.keys_b, (int)n, (int)nseg, 32 + tie_bits, 0, cv.seg_begin, cv.seg_end, cv.cursor,
+                                   cv.keep_cnt, cv.ccount, cv.nrows, cv.nedges);
+  if (kind == 0) k_prep_rot<<<gb, T, 0, st>>>(boxes, cv.vals_b, drop_small, (int)n, cv.rec, cv.dead);
+  else k_prep_quad<<<gb, T, 0, st>>>(boxes, stride, cv.vals_b, (int)n, cv.rec, cv.dead);
 
   NmsArgs a;
-  a.feat = cv.feat; a.order = cv.vals_b; a.dead = cv.dead; a.seg_begin = cv.seg_begin; a.keep_cnt = cv.keep_cnt;
-  a.keep_out = keep_out; a.rows = cv.rows; a.nrows = cv.nrows; a.edges = cv.edges; a.nedges = cv.nedges;
-  a.ecap = cv.ecap; a.n = (int)n; a.C = C;
+  a.rec = cv.rec; a.order = cv.vals_b; a.dead = cv.dead; a.seg_begin = cv.seg_begin; a.seg_end = cv.seg_end;
+  a.cursor = cv.cursor; a.keep_cnt = cv.keep_cnt; a.keep_out = keep_out; a.cidx = cv.cidx; a.ccount = cv.ccount;
+  a.rows = cv.rows; a.nrows = cv.nrows; a.edges = cv.edges; a.nedges = cv.nedges;
+  a.ecap = cv.ecap; a.n = (int)n; a.capmax = C;
   a.max_keep = (int)(max_keep > 0x7fffffffLL ? 0x7fffffffLL : (max_keep < 0 ? 0 : max_keep));
   a.thr = thr;
   a.cull = (thr >= 0.f) ? 1 : 0;      // rejects predict IoU <= 0 or IoU <= thr; with thr < 0 even IoU == 0 suppresses
 
   if (max_seg <= 0 || max_seg > n) max_seg = n;
-  const int nbmax = C / 64;
-  const int64_t nsteps = (max_seg + C - 1) / C;
-  for (int64_t s = 0; s < nsteps; s++) {
-    dim3 ga((unsigned)(nbmax * nbmax), (unsigned)nseg);
-    if (kind == 0) k_chunk_pairs<RotGeom><<<ga, 64, 0, st>>>(a, (int)s);
-    else k_chunk_pairs<QuadGeom><<<ga, 64, 0, st>>>(a, (int)s);
-    k_chunk_resolve<<<(unsigned)nseg, 1024, (size_t)2 * C, st>>>(a, (int)s);
-    int64_t rest = max_seg - (s + 1) * C;
-    if (rest > 0) {
-      dim3 gc((unsigned)((rest + 63) / 64), (unsigned)nseg);
-      if (kind == 0) k_cross<RotGeom><<<gc, 64, 0, st>>>(a, (int)s);
-      else k_cross<QuadGeom><<<gc, 64, 0, st>>>(a, (int)s);
-    }
-  }
-  k_finalize<<<(unsigned)((nseg + 1 + T - 1) / T), T, 0, st>>>(cv.keep_cnt, cv.seg_begin, (int)nseg, max_keep, num_keep, seg_begin_out);
+  nms_steps(kind, a, nseg, max_seg, st);
+  k_finalize<<<gseg, T, 0, st>>>(cv.keep_cnt, cv.seg_begin, (int)nseg, max_keep, num_keep, seg_begin_out);
   return hipGetLastError() == hipSuccess ? OBB_OK : OBB_ERR_LAUNCH;
 }
 
@@ -230,7 +260,7 @@ extern "C" {
 size_t obb_nms_workspace_bytes(int64_t n, int64_t nseg, int kind) {
   Carve cv;
   if (n < 0 || nseg < 1) return 0;
-  if (carve(nullptr, n, nseg, kind == 0 ? RotGeom::NF : QuadGeom::NF, chunk_size(), &cv)) return 0;
+  if (carve(nullptr, n, nseg, kind == 0 ? RotGeom::RECQ : QuadGeom::RECQ, cap_max(nseg), &cv)) return 0;
   return cv.total;
 }
 

@@ -13,12 +13,6 @@
 
 namespace obb {
 
-__device__ __forceinline__ void store_rot_feat(float* t, int i, const RBoxFeat& f) {
-  t[0 * 64 + i] = f.x; t[1 * 64 + i] = f.y; t[2 * 64 + i] = f.w; t[3 * 64 + i] = f.h;
-  t[4 * 64 + i] = f.sh; t[5 * 64 + i] = f.cw; t[6 * 64 + i] = f.ch; t[7 * 64 + i] = f.sw;
-  t[8 * 64 + i] = f.r; t[9 * 64 + i] = f.c; t[10 * 64 + i] = f.s; t[11 * 64 + i] = f.area;
-}
-
 __global__ __launch_bounds__(64) void k_riou_pairs(const float* __restrict__ a5, const float* __restrict__ b5, long long n,
                                                    float* __restrict__ out) {
   __shared__ float scr[RotGeom::SCR * 64];
@@ -27,12 +21,12 @@ __global__ __launch_bounds__(64) void k_riou_pairs(const float* __restrict__ a5,
   const float* a = a5 + i * 5; const float* b = b5 + i * 5;
   RBoxFeat A = rbox_make_feat(a[0], a[1], a[2], a[3], a[4]);
   RBoxFeat B = rbox_make_feat(b[0], b[1], b[2], b[3], b[4]);
-  out[i] = RotGeom::iou(A, B, scr + threadIdx.x);
+  out[i] = rot_iou_value(A, B, scr + threadIdx.x);
 }
 
 __global__ __launch_bounds__(64) void k_riou_matrix(const float* __restrict__ a5, long long n, const float* __restrict__ b5,
                                                     long long k, float* __restrict__ out) {
-  __shared__ float rowf[RotGeom::NF * 64];
+  __shared__ float4 rowrec[64 * 4];
   __shared__ float scr[RotGeom::SCR * 64];
   const int lane = threadIdx.x;
   const long long i0 = (long long)blockIdx.y * 64, j = (long long)blockIdx.x * 64 + lane;
@@ -40,17 +34,17 @@ __global__ __launch_bounds__(64) void k_riou_matrix(const float* __restrict__ a5
     long long i = i0 + lane;
     RBoxFeat f = {};
     if (i < n) { const float* a = a5 + i * 5; f = rbox_make_feat(a[0], a[1], a[2], a[3], a[4]); }
-    store_rot_feat(rowf, lane, f);
+    RotGeom::pack(f, rowrec + lane * 4);
   }
   RBoxFeat B = {};
   if (j < k) { const float* b = b5 + j * 5; B = rbox_make_feat(b[0], b[1], b[2], b[3], b[4]); }
   __syncthreads();
   const int nr = (int)((n - i0) < 64 ? (n - i0) : 64);
   for (int r = 0; r < nr; r++) {
-    RBoxFeat A = RotGeom::load(rowf, r);
+    RBoxFeat A = RotGeom::unpack(rowrec[r * 4], rowrec[r * 4 + 1], rowrec[r * 4 + 2], rowrec[r * 4 + 3]);
     if (j < k) {
-      // the reject only fires where the reference provably returns exactly 0
-      float v = rbox_certainly_disjoint(A, B) ? 0.f : RotGeom::iou(A, B, scr + lane);
+      // the reject only fires where the reference returns exactly 0 (riou_device.h)
+      float v = rbox_certainly_disjoint(A, B) ? 0.f : rot_iou_value(A, B, scr + lane);
       out[(i0 + r) * k + j] = v;
     }
   }
@@ -59,14 +53,17 @@ __global__ __launch_bounds__(64) void k_riou_matrix(const float* __restrict__ a5
 __global__ __launch_bounds__(64) void k_quad_matrix(const float* __restrict__ a, long long sa, long long n,
                                                     const float* __restrict__ b, long long sb, long long k,
                                                     float* __restrict__ out) {
-  __shared__ float rowf[QuadGeom::NF * 64];
+  __shared__ float4 rowrec[64 * 2];
   __shared__ float scr[QuadGeom::SCR * 64];
   const int lane = threadIdx.x;
   const long long i0 = (long long)blockIdx.y * 64, j = (long long)blockIdx.x * 64 + lane;
   {
     long long i = i0 + lane;
+    float v[8];
 #pragma unroll
-    for (int c = 0; c < 8; c++) rowf[c * 64 + lane] = (i < n) ? a[i * sa + c] : 0.f;
+    for (int c = 0; c < 8; c++) v[c] = (i < n) ? a[i * sa + c] : 0.f;
+    rowrec[lane * 2] = make_float4(v[0], v[1], v[2], v[3]);
+    rowrec[lane * 2 + 1] = make_float4(v[4], v[5], v[6], v[7]);
   }
   QuadFeat B = {};
   if (j < k) {
@@ -76,7 +73,7 @@ __global__ __launch_bounds__(64) void k_quad_matrix(const float* __restrict__ a,
   __syncthreads();
   const int nr = (int)((n - i0) < 64 ? (n - i0) : 64);
   for (int r = 0; r < nr; r++) {
-    QuadFeat A = QuadGeom::load(rowf, r);
+    QuadFeat A = QuadGeom::unpack(rowrec[r * 2], rowrec[r * 2 + 1]);
     if (j < k) out[(i0 + r) * k + j] = QuadGeom::iou(A, B, scr + lane);
   }
 }
@@ -98,7 +95,7 @@ __device__ __forceinline__ void rbox_to_quad_devkit(const float* d, float* qx, f
 
 __global__ __launch_bounds__(64) void k_rbox_overlaps(const float* __restrict__ boxes, long long n,
                                                       const float* __restrict__ query, long long k, float* __restrict__ out) {
-  __shared__ float rowf[QuadGeom::NF * 64];
+  __shared__ float4 rowrec[64 * 2];
   __shared__ float scr[QuadGeom::SCR * 64];
   const int lane = threadIdx.x;
   const long long i0 = (long long)blockIdx.y * 64, j = (long long)blockIdx.x * 64 + lane;
@@ -106,15 +103,15 @@ __global__ __launch_bounds__(64) void k_rbox_overlaps(const float* __restrict__ 
     long long i = i0 + lane;
     float qx[4] = {0, 0, 0, 0}, qy[4] = {0, 0, 0, 0};
     if (i < n) rbox_to_quad_devkit(boxes + i * 5, qx, qy);
-#pragma unroll
-    for (int c = 0; c < 4; c++) { rowf[(2 * c) * 64 + lane] = qx[c]; rowf[(2 * c + 1) * 64 + lane] = qy[c]; }
+    rowrec[lane * 2] = make_float4(qx[0], qy[0], qx[1], qy[1]);
+    rowrec[lane * 2 + 1] = make_float4(qx[2], qy[2], qx[3], qy[3]);
   }
   QuadFeat B = {};
   if (j < k) rbox_to_quad_devkit(query + j * 5, B.x, B.y);
   __syncthreads();
   const int nr = (int)((n - i0) < 64 ? (n - i0) : 64);
   for (int r = 0; r < nr; r++) {
-    QuadFeat A = QuadGeom::load(rowf, r);
+    QuadFeat A = QuadGeom::unpack(rowrec[r * 2], rowrec[r * 2 + 1]);
     if (j < k) out[(i0 + r) * k + j] = QuadGeom::iou(A, B, scr + lane);
   }
 }
