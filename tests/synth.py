@@ -60,3 +60,102 @@ def rbox_to_quad(dets):
     for sx, sy in ((1, 1), (1, -1), (-1, -1), (-1, 1)):
         pts += [d[:, 0] + sx * w * c - sy * h * s, d[:, 1] + sx * w * s + sy * h * c]
     return torch.stack(pts, 1).float()
+
+
+def s_pred(bs, A, nc, seed=0, n_obj=40, fg_frac=0.03, extent=1024.0, device="cpu", dtype=torch.float32):
+    """S-pred: a synthetic, already decoded Detect output (bs, A, 5+nc+180), post-sigmoid like models/yolo.py:71-79.
+
+    A fraction `fg_frac` of the anchors sits on one of `n_obj` planted objects per image (jittered copy of the
+    object's box, high objectness, the object's class and a CSL bump at its angle bin); the rest is background
+    (random box, objectness logit ~ N(-6, 1.5), cf. the bias init of models/yolo.py:230)."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    R = lambda *s: torch.rand(*s, generator=g, device=device)
+    N = lambda *s: torch.randn(*s, generator=g, device=device)
+    no = 5 + nc + 180
+    ocx = R(bs, n_obj, 2) * extent
+    owh = torch.stack((R(bs, n_obj) * 150 + 12, R(bs, n_obj) * 40 + 6), -1)      # long edge, short edge
+    obin = torch.randint(0, 180, (bs, n_obj), generator=g, device=device)
+    ocls = torch.randint(0, nc, (bs, n_obj), generator=g, device=device)
+    fg = R(bs, A) < fg_frac
+    k = torch.randint(0, n_obj, (bs, A), generator=g, device=device)
+    bi = torch.arange(bs, device=device)[:, None].expand(bs, A)
+    out = torch.empty(bs, A, no, device=device, dtype=torch.float32)
+    # boxes
+    bg_xy = R(bs, A, 2) * extent
+    bg_wh = torch.stack((R(bs, A) * 120 + 4, R(bs, A) * 40 + 2), -1)
+    fg_xy = ocx[bi, k] + N(bs, A, 2) * 3
+    fg_wh = owh[bi, k] * (1 + 0.1 * N(bs, A, 2)).clamp(0.5, 1.5)
+    out[..., 0:2] = torch.where(fg[..., None], fg_xy, bg_xy)
+    out[..., 2:4] = torch.where(fg[..., None], fg_wh, bg_wh)
+    # objectness
+    out[..., 4] = torch.sigmoid(torch.where(fg, N(bs, A) * 1.5 + 1.0, N(bs, A) * 1.5 - 6.0))
+    # classes
+    cl = N(bs, A, nc) - 4.0
+    hot = torch.nn.functional.one_hot(ocls[bi, k], nc).bool() & fg[..., None]
+    cl = torch.where(hot, N(bs, A, nc) + 2.0, cl)
+    out[..., 5:5 + nc] = torch.sigmoid(cl)
+    # CSL
+    bins = torch.arange(180, device=device)
+    d = (bins[None, None, :] - obin[bi, k][..., None]).abs()
+    d = torch.minimum(d, 180 - d).float()
+    bump = 5.0 * torch.exp(-d * d / 8.0) - 4.0
+    csl = torch.where(fg[..., None], bump, torch.full_like(bump, -4.0)) + 0.5 * N(bs, A, 180)
+    out[..., 5 + nc:] = torch.sigmoid(csl)
+    return out.to(dtype)
+
+
+DEFAULT_ANCHORS = [[10, 13, 16, 30, 33, 23], [30, 61, 62, 45, 59, 119], [116, 90, 156, 198, 373, 326]]  # models/yolov5s.yaml:8-10
+DEFAULT_STRIDES = [8.0, 16.0, 32.0]
+
+
+def grid_anchors():
+    """(nl, na, 2) anchors in grid units, as Detect stores them after Model.__init__ (models/yolo.py:119-124)."""
+    a = torch.tensor(DEFAULT_ANCHORS).float().view(3, 3, 2)
+    return a / torch.tensor(DEFAULT_STRIDES).view(3, 1, 1)
+
+
+HYP_DOTA = dict(box=0.05, cls=0.5, cls_pw=1.0, theta=0.5, theta_pw=1.0, obj=1.0, obj_pw=1.0, anchor_t=4.0, fl_gamma=0.0,
+                label_smoothing=0.0, cls_theta=180, csl_radius=2.0)       # data/hyps/obb/hyp.finetune_dota.yaml
+
+
+def scaled_hyp(nc, imgsz=1024, nl=3):
+    """train.py:249-252 scaling of the loss gains."""
+    h = dict(HYP_DOTA)
+    h['box'] *= 3 / nl
+    h['cls'] *= nc / 80 * 3 / nl
+    h['obj'] *= (imgsz / 640) ** 2 * 3 / nl
+    h['theta'] *= 3 / nl
+    return h
+
+
+def s_loss(bs, nc, nt, seed=0, imgsz=1024, sizes=None):
+    """S-loss: raw head outputs p[i] ~ N(0,1) at (bs,3,ny,nx,5+nc+180) and nt targets
+    [img, cls, cx, cy, l, s, theta, csl x 180] in pixels (utils/datasets.py:637-659 layout)."""
+    from oracle import pyref
+    g = torch.Generator().manual_seed(seed)
+    no = 5 + nc + 180
+    sizes = sizes or [int(imgsz / s) for s in DEFAULT_STRIDES]
+    p = [torch.randn(bs, 3, n, n, no, generator=g) for n in sizes]
+    t = torch.zeros(nt, 7 + 180)
+    if nt:
+        t[:, 0] = torch.randint(0, bs, (nt,), generator=g).float()
+        t[:, 1] = torch.randint(0, nc, (nt,), generator=g).float()
+        t[:, 2:4] = torch.rand(nt, 2, generator=g) * imgsz
+        t[:, 4] = torch.rand(nt, generator=g) * 100 + 20
+        t[:, 5] = torch.rand(nt, generator=g) * 20 + 8
+        th = (torch.rand(nt, generator=g) - 0.5) * pyref.PI
+        t[:, 6] = th
+        ang = th.double().numpy() * 180 / pyref.PI + 90
+        csl = np.stack([pyref.gaussian_label(a, 180, 0, 2.0) for a in ang]) if nt else np.zeros((0, 180))
+        t[:, 7:] = torch.from_numpy(csl).float()
+    return p, t
+
+
+def canon_rows(rows):
+    """Rows of an (n,7) NMS output ordered by (conf desc, then the remaining columns): removes the dependence on how
+    the sort broke score ties (torch's unstable sort in the reference vs this project's ascending-index rule)."""
+    r = rows.detach().cpu().double().numpy() if isinstance(rows, torch.Tensor) else np.asarray(rows, dtype=np.float64)
+    if len(r) == 0:
+        return r
+    key = np.lexsort((r[:, 6], r[:, 4], r[:, 3], r[:, 2], r[:, 1], r[:, 0], -r[:, 5]))
+    return r[key]
