@@ -85,6 +85,33 @@ int obb_nms_rotated_batched_f32(const float* dets5, const float* scores, const i
 int obb_nms_poly_f32(const float* polys, int64_t row_stride, int64_t n, float iou_thr, int64_t max_keep, int64_t* keep_out,
                      int64_t* num_keep, void* ws, size_t ws_bytes, void* stream);
 
+/* ------------------------------------------------------------------ fused NMS driver ----------------- */
+
+/*
+ * The whole of non_max_suppression_obb (utils/general.py:772-862) for a batch, in one stream-ordered call:
+ * confidence filter, obj*cls, CSL decode (arg-max over the 180 angle bins -> theta = (idx-90)/180*3.141592),
+ * multi-label expansion or best class, class filter, per-image top max_nms by confidence, class offset
+ * (xy += cls*max_wh unless agnostic), obb_nms (incl. its min(w,h) < 0.001 filter), max_det truncation.
+ *   pred        [bs][A][no] contiguous, no = 5 + nc + 180, rows [cx cy l s obj cls[nc] csl[180]] as produced by
+ *               Detect's inference branch (models/yolo.py:67-81); dtype 0 = fp32, 1 = fp16 (val.py --half).
+ *               The arithmetic follows the input dtype exactly like the reference (conf = obj*cls is rounded to
+ *               fp16 for fp16 input, thresholds are compared in that dtype).
+ *   classes_host  optional HOST array of allowed class ids (n_classes entries; NULL = all)     (:834-835)
+ *   extra8      optional device rows [img, x, y, l, s, theta, conf, cls] appended as candidates: the apriori
+ *               `labels` of autolabelling (:807-813), prepared by the host layer; n_extra rows
+ *   cap_img     candidate slots reserved per image.  If an image produces more, *status receives that count
+ *               (> cap_img) and the caller must retry with a larger cap_img (A*nc can never overflow).
+ *   out         [bs][max_det][7] fp32 rows [x y l s theta conf cls];  out_count [bs] int64;  status [1] int64
+ * Score ties are ordered by ascending (anchor*nc + class): deterministic, where the reference inherits the order
+ * of torch's unstable sort.
+ */
+size_t obb_nms_obb_workspace_bytes(int64_t bs, int64_t cap_img);
+int obb_non_max_suppression_obb(const void* pred, int dtype, int64_t bs, int64_t A, int64_t no, float conf_thres,
+                                float iou_thres, const int32_t* classes_host, int n_classes, int agnostic, int multi_label,
+                                int64_t max_det, int64_t max_nms, float max_wh, const float* extra8, int64_t n_extra,
+                                int64_t cap_img, float* out, int64_t* out_count, int64_t* status, void* ws, size_t ws_bytes,
+                                void* stream);
+
 /* ------------------------------------------------------------------ pairwise IoU --------------------- */
 
 /* out[i] = IoU(a5[i], b5[i]); the device function behind the NMS

@@ -1,0 +1,73 @@
+"""GPU parity: the fused non_max_suppression_obb (one C-ABI call per batch) against the restated reference
+(oracle/pyref.py, pinned to the imported reference) and against the frozen reference outputs."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import pyref
+from tests import synth
+from tests.test_oracle_golden import G, NMSOBB_CASES, nmsobb_input
+
+pytestmark = pytest.mark.gpu
+
+
+def _cmp(got, ref, ties=False):
+    assert len(got) == len(ref)
+    for g, r in zip(got, ref):
+        g = g.cpu()
+        r = torch.as_tensor(r)
+        assert g.shape == r.shape, (g.shape, r.shape)
+        if ties:
+            assert np.array_equal(synth.canon_rows(g), synth.canon_rows(r))
+        else:
+            assert torch.equal(g, r)
+
+
+@pytest.mark.parametrize("name", list(NMSOBB_CASES))
+def test_fused_nms_obb_vs_golden_reference_outputs(dev, oracle_lib, name):
+    from yolov5_obb_amd.utils.general import non_max_suppression_obb
+    cfg = NMSOBB_CASES[name]
+    pred = nmsobb_input(cfg).to(dev)
+    got = non_max_suppression_obb(pred, **cfg['kw'])
+    ref = [G[f"nmsobb_{name}_{b}"] for b in range(cfg['bs'])]
+    _cmp(got, ref, ties=bool(cfg.get('half')))
+
+
+@pytest.mark.parametrize("bs,A,nc,conf,half", [(4, 20000, 15, 0.001, False), (3, 9000, 16, 0.05, True), (1, 64512, 18, 0.01, False)])
+def test_fused_nms_obb_vs_pyref_larger(dev, oracle_lib, bs, A, nc, conf, half):
+    from yolov5_obb_amd.utils.general import non_max_suppression_obb
+    pred = synth.s_pred(bs, A, nc, seed=100 + bs, fg_frac=0.02, dtype=torch.float16 if half else torch.float32)
+    kw = dict(conf_thres=conf, iou_thres=0.4, multi_label=True, max_det=1500)
+    ref = pyref.non_max_suppression_obb(pred.clone(), **kw)
+    got = non_max_suppression_obb(pred.to(dev), **kw)
+    _cmp(got, ref, ties=half)
+
+
+def test_fused_nms_obb_labels_and_empty(dev, oracle_lib):
+    from yolov5_obb_amd.utils.general import non_max_suppression_obb
+    pred = synth.s_pred(2, 3000, 15, seed=5)
+    labels = [torch.tensor([[3, 100., 120., 60., 20.], [7, 500., 400., 80., 30.]]), torch.zeros((0, 5))]
+    kw = dict(conf_thres=0.3, iou_thres=0.45, multi_label=True, labels=labels)
+    _cmp(non_max_suppression_obb(pred.to(dev), **kw), pyref.non_max_suppression_obb(pred.clone(), **kw))
+    # nothing passes -> empty (0,7) per image
+    out = non_max_suppression_obb(pred.to(dev), conf_thres=1.0)
+    assert all(o.shape == (0, 7) for o in out)
+    with pytest.raises(AssertionError):
+        non_max_suppression_obb(pred.to(dev), conf_thres=1.5)
+    with pytest.raises(RuntimeError):
+        non_max_suppression_obb(pred, conf_thres=0.5)        # CPU tensor
+
+
+def test_fused_nms_obb_candidate_overflow_retry(dev, oracle_lib):
+    """More candidates than the initial per-image reservation: the call reports it and the host layer retries."""
+    from yolov5_obb_amd.utils import general
+    pred = synth.s_pred(1, 12000, 15, seed=9, fg_frac=0.9)          # ~10k foreground anchors, several classes each
+    pred[..., 4] = pred[..., 4].clamp(min=0.9)
+    pred[..., 5:20] = pred[..., 5:20].clamp(min=0.5)                 # every class passes: 180k candidates > 65536
+    general._cap_memo.clear()
+    kw = dict(conf_thres=0.05, iou_thres=0.45, multi_label=True, max_det=300)
+    ref = pyref.non_max_suppression_obb(pred.clone(), **kw)
+    got = general.non_max_suppression_obb(pred.to(dev), **kw)
+    _cmp(got, ref, ties=True)

@@ -13,7 +13,9 @@
 #include <stdlib.h>
 #include <stdio.h>
 #include <string.h>
+#include <hip/hip_fp16.h>
 #include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_segmented_radix_sort.hpp>
 #include "nms_core.h"
 #include "obb_hip.h"
 
@@ -253,6 +255,8 @@ static int run_nms(int kind, const float* boxes, int stride, const float* scores
 
 }  // namespace obb
 
+#include "nmsobb_impl.h"
+
 using namespace obb;
 
 extern "C" {
@@ -325,6 +329,21 @@ void _poly_nms(int* keep_out_host, int* num_out_host, const float* polys_host, i
   hipFree(dp); hipFree(ds); hipFree(dk); hipFree(dn); hipFree(ws);
   free(hs); free(hk);
   if (device_id >= 0 && device_id != cur) hipSetDevice(cur);
+}
+
+size_t obb_nms_obb_workspace_bytes(int64_t bs, int64_t cap_img) {
+  ObbCarve cv;
+  if (bs < 1 || cap_img < 1 || obb_carve(nullptr, bs, cap_img, &cv)) return 0;
+  return cv.total;
+}
+
+int obb_non_max_suppression_obb(const void* pred, int dtype, int64_t bs, int64_t A, int64_t no, float conf_thres,
+                                float iou_thres, const int32_t* classes_host, int n_classes, int agnostic, int multi_label,
+                                int64_t max_det, int64_t max_nms, float max_wh, const float* extra8, int64_t n_extra,
+                                int64_t cap_img, float* out, int64_t* out_count, int64_t* status, void* ws, size_t ws_bytes,
+                                void* stream) {
+  return run_nms_obb(pred, dtype, bs, A, no, conf_thres, iou_thres, classes_host, n_classes, agnostic, multi_label, max_det,
+                     max_nms, max_wh, extra8, n_extra, cap_img, out, out_count, status, ws, ws_bytes, (hipStream_t)stream);
 }
 
 const char* obb_version(void) { return "obb_hip 0.1 (gfx950)"; }

@@ -1,0 +1,310 @@
+// Fused non_max_suppression_obb for gfx950 (included by nms.hip, namespace obb).
+//
+// Replaces the per-image Python loop of utils/general.py:772-862 (>= 10 tiny ATen kernels and >= 3 host
+// syncs per image, then obb_nms with a device->host mask copy) by ONE stream-ordered call for the whole batch:
+//
+//   k_decode      one wave per 64 anchors: strided read of the objectness column only (2-4 B of each 400-800 B
+//                 row); rows that pass `obj > conf` are then processed by the whole wave -- coalesced class
+//                 scores, conf = obj*cls rounded in the input dtype, multi-label expansion by ballot, CSL
+//                 decode = wave arg-max over the 180 angle bins (first maximum), theta = (idx-90)/180*3.141592,
+//                 class filter -- and appended to the image's candidate region together with a 64-bit sort key
+//                 (descending conf, then ascending anchor*nc+class: a deterministic tie rule).
+//   segmented radix sort (rocPRIM) per image, top max_nms (30000) kept           (:845-846)
+//   k_prep_cand   class offset xy += cls*max_wh (:849-851), rotated-box records, too-small filter of obb_nms
+//   LC-NMS steps  (nms_core.h) with max_keep = max_det                           (:853-855)
+//   k_gather_out  rows [x y l s theta conf cls] of the kept candidates, [bs][max_det][7] + counts
+//
+// The only host<->device traffic is the caller reading the bs counts (+ the overflow word) afterwards.
+#pragma once
+
+namespace obb {
+
+struct ClassMask { unsigned long long w[4]; int all; };   // allowed classes (nc <= 256), all != 0: no filter
+
+template <typename T> __device__ __forceinline__ float ld_as_float(const T* p);
+template <> __device__ __forceinline__ float ld_as_float<float>(const float* p) { return *p; }
+template <> __device__ __forceinline__ float ld_as_float<__half>(const __half* p) { return __half2float(*p); }
+// product rounded to the tensor dtype: x[:, 5:ci] *= x[:, 4:5] happens in the input dtype (utils/general.py:820)
+template <typename T> __device__ __forceinline__ float mul_in_dtype(float a, float b);
+template <> __device__ __forceinline__ float mul_in_dtype<float>(float a, float b) { return a * b; }
+template <> __device__ __forceinline__ float mul_in_dtype<__half>(float a, float b) { return __half2float(__float2half_rn(a * b)); }
+// python float threshold compared against a tensor of the input dtype: the scalar is cast to that dtype
+template <typename T> __device__ __forceinline__ float thr_in_dtype(float t);
+template <> __device__ __forceinline__ float thr_in_dtype<float>(float t) { return t; }
+template <> __device__ __forceinline__ float thr_in_dtype<__half>(float t) { return __half2float(__float2half_rn(t)); }
+
+// wave arg-max with "first maximum" tie rule
+__device__ __forceinline__ void wave_argmax_first(float& v, int& i) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    float ov = __shfl_xor(v, d);
+    int oi = __shfl_xor(i, d);
+    if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
+  }
+}
+
+struct DecodeArgs {
+  const void* pred;          // [bs][A][no]
+  long long A;
+  int no, nc, bs;
+  float conf_thres;
+  int multi_label;
+  ClassMask cm;
+  long long cap_img;         // candidate slots per image
+  float4* cand;              // [bs*cap_img][2]: {x,y,l,s} {theta,conf,cls,0}
+  unsigned long long* keys;  // [bs*cap_img]
+  uint32_t* vals;            // [bs*cap_img] slot index inside the image region
+  int* cnt;                  // [bs] candidates produced (may exceed cap_img: overflow)
+};
+
+__device__ __forceinline__ bool class_allowed(const ClassMask& cm, int c) {
+  return cm.all || ((cm.w[(c >> 6) & 3] >> (c & 63)) & 1ull);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_decode(DecodeArgs a) {
+  const T* pred = (const T*)a.pred;
+  const int lane = threadIdx.x & 63;
+  const int b = blockIdx.y;
+  const long long r0 = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 64;
+  if (r0 >= a.A) return;
+  const float thr = thr_in_dtype<T>(a.conf_thres);
+  const T* img = pred + (size_t)b * a.A * a.no;
+  const long long row = r0 + lane;
+  const float obj = (row < a.A) ? ld_as_float<T>(img + (size_t)row * a.no + 4) : 0.f;
+  unsigned long long m = __ballot(row < a.A && obj > thr);          // :785  xc = prediction[..., 4] > conf_thres
+  float4* cand = a.cand + (size_t)b * a.cap_img * 2;
+  unsigned long long* keys = a.keys + (size_t)b * a.cap_img;
+  uint32_t* vals = a.vals + (size_t)b * a.cap_img;
+
+  while (m) {
+    const int rr = __builtin_ctzll(m);
+    m &= m - 1;
+    const long long rw = r0 + rr;
+    const T* base = img + (size_t)rw * a.no;
+    const float o = __shfl(obj, rr);
+
+    // ---- class confidences, in chunks of 64 classes
+    float bestv = -__builtin_inff(); int besti = 0x7fffffff;
+    unsigned long long pass_bits[4] = {0ull, 0ull, 0ull, 0ull};
+    int npass = 0;
+    float myconf[4];
+    for (int c0 = 0, q = 0; c0 < a.nc; c0 += 64, q++) {
+      const int c = c0 + lane;
+      const float v = (c < a.nc) ? mul_in_dtype<T>(ld_as_float<T>(base + 5 + c), o) : -__builtin_inff();   // :820
+      myconf[q & 3] = v;
+      if (a.multi_label) {
+        const bool p = (c < a.nc) && (v > thr) && class_allowed(a.cm, c);                                 // :827, :835
+        const unsigned long long pb = __ballot(p);
+        pass_bits[q & 3] = pb;
+        npass += __popcll(pb);
+      } else if (c < a.nc && (v > bestv)) { bestv = v; besti = c; }   // lanes see ascending c: first max kept
+    }
+    if (!a.multi_label) {
+      wave_argmax_first(bestv, besti);                                                                    // :830
+      npass = (bestv > thr && class_allowed(a.cm, besti)) ? 1 : 0;                                        // :831, :835
+    }
+    if (npass == 0) continue;
+
+    // ---- CSL decode: first arg-max over the 180 bins (:822-823)
+    const T* csl = base + 5 + a.nc;
+    float tv = ld_as_float<T>(csl + lane); int ti = lane;
+    { float v1 = ld_as_float<T>(csl + 64 + lane); if (v1 > tv) { tv = v1; ti = 64 + lane; } }
+    if (lane < 180 - 128) { float v2 = ld_as_float<T>(csl + 128 + lane); if (v2 > tv) { tv = v2; ti = 128 + lane; } }
+    wave_argmax_first(tv, ti);
+    const float theta = ((float)(ti - 90) / 180.0f) * 3.141592f;
+    const float bx = ld_as_float<T>(base + 0), by = ld_as_float<T>(base + 1), bl = ld_as_float<T>(base + 2), bs_ = ld_as_float<T>(base + 3);
+
+    // ---- append
+    int slot0 = 0;
+    if (lane == 0) slot0 = atomicAdd(&a.cnt[b], npass);
+    slot0 = __shfl(slot0, 0);
+    if (a.multi_label) {
+      int before = 0;
+      for (int c0 = 0, q = 0; c0 < a.nc; c0 += 64, q++) {
+        const unsigned long long pb = pass_bits[q & 3];
+        if ((pb >> lane) & 1ull) {
+          const long long slot = (long long)slot0 + before + __popcll(pb & lanemask_lt());
+          if (slot < a.cap_img) {
+            const int c = c0 + lane;
+            const float conf = myconf[q & 3];
+            cand[slot * 2] = make_float4(bx, by, bl, bs_);
+            cand[slot * 2 + 1] = make_float4(theta, conf, (float)c, 0.f);
+            keys[slot] = ((unsigned long long)score_desc_key(conf) << 32) | (unsigned long long)(uint32_t)(rw * a.nc + c);
+            vals[slot] = (uint32_t)slot;
+          }
+        }
+        before += __popcll(pb);
+      }
+    } else if (lane == 0 && slot0 < a.cap_img) {
+      cand[(size_t)slot0 * 2] = make_float4(bx, by, bl, bs_);
+      cand[(size_t)slot0 * 2 + 1] = make_float4(theta, bestv, (float)besti, 0.f);
+      keys[slot0] = ((unsigned long long)score_desc_key(bestv) << 32) | (unsigned long long)(uint32_t)(rw * a.nc + besti);
+      vals[slot0] = (uint32_t)slot0;
+    }
+  }
+}
+
+// apriori label rows (utils/general.py:807-813), prepared by the host layer as [img, x, y, l, s, theta, conf, cls]
+__global__ void k_append_extra(const float* __restrict__ extra8, int m, long long A, int nc, DecodeArgs a) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m) return;
+  const float* e = extra8 + (size_t)i * 8;
+  const int b = (int)e[0];
+  if (b < 0 || b >= a.bs) return;
+  const int slot = atomicAdd(&a.cnt[b], 1);
+  if (slot >= a.cap_img) return;
+  const size_t g = (size_t)b * a.cap_img + slot;
+  a.cand[g * 2] = make_float4(e[1], e[2], e[3], e[4]);
+  a.cand[g * 2 + 1] = make_float4(e[5], e[6], e[7], 0.f);
+  a.keys[g] = ((unsigned long long)score_desc_key(e[6]) << 32) | (unsigned long long)(uint32_t)(A * nc + i);
+  a.vals[g] = (uint32_t)slot;
+}
+
+__global__ void k_cand_segments(const int* __restrict__ cnt, int bs, long long cap_img, long long max_nms, int* sort_begin,
+                                int* sort_end, int* seg_begin, int* seg_end, int* cursor, int* keep_cnt, int* ccount, int* nrows,
+                                int* nedges) {
+  int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= bs) return;
+  long long c = cnt[g];
+  if (c > cap_img) c = cap_img;
+  const int b0 = (int)(g * cap_img);
+  sort_begin[g] = b0; sort_end[g] = b0 + (int)c;
+  if (max_nms > 0 && c > max_nms) c = max_nms;
+  seg_begin[g] = b0; seg_end[g] = b0 + (int)c; cursor[g] = b0;
+  keep_cnt[g] = 0; ccount[g] = 0; nrows[g] = 0; nedges[g] = 0;
+}
+
+__global__ void k_prep_cand(const float4* __restrict__ cand, const uint32_t* __restrict__ vals_sorted,
+                            const int* __restrict__ seg_begin, const int* __restrict__ seg_end, long long cap_img,
+                            float class_offset, float4* __restrict__ rec, uint8_t* __restrict__ dead, uint32_t* __restrict__ order) {
+  const int g = blockIdx.y;
+  const int p = seg_begin[g] + blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= seg_end[g]) return;
+  const size_t ci = (size_t)g * cap_img + vals_sorted[p];
+  const float4 c0 = cand[ci * 2], c1 = cand[ci * 2 + 1];
+  const float off = c1.z * class_offset;                       // :849  c = x[:, 6:7] * (0 if agnostic else max_wh)
+  const float x = c0.x + off, y = c0.y + off;                  // :851
+  RBoxFeat f = rbox_make_feat(x, y, c0.z, c0.w, c1.x);
+  float4 q[4];
+  RotGeom::pack(f, q);
+#pragma unroll
+  for (int k = 0; k < 4; k++) rec[(size_t)p * 4 + k] = q[k];
+  const float mn = (c0.w < c0.z) ? c0.w : c0.z;
+  dead[p] = (mn < 0.001f) ? 1 : 0;                             // nms_rotated_wrapper.py:32
+  order[p] = (uint32_t)ci;
+}
+
+__global__ void k_gather_out(const float4* __restrict__ cand, const int64_t* __restrict__ keep, const int* __restrict__ seg_begin,
+                             const int* __restrict__ keep_cnt, long long max_det, float* __restrict__ out, int64_t* __restrict__ out_count,
+                             const int* __restrict__ cnt, long long cap_img, int64_t* __restrict__ status) {
+  const int g = blockIdx.y;
+  long long nk = keep_cnt[g];
+  if (max_det > 0 && nk > max_det) nk = max_det;
+  const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k == 0) {
+    out_count[g] = nk;
+    if (cnt[g] > cap_img) atomicMax((unsigned long long*)status, (unsigned long long)cnt[g]);   // overflow: caller retries
+  }
+  if (k >= nk) return;
+  const size_t ci = (size_t)keep[(size_t)seg_begin[g] + k];
+  const float4 c0 = cand[ci * 2], c1 = cand[ci * 2 + 1];
+  float* o = out + ((size_t)g * max_det + k) * 7;
+  o[0] = c0.x; o[1] = c0.y; o[2] = c0.z; o[3] = c0.w; o[4] = c1.x; o[5] = c1.y; o[6] = c1.z;
+}
+
+struct ObbCarve {
+  float4* cand; unsigned long long *keys_a, *keys_b; uint32_t *vals_a, *vals_b; int* cnt; int *sort_begin, *sort_end;
+  void* sort_tmp; size_t sort_tmp_bytes;
+  int64_t* keep;
+  Carve nms;          // rec/dead/segment state reuse the NMS carve (keys/vals/sort_tmp of it unused)
+  void* nms_base;
+  size_t total;
+};
+
+static hipError_t seg_sort_tmp_query(size_t n, int nseg, size_t* bytes) {
+  *bytes = 0;
+  return rocprim::segmented_radix_sort_pairs(nullptr, *bytes, (unsigned long long*)nullptr, (unsigned long long*)nullptr,
+                                             (uint32_t*)nullptr, (uint32_t*)nullptr, (unsigned int)n, (unsigned int)nseg,
+                                             (int*)nullptr, (int*)nullptr, 0, 64, (hipStream_t)0, false);
+}
+
+static int obb_carve(void* base, int64_t bs, int64_t cap_img, ObbCarve* cv) {
+  size_t off = 0;
+  auto take = [&](size_t bytes) { size_t o = off; off += align_up(bytes); return base ? (char*)base + o : (char*)nullptr; };
+  const size_t n = (size_t)bs * cap_img;
+  cv->cand = (float4*)take(n * 32);
+  cv->keys_a = (unsigned long long*)take(n * 8); cv->keys_b = (unsigned long long*)take(n * 8);
+  cv->vals_a = (uint32_t*)take(n * 4); cv->vals_b = (uint32_t*)take(n * 4);
+  cv->cnt = (int*)take(bs * 4); cv->sort_begin = (int*)take(bs * 4); cv->sort_end = (int*)take(bs * 4);
+  if (seg_sort_tmp_query(n, (int)bs, &cv->sort_tmp_bytes) != hipSuccess) return OBB_ERR_INTERNAL;
+  cv->sort_tmp = take(cv->sort_tmp_bytes ? cv->sort_tmp_bytes : 16);
+  cv->keep = (int64_t*)take(n * 8);
+  // NMS state sized for bs * cap_img positions
+  cv->nms_base = base ? (char*)base + off : nullptr;
+  int rc = carve(cv->nms_base, (int64_t)n, bs, RotGeom::RECQ, cap_max(bs), &cv->nms);
+  if (rc) return rc;
+  off += cv->nms.total;
+  cv->total = off;
+  return OBB_OK;
+}
+
+static int run_nms_obb(const void* pred, int dtype, int64_t bs, int64_t A, int64_t no, float conf_thres, float iou_thres,
+                       const int32_t* classes_host, int n_classes, int agnostic, int multi_label, int64_t max_det, int64_t max_nms,
+                       float max_wh, const float* extra8, int64_t n_extra, int64_t cap_img, float* out, int64_t* out_count,
+                       int64_t* status, void* ws, size_t ws_bytes, hipStream_t st) {
+  const int nc = (int)(no - 5 - 180);                              // :784
+  if (bs < 1 || A < 1 || nc < 1 || nc > 256 || max_det < 1 || cap_img < 1 || !pred || !out || !out_count || !status)
+    return OBB_ERR_BAD_ARG;
+  if (A * nc + n_extra > 0xffffffffLL || bs * cap_img > 0x7fffffffLL) return OBB_ERR_BAD_ARG;
+  if (dtype != 0 && dtype != 1) return OBB_ERR_BAD_ARG;
+  ObbCarve cv;
+  int rc = obb_carve(ws, bs, cap_img, &cv);
+  if (rc) return rc;
+  if (!ws || ws_bytes < cv.total) return OBB_ERR_WORKSPACE;
+
+  DecodeArgs d;
+  d.pred = pred; d.A = A; d.no = (int)no; d.nc = nc; d.bs = (int)bs; d.conf_thres = conf_thres;
+  d.multi_label = (multi_label && nc > 1) ? 1 : 0;                 // :797
+  d.cm.all = (classes_host == nullptr || n_classes <= 0) ? 1 : 0;
+  for (int i = 0; i < 4; i++) d.cm.w[i] = 0ull;
+  for (int i = 0; i < n_classes && classes_host; i++) {
+    int c = classes_host[i];
+    if (c >= 0 && c < 256) d.cm.w[c >> 6] |= 1ull << (c & 63);
+  }
+  d.cap_img = cap_img; d.cand = cv.cand; d.keys = cv.keys_a; d.vals = cv.vals_a; d.cnt = cv.cnt;
+
+  hipMemsetAsync(cv.cnt, 0, bs * 4, st);
+  hipMemsetAsync(status, 0, 8, st);
+  dim3 gd((unsigned)((A + 255) / 256), (unsigned)bs);
+  if (dtype == 0) k_decode<float><<<gd, 256, 0, st>>>(d);
+  else k_decode<__half><<<gd, 256, 0, st>>>(d);
+  if (n_extra > 0 && extra8) k_append_extra<<<(unsigned)((n_extra + 255) / 256), 256, 0, st>>>(extra8, (int)n_extra, A, nc, d);
+  const unsigned gs = (unsigned)((bs + 255) / 256);
+  Carve& nv = cv.nms;
+  k_cand_segments<<<gs, 256, 0, st>>>(cv.cnt, (int)bs, cap_img, max_nms, cv.sort_begin, cv.sort_end, nv.seg_begin, nv.seg_end,
+                                      nv.cursor, nv.keep_cnt, nv.ccount, nv.nrows, nv.nedges);
+  size_t tmp = cv.sort_tmp_bytes;
+  if (rocprim::segmented_radix_sort_pairs(cv.sort_tmp, tmp, cv.keys_a, cv.keys_b, cv.vals_a, cv.vals_b,
+                                          (unsigned int)(bs * cap_img), (unsigned int)bs, cv.sort_begin, cv.sort_end, 0, 64, st,
+                                          false) != hipSuccess)
+    return OBB_ERR_LAUNCH;
+  const int64_t max_seg = (max_nms > 0 && max_nms < cap_img) ? max_nms : cap_img;
+  dim3 gp((unsigned)((max_seg + 255) / 256), (unsigned)bs);
+  k_prep_cand<<<gp, 256, 0, st>>>(cv.cand, cv.vals_b, nv.seg_begin, nv.seg_end, cap_img, agnostic ? 0.f : max_wh, nv.rec, nv.dead,
+                                  nv.vals_b);
+
+  NmsArgs a;
+  a.rec = nv.rec; a.order = nv.vals_b; a.dead = nv.dead; a.seg_begin = nv.seg_begin; a.seg_end = nv.seg_end;
+  a.cursor = nv.cursor; a.keep_cnt = nv.keep_cnt; a.keep_out = cv.keep; a.cidx = nv.cidx; a.ccount = nv.ccount;
+  a.rows = nv.rows; a.nrows = nv.nrows; a.edges = nv.edges; a.nedges = nv.nedges;
+  a.ecap = nv.ecap; a.n = (int)(bs * cap_img); a.capmax = cap_max(bs);
+  a.max_keep = (int)max_det; a.thr = iou_thres; a.cull = (iou_thres >= 0.f) ? 1 : 0;
+  nms_steps(0, a, bs, max_seg, st);
+
+  dim3 go((unsigned)((max_det + 255) / 256), (unsigned)bs);
+  k_gather_out<<<go, 256, 0, st>>>(cv.cand, cv.keep, nv.seg_begin, nv.keep_cnt, max_det, out, out_count, cv.cnt, cap_img, status);
+  return hipGetLastError() == hipSuccess ? OBB_OK : OBB_ERR_LAUNCH;
+}
+
+}  // namespace obb

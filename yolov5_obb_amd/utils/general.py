@@ -1,0 +1,107 @@
+"""Mirror of the OBB part of the reference's ``utils/general.py``: ``non_max_suppression_obb``
+(utils/general.py:772-862), backed by ONE call into libobb_hip.so for the whole batch
+(``obb_non_max_suppression_obb``, include/obb_hip.h) instead of a per-image loop of small ATen
+kernels, host syncs and a device->host mask copy.
+"""
+import ctypes as C
+
+import torch
+
+from .. import _lib
+
+pi = 3.141592  # utils/general.py:34 (truncated on purpose: it is the constant the labels were encoded with)
+
+_MAX_WH = 4096      # utils/general.py:793
+_MAX_NMS = 30000    # utils/general.py:794
+_CSL = 180          # utils/general.py:784
+_cap_memo = {}      # (A, nc, multi_label) -> candidate slots per image that sufficed last time
+
+
+def _label_rows(labels, bs, nc, device):
+    """Apriori labels for autolabelling (utils/general.py:807-813) as candidate rows [img, x, y, l, s, theta, conf, cls]:
+    obj = 1, one-hot class = 1 -> conf = 1; the CSL part of such a row is all zeros -> arg-max bin 0 -> theta = -90/180*pi."""
+    rows = []
+    theta0 = torch.tensor((0 - 90) / 180, dtype=torch.float32).mul(pi).item()
+    for b in range(bs):
+        if b < len(labels) and len(labels[b]):
+            lb = labels[b].to(device=device, dtype=torch.float32)
+            r = torch.zeros((lb.shape[0], 8), device=device, dtype=torch.float32)
+            r[:, 0] = b
+            r[:, 1:5] = lb[:, 1:5]
+            r[:, 5] = theta0
+            r[:, 6] = 1.0
+            r[:, 7] = lb[:, 0].long().float()
+            rows.append(r)
+    return torch.cat(rows, 0).contiguous() if rows else None
+
+
+def non_max_suppression_obb(prediction, conf_thres=0.25, iou_thres=0.45, classes=None, agnostic=False, multi_label=False,
+                            labels=(), max_det=1500):
+    """Runs Non-Maximum Suppression (NMS) on inference results_obb (utils/general.py:772-862).
+
+    Args:
+        prediction (tensor): (b, n_all_anchors, [cx cy l s obj num_cls theta_cls]), fp32 or fp16, on the GPU
+        agnostic (bool): True = NMS will be applied between elements of different categories
+        labels : () or per-image apriori labels (n, [cls x y l s]) for autolabelling
+    Returns:
+        list of detections, len=batch_size, on (n,7) tensor per image [xylsθ, conf, cls] θ ∈ [-pi/2, pi/2)
+    """
+    _lib.require_cuda(prediction, "prediction")
+    if prediction.dim() != 3:
+        raise RuntimeError(f"prediction must be (bs, anchors, no), got {tuple(prediction.shape)}")
+    nc = prediction.shape[2] - 5 - _CSL  # number of classes
+    # Checks (same asserts as the reference, :789-790)
+    assert 0 <= conf_thres <= 1, f'Invalid Confidence threshold {conf_thres}, valid values are between 0.0 and 1.0'
+    assert 0 <= iou_thres <= 1, f'Invalid IoU {iou_thres}, valid values are between 0.0 and 1.0'
+    if nc < 1 or nc > 256:
+        raise RuntimeError(f"non_max_suppression_obb: 1 <= nc <= 256 supported, got nc = {nc}")
+    if prediction.dtype == torch.float32:
+        dtype = 0
+    elif prediction.dtype == torch.float16:
+        dtype = 1
+    else:
+        raise RuntimeError(f"non_max_suppression_obb: float32 or float16 expected, got {prediction.dtype}")
+    pred = prediction.contiguous()
+    bs, A, no = pred.shape
+    dev = pred.device
+    multi = bool(multi_label) and nc > 1
+    if bs == 0:
+        return []
+    if A == 0:
+        return [torch.zeros((0, 7), device=dev)] * bs
+
+    extra = _label_rows(labels, bs, nc, dev) if labels else None
+    n_extra = 0 if extra is None else extra.shape[0]
+    cls_arr = None
+    if classes is not None:
+        cl = [int(c) for c in (classes if isinstance(classes, (list, tuple)) else list(classes))]
+        cls_arr = (C.c_int32 * max(1, len(cl)))(*cl)
+        n_cls = len(cl)
+        if n_cls == 0:
+            return [torch.zeros((0, 7), device=dev)] * bs
+    else:
+        n_cls = 0
+
+    worst = A * (nc if multi else 1) + n_extra
+    key = (A, nc, multi)
+    cap = min(worst, max(_cap_memo.get(key, 0), 65536))
+    L = _lib.lib()
+    max_det = int(max_det)
+    out = torch.empty((bs, max_det, 7), dtype=torch.float32, device=dev)
+    meta = torch.empty(bs + 1, dtype=torch.int64, device=dev)        # counts[bs] + status
+    while True:
+        with torch.cuda.device(dev):
+            ws = _lib.workspace(L.obb_nms_obb_workspace_bytes(bs, cap), dev)
+            rc = L.obb_non_max_suppression_obb(
+                _lib.ptr(pred), dtype, bs, A, no, float(conf_thres), float(iou_thres),
+                C.cast(cls_arr, C.c_void_p) if cls_arr is not None else C.c_void_p(0), n_cls, int(bool(agnostic)), int(multi),
+                max_det, _MAX_NMS, float(_MAX_WH), _lib.ptr(extra), n_extra, cap, _lib.ptr(out), _lib.ptr(meta),
+                C.c_void_p(meta.data_ptr() + 8 * bs), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev))
+        _lib.check(rc, "obb_non_max_suppression_obb")
+        m = meta.tolist()                                             # the single device->host sync of the call
+        if m[bs] > cap:                                               # an image produced more candidates than slots
+            cap = min(worst, max(int(m[bs]), 2 * cap))
+            continue
+        break
+    _cap_memo[key] = cap
+    return [out[b, :m[b]] for b in range(bs)]
