@@ -1,0 +1,196 @@
+#!/usr/bin/env python3
+"""bench.py -- the hot-path benchmark of the MI355X oriented-box path (contract: see the task's bench section).
+
+One "step" = one pass of the hot path over one batch of synthetic input, with the input already resident in HBM:
+the workload of BASELINE.json configs[1] -- "yolov5s OBB, DOTAv1.0 1024^2 bs=16, val.py --task speed" --
+i.e. the `non_max_suppression_obb` call of val.py:206 on the (16, 64512, 200) fp16 Detect output with the speed-task
+thresholds (conf 0.25, iou 0.45, multi_label=True, max_det 1500; val.py:378-383,206), including the one
+device->host read of the per-image counts the call ends with.  Data is synthetic (tests/synth.py: S-pred), weights do
+not exist on this path.
+
+    python bench.py --gpus N --steps K --warmup W
+N > 1: launched by torch.distributed.run, one rank per GPU; images shard across ranks (pure data parallel, no
+collective on the data path; RCCL is only used for the timing barrier / max-reduce).  value = whole-job images/s.
+
+The JSON line also carries
+  roofline      for the dominant kernel of the step (k_decode, HBM-bound): algorithmic bytes / HIP-event time
+  nms_100k      the second half of BASELINE.json's metric: one rotated-NMS call on 100k candidates (S-clustered,
+                iou 0.4, BASELINE.json configs[3]) in ms, with its own HBM-roofline figure
+                bytes_nms(N) = 24N + 8N + 8N*ceil(N/64)  
+  cpu_baseline  the CPU oracle (port of the reference's CPU path) timed on the host cores on a bounded sample
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+
+
+def bytes_nms(n):
+    return 24 * n + 8 * n + 8 * n * ((n + 63) // 64)
+
+
+def collect_profile(L, nst=8):
+    ms = (C.c_double * nst)()
+    cnt = (C.c_int64 * nst)()
+    rc = L.obb_profile_collect(C.cast(ms, C.c_void_p), C.cast(cnt, C.c_void_p), nst)
+    assert rc == 0
+    return list(ms), list(cnt)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--nms-n", type=int, default=100000)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", 0))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)      # "nccl" is RCCL on ROCm
+
+    from tests import synth
+    from yolov5_obb_amd import _lib, nms_rotated_ext
+    from yolov5_obb_amd.utils.general import non_max_suppression_obb
+    L = _lib.lib()
+
+    # ---------------- workload: configs[1]
+    bs, A, nc = 16, 64512, 15
+    no = 5 + nc + 180
+    kw = dict(conf_thres=0.25, iou_thres=0.45, multi_label=True, max_det=1500)
+    pred = synth.s_pred(bs, A, nc, seed=1000 + rank, n_obj=120, fg_frac=0.03, device=dev, dtype=torch.float16)
+    torch.cuda.synchronize()
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    out = None
+    for _ in range(args.warmup):
+        out = non_max_suppression_obb(pred, **kw)
+    n_det = sum(int(o.shape[0]) for o in out) if out is not None else 0
+    barrier()
+    L.obb_profile_enable(1)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = non_max_suppression_obb(pred, **kw)
+    barrier()
+    dt = time.perf_counter() - t0
+    ms_sum, cnts = collect_profile(L)
+    L.obb_profile_enable(0)
+    if dist is not None:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms_per_step = dt / args.steps * 1e3
+    value = world * bs * args.steps / dt
+
+    # roofline of the dominant kernel of the step: k_decode (stage 0), measured with HIP events in the timed region
+    dec_ms = ms_sum[0] / max(1, cnts[0])
+    n_det = sum(int(o.shape[0]) for o in out)
+    alg_bytes = bs * A * no * 2 + 28 * n_det            # bytes_dec = bs*A*no*sizeof(elem) + 28*n_out
+    achieved = alg_bytes / (dec_ms * 1e-3) / 1e9
+    stage_names = ["decode", "segsort", "prep", "nms_steps", "gather"]
+    stages = {stage_names[i]: round(ms_sum[i] / max(1, cnts[i]), 4) for i in range(5)}
+
+    # ---------------- NMS @ 100k candidates (configs[3] stress), rank 0 only reports
+    n100 = args.nms_n
+    d100, s100 = synth.s_clustered(n100, 300, seed=0)
+    d100, s100 = d100.to(dev), s100.to(dev)
+    for _ in range(3):
+        k100 = nms_rotated_ext.nms_rotated(d100, s100, 0.4)
+    torch.cuda.synchronize()
+    reps = 20
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    L.obb_profile_enable(1)
+    e0.record()
+    for _ in range(reps):
+        k100 = nms_rotated_ext.nms_rotated(d100, s100, 0.4)
+    e1.record()
+    torch.cuda.synchronize()
+    nms_ms = e0.elapsed_time(e1) / reps
+    pms, pc = collect_profile(L)
+    L.obb_profile_enable(0)
+    nms_obj = {
+        "n": n100, "distribution": "S-clustered(K=300)", "iou_thres": 0.4, "kept": int(k100.numel()),
+        "ms_per_call": round(nms_ms, 4),
+        "stages_ms": {"sort": round(pms[5] / max(1, pc[5]), 4), "prep": round(pms[6] / max(1, pc[6]), 4),
+                      "steps": round(pms[7] / max(1, pc[7]), 4)},
+        "roofline": {"bound": "hbm", "achieved": round(bytes_nms(n100) / (nms_ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": round(bytes_nms(n100) / (nms_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                     "traffic": None, "algorithmic_bytes": bytes_nms(n100),
+                     "note": "whole NMS call (sort+prep+all step kernels) over the dense-mask algorithmic bytes"},
+    }
+
+    # ---------------- CPU baseline (rank 0, N=1 only): the oracle port of the reference CPU path, bounded sample
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        try:
+            import oracle
+            from oracle import pyref
+            oracle.build(with_ref=False)
+            sample = pred[:1].float().cpu()                     # 1 image of the same batch, fp32 like --device cpu
+            torch.set_num_threads(os.cpu_count() or 1)
+            t0 = time.perf_counter()
+            nimg = 0
+            while True:
+                pyref.non_max_suppression_obb(sample.clone(), **kw)
+                nimg += 1
+                if time.perf_counter() - t0 > 10.0 or nimg >= 64:
+                    break
+            cdt = time.perf_counter() - t0
+            cpu = {"value": round(nimg / cdt, 3), "unit": "img/s", "cores": int(torch.get_num_threads()), "kind": "port",
+                   "sample": f"{nimg} x 1 image (64512 anchors, fp32) of the same synthetic batch through oracle.pyref."
+                             f"non_max_suppression_obb (torch CPU filter/decode + single-thread C greedy rotated NMS)"}
+            # reference-style CPU NMS alone at 10k candidates (the 100k run would take minutes)
+            dsm, ssm = synth.s_clustered(10000, 300, seed=0)
+            t0 = time.perf_counter()
+            oracle.nms_rotated(dsm.numpy(), ssm.numpy(), 0.4)
+            cpu["nms_10k_clustered_ms"] = round((time.perf_counter() - t0) * 1e3, 2)
+        except Exception as e:                                  # the baseline is informative; never fail the bench on it
+            cpu = {"value": None, "unit": "img/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
+
+    if rank == 0:
+        line = {
+            "metric": "val.py hot path img/s (non_max_suppression_obb, bs16 1024^2) + NMS ms/img @100k cand",
+            "value": round(value, 2), "unit": "img/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f16", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: yolov5s OBB head output (16,64512,200) fp16 -> non_max_suppression_obb "
+                                   "(conf .25, iou .45, multi_label, max_det 1500), val.py --task speed hot path",
+                       "global_batch": bs * world, "anchors_per_image": A, "nc": nc, "detections_per_batch": n_det,
+                       "parallelism": f"dp{world} (images sharded, no data-path collective)"},
+            "stages_ms": stages,
+            "roofline": {"bound": "hbm", "kernel": "obb::k_decode<__half>", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "algorithmic_bytes": alg_bytes, "avg_kernel_ms": round(dec_ms, 5)},
+            "nms_100k": nms_obj,
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -42,6 +42,14 @@ extern "C" {
 const char* obb_version(void);
 int obb_device_info(int* cu_count, int* wave_size, char* arch_name, int arch_name_len);
 
+/* Optional per-stage timing with HIP events recorded on the caller's stream (used by bench.py for the roofline
+ * object).  Stage ids: 0 decode/filter kernel, 1 per-image sort, 2 candidate prep, 3 NMS steps, 4 output gather of
+ * obb_non_max_suppression_obb; 5 sort, 6 prep, 7 NMS steps of obb_nms_*.  obb_profile_collect synchronises the
+ * recorded events, returns summed milliseconds and launch counts per stage, and resets the recording. */
+#define OBB_PROF_STAGES 8
+int obb_profile_enable(int on);
+int obb_profile_collect(double* ms_sum_host, int64_t* count_host, int n_stages);
+
 /* ------------------------------------------------------------------ NMS ------------------------------ */
 
 /* Scratch bytes for n boxes in nseg segments.  kind: 0 = rotated boxes, 1 = quads. */

@@ -28,6 +28,8 @@ _vp, _i64, _i32, _f32, _sz = C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_size
 SIGNATURES = {
     "obb_version": (C.c_char_p, []),
     "obb_device_info": (_i32, [C.POINTER(_i32), C.POINTER(_i32), C.c_char_p, _i32]),
+    "obb_profile_enable": (_i32, [_i32]),
+    "obb_profile_collect": (_i32, [_vp, _vp, _i32]),
     "obb_nms_workspace_bytes": (_sz, [_i64, _i64, _i32]),
     "obb_nms_rotated_f32": (_i32, [_vp, _vp, _i64, _f32, _i32, _i64, _vp, _vp, _vp, _sz, _vp]),
     "obb_nms_rotated_batched_f32": (_i32, [_vp, _vp, _vp, _vp, _i32, _i64, _i64, _i64, _f32, _i32, _i64, _vp, _vp, _vp,

@@ -21,6 +21,29 @@
 
 namespace obb {
 
+// ---------------------------------------------------------------- optional per-stage timing (HIP events)
+// bench.py switches this on to time the dominant kernels on the stream they are launched on.
+enum { PROF_DECODE = 0, PROF_SEGSORT, PROF_PREP, PROF_STEPS, PROF_GATHER, PROF_NMS_SORT, PROF_NMS_PREP, PROF_NMS_STEPS, PROF_N };
+struct ProfState {
+  bool on = false;
+  static constexpr int kMax = 8192;
+  hipEvent_t ev0[kMax], ev1[kMax];
+  int id[kMax];
+  int created = 0, used = 0;
+};
+static ProfState g_prof;
+struct ProfScope {
+  int slot = -1; hipStream_t st;
+  ProfScope(int stage, hipStream_t s) : st(s) {
+    if (!g_prof.on || g_prof.used >= ProfState::kMax) return;
+    slot = g_prof.used++;
+    if (slot >= g_prof.created) { hipEventCreate(&g_prof.ev0[slot]); hipEventCreate(&g_prof.ev1[slot]); g_prof.created = slot + 1; }
+    g_prof.id[slot] = stage;
+    hipEventRecord(g_prof.ev0[slot], st);
+  }
+  ~ProfScope() { if (slot >= 0) hipEventRecord(g_prof.ev1[slot], st); }
+};
+
 // ---------------------------------------------------------------- small kernels
 // Sort key: segments ascending, score descending, NaN first (torch's order),
 // -0 == +0, ties keep ascending original index (LSD radix sort is stable) or the
@@ -227,16 +250,22 @@ static int run_nms(int kind, const float* boxes, int stride, const float* scores
   }
 
   const unsigned gb = (unsigned)((n + T - 1) / T);
-  k_make_keys<<<gb, T, 0, st>>>(scores, score_stride, seg_id, tie, tie_bits, kind == 0 ? boxes : nullptr,
-                                kind == 0 ? drop_small : 0, (int)n, cv.keys_a, cv.vals_a);
-  size_t tmp = cv.sort_tmp_bytes;
-  if (rocprim::radix_sort_pairs(cv.sort_tmp, tmp, cv.keys_a, cv.keys_b, cv.vals_a, cv.vals_b, (size_t)n, 0,
-                                (unsigned)(32 + tie_bits + seg_bits), st, false) != hipSuccess)
-    return OBB_ERR_LAUNCH;
-  k_seg_bounds<<<gseg, T, 0, st>>>(cv.keys_b, (int)n, (int)nseg, 32 + tie_bits, 0, cv.seg_begin, cv.seg_end, cv.cursor,
-                                   cv.keep_cnt, cv.ccount, cv.nrows, cv.nedges);
-  if (kind == 0) k_prep_rot<<<gb, T, 0, st>>>(boxes, cv.vals_b, drop_small, (int)n, cv.rec, cv.dead);
-  else k_prep_quad<<<gb, T, 0, st>>>(boxes, stride, cv.vals_b, (int)n, cv.rec, cv.dead);
+  {
+    ProfScope ps(PROF_NMS_SORT, st);
+    k_make_keys<<<gb, T, 0, st>>>(scores, score_stride, seg_id, tie, tie_bits, kind == 0 ? boxes : nullptr,
+                                  kind == 0 ? drop_small : 0, (int)n, cv.keys_a, cv.vals_a);
+    size_t tmp = cv.sort_tmp_bytes;
+    if (rocprim::radix_sort_pairs(cv.sort_tmp, tmp, cv.keys_a, cv.keys_b, cv.vals_a, cv.vals_b, (size_t)n, 0,
+                                  (unsigned)(32 + tie_bits + seg_bits), st, false) != hipSuccess)
+      return OBB_ERR_LAUNCH;
+    k_seg_bounds<<<gseg, T, 0, st>>>(cv.keys_b, (int)n, (int)nseg, 32 + tie_bits, 0, cv.seg_begin, cv.seg_end, cv.cursor,
+                                     cv.keep_cnt, cv.ccount, cv.nrows, cv.nedges);
+  }
+  {
+    ProfScope ps(PROF_NMS_PREP, st);
+    if (kind == 0) k_prep_rot<<<gb, T, 0, st>>>(boxes, cv.vals_b, drop_small, (int)n, cv.rec, cv.dead);
+    else k_prep_quad<<<gb, T, 0, st>>>(boxes, stride, cv.vals_b, (int)n, cv.rec, cv.dead);
+  }
 
   NmsArgs a;
   a.rec = cv.rec; a.order = cv.vals_b; a.dead = cv.dead; a.seg_begin = cv.seg_begin; a.seg_end = cv.seg_end;
@@ -248,7 +277,10 @@ static int run_nms(int kind, const float* boxes, int stride, const float* scores
   a.cull = (thr >= 0.f) ? 1 : 0;      // rejects predict IoU <= 0 or IoU <= thr; with thr < 0 even IoU == 0 suppresses
 
   if (max_seg <= 0 || max_seg > n) max_seg = n;
-  nms_steps(kind, a, nseg, max_seg, st);
+  {
+    ProfScope ps(PROF_NMS_STEPS, st);
+    nms_steps(kind, a, nseg, max_seg, st);
+  }
   k_finalize<<<gseg, T, 0, st>>>(cv.keep_cnt, cv.seg_begin, (int)nseg, max_keep, num_keep, seg_begin_out);
   return hipGetLastError() == hipSuccess ? OBB_OK : OBB_ERR_LAUNCH;
 }
@@ -344,6 +376,25 @@ int obb_non_max_suppression_obb(const void* pred, int dtype, int64_t bs, int64_t
                                 void* stream) {
   return run_nms_obb(pred, dtype, bs, A, no, conf_thres, iou_thres, classes_host, n_classes, agnostic, multi_label, max_det,
                      max_nms, max_wh, extra8, n_extra, cap_img, out, out_count, status, ws, ws_bytes, (hipStream_t)stream);
+}
+
+int obb_profile_enable(int on) {
+  g_prof.on = on != 0;
+  g_prof.used = 0;
+  return OBB_OK;
+}
+
+int obb_profile_collect(double* ms_sum, int64_t* count, int n_stages) {
+  for (int i = 0; i < n_stages; i++) { ms_sum[i] = 0.0; count[i] = 0; }
+  for (int k = 0; k < g_prof.used; k++) {
+    float ms = 0.f;
+    if (hipEventSynchronize(g_prof.ev1[k]) != hipSuccess) return OBB_ERR_INTERNAL;
+    if (hipEventElapsedTime(&ms, g_prof.ev0[k], g_prof.ev1[k]) != hipSuccess) return OBB_ERR_INTERNAL;
+    const int id = g_prof.id[k];
+    if (id < n_stages) { ms_sum[id] += ms; count[id]++; }
+  }
+  g_prof.used = 0;
+  return OBB_OK;
 }
 
 const char* obb_version(void) { return "obb_hip 0.1 (gfx950)"; }

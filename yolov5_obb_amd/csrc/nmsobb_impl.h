@@ -277,22 +277,31 @@ static int run_nms_obb(const void* pred, int dtype, int64_t bs, int64_t A, int64
   hipMemsetAsync(cv.cnt, 0, bs * 4, st);
   hipMemsetAsync(status, 0, 8, st);
   dim3 gd((unsigned)((A + 255) / 256), (unsigned)bs);
-  if (dtype == 0) k_decode<float><<<gd, 256, 0, st>>>(d);
-  else k_decode<__half><<<gd, 256, 0, st>>>(d);
+  {
+    ProfScope ps(PROF_DECODE, st);
+    if (dtype == 0) k_decode<float><<<gd, 256, 0, st>>>(d);
+    else k_decode<__half><<<gd, 256, 0, st>>>(d);
+  }
   if (n_extra > 0 && extra8) k_append_extra<<<(unsigned)((n_extra + 255) / 256), 256, 0, st>>>(extra8, (int)n_extra, A, nc, d);
   const unsigned gs = (unsigned)((bs + 255) / 256);
   Carve& nv = cv.nms;
   k_cand_segments<<<gs, 256, 0, st>>>(cv.cnt, (int)bs, cap_img, max_nms, cv.sort_begin, cv.sort_end, nv.seg_begin, nv.seg_end,
                                       nv.cursor, nv.keep_cnt, nv.ccount, nv.nrows, nv.nedges);
-  size_t tmp = cv.sort_tmp_bytes;
-  if (rocprim::segmented_radix_sort_pairs(cv.sort_tmp, tmp, cv.keys_a, cv.keys_b, cv.vals_a, cv.vals_b,
-                                          (unsigned int)(bs * cap_img), (unsigned int)bs, cv.sort_begin, cv.sort_end, 0, 64, st,
-                                          false) != hipSuccess)
-    return OBB_ERR_LAUNCH;
+  {
+    ProfScope ps(PROF_SEGSORT, st);
+    size_t tmp = cv.sort_tmp_bytes;
+    if (rocprim::segmented_radix_sort_pairs(cv.sort_tmp, tmp, cv.keys_a, cv.keys_b, cv.vals_a, cv.vals_b,
+                                            (unsigned int)(bs * cap_img), (unsigned int)bs, cv.sort_begin, cv.sort_end, 0, 64,
+                                            st, false) != hipSuccess)
+      return OBB_ERR_LAUNCH;
+  }
   const int64_t max_seg = (max_nms > 0 && max_nms < cap_img) ? max_nms : cap_img;
   dim3 gp((unsigned)((max_seg + 255) / 256), (unsigned)bs);
-  k_prep_cand<<<gp, 256, 0, st>>>(cv.cand, cv.vals_b, nv.seg_begin, nv.seg_end, cap_img, agnostic ? 0.f : max_wh, nv.rec, nv.dead,
-                                  nv.vals_b);
+  {
+    ProfScope ps(PROF_PREP, st);
+    k_prep_cand<<<gp, 256, 0, st>>>(cv.cand, cv.vals_b, nv.seg_begin, nv.seg_end, cap_img, agnostic ? 0.f : max_wh, nv.rec,
+                                    nv.dead, nv.vals_b);
+  }
 
   NmsArgs a;
   a.rec = nv.rec; a.order = nv.vals_b; a.dead = nv.dead; a.seg_begin = nv.seg_begin; a.seg_end = nv.seg_end;
@@ -300,10 +309,15 @@ static int run_nms_obb(const void* pred, int dtype, int64_t bs, int64_t A, int64
   a.rows = nv.rows; a.nrows = nv.nrows; a.edges = nv.edges; a.nedges = nv.nedges;
   a.ecap = nv.ecap; a.n = (int)(bs * cap_img); a.capmax = cap_max(bs);
   a.max_keep = (int)max_det; a.thr = iou_thres; a.cull = (iou_thres >= 0.f) ? 1 : 0;
-  nms_steps(0, a, bs, max_seg, st);
-
+  {
+    ProfScope ps(PROF_STEPS, st);
+    nms_steps(0, a, bs, max_seg, st);
+  }
   dim3 go((unsigned)((max_det + 255) / 256), (unsigned)bs);
-  k_gather_out<<<go, 256, 0, st>>>(cv.cand, cv.keep, nv.seg_begin, nv.keep_cnt, max_det, out, out_count, cv.cnt, cap_img, status);
+  {
+    ProfScope ps(PROF_GATHER, st);
+    k_gather_out<<<go, 256, 0, st>>>(cv.cand, cv.keep, nv.seg_begin, nv.keep_cnt, max_det, out, out_count, cv.cnt, cap_img, status);
+  }
   return hipGetLastError() == hipSuccess ? OBB_OK : OBB_ERR_LAUNCH;
 }
 
