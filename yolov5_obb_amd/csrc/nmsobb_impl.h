@@ -54,95 +54,187 @@ struct DecodeArgs {
   float4* cand;              // [bs*cap_img][2]: {x,y,l,s} {theta,conf,cls,0}
   unsigned long long* keys;  // [bs*cap_img]
   uint32_t* vals;            // [bs*cap_img] slot index inside the image region
-  int* cnt;                  // [bs] candidates produced (may exceed cap_img: overflow)
+  int* cnt;                  // [bs * kCntPad] candidates produced (may exceed cap_img: overflow), one 256-B line each
 };
 
 __device__ __forceinline__ bool class_allowed(const ClassMask& cm, int c) {
-  return cm.all || ((cm.w[(c >> 6) & 3] >> (c & 63)) & 1ull);
+  const int q = (c >> 6) & 3;   // select chain instead of a dynamic index: the mask lives in kernel-argument SGPRs
+  const unsigned long long w = q == 0 ? cm.w[0] : q == 1 ? cm.w[1] : q == 2 ? cm.w[2] : cm.w[3];
+  return cm.all || ((w >> (c & 63)) & 1ull);
 }
 
+// Candidate counters are padded to one 256-byte line each: same-word device atomics retire at ~11 ns apiece
+// (MI355X_MICROARCH.md "fanin"/"dequeue"), and 16 counters packed in one line would share one L2 channel.
+constexpr int kCntPad = 64;   // ints
+
+constexpr int kDecRowsPerWave = 128;   // 2 strided objectness loads in flight per lane
+constexpr int kDecStage = 128;         // staged candidates per wave (LDS) before a flush
+
+// Per-row registers of one lane: everything the row needs is requested up front (one memory latency per row,
+// and the next row's loads are issued before the current row is reduced).
+template <typename T>
+struct DecRow {
+  float cls[4];      // class scores c = q*64 + lane (raw, not yet multiplied by obj)
+  float csl[3];      // angle bins lane, 64+lane, 128+lane
+  float box;         // lanes 0..3: x y l s
+};
+
+template <typename T>
+__device__ __forceinline__ DecRow<T> dec_load_row(const T* base, int nc, int lane) {
+  DecRow<T> r;
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    const int c = q * 64 + lane;
+    r.cls[q] = (c < nc) ? ld_as_float<T>(base + 5 + c) : 0.f;
+  }
+  const T* csl = base + 5 + nc;
+  r.csl[0] = ld_as_float<T>(csl + lane);
+  r.csl[1] = ld_as_float<T>(csl + 64 + lane);
+  r.csl[2] = (lane < 180 - 128) ? ld_as_float<T>(csl + 128 + lane) : -__builtin_inff();
+  r.box = (lane < 4) ? ld_as_float<T>(base + lane) : 0.f;
+  return r;
+}
+
+// k_decode: workgroup = 4 waves x 128 rows.  Phase 1 reads only the objectness column (one 2-4 byte element of
+// each 400-800 byte row; every lane keeps 2 strided loads in flight) and ballots `obj > conf`.  Phase 2 walks the
+// passing rows: the whole wave loads the row (classes, 180 angle bins, box) with the next row prefetched, reduces
+// it, and stages its candidates in LDS.  Slots in the image's candidate region are claimed with ONE atomic per
+// workgroup (plus one per wave whenever its 128-entry stage fills up) and the staged records are written out
+// coalesced.
 template <typename T>
 __global__ __launch_bounds__(256) void k_decode(DecodeArgs a) {
+  __shared__ float4 s_c0[4][kDecStage], s_c1[4][kDecStage];
+  __shared__ unsigned long long s_key[4][kDecStage];
+  __shared__ int s_cnt[4], s_base;
+
   const T* pred = (const T*)a.pred;
-  const int lane = threadIdx.x & 63;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int b = blockIdx.y;
-  const long long r0 = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 64;
-  if (r0 >= a.A) return;
+  const long long r0 = ((long long)blockIdx.x * 4 + wv) * kDecRowsPerWave;
   const float thr = thr_in_dtype<T>(a.conf_thres);
   const T* img = pred + (size_t)b * a.A * a.no;
-  const long long row = r0 + lane;
-  const float obj = (row < a.A) ? ld_as_float<T>(img + (size_t)row * a.no + 4) : 0.f;
-  unsigned long long m = __ballot(row < a.A && obj > thr);          // :785  xc = prediction[..., 4] > conf_thres
   float4* cand = a.cand + (size_t)b * a.cap_img * 2;
   unsigned long long* keys = a.keys + (size_t)b * a.cap_img;
   uint32_t* vals = a.vals + (size_t)b * a.cap_img;
+  float4* c0s = s_c0[wv]; float4* c1s = s_c1[wv]; unsigned long long* kys = s_key[wv];
+  int staged = 0;   // wave-uniform
 
-  while (m) {
-    const int rr = __builtin_ctzll(m);
-    m &= m - 1;
-    const long long rw = r0 + rr;
-    const T* base = img + (size_t)rw * a.no;
-    const float o = __shfl(obj, rr);
+  auto write_out = [&](long long base, int count) {
+    for (int i = lane; i < count; i += 64) {
+      const long long slot = base + i;
+      if (slot < a.cap_img) {
+        cand[slot * 2] = c0s[i];
+        cand[slot * 2 + 1] = c1s[i];
+        keys[slot] = kys[i];
+        vals[slot] = (uint32_t)slot;
+      }
+    }
+  };
+  auto flush_wave = [&]() {   // mid-kernel flush of a full stage: one atomic for the wave
+    int base = 0;
+    if (lane == 0) base = atomicAdd(&a.cnt[b * kCntPad], staged);
+    base = __shfl(base, 0);
+    write_out(base, staged);
+    staged = 0;
+  };
 
-    // ---- class confidences, in chunks of 64 classes
+  // ---- phase 1: objectness column                                     :785  xc = prediction[..., 4] > conf_thres
+  static_assert(kDecRowsPerWave == 128, "two 64-row groups per wave are written out explicitly below");
+  const long long row0 = r0 + lane, row1 = r0 + 64 + lane;
+  const float obj0 = (row0 < a.A) ? ld_as_float<T>(img + (size_t)row0 * a.no + 4) : 0.f;
+  const float obj1 = (row1 < a.A) ? ld_as_float<T>(img + (size_t)row1 * a.no + 4) : 0.f;
+  unsigned long long m0 = __ballot(row0 < a.A && obj0 > thr);
+  unsigned long long m1 = __ballot(row1 < a.A && obj1 > thr);
+
+  // ---- phase 2: passing rows, software-pipelined
+  auto pop = [&](int& k_out, int& rr_out) -> bool {
+    if (m0) { rr_out = __builtin_ctzll(m0); m0 &= m0 - 1; k_out = 0; return true; }
+    if (m1) { rr_out = __builtin_ctzll(m1); m1 &= m1 - 1; k_out = 1; return true; }
+    return false;
+  };
+  int ck = 0, crr = 0;
+  bool have = pop(ck, crr);
+  DecRow<T> cur;
+  if (have) cur = dec_load_row<T>(img + (size_t)(r0 + ck * 64 + crr) * a.no, a.nc, lane);
+  while (have) {
+    int nk = 0, nrr = 0;
+    const bool have_next = pop(nk, nrr);
+    DecRow<T> nxt;
+    if (have_next) nxt = dec_load_row<T>(img + (size_t)(r0 + nk * 64 + nrr) * a.no, a.nc, lane);
+
+    const long long rw = r0 + ck * 64 + crr;
+    const float o = __shfl(ck == 0 ? obj0 : obj1, crr);
+
+    // class confidences (:820 conf = obj * cls in the input dtype)
     float bestv = -__builtin_inff(); int besti = 0x7fffffff;
     unsigned long long pass_bits[4] = {0ull, 0ull, 0ull, 0ull};
-    int npass = 0;
     float myconf[4];
-    for (int c0 = 0, q = 0; c0 < a.nc; c0 += 64, q++) {
-      const int c = c0 + lane;
-      const float v = (c < a.nc) ? mul_in_dtype<T>(ld_as_float<T>(base + 5 + c), o) : -__builtin_inff();   // :820
-      myconf[q & 3] = v;
+    int npass = 0;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int c = q * 64 + lane;
+      const float v = (c < a.nc) ? mul_in_dtype<T>(cur.cls[q], o) : -__builtin_inff();
+      myconf[q] = v;
       if (a.multi_label) {
-        const bool p = (c < a.nc) && (v > thr) && class_allowed(a.cm, c);                                 // :827, :835
-        const unsigned long long pb = __ballot(p);
-        pass_bits[q & 3] = pb;
-        npass += __popcll(pb);
+        const bool p = (c < a.nc) && (v > thr) && (a.cm.all || ((a.cm.w[q] >> lane) & 1ull));               // :827, :835
+        pass_bits[q] = __ballot(p);
+        npass += __popcll(pass_bits[q]);
       } else if (c < a.nc && (v > bestv)) { bestv = v; besti = c; }   // lanes see ascending c: first max kept
     }
     if (!a.multi_label) {
       wave_argmax_first(bestv, besti);                                                                    // :830
       npass = (bestv > thr && class_allowed(a.cm, besti)) ? 1 : 0;                                        // :831, :835
     }
-    if (npass == 0) continue;
-
-    // ---- CSL decode: first arg-max over the 180 bins (:822-823)
-    const T* csl = base + 5 + a.nc;
-    float tv = ld_as_float<T>(csl + lane); int ti = lane;
-    { float v1 = ld_as_float<T>(csl + 64 + lane); if (v1 > tv) { tv = v1; ti = 64 + lane; } }
-    if (lane < 180 - 128) { float v2 = ld_as_float<T>(csl + 128 + lane); if (v2 > tv) { tv = v2; ti = 128 + lane; } }
-    wave_argmax_first(tv, ti);
-    const float theta = ((float)(ti - 90) / 180.0f) * 3.141592f;
-    const float bx = ld_as_float<T>(base + 0), by = ld_as_float<T>(base + 1), bl = ld_as_float<T>(base + 2), bs_ = ld_as_float<T>(base + 3);
-
-    // ---- append
-    int slot0 = 0;
-    if (lane == 0) slot0 = atomicAdd(&a.cnt[b], npass);
-    slot0 = __shfl(slot0, 0);
-    if (a.multi_label) {
-      int before = 0;
-      for (int c0 = 0, q = 0; c0 < a.nc; c0 += 64, q++) {
-        const unsigned long long pb = pass_bits[q & 3];
-        if ((pb >> lane) & 1ull) {
-          const long long slot = (long long)slot0 + before + __popcll(pb & lanemask_lt());
-          if (slot < a.cap_img) {
+    if (npass) {
+      // CSL decode: first arg-max over the 180 bins (:822-823)
+      float tv = cur.csl[0]; int ti = lane;
+      if (cur.csl[1] > tv) { tv = cur.csl[1]; ti = 64 + lane; }
+      if (cur.csl[2] > tv) { tv = cur.csl[2]; ti = 128 + lane; }
+      wave_argmax_first(tv, ti);
+      const float theta = ((float)(ti - 90) / 180.0f) * 3.141592f;
+      const float bx = __shfl(cur.box, 0), by = __shfl(cur.box, 1), bl = __shfl(cur.box, 2), bs_ = __shfl(cur.box, 3);
+      if (a.multi_label) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const int c0 = q * 64;
+          const unsigned long long pb = pass_bits[q];
+          const int np = __popcll(pb);
+          if (np == 0) continue;
+          if (staged + np > kDecStage) flush_wave();
+          if ((pb >> lane) & 1ull) {
+            const int i = staged + __popcll(pb & lanemask_lt());
             const int c = c0 + lane;
-            const float conf = myconf[q & 3];
-            cand[slot * 2] = make_float4(bx, by, bl, bs_);
-            cand[slot * 2 + 1] = make_float4(theta, conf, (float)c, 0.f);
-            keys[slot] = ((unsigned long long)score_desc_key(conf) << 32) | (unsigned long long)(uint32_t)(rw * a.nc + c);
-            vals[slot] = (uint32_t)slot;
+            const float conf = myconf[q];
+            c0s[i] = make_float4(bx, by, bl, bs_);
+            c1s[i] = make_float4(theta, conf, (float)c, 0.f);
+            kys[i] = ((unsigned long long)score_desc_key(conf) << 32) | (unsigned long long)(uint32_t)(rw * a.nc + c);
           }
+          staged += np;
         }
-        before += __popcll(pb);
+      } else {
+        if (staged + 1 > kDecStage) flush_wave();
+        if (lane == 0) {
+          c0s[staged] = make_float4(bx, by, bl, bs_);
+          c1s[staged] = make_float4(theta, bestv, (float)besti, 0.f);
+          kys[staged] = ((unsigned long long)score_desc_key(bestv) << 32) | (unsigned long long)(uint32_t)(rw * a.nc + besti);
+        }
+        staged += 1;
       }
-    } else if (lane == 0 && slot0 < a.cap_img) {
-      cand[(size_t)slot0 * 2] = make_float4(bx, by, bl, bs_);
-      cand[(size_t)slot0 * 2 + 1] = make_float4(theta, bestv, (float)besti, 0.f);
-      keys[slot0] = ((unsigned long long)score_desc_key(bestv) << 32) | (unsigned long long)(uint32_t)(rw * a.nc + besti);
-      vals[slot0] = (uint32_t)slot0;
     }
+    have = have_next; ck = nk; crr = nrr; cur = nxt;
   }
+
+  // ---- one atomic per workgroup for whatever is still staged
+  if (lane == 0) s_cnt[wv] = staged;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int tot = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+    s_base = tot ? atomicAdd(&a.cnt[b * kCntPad], tot) : 0;
+  }
+  __syncthreads();
+  int base = s_base;
+  for (int w = 0; w < wv; w++) base += s_cnt[w];
+  write_out(base, staged);
 }
 
 // apriori label rows (utils/general.py:807-813), prepared by the host layer as [img, x, y, l, s, theta, conf, cls]
@@ -152,7 +244,7 @@ __global__ void k_append_extra(const float* __restrict__ extra8, int m, long lon
   const float* e = extra8 + (size_t)i * 8;
   const int b = (int)e[0];
   if (b < 0 || b >= a.bs) return;
-  const int slot = atomicAdd(&a.cnt[b], 1);
+  const int slot = atomicAdd(&a.cnt[b * kCntPad], 1);
   if (slot >= a.cap_img) return;
   const size_t g = (size_t)b * a.cap_img + slot;
   a.cand[g * 2] = make_float4(e[1], e[2], e[3], e[4]);
@@ -166,7 +258,7 @@ __global__ void k_cand_segments(const int* __restrict__ cnt, int bs, long long c
                                 int* nedges) {
   int g = blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= bs) return;
-  long long c = cnt[g];
+  long long c = cnt[g * kCntPad];
   if (c > cap_img) c = cap_img;
   const int b0 = (int)(g * cap_img);
   sort_begin[g] = b0; sort_end[g] = b0 + (int)c;
@@ -204,7 +296,7 @@ __global__ void k_gather_out(const float4* __restrict__ cand, const int64_t* __r
   const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (k == 0) {
     out_count[g] = nk;
-    if (cnt[g] > cap_img) atomicMax((unsigned long long*)status, (unsigned long long)cnt[g]);   // overflow: caller retries
+    if (cnt[g * kCntPad] > cap_img) atomicMax((unsigned long long*)status, (unsigned long long)cnt[g * kCntPad]);   // overflow: caller retries
   }
   if (k >= nk) return;
   const size_t ci = (size_t)keep[(size_t)seg_begin[g] + k];
@@ -236,7 +328,7 @@ static int obb_carve(void* base, int64_t bs, int64_t cap_img, ObbCarve* cv) {
   cv->cand = (float4*)take(n * 32);
   cv->keys_a = (unsigned long long*)take(n * 8); cv->keys_b = (unsigned long long*)take(n * 8);
   cv->vals_a = (uint32_t*)take(n * 4); cv->vals_b = (uint32_t*)take(n * 4);
-  cv->cnt = (int*)take(bs * 4); cv->sort_begin = (int*)take(bs * 4); cv->sort_end = (int*)take(bs * 4);
+  cv->cnt = (int*)take(bs * 4 * kCntPad); cv->sort_begin = (int*)take(bs * 4); cv->sort_end = (int*)take(bs * 4);
   if (seg_sort_tmp_query(n, (int)bs, &cv->sort_tmp_bytes) != hipSuccess) return OBB_ERR_INTERNAL;
   cv->sort_tmp = take(cv->sort_tmp_bytes ? cv->sort_tmp_bytes : 16);
   cv->keep = (int64_t*)take(n * 8);
@@ -274,9 +366,9 @@ static int run_nms_obb(const void* pred, int dtype, int64_t bs, int64_t A, int64
   }
   d.cap_img = cap_img; d.cand = cv.cand; d.keys = cv.keys_a; d.vals = cv.vals_a; d.cnt = cv.cnt;
 
-  hipMemsetAsync(cv.cnt, 0, bs * 4, st);
+  hipMemsetAsync(cv.cnt, 0, bs * 4 * kCntPad, st);
   hipMemsetAsync(status, 0, 8, st);
-  dim3 gd((unsigned)((A + 255) / 256), (unsigned)bs);
+  dim3 gd((unsigned)((A + 4 * kDecRowsPerWave - 1) / (4 * kDecRowsPerWave)), (unsigned)bs);
   {
     ProfScope ps(PROF_DECODE, st);
     if (dtype == 0) k_decode<float><<<gd, 256, 0, st>>>(d);
