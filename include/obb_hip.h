@@ -120,6 +120,57 @@ int obb_non_max_suppression_obb(const void* pred, int dtype, int64_t bs, int64_t
                                 int64_t cap_img, float* out, int64_t* out_count, int64_t* status, void* ws, size_t ws_bytes,
                                 void* stream);
 
+/* ------------------------------------------------------------------ training loss -------------------- */
+
+/*
+ * ComputeLoss of the OBB head (utils/loss.py:90-275): build_targets + box (horizontal CIoU) / objectness / class /
+ * CSL-angle losses, forward and backward, for raw head outputs p[i] of shape (bs, na, ny_i, nx_i, no) and the
+ * dataloader's target tensor (nt, 7+180) rows [img, cls, cx, cy, l, s, theta, csl x 180] in pixels
+ * (utils/datasets.py:637-672).  Everything ComputeLoss.__init__ reads from the model (utils/loss.py:93-120) travels
+ * in obb_loss_config (host memory, plain C).
+ */
+#define OBB_LOSS_MAX_LEVELS 8
+#define OBB_LOSS_MAX_ANCHORS 8
+typedef struct obb_loss_config {
+  int32_t nl, na, nc, no, bs;          /* Detect.nl / na / nc / no (= 5 + nc + 180), batch size            */
+  int32_t ny[OBB_LOSS_MAX_LEVELS], nx[OBB_LOSS_MAX_LEVELS];     /* p[i].shape[2], p[i].shape[3]             */
+  float anchors[OBB_LOSS_MAX_LEVELS][OBB_LOSS_MAX_ANCHORS][2];   /* Detect.anchors (grid units), (l, s)      */
+  float stride[OBB_LOSS_MAX_LEVELS];                             /* Detect.stride                            */
+  float balance[OBB_LOSS_MAX_LEVELS];                            /* utils/loss.py:114                        */
+  float anchor_t;                      /* hyp['anchor_t']                                                   */
+  float cp, cn;                        /* smooth_BCE(label_smoothing), utils/loss.py:104                    */
+  float cls_pw, theta_pw, obj_pw;      /* BCE pos_weights, utils/loss.py:98-100                             */
+  float gain_box, gain_obj, gain_cls, gain_theta;   /* hyp['box'|'obj'|'cls'|'theta'], utils/loss.py:185-188 */
+  float gr;                            /* iou ratio, utils/loss.py:116                                      */
+  int32_t sort_obj_iou;                /* utils/loss.py:93,156-158                                          */
+} obb_loss_config;
+
+size_t obb_loss_workspace_bytes(const obb_loss_config* cfg, int64_t nt);
+
+/* ComputeLoss.build_targets (utils/loss.py:194-275) into the workspace; counts_out[0..nl) (device, int32) receives
+ * the number of matched rows per level and counts_out[OBB_LOSS_MAX_LEVELS] a non-zero flag when a target row names
+ * an image or class outside the batch (the reference raises IndexError there).  No host synchronisation. */
+int obb_loss_build_targets(const obb_loss_config* cfg, const float* targets, int64_t nt, int64_t tcols, int32_t* counts_out,
+                           void* ws, size_t ws_bytes, void* stream);
+/* Rows of one level in the reference's order (offset-major, anchor-major, target order), after the caller has read
+ * the count n: indices4 [n][4] int64 (b, a, gj, gi); tbox4 [n][4]; anch2 [n][2]; tcls [n] int64; csl180 [n][180]. */
+int obb_loss_export_targets(const obb_loss_config* cfg, int64_t nt, int level, int64_t n, int64_t* indices4, float* tbox4,
+                            float* anch2, int64_t* tcls, float* csl180, void* ws, size_t ws_bytes, void* stream);
+
+/* ComputeLoss.__call__ forward (utils/loss.py:122-192).  p_levels_host: HOST array of nl device pointers;
+ * dtype 0 = fp32, 1 = fp16 (arithmetic is fp32 either way).  loss_out (device, 5 + nl floats):
+ * [0] (lbox+lobj+lcls+ltheta)*bs, [1..4] lbox, lobj, lcls, ltheta (gains applied), [5+i] the un-balanced objectness
+ * BCE of level i (what autobalance reads, :180-181).  [0] is NaN when a target row is out of range.
+ * The workspace keeps the matched rows for obb_loss_backward: pass the same buffer, untouched. */
+int obb_loss_forward(const obb_loss_config* cfg, const void* const* p_levels_host, int dtype, const float* targets, int64_t nt,
+                     int64_t tcols, float* loss_out, void* ws, size_t ws_bytes, void* stream);
+/* Gradient of loss_out[0] with respect to every p[i], times *grad_scale (device scalar: the incoming dL/dloss, e.g.
+ * the GradScaler factor).  grad_levels_host: HOST array of nl device pointers, same shapes / dtype as p; every
+ * element is written exactly once (no prior zero-fill needed). */
+int obb_loss_backward(const obb_loss_config* cfg, const void* const* p_levels_host, int dtype, const float* targets, int64_t nt,
+                      int64_t tcols, const float* grad_scale, void* const* grad_levels_host, void* ws, size_t ws_bytes,
+                      void* stream);
+
 /* ------------------------------------------------------------------ pairwise IoU --------------------- */
 
 /* out[i] = IoU(a5[i], b5[i]); the device function behind the NMS

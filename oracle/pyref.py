@@ -220,8 +220,8 @@ def build_targets(spec, p, targets):
     return out
 
 
-def compute_loss(spec, p, targets):
-    """utils/loss.py:122-192 (fl_gamma == 0, autobalance off).  p[i]: (bs, na, ny, nx, no) logits (requires_grad ok)."""
+def compute_loss(spec, p, targets, sort_obj_iou=False):
+    """utils/loss.py:122-192 (fl_gamma == 0, autobalance off; sort_obj_iou :156-158 with a stable sort).  p[i]: (bs, na, ny, nx, no) logits (requires_grad ok)."""
     h = spec.hyp
     bce = torch.nn.functional.binary_cross_entropy_with_logits
     pw_cls, pw_th, pw_obj = (torch.tensor([h[k]], dtype=torch.float32) for k in ('cls_pw', 'theta_pw', 'obj_pw'))
@@ -238,7 +238,19 @@ def compute_loss(spec, p, targets):
             pwh = (ps[:, 2:4].sigmoid() * 2) ** 2 * t['anch']
             iou = bbox_ciou(torch.cat((pxy, pwh), 1).T, t['tbox'])
             lbox = lbox + (1.0 - iou).mean()
-            tobj[t['b'], t['a'], t['gj'], t['gi']] = (1.0 - spec.gr) + spec.gr * iou.detach().clamp(0).type(tobj.dtype)
+            score = iou.detach().clamp(0).type(tobj.dtype)
+            ib, ia, igj, igi = t['b'], t['a'], t['gj'], t['gi']
+            if sort_obj_iou:                                                            # :156-158
+                sid = torch.argsort(score, stable=True)
+                ib, ia, igj, igi, score = ib[sid], ia[sid], igj[sid], igi[sid], score[sid]
+            # :159  tobj[b, a, gj, gi] = ...  Duplicate cells: torch's index_put_ is sequential (last writer wins) only
+            # for small inputs; it runs multi-threaded (CPU) / unordered (CUDA) for large ones.  Pinned rule: the LAST
+            # row in row order wins, made explicit here so that the oracle does not depend on torch's threading.
+            lin = ((ib * pi.shape[1] + ia) * pi.shape[2] + igj) * pi.shape[3] + igi
+            last = torch.full((tobj.numel(),), -1, dtype=torch.long)
+            last.scatter_reduce_(0, lin, torch.arange(n), reduce='amax', include_self=True)
+            win = last[lin] == torch.arange(n)
+            tobj.view(-1)[lin[win]] = ((1.0 - spec.gr) + spec.gr * score)[win]
             if spec.nc > 1:
                 tc = torch.full_like(ps[:, 5:ci], spec.cn)
                 tc[torch.arange(n), t['tcls']] = spec.cp

@@ -159,3 +159,27 @@ def canon_rows(rows):
         return r
     key = np.lexsort((r[:, 6], r[:, 4], r[:, 3], r[:, 2], r[:, 1], r[:, 0], -r[:, 5]))
     return r[key]
+
+
+class FakeDetect(torch.nn.Module):
+    """The attributes ComputeLoss reads from Detect (models/yolo.py:33-47)."""
+
+    def __init__(self, nc, anchors, strides):
+        super().__init__()
+        self.nc, self.nl, self.na = nc, anchors.shape[0], anchors.shape[1]
+        self.no = nc + 5 + 180
+        self.register_buffer('anchors', anchors.clone().float())
+        self.stride = strides.clone().float()
+
+
+class FakeModel(torch.nn.Module):
+    """What ComputeLoss.__init__ needs from the model (utils/loss.py:93-120): parameters(), .hyp, .model[-1]."""
+
+    def __init__(self, nc, hyp, device, anchors=None, strides=None):
+        super().__init__()
+        anchors = grid_anchors() if anchors is None else anchors
+        strides = torch.tensor(DEFAULT_STRIDES) if strides is None else strides
+        self.model = torch.nn.ModuleList([torch.nn.Identity(), FakeDetect(nc, anchors, strides)])
+        self.w = torch.nn.Parameter(torch.zeros(1))
+        self.hyp = dict(hyp)
+        self.to(device)

@@ -16,14 +16,12 @@
 //
 // The only host<->device traffic is the caller reading the bs counts (+ the overflow word) afterwards.
 #pragma once
+#include "dtype_device.h"
 
 namespace obb {
 
 struct ClassMask { unsigned long long w[4]; int all; };   // allowed classes (nc <= 256), all != 0: no filter
 
-template <typename T> __device__ __forceinline__ float ld_as_float(const T* p);
-template <> __device__ __forceinline__ float ld_as_float<float>(const float* p) { return *p; }
-template <> __device__ __forceinline__ float ld_as_float<__half>(const __half* p) { return __half2float(*p); }
 // product rounded to the tensor dtype: x[:, 5:ci] *= x[:, 4:5] happens in the input dtype (utils/general.py:820)
 template <typename T> __device__ __forceinline__ float mul_in_dtype(float a, float b);
 template <> __device__ __forceinline__ float mul_in_dtype<float>(float a, float b) { return a * b; }
