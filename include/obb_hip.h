@@ -171,6 +171,28 @@ int obb_loss_backward(const obb_loss_config* cfg, const void* const* p_levels_ho
                       int64_t tcols, const float* grad_scale, void* const* grad_levels_host, void* ws, size_t ws_bytes,
                       void* stream);
 
+/* ------------------------------------------------------------------ Detect head / CSL / box utils ----- */
+
+/*
+ * Detect.forward, inference branch, for ONE level (models/yolo.py:61-79): conv_out is the 1x1-conv output
+ * (bs, na*no, ny, nx), contiguous, dtype 0 = fp32 / 1 = fp16.  Writes (either pointer may be NULL)
+ *   x_perm_out  (bs, na, ny, nx, no)  the raw head, what `x[i].view(bs,na,no,ny,nx).permute(0,1,3,4,2).contiguous()` returns (:65)
+ *   z_out       rows [a_offset, a_offset + na*ny*nx) of every image of the concatenated prediction tensor
+ *               (bs, a_total, no): sigmoid, xy = (y*2-0.5+grid)*stride, wh = (y*2)^2*anchor_grid (:71-79),
+ *               arithmetic and rounding steps in the tensor dtype exactly as the reference's in-place branch.
+ *   anchors_px_host  HOST array [na][2] = Detect.anchors[i] * stride[i] (anchor_grid, :90-91)
+ */
+int obb_detect_decode(const void* conv_out, int dtype, int64_t bs, int64_t na, int64_t no, int64_t ny, int64_t nx,
+                      const float* anchors_px_host, float stride, void* x_perm_out, void* z_out, int64_t a_total,
+                      int64_t a_offset, void* stream);
+
+/* gaussian_label_cpu (utils/rboxs_utils.py:9-26) for n angles at once: out [n][num_class] fp32, evaluated in double. */
+int obb_csl_encode_f32(const float* labels, int64_t n, int num_class, double u, double sig, float* out, void* stream);
+
+/* rbox2poly (utils/rboxs_utils.py:106-145) and poly2hbb of the result (:147-181): rows [cx cy l s theta ...] with
+ * row_stride >= 5 floats -> poly8 [n][8] and/or hbb4 [n][4] = [xc yc w h] (either may be NULL). */
+int obb_rbox2poly_f32(const float* rboxes, int64_t n, int64_t row_stride, float* poly8, float* hbb4, void* stream);
+
 /* ------------------------------------------------------------------ pairwise IoU --------------------- */
 
 /* out[i] = IoU(a5[i], b5[i]); the device function behind the NMS

@@ -1,0 +1,194 @@
+// Detect-head inference decode, CSL label encode and the small box conversions -- gfx950 kernels + C ABI.
+//
+//   obb_detect_decode   models/yolo.py:61-79 (Detect.forward, inference branch) for one level in ONE pass over the
+//                       1x1-conv output: the reference runs view+permute+contiguous (1 read + 1 write of the level),
+//                       sigmoid (1+1), two in-place slice updates and a torch.cat (1+1).  Here a workgroup moves a
+//                       64-position x no-channel tile through LDS (coalesced 128-256 byte reads along the spatial
+//                       axis, one contiguous 64*no-element write per output) and emits both results of the
+//                       reference: the permuted raw head x[i] (bs,na,ny,nx,no) and the decoded rows, written straight
+//                       into their slice of the concatenated (bs, sum A_i, no) prediction tensor.
+//   obb_csl_encode      utils/rboxs_utils.py:9-26 gaussian_label_cpu for a batch of angles on the device.
+//   obb_rbox2poly       utils/rboxs_utils.py:106-145 (+ poly2hbb :147-181) for (n,5) long-edge boxes.
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+#include "obb_hip.h"
+#include "dtype_device.h"
+#include "loss_math.h"
+
+namespace obb {
+
+struct DetectArgs {
+  const void* in;      // (bs, na*no, ny, nx) conv output
+  void* xperm;         // (bs, na, ny, nx, no) or null
+  void* z;             // (bs, a_total, no) or null
+  int bs, na, no, ny, nx;
+  long long a_total, a_off;
+  float stride;
+  float anchor_px[OBB_LOSS_MAX_ANCHORS][2];   // anchors * stride (anchor_grid, models/yolo.py:90-91)
+};
+
+// y = x.sigmoid() in the tensor dtype, then (models/yolo.py:71-74, inplace branch)
+//   xy = (y*2 - 0.5 + grid) * stride     y*2 and -0.5 in the tensor dtype; grid is a float32 tensor -> fp32 from there
+//   wh = (y*2)**2 * anchor_grid          (y*2)**2 in the tensor dtype; anchor_grid is float32 -> fp32 product
+// and the result is rounded to the tensor dtype by the slice assignment.
+template <typename T>
+__device__ __forceinline__ float detect_decode_one(float raw, int ch, float gx, float gy, float stride, float aw, float ah) {
+  const float y = round_to_dtype<T>(sigmoid_f(raw));
+  if (ch >= 4) return y;
+  const float t = round_to_dtype<T>(y * 2.0f);
+  if (ch < 2) {
+    const float u = round_to_dtype<T>(t - 0.5f);
+    return round_to_dtype<T>((u + (ch == 0 ? gx : gy)) * stride);
+  }
+  const float q = round_to_dtype<T>(t * t);
+  return round_to_dtype<T>(q * (ch == 2 ? aw : ah));
+}
+
+constexpr int kTileHW = 64;
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_detect_decode(DetectArgs d) {
+  extern __shared__ unsigned char smem_raw[];
+  T* tile = reinterpret_cast<T*>(smem_raw);            // [no][kTileHW + 1]
+  const int tid = threadIdx.x;
+  const int HW = d.ny * d.nx;
+  const int ba = blockIdx.y;                            // b * na + a
+  const int a = ba % d.na, b = ba / d.na;
+  const int hw0 = blockIdx.x * kTileHW;
+  const int nhw = min(kTileHW, HW - hw0);
+  const int no = d.no;
+  const T* in = (const T*)d.in + ((size_t)ba * no) * HW + hw0;
+  constexpr int LD = kTileHW + 1;
+
+  // ---- load: 4 channel rows x 64 positions per step (coalesced along hw)
+  {
+    const int hw = tid & 63, c4 = tid >> 6;
+    for (int c = c4; c < no; c += 4)
+      if (hw < nhw) tile[c * LD + hw] = in[(size_t)c * HW + hw];
+  }
+  __syncthreads();
+
+  // ---- store: the tile's nhw*no output elements are contiguous in both outputs
+  const int nel = nhw * no;
+  T* xo = d.xperm ? (T*)d.xperm + ((size_t)ba * HW + hw0) * no : nullptr;
+  T* zo = d.z ? (T*)d.z + ((size_t)b * d.a_total + d.a_off + (size_t)a * HW + hw0) * no : nullptr;
+  const float aw = d.anchor_px[a][0], ah = d.anchor_px[a][1];
+  int c = tid % no, hw = tid / no;
+  const int dc = 256 % no, dh = 256 / no;
+  for (int e = tid; e < nel; e += 256) {
+    const T raw = tile[c * LD + hw];
+    if (xo) xo[e] = raw;
+    if (zo) {
+      const int pos = hw0 + hw;
+      const float gy = (float)(pos / d.nx), gx = (float)(pos - (pos / d.nx) * d.nx);
+      const float v = detect_decode_one<T>(ld_as_float<T>(&raw), c, gx, gy, d.stride, aw, ah);
+      st_from_float<T>(zo + e, v);
+    }
+    c += dc; hw += dh;
+    if (c >= no) { c -= no; hw++; }
+  }
+}
+
+// ------------------------------------------------------------------ CSL encode (utils/rboxs_utils.py:9-26)
+// out[i][k] = y_sig[(k + index_i) mod n],  y_sig[j] = exp(-((j - n/2) - u)^2 / (2 sig^2)),  index_i = int(n/2 - label_i)
+// (python slice semantics: |index| > n leaves the window unrolled).  Evaluated in double like numpy, stored as float.
+__global__ void k_csl_encode(const float* __restrict__ labels, long long n, int num_class, double u, double sig,
+                             float* __restrict__ out) {
+  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n * num_class) return;
+  const long long i = e / num_class;
+  const int k = (int)(e - i * num_class);
+  const double half = (double)num_class / 2.0;
+  const double v = half - (double)labels[i];
+  long long index = (long long)v;                       // int() truncates toward zero
+  long long shift = 0;
+  if (index <= num_class && index >= -(long long)num_class) { shift = index % num_class; if (shift < 0) shift += num_class; }
+  const int j = (int)((k + shift) % num_class);
+  const double x = (double)j - half;
+  out[e] = (float)exp(-((x - u) * (x - u)) / (2.0 * sig * sig));
+}
+
+// ------------------------------------------------------------------ rbox2poly / poly2hbb (utils/rboxs_utils.py:106-181)
+__global__ void k_rbox2poly(const float* __restrict__ rb, long long n, int stride_in, float* __restrict__ poly8,
+                            float* __restrict__ hbb4) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float* r = rb + i * stride_in;
+  const float x = r[0], y = r[1], w = r[2], h = r[3], th = r[4];
+  const float Cos = cosf(th), Sin = sinf(th);
+  const float v1x = w / 2 * Cos, v1y = -w / 2 * Sin;      // vector1 :127
+  const float v2x = -h / 2 * Sin, v2y = -h / 2 * Cos;     // vector2 :129
+  float p[8];
+  p[0] = x + v1x + v2x; p[1] = y + v1y + v2y;             // :131-134
+  p[2] = x + v1x - v2x; p[3] = y + v1y - v2y;
+  p[4] = x - v1x - v2x; p[5] = y - v1y - v2y;
+  p[6] = x - v1x + v2x; p[7] = y - v1y + v2y;
+  if (poly8) {
+#pragma unroll
+    for (int k = 0; k < 8; k++) poly8[i * 8 + k] = p[k];
+  }
+  if (hbb4) {                                              // :166-171
+    const float xmax = fmaxf(fmaxf(p[0], p[2]), fmaxf(p[4], p[6])), xmin = fminf(fminf(p[0], p[2]), fminf(p[4], p[6]));
+    const float ymax = fmaxf(fmaxf(p[1], p[3]), fmaxf(p[5], p[7])), ymin = fminf(fminf(p[1], p[3]), fminf(p[5], p[7]));
+    hbb4[i * 4 + 0] = (xmax + xmin) / 2.0f; hbb4[i * 4 + 1] = (ymax + ymin) / 2.0f;
+    hbb4[i * 4 + 2] = xmax - xmin; hbb4[i * 4 + 3] = ymax - ymin;
+  }
+}
+
+}  // namespace obb
+
+using namespace obb;
+
+extern "C" {
+
+int obb_detect_decode(const void* conv_out, int dtype, int64_t bs, int64_t na, int64_t no, int64_t ny, int64_t nx,
+                      const float* anchors_px_host, float stride, void* x_perm_out, void* z_out, int64_t a_total,
+                      int64_t a_offset, void* stream) {
+  if (!conv_out || bs < 1 || na < 1 || na > OBB_LOSS_MAX_ANCHORS || no < 6 || no > 5 + 256 + 180 || ny < 1 || nx < 1 ||
+      (dtype != 0 && dtype != 1) || !anchors_px_host)
+    return OBB_ERR_BAD_ARG;
+  if (!x_perm_out && !z_out) return OBB_OK;
+  if (z_out && (a_offset < 0 || a_offset + na * ny * nx > a_total)) return OBB_ERR_BAD_ARG;
+  if (bs * na > 65535 || ny * nx > 0x7fffffffLL) return OBB_ERR_BAD_ARG;
+  DetectArgs d;
+  d.in = conv_out; d.xperm = x_perm_out; d.z = z_out;
+  d.bs = (int)bs; d.na = (int)na; d.no = (int)no; d.ny = (int)ny; d.nx = (int)nx;
+  d.a_total = a_total; d.a_off = a_offset; d.stride = stride;
+  for (int a = 0; a < OBB_LOSS_MAX_ANCHORS; a++) {
+    d.anchor_px[a][0] = a < na ? anchors_px_host[a * 2] : 0.f;
+    d.anchor_px[a][1] = a < na ? anchors_px_host[a * 2 + 1] : 0.f;
+  }
+  const int HW = (int)(ny * nx);
+  dim3 grid((unsigned)((HW + kTileHW - 1) / kTileHW), (unsigned)(bs * na));
+  const size_t lds = (size_t)no * (kTileHW + 1) * (dtype == 0 ? 4 : 2);
+  hipStream_t st = (hipStream_t)stream;
+  if (lds > 48 * 1024) {   // raise the dynamic-LDS limit (160 KB per CU on gfx950)
+    if (lds > 150 * 1024) return OBB_ERR_BAD_ARG;
+    hipError_t e = dtype == 0 ? hipFuncSetAttribute((const void*)k_detect_decode<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
+                              : hipFuncSetAttribute((const void*)k_detect_decode<__half>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return OBB_ERR_LAUNCH;
+  }
+  if (dtype == 0) k_detect_decode<float><<<grid, 256, lds, st>>>(d);
+  else k_detect_decode<__half><<<grid, 256, lds, st>>>(d);
+  return hipGetLastError() == hipSuccess ? OBB_OK : OBB_ERR_LAUNCH;
+}
+
+int obb_csl_encode_f32(const float* labels, int64_t n, int num_class, double u, double sig, float* out, void* stream) {
+  if (n < 0 || num_class < 1 || !(sig > 0.0)) return OBB_ERR_BAD_ARG;
+  if (n == 0) return OBB_OK;
+  if (!labels || !out) return OBB_ERR_BAD_ARG;
+  const long long tot = (long long)n * num_class;
+  k_csl_encode<<<(unsigned)((tot + 255) / 256), 256, 0, (hipStream_t)stream>>>(labels, n, num_class, u, sig, out);
+  return hipGetLastError() == hipSuccess ? OBB_OK : OBB_ERR_LAUNCH;
+}
+
+int obb_rbox2poly_f32(const float* rboxes, int64_t n, int64_t row_stride, float* poly8, float* hbb4, void* stream) {
+  if (n < 0 || row_stride < 5) return OBB_ERR_BAD_ARG;
+  if (n == 0) return OBB_OK;
+  if (!rboxes || (!poly8 && !hbb4)) return OBB_ERR_BAD_ARG;
+  k_rbox2poly<<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(rboxes, n, (int)row_stride, poly8, hbb4);
+  return hipGetLastError() == hipSuccess ? OBB_OK : OBB_ERR_LAUNCH;
+}
+
+}  // extern "C"

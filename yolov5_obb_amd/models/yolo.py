@@ -1,0 +1,101 @@
+"""Mirror of the OBB ``Detect`` head of the reference's ``models/yolo.py`` (:33-92).
+
+Only the head is mirrored: ``Model`` / ``parse_model`` / the CSP backbone stay the reference's PyTorch code (they run on
+PyTorch-ROCm unchanged).  This class keeps the reference's constructor, attributes (``nc no nl na anchors m grid
+anchor_grid stride inplace onnx_dynamic``), parameter names and return values, so checkpoints and ``parse_model`` can use it
+in place of the reference's ``Detect``.  In inference mode on the GPU the per-level chain
+``view -> permute -> contiguous -> sigmoid -> 2 slice updates -> cat`` is ONE pass of ``obb_detect_decode``
+(libobb_hip.so, csrc/head.hip) per level.
+"""
+import ctypes as C
+
+import torch
+import torch.nn as nn
+
+from .. import _lib
+
+
+class Detect(nn.Module):
+    stride = None  # strides computed during build
+    onnx_dynamic = False  # ONNX export parameter
+
+    def __init__(self, nc=80, anchors=(), ch=(), inplace=True):  # detection layer
+        super().__init__()
+        self.nc = nc  # number of classes
+        self.no = nc + 5 + 180  # number of outputs per anchor (models/yolo.py:40)
+        self.nl = len(anchors)  # number of detection layers
+        self.na = len(anchors[0]) // 2  # number of anchors
+        self.grid = [torch.zeros(1)] * self.nl  # init grid
+        self.anchor_grid = [torch.zeros(1)] * self.nl  # init anchor grid
+        self.register_buffer('anchors', torch.tensor(anchors).float().view(self.nl, -1, 2))  # shape(nl,na,2)
+        self.m = nn.ModuleList(nn.Conv2d(x, self.no * self.na, 1) for x in ch)  # output conv
+        self.inplace = inplace  # use in-place ops (e.g. slice assignment)
+        self._anchor_px = None  # host copy of anchors * stride, built on first inference call
+
+    def _host_tables(self):
+        if self._anchor_px is None:
+            st = [float(s) for s in torch.as_tensor(self.stride).float().cpu().tolist()]
+            an = self.anchors.detach().float().cpu()
+            px = [(an[i] * st[i]).reshape(-1).tolist() for i in range(self.nl)]      # anchor_grid values (:90-91)
+            self._anchor_px = ([(C.c_float * len(p))(*p) for p in px], st)
+        return self._anchor_px
+
+    def _apply(self, fn):  # anchors / stride may change (Model._apply, autoanchor): drop the host cache
+        self._anchor_px = None
+        return super()._apply(fn)
+
+    def forward(self, x):
+        """
+        Args:
+            x (list[P3_in,...]): torch.Size(b, c_i, h_i, w_i)
+        Return：
+            if train:
+                x (list[P3_out,...]): torch.Size(b, self.na, h_i, w_i, self.no)
+            else:
+                inference (tensor): (b, n_all_anchors, self.no)
+                x (list[P3_out,...]): torch.Size(b, self.na, h_i, w_i, self.no)
+        """
+        if self.training:
+            for i in range(self.nl):
+                x[i] = self.m[i](x[i])  # conv
+                bs, _, ny, nx = x[i].shape
+                x[i] = x[i].view(bs, self.na, self.no, ny, nx).permute(0, 1, 3, 4, 2).contiguous()
+            return x
+
+        convs = [self.m[i](x[i]).contiguous() for i in range(self.nl)]
+        c0 = convs[0]
+        if not c0.is_cuda:
+            raise RuntimeError("Detect (inference): yolov5_obb_amd is compiled for MI355X only (no CPU path, by design)")
+        if c0.dtype == torch.float32:
+            code = 0
+        elif c0.dtype == torch.float16:
+            code = 1
+        else:
+            raise RuntimeError(f"Detect (inference): float32 or float16 expected, got {c0.dtype}")
+        anchor_px, strides = self._host_tables()
+        bs = c0.shape[0]
+        shapes = [(c.shape[2], c.shape[3]) for c in convs]
+        a_total = sum(self.na * ny * nx for ny, nx in shapes)
+        z = torch.empty((bs, a_total, self.no), dtype=c0.dtype, device=c0.device)
+        L = _lib.lib()
+        off = 0
+        with torch.cuda.device(c0.device):
+            st = _lib.stream_ptr(c0.device)
+            for i in range(self.nl):
+                ny, nx = shapes[i]
+                if self.onnx_dynamic or self.grid[i].shape[2:4] != (ny, nx):
+                    self.grid[i], self.anchor_grid[i] = self._make_grid(nx, ny, i)      # kept for attribute compatibility
+                xp = torch.empty((bs, self.na, ny, nx, self.no), dtype=c0.dtype, device=c0.device)
+                rc = L.obb_detect_decode(_lib.ptr(convs[i]), code, bs, self.na, self.no, ny, nx, C.cast(anchor_px[i], C.c_void_p),
+                                         strides[i], _lib.ptr(xp), _lib.ptr(z), a_total, off, st)
+                _lib.check(rc, "obb_detect_decode")
+                x[i] = xp
+                off += self.na * ny * nx
+        return z, x
+
+    def _make_grid(self, nx=20, ny=20, i=0):  # models/yolo.py:83-92
+        d = self.anchors[i].device
+        yv, xv = torch.meshgrid([torch.arange(ny, device=d), torch.arange(nx, device=d)], indexing='ij')
+        grid = torch.stack((xv, yv), 2).expand((1, self.na, ny, nx, 2)).float()
+        anchor_grid = (self.anchors[i].clone() * self.stride[i]).view((1, self.na, 1, 1, 2)).expand((1, self.na, ny, nx, 2)).float()
+        return grid, anchor_grid

@@ -9,7 +9,40 @@ ImportError when cv2 is not installed.
 import numpy as np
 import torch
 
+from .. import _lib
+
 pi = 3.141592  # utils/rboxs_utils.py:5
+
+
+def csl_encode(angles, num_class=180, u=0.0, sig=4.0):
+    """Device-side batch form of ``gaussian_label_cpu``: angles (n,) CUDA tensor in [0, num_class) -> (n, num_class)
+    float32 Circular Smooth Labels, one ``obb_csl_encode_f32`` launch (what utils/datasets.py:639-642 computes per
+    sample on the CPU through poly2rbox)."""
+    _lib.require_cuda(angles, "angles")
+    a = angles.reshape(-1).to(torch.float32).contiguous()
+    out = torch.empty((a.shape[0], int(num_class)), dtype=torch.float32, device=a.device)
+    with torch.cuda.device(a.device):
+        rc = _lib.lib().obb_csl_encode_f32(_lib.ptr(a), a.shape[0], int(num_class), float(u), float(sig), _lib.ptr(out),
+                                           _lib.stream_ptr(a.device))
+    _lib.check(rc, "obb_csl_encode_f32")
+    return out
+
+
+def _rbox2poly_device(obboxes, want_poly=True, want_hbb=False):
+    r = obboxes.to(torch.float32).contiguous()
+    n = r.shape[0]
+    poly = torch.empty((n, 8), dtype=torch.float32, device=r.device) if want_poly else None
+    hbb = torch.empty((n, 4), dtype=torch.float32, device=r.device) if want_hbb else None
+    with torch.cuda.device(r.device):
+        rc = _lib.lib().obb_rbox2poly_f32(_lib.ptr(r), n, r.shape[1], _lib.ptr(poly), _lib.ptr(hbb), _lib.stream_ptr(r.device))
+    _lib.check(rc, "obb_rbox2poly_f32")
+    return poly, hbb
+
+
+def rbox2hbb(obboxes):
+    """rbox2poly followed by poly2hbb in one kernel for CUDA tensors (val.py:226-241 uses the pair back to back)."""
+    _lib.require_cuda(obboxes, "obboxes")
+    return _rbox2poly_device(obboxes, want_poly=False, want_hbb=True)[1]
 
 
 def gaussian_label_cpu(label, num_class, u=0, sig=4.0):
@@ -57,6 +90,9 @@ def poly2rbox(polys, num_cls_thata=180, radius=6.0, use_pi=False, use_gaussian=F
 
 def rbox2poly(obboxes):
     """(…,[cx cy l s θ]) θ∈[-pi/2, pi/2) -> (…,[x1 y1 x2 y2 x3 y3 x4 y4]) (utils/rboxs_utils.py:106-145)."""
+    if isinstance(obboxes, torch.Tensor) and obboxes.is_cuda and obboxes.dim() == 2 and obboxes.dtype == torch.float32 \
+            and not obboxes.requires_grad:
+        return _rbox2poly_device(obboxes)[0]      # one fused kernel (csrc/head.hip)
     if isinstance(obboxes, torch.Tensor):
         center, w, h, theta = obboxes[:, :2], obboxes[:, 2:3], obboxes[:, 3:4], obboxes[:, 4:5]
         Cos, Sin = torch.cos(theta), torch.sin(theta)
