@@ -1,0 +1,69 @@
+"""CPU, world_size 2, gloo: the N>1 path of the inference sharding (yolov5_obb_amd/utils/shard.py) -- every image is
+processed by exactly one rank, results come back on rank 0 in the original order, timing is the MAX over ranks.
+(The data path itself has no collective; the HIP kernels are covered by the -m gpu tests.)"""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _fake_detections(i):
+    """Deterministic stand-in for one image's (n,7) NMS output."""
+    g = np.random.default_rng(1000 + i)
+    return g.random((i % 5, 7)).astype(np.float32)
+
+
+def _worker(rank, world_size, port, n_items, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world_size))
+    dist.init_process_group("gloo", rank=rank, world_size=world_size)
+    try:
+        from yolov5_obb_amd.utils import shard
+        assert shard.world() == (rank, world_size)
+        idx = shard.shard_indices(n_items)
+        res = [torch.from_numpy(_fake_detections(i)) for i in idx]
+        full = shard.gather_results(idx, res, n_items, dst=0)
+        t = shard.max_over_ranks(1.0 + rank)
+        if rank == 0:
+            ok = all(np.array_equal(full[i].numpy(), _fake_detections(i)) for i in range(n_items))
+            q.put(("ok" if ok and len(full) == n_items and t == float(world_size) else "bad", len(idx)))
+        else:
+            assert full is None and t == float(world_size)
+            q.put(("peer", len(idx)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_sharding_and_gather():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    n_items = 37
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_items, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    got = sorted(q.get(timeout=10) for _ in range(2))
+    assert got[0][0] == "ok" and got[1][0] == "peer"
+    assert got[0][1] + got[1][1] == n_items and abs(got[0][1] - got[1][1]) <= 1
+
+
+def test_single_process_paths():
+    from yolov5_obb_amd.utils import shard
+    assert shard.world() == (0, 1)
+    assert shard.shard_indices(5) == [0, 1, 2, 3, 4]
+    assert shard.shard_indices(7, 1, 3) == [1, 4]
+    assert shard.gather_results([0, 1], ["a", "b"], 2) == ["a", "b"]
+    assert shard.max_over_ranks(0.25) == 0.25

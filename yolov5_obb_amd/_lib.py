@@ -81,6 +81,13 @@ def check(rc, what):
         raise RuntimeError(f"{what} failed: {_ERR.get(rc, 'error')} (code {rc})")
 
 
+def checked_count(n, what):
+    """A negative kept-count is the device-side abort signal of the persistent NMS kernel (a team barrier timed out)."""
+    if n < 0:
+        raise RuntimeError(f"{what}: the NMS kernel aborted (a workgroup barrier timed out); results are invalid")
+    return n
+
+
 def stream_ptr(device):
     return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 

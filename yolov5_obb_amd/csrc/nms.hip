@@ -101,39 +101,47 @@ __global__ void k_seg_bounds(const uint64_t* __restrict__ keys, int n, int nseg,
   keep_cnt[g] = 0; ccount[g] = 0; nrows[g] = 0; nedges[g] = 0;
 }
 
+// blockDim.x is a multiple of 64 and p starts at 0: every wave covers one word of the alive bitmap
 __global__ void k_prep_rot(const float* __restrict__ dets5, const uint32_t* __restrict__ order, int drop_small, int n,
-                           float4* __restrict__ rec, uint8_t* __restrict__ dead) {
+                           float4* __restrict__ rec, u64* __restrict__ alive) {
   int p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= n) return;
-  const float* d = dets5 + (size_t)order[p] * 5;
-  float x = d[0], y = d[1], w = d[2], h = d[3], a = d[4];
-  RBoxFeat f = rbox_make_feat(x, y, w, h, a);
-  float4 q[4];
-  RotGeom::pack(f, q);
+  bool ok = false;
+  if (p < n) {
+    const float* d = dets5 + (size_t)order[p] * 5;
+    float x = d[0], y = d[1], w = d[2], h = d[3], a = d[4];
+    RBoxFeat f = rbox_make_feat(x, y, w, h, a);
+    float4 q[4];
+    RotGeom::pack(f, q);
 #pragma unroll
-  for (int k = 0; k < 4; k++) rec[(size_t)p * 4 + k] = q[k];
-  float mn = (h < w) ? h : w;
-  dead[p] = (drop_small && mn < 0.001f) ? 1 : 0;
+    for (int k = 0; k < 4; k++) rec[(size_t)p * 4 + k] = q[k];
+    float mn = (h < w) ? h : w;
+    ok = !(drop_small && mn < 0.001f);
+  }
+  const u64 m = __ballot(ok);
+  if ((threadIdx.x & 63) == 0 && (p & ~63) < n) alive[p >> 6] = m;
 }
 
 __global__ void k_prep_quad(const float* __restrict__ polys, int stride, const uint32_t* __restrict__ order, int n,
-                            float4* __restrict__ rec, uint8_t* __restrict__ dead) {
+                            float4* __restrict__ rec, u64* __restrict__ alive) {
   int p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= n) return;
-  const float* d = polys + (size_t)order[p] * stride;
-  rec[(size_t)p * 2 + 0] = make_float4(d[0], d[1], d[2], d[3]);
-  rec[(size_t)p * 2 + 1] = make_float4(d[4], d[5], d[6], d[7]);
-  dead[p] = 0;
+  if (p < n) {
+    const float* d = polys + (size_t)order[p] * stride;
+    rec[(size_t)p * 2 + 0] = make_float4(d[0], d[1], d[2], d[3]);
+    rec[(size_t)p * 2 + 1] = make_float4(d[4], d[5], d[6], d[7]);
+  }
+  const u64 m = __ballot(p < n);
+  if ((threadIdx.x & 63) == 0 && (p & ~63) < n) alive[p >> 6] = m;
 }
 
+// num_keep[g] = -1 when the persistent kernel gave up on a barrier (abort flag): the host layer raises
 __global__ void k_finalize(const int* __restrict__ keep_cnt, const int* __restrict__ seg_begin, int nseg, long long max_keep,
-                           int64_t* __restrict__ num_keep, int64_t* __restrict__ seg_begin_out) {
+                           const int* __restrict__ abort_flag, int64_t* __restrict__ num_keep, int64_t* __restrict__ seg_begin_out) {
   int g = blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= nseg) return;
   if (seg_begin_out) seg_begin_out[g] = seg_begin[g];
   long long c = keep_cnt[g];
   if (max_keep > 0 && c > max_keep) c = max_keep;
-  num_keep[g] = c;
+  num_keep[g] = (abort_flag && *abort_flag) ? -1 : c;
 }
 
 // ---------------------------------------------------------------- workspace
@@ -157,12 +165,17 @@ static int cap_max(int64_t nseg) {
   return c < cap_first() ? cap_first() : c;
 }
 
+constexpr int kMaxTeams = 1024;     // >= number of CUs of any gfx950 part
+
 struct Carve {
   uint64_t *keys_a, *keys_b;
   uint32_t *vals_a, *vals_b;
   void* sort_tmp; size_t sort_tmp_bytes;
-  float4* rec; uint8_t* dead;
+  float4* rec; u64* alive; size_t alive_bytes;
   int *seg_begin, *seg_end, *cursor, *keep_cnt, *ccount, *nrows, *nedges;
+  int* bar; size_t bar_bytes;          // team barrier counters + the abort flag (zeroed before every launch)
+  int* abort_flag;
+  u64* prof;                           // in-kernel phase timing (OBB_NMS_PHASE_PROF=1)
   uint32_t *cidx, *rows, *edges;
   long long ecap;
   size_t total;
@@ -183,7 +196,12 @@ static int carve(void* base, int64_t n, int64_t nseg, int recq, int C, Carve* cv
   if (sort_tmp_query(nn, &cv->sort_tmp_bytes) != hipSuccess) return OBB_ERR_INTERNAL;
   cv->sort_tmp = take(cv->sort_tmp_bytes ? cv->sort_tmp_bytes : 16);
   cv->rec = (float4*)take(nn * recq * 16);
-  cv->dead = (uint8_t*)take(nn + 64);
+  cv->alive_bytes = (nn / 64 + 8) * 8;
+  cv->alive = (u64*)take(cv->alive_bytes);
+  cv->bar_bytes = ((size_t)kMaxTeams * 128 + 64) * 4;
+  cv->bar = (int*)take(cv->bar_bytes);
+  cv->abort_flag = cv->bar + (size_t)kMaxTeams * 128;
+  cv->prof = (u64*)take(16 * 8);
   cv->seg_begin = (int*)take(ns * 4); cv->seg_end = (int*)take(ns * 4); cv->cursor = (int*)take(ns * 4);
   cv->keep_cnt = (int*)take(ns * 4); cv->ccount = (int*)take(ns * 4);
   cv->nrows = (int*)take(ns * 4); cv->nedges = (int*)take(ns * 4);
@@ -195,31 +213,66 @@ static int carve(void* base, int64_t n, int64_t nseg, int recq, int C, Carve* cv
   return OBB_OK;
 }
 
-// The step loop shared by every entry point.  max_seg: host-side upper bound on the number of boxes of any
-// segment that take part (bounds the number of steps and the grid sizes; kernels read the true sizes on device).
-static void nms_steps(int kind, NmsArgs& a, int64_t nseg, int64_t max_seg, hipStream_t st) {
-  int cap = cap_first();
-  if (cap > a.capmax) cap = a.capmax;
-  int64_t covered = 0;
-  while (covered < max_seg) {
-    k_select_chunk<<<(unsigned)nseg, 1024, 0, st>>>(a, cap);
-    const int64_t cn = (max_seg - covered) < cap ? (max_seg - covered) : cap;   // bound on this step's chunk size
-    const int64_t nb = (cn + 63) / 64;
-    int64_t g1 = nb * nb; if (g1 > 4096) g1 = 4096; if (g1 < 1) g1 = 1;
-    dim3 ga((unsigned)g1, (unsigned)nseg);
-    if (kind == 0) k_chunk_pairs<RotGeom><<<ga, 64, 0, st>>>(a);
-    else k_chunk_pairs<QuadGeom><<<ga, 64, 0, st>>>(a);
-    k_chunk_resolve<<<(unsigned)nseg, 1024, (size_t)2 * a.capmax, st>>>(a);
-    covered += cap;
-    const int64_t rest = max_seg - covered;
-    if (rest > 0) {
-      int64_t g2 = ((rest + 63) / 64) * nb; if (g2 > 4096) g2 = 4096; if (g2 < 1) g2 = 1;
-      dim3 gc((unsigned)g2, (unsigned)nseg);
-      if (kind == 0) k_cross<RotGeom><<<gc, 64, 0, st>>>(a);
-      else k_cross<QuadGeom><<<gc, 64, 0, st>>>(a);
-    }
-    if (cap < a.capmax) { cap *= 2; if (cap > a.capmax) cap = a.capmax; }
+// One persistent launch runs the whole step loop (nms_core.h).  Grid: one 512-thread workgroup per CU at most --
+// all workgroups must be resident because they meet at team barriers; smaller problems get fewer workgroups
+// (cheaper barriers).
+static int cu_count() {
+  static int cus = 0;
+  if (!cus) {
+    int dev = 0; hipDeviceProp_t p;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) cus = p.multiProcessorCount;
+    if (cus < 1) cus = 1;
+    if (cus > kMaxTeams) cus = kMaxTeams;
   }
+  return cus;
+}
+
+constexpr size_t kPersistLdsMax = 152 * 1024;   // of the 160 KB per CU: exactly one workgroup per CU
+
+template <class G>
+static int launch_persist(const NmsArgs& a, unsigned nb, hipStream_t st) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)k_nms_persist<G>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPersistLdsMax) != hipSuccess)
+      return OBB_ERR_LAUNCH;
+    attr_set = true;
+  }
+  size_t lds = sizeof(WaveLds<G>) * kNmsWaves;                // pair phases: one scratch block per wave
+  if (lds < (size_t)2 * a.capmax) return OBB_ERR_INTERNAL;    // (aliased by resolve: state + blocked bytes of one chunk)
+  lds += (size_t)a.capmax * 4;                                // + this workgroup's copy of the chunk list
+  if (lds > kPersistLdsMax) return OBB_ERR_INTERNAL;
+  k_nms_persist<G><<<nb, kNmsThreads, lds, st>>>(a);
+  return OBB_OK;
+}
+
+// n_slots: number of sorted positions that can hold a box (bounds the useful parallelism)
+static int nms_steps(int kind, NmsArgs& a, const Carve& cv, int64_t nseg, int64_t n_slots, hipStream_t st) {
+  hipMemsetAsync(cv.bar, 0, cv.bar_bytes, st);
+  a.bar = cv.bar; a.abort_flag = cv.abort_flag; a.nseg = (int)nseg;
+  a.cap_first = cap_first();
+  static int phase_prof = -1;
+  if (phase_prof < 0) { const char* e = getenv("OBB_NMS_PHASE_PROF"); phase_prof = (e && atoi(e)) ? 1 : 0; }
+  a.prof = nullptr;
+  if (phase_prof) {   // development aid: print the previous call's phase times (synchronises!)
+    u64 h[16];
+    if (hipMemcpy(h, cv.prof, sizeof h, hipMemcpyDeviceToHost) == hipSuccess && h[6] > 0 && h[6] < (1ull << 40))
+      fprintf(stderr, "[nms phases, wg0, us] select %.1f pairs %.1f wait-resolve %.1f cross %.1f barrier %.1f steps %llu | resolve (any wg) %.1f\n",
+              h[1] * 0.01, h[2] * 0.01, h[3] * 0.01, h[5] * 0.01, h[0] * 0.01, h[6], h[9] * 0.01);
+    hipMemsetAsync(cv.prof, 0, 16 * 8, st);
+    a.prof = cv.prof;
+  }
+  const int cus = cu_count();
+  int64_t nb = (n_slots + 511) / 512;                 // 8 waves x 64 columns per workgroup
+  {                                                   // ... and one wave per tile of the first chunk's triangle
+    const int64_t per_seg = (n_slots + nseg - 1) / nseg;
+    const int64_t c = per_seg < a.cap_first ? per_seg : a.cap_first;
+    const int64_t tiles = ((c + 63) / 64) * ((c + 63) / 64 + 1) / 2 * nseg;
+    if (nb < (tiles + 7) / 8) nb = (tiles + 7) / 8;
+  }
+  if (nb < nseg) nb = nseg;
+  if (nb > cus) nb = cus;
+  if (nb < 1) nb = 1;
+  return kind == 0 ? launch_persist<RotGeom>(a, (unsigned)nb, st) : launch_persist<QuadGeom>(a, (unsigned)nb, st);
 }
 
 // kind: 0 rotated (5 floats + score array), 1 quad (rows of `stride` floats, score in column 8)
@@ -245,7 +298,7 @@ static int run_nms(int kind, const float* boxes, int stride, const float* scores
   if (n == 0) {
     hipMemsetAsync(cv.keep_cnt, 0, nseg * 4, st);
     hipMemsetAsync(cv.seg_begin, 0, nseg * 4, st);
-    k_finalize<<<gseg, T, 0, st>>>(cv.keep_cnt, cv.seg_begin, (int)nseg, max_keep, num_keep, seg_begin_out);
+    k_finalize<<<gseg, T, 0, st>>>(cv.keep_cnt, cv.seg_begin, (int)nseg, max_keep, nullptr, num_keep, seg_begin_out);
     return hipGetLastError() == hipSuccess ? OBB_OK : OBB_ERR_LAUNCH;
   }
 
@@ -263,25 +316,27 @@ static int run_nms(int kind, const float* boxes, int stride, const float* scores
   }
   {
     ProfScope ps(PROF_NMS_PREP, st);
-    if (kind == 0) k_prep_rot<<<gb, T, 0, st>>>(boxes, cv.vals_b, drop_small, (int)n, cv.rec, cv.dead);
-    else k_prep_quad<<<gb, T, 0, st>>>(boxes, stride, cv.vals_b, (int)n, cv.rec, cv.dead);
+    hipMemsetAsync(cv.alive, 0, cv.alive_bytes, st);
+    if (kind == 0) k_prep_rot<<<gb, T, 0, st>>>(boxes, cv.vals_b, drop_small, (int)n, cv.rec, cv.alive);
+    else k_prep_quad<<<gb, T, 0, st>>>(boxes, stride, cv.vals_b, (int)n, cv.rec, cv.alive);
   }
 
   NmsArgs a;
-  a.rec = cv.rec; a.order = cv.vals_b; a.dead = cv.dead; a.seg_begin = cv.seg_begin; a.seg_end = cv.seg_end;
-  a.cursor = cv.cursor; a.keep_cnt = cv.keep_cnt; a.keep_out = keep_out; a.cidx = cv.cidx; a.ccount = cv.ccount;
+  a.rec = cv.rec; a.order = cv.vals_b; a.alive = cv.alive; a.seg_begin = cv.seg_begin; a.seg_end = cv.seg_end;
+  a.keep_cnt = cv.keep_cnt; a.keep_out = keep_out;
   a.rows = cv.rows; a.nrows = cv.nrows; a.edges = cv.edges; a.nedges = cv.nedges;
   a.ecap = cv.ecap; a.n = (int)n; a.capmax = C;
   a.max_keep = (int)(max_keep > 0x7fffffffLL ? 0x7fffffffLL : (max_keep < 0 ? 0 : max_keep));
   a.thr = thr;
   a.cull = (thr >= 0.f) ? 1 : 0;      // rejects predict IoU <= 0 or IoU <= thr; with thr < 0 even IoU == 0 suppresses
 
-  if (max_seg <= 0 || max_seg > n) max_seg = n;
+  (void)max_seg;   // the step loop is device-driven now: no host-side bound on the segment size is needed
   {
     ProfScope ps(PROF_NMS_STEPS, st);
-    nms_steps(kind, a, nseg, max_seg, st);
+    rc = nms_steps(kind, a, cv, nseg, n, st);
+    if (rc) return rc;
   }
-  k_finalize<<<gseg, T, 0, st>>>(cv.keep_cnt, cv.seg_begin, (int)nseg, max_keep, num_keep, seg_begin_out);
+  k_finalize<<<gseg, T, 0, st>>>(cv.keep_cnt, cv.seg_begin, (int)nseg, max_keep, cv.abort_flag, num_keep, seg_begin_out);
   return hipGetLastError() == hipSuccess ? OBB_OK : OBB_ERR_LAUNCH;
 }
 

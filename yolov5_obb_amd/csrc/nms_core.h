@@ -1,30 +1,34 @@
-// Lazy chunked greedy NMS ("LC-NMS") for gfx950 -- device side.
+// Lazy chunked greedy NMS ("LC-NMS") for gfx950 -- device side, ONE persistent launch per call.
 //
-// What it computes: exactly the kept set (and order) of the reference's greedy
-// NMS -- sort by score, a box is dropped iff an earlier *kept* box has
-// IoU(kept, box) > thr   (nms_rotated_cuda.cu:60,116-128; poly_nms_cuda.cu:187,242-254).
+// What it computes: exactly the kept set (and order) of the reference's greedy NMS -- sort by score, a box is
+// dropped iff an earlier *kept* box has IoU(kept, box) > thr   (nms_rotated_cuda.cu:60,116-128;
+// poly_nms_cuda.cu:187,242-254).
 //
-// How (MI355X-first, not the reference's N x N/64 bitmask + host scan):
-//   per step, per segment (= image):
-//   S   k_select_chunk  the next `cap` still-alive boxes in score order become the chunk
-//                       (ordered compaction of the alive flags by one workgroup).
-//   A1  k_chunk_pairs   64x64 tiles of the chunk's upper triangle, one wave each:
-//                       columns in registers, rows as 16-byte LDS broadcasts, a ~13-op
-//                       circle test in the hot loop; survivors are compacted through an
-//                       LDS ring (wave ballot + popcount prefix) so that the expensive
-//                       part (separating axes, area bound, exact clip) always runs on
-//                       full waves; pairs with IoU > thr go to a per-segment edge list.
-//   A2  k_chunk_resolve one workgroup per segment: lexicographically-first maximal
-//                       independent set over the edge list by parallel rounds (== the
-//                       sequential greedy scan), ordered compaction of the kept boxes,
-//                       output write.
-//   B   k_cross         only the chunk's *kept* rows are tested against the still-alive
-//                       later boxes (lazy: a suppressed box never generates work again).
-//   Work is O(kept x alive) instead of N^2, memory is O(N): the N x N/64 mask of the
-//   reference (1.25 GB at N = 100k) is never materialised, nothing is copied to the
-//   host, and `max_keep` (the caller's max_det) stops a segment early.  Segments run
-//   side by side in gridDim.y; grids are fixed-size and stride over work items whose
-//   count is only known on the device.
+// How (MI355X-first, not the reference's N x N/64 bitmask + device->host copy + host scan):
+//   * the boxes live in score order as 16-byte-quad records (geom.h); "still alive" is one BIT per position
+//     (64 positions = one u64 = one wave ballot);
+//   * per step and segment (= image):
+//       S   select   the next `cap` alive positions become the chunk (popcount prefix over the bitmap);
+//       A1  pairs    64x64 tiles of the chunk's upper triangle, one wave each: columns in registers, rows as
+//                    16-byte LDS broadcasts, a ~13-op circle test in the hot loop; survivors are compacted
+//                    through an LDS ring (ballot + popcount prefix) so that the expensive part (separating
+//                    axes, area bound, exact clip) always runs on full waves; hits go to an edge list;
+//       A2  resolve  lexicographically-first maximal independent set over the edge list by parallel rounds
+//                    (== the sequential greedy scan), ordered compaction of the kept boxes, output;
+//       B   cross    only the chunk's KEPT rows are tested against the still-alive later positions; kills are
+//                    one atomicAnd per 64 positions.  A suppressed box never generates work again.
+//     Work is O(kept x alive) instead of N^2, memory is O(N): the reference's N x N/64 mask (1.25 GB at
+//     N = 100k) never exists and nothing is copied to the host.
+//   * the whole step loop runs inside ONE launch: one 512-thread workgroup per CU, grouped into teams (one team
+//     per segment, NB/nseg workgroups each).  The control state (cursor, kept count, chunk size) is a replicated
+//     state machine: every workgroup of a team computes S itself from the shared bitmap (identical result, chunk
+//     list in its own LDS), so no control word travels between workgroups.  A step needs two team barriers: after
+//     A1 the workgroup that arrives LAST runs A2 while the others wait (no separate launch, no host round trip),
+//     after B a plain barrier makes the kills visible.  Unlike a host-driven loop no step is ever issued for a
+//     segment that is already finished.  What workgroups do exchange (bitmap words, edges, kept rows) goes through
+//     agent-scope (sc1) stores / atomics and either sc1 loads or ONE agent acquire followed by plain loads
+//     (cdna_hip_programming.md guideline 16); nothing depends on dispatch order or XCD placement; spins are
+//     bounded and raise an abort flag instead of hanging the device.
 #pragma once
 #include <hip/hip_runtime.h>
 #include "obb_device.h"
@@ -32,167 +36,218 @@
 
 namespace obb {
 
+typedef unsigned long long u64;
+
 struct NmsArgs {
-  const float4* rec;         // [n][RECQ] AoS records in sorted order
+  const float4* rec;         // [n][RECQ] AoS records in sorted order (read-only in this kernel)
   const uint32_t* order;     // sorted position -> original index
-  uint8_t* dead;             // [n] 1 = suppressed / invalid
+  u64* alive;                // [n/64 + 2] bit (p & 63) of word (p >> 6): still a candidate (only B clears bits)
   const int* seg_begin;      // [nseg] first sorted position of the segment
   const int* seg_end;        // [nseg] one past the last position considered (top-k cap applied)
-  int* cursor;               // [nseg] next position not yet placed in a chunk
-  int* keep_cnt;             // [nseg]
+  int* keep_cnt;             // [nseg] (output)
   int64_t* keep_out;         // segment g writes at keep_out[seg_begin[g] + k]
-  uint32_t* cidx;            // [nseg][capmax] positions of the current chunk
-  int* ccount;               // [nseg]
   uint32_t* rows;            // [nseg][capmax] kept rows of the current chunk (positions)
   int* nrows;                // [nseg]
   uint32_t* edges;           // [nseg][ecap] (i << 16 | j), chunk-local indices, i < j
   int* nedges;               // [nseg]
+  int* bar;                  // [nteams][2][64] arrive / go counters, one 256-byte line each
+  int* abort_flag;           // [1] set when a spin gave up
+  u64* prof;                 // optional [16]: wall-clock ticks (10 ns) per phase (development aid)
   long long ecap;
-  int n;
-  int capmax;
+  int n, nseg;
+  int capmax, cap_first;
   int max_keep;              // 0 = unlimited
   float thr;
   int cull;                  // 1: conservative rejects allowed (thr >= 0)
 };
 
-// ------------------------------------------------------------------ wave helpers
-__device__ __forceinline__ unsigned long long lanemask_lt() { return (1ull << (threadIdx.x & 63)) - 1ull; }
+// ------------------------------------------------------------------ agent-scope accessors
+template <typename T> __device__ __forceinline__ T ldg_agent(const T* p) {
+  return __hip_atomic_load(const_cast<T*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <typename T> __device__ __forceinline__ void stg_agent(T* p, T v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ u64 lanemask_lt() { return (1ull << (threadIdx.x & 63)) - 1ull; }
+__device__ __forceinline__ void wave_sync() { __builtin_amdgcn_wave_barrier(); }
+
+constexpr int kNmsThreads = 512;
+constexpr int kNmsWaves = kNmsThreads / 64;
+constexpr unsigned kSpinLimit = 1u << 22;
+
+// Team barriers on one monotonic arrive counter (every barrier of either kind adds T arrivals) and one go word.
+struct TeamBar {
+  int* arrive; int* go; int T; int epoch; int* abort_flag;
+};
+// spin until *word >= target; false when the spin gave up or another workgroup raised the abort flag
+__device__ __forceinline__ bool spin_until(int* word, int target, int* abort_flag) {
+  for (unsigned spins = 0; ldg_agent(word) < target; spins++) {
+    __builtin_amdgcn_s_sleep(1);
+    if ((spins & 1023u) == 1023u && ldg_agent(abort_flag)) return false;
+    if (spins > kSpinLimit) { stg_agent(abort_flag, 1); return false; }
+  }
+  return true;
+}
+// plain barrier: returns false on abort
+__device__ __forceinline__ bool team_barrier(TeamBar& b, int* s_flag) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // every wave drains its write-through stores / atomics
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __hip_atomic_fetch_add(b.arrive, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    *s_flag = spin_until(b.arrive, b.T * (b.epoch + 1), b.abort_flag) ? 0 : 1;
+  }
+  __syncthreads();
+  b.epoch++;
+  return *s_flag == 0;
+}
+// barrier with a serial section: true in the workgroup that arrived last (it runs the serial part, then serial_end)
+__device__ __forceinline__ bool serial_begin(TeamBar& b, int* s_flag) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int t = __hip_atomic_fetch_add(b.arrive, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int last = (t == b.T * (b.epoch + 1) - 1) ? 1 : 0;
+    // the last arriver reads what the others published in bulk: ONE agent acquire, then plain loads (guideline 16, R1)
+    if (last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    *s_flag = last;
+  }
+  __syncthreads();
+  return *s_flag != 0;
+}
+__device__ __forceinline__ void serial_end(TeamBar& b) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) stg_agent(b.go, b.epoch + 1);
+  b.epoch++;
+}
+__device__ __forceinline__ bool serial_wait(TeamBar& b, int* s_flag) {
+  if (threadIdx.x == 0) *s_flag = spin_until(b.go, b.epoch + 1, b.abort_flag) ? 0 : 1;
+  __syncthreads();
+  b.epoch++;
+  return *s_flag == 0;
+}
+
+// ------------------------------------------------------------------ per-wave LDS scratch of the pair phases
+template <class G>
+struct WaveLds {
+  float4 rowq0[64];
+  uint32_t rowpos[64], colpos[64];
+  float scr[G::SCR * 64];
+  uint32_t qbuf[128];
+  uint8_t cdead[64];
+  uint8_t pad[192];
+};
 
 // Ring queue of pending (row, col) pairs in LDS; all bookkeeping is wave-uniform.
 struct PairQueue {
   uint32_t* q;  // LDS, 128 entries
   int head, count;
   __device__ __forceinline__ void push(bool pass, uint32_t item) {
-    unsigned long long m = __ballot(pass);
+    const u64 m = __ballot(pass);
     if (pass) q[(head + count + __popcll(m & lanemask_lt())) & 127] = item;
     count += __popcll(m);
   }
 };
 
-__device__ __forceinline__ bool seg_done(const NmsArgs& a, int g) {
-  return a.max_keep > 0 && a.keep_cnt[g] >= a.max_keep;
-}
-
-// ------------------------------------------------------------------ S
-// One workgroup (1024 threads) per segment: chunk = the first `cap` alive positions >= cursor.
-__global__ __launch_bounds__(1024) void k_select_chunk(NmsArgs a, int cap) {
-  __shared__ int s_wave[16];
-  __shared__ int s_newcur;
-  const int g = blockIdx.x, tid = threadIdx.x;
-  const int se = a.seg_end[g];
-  const int cur = a.cursor[g];
-  if (cur >= se || seg_done(a, g)) {
-    if (tid == 0) a.ccount[g] = 0;
-    return;
-  }
-  uint32_t* cidx = a.cidx + (size_t)g * a.capmax;
-  if (tid == 0) s_newcur = se;
+// ------------------------------------------------------------------ S: the next chunk (every workgroup, identical result)
+// chunk = the first `cap` alive positions in [cur, se); their positions go to this workgroup's LDS list; returns the
+// chunk size and moves `cur` behind the last member.  Members keep their alive bit: nothing reads positions below
+// the cursor again.
+__device__ int nms_select(const NmsArgs& a, int se, int& cur, int cap, uint32_t* cidx, int* s_i) {
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int w_first = cur >> 6, w_last = (se - 1) >> 6;
   int off = 0;
-  for (int base = cur; base < se && off < cap; base += 4096) {
-    const int p0 = base + tid * 4;
-    bool al[4];
-    int cnt = 0;
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-      int pos = p0 + k;
-      al[k] = (pos < se) && !a.dead[pos];
-      cnt += al[k] ? 1 : 0;
+  __syncthreads();
+  if (tid == 0) s_i[8] = se;
+  for (int wbase = w_first; wbase <= w_last && off < cap; wbase += kNmsThreads) {
+    const int w = wbase + tid;
+    u64 m = 0ull;
+    if (w <= w_last) {
+      m = ldg_agent(a.alive + w);
+      const long long lo = (long long)w * 64;
+      if (lo < cur) m &= ~((1ull << (cur - lo)) - 1ull);              // positions below the cursor / of the previous segment
+      if (lo + 64 > se) m &= (1ull << (se - lo)) - 1ull;
     }
+    const int cnt = __popcll(m);
     int incl = cnt;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
-      int v = __shfl_up(incl, d);
-      if ((tid & 63) >= d) incl += v;
+      const int v = __shfl_up(incl, d);
+      if (lane >= d) incl += v;
     }
-    __syncthreads();                       // previous iteration's s_wave readers are done
-    if ((tid & 63) == 63) s_wave[tid >> 6] = incl;
+    __syncthreads();                       // previous iteration's readers of s_i are done
+    if (lane == 63) s_i[wv] = incl;
     __syncthreads();
     int wpre = 0, tot = 0;
 #pragma unroll
-    for (int w = 0; w < 16; w++) {
-      int t = s_wave[w];
-      if (w < (tid >> 6)) wpre += t;
-      tot += t;
-    }
+    for (int k = 0; k < kNmsWaves; k++) { const int t = s_i[k]; if (k < wv) wpre += t; tot += t; }
     int slot = off + wpre + incl - cnt;
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-      if (al[k]) {
-        if (slot < cap) {
-          cidx[slot] = (uint32_t)(p0 + k);
-          if (slot == cap - 1) s_newcur = p0 + k + 1;
-        }
-        slot++;
-      }
+    while (m && slot < cap) {
+      const int b = __builtin_ctzll(m);
+      m &= m - 1;
+      const uint32_t pos = (uint32_t)(w * 64 + b);
+      cidx[slot] = pos;
+      if (slot == cap - 1) s_i[8] = (int)pos + 1;
+      slot++;
     }
     off += tot;
   }
   __syncthreads();
-  if (tid == 0) {
-    a.ccount[g] = off < cap ? off : cap;
-    a.cursor[g] = s_newcur;
-  }
+  cur = s_i[8];
+  return off < cap ? off : cap;
 }
 
-// ------------------------------------------------------------------ A1
+// ------------------------------------------------------------------ A1: pairs inside the chunk (all waves of the team)
 template <class G>
-__global__ __launch_bounds__(64) void k_chunk_pairs(NmsArgs a) {
-  __shared__ float4 rowq0[64];
-  __shared__ uint32_t rowpos[64], colpos[64];
-  __shared__ float scr[G::SCR * 64];
-  __shared__ uint32_t qbuf[128];
-
-  const int g = blockIdx.y, lane = threadIdx.x;
-  const int cn = a.ccount[g];
-  if (cn == 0) return;
+__device__ void nms_pairs(const NmsArgs& a, int g, int cn, const uint32_t* cidx, int tw, int ntw, WaveLds<G>& L) {
+  const int lane = threadIdx.x & 63;
   const int nb = (cn + 63) >> 6;
   const int items = nb * nb;
-  const uint32_t* cidx = a.cidx + (size_t)g * a.capmax;
   uint32_t* edges = a.edges + (size_t)g * a.ecap;
   const bool cull = a.cull != 0;
-  PairQueue Q{qbuf, 0, 0};
+  PairQueue Q{L.qbuf, 0, 0};
 
-  for (int item = blockIdx.x; item < items; item += gridDim.x) {
+  for (int item = tw; item < items; item += ntw) {
     const int rb = item / nb, cb = item - rb * nb;
     if (rb > cb) continue;
     const int r = rb * 64 + lane, c = cb * 64 + lane;
     const bool rvalid = r < cn, cvalid = c < cn;
     const uint32_t rp = rvalid ? cidx[r] : 0u, cp = cvalid ? cidx[c] : 0u;
-    __syncthreads();
-    rowpos[lane] = rp; colpos[lane] = cp;
-    rowq0[lane] = rvalid ? a.rec[(size_t)rp * G::RECQ] : make_float4(0.f, 0.f, 0.f, 0.f);
+    wave_sync();
+    L.rowpos[lane] = rp; L.colpos[lane] = cp;
+    L.rowq0[lane] = rvalid ? a.rec[(size_t)rp * G::RECQ] : make_float4(0.f, 0.f, 0.f, 0.f);
     const float4 cq = cvalid ? a.rec[(size_t)cp * G::RECQ] : make_float4(0.f, 0.f, 0.f, 0.f);
     const int nrow = min(64, cn - rb * 64);
     const bool diag = rb == cb;
-    __syncthreads();
+    wave_sync();
 
     auto drain = [&](int cnt) {   // wave-uniform cnt <= 64
-      __syncthreads();
+      wave_sync();
       bool hit = false;
       uint32_t packed = 0;
       if (lane < cnt) {
-        const uint32_t it = qbuf[(Q.head + lane) & 127];
+        const uint32_t it = L.qbuf[(Q.head + lane) & 127];
         const int rr = it >> 8, cc = it & 255;
-        hit = G::hit(a.rec + (size_t)rowpos[rr] * G::RECQ, a.rec + (size_t)colpos[cc] * G::RECQ, a.thr, cull, scr + lane);
+        hit = G::hit(a.rec + (size_t)L.rowpos[rr] * G::RECQ, a.rec + (size_t)L.colpos[cc] * G::RECQ, a.thr, cull, L.scr + lane);
         packed = ((uint32_t)(rb * 64 + rr) << 16) | (uint32_t)(cb * 64 + cc);
       }
-      const unsigned long long hm = __ballot(hit);
+      const u64 hm = __ballot(hit);
       if (hm) {
         int base = 0;
         if (lane == 0) base = atomicAdd(&a.nedges[g], __popcll(hm));
         base = __shfl(base, 0);
         if (hit) {
           const long long pos = (long long)base + __popcll(hm & lanemask_lt());
-          if (pos < a.ecap) edges[pos] = packed;
+          if (pos < a.ecap) stg_agent(edges + pos, packed);
         }
       }
       Q.head = (Q.head + cnt) & 127;
       Q.count -= cnt;
-      __syncthreads();
+      wave_sync();
     };
 
     for (int rr = 0; rr < nrow; rr++) {
-      const float4 rq = rowq0[rr];
+      const float4 rq = L.rowq0[rr];
       bool pass = cvalid && (!diag || lane > rr);
       if (pass && cull) pass = !G::cheap_reject(rq, cq);
       if (__ballot(pass)) {
@@ -204,56 +259,49 @@ __global__ __launch_bounds__(64) void k_chunk_pairs(NmsArgs a) {
   }
 }
 
-// ------------------------------------------------------------------ A2
-// One workgroup (1024 threads) per segment.
-__global__ __launch_bounds__(1024) void k_chunk_resolve(NmsArgs a) {
-  extern __shared__ uint8_t smem[];   // state[capmax] | blocked[capmax]
-  __shared__ int s_remain, s_wave_tot[16], s_total;
-  const int g = blockIdx.x, tid = threadIdx.x;
-  const int cn = a.ccount[g];
-  if (cn == 0) {
-    if (tid == 0) { a.nrows[g] = 0; a.nedges[g] = 0; }
-    return;
-  }
+// ------------------------------------------------------------------ A2: resolve the chunk (serial section, 512 threads)
+// returns the number of kept boxes of the chunk (also published in nrows[g])
+__device__ int nms_resolve(const NmsArgs& a, int g, int cn, int kept_before, const uint32_t* cidx, uint8_t* smem, int* s_i) {
+  const int tid = threadIdx.x;
   uint8_t* state = smem;              // 0 undecided, 1 kept, 2 dead
   uint8_t* blocked = smem + a.capmax;
-  for (int j = tid; j < a.capmax; j += 1024) { state[j] = (j < cn) ? 0 : 2; blocked[j] = 0; }
-  long long E = a.nedges[g];
+  for (int j = tid; j < a.capmax; j += kNmsThreads) { state[j] = (j < cn) ? 0 : 2; blocked[j] = 0; }
+  long long E = ldg_agent(a.nedges + g);
   if (E > a.ecap) E = a.ecap;         // cannot happen: ecap is the worst case capmax*(capmax-1)/2
-  const uint32_t* edges = a.edges + (size_t)g * a.ecap;
+  const uint32_t* edges = a.edges + (size_t)g * a.ecap;   // plain loads: acquired in serial_begin
   __syncthreads();
 
   for (int round = 0;; round++) {
     if (round > 0) {
-      for (long long k = tid; k < E; k += 1024) {
+      for (long long k = tid; k < E; k += kNmsThreads) {
         const uint32_t ed = edges[k];
         const int i = ed >> 16, j = ed & 0xffff;
         if (state[i] == 1 && state[j] == 0) state[j] = 2;
       }
       __syncthreads();
     }
-    for (long long k = tid; k < E; k += 1024) {
+    for (long long k = tid; k < E; k += kNmsThreads) {
       const uint32_t ed = edges[k];
       const int i = ed >> 16, j = ed & 0xffff;
       if (state[i] == 0 && state[j] == 0) blocked[j] = 1;
     }
-    if (tid == 0) s_remain = 0;
+    if (tid == 0) s_i[9] = 0;
     __syncthreads();
     bool rem = false;
-    for (int j = tid; j < cn; j += 1024) {
+    for (int j = tid; j < cn; j += kNmsThreads) {
       if (state[j] == 0) {
         if (blocked[j]) { rem = true; blocked[j] = 0; }
         else state[j] = 1;
       }
     }
-    if (rem) s_remain = 1;
+    if (rem) s_i[9] = 1;
     __syncthreads();
-    if (!s_remain) break;
+    if (!s_i[9]) break;
     __syncthreads();
   }
 
   // ordered compaction of the kept boxes: thread t owns chunk positions [t*per, (t+1)*per)
-  const int per = (a.capmax + 1023) / 1024;
+  const int per = (a.capmax + kNmsThreads - 1) / kNmsThreads;
   int mine = 0;
   for (int q = 0; q < per; q++) {
     const int j = tid * per + q;
@@ -262,110 +310,177 @@ __global__ __launch_bounds__(1024) void k_chunk_resolve(NmsArgs a) {
   int incl = mine;
 #pragma unroll
   for (int d = 1; d < 64; d <<= 1) {
-    int v = __shfl_up(incl, d);
+    const int v = __shfl_up(incl, d);
     if ((tid & 63) >= d) incl += v;
   }
-  if ((tid & 63) == 63) s_wave_tot[tid >> 6] = incl;
+  if ((tid & 63) == 63) s_i[tid >> 6] = incl;
   __syncthreads();
-  if (tid == 0) {
-    int acc = 0;
-    for (int w = 0; w < 16; w++) { int t = s_wave_tot[w]; s_wave_tot[w] = acc; acc += t; }
-    s_total = acc;
-  }
-  __syncthreads();
-  int rank = s_wave_tot[tid >> 6] + incl - mine;
-  const int cnt0 = a.keep_cnt[g];
+  int wpre = 0, total = 0;
+#pragma unroll
+  for (int k = 0; k < kNmsWaves; k++) { const int t = s_i[k]; if (k < (tid >> 6)) wpre += t; total += t; }
+  int rank = wpre + incl - mine;
   const int sb = a.seg_begin[g];
-  const uint32_t* cidx = a.cidx + (size_t)g * a.capmax;
   uint32_t* rows = a.rows + (size_t)g * a.capmax;
   for (int q = 0; q < per; q++) {
     const int j = tid * per + q;
     if (j < cn && state[j] == 1) {
       const uint32_t pos = cidx[j];
-      rows[rank] = pos;
-      const long long o = (long long)cnt0 + rank;
+      stg_agent(rows + rank, pos);
+      const long long o = (long long)kept_before + rank;
       if (a.max_keep <= 0 || o < a.max_keep) a.keep_out[(size_t)sb + o] = (int64_t)a.order[pos];
       rank++;
     }
   }
-  __syncthreads();
   if (tid == 0) {
-    a.nrows[g] = s_total;
-    a.keep_cnt[g] = cnt0 + s_total;
-    a.nedges[g] = 0;
+    stg_agent(a.nrows + g, total);
+    stg_agent(a.nedges + g, 0);
+    stg_agent(a.keep_cnt + g, kept_before + total);   // write-through: resolvers of different steps sit on different XCDs
+  }
+  __syncthreads();
+  return total;
+}
+
+// ------------------------------------------------------------------ B: kept rows x still-alive later positions
+template <class G>
+__device__ void nms_cross(const NmsArgs& a, int g, int nr, int c0, int se, int tw, int ntw, WaveLds<G>& L) {
+  const int lane = threadIdx.x & 63;
+  const int w0 = c0 >> 6, w1 = (se - 1) >> 6;
+  const int ncw = w1 - w0 + 1, nrt = (nr + 63) >> 6;
+  // split the row tiles of one column word over several waves only when there are fewer column words than waves
+  int rgn = (8 * ntw + ncw - 1) / ncw;
+  if (rgn < 1) rgn = 1;
+  if (rgn > nrt) rgn = nrt;
+  const int rt_per = (nrt + rgn - 1) / rgn;
+  const long long items = (long long)ncw * rgn;
+  const uint32_t* rows = a.rows + (size_t)g * a.capmax;
+  const bool cull = a.cull != 0;
+  PairQueue Q{L.qbuf, 0, 0};
+
+  for (long long item = tw; item < items; item += ntw) {
+    const int cw = (int)(item / rgn), rgi = (int)(item - (long long)cw * rgn);
+    const int w = w0 + cw;
+    const int cbase = w * 64;
+    const int c = cbase + lane;
+    u64 m = ldg_agent(a.alive + w);
+    if (cbase < c0) m &= ~((1ull << (c0 - cbase)) - 1ull);
+    if (cbase + 64 > se) m &= (1ull << (se - cbase)) - 1ull;
+    if (m == 0ull) continue;
+    const bool alive0 = (m >> lane) & 1ull;
+    const float4 cq = alive0 ? a.rec[(size_t)c * G::RECQ] : make_float4(0.f, 0.f, 0.f, 0.f);
+    bool alive = alive0;
+    wave_sync();
+    L.cdead[lane] = alive0 ? 0 : 1;
+    const int rt_lo = rgi * rt_per, rt_hi = min(nrt, rt_lo + rt_per);
+
+    for (int rt = rt_lo; rt < rt_hi; rt++) {
+      if (__ballot(alive) == 0ull) break;
+      const int rr0 = rt * 64;
+      const int nrow = min(64, nr - rr0);
+      wave_sync();
+      {
+        const uint32_t rp = lane < nrow ? ldg_agent(rows + rr0 + lane) : 0u;
+        L.rowpos[lane] = rp;
+        L.rowq0[lane] = lane < nrow ? a.rec[(size_t)rp * G::RECQ] : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      wave_sync();
+
+      auto drain = [&](int cnt) {
+        wave_sync();
+        if (lane < cnt) {
+          const uint32_t it = L.qbuf[(Q.head + lane) & 127];
+          const int rr = it >> 8, cc = it & 255;
+          if (!L.cdead[cc]) {
+            if (G::hit(a.rec + (size_t)L.rowpos[rr] * G::RECQ, a.rec + (size_t)(cbase + cc) * G::RECQ, a.thr, cull, L.scr + lane))
+              L.cdead[cc] = 1;
+          }
+        }
+        Q.head = (Q.head + cnt) & 127;
+        Q.count -= cnt;
+        wave_sync();
+      };
+
+      for (int rr = 0; rr < nrow; rr++) {
+        const float4 rq = L.rowq0[rr];
+        bool pass = alive;
+        if (pass && cull) pass = !G::cheap_reject(rq, cq);
+        if (__ballot(pass)) {
+          Q.push(pass, ((uint32_t)rr << 8) | (uint32_t)lane);
+          if (Q.count >= 64) {
+            drain(64);
+            alive = alive && !L.cdead[lane];
+          }
+        }
+      }
+      if (Q.count > 0) { drain(Q.count); alive = alive && !L.cdead[lane]; }
+    }
+    const u64 kill = __ballot(alive0 && !alive);
+    if (kill && lane == 0) {
+      // RETURNING atomic whose result is consumed: the wave's vmcnt then covers the completed read-modify-write
+      // (a fire-and-forget atomic is only counted until the local L2 accepted it)
+      const u64 old = atomicAnd(a.alive + w, ~kill);
+      asm volatile("; kill applied %0" ::"v"((unsigned)(old >> 32) ^ (unsigned)old));
+    }
   }
 }
 
-// ------------------------------------------------------------------ B
-// Work item = (tile of 64 later positions, tile of 64 kept rows); one wave per item.
+// ------------------------------------------------------------------ the persistent kernel
+// dynamic LDS: [kNmsWaves x WaveLds<G>] (aliased by the resolve state) | chunk list [capmax] u32
 template <class G>
-__global__ __launch_bounds__(64) void k_cross(NmsArgs a) {
-  __shared__ float4 rowq0[64];
-  __shared__ uint32_t rowpos[64];
-  __shared__ float scr[G::SCR * 64];
-  __shared__ uint32_t qbuf[128];
-  __shared__ uint8_t cdead[64];
+__global__ __launch_bounds__(kNmsThreads) void k_nms_persist(NmsArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __shared__ int s_i[16];
+  __shared__ int s_flag;
+  const int tid = threadIdx.x, wv = tid >> 6;
+  const int NB = gridDim.x;
+  const int nteams = a.nseg < NB ? a.nseg : NB;
+  const int T = NB / nteams;
+  const int team = blockIdx.x / T, wg = blockIdx.x - team * T;
+  if (team >= nteams) return;
+  WaveLds<G>& L = reinterpret_cast<WaveLds<G>*>(smem)[wv];
+  uint32_t* cidx = reinterpret_cast<uint32_t*>(smem + sizeof(WaveLds<G>) * kNmsWaves);
+  const int tw = wg * kNmsWaves + wv, ntw = T * kNmsWaves;
+  TeamBar bar{a.bar + (size_t)team * 128, a.bar + (size_t)team * 128 + 64, T, 0, a.abort_flag};
 
-  const int g = blockIdx.y, lane = threadIdx.x;
-  const int nr = a.nrows[g];
-  if (nr == 0 || seg_done(a, g)) return;
-  const int c0 = a.cursor[g], se = a.seg_end[g];
-  if (c0 >= se) return;
-  const int nct = (se - c0 + 63) >> 6, nrt = (nr + 63) >> 6;
-  const long long items = (long long)nct * nrt;
-  const uint32_t* rows = a.rows + (size_t)g * a.capmax;
-  const bool cull = a.cull != 0;
-  PairQueue Q{qbuf, 0, 0};
+  const bool prof = a.prof != nullptr && blockIdx.x == 0 && tid == 0;
+  u64 t0 = prof ? wall_clock64() : 0ull;
+  auto lap = [&](int slot) {
+    if (prof) { const u64 t1 = wall_clock64(); a.prof[slot] += t1 - t0; t0 = t1; }
+  };
 
-  for (long long item = blockIdx.x; item < items; item += gridDim.x) {
-    const int ct = (int)(item / nrt), rt = (int)(item - (long long)ct * nrt);
-    const int cbase = c0 + ct * 64;
-    const int c = cbase + lane;
-    const bool cvalid = c < se;
-    const bool alive0 = cvalid && !a.dead[c];
-    if (__ballot(alive0) == 0ull) continue;
-    const int rr0 = rt * 64;
-    const int nrow = min(64, nr - rr0);
-    __syncthreads();
-    {
-      const uint32_t rp = lane < nrow ? rows[rr0 + lane] : 0u;
-      rowpos[lane] = rp;
-      rowq0[lane] = lane < nrow ? a.rec[(size_t)rp * G::RECQ] : make_float4(0.f, 0.f, 0.f, 0.f);
-      cdead[lane] = alive0 ? 0 : 1;
-    }
-    const float4 cq = cvalid ? a.rec[(size_t)c * G::RECQ] : make_float4(0.f, 0.f, 0.f, 0.f);
-    bool alive = alive0;
-    __syncthreads();
-
-    auto drain = [&](int cnt) {
-      __syncthreads();
-      if (lane < cnt) {
-        const uint32_t it = qbuf[(Q.head + lane) & 127];
-        const int rr = it >> 8, cc = it & 255;
-        if (!cdead[cc]) {
-          if (G::hit(a.rec + (size_t)rowpos[rr] * G::RECQ, a.rec + (size_t)(cbase + cc) * G::RECQ, a.thr, cull, scr + lane))
-            cdead[cc] = 1;
-        }
+  for (int g = team; g < a.nseg; g += nteams) {
+    const int se = a.seg_end[g];
+    int cur = a.seg_begin[g], kept = 0;
+    int cap = a.cap_first < a.capmax ? a.cap_first : a.capmax;
+    while (cur < se && !(a.max_keep > 0 && kept >= a.max_keep)) {
+      const int cn = nms_select(a, se, cur, cap, cidx, s_i);
+      lap(1);
+      if (cn == 0) break;
+      nms_pairs<G>(a, g, cn, cidx, tw, ntw, L);
+      lap(2);
+      // ---- all edges are out: the last arriver resolves the chunk, the others wait for its rows
+      if (serial_begin(bar, &s_flag)) {
+        lap(3);
+        const u64 ts = (a.prof && tid == 0) ? wall_clock64() : 0ull;
+        nms_resolve(a, g, cn, kept, cidx, smem, s_i);
+        serial_end(bar);
+        if (a.prof && tid == 0) { atomicAdd(a.prof + 9, wall_clock64() - ts); }
+        lap(4);
+      } else {
+        if (!serial_wait(bar, &s_flag)) return;
+        lap(3);
       }
-      Q.head = (Q.head + cnt) & 127;
-      Q.count -= cnt;
-      __syncthreads();
-    };
-
-    for (int rr = 0; rr < nrow; rr++) {
-      const float4 rq = rowq0[rr];
-      bool pass = alive;
-      if (pass && cull) pass = !G::cheap_reject(rq, cq);
-      if (__ballot(pass)) {
-        Q.push(pass, ((uint32_t)rr << 8) | (uint32_t)lane);
-        if (Q.count >= 64) {
-          drain(64);
-          alive = alive && !cdead[lane];
-        }
+      const int nr = ldg_agent(a.nrows + g);
+      kept += nr;
+      const bool more = cur < se && !(a.max_keep > 0 && kept >= a.max_keep);
+      if (nr > 0 && more) {
+        nms_cross<G>(a, g, nr, cur, se, tw, ntw, L);
+        lap(5);
+        if (!team_barrier(bar, &s_flag)) return;       // the kills are visible before anybody selects again
+        lap(0);
       }
+      if (prof) a.prof[6] += 1;
+      if (cap < a.capmax) { cap *= 2; if (cap > a.capmax) cap = a.capmax; }
     }
-    if (Q.count > 0) drain(Q.count);
-    if (alive0 && cdead[lane]) a.dead[c] = 1;
   }
 }
 

@@ -267,33 +267,40 @@ __global__ void k_cand_segments(const int* __restrict__ cnt, int bs, long long c
 
 __global__ void k_prep_cand(const float4* __restrict__ cand, const uint32_t* __restrict__ vals_sorted,
                             const int* __restrict__ seg_begin, const int* __restrict__ seg_end, long long cap_img,
-                            float class_offset, float4* __restrict__ rec, uint8_t* __restrict__ dead, uint32_t* __restrict__ order) {
+                            float class_offset, float4* __restrict__ rec, u64* __restrict__ alive, uint32_t* __restrict__ order) {
+  // seg_begin[g] = g * cap_img with cap_img a multiple of 64: every wave covers exactly one word of the alive bitmap
   const int g = blockIdx.y;
   const int p = seg_begin[g] + blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= seg_end[g]) return;
-  const size_t ci = (size_t)g * cap_img + vals_sorted[p];
-  const float4 c0 = cand[ci * 2], c1 = cand[ci * 2 + 1];
-  const float off = c1.z * class_offset;                       // :849  c = x[:, 6:7] * (0 if agnostic else max_wh)
-  const float x = c0.x + off, y = c0.y + off;                  // :851
-  RBoxFeat f = rbox_make_feat(x, y, c0.z, c0.w, c1.x);
-  float4 q[4];
-  RotGeom::pack(f, q);
+  const int se = seg_end[g];
+  bool ok = false;
+  if (p < se) {
+    const size_t ci = (size_t)g * cap_img + vals_sorted[p];
+    const float4 c0 = cand[ci * 2], c1 = cand[ci * 2 + 1];
+    const float off = c1.z * class_offset;                       // :849  c = x[:, 6:7] * (0 if agnostic else max_wh)
+    const float x = c0.x + off, y = c0.y + off;                  // :851
+    RBoxFeat f = rbox_make_feat(x, y, c0.z, c0.w, c1.x);
+    float4 q[4];
+    RotGeom::pack(f, q);
 #pragma unroll
-  for (int k = 0; k < 4; k++) rec[(size_t)p * 4 + k] = q[k];
-  const float mn = (c0.w < c0.z) ? c0.w : c0.z;
-  dead[p] = (mn < 0.001f) ? 1 : 0;                             // nms_rotated_wrapper.py:32
-  order[p] = (uint32_t)ci;
+    for (int k = 0; k < 4; k++) rec[(size_t)p * 4 + k] = q[k];
+    const float mn = (c0.w < c0.z) ? c0.w : c0.z;
+    ok = !(mn < 0.001f);                                         // nms_rotated_wrapper.py:32
+    order[p] = (uint32_t)ci;
+  }
+  const u64 m = __ballot(ok);
+  if ((threadIdx.x & 63) == 0 && m) alive[p >> 6] = m;           // the bitmap was zeroed before
 }
 
 __global__ void k_gather_out(const float4* __restrict__ cand, const int64_t* __restrict__ keep, const int* __restrict__ seg_begin,
                              const int* __restrict__ keep_cnt, long long max_det, float* __restrict__ out, int64_t* __restrict__ out_count,
-                             const int* __restrict__ cnt, long long cap_img, int64_t* __restrict__ status) {
+                             const int* __restrict__ cnt, long long cap_img, int64_t* __restrict__ status,
+                             const int* __restrict__ abort_flag) {
   const int g = blockIdx.y;
   long long nk = keep_cnt[g];
   if (max_det > 0 && nk > max_det) nk = max_det;
   const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (k == 0) {
-    out_count[g] = nk;
+    out_count[g] = *abort_flag ? -1 : nk;                        // -1: the NMS kernel gave up on a barrier (host raises)
     if (cnt[g * kCntPad] > cap_img) atomicMax((unsigned long long*)status, (unsigned long long)cnt[g * kCntPad]);   // overflow: caller retries
   }
   if (k >= nk) return;
@@ -319,7 +326,10 @@ static hipError_t seg_sort_tmp_query(size_t n, int nseg, size_t* bytes) {
                                              (int*)nullptr, (int*)nullptr, 0, 64, (hipStream_t)0, false);
 }
 
+static inline int64_t round_cap(int64_t cap_img) { return (cap_img + 63) / 64 * 64; }   // image regions start on alive-bitmap words
+
 static int obb_carve(void* base, int64_t bs, int64_t cap_img, ObbCarve* cv) {
+  cap_img = round_cap(cap_img);
   size_t off = 0;
   auto take = [&](size_t bytes) { size_t o = off; off += align_up(bytes); return base ? (char*)base + o : (char*)nullptr; };
   const size_t n = (size_t)bs * cap_img;
@@ -348,6 +358,7 @@ static int run_nms_obb(const void* pred, int dtype, int64_t bs, int64_t A, int64
     return OBB_ERR_BAD_ARG;
   if (A * nc + n_extra > 0xffffffffLL || bs * cap_img > 0x7fffffffLL) return OBB_ERR_BAD_ARG;
   if (dtype != 0 && dtype != 1) return OBB_ERR_BAD_ARG;
+  cap_img = round_cap(cap_img);
   ObbCarve cv;
   int rc = obb_carve(ws, bs, cap_img, &cv);
   if (rc) return rc;
@@ -389,24 +400,27 @@ static int run_nms_obb(const void* pred, int dtype, int64_t bs, int64_t A, int64
   dim3 gp((unsigned)((max_seg + 255) / 256), (unsigned)bs);
   {
     ProfScope ps(PROF_PREP, st);
+    hipMemsetAsync(nv.alive, 0, nv.alive_bytes, st);
     k_prep_cand<<<gp, 256, 0, st>>>(cv.cand, cv.vals_b, nv.seg_begin, nv.seg_end, cap_img, agnostic ? 0.f : max_wh, nv.rec,
-                                    nv.dead, nv.vals_b);
+                                    nv.alive, nv.vals_b);
   }
 
   NmsArgs a;
-  a.rec = nv.rec; a.order = nv.vals_b; a.dead = nv.dead; a.seg_begin = nv.seg_begin; a.seg_end = nv.seg_end;
-  a.cursor = nv.cursor; a.keep_cnt = nv.keep_cnt; a.keep_out = cv.keep; a.cidx = nv.cidx; a.ccount = nv.ccount;
+  a.rec = nv.rec; a.order = nv.vals_b; a.alive = nv.alive; a.seg_begin = nv.seg_begin; a.seg_end = nv.seg_end;
+  a.keep_cnt = nv.keep_cnt; a.keep_out = cv.keep;
   a.rows = nv.rows; a.nrows = nv.nrows; a.edges = nv.edges; a.nedges = nv.nedges;
   a.ecap = nv.ecap; a.n = (int)(bs * cap_img); a.capmax = cap_max(bs);
   a.max_keep = (int)max_det; a.thr = iou_thres; a.cull = (iou_thres >= 0.f) ? 1 : 0;
   {
     ProfScope ps(PROF_STEPS, st);
-    nms_steps(0, a, bs, max_seg, st);
+    rc = nms_steps(0, a, nv, bs, bs * max_seg, st);
+    if (rc) return rc;
   }
   dim3 go((unsigned)((max_det + 255) / 256), (unsigned)bs);
   {
     ProfScope ps(PROF_GATHER, st);
-    k_gather_out<<<go, 256, 0, st>>>(cv.cand, cv.keep, nv.seg_begin, nv.keep_cnt, max_det, out, out_count, cv.cnt, cap_img, status);
+    k_gather_out<<<go, 256, 0, st>>>(cv.cand, cv.keep, nv.seg_begin, nv.keep_cnt, max_det, out, out_count, cv.cnt, cap_img, status,
+                                   nv.abort_flag);
   }
   return hipGetLastError() == hipSuccess ? OBB_OK : OBB_ERR_LAUNCH;
 }

@@ -23,7 +23,7 @@ def _run_rotated(dets, scores, iou_threshold, flags=0, max_keep=0):
         rc = L.obb_nms_rotated_f32(_lib.ptr(dets), _lib.ptr(scores), n, float(iou_threshold), int(flags), int(max_keep),
                                    _lib.ptr(keep), _lib.ptr(cnt), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev))
     _lib.check(rc, "obb_nms_rotated_f32")
-    return keep[: int(cnt.item())]
+    return keep[: _lib.checked_count(int(cnt.item()), "obb_nms_rotated_f32")]
 
 
 def nms_rotated(dets, scores, iou_threshold):
@@ -72,4 +72,4 @@ def nms_poly(dets, iou_threshold):
         rc = L.obb_nms_poly_f32(_lib.ptr(dets), stride, n, float(iou_threshold), 0, _lib.ptr(keep), _lib.ptr(cnt),
                                 _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev))
     _lib.check(rc, "obb_nms_poly_f32")
-    return keep[: int(cnt.item())]
+    return keep[: _lib.checked_count(int(cnt.item()), "obb_nms_poly_f32")]

@@ -99,6 +99,8 @@ def non_max_suppression_obb(prediction, conf_thres=0.25, iou_thres=0.45, classes
                 C.c_void_p(meta.data_ptr() + 8 * bs), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev))
         _lib.check(rc, "obb_non_max_suppression_obb")
         m = meta.tolist()                                             # the single device->host sync of the call
+        for b in range(bs):
+            _lib.checked_count(m[b], "obb_non_max_suppression_obb")
         if m[bs] > cap:                                               # an image produced more candidates than slots
             cap = min(worst, max(int(m[bs]), 2 * cap))
             continue
