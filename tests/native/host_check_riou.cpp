@@ -16,6 +16,9 @@ int main(int argc, char** argv) {
   std::mt19937 g(seed);
   std::uniform_real_distribution<float> U(0.f, 1.f);
   long mism = 0, cullv = 0, ubv = 0, culled = 0, nonzero = 0;
+  long fb_safe = 0, fb_viol = 0, fb_cand = 0, fb_decided[4] = {0, 0, 0, 0};
+  const float thrs[4] = {0.1f, 0.2f, 0.4f, 0.45f};
+  double fb_width = 0.0;
   float px[24], py[24];
   for (long i = 0; i < n; i++) {
     float a[5], b[5];
@@ -39,7 +42,21 @@ int main(int argc, char** argv) {
     if (obb::rbox_certainly_disjoint(A, B)) { culled++; if (ref != 0.f) cullv++; }
     if (ref > obb::rbox_iou_upper_bound(A, B)) ubv++;
     if (ref > 0) nonzero++;
+    // fast interval filter: must contain the reference value whenever it vouches for the pair
+    if (!obb::rbox_certainly_disjoint(A, B)) {
+      fb_cand++;
+      obb::IouBounds bd;
+      if (obb::rbox_fast_iou_bounds(A, B, &bd)) {
+        fb_safe++;
+        fb_width += (double)(bd.hi - bd.lo);
+        if (!(bd.lo <= ref && ref <= bd.hi)) { if (fb_viol < 8) printf("BOUND VIOLATION mode %d ref %.9g lo %.9g hi %.9g\n", mode, ref, bd.lo, bd.hi); fb_viol++; }
+        for (int q = 0; q < 4; q++) if (bd.lo > thrs[q] || bd.hi <= thrs[q]) fb_decided[q]++;
+      }
+    }
   }
+  printf("fast_bounds: candidates=%ld vouched=%ld violations=%ld mean_width=%.3g decided@0.1/0.2/0.4/0.45=%ld/%ld/%ld/%ld\n", fb_cand, fb_safe,
+         fb_viol, fb_safe ? fb_width / fb_safe : 0.0, fb_decided[0], fb_decided[1], fb_decided[2], fb_decided[3]);
+  if (fb_viol) return 1;
   printf("mismatches=%ld cull_violations=%ld ub_violations=%ld culled=%ld nonzero=%ld n=%ld\n", mism, cullv, ubv, culled, nonzero, n);
   return (mism || cullv || ubv) ? 1 : 0;
 }

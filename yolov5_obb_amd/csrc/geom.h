@@ -41,14 +41,28 @@ struct RotGeom {
     bool wc = fminf(a.w, b.w) >= 2e-5f * M;
     return wc && (dx * dx + dy * dy > rs * rs);
   }
-  // Survivors: separating-axis reject, area-ratio bound, then the exact clip.  Returns IoU > thr.
-  static __device__ __forceinline__ bool hit(const float4* ra, const float4* rb, float thr, bool cull, float* scr) {
+  // Two-stage decision of "IoU > thr" for the pairs that survive the hot loop.
+  //   classify  registers only: separating-axis reject, area-ratio bound, then the IoU interval of
+  //             rbox_fast_iou_bounds -- answers 0 (no) / 1 (yes) whenever the whole interval lies on one side of the
+  //             threshold, 2 = undecided (a few % of the pairs);
+  //   hit_exact the reference's clip + Graham scan, bit for bit, on the LDS scratch column of the lane.
+  static constexpr bool HAS_FAST = true;
+  static __device__ __forceinline__ int classify(const float4* ra, const float4* rb, float thr, bool cull) {
+    if (!cull) return 2;
     RBoxFeat A = unpack(ra[0], ra[1], ra[2], ra[3]);
     RBoxFeat B = unpack(rb[0], rb[1], rb[2], rb[3]);
-    if (cull) {
-      if (rbox_certainly_disjoint(A, B)) return false;
-      if (rbox_iou_upper_bound(A, B) <= thr) return false;
+    if (rbox_certainly_disjoint(A, B)) return 0;
+    if (rbox_iou_upper_bound(A, B) <= thr) return 0;
+    IouBounds bd;
+    if (rbox_fast_iou_bounds(A, B, &bd)) {
+      if (bd.lo > thr) return 1;
+      if (bd.hi <= thr) return 0;
     }
+    return 2;
+  }
+  static __device__ __forceinline__ bool hit_exact(const float4* ra, const float4* rb, float thr, float* scr) {
+    RBoxFeat A = unpack(ra[0], ra[1], ra[2], ra[3]);
+    RBoxFeat B = unpack(rb[0], rb[1], rb[2], rb[3]);
     return rbox_iou<64>(A, B, scr, scr + 24 * 64) > thr;
   }
 };
@@ -71,7 +85,9 @@ struct QuadGeom {
   static __device__ __forceinline__ float iou(const QuadFeat& A, const QuadFeat& B, float* scr) {
     return quad_iou<64>(A, B, scr, scr + 10 * 64, scr + 20 * 64, scr + 30 * 64);
   }
-  static __device__ __forceinline__ bool hit(const float4* ra, const float4* rb, float thr, bool, float* scr) {
+  static constexpr bool HAS_FAST = false;      // every pair is undecided: the reference's value is not predictable (see above)
+  static __device__ __forceinline__ int classify(const float4*, const float4*, float, bool) { return 2; }
+  static __device__ __forceinline__ bool hit_exact(const float4* ra, const float4* rb, float thr, float* scr) {
     return iou(unpack(ra[0], ra[1]), unpack(rb[0], rb[1]), scr) > thr;
   }
 };

@@ -78,6 +78,25 @@ __global__ void k_make_keys(const float* __restrict__ scores, int score_stride, 
   vals[i] = (uint32_t)i;
 }
 
+// single list, no explicit tie word: 32-bit keys (half the sort traffic, half the radix passes)
+__global__ void k_make_keys32(const float* __restrict__ scores, int score_stride, const float* __restrict__ dets5, int drop_small,
+                              int n, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint32_t k = score_desc_key(scores[(size_t)i * score_stride]);
+  if (drop_small) {
+    float w = dets5[(size_t)i * 5 + 2], h = dets5[(size_t)i * 5 + 3];
+    float mn = (h < w) ? h : w;
+    if (mn < 0.001f) k = 0xFFFFFFFFu;
+  }
+  keys[i] = k;
+  vals[i] = (uint32_t)i;
+}
+
+__global__ void k_seg_single(int n, int* seg_begin, int* seg_end, int* keep_cnt, int* nrows, int* nedges) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) { seg_begin[0] = 0; seg_end[0] = n; keep_cnt[0] = 0; nrows[0] = 0; nedges[0] = 0; }
+}
+
 __device__ __forceinline__ int key_lower_bound(const uint64_t* keys, int n, uint64_t target) {
   int lo = 0, hi = n;
   while (lo < hi) {
@@ -183,8 +202,14 @@ struct Carve {
 
 static hipError_t sort_tmp_query(size_t n, size_t* bytes) {
   *bytes = 0;
-  return rocprim::radix_sort_pairs(nullptr, *bytes, (uint64_t*)nullptr, (uint64_t*)nullptr, (uint32_t*)nullptr,
-                                   (uint32_t*)nullptr, n, 0, 64, (hipStream_t)0, false);
+  size_t b64 = 0, b32 = 0;
+  hipError_t e = rocprim::radix_sort_pairs(nullptr, b64, (uint64_t*)nullptr, (uint64_t*)nullptr, (uint32_t*)nullptr,
+                                           (uint32_t*)nullptr, n, 0, 64, (hipStream_t)0, false);
+  if (e != hipSuccess) return e;
+  e = rocprim::radix_sort_pairs(nullptr, b32, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, n, 0,
+                                32, (hipStream_t)0, false);
+  *bytes = b64 > b32 ? b64 : b32;
+  return e;
 }
 
 static int carve(void* base, int64_t n, int64_t nseg, int recq, int C, Carve* cv) {
@@ -256,8 +281,8 @@ static int nms_steps(int kind, NmsArgs& a, const Carve& cv, int64_t nseg, int64_
   if (phase_prof) {   // development aid: print the previous call's phase times (synchronises!)
     u64 h[16];
     if (hipMemcpy(h, cv.prof, sizeof h, hipMemcpyDeviceToHost) == hipSuccess && h[6] > 0 && h[6] < (1ull << 40))
-      fprintf(stderr, "[nms phases, wg0, us] select %.1f pairs %.1f wait-resolve %.1f cross %.1f barrier %.1f steps %llu | resolve (any wg) %.1f\n",
-              h[1] * 0.01, h[2] * 0.01, h[3] * 0.01, h[5] * 0.01, h[0] * 0.01, h[6], h[9] * 0.01);
+      fprintf(stderr, "[nms phases, wg0, us] select %.1f pairs %.1f wait-resolve %.1f cross %.1f barrier %.1f steps %llu | resolve (any wg) %.1f rounds %llu [first round %.1f other rounds %.1f output %.1f]\n",
+              h[1] * 0.01, h[2] * 0.01, h[3] * 0.01, h[5] * 0.01, h[0] * 0.01, h[6], h[9] * 0.01, h[11], h[12] * 0.01, h[13] * 0.01, h[14] * 0.01);
     hipMemsetAsync(cv.prof, 0, 16 * 8, st);
     a.prof = cv.prof;
   }
@@ -269,6 +294,7 @@ static int nms_steps(int kind, NmsArgs& a, const Carve& cv, int64_t nseg, int64_
     const int64_t tiles = ((c + 63) / 64) * ((c + 63) / 64 + 1) / 2 * nseg;
     if (nb < (tiles + 7) / 8) nb = (tiles + 7) / 8;
   }
+  if (n_slots >= 8192) nb = cus;                      // enough work for the whole chip
   if (nb < nseg) nb = nseg;
   if (nb > cus) nb = cus;
   if (nb < 1) nb = 1;
@@ -305,14 +331,24 @@ static int run_nms(int kind, const float* boxes, int stride, const float* scores
   const unsigned gb = (unsigned)((n + T - 1) / T);
   {
     ProfScope ps(PROF_NMS_SORT, st);
-    k_make_keys<<<gb, T, 0, st>>>(scores, score_stride, seg_id, tie, tie_bits, kind == 0 ? boxes : nullptr,
-                                  kind == 0 ? drop_small : 0, (int)n, cv.keys_a, cv.vals_a);
     size_t tmp = cv.sort_tmp_bytes;
-    if (rocprim::radix_sort_pairs(cv.sort_tmp, tmp, cv.keys_a, cv.keys_b, cv.vals_a, cv.vals_b, (size_t)n, 0,
-                                  (unsigned)(32 + tie_bits + seg_bits), st, false) != hipSuccess)
-      return OBB_ERR_LAUNCH;
-    k_seg_bounds<<<gseg, T, 0, st>>>(cv.keys_b, (int)n, (int)nseg, 32 + tie_bits, 0, cv.seg_begin, cv.seg_end, cv.cursor,
-                                     cv.keep_cnt, cv.ccount, cv.nrows, cv.nedges);
+    if (nseg == 1 && tie_bits == 0) {
+      uint32_t* k32a = reinterpret_cast<uint32_t*>(cv.keys_a);
+      uint32_t* k32b = reinterpret_cast<uint32_t*>(cv.keys_b);
+      k_make_keys32<<<gb, T, 0, st>>>(scores, score_stride, kind == 0 ? boxes : nullptr, kind == 0 ? drop_small : 0, (int)n, k32a,
+                                      cv.vals_a);
+      if (rocprim::radix_sort_pairs(cv.sort_tmp, tmp, k32a, k32b, cv.vals_a, cv.vals_b, (size_t)n, 0, 32, st, false) != hipSuccess)
+        return OBB_ERR_LAUNCH;
+      k_seg_single<<<1, 64, 0, st>>>((int)n, cv.seg_begin, cv.seg_end, cv.keep_cnt, cv.nrows, cv.nedges);
+    } else {
+      k_make_keys<<<gb, T, 0, st>>>(scores, score_stride, seg_id, tie, tie_bits, kind == 0 ? boxes : nullptr,
+                                    kind == 0 ? drop_small : 0, (int)n, cv.keys_a, cv.vals_a);
+      if (rocprim::radix_sort_pairs(cv.sort_tmp, tmp, cv.keys_a, cv.keys_b, cv.vals_a, cv.vals_b, (size_t)n, 0,
+                                    (unsigned)(32 + tie_bits + seg_bits), st, false) != hipSuccess)
+        return OBB_ERR_LAUNCH;
+      k_seg_bounds<<<gseg, T, 0, st>>>(cv.keys_b, (int)n, (int)nseg, 32 + tie_bits, 0, cv.seg_begin, cv.seg_end, cv.cursor,
+                                       cv.keep_cnt, cv.ccount, cv.nrows, cv.nedges);
+    }
   }
   {
     ProfScope ps(PROF_NMS_PREP, st);

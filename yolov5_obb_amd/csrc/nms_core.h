@@ -70,6 +70,13 @@ template <typename T> __device__ __forceinline__ void stg_agent(T* p, T v) {
 }
 __device__ __forceinline__ u64 lanemask_lt() { return (1ull << (threadIdx.x & 63)) - 1ull; }
 __device__ __forceinline__ void wave_sync() { __builtin_amdgcn_wave_barrier(); }
+// wave-uniform lane -> scalar register: the row box of the hot loop is broadcast with v_readlane (no LDS round trip)
+__device__ __forceinline__ float rdlane(float v, int l) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+}
+__device__ __forceinline__ float4 rdlane4(const float4& v, int l) {
+  return make_float4(rdlane(v.x, l), rdlane(v.y, l), rdlane(v.z, l), rdlane(v.w, l));
+}
 
 constexpr int kNmsThreads = 512;
 constexpr int kNmsWaves = kNmsThreads / 64;
@@ -114,14 +121,23 @@ __device__ __forceinline__ bool serial_begin(TeamBar& b, int* s_flag) {
   __syncthreads();
   return *s_flag != 0;
 }
+// Both sides end with ONE agent acquire: what the serial section published in bulk (the kept rows) is read with
+// plain, cacheable loads afterwards (the resolver's own CU may hold lines of the previous step as well).
 __device__ __forceinline__ void serial_end(TeamBar& b) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  if (threadIdx.x == 0) stg_agent(b.go, b.epoch + 1);
+  if (threadIdx.x == 0) {
+    stg_agent(b.go, b.epoch + 1);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  }
+  __syncthreads();
   b.epoch++;
 }
 __device__ __forceinline__ bool serial_wait(TeamBar& b, int* s_flag) {
-  if (threadIdx.x == 0) *s_flag = spin_until(b.go, b.epoch + 1, b.abort_flag) ? 0 : 1;
+  if (threadIdx.x == 0) {
+    *s_flag = spin_until(b.go, b.epoch + 1, b.abort_flag) ? 0 : 1;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  }
   __syncthreads();
   b.epoch++;
   return *s_flag == 0;
@@ -130,12 +146,14 @@ __device__ __forceinline__ bool serial_wait(TeamBar& b, int* s_flag) {
 // ------------------------------------------------------------------ per-wave LDS scratch of the pair phases
 template <class G>
 struct WaveLds {
-  float4 rowq0[64];
   uint32_t rowpos[64], colpos[64];
   float scr[G::SCR * 64];
-  uint32_t qbuf[128];
+  uint32_t qbuf[128];      // stage 1: pairs that passed the hot loop
+  uint32_t qbuf2[128];     // stage 2: pairs the register-only classifier could not decide (exact clip)
+  uint8_t q2col[128];      // cross phase: column lane of a stage-2 entry
   uint8_t cdead[64];
-  uint8_t pad[192];
+  uint8_t pad[64];
+  float4 align16[0];
 };
 
 // Ring queue of pending (row, col) pairs in LDS; all bookkeeping is wave-uniform.
@@ -205,7 +223,31 @@ __device__ void nms_pairs(const NmsArgs& a, int g, int cn, const uint32_t* cidx,
   const int items = nb * nb;
   uint32_t* edges = a.edges + (size_t)g * a.ecap;
   const bool cull = a.cull != 0;
-  PairQueue Q{L.qbuf, 0, 0};
+  PairQueue Q{L.qbuf, 0, 0}, Q2{L.qbuf2, 0, 0};
+  // stage 2: exact clip; entries are chunk-local (i << 16 | j), so the queue lives across tiles
+  auto drain2 = [&](int cnt) {
+    wave_sync();
+    bool hit = false;
+    uint32_t packed = 0;
+    if (lane < cnt) {
+      packed = L.qbuf2[(Q2.head + lane) & 127];
+      const uint32_t pi = cidx[packed >> 16], pj = cidx[packed & 0xffff];
+      hit = G::hit_exact(a.rec + (size_t)pi * G::RECQ, a.rec + (size_t)pj * G::RECQ, a.thr, L.scr + lane);
+    }
+    const u64 hm = __ballot(hit);
+    if (hm) {
+      int base = 0;
+      if (lane == 0) base = atomicAdd(&a.nedges[g], __popcll(hm));
+      base = __shfl(base, 0);
+      if (hit) {
+        const long long pos = (long long)base + __popcll(hm & lanemask_lt());
+        if (pos < a.ecap) stg_agent((a.edges + (size_t)g * a.ecap) + pos, packed);
+      }
+    }
+    Q2.head = (Q2.head + cnt) & 127;
+    Q2.count -= cnt;
+    wave_sync();
+  };
 
   for (int item = tw; item < items; item += ntw) {
     const int rb = item / nb, cb = item - rb * nb;
@@ -215,22 +257,13 @@ __device__ void nms_pairs(const NmsArgs& a, int g, int cn, const uint32_t* cidx,
     const uint32_t rp = rvalid ? cidx[r] : 0u, cp = cvalid ? cidx[c] : 0u;
     wave_sync();
     L.rowpos[lane] = rp; L.colpos[lane] = cp;
-    L.rowq0[lane] = rvalid ? a.rec[(size_t)rp * G::RECQ] : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 myrow = rvalid ? a.rec[(size_t)rp * G::RECQ] : make_float4(0.f, 0.f, 0.f, 0.f);
     const float4 cq = cvalid ? a.rec[(size_t)cp * G::RECQ] : make_float4(0.f, 0.f, 0.f, 0.f);
     const int nrow = min(64, cn - rb * 64);
     const bool diag = rb == cb;
     wave_sync();
 
-    auto drain = [&](int cnt) {   // wave-uniform cnt <= 64
-      wave_sync();
-      bool hit = false;
-      uint32_t packed = 0;
-      if (lane < cnt) {
-        const uint32_t it = L.qbuf[(Q.head + lane) & 127];
-        const int rr = it >> 8, cc = it & 255;
-        hit = G::hit(a.rec + (size_t)L.rowpos[rr] * G::RECQ, a.rec + (size_t)L.colpos[cc] * G::RECQ, a.thr, cull, L.scr + lane);
-        packed = ((uint32_t)(rb * 64 + rr) << 16) | (uint32_t)(cb * 64 + cc);
-      }
+    auto emit = [&](bool hit, uint32_t packed) {           // hits -> the segment's edge list
       const u64 hm = __ballot(hit);
       if (hm) {
         int base = 0;
@@ -241,13 +274,28 @@ __device__ void nms_pairs(const NmsArgs& a, int g, int cn, const uint32_t* cidx,
           if (pos < a.ecap) stg_agent(edges + pos, packed);
         }
       }
+    };
+    auto drain = [&](int cnt) {   // stage 1, wave-uniform cnt <= 64
+      wave_sync();
+      int res = 0;
+      uint32_t packed = 0;
+      if (lane < cnt) {
+        const uint32_t it = L.qbuf[(Q.head + lane) & 127];
+        const int rr = it >> 8, cc = it & 255;
+        res = G::classify(a.rec + (size_t)L.rowpos[rr] * G::RECQ, a.rec + (size_t)L.colpos[cc] * G::RECQ, a.thr, cull);
+        packed = ((uint32_t)(rb * 64 + rr) << 16) | (uint32_t)(cb * 64 + cc);
+      }
+      emit(res == 1, packed);
       Q.head = (Q.head + cnt) & 127;
       Q.count -= cnt;
+      Q2.push(res == 2, packed);
       wave_sync();
+      if (Q2.count >= 64) drain2(64);
     };
 
+#pragma unroll 2
     for (int rr = 0; rr < nrow; rr++) {
-      const float4 rq = L.rowq0[rr];
+      const float4 rq = rdlane4(myrow, rr);
       bool pass = cvalid && (!diag || lane > rr);
       if (pass && cull) pass = !G::cheap_reject(rq, cq);
       if (__ballot(pass)) {
@@ -257,33 +305,78 @@ __device__ void nms_pairs(const NmsArgs& a, int g, int cn, const uint32_t* cidx,
     }
     if (Q.count > 0) drain(Q.count);
   }
+  if (Q2.count > 0) drain2(Q2.count);
 }
 
 // ------------------------------------------------------------------ A2: resolve the chunk (serial section, 512 threads)
+// Greedy NMS inside the chunk == the lexicographically-first maximal independent set of the conflict graph (edges
+// i < j, i the higher score).  Parallel rounds: a node is kept as soon as none of its lower-index neighbours is still
+// undecided; kept nodes kill their higher-index neighbours.  The edge list lives in LDS (when it fits) as one
+// contiguous block per thread and PRUNES itself: an edge is dropped the moment its target is decided or its source
+// is dead / has delivered its kill, so the rounds get cheaper geometrically.
+// LDS (aliasing the wave scratch): state[capmax] | blocked[capmax] | edges[...]
 // returns the number of kept boxes of the chunk (also published in nrows[g])
-__device__ int nms_resolve(const NmsArgs& a, int g, int cn, int kept_before, const uint32_t* cidx, uint8_t* smem, int* s_i) {
+__device__ int nms_resolve(const NmsArgs& a, int g, int cn, int kept_before, const uint32_t* cidx, uint8_t* smem, size_t smem_bytes,
+                           int* s_i) {
   const int tid = threadIdx.x;
   uint8_t* state = smem;              // 0 undecided, 1 kept, 2 dead
   uint8_t* blocked = smem + a.capmax;
-  for (int j = tid; j < a.capmax; j += kNmsThreads) { state[j] = (j < cn) ? 0 : 2; blocked[j] = 0; }
+  uint32_t* ledges = reinterpret_cast<uint32_t*>(smem + 2 * (size_t)a.capmax);
+  const long long lcap = ((long long)smem_bytes - 2LL * a.capmax) / 4;
+  for (int j = tid; j < cn; j += kNmsThreads) { state[j] = 0; blocked[j] = 0; }
   long long E = ldg_agent(a.nedges + g);
   if (E > a.ecap) E = a.ecap;         // cannot happen: ecap is the worst case capmax*(capmax-1)/2
   const uint32_t* edges = a.edges + (size_t)g * a.ecap;   // plain loads: acquired in serial_begin
+  const bool in_lds = E <= lcap;
+  int per = (int)((E + kNmsThreads - 1) / kNmsThreads);
+  per |= 1;                            // odd block length: conflict-free LDS banks across the lanes
+  int mycnt = 0;
+  uint32_t* mine_e = ledges + (size_t)tid * per;
+  if (in_lds && (long long)per * kNmsThreads <= lcap) {
+    // thread t takes edges t, t+512, ... (coalesced global reads, 8 in flight) into its own LDS block
+    for (long long k0 = tid; k0 < E; k0 += 8 * kNmsThreads) {
+      uint32_t v[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) { const long long k = k0 + (long long)u * kNmsThreads; v[u] = k < E ? edges[k] : 0u; }
+#pragma unroll
+      for (int u = 0; u < 8; u++) if (k0 + (long long)u * kNmsThreads < E) mine_e[mycnt++] = v[u];
+    }
+  }
+  const bool lds_mode = in_lds && (long long)per * kNmsThreads <= lcap;
   __syncthreads();
+  u64 tp = 0;
+  if (a.prof && tid == 0) { tp = wall_clock64(); }
+  auto plap = [&](int slot) { if (a.prof && tid == 0) { const u64 t = wall_clock64(); atomicAdd(a.prof + slot, t - tp); tp = t; } };
 
   for (int round = 0;; round++) {
-    if (round > 0) {
+    if (lds_mode) {
+      int w = 0;
+      for (int k = 0; k < mycnt; k++) {
+        const uint32_t ed = mine_e[k];
+        const int i = ed >> 16, j = ed & 0xffff;
+        const uint8_t sj = state[j];
+        if (sj != 0) continue;                       // target decided: the edge is done
+        const uint8_t si = state[i];
+        if (si == 1) { state[j] = 2; continue; }     // kept source kills the target
+        if (si == 2) continue;                       // dead source never matters again
+        blocked[j] = 1;                              // both undecided: j has to wait for i
+        mine_e[w++] = ed;
+      }
+      mycnt = w;
+    } else {
+      if (round > 0) {
+        for (long long k = tid; k < E; k += kNmsThreads) {
+          const uint32_t ed = edges[k];
+          const int i = ed >> 16, j = ed & 0xffff;
+          if (state[i] == 1 && state[j] == 0) state[j] = 2;
+        }
+        __syncthreads();
+      }
       for (long long k = tid; k < E; k += kNmsThreads) {
         const uint32_t ed = edges[k];
         const int i = ed >> 16, j = ed & 0xffff;
-        if (state[i] == 1 && state[j] == 0) state[j] = 2;
+        if (state[i] == 0 && state[j] == 0) blocked[j] = 1;
       }
-      __syncthreads();
-    }
-    for (long long k = tid; k < E; k += kNmsThreads) {
-      const uint32_t ed = edges[k];
-      const int i = ed >> 16, j = ed & 0xffff;
-      if (state[i] == 0 && state[j] == 0) blocked[j] = 1;
     }
     if (tid == 0) s_i[9] = 0;
     __syncthreads();
@@ -296,15 +389,17 @@ __device__ int nms_resolve(const NmsArgs& a, int g, int cn, int kept_before, con
     }
     if (rem) s_i[9] = 1;
     __syncthreads();
-    if (!s_i[9]) break;
+    if (!s_i[9]) { if (a.prof && tid == 0) atomicAdd(a.prof + 11, (u64)(round + 1)); break; }
+    if (round == 0) plap(12);
     __syncthreads();
   }
 
-  // ordered compaction of the kept boxes: thread t owns chunk positions [t*per, (t+1)*per)
-  const int per = (a.capmax + kNmsThreads - 1) / kNmsThreads;
+  plap(13);
+  // ordered compaction of the kept boxes: thread t owns chunk positions [t*per_n, (t+1)*per_n)
+  const int per_n = (cn + kNmsThreads - 1) / kNmsThreads;
   int mine = 0;
-  for (int q = 0; q < per; q++) {
-    const int j = tid * per + q;
+  for (int q = 0; q < per_n; q++) {
+    const int j = tid * per_n + q;
     if (j < cn && state[j] == 1) mine++;
   }
   int incl = mine;
@@ -321,8 +416,8 @@ __device__ int nms_resolve(const NmsArgs& a, int g, int cn, int kept_before, con
   int rank = wpre + incl - mine;
   const int sb = a.seg_begin[g];
   uint32_t* rows = a.rows + (size_t)g * a.capmax;
-  for (int q = 0; q < per; q++) {
-    const int j = tid * per + q;
+  for (int q = 0; q < per_n; q++) {
+    const int j = tid * per_n + q;
     if (j < cn && state[j] == 1) {
       const uint32_t pos = cidx[j];
       stg_agent(rows + rank, pos);
@@ -337,6 +432,7 @@ __device__ int nms_resolve(const NmsArgs& a, int g, int cn, int kept_before, con
     stg_agent(a.keep_cnt + g, kept_before + total);   // write-through: resolvers of different steps sit on different XCDs
   }
   __syncthreads();
+  plap(14);
   return total;
 }
 
@@ -346,61 +442,97 @@ __device__ void nms_cross(const NmsArgs& a, int g, int nr, int c0, int se, int t
   const int lane = threadIdx.x & 63;
   const int w0 = c0 >> 6, w1 = (se - 1) >> 6;
   const int ncw = w1 - w0 + 1, nrt = (nr + 63) >> 6;
-  // split the row tiles of one column word over several waves only when there are fewer column words than waves
-  int rgn = (8 * ntw + ncw - 1) / ncw;
+  // one wave per column word; the row tiles of a word are split over several waves only when there are fewer
+  // column words than waves
+  int rgn = ntw / ncw;
   if (rgn < 1) rgn = 1;
   if (rgn > nrt) rgn = nrt;
   const int rt_per = (nrt + rgn - 1) / rgn;
   const long long items = (long long)ncw * rgn;
-  const uint32_t* rows = a.rows + (size_t)g * a.capmax;
+  const uint32_t* rows = a.rows + (size_t)g * a.capmax;   // plain loads: acquired after the serial section
   const bool cull = a.cull != 0;
-  PairQueue Q{L.qbuf, 0, 0};
+  PairQueue Q{L.qbuf, 0, 0}, Q2{L.qbuf2, 0, 0};
 
   for (long long item = tw; item < items; item += ntw) {
     const int cw = (int)(item / rgn), rgi = (int)(item - (long long)cw * rgn);
     const int w = w0 + cw;
     const int cbase = w * 64;
     const int c = cbase + lane;
+    const int rt_lo = rgi * rt_per, rt_hi = min(nrt, rt_lo + rt_per);
+    if (rt_lo >= rt_hi) continue;
+    // first row tile's loads are issued before the (slow, write-through) bitmap word arrives
+    uint32_t rp0 = (rt_lo * 64 + lane < nr) ? rows[rt_lo * 64 + lane] : 0u;
     u64 m = ldg_agent(a.alive + w);
     if (cbase < c0) m &= ~((1ull << (c0 - cbase)) - 1ull);
     if (cbase + 64 > se) m &= (1ull << (se - cbase)) - 1ull;
     if (m == 0ull) continue;
     const bool alive0 = (m >> lane) & 1ull;
     const float4 cq = alive0 ? a.rec[(size_t)c * G::RECQ] : make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 rq0 = a.rec[(size_t)rp0 * G::RECQ];
+    uint32_t rp1 = (rt_lo + 1 < rt_hi && (rt_lo + 1) * 64 + lane < nr) ? rows[(rt_lo + 1) * 64 + lane] : 0u;
     bool alive = alive0;
     wave_sync();
     L.cdead[lane] = alive0 ? 0 : 1;
-    const int rt_lo = rgi * rt_per, rt_hi = min(nrt, rt_lo + rt_per);
+    auto drain2 = [&](int cnt) {                   // stage 2: exact clip; entries carry the row position itself
+      wave_sync();
+      if (lane < cnt) {
+        const int slot = (Q2.head + lane) & 127;
+        const uint32_t rowp = L.qbuf2[slot];
+        const int cc = L.q2col[slot];
+        if (!L.cdead[cc]) {
+          if (G::hit_exact(a.rec + (size_t)rowp * G::RECQ, a.rec + (size_t)(cbase + cc) * G::RECQ, a.thr, L.scr + lane)) L.cdead[cc] = 1;
+        }
+      }
+      Q2.head = (Q2.head + cnt) & 127;
+      Q2.count -= cnt;
+      wave_sync();
+    };
 
     for (int rt = rt_lo; rt < rt_hi; rt++) {
       if (__ballot(alive) == 0ull) break;
       const int rr0 = rt * 64;
       const int nrow = min(64, nr - rr0);
       wave_sync();
-      {
-        const uint32_t rp = lane < nrow ? ldg_agent(rows + rr0 + lane) : 0u;
-        L.rowpos[lane] = rp;
-        L.rowq0[lane] = lane < nrow ? a.rec[(size_t)rp * G::RECQ] : make_float4(0.f, 0.f, 0.f, 0.f);
-      }
+      L.rowpos[lane] = rp0;
+      const float4 myrow = rq0;
+      // next tile's record and the positions of the tile after it travel while this tile is processed
+      rp0 = rp1;
+      if (rt + 1 < rt_hi) rq0 = a.rec[(size_t)rp1 * G::RECQ];
+      rp1 = (rt + 2 < rt_hi && (rt + 2) * 64 + lane < nr) ? rows[(rt + 2) * 64 + lane] : 0u;
       wave_sync();
 
-      auto drain = [&](int cnt) {
+      auto drain = [&](int cnt) {                 // stage 1: register-only classifier
         wave_sync();
+        int res = 0;
+        uint32_t rowp = 0, cc = 0;
         if (lane < cnt) {
           const uint32_t it = L.qbuf[(Q.head + lane) & 127];
-          const int rr = it >> 8, cc = it & 255;
+          const int rr = it >> 8;
+          cc = it & 255;
+          rowp = L.rowpos[rr];
           if (!L.cdead[cc]) {
-            if (G::hit(a.rec + (size_t)L.rowpos[rr] * G::RECQ, a.rec + (size_t)(cbase + cc) * G::RECQ, a.thr, cull, L.scr + lane))
-              L.cdead[cc] = 1;
+            res = G::classify(a.rec + (size_t)rowp * G::RECQ, a.rec + (size_t)(cbase + cc) * G::RECQ, a.thr, cull);
+            if (res == 1) L.cdead[cc] = 1;
           }
         }
         Q.head = (Q.head + cnt) & 127;
         Q.count -= cnt;
+        {                                          // undecided pairs: (row position, column lane) into stage 2
+          const u64 m2 = __ballot(res == 2);
+          if (res == 2) {
+            const int slot = (Q2.head + Q2.count + __popcll(m2 & lanemask_lt())) & 127;
+            L.qbuf2[slot] = rowp;
+            L.q2col[slot] = (uint8_t)cc;
+          }
+          Q2.count += __popcll(m2);
+        }
         wave_sync();
+        if (Q2.count >= 64) drain2(64);
       };
 
+#pragma unroll 2
       for (int rr = 0; rr < nrow; rr++) {
-        const float4 rq = L.rowq0[rr];
+        const float4 rq = rdlane4(myrow, rr);
         bool pass = alive;
         if (pass && cull) pass = !G::cheap_reject(rq, cq);
         if (__ballot(pass)) {
@@ -413,10 +545,10 @@ __device__ void nms_cross(const NmsArgs& a, int g, int nr, int c0, int se, int t
       }
       if (Q.count > 0) { drain(Q.count); alive = alive && !L.cdead[lane]; }
     }
+    if (Q2.count > 0) { drain2(Q2.count); alive = alive && !L.cdead[lane]; }
     const u64 kill = __ballot(alive0 && !alive);
     if (kill && lane == 0) {
       // RETURNING atomic whose result is consumed: the wave's vmcnt then covers the completed read-modify-write
-      // (a fire-and-forget atomic is only counted until the local L2 accepted it)
       const u64 old = atomicAnd(a.alive + w, ~kill);
       asm volatile("; kill applied %0" ::"v"((unsigned)(old >> 32) ^ (unsigned)old));
     }
@@ -461,7 +593,7 @@ __global__ __launch_bounds__(kNmsThreads) void k_nms_persist(NmsArgs a) {
       if (serial_begin(bar, &s_flag)) {
         lap(3);
         const u64 ts = (a.prof && tid == 0) ? wall_clock64() : 0ull;
-        nms_resolve(a, g, cn, kept, cidx, smem, s_i);
+        nms_resolve(a, g, cn, kept, cidx, smem, sizeof(WaveLds<G>) * kNmsWaves, s_i);
         serial_end(bar);
         if (a.prof && tid == 0) { atomicAdd(a.prof + 9, wall_clock64() - ts); }
         lap(4);

@@ -97,6 +97,98 @@ OBB_HD float rbox_iou_upper_bound(const RBoxFeat& A, const RBoxFeat& B) {
   return lo / hi * 1.001f;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Register-only IoU BOUNDS (no scratch, no sort, no data-dependent indexing): a filter in front of the exact clip.
+//
+// 2*Area(A n B) = sum over the edges of A of (t1-t0)+ * cross(a_k, e_k)  +  the same over the edges of B, where
+// [t0,t1] is the part of the edge inside the other rectangle (Liang-Barsky against an axis-aligned box in the other
+// rectangle's own frame) -- Green's theorem around the intersection polygon, origin = midpoint of the two centres.
+// Unlike the reference's point set + Graham scan this formulation has a FIRST-order error at shallow crossings (the
+// two rectangles locate the same crossing independently), so the function returns an interval [lo, hi] that contains
+// the IoU the reference computes, with the width derived from the crossing angles, and reports `false` whenever it
+// cannot vouch for the interval: nearly coincident edges, tiny or badly conditioned boxes, non-finite input.  The NMS
+// only acts on it when the whole interval lies on one side of the threshold; everything else runs the exact clip.
+// tests/native/host_check_riou.cpp checks the containment against the oracle on tens of millions of seeded pairs.
+struct IouBounds { float lo, hi; };
+
+OBB_HD bool rbox_fast_iou_bounds(const RBoxFeat& A, const RBoxFeat& B, IouBounds* out) {
+  const float wA = A.w, hA = A.h, wB = B.w, hB = B.h;
+  const float mn = fminf(fminf(wA, hA), fminf(wB, hB));
+  if (!(mn >= 1.0f)) return false;                       // small / negative / NaN sizes: the exact path decides
+  const float dx = B.x - A.x, dy = B.y - A.y;
+  const float R = 0.5f * (fabsf(dx) + fabsf(dy)) + A.r + B.r;
+  if (!(R < 1e6f) || !(mn >= 1e-3f * R)) return false;   // extreme aspect / spread: not worth a bound
+  const float hx = 0.5f * dx, hy = 0.5f * dy;            // centres: A = (-hx,-hy), B = (+hx,+hy)
+  const float eps = 4e-6f * R;                           // error of a signed distance computed below
+  const float tol = 1e-4f * R;
+  const float tolc = 5e-5f * R;                          // ~100x the reference's rounding of a corner-to-edge distance
+  float sum2 = 0.f, err = 0.f;
+  bool safe = true;
+
+  // one direction: edges of P (centre (px,py), axes from (c,s), half sizes hw,hh) clipped by Q
+  auto clip_edges = [&](float pcx, float pcy, float pc, float ps, float phw, float phh, float qcx, float qcy, float qc, float qs,
+                        float qhw, float qhh) {
+    // P's corners relative to the midpoint, counter-clockwise: +w+h, -w+h, -w-h, +w-h with e_w = (c,-s), e_h = (s,c)
+    const float wx = phw * pc, wy = -phw * ps, hxv = phh * ps, hyv = phh * pc;
+    float cx[4], cy[4];
+    cx[0] = pcx + wx + hxv; cy[0] = pcy + wy + hyv;
+    cx[1] = pcx - wx + hxv; cy[1] = pcy - wy + hyv;
+    cx[2] = pcx - wx - hxv; cy[2] = pcy - wy - hyv;
+    cx[3] = pcx + wx - hxv; cy[3] = pcy + wy - hyv;
+    // the same corners in Q's frame
+    float ux[4], uy[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const float rx = cx[k] - qcx, ry = cy[k] - qcy;
+      ux[k] = rx * qc - ry * qs;      // . e_w(Q) = (c, -s)
+      uy[k] = rx * qs + ry * qc;      // . e_h(Q) = (s, c)
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int k1 = (k + 1) & 3;
+      const float len = (k & 1) ? 2.f * phh : 2.f * phw;
+      const float x0 = ux[k], y0 = uy[k], ddx = ux[k1] - ux[k], ddy = uy[k1] - uy[k];
+      float t0 = 0.f, t1 = 1.f;
+      // boundary: q(t) = q - p*t >= 0 is inside
+      auto side = [&](float p, float q) {
+        const float q1 = q - p;
+        if (fabsf(q) < tol && fabsf(q1) < tol) safe = false;               // the edge lies on Q's boundary line
+        // a corner within rounding distance of the other rectangle's boundary is where the REFERENCE is fragile: its
+        // corner-inside test and the two adjacent edge crossings (t ~ 0 or 1) can all miss by one ulp and drop a
+        // vertex of the intersection polygon (seen: IoU 0.29 instead of 0.88 for thin boxes).  Never vouch there.
+        if (fabsf(q) < tolc) safe = false;
+        if ((q < 0.f) != (q1 < 0.f)) err += eps * len / fmaxf(fabsf(p), 1e-30f);   // a crossing: located to +-eps/sin(phi)
+        const float r = q / p;                                              // p == 0: +-inf or NaN, handled below
+        if (p < 0.f) t0 = fmaxf(t0, r);
+        else if (p > 0.f) t1 = fminf(t1, r);
+        else if (q < 0.f) t1 = -1.f;                                        // parallel and outside
+      };
+      side(-ddx, x0 + qhw);
+      side(ddx, qhw - x0);
+      side(-ddy, y0 + qhh);
+      side(ddy, qhh - y0);
+      const float ex = cx[k1] - cx[k], ey = cy[k1] - cy[k];
+      const float span = fmaxf(t1 - t0, 0.f);
+      sum2 += span * (cx[k] * ey - cy[k] * ex);
+    }
+  };
+  clip_edges(-hx, -hy, A.c, A.s, 0.5f * wA, 0.5f * hA, hx, hy, B.c, B.s, 0.5f * wB, 0.5f * hB);
+  clip_edges(hx, hy, B.c, B.s, 0.5f * wB, 0.5f * hB, -hx, -hy, A.c, A.s, 0.5f * wA, 0.5f * hA);
+  if (!safe) return false;
+  const float aA = A.area, aB = B.area;
+  // a mislocated crossing opens / overlaps the boundary by its location error: area error <= 0.5 * R * that length;
+  // plus the rounding of eight products of magnitude R * len
+  const float e_area = 0.5f * R * err + 2e-5f * R * R;
+  float inter = 0.5f * sum2;
+  if (!(inter == inter) || !(e_area == e_area)) return false;
+  float ilo = fmaxf(inter - e_area, 0.f), ihi = fminf(fmaxf(inter + e_area, 0.f), fminf(aA, aB));
+  if (ilo > ihi) ilo = ihi;
+  const float s = aA + aB;
+  out->lo = ilo / (s - ilo) - 3e-5f;
+  out->hi = ihi / (s - ihi) + 3e-5f;
+  return out->lo == out->lo && out->hi == out->hi;
+}
+
 // Full clip.  A = higher-scored ("row") box, B = lower-scored ("column") box:
 // the argument order is part of the contract (nms_rotated_cuda.cu:60).
 // px/py: scratch for 24 points, element i at [i * STRIDE].
