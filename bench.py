@@ -13,10 +13,16 @@ N > 1: launched by torch.distributed.run, one rank per GPU; images shard across 
 collective on the data path; RCCL is only used for the timing barrier / max-reduce).  value = whole-job images/s.
 
 The JSON line also carries
-  roofline      for the dominant kernel of the step (k_decode, HBM-bound): algorithmic bytes / HIP-event time
+  roofline      for the dominant kernel of the step (the persistent NMS kernel k_nms_persist): algorithmic bytes
+                sum_img bytes_nms(N_img), bytes_nms(N) = 24N + 8N + 8N*ceil(N/64), over the
+                HIP-event time of the kernel measured inside the timed region; `traffic` = HBM bytes per launch from
+                the rocprofv3 --pmc passes of the same workload (profiles/r1_pmc.json; FETCH_SIZE doubled as the
+                MI355X guide prescribes, calibrated on a 256 MiB copy in the same run)
+  kernels       the same roofline figures for the other kernels of the step (k_decode: HBM-bound streaming filter)
   nms_100k      the second half of BASELINE.json's metric: one rotated-NMS call on 100k candidates (S-clustered,
                 iou 0.4, BASELINE.json configs[3]) in ms, with its own HBM-roofline figure
-                bytes_nms(N) = 24N + 8N + 8N*ceil(N/64)  
+  loss, detect  secondary timings of the other rows of the hot path (ComputeLoss fwd+bwd at the configs[2] per-GPU
+                shape; Detect inference decode of the configs[1] batch), not part of `value`
   cpu_baseline  the CPU oracle (port of the reference's CPU path) timed on the host cores on a bounded sample
 """
 import argparse
@@ -70,6 +76,7 @@ def main():
 
     from tests import synth
     from yolov5_obb_amd import _lib, nms_rotated_ext
+    from yolov5_obb_amd.utils import shard
     from yolov5_obb_amd.utils.general import non_max_suppression_obb
     L = _lib.lib()
 
@@ -98,18 +105,27 @@ def main():
     dt = time.perf_counter() - t0
     ms_sum, cnts = collect_profile(L)
     L.obb_profile_enable(0)
-    if dist is not None:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = shard.max_over_ranks(dt, device=dev)           # the job is as slow as its slowest rank
     ms_per_step = dt / args.steps * 1e3
     value = world * bs * args.steps / dt
 
     # roofline of the dominant kernel of the step: k_decode (stage 0), measured with HIP events in the timed region
     dec_ms = ms_sum[0] / max(1, cnts[0])
+    nms_ms_step = ms_sum[3] / max(1, cnts[3])
     n_det = sum(int(o.shape[0]) for o in out)
     alg_bytes = bs * A * no * 2 + 28 * n_det            # bytes_dec = bs*A*no*sizeof(elem) + 28*n_out
     achieved = alg_bytes / (dec_ms * 1e-3) / 1e9
+    # candidates per image (what the NMS kernel sees), same arithmetic as the kernel: conf = obj*cls rounded to fp16
+    with torch.no_grad():
+        objm = pred[..., 4:5] > kw["conf_thres"]
+        cand = (((pred[..., 5:5 + nc] * pred[..., 4:5]) > kw["conf_thres"]) & objm).sum((1, 2)).clamp(max=30000).tolist()
+    nms_alg = int(sum(bytes_nms(int(c)) for c in cand))
+    nms_ach = nms_alg / (nms_ms_step * 1e-3) / 1e9
+    pmc = {}
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc.json")))
+    except Exception:
+        pass
     stage_names = ["decode", "segsort", "prep", "nms_steps", "gather"]
     stages = {stage_names[i]: round(ms_sum[i] / max(1, cnts[i]), 4) for i in range(5)}
 
@@ -138,9 +154,70 @@ def main():
                       "steps": round(pms[7] / max(1, pc[7]), 4)},
         "roofline": {"bound": "hbm", "achieved": round(bytes_nms(n100) / (nms_ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": round(bytes_nms(n100) / (nms_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                     "traffic": None, "algorithmic_bytes": bytes_nms(n100),
+                     "traffic": pmc.get("k_nms_persist_100k"), "algorithmic_bytes": bytes_nms(n100),
                      "note": "whole NMS call (sort+prep+all step kernels) over the dense-mask algorithmic bytes"},
     }
+
+    # ---------------- secondary rows of the hot path (rank 0 reports; not part of `value`)
+    loss_obj = detect_obj = None
+    if rank == 0:
+        try:
+            import ctypes as C2
+            from yolov5_obb_amd.utils.loss import ComputeLoss
+            lnc = 16
+            p_l, t_l = synth.s_loss(16, lnc, 1500, 3, imgsz=1024, sizes=[128, 64, 32])
+            cl = ComputeLoss(synth.FakeModel(lnc, synth.scaled_hyp(lnc, 1024), dev))
+            pg = [x.to(dev).requires_grad_(True) for x in p_l]
+            tg = t_l.to(dev)
+
+            def loss_step():
+                for x in pg:
+                    x.grad = None
+                ls, _ = cl(pg, tg)
+                ls.backward()
+            for _ in range(3):
+                loss_step()
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(10):
+                loss_step()
+            e1.record()
+            torch.cuda.synchronize()
+            lms = e0.elapsed_time(e1) / 10
+            gbytes = sum(x.numel() * 4 for x in pg)
+            loss_obj = {"workload": "ComputeLoss fwd+bwd, p = (16,3,{128,64,32}^2,201) fp32, nt = 1500 (configs[2] per GPU)",
+                        "ms_fwd_bwd": round(lms, 4), "grad_bytes": gbytes,
+                        "note": "gradient tensors written exactly once (k_loss_bwd_dense, HBM-write bound)"}
+            del pg
+            # Detect decode of the configs[1] batch: 3 conv outputs (16, 3*200, n, n) fp16 -> z (16,64512,200) + permuted heads
+            na_d, sizes_d = 3, (128, 64, 32)
+            convs = [torch.randn(bs, na_d * no, n, n, device=dev, dtype=torch.float16) for n in sizes_d]
+            z = torch.empty(bs, A, no, device=dev, dtype=torch.float16)
+            xs = [torch.empty(bs, na_d, n, n, no, device=dev, dtype=torch.float16) for n in sizes_d]
+            arrs = [(C2.c_float * 6)(*(synth.grid_anchors()[i] * synth.DEFAULT_STRIDES[i]).reshape(-1).tolist()) for i in range(3)]
+
+            def det_step():
+                off = 0
+                for i, n in enumerate(sizes_d):
+                    L.obb_detect_decode(_lib.ptr(convs[i]), 1, bs, na_d, no, n, n, C2.cast(arrs[i], C2.c_void_p), synth.DEFAULT_STRIDES[i],
+                                        _lib.ptr(xs[i]), _lib.ptr(z), A, off, _lib.stream_ptr(dev))
+                    off += na_d * n * n
+            for _ in range(3):
+                det_step()
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(20):
+                det_step()
+            e1.record()
+            torch.cuda.synchronize()
+            dms = e0.elapsed_time(e1) / 20
+            dbytes = 3 * z.numel() * 2
+            detect_obj = {"workload": "Detect inference decode, 3 levels, (16,64512,200) fp16", "ms": round(dms, 4),
+                          "algorithmic_bytes": dbytes, "achieved_GBs": round(dbytes / (dms * 1e-3) / 1e9, 1),
+                          "frac_of_peak": round(dbytes / (dms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+            del convs, z, xs
+        except Exception as e:                                  # secondary figures never fail the bench
+            loss_obj = loss_obj or {"error": str(e)}
 
     # ---------------- CPU baseline (rank 0, N=1 only): the oracle port of the reference CPU path, bounded sample
     cpu = None
@@ -181,10 +258,18 @@ def main():
                        "global_batch": bs * world, "anchors_per_image": A, "nc": nc, "detections_per_batch": n_det,
                        "parallelism": f"dp{world} (images sharded, no data-path collective)"},
             "stages_ms": stages,
-            "roofline": {"bound": "hbm", "kernel": "obb::k_decode<__half>", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                         "algorithmic_bytes": alg_bytes, "avg_kernel_ms": round(dec_ms, 5)},
+            "roofline": {"bound": "hbm", "kernel": "obb::k_nms_persist<obb::RotGeom>", "achieved": round(nms_ach, 2),
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(nms_ach / HBM_PEAK_GBS, 5),
+                         "traffic": pmc.get("k_nms_persist_bs16"), "algorithmic_bytes": nms_alg,
+                         "avg_kernel_ms": round(nms_ms_step, 5), "candidates_per_image": [int(c) for c in cand],
+                         "note": "dominant kernel of the step by time; latency / VALU bound at these sizes (a few thousand "
+                                 "candidates per image), not HBM bound -- see nms_100k for the 100k-candidate figure"},
+            "kernels": {"obb::k_decode<__half>": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                                  "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc.get("k_decode"),
+                                                  "algorithmic_bytes": alg_bytes, "avg_kernel_ms": round(dec_ms, 5),
+                                                  "note": "reads only the objectness sector of each row + the rows that pass"}},
             "nms_100k": nms_obj,
+            "loss": loss_obj, "detect": detect_obj,
             "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)

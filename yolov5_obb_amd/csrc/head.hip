@@ -47,9 +47,15 @@ __device__ __forceinline__ float detect_decode_one(float raw, int ch, float gx, 
 
 constexpr int kTileHW = 64;
 
-template <typename T>
+template <typename T> struct Pack16;                                   // 16 bytes of T
+template <> struct Pack16<float> { static constexpr int V = 4; };
+template <> struct Pack16<__half> { static constexpr int V = 8; };
+
+// VEC: the input rows are 4-element aligned (HW % 4 == 0) and both outputs are 16-byte aligned at every tile start,
+// so the tile is read with 8/16-byte loads and written with 16-byte stores; otherwise element-wise accesses.
+template <typename T, bool VEC>
 __global__ __launch_bounds__(256) void k_detect_decode(DetectArgs d) {
-  extern __shared__ unsigned char smem_raw[];
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   T* tile = reinterpret_cast<T*>(smem_raw);            // [no][kTileHW + 1]
   const int tid = threadIdx.x;
   const int HW = d.ny * d.nx;
@@ -61,8 +67,23 @@ __global__ __launch_bounds__(256) void k_detect_decode(DetectArgs d) {
   const T* in = (const T*)d.in + ((size_t)ba * no) * HW + hw0;
   constexpr int LD = kTileHW + 1;
 
-  // ---- load: 4 channel rows x 64 positions per step (coalesced along hw)
-  {
+  // ---- load (coalesced along hw)
+  if constexpr (VEC) {
+    // 16 threads x 4 positions cover the 64 positions of one channel row; 16 channel rows per step
+    const int q = tid & 15, c16 = tid >> 4;
+    const int hw = q * 4;
+    for (int c = c16; c < no; c += 16) {
+      if (hw + 3 < nhw) {
+        T v[4];
+        if constexpr (sizeof(T) == 2) *reinterpret_cast<uint2*>(v) = *reinterpret_cast<const uint2*>(in + (size_t)c * HW + hw);
+        else *reinterpret_cast<float4*>(v) = *reinterpret_cast<const float4*>(in + (size_t)c * HW + hw);
+#pragma unroll
+        for (int j = 0; j < 4; j++) tile[c * LD + hw + j] = v[j];
+      } else {
+        for (int j = 0; j < 4; j++) if (hw + j < nhw) tile[c * LD + hw + j] = in[(size_t)c * HW + hw + j];
+      }
+    }
+  } else {
     const int hw = tid & 63, c4 = tid >> 6;
     for (int c = c4; c < no; c += 4)
       if (hw < nhw) tile[c * LD + hw] = in[(size_t)c * HW + hw];
@@ -74,19 +95,45 @@ __global__ __launch_bounds__(256) void k_detect_decode(DetectArgs d) {
   T* xo = d.xperm ? (T*)d.xperm + ((size_t)ba * HW + hw0) * no : nullptr;
   T* zo = d.z ? (T*)d.z + ((size_t)b * d.a_total + d.a_off + (size_t)a * HW + hw0) * no : nullptr;
   const float aw = d.anchor_px[a][0], ah = d.anchor_px[a][1];
-  int c = tid % no, hw = tid / no;
-  const int dc = 256 % no, dh = 256 / no;
-  for (int e = tid; e < nel; e += 256) {
-    const T raw = tile[c * LD + hw];
-    if (xo) xo[e] = raw;
-    if (zo) {
-      const int pos = hw0 + hw;
-      const float gy = (float)(pos / d.nx), gx = (float)(pos - (pos / d.nx) * d.nx);
-      const float v = detect_decode_one<T>(ld_as_float<T>(&raw), c, gx, gy, d.stride, aw, ah);
-      st_from_float<T>(zo + e, v);
+  auto decode_at = [&](T raw, int c, int hw) -> float {
+    const int pos = hw0 + hw;
+    const int gyi = pos / d.nx;
+    return detect_decode_one<T>(ld_as_float<T>(&raw), c, (float)(pos - gyi * d.nx), (float)gyi, d.stride, aw, ah);
+  };
+  if constexpr (VEC) {
+    constexpr int V = Pack16<T>::V;
+    const int nvec = nel / V;                           // full 16-byte groups; the tail (< V elements) goes element-wise
+    for (int g = tid; g < nvec; g += 256) {
+      const int e0 = g * V;
+      int hw = e0 / no, c = e0 - hw * no;
+      alignas(16) T rawv[V];
+      alignas(16) T decv[V];
+#pragma unroll
+      for (int j = 0; j < V; j++) {
+        const T raw = tile[c * LD + hw];
+        rawv[j] = raw;
+        if (zo) { T o; st_from_float<T>(&o, decode_at(raw, c, hw)); decv[j] = o; }
+        if (++c == no) { c = 0; hw++; }
+      }
+      if (xo) *reinterpret_cast<uint4*>(xo + e0) = *reinterpret_cast<const uint4*>(rawv);
+      if (zo) *reinterpret_cast<uint4*>(zo + e0) = *reinterpret_cast<const uint4*>(decv);
     }
-    c += dc; hw += dh;
-    if (c >= no) { c -= no; hw++; }
+    for (int e = nvec * V + tid; e < nel; e += 256) {
+      const int hw = e / no, c = e - hw * no;
+      const T raw = tile[c * LD + hw];
+      if (xo) xo[e] = raw;
+      if (zo) st_from_float<T>(zo + e, decode_at(raw, c, hw));
+    }
+  } else {
+    int c = tid % no, hw = tid / no;
+    const int dc = 256 % no, dh = 256 / no;
+    for (int e = tid; e < nel; e += 256) {
+      const T raw = tile[c * LD + hw];
+      if (xo) xo[e] = raw;
+      if (zo) st_from_float<T>(zo + e, decode_at(raw, c, hw));
+      c += dc; hw += dh;
+      if (c >= no) { c -= no; hw++; }
+    }
   }
 }
 
@@ -161,16 +208,24 @@ int obb_detect_decode(const void* conv_out, int dtype, int64_t bs, int64_t na, i
   }
   const int HW = (int)(ny * nx);
   dim3 grid((unsigned)((HW + kTileHW - 1) / kTileHW), (unsigned)(bs * na));
-  const size_t lds = (size_t)no * (kTileHW + 1) * (dtype == 0 ? 4 : 2);
+  const size_t esz = dtype == 0 ? 4 : 2;
+  const size_t lds = (size_t)no * (kTileHW + 1) * esz;
   hipStream_t st = (hipStream_t)stream;
-  if (lds > 48 * 1024) {   // raise the dynamic-LDS limit (160 KB per CU on gfx950)
-    if (lds > 150 * 1024) return OBB_ERR_BAD_ARG;
-    hipError_t e = dtype == 0 ? hipFuncSetAttribute((const void*)k_detect_decode<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
-                              : hipFuncSetAttribute((const void*)k_detect_decode<__half>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return OBB_ERR_LAUNCH;
-  }
-  if (dtype == 0) k_detect_decode<float><<<grid, 256, lds, st>>>(d);
-  else k_detect_decode<__half><<<grid, 256, lds, st>>>(d);
+  // vector path: input rows 4-element aligned, every tile of both outputs 16-byte aligned
+  auto al16 = [](const void* p) { return p == nullptr || (((uintptr_t)p) & 15) == 0; };
+  bool vec = (HW % 4 == 0) && al16(conv_out) && al16(x_perm_out) && al16(z_out);
+  vec = vec && ((size_t)HW * no * esz) % 16 == 0 && ((size_t)a_total * no * esz) % 16 == 0 && ((size_t)a_offset * no * esz) % 16 == 0;
+  if (lds > 150 * 1024) return OBB_ERR_BAD_ARG;
+#define OBB_LAUNCH_DETECT(T, VEC)                                                                                                  \
+  do {                                                                                                                              \
+    if (lds > 48 * 1024 &&                                                                                                          \
+        hipFuncSetAttribute((const void*)k_detect_decode<T, VEC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) \
+      return OBB_ERR_LAUNCH;                                                                                                        \
+    k_detect_decode<T, VEC><<<grid, 256, lds, st>>>(d);                                                                             \
+  } while (0)
+  if (dtype == 0) { if (vec) OBB_LAUNCH_DETECT(float, true); else OBB_LAUNCH_DETECT(float, false); }
+  else { if (vec) OBB_LAUNCH_DETECT(__half, true); else OBB_LAUNCH_DETECT(__half, false); }
+#undef OBB_LAUNCH_DETECT
   return hipGetLastError() == hipSuccess ? OBB_OK : OBB_ERR_LAUNCH;
 }
 

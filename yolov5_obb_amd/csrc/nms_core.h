@@ -171,7 +171,7 @@ struct PairQueue {
 // chunk = the first `cap` alive positions in [cur, se); their positions go to this workgroup's LDS list; returns the
 // chunk size and moves `cur` behind the last member.  Members keep their alive bit: nothing reads positions below
 // the cursor again.
-__device__ int nms_select(const NmsArgs& a, int se, int& cur, int cap, uint32_t* cidx, int* s_i) {
+__device__ __forceinline__ int nms_select(const NmsArgs& a, int se, int& cur, int cap, uint32_t* cidx, int* s_i) {
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int w_first = cur >> 6, w_last = (se - 1) >> 6;
   int off = 0;
@@ -217,7 +217,7 @@ __device__ int nms_select(const NmsArgs& a, int se, int& cur, int cap, uint32_t*
 
 // ------------------------------------------------------------------ A1: pairs inside the chunk (all waves of the team)
 template <class G>
-__device__ void nms_pairs(const NmsArgs& a, int g, int cn, const uint32_t* cidx, int tw, int ntw, WaveLds<G>& L) {
+__device__ __forceinline__ void nms_pairs(const NmsArgs& a, int g, int cn, const uint32_t* cidx, int tw, int ntw, WaveLds<G>& L) {
   const int lane = threadIdx.x & 63;
   const int nb = (cn + 63) >> 6;
   const int items = nb * nb;
@@ -316,7 +316,7 @@ __device__ void nms_pairs(const NmsArgs& a, int g, int cn, const uint32_t* cidx,
 // is dead / has delivered its kill, so the rounds get cheaper geometrically.
 // LDS (aliasing the wave scratch): state[capmax] | blocked[capmax] | edges[...]
 // returns the number of kept boxes of the chunk (also published in nrows[g])
-__device__ int nms_resolve(const NmsArgs& a, int g, int cn, int kept_before, const uint32_t* cidx, uint8_t* smem, size_t smem_bytes,
+__device__ __forceinline__ int nms_resolve(const NmsArgs& a, int g, int cn, int kept_before, const uint32_t* cidx, uint8_t* smem, size_t smem_bytes,
                            int* s_i) {
   const int tid = threadIdx.x;
   uint8_t* state = smem;              // 0 undecided, 1 kept, 2 dead
@@ -364,19 +364,31 @@ __device__ int nms_resolve(const NmsArgs& a, int g, int cn, int kept_before, con
       }
       mycnt = w;
     } else {
-      if (round > 0) {
-        for (long long k = tid; k < E; k += kNmsThreads) {
-          const uint32_t ed = edges[k];
+      // the list does not fit in LDS: same self-pruning pass on the thread's own strided slots of the global list
+      // (slots tid, tid+512, ...: coalesced, nobody else touches them), four loads in flight
+      uint32_t* gedges = a.edges + (size_t)g * a.ecap;
+      if (round == 0) mycnt = (int)((E - tid + kNmsThreads - 1) / kNmsThreads);
+      int w = 0;
+      for (int k0 = 0; k0 < mycnt; k0 += 4) {
+        uint32_t v[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) v[u] = (k0 + u < mycnt) ? gedges[(size_t)tid + (size_t)(k0 + u) * kNmsThreads] : 0u;
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          if (k0 + u >= mycnt) break;
+          const uint32_t ed = v[u];
           const int i = ed >> 16, j = ed & 0xffff;
-          if (state[i] == 1 && state[j] == 0) state[j] = 2;
+          const uint8_t sj = state[j];
+          if (sj != 0) continue;
+          const uint8_t si = state[i];
+          if (si == 1) { state[j] = 2; continue; }
+          if (si == 2) continue;
+          blocked[j] = 1;
+          gedges[(size_t)tid + (size_t)w * kNmsThreads] = ed;
+          w++;
         }
-        __syncthreads();
       }
-      for (long long k = tid; k < E; k += kNmsThreads) {
-        const uint32_t ed = edges[k];
-        const int i = ed >> 16, j = ed & 0xffff;
-        if (state[i] == 0 && state[j] == 0) blocked[j] = 1;
-      }
+      mycnt = w;
     }
     if (tid == 0) s_i[9] = 0;
     __syncthreads();
@@ -438,7 +450,7 @@ __device__ int nms_resolve(const NmsArgs& a, int g, int cn, int kept_before, con
 
 // ------------------------------------------------------------------ B: kept rows x still-alive later positions
 template <class G>
-__device__ void nms_cross(const NmsArgs& a, int g, int nr, int c0, int se, int tw, int ntw, WaveLds<G>& L) {
+__device__ __forceinline__ void nms_cross(const NmsArgs& a, int g, int nr, int c0, int se, int tw, int ntw, WaveLds<G>& L) {
   const int lane = threadIdx.x & 63;
   const int w0 = c0 >> 6, w1 = (se - 1) >> 6;
   const int ncw = w1 - w0 + 1, nrt = (nr + 63) >> 6;
@@ -557,8 +569,10 @@ __device__ void nms_cross(const NmsArgs& a, int g, int nr, int c0, int se, int t
 
 // ------------------------------------------------------------------ the persistent kernel
 // dynamic LDS: [kNmsWaves x WaveLds<G>] (aliased by the resolve state) | chunk list [capmax] u32
+// One workgroup per CU (the LDS footprint allows no second one) = 2 waves per SIMD: let the compiler use the whole
+// 256-register budget of such a wave instead of spilling to scratch (measured: 20 MB of scratch writes per launch).
 template <class G>
-__global__ __launch_bounds__(kNmsThreads) void k_nms_persist(NmsArgs a) {
+__global__ __launch_bounds__(kNmsThreads) __attribute__((amdgpu_waves_per_eu(1, 2))) void k_nms_persist(NmsArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __shared__ int s_i[16];
   __shared__ int s_flag;

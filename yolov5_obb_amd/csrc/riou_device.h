@@ -127,7 +127,7 @@ OBB_HD bool rbox_fast_iou_bounds(const RBoxFeat& A, const RBoxFeat& B, IouBounds
 
   // one direction: edges of P (centre (px,py), axes from (c,s), half sizes hw,hh) clipped by Q
   auto clip_edges = [&](float pcx, float pcy, float pc, float ps, float phw, float phh, float qcx, float qcy, float qc, float qs,
-                        float qhw, float qhh) {
+                        float qhw, float qhh) __attribute__((always_inline)) {
     // P's corners relative to the midpoint, counter-clockwise: +w+h, -w+h, -w-h, +w-h with e_w = (c,-s), e_h = (s,c)
     const float wx = phw * pc, wy = -phw * ps, hxv = phh * ps, hyv = phh * pc;
     float cx[4], cy[4];
@@ -150,7 +150,7 @@ OBB_HD bool rbox_fast_iou_bounds(const RBoxFeat& A, const RBoxFeat& B, IouBounds
       const float x0 = ux[k], y0 = uy[k], ddx = ux[k1] - ux[k], ddy = uy[k1] - uy[k];
       float t0 = 0.f, t1 = 1.f;
       // boundary: q(t) = q - p*t >= 0 is inside
-      auto side = [&](float p, float q) {
+      auto side = [&](float p, float q) __attribute__((always_inline)) {
         const float q1 = q - p;
         if (fabsf(q) < tol && fabsf(q1) < tol) safe = false;               // the edge lies on Q's boundary line
         // a corner within rounding distance of the other rectangle's boundary is where the REFERENCE is fragile: its
