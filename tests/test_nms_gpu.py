@@ -193,3 +193,19 @@ def test_devkit_overlaps_and_poly_gpu_nms(dev, oracle_lib):
     got_keep = poly_gpu_nms(polys, 0.3)
     assert isinstance(got_keep, list) and np.array_equal(np.asarray(got_keep), ref_keep)
     assert poly_nms_gpu(polys[:0], 0.3) == []
+
+
+def test_heavy_duplication_is_repeatable(dev, oracle_lib):
+    """Few objects with thousands of near-duplicates each: the chunk's conflict graph has far more edges than fit in
+    LDS (resolve runs on the global edge list), several steps with a cross phase each.  Every repetition must give the
+    oracle's kept list -- this is the configuration that exposes inter-workgroup visibility mistakes."""
+    import oracle
+    for n, k, seed, thr in ((12000, 12, 5, 0.3), (30000, 40, 6, 0.5), (6000, 3, 7, 0.45)):
+        d, s = synth.s_clustered(n, k, seed)
+        s = synth.tie_free(s)
+        ref = oracle.nms_rotated(d.numpy(), s.numpy(), thr)
+        dd, ss = d.to(dev), s.to(dev)
+        from yolov5_obb_amd import nms_rotated_ext
+        for rep in range(6):
+            got = nms_rotated_ext.nms_rotated(dd, ss, thr).cpu().numpy()
+            assert np.array_equal(got, ref), (n, k, rep, len(got), len(ref))

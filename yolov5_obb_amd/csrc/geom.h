@@ -16,10 +16,10 @@ namespace obb {
 struct RotGeom {
   static constexpr int RECQ = 4;
   static constexpr int SCR = 48;  // 24 clip points x (x,y) per lane
-  // q0 = {x, y, r, ms}  q1 = {w, h, c, s}  q2 = {sh, cw, ch, sw}  q3 = {area, 0, 0, 0}
+  // q0 = {x, y, r, ms^2}  q1 = {w, h, c, s}  q2 = {sh, cw, ch, sw}  q3 = {area, 0, 0, 0}
   static OBB_HD void pack(const RBoxFeat& f, float4* q) {
     float ms = fminf(fabsf(f.w), fabsf(f.h));
-    q[0] = make_float4(f.x, f.y, f.r, ms);
+    q[0] = make_float4(f.x, f.y, f.r, ms * ms);
     q[1] = make_float4(f.w, f.h, f.c, f.s);
     q[2] = make_float4(f.sh, f.cw, f.ch, f.sw);
     q[3] = make_float4(f.area, 0.f, 0.f, 0.f);
@@ -33,13 +33,15 @@ struct RotGeom {
     return f;
   }
   // Hot-loop test on quad 0 only: circumscribed circles clearly apart AND the pair is well
-  // conditioned (riou_device.h) -> the reference returns exactly 0.  ~13 VALU ops.
+  // conditioned (riou_device.h) -> the reference returns exactly 0.  ~11 VALU ops.
+  // Conditioning: riou_device.h asks for min side >= 2e-5 * M with M = |dx| + |dy| + rs.  When the circles are apart
+  // (d > rs) M <= (sqrt(2) + 1) * d, so  ms^2 >= 2.34e-9 * d^2  (= (2e-5 * 2.4143)^2 rounded up) is sufficient --
+  // a slightly stricter guard than the original, never a weaker one.
   static __device__ __forceinline__ bool cheap_reject(const float4& a, const float4& b) {
-    float dx = b.x - a.x, dy = b.y - a.y;
-    float rs = a.z + b.z;
-    float M = fabsf(dx) + fabsf(dy) + rs;
-    bool wc = fminf(a.w, b.w) >= 2e-5f * M;
-    return wc && (dx * dx + dy * dy > rs * rs);
+    const float dx = b.x - a.x, dy = b.y - a.y;
+    const float rs = a.z + b.z;
+    const float d2 = dx * dx + dy * dy;
+    return (d2 > rs * rs) && (fminf(a.w, b.w) >= 2.34e-9f * d2);
   }
   // Two-stage decision of "IoU > thr" for the pairs that survive the hot loop.
   //   classify  registers only: separating-axis reject, area-ratio bound, then the IoU interval of

@@ -226,7 +226,7 @@ static int carve(void* base, int64_t n, int64_t nseg, int recq, int C, Carve* cv
   cv->bar_bytes = ((size_t)kMaxTeams * 128 + 64) * 4;
   cv->bar = (int*)take(cv->bar_bytes);
   cv->abort_flag = cv->bar + (size_t)kMaxTeams * 128;
-  cv->prof = (u64*)take(16 * 8);
+  cv->prof = (u64*)take(32 * 8);
   cv->seg_begin = (int*)take(ns * 4); cv->seg_end = (int*)take(ns * 4); cv->cursor = (int*)take(ns * 4);
   cv->keep_cnt = (int*)take(ns * 4); cv->ccount = (int*)take(ns * 4);
   cv->nrows = (int*)take(ns * 4); cv->nedges = (int*)take(ns * 4);
@@ -279,11 +279,13 @@ static int nms_steps(int kind, NmsArgs& a, const Carve& cv, int64_t nseg, int64_
   if (phase_prof < 0) { const char* e = getenv("OBB_NMS_PHASE_PROF"); phase_prof = (e && atoi(e)) ? 1 : 0; }
   a.prof = nullptr;
   if (phase_prof) {   // development aid: print the previous call's phase times (synchronises!)
-    u64 h[16];
+    u64 h[32];
     if (hipMemcpy(h, cv.prof, sizeof h, hipMemcpyDeviceToHost) == hipSuccess && h[6] > 0 && h[6] < (1ull << 40))
       fprintf(stderr, "[nms phases, wg0, us] select %.1f pairs %.1f wait-resolve %.1f cross %.1f barrier %.1f steps %llu | resolve (any wg) %.1f rounds %llu [first round %.1f other rounds %.1f output %.1f]\n",
               h[1] * 0.01, h[2] * 0.01, h[3] * 0.01, h[5] * 0.01, h[0] * 0.01, h[6], h[9] * 0.01, h[11], h[12] * 0.01, h[13] * 0.01, h[14] * 0.01);
-    hipMemsetAsync(cv.prof, 0, 16 * 8, st);
+      fprintf(stderr, "    cross, wave 0: items %llu row-loops %.1f us, stage-1 drains %llu = %.1f us, stage-2 drains %llu = %.1f us\n", h[21],
+              h[16] * 0.01, h[19], h[17] * 0.01, h[20], h[18] * 0.01);
+    hipMemsetAsync(cv.prof, 0, 32 * 8, st);
     a.prof = cv.prof;
   }
   const int cus = cu_count();

@@ -365,14 +365,16 @@ __device__ __forceinline__ int nms_resolve(const NmsArgs& a, int g, int cn, int 
       mycnt = w;
     } else {
       // the list does not fit in LDS: same self-pruning pass on the thread's own strided slots of the global list
-      // (slots tid, tid+512, ...: coalesced, nobody else touches them), four loads in flight
+      // (slots tid, tid+512, ...: coalesced, nobody else touches them), four loads in flight.  Loads AND stores are
+      // agent-scope (write-through): a plain store would leave a dirty line in this XCD's L2 that can be written back
+      // after the next step's edges have been published by other XCDs, and a plain re-load could hit this CU's L1.
       uint32_t* gedges = a.edges + (size_t)g * a.ecap;
       if (round == 0) mycnt = (int)((E - tid + kNmsThreads - 1) / kNmsThreads);
       int w = 0;
       for (int k0 = 0; k0 < mycnt; k0 += 4) {
         uint32_t v[4];
 #pragma unroll
-        for (int u = 0; u < 4; u++) v[u] = (k0 + u < mycnt) ? gedges[(size_t)tid + (size_t)(k0 + u) * kNmsThreads] : 0u;
+        for (int u = 0; u < 4; u++) v[u] = (k0 + u < mycnt) ? ldg_agent(gedges + (size_t)tid + (size_t)(k0 + u) * kNmsThreads) : 0u;
 #pragma unroll
         for (int u = 0; u < 4; u++) {
           if (k0 + u >= mycnt) break;
@@ -384,13 +386,12 @@ __device__ __forceinline__ int nms_resolve(const NmsArgs& a, int g, int cn, int 
           if (si == 1) { state[j] = 2; continue; }
           if (si == 2) continue;
           blocked[j] = 1;
-          gedges[(size_t)tid + (size_t)w * kNmsThreads] = ed;
+          stg_agent(gedges + (size_t)tid + (size_t)w * kNmsThreads, ed);
           w++;
         }
       }
       mycnt = w;
     }
-    if (tid == 0) s_i[9] = 0;
     __syncthreads();
     bool rem = false;
     for (int j = tid; j < cn; j += kNmsThreads) {
@@ -399,11 +400,9 @@ __device__ __forceinline__ int nms_resolve(const NmsArgs& a, int g, int cn, int 
         else state[j] = 1;
       }
     }
-    if (rem) s_i[9] = 1;
-    __syncthreads();
-    if (!s_i[9]) { if (a.prof && tid == 0) atomicAdd(a.prof + 11, (u64)(round + 1)); break; }
+    const int any = __syncthreads_or(rem ? 1 : 0);     // barrier + "somebody is still undecided" in one
+    if (!any) { if (a.prof && tid == 0) atomicAdd(a.prof + 11, (u64)(round + 1)); break; }
     if (round == 0) plap(12);
-    __syncthreads();
   }
 
   plap(13);
@@ -464,8 +463,13 @@ __device__ __forceinline__ void nms_cross(const NmsArgs& a, int g, int nr, int c
   const uint32_t* rows = a.rows + (size_t)g * a.capmax;   // plain loads: acquired after the serial section
   const bool cull = a.cull != 0;
   PairQueue Q{L.qbuf, 0, 0}, Q2{L.qbuf2, 0, 0};
+  const bool cprof = a.prof != nullptr && blockIdx.x == 0 && threadIdx.x == 0;
+  u64 ct0 = 0, c_loop = 0, c_d1 = 0, c_d2 = 0, c_n1 = 0, c_n2 = 0, c_items = 0;
+  auto ctick = [&]() { if (cprof) ct0 = wall_clock64(); };
+  auto ctock = [&](u64& acc) { if (cprof) acc += wall_clock64() - ct0; };
 
   for (long long item = tw; item < items; item += ntw) {
+    c_items++;
     const int cw = (int)(item / rgn), rgi = (int)(item - (long long)cw * rgn);
     const int w = w0 + cw;
     const int cbase = w * 64;
@@ -542,6 +546,7 @@ __device__ __forceinline__ void nms_cross(const NmsArgs& a, int g, int nr, int c
         if (Q2.count >= 64) drain2(64);
       };
 
+      ctick();
 #pragma unroll 2
       for (int rr = 0; rr < nrow; rr++) {
         const float4 rq = rdlane4(myrow, rr);
@@ -550,20 +555,26 @@ __device__ __forceinline__ void nms_cross(const NmsArgs& a, int g, int nr, int c
         if (__ballot(pass)) {
           Q.push(pass, ((uint32_t)rr << 8) | (uint32_t)lane);
           if (Q.count >= 64) {
-            drain(64);
+            ctock(c_loop);
+            ctick(); drain(64); ctock(c_d1); c_n1++;
             alive = alive && !L.cdead[lane];
+            ctick();
           }
         }
       }
-      if (Q.count > 0) { drain(Q.count); alive = alive && !L.cdead[lane]; }
+      ctock(c_loop);
+      if (Q.count > 0) { ctick(); drain(Q.count); ctock(c_d1); c_n1++; alive = alive && !L.cdead[lane]; }
     }
-    if (Q2.count > 0) { drain2(Q2.count); alive = alive && !L.cdead[lane]; }
+    if (Q2.count > 0) { ctick(); drain2(Q2.count); ctock(c_d2); c_n2++; alive = alive && !L.cdead[lane]; }
     const u64 kill = __ballot(alive0 && !alive);
     if (kill && lane == 0) {
       // RETURNING atomic whose result is consumed: the wave's vmcnt then covers the completed read-modify-write
       const u64 old = atomicAnd(a.alive + w, ~kill);
       asm volatile("; kill applied %0" ::"v"((unsigned)(old >> 32) ^ (unsigned)old));
     }
+  }
+  if (cprof) {
+    a.prof[16] += c_loop; a.prof[17] += c_d1; a.prof[18] += c_d2; a.prof[19] += c_n1; a.prof[20] += c_n2; a.prof[21] += c_items;
   }
 }
 
