@@ -258,16 +258,33 @@ def main():
                        "global_batch": bs * world, "anchors_per_image": A, "nc": nc, "detections_per_batch": n_det,
                        "parallelism": f"dp{world} (images sharded, no data-path collective)"},
             "stages_ms": stages,
-            "roofline": {"bound": "hbm", "kernel": "obb::k_nms_persist<obb::RotGeom>", "achieved": round(nms_ach, 2),
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(nms_ach / HBM_PEAK_GBS, 5),
-                         "traffic": pmc.get("k_nms_persist_bs16"), "algorithmic_bytes": nms_alg,
-                         "avg_kernel_ms": round(nms_ms_step, 5), "candidates_per_image": [int(c) for c in cand],
-                         "note": "dominant kernel of the step by time; latency / VALU bound at these sizes (a few thousand "
-                                 "candidates per image), not HBM bound -- see nms_100k for the 100k-candidate figure"},
-            "kernels": {"obb::k_decode<__half>": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                                  "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc.get("k_decode"),
-                                                  "algorithmic_bytes": alg_bytes, "avg_kernel_ms": round(dec_ms, 5),
-                                                  "note": "reads only the objectness sector of each row + the rows that pass"}},
+            # the roofline target of BASELINE.json's north_star: rotated NMS at 100k candidates (configs[3] stress),
+            # SURVEY 8d formula over the whole call (sort + prep + the persistent kernel)
+            "roofline": dict(nms_obj["roofline"], kernel="obb::k_nms_persist<obb::RotGeom> (+ sort, prep) @ N = 100k",
+                             avg_call_ms=nms_obj["ms_per_call"], avg_kernel_ms=nms_obj["stages_ms"]["steps"]),
+            "kernels": {
+                "obb::k_nms_persist<obb::RotGeom> (bs16 step)": {
+                    "bound": "hbm", "achieved": round(nms_ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(nms_ach / HBM_PEAK_GBS, 5), "traffic": pmc.get("k_nms_persist_bs16"), "algorithmic_bytes": nms_alg,
+                    "avg_kernel_ms": round(nms_ms_step, 5), "candidates_per_image": [int(c) for c in cand],
+                    "note": "largest share of the step; latency / VALU bound at ~1.7k candidates per image, not HBM bound"},
+                "obb::k_decode<__half>": {
+                    "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc.get("k_decode"), "algorithmic_bytes": alg_bytes,
+                    "avg_kernel_ms": round(dec_ms, 5),
+                    "note": "touches only the 128-byte line holding obj of each row + the rows that pass: traffic < algorithmic bytes"},
+                "obb::k_detect_decode<__half> (3 levels)": None if not detect_obj or "ms" not in detect_obj else {
+                    "bound": "hbm", "achieved": detect_obj["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": detect_obj["frac_of_peak"], "traffic": pmc.get("k_detect_decode"),
+                    "algorithmic_bytes": detect_obj["algorithmic_bytes"], "avg_kernel_ms": detect_obj["ms"]},
+                "obb::k_loss_bwd_dense<float>": {
+                    "bound": "hbm", "traffic": pmc.get("k_loss_bwd_dense"), "algorithmic_bytes": 829882368,
+                    "avg_kernel_ms": pmc.get("k_loss_bwd_dense_ms"),
+                    "achieved": None if not pmc.get("k_loss_bwd_dense_ms") else round(829882368 / (pmc["k_loss_bwd_dense_ms"] * 1e-3) / 1e9, 1),
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": None if not pmc.get("k_loss_bwd_dense_ms") else round(829882368 / (pmc["k_loss_bwd_dense_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                    "note": "kernel time from the rocprofv3 kernel trace in profiles/ (the bench times ComputeLoss fwd+bwd as a whole)"},
+            },
             "nms_100k": nms_obj,
             "loss": loss_obj, "detect": detect_obj,
             "cpu_baseline": cpu,
