@@ -126,7 +126,7 @@ int obb_non_max_suppression_obb(const void* pred, int dtype, int64_t bs, int64_t
  * ComputeLoss of the OBB head (utils/loss.py:90-275): build_targets + box (horizontal CIoU) / objectness / class /
  * CSL-angle losses, forward and backward, for raw head outputs p[i] of shape (bs, na, ny_i, nx_i, no) and the
  * dataloader's target tensor (nt, 7+180) rows [img, cls, cx, cy, l, s, theta, csl x 180] in pixels
- * (utils/datasets.py:637-672).  Everything ComputeLoss.__init__ reads from the model (utils/loss.py:93-120) travels
+ * (utils/datasets.py:637-672) -- or (nt, 7) rows without the labels, see obb_loss_config.csl_radius.  Everything ComputeLoss.__init__ reads from the model (utils/loss.py:93-120) travels
  * in obb_loss_config (host memory, plain C).
  */
 #define OBB_LOSS_MAX_LEVELS 8
@@ -143,6 +143,10 @@ typedef struct obb_loss_config {
   float gain_box, gain_obj, gain_cls, gain_theta;   /* hyp['box'|'obj'|'cls'|'theta'], utils/loss.py:185-188 */
   float gr;                            /* iou ratio, utils/loss.py:116                                      */
   int32_t sort_obj_iou;                /* utils/loss.py:93,156-158                                          */
+  float csl_radius;                    /* hyp['csl_radius'] (data/hyps/obb/*.yaml; <= 0: 2.0).  Used only when the target
+                                          rows carry no CSL labels (tcols == 7): the 180-bin label is then regenerated on
+                                          the device from theta exactly as gaussian_label_cpu rolls its window
+                                          (utils/rboxs_utils.py:9-26, utils/datasets.py:639-642) -- SURVEY 8(f) row 3   */
 } obb_loss_config;
 
 size_t obb_loss_workspace_bytes(const obb_loss_config* cfg, int64_t nt);

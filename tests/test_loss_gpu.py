@@ -192,3 +192,22 @@ def test_rejects_cpu_and_focal(dev):
     hyp['fl_gamma'] = 1.5
     with pytest.raises(NotImplementedError):
         ComputeLoss(synth.FakeModel(16, hyp, dev))
+
+
+def test_targets_without_csl_columns_are_encoded_on_the_device(dev):
+    """(nt,7) targets -- the 180-bin CSL rows are regenerated inside the loss kernels from theta with
+    hyp['csl_radius'], exactly as gaussian_label_cpu rolls its window; same loss / gradients as the (nt,187) wire format."""
+    cl, spec, p, t = make(dev, nt=200, seed=44)
+    pg1 = [x.clone().to(dev).requires_grad_(True) for x in p]
+    l1, i1 = cl(pg1, t.to(dev))
+    l1.backward()
+    pg2 = [x.clone().to(dev).requires_grad_(True) for x in p]
+    l2, i2 = cl(pg2, t[:, :7].contiguous().to(dev))
+    l2.backward()
+    assert torch.allclose(l1, l2, rtol=1e-6, atol=1e-7) and torch.allclose(i1, i2, rtol=1e-6, atol=1e-7)
+    for a, b in zip(pg1, pg2):
+        assert torch.allclose(a.grad, b.grad, rtol=1e-5, atol=1e-9)
+    tc1 = cl.build_targets(pg1, t.to(dev))[4]
+    tc2 = cl.build_targets(pg2, t[:, :7].contiguous().to(dev))[4]
+    for a, b in zip(tc1, tc2):
+        assert torch.allclose(a, b, rtol=1e-6, atol=1e-30)

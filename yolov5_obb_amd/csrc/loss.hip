@@ -5,8 +5,8 @@
 // (nt,187) target rows x3 anchors x5 offsets, and its backward materialises three dense zero tensors of the head's
 // size before scatter-adding.  Here:
 //
-//   k_bt_match          one workgroup per level: anchor-ratio match + the 5 neighbour-cell candidates, written by an
-//                       ordered compaction in the reference's row order (offset-major, anchor-major, target order);
+//   k_bt_count/_write   anchor-ratio match + the 5 neighbour-cell candidates (two passes: per-block counts, then an
+//                       ordered write that reproduces the reference's row order: offset-major, anchor-major, target order);
 //                       every entry links itself into a per-cell list (atomicExch on a dense int32 head map) so that
 //                       cells hit by several entries can be resolved deterministically later.  No host sync: the
 //                       counts stay on the device.  CSL rows are NOT replicated -- entries keep the target index.
@@ -45,6 +45,9 @@ struct LossDev {
   float anchors[kLv][kNa][2];
   float stride[kLv], balance[kLv];
   float anchor_t, cp, cn, cls_pw, theta_pw, obj_pw, g_box, g_obj, g_cls, g_theta, gr;
+  int csl_from_theta;       // 1: targets are (nt,7): the CSL row is regenerated from theta (column 6)
+  float csl_radius;
+  float csl_lut[kCslBins];  // gaussian window y_sig[j], j = 0..179 (utils/rboxs_utils.py:22-23), filled by k_loss_setup
   const void* p[kLv];
   void* grad[kLv];
   const float* targets;
@@ -60,72 +63,131 @@ struct LossDev {
 };
 
 __global__ void k_loss_setup(LossDev d, LossDev* dst) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) *dst = d;
+  if (threadIdx.x == 0) { *dst = d; __threadfence(); }      // the struct copy (incl. a zeroed table) lands first
+  __syncthreads();
+  // y_sig[j] = exp(-(x_j - u)^2 / (2 sig^2)), x_j = j - 90, u = 0: evaluated in double like numpy, stored as float
+  for (int j = threadIdx.x; j < kCslBins; j += blockDim.x) {
+    const double x = (double)j - 90.0, sg = (double)d.csl_radius;
+    dst->csl_lut[j] = (float)exp(-(x * x) / (2.0 * sg * sg));
+  }
+}
+
+// CSL label of angle bin k for a target row: either stored behind the 7 geometry columns (the dataloader's (nt,187) rows,
+// utils/datasets.py:637-659) or regenerated from theta (column 6) exactly as gaussian_label_cpu rolls its window
+// (utils/rboxs_utils.py:24-26: index = int(90 - angle), label = concat(y[index:], y[:index]), angle = theta*180/pi + 90).
+struct CslRow {
+  const float* stored; const float* lut; int shift;
+  __device__ __forceinline__ float at(int k) const {
+    if (stored) return stored[k];
+    int j = k + shift;
+    if (j >= kCslBins) j -= kCslBins;
+    return lut[j];
+  }
+};
+__device__ __forceinline__ CslRow csl_row(const LossDev& d, const float* tr) {
+  CslRow r;
+  r.lut = d.csl_lut; r.shift = 0; r.stored = nullptr;
+  if (!d.csl_from_theta) { r.stored = tr + 7; return r; }
+  const double angle = (double)tr[6] * 180.0 / 3.141592 + 90.0;      // utils/rboxs_utils.py:72 with pi = 3.141592
+  const long long index = (long long)(90.0 - angle);                   // int() truncates toward zero
+  if (index <= kCslBins && index >= -(long long)kCslBins) { long long sft = index % kCslBins; if (sft < 0) sft += kCslBins; r.shift = (int)sft; }
+  return r;
 }
 
 __device__ __forceinline__ unsigned long long lanemask_lt_l() { return (1ull << (threadIdx.x & 63)) - 1ull; }
 
 // ------------------------------------------------------------------ build_targets (utils/loss.py:194-275)
-__global__ __launch_bounds__(1024) void k_bt_match(const LossDev* __restrict__ dp) {
+struct BtCand {          // one (offset, anchor, target) candidate of a level
+  bool ok, bad;
+  int t, a, o, b;
+  float gx, gy, gl, gs;
+};
+
+__device__ __forceinline__ BtCand bt_eval(const LossDev& d, int lv, long long idx, long long E) {
+  BtCand c;
+  c.ok = false; c.bad = false; c.t = c.a = c.o = c.b = 0; c.gx = c.gy = c.gl = c.gs = 0.f;
+  if (idx >= E) return c;
+  const int nt = d.nt, na = d.na, nx = d.nx[lv], ny = d.ny[lv];
+  const float st = d.stride[lv];
+  c.o = (int)(idx / ((long long)na * nt));
+  const long long rem = idx - (long long)c.o * na * nt;
+  c.a = (int)(rem / nt);
+  c.t = (int)(rem - (long long)c.a * nt);
+  const float* tr = d.targets + (size_t)c.t * d.tcols;
+  c.gx = tr[2] / st; c.gy = tr[3] / st; c.gl = tr[4] / st; c.gs = tr[5] / st;          // :234
+  const float r0 = c.gl / d.anchors[lv][c.a][0], r1 = c.gs / d.anchors[lv][c.a][1];    // :237
+  bool ok = fmaxf(fmaxf(r0, 1.0f / r0), fmaxf(r1, 1.0f / r1)) < d.anchor_t;           // :238
+  if (r0 != r0 || r1 != r1) ok = false;                                                // torch.max propagates NaN
+  if (ok && c.o > 0) {                                                                 // :243-250, g = 0.5
+    if (c.o == 1) ok = remainder1_f(c.gx) < 0.5f && c.gx > 1.0f;
+    else if (c.o == 2) ok = remainder1_f(c.gy) < 0.5f && c.gy > 1.0f;
+    else if (c.o == 3) { const float xi = (float)nx - c.gx; ok = remainder1_f(xi) < 0.5f && xi > 1.0f; }
+    else { const float yi = (float)ny - c.gy; ok = remainder1_f(yi) < 0.5f && yi > 1.0f; }
+  }
+  if (ok) {
+    c.b = (int)tr[0];                                                                  // :256  .long() truncates
+    const int cls = (int)tr[1];
+    if (c.b < 0 || c.b >= d.bs || cls < 0 || cls >= d.nc) { ok = false; c.bad = true; }   // the reference raises IndexError
+  }
+  c.ok = ok;
+  return c;
+}
+
+// pass 1: matches per 1024-candidate block
+__global__ __launch_bounds__(1024) void k_bt_count(const LossDev* __restrict__ dp, int* __restrict__ blkcnt) {
   __shared__ int s_wave[16];
   const LossDev& d = *dp;
-  const int lv = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int nt = d.nt, na = d.na, nx = d.nx[lv], ny = d.ny[lv];
-  const long long E = 5LL * na * nt;
-  const float st = d.stride[lv];
-  int running = 0, bad = 0;
-  for (long long base = 0; base < E; base += 1024) {
-    const long long idx = base + tid;
-    bool ok = false;
-    int t = 0, a = 0, o = 0, b = 0;
-    float gx = 0.f, gy = 0.f, gl = 0.f, gs = 0.f;
-    if (idx < E) {
-      o = (int)(idx / ((long long)na * nt));
-      const long long rem = idx - (long long)o * na * nt;
-      a = (int)(rem / nt);
-      t = (int)(rem - (long long)a * nt);
-      const float* tr = d.targets + (size_t)t * d.tcols;
-      gx = tr[2] / st; gy = tr[3] / st; gl = tr[4] / st; gs = tr[5] / st;          // :234
-      const float r0 = gl / d.anchors[lv][a][0], r1 = gs / d.anchors[lv][a][1];    // :237
-      ok = fmaxf(fmaxf(r0, 1.0f / r0), fmaxf(r1, 1.0f / r1)) < d.anchor_t;         // :238
-      if (r0 != r0 || r1 != r1) ok = false;                                        // torch.max propagates NaN
-      if (ok && o > 0) {                                                           // :243-250, g = 0.5
-        if (o == 1) ok = remainder1_f(gx) < 0.5f && gx > 1.0f;
-        else if (o == 2) ok = remainder1_f(gy) < 0.5f && gy > 1.0f;
-        else if (o == 3) { const float xi = (float)nx - gx; ok = remainder1_f(xi) < 0.5f && xi > 1.0f; }
-        else { const float yi = (float)ny - gy; ok = remainder1_f(yi) < 0.5f && yi > 1.0f; }
-      }
-      if (ok) {
-        b = (int)tr[0];                                                            // :256  .long() truncates
-        const int c = (int)tr[1];
-        if (b < 0 || b >= d.bs || c < 0 || c >= d.nc) { ok = false; bad = 1; }     // the reference raises IndexError
-      }
-    }
-    const unsigned long long bal = __ballot(ok);
-    const int rank = __popcll(bal & lanemask_lt_l());
-    __syncthreads();
-    if (lane == 0) s_wave[wv] = __popcll(bal);
-    __syncthreads();
-    int wpre = 0, tot = 0;
+  const int lv = blockIdx.y, tid = threadIdx.x;
+  const long long E = 5LL * d.na * d.nt;
+  const BtCand c = bt_eval(d, lv, (long long)blockIdx.x * 1024 + tid, E);
+  const unsigned long long bal = __ballot(c.ok);
+  if ((tid & 63) == 0) s_wave[tid >> 6] = __popcll(bal);
+  if (c.bad) atomicOr(&d.counts[kLv], 1);
+  __syncthreads();
+  if (tid == 0) {
+    int tot = 0;
 #pragma unroll
-    for (int w = 0; w < 16; w++) { const int c = s_wave[w]; if (w < wv) wpre += c; tot += c; }
-    if (ok) {
-      const int pos = running + wpre + rank;
-      const int eg = lv * d.cap + pos;
-      const float ox = (o == 1) ? 0.5f : (o == 3) ? -0.5f : 0.0f;                  // :220-224 off * g
-      const float oy = (o == 2) ? 0.5f : (o == 4) ? -0.5f : 0.0f;
-      int gi = (int)(gx - ox), gj = (int)(gy - oy);                                // :261  (gxy - offsets).long()
-      gi = gi < 0 ? 0 : (gi > nx - 1 ? nx - 1 : gi);                               // :267  clamp_ (mutates gij)
-      gj = gj < 0 ? 0 : (gj > ny - 1 ? ny - 1 : gj);
-      const int cell = ((b * na + a) * ny + gj) * nx + gi;
-      d.e_cell[eg] = cell; d.e_t[eg] = t; d.e_ao[eg] = a | (o << 8);
-      d.e_tbox[eg] = make_float4(gx - (float)gi, gy - (float)gj, gl, gs);          // :268
-      d.prev[eg] = atomicExch(&d.head[d.cell_off[lv] + cell], eg + 1);
-    }
-    running += tot;
+    for (int w = 0; w < 16; w++) tot += s_wave[w];
+    blkcnt[lv * gridDim.x + blockIdx.x] = tot;
   }
-  if (tid == 0) d.counts[lv] = running;
-  if (bad) atomicOr(&d.counts[kLv], 1);
+}
+
+// pass 2: ordered write -- row order = candidate order (offset-major, anchor-major, target order), as the reference
+__global__ __launch_bounds__(1024) void k_bt_write(const LossDev* __restrict__ dp, const int* __restrict__ blkcnt) {
+  __shared__ int s_wave[16];
+  __shared__ int s_part[16];
+  const LossDev& d = *dp;
+  const int lv = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int nx = d.nx[lv], ny = d.ny[lv], na = d.na;
+  const long long E = 5LL * na * d.nt;
+  // matches in the blocks before this one (and, for the last block, the level's total)
+  int before = 0;
+  for (int k = tid; k < (int)blockIdx.x; k += 1024) before += blkcnt[lv * gridDim.x + k];
+#pragma unroll
+  for (int s2 = 32; s2 >= 1; s2 >>= 1) before += __shfl_xor(before, s2);
+  if (lane == 0) s_part[wv] = before;
+  const BtCand c = bt_eval(d, lv, (long long)blockIdx.x * 1024 + tid, E);
+  const unsigned long long bal = __ballot(c.ok);
+  const int rank = __popcll(bal & lanemask_lt_l());
+  if (lane == 0) s_wave[wv] = __popcll(bal);
+  __syncthreads();
+  int base = 0, wpre = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < 16; w++) { base += s_part[w]; const int q = s_wave[w]; if (w < wv) wpre += q; tot += q; }
+  if (c.ok) {
+    const int pos = base + wpre + rank;
+    const int eg = lv * d.cap + pos;
+    const float ox = (c.o == 1) ? 0.5f : (c.o == 3) ? -0.5f : 0.0f;                  // :220-224 off * g
+    const float oy = (c.o == 2) ? 0.5f : (c.o == 4) ? -0.5f : 0.0f;
+    int gi = (int)(c.gx - ox), gj = (int)(c.gy - oy);                                // :261  (gxy - offsets).long()
+    gi = gi < 0 ? 0 : (gi > nx - 1 ? nx - 1 : gi);                                   // :267  clamp_ (mutates gij)
+    gj = gj < 0 ? 0 : (gj > ny - 1 ? ny - 1 : gj);
+    const int cell = ((c.b * na + c.a) * ny + gj) * nx + gi;
+    d.e_cell[eg] = cell; d.e_t[eg] = c.t; d.e_ao[eg] = c.a | (c.o << 8);
+    d.e_tbox[eg] = make_float4(c.gx - (float)gi, c.gy - (float)gj, c.gl, c.gs);      // :268
+    d.prev[eg] = atomicExch(&d.head[d.cell_off[lv] + cell], eg + 1);
+  }
+  if (blockIdx.x == gridDim.x - 1 && tid == 0) d.counts[lv] = base + tot;
 }
 
 // rows of the build_targets() return value for one level (utils/loss.py:265-272)
@@ -146,8 +208,8 @@ __global__ void k_bt_export(const LossDev* __restrict__ dp, int lv, int n, int64
     anch2[(size_t)e * 2 + 0] = d.anchors[lv][a][0]; anch2[(size_t)e * 2 + 1] = d.anchors[lv][a][1];
     tcls[e] = (int64_t)(int)d.targets[(size_t)t * d.tcols + 1];
   }
-  const float* src = d.targets + (size_t)t * d.tcols + 7;
-  for (int k = lane; k < kCslBins; k += 64) csl[(size_t)e * kCslBins + k] = src[k];
+  const CslRow row = csl_row(d, d.targets + (size_t)t * d.tcols);
+  for (int k = lane; k < kCslBins; k += 64) csl[(size_t)e * kCslBins + k] = row.at(k);
 }
 
 // ------------------------------------------------------------------ reductions
@@ -224,12 +286,13 @@ __global__ __launch_bounds__(256) void k_loss_entries_fwd(const LossDev* __restr
     const CiouOut co = ciou_fwd_bwd(pb.x, pb.y, pb.w, pb.h, tb.x, tb.y, tb.z, tb.w);               // :151
     const float* tr = d.targets + (size_t)t * d.tcols;
     const int tc = (int)tr[1];
+    const CslRow csl = csl_row(d, tr);
     float scls = 0.f, sth = 0.f;
 #pragma unroll
     for (int k = 0; k < kChunks; k++) {
       const int ch = lane + 64 * k;
       if (ch >= 5 && ch < 5 + nc) scls += bce_logits(R.x[k], (ch - 5 == tc) ? d.cp : d.cn, d.cls_pw);   // :162-168
-      else if (ch >= 5 + nc && ch < no) sth += bce_logits(R.x[k], tr[7 + ch - 5 - nc], d.theta_pw);     // :171-172
+      else if (ch >= 5 + nc && ch < no) sth += bce_logits(R.x[k], csl.at(ch - 5 - nc), d.theta_pw);     // :171-172
     }
     scls = wave_sum_f(scls); sth = wave_sum_f(sth);
     float corr = 0.f;
@@ -271,12 +334,14 @@ __device__ __forceinline__ double block_sum_1024(double v, double* s_tmp) {
   return t;
 }
 
-__global__ __launch_bounds__(1024) void k_loss_finalize(const LossDev* __restrict__ dp) {
+// one workgroup per level reduces the level's partial sums in a fixed order; the workgroup that finishes last (ticket)
+// combines the levels in level order.  Inter-workgroup hand-off through agent-scope (write-through) stores / loads.
+__global__ __launch_bounds__(1024) void k_loss_finalize(const LossDev* __restrict__ dp, float* __restrict__ lvl_out, int* __restrict__ ticket) {
   __shared__ double s_tmp[16];
+  __shared__ int s_last;
   const LossDev& d = *dp;
-  const int tid = threadIdx.x;
-  float lbox = 0.f, lobj = 0.f, lcls = 0.f, lth = 0.f;
-  for (int lv = 0; lv < d.nl; lv++) {
+  const int tid = threadIdx.x, lv = blockIdx.x;
+  {
     const int n = d.counts[lv];
     double sb = 0.0, sc = 0.0, st = 0.0, so = 0.0, sd = 0.0;
     for (int e = tid; e < n; e += 1024) {
@@ -286,16 +351,33 @@ __global__ __launch_bounds__(1024) void k_loss_finalize(const LossDev* __restric
     for (int k = tid; k < kDenseBlocks; k += 1024) sd += d.dense_part[lv * kDenseBlocks + k];
     sb = block_sum_1024(sb, s_tmp); sc = block_sum_1024(sc, s_tmp); st = block_sum_1024(st, s_tmp);
     so = block_sum_1024(so, s_tmp); sd = block_sum_1024(sd, s_tmp);
-    if (n > 0) {
-      lbox += (float)(sb / (double)n);                                      // :152  (1.0 - iou).mean()
-      if (d.nc > 1) lcls += (float)(sc / ((double)n * d.nc));               // :168
-      lth += (float)(st / ((double)n * kCslBins));                          // :172
+    if (tid == 0) {
+      float lb = 0.f, lc = 0.f, lt = 0.f;
+      if (n > 0) {
+        lb = (float)(sb / (double)n);                                      // :152  (1.0 - iou).mean()
+        if (d.nc > 1) lc = (float)(sc / ((double)n * d.nc));               // :168
+        lt = (float)(st / ((double)n * kCslBins));                         // :172
+      }
+      const float obji = (float)((sd + so) / (double)d.rows[lv]);          // :178
+      __hip_atomic_store(lvl_out + lv * 4 + 0, lb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(lvl_out + lv * 4 + 1, lc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(lvl_out + lv * 4 + 2, lt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(lvl_out + lv * 4 + 3, obji, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      s_last = (atomicAdd(ticket, 1) == (int)gridDim.x - 1) ? 1 : 0;
     }
-    const float obji = (float)((sd + so) / (double)d.rows[lv]);            // :178
-    lobj += obji * d.balance[lv];                                           // :179
-    if (tid == 0) d.out[5 + lv] = obji;
+    __syncthreads();
   }
-  if (tid == 0) {
+  if (s_last && tid == 0) {
+    float lbox = 0.f, lobj = 0.f, lcls = 0.f, lth = 0.f;
+    for (int l = 0; l < d.nl; l++) {
+      lbox += __hip_atomic_load(lvl_out + l * 4 + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      lcls += __hip_atomic_load(lvl_out + l * 4 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      lth += __hip_atomic_load(lvl_out + l * 4 + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const float obji = __hip_atomic_load(lvl_out + l * 4 + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      lobj += obji * d.balance[l];                                          // :179
+      d.out[5 + l] = obji;
+    }
     lbox *= d.g_box; lobj *= d.g_obj; lcls *= d.g_cls; lth *= d.g_theta;    // :185-188
     float total = (lbox + lobj + lcls + lth) * (float)d.bs;                 // :192
     if (d.counts[kLv]) total = __builtin_nanf("");                          // a target row pointed outside the batch / classes
@@ -403,6 +485,7 @@ __global__ __launch_bounds__(256) void k_loss_entries_bwd(const LossDev* __restr
       else if (co.ciou >= best) { best = co.ciou; w = cur; iou_w = co.ciou; }
       const float* tr = d.targets + (size_t)d.e_t[cur] * d.tcols;
       const int tc = (int)tr[1];
+      const CslRow csl = csl_row(d, tr);
       // d(1 - ciou)/d logit for channels 0..3
       const float gbox = (lane == 0) ? -co.d[0] * pb.dx : (lane == 1) ? -co.d[1] * pb.dy : (lane == 2) ? -co.d[2] * pb.dw : -co.d[3] * pb.dh;
 #pragma unroll
@@ -410,7 +493,7 @@ __global__ __launch_bounds__(256) void k_loss_entries_bwd(const LossDev* __restr
         const int ch = lane + 64 * k;
         if (k == 0 && ch < 4) acc[k] += gbox * s_box;
         else if (ch >= 5 && ch < 5 + nc) { if (nc > 1) acc[k] += bce_logits_grad(R.x[k], (ch - 5 == tc) ? d.cp : d.cn, d.cls_pw) * s_cls; }
-        else if (ch >= 5 + nc && ch < no) acc[k] += bce_logits_grad(R.x[k], tr[7 + ch - 5 - nc], d.theta_pw) * s_th;
+        else if (ch >= 5 + nc && ch < no) acc[k] += bce_logits_grad(R.x[k], csl.at(ch - 5 - nc), d.theta_pw) * s_th;
       }
     }
     (void)w;
@@ -432,6 +515,7 @@ struct LossCarve {
   LossDev* dev;
   int* counts; int* head; int *e_cell, *e_t, *e_ao, *prev; float4* e_tbox;
   float *part_box, *part_cls, *part_th, *part_obj; double* dense_part;
+  int* blkcnt; float* lvl_out;
   size_t head_bytes, total;
 };
 
@@ -456,13 +540,15 @@ static void loss_carve(void* base, const obb_loss_config* c, int64_t nt, LossCar
   for (int i = 0; i < c->nl; i++) tot += (long long)c->bs * c->na * c->ny[i] * c->nx[i];
   const size_t ce = (size_t)5 * c->na * (size_t)nt * c->nl;
   cv->dev = (LossDev*)take(sizeof(LossDev));
-  cv->counts = (int*)take((kLv + 1) * 4);
+  cv->counts = (int*)take((kLv + 2) * 4);      // [kLv] entries per level | bad-target flag | finalize ticket
   cv->head_bytes = (size_t)tot * 4;
   cv->head = (int*)take(cv->head_bytes);
   cv->e_cell = (int*)take(ce * 4); cv->e_t = (int*)take(ce * 4); cv->e_ao = (int*)take(ce * 4); cv->prev = (int*)take(ce * 4);
   cv->e_tbox = (float4*)take(ce * 16);
   cv->part_box = (float*)take(ce * 4); cv->part_cls = (float*)take(ce * 4); cv->part_th = (float*)take(ce * 4); cv->part_obj = (float*)take(ce * 4);
   cv->dense_part = (double*)take((size_t)kLv * kDenseBlocks * 8);
+  cv->lvl_out = (float*)take(kLv * 4 * 4);
+  cv->blkcnt = (int*)take(((size_t)5 * c->na * (size_t)nt / 1024 + 2) * c->nl * 4);
   cv->total = off;
 }
 
@@ -480,6 +566,8 @@ static void loss_fill(LossDev& d, const obb_loss_config* c, const LossCarve& cv,
   }
   d.anchor_t = c->anchor_t; d.cp = c->cp; d.cn = c->cn; d.cls_pw = c->cls_pw; d.theta_pw = c->theta_pw; d.obj_pw = c->obj_pw;
   d.g_box = c->gain_box; d.g_obj = c->gain_obj; d.g_cls = c->gain_cls; d.g_theta = c->gain_theta; d.gr = c->gr;
+  d.csl_from_theta = (tcols < 7 + kCslBins) ? 1 : 0;
+  d.csl_radius = c->csl_radius > 0.f ? c->csl_radius : 2.0f;
   d.targets = targets;
   d.counts = cv.counts; d.head = cv.head; d.e_cell = cv.e_cell; d.e_t = cv.e_t; d.e_ao = cv.e_ao; d.prev = cv.prev;
   d.e_tbox = cv.e_tbox; d.part_box = cv.part_box; d.part_cls = cv.part_cls; d.part_th = cv.part_th; d.part_obj = cv.part_obj;
@@ -487,10 +575,15 @@ static void loss_fill(LossDev& d, const obb_loss_config* c, const LossCarve& cv,
 }
 
 static int run_match(const obb_loss_config* c, const LossCarve& cv, const LossDev& d, hipStream_t st) {
-  hipMemsetAsync(cv.counts, 0, (kLv + 1) * 4, st);
+  hipMemsetAsync(cv.counts, 0, (kLv + 2) * 4, st);
   hipMemsetAsync(cv.head, 0, cv.head_bytes, st);
-  k_loss_setup<<<1, 64, 0, st>>>(d, cv.dev);
-  if (d.nt > 0) k_bt_match<<<c->nl, 1024, 0, st>>>(cv.dev);
+  k_loss_setup<<<1, 256, 0, st>>>(d, cv.dev);
+  if (d.nt > 0) {
+    const unsigned nblk = (unsigned)((5LL * c->na * d.nt + 1023) / 1024);
+    dim3 gb(nblk, c->nl);
+    k_bt_count<<<gb, 1024, 0, st>>>(cv.dev, cv.blkcnt);
+    k_bt_write<<<gb, 1024, 0, st>>>(cv.dev, cv.blkcnt);
+  }
   return hipGetLastError() == hipSuccess ? OBB_OK : OBB_ERR_LAUNCH;
 }
 
@@ -518,7 +611,7 @@ int obb_loss_build_targets(const obb_loss_config* cfg, const float* targets, int
                            void* ws, size_t ws_bytes, void* stream) {
   int rc = loss_check(cfg, nt);
   if (rc) return rc;
-  if ((nt > 0 && !targets) || tcols < 7 + kCslBins || !counts_out) return OBB_ERR_BAD_ARG;
+  if ((nt > 0 && !targets) || (nt > 0 && tcols < 7) || !counts_out) return OBB_ERR_BAD_ARG;
   LossCarve cv;
   loss_carve(ws, cfg, nt, &cv);
   if (!ws || ws_bytes < cv.total) return OBB_ERR_WORKSPACE;
@@ -549,7 +642,7 @@ int obb_loss_forward(const obb_loss_config* cfg, const void* const* p_levels_hos
                      int64_t tcols, float* loss_out, void* ws, size_t ws_bytes, void* stream) {
   int rc = loss_check(cfg, nt);
   if (rc) return rc;
-  if (!p_levels_host || !loss_out || (nt > 0 && !targets) || (nt > 0 && tcols < 7 + kCslBins) || (dtype != 0 && dtype != 1))
+  if (!p_levels_host || !loss_out || (nt > 0 && !targets) || (nt > 0 && tcols < 7) || (dtype != 0 && dtype != 1))
     return OBB_ERR_BAD_ARG;
   LossCarve cv;
   loss_carve(ws, cfg, nt, &cv);
@@ -568,7 +661,7 @@ int obb_loss_forward(const obb_loss_config* cfg, const void* const* p_levels_hos
     if (dtype == 0) k_loss_entries_fwd<float><<<entry_grid(d), 256, 0, st>>>(cv.dev);
     else k_loss_entries_fwd<__half><<<entry_grid(d), 256, 0, st>>>(cv.dev);
   }
-  k_loss_finalize<<<1, 1024, 0, st>>>(cv.dev);
+  k_loss_finalize<<<cfg->nl, 1024, 0, st>>>(cv.dev, cv.lvl_out, cv.counts + kLv + 1);
   return hipGetLastError() == hipSuccess ? OBB_OK : OBB_ERR_LAUNCH;
 }
 
@@ -589,7 +682,7 @@ int obb_loss_backward(const obb_loss_config* cfg, const void* const* p_levels_ho
     if (!p_levels_host[i] || !grad_levels_host[i]) return OBB_ERR_BAD_ARG;
     d.p[i] = p_levels_host[i]; d.grad[i] = grad_levels_host[i];
   }
-  k_loss_setup<<<1, 64, 0, st>>>(d, cv.dev);
+  k_loss_setup<<<1, 256, 0, st>>>(d, cv.dev);
   dim3 gd(2048, cfg->nl);
   if (dtype == 0) k_loss_bwd_dense<float><<<gd, 256, 0, st>>>(cv.dev);
   else k_loss_bwd_dense<__half><<<gd, 256, 0, st>>>(cv.dev);

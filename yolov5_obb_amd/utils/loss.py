@@ -24,7 +24,7 @@ class _LossConfig(C.Structure):
                 ("anchor_t", C.c_float), ("cp", C.c_float), ("cn", C.c_float),
                 ("cls_pw", C.c_float), ("theta_pw", C.c_float), ("obj_pw", C.c_float),
                 ("gain_box", C.c_float), ("gain_obj", C.c_float), ("gain_cls", C.c_float), ("gain_theta", C.c_float),
-                ("gr", C.c_float), ("sort_obj_iou", C.c_int32)]
+                ("gr", C.c_float), ("sort_obj_iou", C.c_int32), ("csl_radius", C.c_float)]
 
 
 def smooth_BCE(eps=0.1):  # utils/loss.py:13-15
@@ -142,6 +142,7 @@ class ComputeLoss:
         cfg.gain_box, cfg.gain_obj, cfg.gain_cls, cfg.gain_theta = float(h['box']), float(h['obj']), float(h['cls']), float(h['theta'])
         cfg.gr = float(self.gr)
         cfg.sort_obj_iou = int(bool(self.sort_obj_iou))
+        cfg.csl_radius = float(h.get('csl_radius', 2.0))      # only used for (nt,7) targets: labels regenerated on the device
         return cfg
 
     def __call__(self, p, targets):  # predictions, targets, model
