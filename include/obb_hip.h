@@ -113,7 +113,7 @@ int obb_nms_poly_f32(const float* polys, int64_t row_stride, int64_t n, float io
  * Score ties are ordered by ascending (anchor*nc + class): deterministic, where the reference inherits the order
  * of torch's unstable sort.
  */
-size_t obb_nms_obb_workspace_bytes(int64_t bs, int64_t cap_img);
+size_t obb_nms_obb_workspace_bytes(int64_t bs, int64_t cap_img, int64_t nc, int agnostic);
 int obb_non_max_suppression_obb(const void* pred, int dtype, int64_t bs, int64_t A, int64_t no, float conf_thres,
                                 float iou_thres, const int32_t* classes_host, int n_classes, int agnostic, int multi_label,
                                 int64_t max_det, int64_t max_nms, float max_wh, const float* extra8, int64_t n_extra,

@@ -71,3 +71,28 @@ def test_fused_nms_obb_candidate_overflow_retry(dev, oracle_lib):
     ref = pyref.non_max_suppression_obb(pred.clone(), **kw)
     got = general.non_max_suppression_obb(pred.to(dev), **kw)
     _cmp(got, ref, ties=True)
+
+
+def test_class_segmentation_and_its_fallbacks(dev, oracle_lib):
+    """One batch, three regimes inside ONE call: image 0 qualifies for per-class NMS segments, image 1 carries boxes with a
+    sub-pixel short side (0.001 <= s < 1: the single-list path must be used because the reference's fp32 corner rounding
+    can make such a box interact across the cls*4096 offsets), image 2 is plain.  All must equal the single-list oracle,
+    for several max_det values (the merge of the per-class kept lists must reproduce the global score order)."""
+    from yolov5_obb_amd.utils.general import non_max_suppression_obb
+    pred = synth.s_pred(3, 16000, 15, seed=77, n_obj=60, fg_frac=0.05)
+    g = torch.Generator().manual_seed(3)
+    thin = torch.rand(16000, generator=g) < 0.02
+    pred[1, thin, 3] = torch.rand(int(thin.sum()), generator=g) * 0.9 + 0.002        # short side in (0.002, 0.9)
+    pred[1, thin, 4] = 0.95
+    for max_det, multi in ((1500, True), (40, True), (300, False)):
+        kw = dict(conf_thres=0.1, iou_thres=0.45, multi_label=multi, max_det=max_det)
+        ref = pyref.non_max_suppression_obb(pred.clone(), **kw)
+        for rep in range(3):
+            got = non_max_suppression_obb(pred.to(dev), **kw)
+            _cmp(got, ref)
+    # agnostic: no class offsets, one segment per image
+    kw = dict(conf_thres=0.1, iou_thres=0.45, multi_label=True, max_det=1500, agnostic=True)
+    _cmp(non_max_suppression_obb(pred.to(dev), **kw), pyref.non_max_suppression_obb(pred.clone(), **kw))
+    # class filter
+    kw = dict(conf_thres=0.1, iou_thres=0.45, multi_label=True, max_det=1500, classes=[1, 4, 9])
+    _cmp(non_max_suppression_obb(pred.to(dev), **kw), pyref.non_max_suppression_obb(pred.clone(), **kw))

@@ -93,8 +93,8 @@ __global__ void k_make_keys32(const float* __restrict__ scores, int score_stride
   vals[i] = (uint32_t)i;
 }
 
-__global__ void k_seg_single(int n, int* seg_begin, int* seg_end, int* keep_cnt, int* nrows, int* nedges) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) { seg_begin[0] = 0; seg_end[0] = n; keep_cnt[0] = 0; nrows[0] = 0; nedges[0] = 0; }
+__global__ void k_seg_single(int n, int* seg_begin, int* seg_end, int* keep_cnt) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) { seg_begin[0] = 0; seg_end[0] = n; keep_cnt[0] = 0; }
 }
 
 __device__ __forceinline__ int key_lower_bound(const uint64_t* keys, int n, uint64_t target) {
@@ -109,15 +109,14 @@ __device__ __forceinline__ int key_lower_bound(const uint64_t* keys, int n, uint
 // segment g = sorted positions [seg_begin[g], seg_begin[g+1]); only the first `topk` of them take part
 // (utils/general.py:845-846: x = x[x[:, 5].argsort(descending=True)[:max_nms]])
 __global__ void k_seg_bounds(const uint64_t* __restrict__ keys, int n, int nseg, int shift, long long topk,
-                             int* __restrict__ seg_begin, int* __restrict__ seg_end, int* cursor, int* keep_cnt, int* ccount,
-                             int* nrows, int* nedges) {
+                             int* __restrict__ seg_begin, int* __restrict__ seg_end, int* keep_cnt) {
   int g = blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= nseg) return;
   int lo = key_lower_bound(keys, n, (uint64_t)g << shift);
   int hi = (g + 1 == nseg) ? n : key_lower_bound(keys, n, (uint64_t)(g + 1) << shift);
   if (topk > 0 && hi - lo > topk) hi = lo + (int)topk;
-  seg_begin[g] = lo; seg_end[g] = hi; cursor[g] = lo;
-  keep_cnt[g] = 0; ccount[g] = 0; nrows[g] = 0; nedges[g] = 0;
+  seg_begin[g] = lo; seg_end[g] = hi;
+  keep_cnt[g] = 0;
 }
 
 // blockDim.x is a multiple of 64 and p starts at 0: every wave covers one word of the alive bitmap
@@ -176,12 +175,17 @@ static int env_int(const char* name, int dflt, int lo, int hi) {
   if (v > hi) v = hi;
   return (v + 63) / 64 * 64;
 }
-static int cap_first() { static int c = 0; if (!c) c = env_int("OBB_NMS_CHUNK", 2048, 64, 8192); return c; }
+static int cap_first() { static int c = 0; if (!c) c = env_int("OBB_NMS_CHUNK", 2048, 64, 8192); return c; }   // clipped to cap_max in the kernel
+// (the edge list of a team is sized for the worst case cap*(cap-1)/2 of one chunk: 134 MB at 8192, 8.4 MB at 2048,
+//  2 MB at 1024 -- times the number of teams)
 static int cap_max(int64_t nseg) {
-  static int c1 = 0, cb = 0;
-  if (!c1) { c1 = env_int("OBB_NMS_CHUNK_MAX", 8192, 64, 16384); cb = env_int("OBB_NMS_CHUNK_MAX_BATCHED", 2048, 64, 16384); }
-  int c = nseg > 1 ? cb : c1;
-  return c < cap_first() ? cap_first() : c;
+  static int c1 = 0, cb = 0, cm = 0;
+  if (!c1) {
+    c1 = env_int("OBB_NMS_CHUNK_MAX", 8192, 64, 16384);
+    cb = env_int("OBB_NMS_CHUNK_MAX_BATCHED", 2048, 64, 16384);
+    cm = env_int("OBB_NMS_CHUNK_MAX_MANY", 1024, 64, 16384);
+  }
+  return nseg == 1 ? c1 : (nseg <= 64 ? cb : cm);
 }
 
 constexpr int kMaxTeams = 1024;     // >= number of CUs of any gfx950 part
@@ -191,14 +195,28 @@ struct Carve {
   uint32_t *vals_a, *vals_b;
   void* sort_tmp; size_t sort_tmp_bytes;
   float4* rec; u64* alive; size_t alive_bytes;
-  int *seg_begin, *seg_end, *cursor, *keep_cnt, *ccount, *nrows, *nedges;
-  int* bar; size_t bar_bytes;          // team barrier counters + the abort flag (zeroed before every launch)
-  int* abort_flag;
+  int *seg_begin, *seg_end, *keep_cnt;
+  int* bar; size_t bar_bytes;          // team barrier counters, abort flag, per-team nrows / nedges (zeroed before every launch)
+  int *abort_flag, *nrows, *nedges;
   u64* prof;                           // in-kernel phase timing (OBB_NMS_PHASE_PROF=1)
-  uint32_t *cidx, *rows, *edges;
+  uint32_t *rows, *edges;
   long long ecap;
   size_t total;
 };
+
+// One persistent launch runs the whole step loop (nms_core.h).  Grid: one 512-thread workgroup per CU at most --
+// all workgroups must be resident because they meet at team barriers; smaller problems get fewer workgroups
+// (cheaper barriers).
+static int cu_count() {
+  static int cus = 0;
+  if (!cus) {
+    int dev = 0; hipDeviceProp_t p;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) cus = p.multiProcessorCount;
+    if (cus < 1) cus = 1;
+    if (cus > kMaxTeams) cus = kMaxTeams;
+  }
+  return cus;
+}
 
 static hipError_t sort_tmp_query(size_t n, size_t* bytes) {
   *bytes = 0;
@@ -223,33 +241,21 @@ static int carve(void* base, int64_t n, int64_t nseg, int recq, int C, Carve* cv
   cv->rec = (float4*)take(nn * recq * 16);
   cv->alive_bytes = (nn / 64 + 8) * 8;
   cv->alive = (u64*)take(cv->alive_bytes);
-  cv->bar_bytes = ((size_t)kMaxTeams * 128 + 64) * 4;
+  cv->bar_bytes = ((size_t)kMaxTeams * 128 + 64 + 2 * (size_t)kMaxTeams) * 4;
   cv->bar = (int*)take(cv->bar_bytes);
   cv->abort_flag = cv->bar + (size_t)kMaxTeams * 128;
+  cv->nrows = cv->abort_flag + 64;
+  cv->nedges = cv->nrows + kMaxTeams;
   cv->prof = (u64*)take(32 * 8);
-  cv->seg_begin = (int*)take(ns * 4); cv->seg_end = (int*)take(ns * 4); cv->cursor = (int*)take(ns * 4);
-  cv->keep_cnt = (int*)take(ns * 4); cv->ccount = (int*)take(ns * 4);
-  cv->nrows = (int*)take(ns * 4); cv->nedges = (int*)take(ns * 4);
-  cv->cidx = (uint32_t*)take(ns * (size_t)C * 4);
-  cv->rows = (uint32_t*)take(ns * (size_t)C * 4);
+  cv->seg_begin = (int*)take(ns * 4); cv->seg_end = (int*)take(ns * 4);
+  cv->keep_cnt = (int*)take(ns * 4);
+  // scratch that only the segment a team is working on needs: one copy per team, not per segment
+  size_t nteams = ns < (size_t)cu_count() ? ns : (size_t)cu_count();
+  cv->rows = (uint32_t*)take(nteams * (size_t)C * 4);
   cv->ecap = (long long)C * (C - 1) / 2; if (cv->ecap < 1) cv->ecap = 1;
-  cv->edges = (uint32_t*)take(ns * (size_t)cv->ecap * 4);
+  cv->edges = (uint32_t*)take(nteams * (size_t)cv->ecap * 4);
   cv->total = off;
   return OBB_OK;
-}
-
-// One persistent launch runs the whole step loop (nms_core.h).  Grid: one 512-thread workgroup per CU at most --
-// all workgroups must be resident because they meet at team barriers; smaller problems get fewer workgroups
-// (cheaper barriers).
-static int cu_count() {
-  static int cus = 0;
-  if (!cus) {
-    int dev = 0; hipDeviceProp_t p;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) cus = p.multiProcessorCount;
-    if (cus < 1) cus = 1;
-    if (cus > kMaxTeams) cus = kMaxTeams;
-  }
-  return cus;
 }
 
 constexpr size_t kPersistLdsMax = 152 * 1024;   // of the 160 KB per CU: exactly one workgroup per CU
@@ -283,6 +289,7 @@ static int nms_steps(int kind, NmsArgs& a, const Carve& cv, int64_t nseg, int64_
     if (hipMemcpy(h, cv.prof, sizeof h, hipMemcpyDeviceToHost) == hipSuccess && h[6] > 0 && h[6] < (1ull << 40))
       fprintf(stderr, "[nms phases, wg0, us] select %.1f pairs %.1f wait-resolve %.1f cross %.1f barrier %.1f steps %llu | resolve (any wg) %.1f rounds %llu [first round %.1f other rounds %.1f output %.1f]\n",
               h[1] * 0.01, h[2] * 0.01, h[3] * 0.01, h[5] * 0.01, h[0] * 0.01, h[6], h[9] * 0.01, h[11], h[12] * 0.01, h[13] * 0.01, h[14] * 0.01);
+      fprintf(stderr, "    workgroups: %llu, busy time max %.1f us, mean %.1f us\n", h[24], h[22] * 0.01, h[24] ? h[23] * 0.01 / h[24] : 0.0);
       fprintf(stderr, "    cross, wave 0: items %llu row-loops %.1f us, stage-1 drains %llu = %.1f us, stage-2 drains %llu = %.1f us\n", h[21],
               h[16] * 0.01, h[19], h[17] * 0.01, h[20], h[18] * 0.01);
     hipMemsetAsync(cv.prof, 0, 32 * 8, st);
@@ -341,15 +348,14 @@ static int run_nms(int kind, const float* boxes, int stride, const float* scores
                                       cv.vals_a);
       if (rocprim::radix_sort_pairs(cv.sort_tmp, tmp, k32a, k32b, cv.vals_a, cv.vals_b, (size_t)n, 0, 32, st, false) != hipSuccess)
         return OBB_ERR_LAUNCH;
-      k_seg_single<<<1, 64, 0, st>>>((int)n, cv.seg_begin, cv.seg_end, cv.keep_cnt, cv.nrows, cv.nedges);
+      k_seg_single<<<1, 64, 0, st>>>((int)n, cv.seg_begin, cv.seg_end, cv.keep_cnt);
     } else {
       k_make_keys<<<gb, T, 0, st>>>(scores, score_stride, seg_id, tie, tie_bits, kind == 0 ? boxes : nullptr,
                                     kind == 0 ? drop_small : 0, (int)n, cv.keys_a, cv.vals_a);
       if (rocprim::radix_sort_pairs(cv.sort_tmp, tmp, cv.keys_a, cv.keys_b, cv.vals_a, cv.vals_b, (size_t)n, 0,
                                     (unsigned)(32 + tie_bits + seg_bits), st, false) != hipSuccess)
         return OBB_ERR_LAUNCH;
-      k_seg_bounds<<<gseg, T, 0, st>>>(cv.keys_b, (int)n, (int)nseg, 32 + tie_bits, 0, cv.seg_begin, cv.seg_end, cv.cursor,
-                                       cv.keep_cnt, cv.ccount, cv.nrows, cv.nedges);
+      k_seg_bounds<<<gseg, T, 0, st>>>(cv.keys_b, (int)n, (int)nseg, 32 + tie_bits, 0, cv.seg_begin, cv.seg_end, cv.keep_cnt);
     }
   }
   {
@@ -456,9 +462,9 @@ void _poly_nms(int* keep_out_host, int* num_out_host, const float* polys_host, i
   if (device_id >= 0 && device_id != cur) hipSetDevice(cur);
 }
 
-size_t obb_nms_obb_workspace_bytes(int64_t bs, int64_t cap_img) {
+size_t obb_nms_obb_workspace_bytes(int64_t bs, int64_t cap_img, int64_t nc, int agnostic) {
   ObbCarve cv;
-  if (bs < 1 || cap_img < 1 || obb_carve(nullptr, bs, cap_img, &cv)) return 0;
+  if (bs < 1 || cap_img < 1 || nc < 1 || nc > 256 || obb_carve(nullptr, bs, cap_img, agnostic ? 1 : nc, &cv)) return 0;
   return cv.total;
 }
 

@@ -40,16 +40,16 @@ typedef unsigned long long u64;
 
 struct NmsArgs {
   const float4* rec;         // [n][RECQ] AoS records in sorted order (read-only in this kernel)
-  const uint32_t* order;     // sorted position -> original index
+  const uint32_t* order;     // sorted position -> original index (NULL: keep_out receives the sorted position itself)
   u64* alive;                // [n/64 + 2] bit (p & 63) of word (p >> 6): still a candidate (only B clears bits)
   const int* seg_begin;      // [nseg] first sorted position of the segment
   const int* seg_end;        // [nseg] one past the last position considered (top-k cap applied)
   int* keep_cnt;             // [nseg] (output)
   int64_t* keep_out;         // segment g writes at keep_out[seg_begin[g] + k]
-  uint32_t* rows;            // [nseg][capmax] kept rows of the current chunk (positions)
-  int* nrows;                // [nseg]
-  uint32_t* edges;           // [nseg][ecap] (i << 16 | j), chunk-local indices, i < j
-  int* nedges;               // [nseg]
+  uint32_t* rows;            // [nteams][capmax] kept rows of the team's current chunk (positions)
+  int* nrows;                // [nteams]
+  uint32_t* edges;           // [nteams][ecap] (i << 16 | j), chunk-local indices, i < j
+  int* nedges;               // [nteams]   (a team works on one segment at a time: scratch is per team)
   int* bar;                  // [nteams][2][64] arrive / go counters, one 256-byte line each
   int* abort_flag;           // [1] set when a spin gave up
   u64* prof;                 // optional [16]: wall-clock ticks (10 ns) per phase (development aid)
@@ -217,11 +217,11 @@ __device__ __forceinline__ int nms_select(const NmsArgs& a, int se, int& cur, in
 
 // ------------------------------------------------------------------ A1: pairs inside the chunk (all waves of the team)
 template <class G>
-__device__ __forceinline__ void nms_pairs(const NmsArgs& a, int g, int cn, const uint32_t* cidx, int tw, int ntw, WaveLds<G>& L) {
+__device__ __forceinline__ void nms_pairs(const NmsArgs& a, int tm, int cn, const uint32_t* cidx, int tw, int ntw, WaveLds<G>& L) {
   const int lane = threadIdx.x & 63;
   const int nb = (cn + 63) >> 6;
   const int items = nb * nb;
-  uint32_t* edges = a.edges + (size_t)g * a.ecap;
+  uint32_t* edges = a.edges + (size_t)tm * a.ecap;
   const bool cull = a.cull != 0;
   PairQueue Q{L.qbuf, 0, 0}, Q2{L.qbuf2, 0, 0};
   // stage 2: exact clip; entries are chunk-local (i << 16 | j), so the queue lives across tiles
@@ -237,11 +237,11 @@ __device__ __forceinline__ void nms_pairs(const NmsArgs& a, int g, int cn, const
     const u64 hm = __ballot(hit);
     if (hm) {
       int base = 0;
-      if (lane == 0) base = atomicAdd(&a.nedges[g], __popcll(hm));
+      if (lane == 0) base = atomicAdd(&a.nedges[tm], __popcll(hm));
       base = __shfl(base, 0);
       if (hit) {
         const long long pos = (long long)base + __popcll(hm & lanemask_lt());
-        if (pos < a.ecap) stg_agent((a.edges + (size_t)g * a.ecap) + pos, packed);
+        if (pos < a.ecap) stg_agent(edges + pos, packed);
       }
     }
     Q2.head = (Q2.head + cnt) & 127;
@@ -249,7 +249,13 @@ __device__ __forceinline__ void nms_pairs(const NmsArgs& a, int g, int cn, const
     wave_sync();
   };
 
-  for (int item = tw; item < items; item += ntw) {
+  // small chunks: split every 64-row tile into 2 or 4 row slices so that all waves of the team have work
+  const int tri = nb * (nb + 1) / 2;
+  const int nsub = (tri * 2 <= ntw) ? 4 : ((tri <= ntw) ? 2 : 1);
+  const int rows_sub = 64 / nsub;
+  const int items_sub = items * nsub;
+  for (int it2 = tw; it2 < items_sub; it2 += ntw) {
+    const int item = it2 / nsub, sub = it2 - item * nsub;
     const int rb = item / nb, cb = item - rb * nb;
     if (rb > cb) continue;
     const int r = rb * 64 + lane, c = cb * 64 + lane;
@@ -260,6 +266,7 @@ __device__ __forceinline__ void nms_pairs(const NmsArgs& a, int g, int cn, const
     const float4 myrow = rvalid ? a.rec[(size_t)rp * G::RECQ] : make_float4(0.f, 0.f, 0.f, 0.f);
     const float4 cq = cvalid ? a.rec[(size_t)cp * G::RECQ] : make_float4(0.f, 0.f, 0.f, 0.f);
     const int nrow = min(64, cn - rb * 64);
+    const int rr_lo = sub * rows_sub, rr_hi = min(nrow, rr_lo + rows_sub);
     const bool diag = rb == cb;
     wave_sync();
 
@@ -267,7 +274,7 @@ __device__ __forceinline__ void nms_pairs(const NmsArgs& a, int g, int cn, const
       const u64 hm = __ballot(hit);
       if (hm) {
         int base = 0;
-        if (lane == 0) base = atomicAdd(&a.nedges[g], __popcll(hm));
+        if (lane == 0) base = atomicAdd(&a.nedges[tm], __popcll(hm));
         base = __shfl(base, 0);
         if (hit) {
           const long long pos = (long long)base + __popcll(hm & lanemask_lt());
@@ -294,7 +301,7 @@ __device__ __forceinline__ void nms_pairs(const NmsArgs& a, int g, int cn, const
     };
 
 #pragma unroll 2
-    for (int rr = 0; rr < nrow; rr++) {
+    for (int rr = rr_lo; rr < rr_hi; rr++) {
       const float4 rq = rdlane4(myrow, rr);
       bool pass = cvalid && (!diag || lane > rr);
       if (pass && cull) pass = !G::cheap_reject(rq, cq);
@@ -316,7 +323,7 @@ __device__ __forceinline__ void nms_pairs(const NmsArgs& a, int g, int cn, const
 // is dead / has delivered its kill, so the rounds get cheaper geometrically.
 // LDS (aliasing the wave scratch): state[capmax] | blocked[capmax] | edges[...]
 // returns the number of kept boxes of the chunk (also published in nrows[g])
-__device__ __forceinline__ int nms_resolve(const NmsArgs& a, int g, int cn, int kept_before, const uint32_t* cidx, uint8_t* smem, size_t smem_bytes,
+__device__ __forceinline__ int nms_resolve(const NmsArgs& a, int g, int tm, int cn, int kept_before, const uint32_t* cidx, uint8_t* smem, size_t smem_bytes,
                            int* s_i) {
   const int tid = threadIdx.x;
   uint8_t* state = smem;              // 0 undecided, 1 kept, 2 dead
@@ -324,9 +331,9 @@ __device__ __forceinline__ int nms_resolve(const NmsArgs& a, int g, int cn, int 
   uint32_t* ledges = reinterpret_cast<uint32_t*>(smem + 2 * (size_t)a.capmax);
   const long long lcap = ((long long)smem_bytes - 2LL * a.capmax) / 4;
   for (int j = tid; j < cn; j += kNmsThreads) { state[j] = 0; blocked[j] = 0; }
-  long long E = ldg_agent(a.nedges + g);
+  long long E = ldg_agent(a.nedges + tm);
   if (E > a.ecap) E = a.ecap;         // cannot happen: ecap is the worst case capmax*(capmax-1)/2
-  const uint32_t* edges = a.edges + (size_t)g * a.ecap;   // plain loads: acquired in serial_begin
+  const uint32_t* edges = a.edges + (size_t)tm * a.ecap;   // plain loads: acquired in serial_begin
   const bool in_lds = E <= lcap;
   int per = (int)((E + kNmsThreads - 1) / kNmsThreads);
   per |= 1;                            // odd block length: conflict-free LDS banks across the lanes
@@ -368,7 +375,7 @@ __device__ __forceinline__ int nms_resolve(const NmsArgs& a, int g, int cn, int 
       // (slots tid, tid+512, ...: coalesced, nobody else touches them), four loads in flight.  Loads AND stores are
       // agent-scope (write-through): a plain store would leave a dirty line in this XCD's L2 that can be written back
       // after the next step's edges have been published by other XCDs, and a plain re-load could hit this CU's L1.
-      uint32_t* gedges = a.edges + (size_t)g * a.ecap;
+      uint32_t* gedges = a.edges + (size_t)tm * a.ecap;
       if (round == 0) mycnt = (int)((E - tid + kNmsThreads - 1) / kNmsThreads);
       int w = 0;
       for (int k0 = 0; k0 < mycnt; k0 += 4) {
@@ -426,20 +433,20 @@ __device__ __forceinline__ int nms_resolve(const NmsArgs& a, int g, int cn, int 
   for (int k = 0; k < kNmsWaves; k++) { const int t = s_i[k]; if (k < (tid >> 6)) wpre += t; total += t; }
   int rank = wpre + incl - mine;
   const int sb = a.seg_begin[g];
-  uint32_t* rows = a.rows + (size_t)g * a.capmax;
+  uint32_t* rows = a.rows + (size_t)tm * a.capmax;
   for (int q = 0; q < per_n; q++) {
     const int j = tid * per_n + q;
     if (j < cn && state[j] == 1) {
       const uint32_t pos = cidx[j];
       stg_agent(rows + rank, pos);
       const long long o = (long long)kept_before + rank;
-      if (a.max_keep <= 0 || o < a.max_keep) a.keep_out[(size_t)sb + o] = (int64_t)a.order[pos];
+      if (a.max_keep <= 0 || o < a.max_keep) a.keep_out[(size_t)sb + o] = a.order ? (int64_t)a.order[pos] : (int64_t)pos;
       rank++;
     }
   }
   if (tid == 0) {
-    stg_agent(a.nrows + g, total);
-    stg_agent(a.nedges + g, 0);
+    stg_agent(a.nrows + tm, total);
+    stg_agent(a.nedges + tm, 0);
     stg_agent(a.keep_cnt + g, kept_before + total);   // write-through: resolvers of different steps sit on different XCDs
   }
   __syncthreads();
@@ -449,7 +456,7 @@ __device__ __forceinline__ int nms_resolve(const NmsArgs& a, int g, int cn, int 
 
 // ------------------------------------------------------------------ B: kept rows x still-alive later positions
 template <class G>
-__device__ __forceinline__ void nms_cross(const NmsArgs& a, int g, int nr, int c0, int se, int tw, int ntw, WaveLds<G>& L) {
+__device__ __forceinline__ void nms_cross(const NmsArgs& a, int tm, int nr, int c0, int se, int tw, int ntw, WaveLds<G>& L) {
   const int lane = threadIdx.x & 63;
   const int w0 = c0 >> 6, w1 = (se - 1) >> 6;
   const int ncw = w1 - w0 + 1, nrt = (nr + 63) >> 6;
@@ -460,7 +467,7 @@ __device__ __forceinline__ void nms_cross(const NmsArgs& a, int g, int nr, int c
   if (rgn > nrt) rgn = nrt;
   const int rt_per = (nrt + rgn - 1) / rgn;
   const long long items = (long long)ncw * rgn;
-  const uint32_t* rows = a.rows + (size_t)g * a.capmax;   // plain loads: acquired after the serial section
+  const uint32_t* rows = a.rows + (size_t)tm * a.capmax;   // plain loads: acquired after the serial section
   const bool cull = a.cull != 0;
   PairQueue Q{L.qbuf, 0, 0}, Q2{L.qbuf2, 0, 0};
   const bool cprof = a.prof != nullptr && blockIdx.x == 0 && threadIdx.x == 0;
@@ -600,6 +607,7 @@ __global__ __launch_bounds__(kNmsThreads) __attribute__((amdgpu_waves_per_eu(1, 
 
   const bool prof = a.prof != nullptr && blockIdx.x == 0 && tid == 0;
   u64 t0 = prof ? wall_clock64() : 0ull;
+  const u64 t_wg0 = (a.prof && tid == 0) ? wall_clock64() : 0ull;
   auto lap = [&](int slot) {
     if (prof) { const u64 t1 = wall_clock64(); a.prof[slot] += t1 - t0; t0 = t1; }
   };
@@ -612,13 +620,13 @@ __global__ __launch_bounds__(kNmsThreads) __attribute__((amdgpu_waves_per_eu(1, 
       const int cn = nms_select(a, se, cur, cap, cidx, s_i);
       lap(1);
       if (cn == 0) break;
-      nms_pairs<G>(a, g, cn, cidx, tw, ntw, L);
+      nms_pairs<G>(a, team, cn, cidx, tw, ntw, L);
       lap(2);
       // ---- all edges are out: the last arriver resolves the chunk, the others wait for its rows
       if (serial_begin(bar, &s_flag)) {
         lap(3);
         const u64 ts = (a.prof && tid == 0) ? wall_clock64() : 0ull;
-        nms_resolve(a, g, cn, kept, cidx, smem, sizeof(WaveLds<G>) * kNmsWaves, s_i);
+        nms_resolve(a, g, team, cn, kept, cidx, smem, sizeof(WaveLds<G>) * kNmsWaves, s_i);
         serial_end(bar);
         if (a.prof && tid == 0) { atomicAdd(a.prof + 9, wall_clock64() - ts); }
         lap(4);
@@ -626,11 +634,11 @@ __global__ __launch_bounds__(kNmsThreads) __attribute__((amdgpu_waves_per_eu(1, 
         if (!serial_wait(bar, &s_flag)) return;
         lap(3);
       }
-      const int nr = ldg_agent(a.nrows + g);
+      const int nr = ldg_agent(a.nrows + team);
       kept += nr;
       const bool more = cur < se && !(a.max_keep > 0 && kept >= a.max_keep);
       if (nr > 0 && more) {
-        nms_cross<G>(a, g, nr, cur, se, tw, ntw, L);
+        nms_cross<G>(a, team, nr, cur, se, tw, ntw, L);
         lap(5);
         if (!team_barrier(bar, &s_flag)) return;       // the kills are visible before anybody selects again
         lap(0);
@@ -639,6 +647,7 @@ __global__ __launch_bounds__(kNmsThreads) __attribute__((amdgpu_waves_per_eu(1, 
       if (cap < a.capmax) { cap *= 2; if (cap > a.capmax) cap = a.capmax; }
     }
   }
+  if (a.prof && tid == 0) { const u64 el = wall_clock64() - t_wg0; atomicMax(a.prof + 22, el); atomicAdd(a.prof + 23, el); atomicAdd(a.prof + 24, 1ull); }
 }
 
 }  // namespace obb

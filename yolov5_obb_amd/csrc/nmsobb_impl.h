@@ -11,8 +11,19 @@
 //                 (descending conf, then ascending anchor*nc+class: a deterministic tie rule).
 //   segmented radix sort (rocPRIM) per image, top max_nms (30000) kept           (:845-846)
 //   k_prep_cand   class offset xy += cls*max_wh (:849-851), rotated-box records, too-small filter of obb_nms
-//   LC-NMS steps  (nms_core.h) with max_keep = max_det                           (:853-855)
+//   LC-NMS        (nms_core.h) with max_keep = max_det                           (:853-855)
 //   k_gather_out  rows [x y l s theta conf cls] of the kept candidates, [bs][max_det][7] + counts
+//
+// Class segmentation.  The reference runs ONE greedy NMS per image over boxes shifted by cls*4096 so that boxes of
+// different classes never overlap (:849-851).  Whenever that premise provably holds for what the reference's IoU
+// code computes -- no candidate with 0.001 <= min(l,s) < 1 px (a box that thin, seen from >= 2.5k px away, is where the
+// reference's fp32 corner rounding can fabricate an overlap, riou_device.h), at most max_nms candidates, not agnostic
+// -- the image is split into one NMS segment per class: the sort key gets the class in its top byte (k_rekey), the
+// segments are found by binary search (k_class_bounds), and the per-class kept lists (each in descending score) are
+// merged back into the reference's global descending-score order by rank counting (k_gather_out).  The kept set and
+// its order are identical to the single-list NMS; the work drops by about the number of classes and the segments
+// (bs*nc of them) each get their own workgroup, so no inter-workgroup barrier is left on the path.  Images that do not
+// qualify keep the single-list path inside the same launch (segment 0 of the image holds everything).
 //
 // The only host<->device traffic is the caller reading the bs counts (+ the overflow word) afterwards.
 #pragma once
@@ -53,6 +64,7 @@ struct DecodeArgs {
   unsigned long long* keys;  // [bs*cap_img]
   uint32_t* vals;            // [bs*cap_img] slot index inside the image region
   int* cnt;                  // [bs * kCntPad] candidates produced (may exceed cap_img: overflow), one 256-B line each
+  int* tiny;                 // [bs] set when the image has a candidate with 0.001 <= min(l,s) < 1 (no class segmentation)
 };
 
 __device__ __forceinline__ bool class_allowed(const ClassMask& cm, int c) {
@@ -116,6 +128,7 @@ __global__ __launch_bounds__(256) void k_decode(DecodeArgs a) {
   uint32_t* vals = a.vals + (size_t)b * a.cap_img;
   float4* c0s = s_c0[wv]; float4* c1s = s_c1[wv]; unsigned long long* kys = s_key[wv];
   int staged = 0;   // wave-uniform
+  bool tiny_seen = false;
 
   auto write_out = [&](long long base, int count) {
     for (int i = lane; i < count; i += 64) {
@@ -191,6 +204,7 @@ __global__ __launch_bounds__(256) void k_decode(DecodeArgs a) {
       wave_argmax_first(tv, ti);
       const float theta = ((float)(ti - 90) / 180.0f) * 3.141592f;
       const float bx = __shfl(cur.box, 0), by = __shfl(cur.box, 1), bl = __shfl(cur.box, 2), bs_ = __shfl(cur.box, 3);
+      { const float mn = (bs_ < bl) ? bs_ : bl; if (mn >= 0.001f && mn < 1.0f) tiny_seen = true; }
       if (a.multi_label) {
 #pragma unroll
         for (int q = 0; q < 4; q++) {
@@ -222,6 +236,7 @@ __global__ __launch_bounds__(256) void k_decode(DecodeArgs a) {
     have = have_next; ck = nk; crr = nrr; cur = nxt;
   }
 
+  if (tiny_seen && lane == 0) atomicOr(&a.tiny[b], 1);
   // ---- one atomic per workgroup for whatever is still staged
   if (lane == 0) s_cnt[wv] = staged;
   __syncthreads();
@@ -243,6 +258,7 @@ __global__ void k_append_extra(const float* __restrict__ extra8, int m, long lon
   const int b = (int)e[0];
   if (b < 0 || b >= a.bs) return;
   const int slot = atomicAdd(&a.cnt[b * kCntPad], 1);
+  { const float mn = (e[4] < e[3]) ? e[4] : e[3]; if (mn >= 0.001f && mn < 1.0f) atomicOr(&a.tiny[b], 1); }
   if (slot >= a.cap_img) return;
   const size_t g = (size_t)b * a.cap_img + slot;
   a.cand[g * 2] = make_float4(e[1], e[2], e[3], e[4]);
@@ -251,27 +267,71 @@ __global__ void k_append_extra(const float* __restrict__ extra8, int m, long lon
   a.vals[g] = (uint32_t)slot;
 }
 
-__global__ void k_cand_segments(const int* __restrict__ cnt, int bs, long long cap_img, long long max_nms, int* sort_begin,
-                                int* sort_end, int* seg_begin, int* seg_end, int* cursor, int* keep_cnt, int* ccount, int* nrows,
-                                int* nedges) {
+// per image: sort range, mode (1 = one NMS segment per class), number of positions that take part
+__global__ void k_cand_segments(const int* __restrict__ cnt, const int* __restrict__ tiny, int bs, long long cap_img, long long max_nms,
+                                int class_ok, int* sort_begin, int* sort_end, int* img_end, int* mode) {
   int g = blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= bs) return;
   long long c = cnt[g * kCntPad];
-  if (c > cap_img) c = cap_img;
+  const bool over_cap = c > cap_img;
+  if (over_cap) c = cap_img;
   const int b0 = (int)(g * cap_img);
   sort_begin[g] = b0; sort_end[g] = b0 + (int)c;
-  if (max_nms > 0 && c > max_nms) c = max_nms;
-  seg_begin[g] = b0; seg_end[g] = b0 + (int)c; cursor[g] = b0;
-  keep_cnt[g] = 0; ccount[g] = 0; nrows[g] = 0; nedges[g] = 0;
+  const bool over_nms = max_nms > 0 && c > max_nms;
+  if (over_nms) c = max_nms;                                 // :845-846 top max_nms by confidence
+  img_end[g] = b0 + (int)c;
+  mode[g] = (class_ok && !over_cap && !over_nms && !tiny[g]) ? 1 : 0;
+}
+
+// class-segmented images: key (score_desc << 32 | anchor*nc + cls)  ->  (cls << 56 | score_desc << 24 | anchor)
+// (ascending key order inside a class = descending score, ties by ascending anchor; extra rows count as anchors A, A+1, ..)
+__global__ void k_rekey(const float4* __restrict__ cand, unsigned long long* __restrict__ keys, const int* __restrict__ sort_begin,
+                        const int* __restrict__ sort_end, const int* __restrict__ mode, long long A, int nc) {
+  const int g = blockIdx.y;
+  if (!mode[g]) return;
+  const int p = sort_begin[g] + blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= sort_end[g]) return;
+  const unsigned long long k = keys[p];
+  const unsigned long long score = k >> 32, tie = k & 0xffffffffull;
+  const unsigned long long cls = (unsigned long long)(int)cand[(size_t)p * 2 + 1].z;
+  const unsigned long long lim = (unsigned long long)A * nc;
+  const unsigned long long anchor = tie < lim ? tie / nc : (unsigned long long)A + (tie - lim);
+  keys[p] = (cls << 56) | (score << 24) | (anchor & 0xffffffull);
+}
+
+__device__ __forceinline__ int key_lower_bound_range(const unsigned long long* keys, int lo, int hi, unsigned long long target) {
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (keys[mid] < target) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+
+// segment table: ncs segments per image (ncs = nc, or 1 when the call is class-agnostic)
+__global__ void k_class_bounds(const unsigned long long* __restrict__ keys_sorted, const int* __restrict__ sort_begin,
+                               const int* __restrict__ img_end, const int* __restrict__ mode, int bs, int ncs, int* __restrict__ seg_begin,
+                               int* __restrict__ seg_end, int* __restrict__ keep_cnt) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= bs * ncs) return;
+  const int g = s / ncs, c = s - g * ncs;
+  const int b0 = sort_begin[g], e0 = img_end[g];
+  int lo = b0, hi = b0;
+  if (mode[g]) {
+    lo = key_lower_bound_range(keys_sorted, b0, e0, (unsigned long long)c << 56);
+    hi = (c >= 255) ? e0 : key_lower_bound_range(keys_sorted, b0, e0, (unsigned long long)(c + 1) << 56);
+  } else if (c == 0) {
+    hi = e0;                                                   // single list: everything in segment 0 of the image
+  }
+  seg_begin[s] = lo; seg_end[s] = hi; keep_cnt[s] = 0;
 }
 
 __global__ void k_prep_cand(const float4* __restrict__ cand, const uint32_t* __restrict__ vals_sorted,
-                            const int* __restrict__ seg_begin, const int* __restrict__ seg_end, long long cap_img,
-                            float class_offset, float4* __restrict__ rec, u64* __restrict__ alive, uint32_t* __restrict__ order) {
-  // seg_begin[g] = g * cap_img with cap_img a multiple of 64: every wave covers exactly one word of the alive bitmap
+                            const int* __restrict__ img_begin, const int* __restrict__ img_end, long long cap_img,
+                            float class_offset, float4* __restrict__ rec, u64* __restrict__ alive) {
+  // img_begin[g] = g * cap_img with cap_img a multiple of 64: every wave covers exactly one word of the alive bitmap
   const int g = blockIdx.y;
-  const int p = seg_begin[g] + blockIdx.x * blockDim.x + threadIdx.x;
-  const int se = seg_end[g];
+  const int p = img_begin[g] + blockIdx.x * blockDim.x + threadIdx.x;
+  const int se = img_end[g];
   bool ok = false;
   if (p < se) {
     const size_t ci = (size_t)g * cap_img + vals_sorted[p];
@@ -285,33 +345,85 @@ __global__ void k_prep_cand(const float4* __restrict__ cand, const uint32_t* __r
     for (int k = 0; k < 4; k++) rec[(size_t)p * 4 + k] = q[k];
     const float mn = (c0.w < c0.z) ? c0.w : c0.z;
     ok = !(mn < 0.001f);                                         // nms_rotated_wrapper.py:32
-    order[p] = (uint32_t)ci;
   }
   const u64 m = __ballot(ok);
   if ((threadIdx.x & 63) == 0 && m) alive[p >> 6] = m;           // the bitmap was zeroed before
 }
 
-__global__ void k_gather_out(const float4* __restrict__ cand, const int64_t* __restrict__ keep, const int* __restrict__ seg_begin,
-                             const int* __restrict__ keep_cnt, long long max_det, float* __restrict__ out, int64_t* __restrict__ out_count,
-                             const int* __restrict__ cnt, long long cap_img, int64_t* __restrict__ status,
-                             const int* __restrict__ abort_flag) {
-  const int g = blockIdx.y;
-  long long nk = keep_cnt[g];
-  if (max_det > 0 && nk > max_det) nk = max_det;
-  const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (k == 0) {
+// Output: the kept boxes of the image's segments merged into descending-score order (the order of the reference's single
+// greedy pass), first max_det of them.  One workgroup per image.  Each segment's kept list is already in ascending key
+// order; the global rank of an entry = its index in its own list + the number of entries of every other list that
+// precede it -- binary searches on merge keys (score, anchor, class) staged in LDS.
+constexpr int kMergeLds = 4096;
+__global__ __launch_bounds__(256) void k_gather_out(const float4* __restrict__ cand, const uint32_t* __restrict__ vals_sorted,
+                                                    const unsigned long long* __restrict__ keys_sorted, const int64_t* __restrict__ keep,
+                                                    const int* __restrict__ seg_begin, const int* __restrict__ keep_cnt,
+                                                    const int* __restrict__ mode, int ncs, long long max_det, float* __restrict__ out,
+                                                    int64_t* __restrict__ out_count, const int* __restrict__ cnt, long long cap_img,
+                                                    int64_t* __restrict__ status, const int* __restrict__ abort_flag) {
+  __shared__ int s_pre[257];
+  __shared__ unsigned long long s_key[kMergeLds];
+  const int g = blockIdx.x, tid = threadIdx.x;
+  // kept per segment (clipped to max_det: a class contributes at most max_det rows to the first max_det overall)
+  for (int c = tid; c < ncs; c += 256) {
+    long long k = keep_cnt[g * ncs + c];
+    if (max_det > 0 && k > max_det) k = max_det;
+    s_pre[c + 1] = (int)k;
+  }
+  if (tid == 0) s_pre[0] = 0;
+  __syncthreads();
+  if (tid == 0) for (int c = 0; c < ncs; c++) s_pre[c + 1] += s_pre[c];
+  __syncthreads();
+  const int total = s_pre[ncs];
+  if (tid == 0) {
+    long long nk = total;
+    if (max_det > 0 && nk > max_det) nk = max_det;
     out_count[g] = *abort_flag ? -1 : nk;                        // -1: the NMS kernel gave up on a barrier (host raises)
     if (cnt[g * kCntPad] > cap_img) atomicMax((unsigned long long*)status, (unsigned long long)cnt[g * kCntPad]);   // overflow: caller retries
   }
-  if (k >= nk) return;
-  const size_t ci = (size_t)keep[(size_t)seg_begin[g] + k];
-  const float4 c0 = cand[ci * 2], c1 = cand[ci * 2 + 1];
-  float* o = out + ((size_t)g * max_det + k) * 7;
-  o[0] = c0.x; o[1] = c0.y; o[2] = c0.z; o[3] = c0.w; o[4] = c1.x; o[5] = c1.y; o[6] = c1.z;
+  const bool single = !mode[g];
+  // merge key of entry e = (class c, index k): class-mode key rotated so that it orders by (score, anchor, class)
+  auto entry_pos = [&](int c, int k) -> uint32_t { return (uint32_t)keep[(size_t)seg_begin[g * ncs + c] + k]; };
+  auto mkey_at = [&](uint32_t p) -> unsigned long long { const unsigned long long k = keys_sorted[p]; return (k << 8) | (k >> 56); };
+  const bool in_lds = total <= kMergeLds;
+  if (!single && in_lds) {
+    for (int e = tid; e < total; e += 256) {
+      int c = 0;
+      while (s_pre[c + 1] <= e) c++;
+      s_key[e] = mkey_at(entry_pos(c, e - s_pre[c]));
+    }
+    __syncthreads();
+  }
+  for (int e = tid; e < total; e += 256) {
+    int c = 0;
+    while (s_pre[c + 1] <= e) c++;
+    const int k = e - s_pre[c];
+    const uint32_t p = entry_pos(c, k);
+    long long rank = k;
+    if (!single) {
+      const unsigned long long mk = in_lds ? s_key[e] : mkey_at(p);
+      for (int c2 = 0; c2 < ncs; c2++) {
+        if (c2 == c) continue;
+        int lo = 0, hi = s_pre[c2 + 1] - s_pre[c2];
+        while (lo < hi) {
+          const int mid = (lo + hi) >> 1;
+          const unsigned long long mk2 = in_lds ? s_key[s_pre[c2] + mid] : mkey_at(entry_pos(c2, mid));
+          if (mk2 < mk) lo = mid + 1; else hi = mid;
+        }
+        rank += lo;
+      }
+    }
+    if (max_det > 0 && rank >= max_det) continue;
+    const size_t ci = (size_t)g * cap_img + vals_sorted[p];
+    const float4 c0 = cand[ci * 2], c1 = cand[ci * 2 + 1];
+    float* o = out + ((size_t)g * max_det + rank) * 7;
+    o[0] = c0.x; o[1] = c0.y; o[2] = c0.z; o[3] = c0.w; o[4] = c1.x; o[5] = c1.y; o[6] = c1.z;
+  }
 }
 
 struct ObbCarve {
   float4* cand; unsigned long long *keys_a, *keys_b; uint32_t *vals_a, *vals_b; int* cnt; int *sort_begin, *sort_end;
+  int *img_end, *mode, *tiny;
   void* sort_tmp; size_t sort_tmp_bytes;
   int64_t* keep;
   Carve nms;          // rec/dead/segment state reuse the NMS carve (keys/vals/sort_tmp of it unused)
@@ -328,7 +440,7 @@ static hipError_t seg_sort_tmp_query(size_t n, int nseg, size_t* bytes) {
 
 static inline int64_t round_cap(int64_t cap_img) { return (cap_img + 63) / 64 * 64; }   // image regions start on alive-bitmap words
 
-static int obb_carve(void* base, int64_t bs, int64_t cap_img, ObbCarve* cv) {
+static int obb_carve(void* base, int64_t bs, int64_t cap_img, int64_t ncs, ObbCarve* cv) {
   cap_img = round_cap(cap_img);
   size_t off = 0;
   auto take = [&](size_t bytes) { size_t o = off; off += align_up(bytes); return base ? (char*)base + o : (char*)nullptr; };
@@ -337,12 +449,13 @@ static int obb_carve(void* base, int64_t bs, int64_t cap_img, ObbCarve* cv) {
   cv->keys_a = (unsigned long long*)take(n * 8); cv->keys_b = (unsigned long long*)take(n * 8);
   cv->vals_a = (uint32_t*)take(n * 4); cv->vals_b = (uint32_t*)take(n * 4);
   cv->cnt = (int*)take(bs * 4 * kCntPad); cv->sort_begin = (int*)take(bs * 4); cv->sort_end = (int*)take(bs * 4);
+  cv->img_end = (int*)take(bs * 4); cv->mode = (int*)take(bs * 4); cv->tiny = (int*)take(bs * 4);
   if (seg_sort_tmp_query(n, (int)bs, &cv->sort_tmp_bytes) != hipSuccess) return OBB_ERR_INTERNAL;
   cv->sort_tmp = take(cv->sort_tmp_bytes ? cv->sort_tmp_bytes : 16);
   cv->keep = (int64_t*)take(n * 8);
   // NMS state sized for bs * cap_img positions
   cv->nms_base = base ? (char*)base + off : nullptr;
-  int rc = carve(cv->nms_base, (int64_t)n, bs, RotGeom::RECQ, cap_max(bs), &cv->nms);
+  int rc = carve(cv->nms_base, (int64_t)n, bs * ncs, RotGeom::RECQ, cap_max(bs * ncs), &cv->nms);
   if (rc) return rc;
   off += cv->nms.total;
   cv->total = off;
@@ -359,8 +472,11 @@ static int run_nms_obb(const void* pred, int dtype, int64_t bs, int64_t A, int64
   if (A * nc + n_extra > 0xffffffffLL || bs * cap_img > 0x7fffffffLL) return OBB_ERR_BAD_ARG;
   if (dtype != 0 && dtype != 1) return OBB_ERR_BAD_ARG;
   cap_img = round_cap(cap_img);
+  const int ncs = agnostic ? 1 : nc;                               // NMS segments per image
+  // class segmentation needs the class in 8 and the anchor index in 24 key bits
+  const int class_ok = (!agnostic && nc > 1 && A + n_extra < (1ll << 24)) ? 1 : 0;
   ObbCarve cv;
-  int rc = obb_carve(ws, bs, cap_img, &cv);
+  int rc = obb_carve(ws, bs, cap_img, ncs, &cv);
   if (rc) return rc;
   if (!ws || ws_bytes < cv.total) return OBB_ERR_WORKSPACE;
 
@@ -373,9 +489,10 @@ static int run_nms_obb(const void* pred, int dtype, int64_t bs, int64_t A, int64
     int c = classes_host[i];
     if (c >= 0 && c < 256) d.cm.w[c >> 6] |= 1ull << (c & 63);
   }
-  d.cap_img = cap_img; d.cand = cv.cand; d.keys = cv.keys_a; d.vals = cv.vals_a; d.cnt = cv.cnt;
+  d.cap_img = cap_img; d.cand = cv.cand; d.keys = cv.keys_a; d.vals = cv.vals_a; d.cnt = cv.cnt; d.tiny = cv.tiny;
 
   hipMemsetAsync(cv.cnt, 0, bs * 4 * kCntPad, st);
+  hipMemsetAsync(cv.tiny, 0, bs * 4, st);
   hipMemsetAsync(status, 0, 8, st);
   dim3 gd((unsigned)((A + 4 * kDecRowsPerWave - 1) / (4 * kDecRowsPerWave)), (unsigned)bs);
   {
@@ -386,41 +503,46 @@ static int run_nms_obb(const void* pred, int dtype, int64_t bs, int64_t A, int64
   if (n_extra > 0 && extra8) k_append_extra<<<(unsigned)((n_extra + 255) / 256), 256, 0, st>>>(extra8, (int)n_extra, A, nc, d);
   const unsigned gs = (unsigned)((bs + 255) / 256);
   Carve& nv = cv.nms;
-  k_cand_segments<<<gs, 256, 0, st>>>(cv.cnt, (int)bs, cap_img, max_nms, cv.sort_begin, cv.sort_end, nv.seg_begin, nv.seg_end,
-                                      nv.cursor, nv.keep_cnt, nv.ccount, nv.nrows, nv.nedges);
+  const int64_t max_seg = (max_nms > 0 && max_nms < cap_img) ? max_nms : cap_img;
   {
     ProfScope ps(PROF_SEGSORT, st);
+    k_cand_segments<<<gs, 256, 0, st>>>(cv.cnt, cv.tiny, (int)bs, cap_img, max_nms, class_ok, cv.sort_begin, cv.sort_end, cv.img_end,
+                                        cv.mode);
+    if (class_ok) {
+      dim3 gr((unsigned)((cap_img + 255) / 256), (unsigned)bs);
+      k_rekey<<<gr, 256, 0, st>>>(cv.cand, cv.keys_a, cv.sort_begin, cv.sort_end, cv.mode, A, nc);
+    }
     size_t tmp = cv.sort_tmp_bytes;
     if (rocprim::segmented_radix_sort_pairs(cv.sort_tmp, tmp, cv.keys_a, cv.keys_b, cv.vals_a, cv.vals_b,
                                             (unsigned int)(bs * cap_img), (unsigned int)bs, cv.sort_begin, cv.sort_end, 0, 64,
                                             st, false) != hipSuccess)
       return OBB_ERR_LAUNCH;
+    const int64_t nseg = bs * ncs;
+    k_class_bounds<<<(unsigned)((nseg + 255) / 256), 256, 0, st>>>(cv.keys_b, cv.sort_begin, cv.img_end, cv.mode, (int)bs, ncs,
+                                                                   nv.seg_begin, nv.seg_end, nv.keep_cnt);
   }
-  const int64_t max_seg = (max_nms > 0 && max_nms < cap_img) ? max_nms : cap_img;
   dim3 gp((unsigned)((max_seg + 255) / 256), (unsigned)bs);
   {
     ProfScope ps(PROF_PREP, st);
     hipMemsetAsync(nv.alive, 0, nv.alive_bytes, st);
-    k_prep_cand<<<gp, 256, 0, st>>>(cv.cand, cv.vals_b, nv.seg_begin, nv.seg_end, cap_img, agnostic ? 0.f : max_wh, nv.rec,
-                                    nv.alive, nv.vals_b);
+    k_prep_cand<<<gp, 256, 0, st>>>(cv.cand, cv.vals_b, cv.sort_begin, cv.img_end, cap_img, agnostic ? 0.f : max_wh, nv.rec, nv.alive);
   }
 
   NmsArgs a;
-  a.rec = nv.rec; a.order = nv.vals_b; a.alive = nv.alive; a.seg_begin = nv.seg_begin; a.seg_end = nv.seg_end;
+  a.rec = nv.rec; a.order = nullptr; a.alive = nv.alive; a.seg_begin = nv.seg_begin; a.seg_end = nv.seg_end;   // keep_out: sorted positions
   a.keep_cnt = nv.keep_cnt; a.keep_out = cv.keep;
   a.rows = nv.rows; a.nrows = nv.nrows; a.edges = nv.edges; a.nedges = nv.nedges;
-  a.ecap = nv.ecap; a.n = (int)(bs * cap_img); a.capmax = cap_max(bs);
+  a.ecap = nv.ecap; a.n = (int)(bs * cap_img); a.capmax = cap_max(bs * ncs);
   a.max_keep = (int)max_det; a.thr = iou_thres; a.cull = (iou_thres >= 0.f) ? 1 : 0;
   {
     ProfScope ps(PROF_STEPS, st);
-    rc = nms_steps(0, a, nv, bs, bs * max_seg, st);
+    rc = nms_steps(0, a, nv, bs * ncs, bs * max_seg, st);
     if (rc) return rc;
   }
-  dim3 go((unsigned)((max_det + 255) / 256), (unsigned)bs);
   {
     ProfScope ps(PROF_GATHER, st);
-    k_gather_out<<<go, 256, 0, st>>>(cv.cand, cv.keep, nv.seg_begin, nv.keep_cnt, max_det, out, out_count, cv.cnt, cap_img, status,
-                                   nv.abort_flag);
+    k_gather_out<<<(unsigned)bs, 256, 0, st>>>(cv.cand, cv.vals_b, cv.keys_b, cv.keep, nv.seg_begin, nv.keep_cnt, cv.mode, ncs, max_det,
+                                              out, out_count, cv.cnt, cap_img, status, nv.abort_flag);
   }
   return hipGetLastError() == hipSuccess ? OBB_OK : OBB_ERR_LAUNCH;
 }

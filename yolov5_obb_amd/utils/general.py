@@ -91,7 +91,7 @@ def non_max_suppression_obb(prediction, conf_thres=0.25, iou_thres=0.45, classes
     meta = torch.empty(bs + 1, dtype=torch.int64, device=dev)        # counts[bs] + status
     while True:
         with torch.cuda.device(dev):
-            ws = _lib.workspace(L.obb_nms_obb_workspace_bytes(bs, cap), dev)
+            ws = _lib.workspace(L.obb_nms_obb_workspace_bytes(bs, cap, nc, int(bool(agnostic))), dev)
             rc = L.obb_non_max_suppression_obb(
                 _lib.ptr(pred), dtype, bs, A, no, float(conf_thres), float(iou_thres),
                 C.cast(cls_arr, C.c_void_p) if cls_arr is not None else C.c_void_p(0), n_cls, int(bool(agnostic)), int(multi),
