@@ -107,9 +107,13 @@ int obb_nms_poly_f32(const float* polys, int64_t row_stride, int64_t n, float io
  *   classes_host  optional HOST array of allowed class ids (n_classes entries; NULL = all)     (:834-835)
  *   extra8      optional device rows [img, x, y, l, s, theta, conf, cls] appended as candidates: the apriori
  *               `labels` of autolabelling (:807-813), prepared by the host layer; n_extra rows
- *   cap_img     candidate slots reserved per image.  If an image produces more, *status receives that count
+ *   cap_img     candidate slots reserved per image.  If an image produces more, status[0] receives that count
  *               (> cap_img) and the caller must retry with a larger cap_img (A*nc can never overflow).
- *   out         [bs][max_det][7] fp32 rows [x y l s theta conf cls];  out_count [bs] int64;  status [1] int64
+ *   expected_cand  performance hint only: candidates per image the caller expects (e.g. status[1] of its previous call;
+ *               0 = unknown).  Above ~12k the per-image sort runs on many workgroups per image (csrc/segsort.h) instead
+ *               of rocPRIM's one-workgroup-per-segment sort; the result does not depend on the hint.
+ *   out         [bs][max_det][7] fp32 rows [x y l s theta conf cls];  out_count [bs] int64 (-1: device-side abort);
+ *               status [2] int64: [0] overflow count (see cap_img), [1] largest candidate count of any image
  * Score ties are ordered by ascending (anchor*nc + class): deterministic, where the reference inherits the order
  * of torch's unstable sort.
  */
@@ -117,8 +121,8 @@ size_t obb_nms_obb_workspace_bytes(int64_t bs, int64_t cap_img, int64_t nc, int 
 int obb_non_max_suppression_obb(const void* pred, int dtype, int64_t bs, int64_t A, int64_t no, float conf_thres,
                                 float iou_thres, const int32_t* classes_host, int n_classes, int agnostic, int multi_label,
                                 int64_t max_det, int64_t max_nms, float max_wh, const float* extra8, int64_t n_extra,
-                                int64_t cap_img, float* out, int64_t* out_count, int64_t* status, void* ws, size_t ws_bytes,
-                                void* stream);
+                                int64_t cap_img, int64_t expected_cand, float* out, int64_t* out_count, int64_t* status, void* ws,
+                                size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------ training loss -------------------- */
 

@@ -96,3 +96,19 @@ def test_class_segmentation_and_its_fallbacks(dev, oracle_lib):
     # class filter
     kw = dict(conf_thres=0.1, iou_thres=0.45, multi_label=True, max_det=1500, classes=[1, 4, 9])
     _cmp(non_max_suppression_obb(pred.to(dev), **kw), pyref.non_max_suppression_obb(pred.clone(), **kw))
+
+
+def test_large_candidate_counts_use_the_multi_workgroup_sort(dev, oracle_lib):
+    """val.py's default conf_thres = 0.001 regime: tens of thousands of candidates per image.  The first call learns the
+    candidate count (status[1]); the second one sorts with csrc/segsort.h instead of rocPRIM's one-workgroup-per-image
+    sort.  Both must give the oracle's rows (fp32: exact; > max_nms candidates: top-30000 cut + single-list path)."""
+    from yolov5_obb_amd.utils import general
+    pred = synth.s_pred(2, 40000, 15, seed=21, n_obj=80, fg_frac=0.05)
+    general._cand_memo.clear()
+    for conf in (0.02, 0.001):
+        kw = dict(conf_thres=conf, iou_thres=0.45, multi_label=True, max_det=1500)
+        ref = pyref.non_max_suppression_obb(pred.clone(), **kw)
+        for rep in range(3):
+            got = general.non_max_suppression_obb(pred.to(dev), **kw)
+            _cmp(got, ref)
+    assert max(general._cand_memo.values()) > 12288          # the last calls did take the multi-workgroup sort

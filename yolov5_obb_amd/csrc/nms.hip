@@ -199,6 +199,7 @@ struct Carve {
   int* bar; size_t bar_bytes;          // team barrier counters, abort flag, per-team nrows / nedges (zeroed before every launch)
   int *abort_flag, *nrows, *nedges;
   u64* prof;                           // in-kernel phase timing (OBB_NMS_PHASE_PROF=1)
+  int4* plan;                          // per-workgroup team plan (k_plan_teams)
   uint32_t *rows, *edges;
   long long ecap;
   size_t total;
@@ -247,6 +248,7 @@ static int carve(void* base, int64_t n, int64_t nseg, int recq, int C, Carve* cv
   cv->nrows = cv->abort_flag + 64;
   cv->nedges = cv->nrows + kMaxTeams;
   cv->prof = (u64*)take(32 * 8);
+  cv->plan = (int4*)take((size_t)kMaxTeams * 16);
   cv->seg_begin = (int*)take(ns * 4); cv->seg_end = (int*)take(ns * 4);
   cv->keep_cnt = (int*)take(ns * 4);
   // scratch that only the segment a team is working on needs: one copy per team, not per segment
@@ -307,6 +309,12 @@ static int nms_steps(int kind, NmsArgs& a, const Carve& cv, int64_t nseg, int64_
   if (nb < nseg) nb = nseg;
   if (nb > cus) nb = cus;
   if (nb < 1) nb = 1;
+  a.plan = nullptr;
+  if (nseg > 1 && nseg * 2 <= nb) {                    // room to hand out: workgroups in proportion to the segment sizes
+    int c1 = a.cap_first < a.capmax ? a.cap_first : a.capmax;
+    k_plan_teams<<<1, 1024, 0, st>>>(a.seg_begin, a.seg_end, (int)nseg, (int)nb, c1, cv.plan);
+    a.plan = cv.plan;
+  }
   return kind == 0 ? launch_persist<RotGeom>(a, (unsigned)nb, st) : launch_persist<QuadGeom>(a, (unsigned)nb, st);
 }
 
@@ -471,10 +479,11 @@ size_t obb_nms_obb_workspace_bytes(int64_t bs, int64_t cap_img, int64_t nc, int 
 int obb_non_max_suppression_obb(const void* pred, int dtype, int64_t bs, int64_t A, int64_t no, float conf_thres,
                                 float iou_thres, const int32_t* classes_host, int n_classes, int agnostic, int multi_label,
                                 int64_t max_det, int64_t max_nms, float max_wh, const float* extra8, int64_t n_extra,
-                                int64_t cap_img, float* out, int64_t* out_count, int64_t* status, void* ws, size_t ws_bytes,
-                                void* stream) {
+                                int64_t cap_img, int64_t expected_cand, float* out, int64_t* out_count, int64_t* status, void* ws,
+                                size_t ws_bytes, void* stream) {
   return run_nms_obb(pred, dtype, bs, A, no, conf_thres, iou_thres, classes_host, n_classes, agnostic, multi_label, max_det,
-                     max_nms, max_wh, extra8, n_extra, cap_img, out, out_count, status, ws, ws_bytes, (hipStream_t)stream);
+                     max_nms, max_wh, extra8, n_extra, cap_img, expected_cand, out, out_count, status, ws, ws_bytes,
+                     (hipStream_t)stream);
 }
 
 int obb_profile_enable(int on) {

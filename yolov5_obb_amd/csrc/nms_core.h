@@ -52,7 +52,9 @@ struct NmsArgs {
   int* nedges;               // [nteams]   (a team works on one segment at a time: scratch is per team)
   int* bar;                  // [nteams][2][64] arrive / go counters, one 256-byte line each
   int* abort_flag;           // [1] set when a spin gave up
-  u64* prof;                 // optional [16]: wall-clock ticks (10 ns) per phase (development aid)
+  u64* prof;                 // optional [32]: wall-clock ticks (10 ns) per phase (development aid)
+  const int4* plan;          // optional [gridDim.x] {segment, team, index in team, team size} per workgroup (k_plan_teams):
+                             // workgroups in proportion to the segment sizes; NULL or plan[0].w == 0: static teams
   long long ecap;
   int n, nseg;
   int capmax, cap_first;
@@ -596,10 +598,17 @@ __global__ __launch_bounds__(kNmsThreads) __attribute__((amdgpu_waves_per_eu(1, 
   __shared__ int s_flag;
   const int tid = threadIdx.x, wv = tid >> 6;
   const int NB = gridDim.x;
-  const int nteams = a.nseg < NB ? a.nseg : NB;
-  const int T = NB / nteams;
-  const int team = blockIdx.x / T, wg = blockIdx.x - team * T;
-  if (team >= nteams) return;
+  int nteams = a.nseg < NB ? a.nseg : NB;
+  int T = NB / nteams;
+  int team = blockIdx.x / T, wg = blockIdx.x - team * T;
+  int g_first = team, g_step = nteams;
+  if (a.plan != nullptr && a.plan[0].w > 0) {          // planned teams: exactly one segment per team
+    const int4 pl = a.plan[blockIdx.x];
+    if (pl.x < 0) return;
+    g_first = pl.x; g_step = a.nseg; team = pl.y; wg = pl.z; T = pl.w;
+  } else if (team >= nteams) {
+    return;
+  }
   WaveLds<G>& L = reinterpret_cast<WaveLds<G>*>(smem)[wv];
   uint32_t* cidx = reinterpret_cast<uint32_t*>(smem + sizeof(WaveLds<G>) * kNmsWaves);
   const int tw = wg * kNmsWaves + wv, ntw = T * kNmsWaves;
@@ -612,7 +621,7 @@ __global__ __launch_bounds__(kNmsThreads) __attribute__((amdgpu_waves_per_eu(1, 
     if (prof) { const u64 t1 = wall_clock64(); a.prof[slot] += t1 - t0; t0 = t1; }
   };
 
-  for (int g = team; g < a.nseg; g += nteams) {
+  for (int g = g_first; g < a.nseg; g += g_step) {
     const int se = a.seg_end[g];
     int cur = a.seg_begin[g], kept = 0;
     int cap = a.cap_first < a.capmax ? a.cap_first : a.capmax;
@@ -648,6 +657,79 @@ __global__ __launch_bounds__(kNmsThreads) __attribute__((amdgpu_waves_per_eu(1, 
     }
   }
   if (a.prof && tid == 0) { const u64 el = wall_clock64() - t_wg0; atomicMax(a.prof + 22, el); atomicAdd(a.prof + 23, el); atomicAdd(a.prof + 24, 1ull); }
+}
+
+// ------------------------------------------------------------------ team planning for many small segments
+// One workgroup: hands the NB workgroups of the persistent launch to the non-empty segments in proportion to their
+// estimated work (64x64 tiles of the first chunk's triangle + a fixed part), at least one each.  plan[w] = {segment, team,
+// index in team, team size}; plan[0].w == 0 signals "use the static teams" (more non-empty segments than workgroups).
+__global__ __launch_bounds__(1024) void k_plan_teams(const int* __restrict__ seg_begin, const int* __restrict__ seg_end, int nseg, int NB,
+                                                     int chunk, int4* __restrict__ plan) {
+  __shared__ long long s_cost[1024];
+  __shared__ int s_cnt[1024], s_t[1024];
+  __shared__ long long s_total;
+  __shared__ int s_nne;
+  const int tid = threadIdx.x;
+  const int per = (nseg + 1023) / 1024;
+  auto cost_of = [&](int g) -> long long {
+    const long long sz = (g < nseg) ? (long long)(seg_end[g] - seg_begin[g]) : 0;
+    if (sz <= 0) return 0;
+    const long long c = sz < chunk ? sz : chunk;
+    const long long nb = (c + 63) / 64;
+    return nb * (nb + 1) / 2 * 8 + 32 + (sz > chunk ? (sz - chunk) / 16 : 0);
+  };
+  long long myc = 0; int myn = 0;
+  for (int k = 0; k < per; k++) { const long long c = cost_of(tid * per + k); myc += c; myn += c > 0 ? 1 : 0; }
+  s_cost[tid] = myc; s_cnt[tid] = myn;
+  __syncthreads();
+  if (tid == 0) {
+    long long tc = 0; int tn = 0;
+    for (int i = 0; i < 1024; i++) { tc += s_cost[i]; tn += s_cnt[i]; }
+    s_total = tc; s_nne = tn;
+  }
+  __syncthreads();
+  const int nne = s_nne;
+  const long long total = s_total;
+  if (nne == 0 || nne > NB) {
+    for (int w = tid; w < NB; w += 1024) plan[w] = make_int4(-1, 0, 0, 0);
+    return;
+  }
+  const long long spare = NB - nne;
+  // team sizes of this thread's segments, then exclusive prefixes of (workgroups, teams) over the threads
+  int myt = 0;
+  for (int k = 0; k < per; k++) {
+    const long long c = cost_of(tid * per + k);
+    if (c > 0) {
+      long long t = 1 + spare * c / total;
+      const long long useful = (c + 63) / 64;               // more workgroups than ~tiles/8 only add barrier cost
+      if (t > useful) t = useful;
+      if (t < 1) t = 1;
+      myt += (int)t;
+    }
+  }
+  s_t[tid] = myt;
+  __syncthreads();
+  if (tid == 0) {
+    int accw = 0, accn = 0;
+    for (int i = 0; i < 1024; i++) { const int t = s_t[i], n = s_cnt[i]; s_t[i] = accw; s_cnt[i] = accn; accw += t; accn += n; }
+    s_nne = accw;                                             // workgroups in use
+  }
+  __syncthreads();
+  int w0 = s_t[tid], team = s_cnt[tid];
+  for (int k = 0; k < per; k++) {
+    const int g = tid * per + k;
+    const long long c = cost_of(g);
+    if (c > 0) {
+      long long t = 1 + spare * c / total;
+      const long long useful = (c + 63) / 64;
+      if (t > useful) t = useful;
+      if (t < 1) t = 1;
+      for (int i = 0; i < (int)t; i++) plan[w0 + i] = make_int4(g, team, i, (int)t);
+      w0 += (int)t; team++;
+    }
+  }
+  const int used = s_nne;
+  for (int w = used + tid; w < NB; w += 1024) plan[w] = make_int4(-1, 0, 0, 0);
 }
 
 }  // namespace obb

@@ -28,6 +28,7 @@
 // The only host<->device traffic is the caller reading the bs counts (+ the overflow word) afterwards.
 #pragma once
 #include "dtype_device.h"
+#include "segsort.h"
 
 namespace obb {
 
@@ -355,6 +356,7 @@ __global__ void k_prep_cand(const float4* __restrict__ cand, const uint32_t* __r
 // order; the global rank of an entry = its index in its own list + the number of entries of every other list that
 // precede it -- binary searches on merge keys (score, anchor, class) staged in LDS.
 constexpr int kMergeLds = 4096;
+constexpr int64_t kSortLargeFrom = 12288;   // expected candidates per image above which the multi-workgroup sort is used
 __global__ __launch_bounds__(256) void k_gather_out(const float4* __restrict__ cand, const uint32_t* __restrict__ vals_sorted,
                                                     const unsigned long long* __restrict__ keys_sorted, const int64_t* __restrict__ keep,
                                                     const int* __restrict__ seg_begin, const int* __restrict__ keep_cnt,
@@ -380,6 +382,7 @@ __global__ __launch_bounds__(256) void k_gather_out(const float4* __restrict__ c
     if (max_det > 0 && nk > max_det) nk = max_det;
     out_count[g] = *abort_flag ? -1 : nk;                        // -1: the NMS kernel gave up on a barrier (host raises)
     if (cnt[g * kCntPad] > cap_img) atomicMax((unsigned long long*)status, (unsigned long long)cnt[g * kCntPad]);   // overflow: caller retries
+    atomicMax((unsigned long long*)status + 1, (unsigned long long)cnt[g * kCntPad]);   // feedback for the caller's next call
   }
   const bool single = !mode[g];
   // merge key of entry e = (class c, index k): class-mode key rotated so that it orders by (score, anchor, class)
@@ -424,6 +427,7 @@ __global__ __launch_bounds__(256) void k_gather_out(const float4* __restrict__ c
 struct ObbCarve {
   float4* cand; unsigned long long *keys_a, *keys_b; uint32_t *vals_a, *vals_b; int* cnt; int *sort_begin, *sort_end;
   int *img_end, *mode, *tiny;
+  uint32_t* srs_hist;
   void* sort_tmp; size_t sort_tmp_bytes;
   int64_t* keep;
   Carve nms;          // rec/dead/segment state reuse the NMS carve (keys/vals/sort_tmp of it unused)
@@ -450,6 +454,7 @@ static int obb_carve(void* base, int64_t bs, int64_t cap_img, int64_t ncs, ObbCa
   cv->vals_a = (uint32_t*)take(n * 4); cv->vals_b = (uint32_t*)take(n * 4);
   cv->cnt = (int*)take(bs * 4 * kCntPad); cv->sort_begin = (int*)take(bs * 4); cv->sort_end = (int*)take(bs * 4);
   cv->img_end = (int*)take(bs * 4); cv->mode = (int*)take(bs * 4); cv->tiny = (int*)take(bs * 4);
+  cv->srs_hist = (uint32_t*)take((size_t)bs * ((size_t)(cap_img + kSrsTile - 1) / kSrsTile) * 256 * 4);
   if (seg_sort_tmp_query(n, (int)bs, &cv->sort_tmp_bytes) != hipSuccess) return OBB_ERR_INTERNAL;
   cv->sort_tmp = take(cv->sort_tmp_bytes ? cv->sort_tmp_bytes : 16);
   cv->keep = (int64_t*)take(n * 8);
@@ -464,8 +469,8 @@ static int obb_carve(void* base, int64_t bs, int64_t cap_img, int64_t ncs, ObbCa
 
 static int run_nms_obb(const void* pred, int dtype, int64_t bs, int64_t A, int64_t no, float conf_thres, float iou_thres,
                        const int32_t* classes_host, int n_classes, int agnostic, int multi_label, int64_t max_det, int64_t max_nms,
-                       float max_wh, const float* extra8, int64_t n_extra, int64_t cap_img, float* out, int64_t* out_count,
-                       int64_t* status, void* ws, size_t ws_bytes, hipStream_t st) {
+                       float max_wh, const float* extra8, int64_t n_extra, int64_t cap_img, int64_t expected_cand, float* out,
+                       int64_t* out_count, int64_t* status, void* ws, size_t ws_bytes, hipStream_t st) {
   const int nc = (int)(no - 5 - 180);                              // :784
   if (bs < 1 || A < 1 || nc < 1 || nc > 256 || max_det < 1 || cap_img < 1 || !pred || !out || !out_count || !status)
     return OBB_ERR_BAD_ARG;
@@ -474,7 +479,9 @@ static int run_nms_obb(const void* pred, int dtype, int64_t bs, int64_t A, int64
   cap_img = round_cap(cap_img);
   const int ncs = agnostic ? 1 : nc;                               // NMS segments per image
   // class segmentation needs the class in 8 and the anchor index in 24 key bits
-  const int class_ok = (!agnostic && nc > 1 && A + n_extra < (1ll << 24)) ? 1 : 0;
+  static int no_class_seg = -1;                                    // OBB_NO_CLASS_SEG=1: A/B switch for measurements
+  if (no_class_seg < 0) { const char* e = getenv("OBB_NO_CLASS_SEG"); no_class_seg = (e && atoi(e)) ? 1 : 0; }
+  const int class_ok = (!no_class_seg && !agnostic && nc > 1 && A + n_extra < (1ll << 24)) ? 1 : 0;
   ObbCarve cv;
   int rc = obb_carve(ws, bs, cap_img, ncs, &cv);
   if (rc) return rc;
@@ -493,7 +500,7 @@ static int run_nms_obb(const void* pred, int dtype, int64_t bs, int64_t A, int64
 
   hipMemsetAsync(cv.cnt, 0, bs * 4 * kCntPad, st);
   hipMemsetAsync(cv.tiny, 0, bs * 4, st);
-  hipMemsetAsync(status, 0, 8, st);
+  hipMemsetAsync(status, 0, 16, st);
   dim3 gd((unsigned)((A + 4 * kDecRowsPerWave - 1) / (4 * kDecRowsPerWave)), (unsigned)bs);
   {
     ProfScope ps(PROF_DECODE, st);
@@ -512,11 +519,23 @@ static int run_nms_obb(const void* pred, int dtype, int64_t bs, int64_t A, int64
       dim3 gr((unsigned)((cap_img + 255) / 256), (unsigned)bs);
       k_rekey<<<gr, 256, 0, st>>>(cv.cand, cv.keys_a, cv.sort_begin, cv.sort_end, cv.mode, A, nc);
     }
-    size_t tmp = cv.sort_tmp_bytes;
-    if (rocprim::segmented_radix_sort_pairs(cv.sort_tmp, tmp, cv.keys_a, cv.keys_b, cv.vals_a, cv.vals_b,
-                                            (unsigned int)(bs * cap_img), (unsigned int)bs, cv.sort_begin, cv.sort_end, 0, 64,
-                                            st, false) != hipSuccess)
-      return OBB_ERR_LAUNCH;
+    if (expected_cand > kSortLargeFrom) {
+      // large images (val.py's default conf_thres = 0.001): every image spread over many workgroups (segsort.h)
+      int tb = 0;
+      while ((1ll << tb) < A * nc + n_extra + 1) tb++;                 // significant bits of the tie word
+      unsigned mask = 0xF0u;                                            // single-list key: score in bytes 4..7
+      for (int d = 0; d < 4; d++) if (tb > d * 8) mask |= 1u << d;
+      if (class_ok) mask = 0xFFu;                                       // + class-mode key: anchor 0..2, score 3..6, class 7
+      rc = seg_radix_sort_large(cv.keys_a, cv.keys_b, cv.vals_a, cv.vals_b, cv.sort_begin, cv.sort_end, (int)bs, cap_img, bs * cap_img,
+                                mask, cv.srs_hist, st);
+      if (rc) return rc;
+    } else {
+      size_t tmp = cv.sort_tmp_bytes;
+      if (rocprim::segmented_radix_sort_pairs(cv.sort_tmp, tmp, cv.keys_a, cv.keys_b, cv.vals_a, cv.vals_b,
+                                              (unsigned int)(bs * cap_img), (unsigned int)bs, cv.sort_begin, cv.sort_end, 0, 64,
+                                              st, false) != hipSuccess)
+        return OBB_ERR_LAUNCH;
+    }
     const int64_t nseg = bs * ncs;
     k_class_bounds<<<(unsigned)((nseg + 255) / 256), 256, 0, st>>>(cv.keys_b, cv.sort_begin, cv.img_end, cv.mode, (int)bs, ncs,
                                                                    nv.seg_begin, nv.seg_end, nv.keep_cnt);

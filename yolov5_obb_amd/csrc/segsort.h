@@ -1,0 +1,131 @@
+// Segmented LSD radix sort of (u64 key, u32 value) pairs for LARGE segments -- gfx950 (included by nms.hip, namespace obb).
+//
+// Why: rocprim::segmented_radix_sort_pairs gives every segment to ONE workgroup.  That is the right shape for the
+// speed-test regime (16 images x ~2k candidates: 0.04 ms) and the wrong one for val.py's default conf_thres = 0.001,
+// where every image brings ~65k candidates: 16 workgroups grind through 1M pairs in 2.6 ms.  Here every segment is
+// spread over as many workgroups as it has 2048-element tiles (grid = tiles x segments), one 8-bit digit per pass,
+// three small kernels per pass: tile histograms -> per-segment scan -> stable scatter (wave multi-split: lanes with the
+// same digit find each other with 8 ballots, so the order inside a digit is the input order).  Passes over digits that
+// are constant for the whole call (unused tie / class bits) are skipped by the host.
+#pragma once
+
+namespace obb {
+
+constexpr int kSrsTile = 2048;      // elements per workgroup (256 threads x 8 rounds of one element per lane ... per wave 512)
+constexpr int kSrsThreads = 256;
+
+struct SrsArgs {
+  const unsigned long long* kin; unsigned long long* kout;
+  const uint32_t* vin; uint32_t* vout;
+  const int* seg_begin; const int* seg_end;     // [nseg]
+  uint32_t* hist;                               // [nseg][tiles][256] tile histograms, then tile offsets
+  int tiles;                                    // tiles per segment (capacity / kSrsTile)
+  int shift;
+};
+
+__global__ __launch_bounds__(kSrsThreads) void k_srs_hist(SrsArgs a) {
+  __shared__ uint32_t s_h[256];
+  const int g = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x;
+  const int b0 = a.seg_begin[g] + tile * kSrsTile, se = a.seg_end[g];
+  uint32_t* out = a.hist + ((size_t)g * a.tiles + tile) * 256;
+  if (b0 >= se) { out[tid] = 0u; return; }
+  s_h[tid] = 0u;
+  __syncthreads();
+  const int e0 = min(se, b0 + kSrsTile);
+  for (int p = b0 + tid; p < e0; p += kSrsThreads) atomicAdd(&s_h[(uint32_t)(a.kin[p] >> a.shift) & 255u], 1u);
+  __syncthreads();
+  out[tid] = s_h[tid];
+}
+
+// one workgroup per segment: hist[g][tile][d] <- number of elements of the segment that precede tile `tile`'s digit-d run
+__global__ __launch_bounds__(256) void k_srs_scan(SrsArgs a) {
+  __shared__ uint32_t s_tot[256];
+  const int g = blockIdx.x, d = threadIdx.x;
+  uint32_t* h = a.hist + (size_t)g * a.tiles * 256;
+  const int nt = (a.seg_end[g] - a.seg_begin[g] + kSrsTile - 1) / kSrsTile;
+  uint32_t run = 0;
+  for (int t = 0; t < nt; t++) { const uint32_t c = h[(size_t)t * 256 + d]; h[(size_t)t * 256 + d] = run; run += c; }
+  s_tot[d] = run;
+  __syncthreads();
+  uint32_t base = 0;                                         // exclusive prefix over the digits (256 values: a plain loop)
+  for (int k = 0; k < d; k++) base += s_tot[k];
+  for (int t = 0; t < nt; t++) h[(size_t)t * 256 + d] += base;
+}
+
+__global__ __launch_bounds__(kSrsThreads) void k_srs_scatter(SrsArgs a) {
+  __shared__ uint32_t s_run[4][256];     // per wave: running count of each digit inside the wave's 512-element slice
+  const int g = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int sb = a.seg_begin[g], se = a.seg_end[g];
+  const int b0 = sb + tile * kSrsTile;
+  if (b0 >= se) return;
+  const uint32_t* off = a.hist + ((size_t)g * a.tiles + tile) * 256;
+  for (int k = tid; k < 4 * 256; k += kSrsThreads) (&s_run[0][0])[k] = 0u;
+  __syncthreads();
+  const int w0 = b0 + wv * 512;
+  unsigned long long key[8]; uint32_t val[8]; uint32_t rnk[8]; bool ok[8];
+  // pass A: per round the rank among the lanes of the wave with the same digit, and the wave's digit totals
+#pragma unroll
+  for (int r = 0; r < 8; r++) {
+    const int p = w0 + r * 64 + lane;
+    ok[r] = p < se && p < b0 + kSrsTile;
+    key[r] = ok[r] ? a.kin[p] : ~0ull;
+    val[r] = ok[r] ? a.vin[p] : 0u;
+    const uint32_t dg = (uint32_t)(key[r] >> a.shift) & 255u;
+    unsigned long long peers = __ballot(ok[r]);
+#pragma unroll
+    for (int bit = 0; bit < 8; bit++) {
+      const unsigned long long m = __ballot((dg >> bit) & 1u);
+      peers &= ((dg >> bit) & 1u) ? m : ~m;
+    }
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    const uint32_t before = (uint32_t)__popcll(peers & lt);
+    uint32_t base = 0;
+    if (ok[r]) {
+      base = s_run[wv][dg];                                  // all peers read the same value ...
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (ok[r] && before == 0) s_run[wv][dg] = base + (uint32_t)__popcll(peers);   // ... the first peer advances it
+    __builtin_amdgcn_wave_barrier();
+    rnk[r] = base + before;
+  }
+  __syncthreads();                                           // s_run now holds the waves' digit totals
+  // pass B: global position = tile offset of the digit + same digit in earlier waves + rank inside the wave
+#pragma unroll
+  for (int r = 0; r < 8; r++) {
+    if (!ok[r]) continue;
+    const uint32_t dg = (uint32_t)(key[r] >> a.shift) & 255u;
+    uint32_t pos = off[dg] + rnk[r];
+    for (int w = 0; w < wv; w++) pos += s_run[w][dg];
+    a.kout[(size_t)sb + pos] = key[r];
+    a.vout[(size_t)sb + pos] = val[r];
+  }
+}
+
+// Sorts every segment [seg_begin[g], seg_end[g]) (capacity `cap` elements each, `total` elements in the arrays) by the key
+// bytes selected in `digit_mask` (bit d set = byte d of the key takes part), result in (kb, vb).
+static int seg_radix_sort_large(unsigned long long* ka, unsigned long long* kb, uint32_t* va, uint32_t* vb, const int* seg_begin,
+                                const int* seg_end, int nseg, long long cap, long long total, unsigned digit_mask, uint32_t* hist,
+                                hipStream_t st) {
+  SrsArgs a;
+  a.seg_begin = seg_begin; a.seg_end = seg_end; a.hist = hist;
+  a.tiles = (int)((cap + kSrsTile - 1) / kSrsTile);
+  bool a_to_b = true;
+  dim3 gt((unsigned)a.tiles, (unsigned)nseg);
+  for (int d = 0; d < 8; d++) {
+    if (!((digit_mask >> d) & 1)) continue;
+    a.shift = d * 8;
+    a.kin = a_to_b ? ka : kb; a.kout = a_to_b ? kb : ka;
+    a.vin = a_to_b ? va : vb; a.vout = a_to_b ? vb : va;
+    k_srs_hist<<<gt, kSrsThreads, 0, st>>>(a);
+    k_srs_scan<<<(unsigned)nseg, 256, 0, st>>>(a);
+    k_srs_scatter<<<gt, kSrsThreads, 0, st>>>(a);
+    a_to_b = !a_to_b;
+  }
+  if (a_to_b) {                                              // even number of passes: the result sits in (ka, va)
+    hipMemcpyAsync(kb, ka, (size_t)total * 8, hipMemcpyDeviceToDevice, st);
+    hipMemcpyAsync(vb, va, (size_t)total * 4, hipMemcpyDeviceToDevice, st);
+  }
+  return hipGetLastError() == hipSuccess ? OBB_OK : OBB_ERR_LAUNCH;
+}
+
+}  // namespace obb

@@ -15,6 +15,7 @@ _MAX_WH = 4096      # utils/general.py:793
 _MAX_NMS = 30000    # utils/general.py:794
 _CSL = 180          # utils/general.py:784
 _cap_memo = {}      # (A, nc, multi_label) -> candidate slots per image that sufficed last time
+_cand_memo = {}     # same key -> largest candidate count of an image in the previous call (sort-algorithm hint)
 
 
 def _label_rows(labels, bs, nc, device):
@@ -88,14 +89,14 @@ def non_max_suppression_obb(prediction, conf_thres=0.25, iou_thres=0.45, classes
     L = _lib.lib()
     max_det = int(max_det)
     out = torch.empty((bs, max_det, 7), dtype=torch.float32, device=dev)
-    meta = torch.empty(bs + 1, dtype=torch.int64, device=dev)        # counts[bs] + status
+    meta = torch.empty(bs + 2, dtype=torch.int64, device=dev)        # counts[bs] + status[2]
     while True:
         with torch.cuda.device(dev):
             ws = _lib.workspace(L.obb_nms_obb_workspace_bytes(bs, cap, nc, int(bool(agnostic))), dev)
             rc = L.obb_non_max_suppression_obb(
                 _lib.ptr(pred), dtype, bs, A, no, float(conf_thres), float(iou_thres),
                 C.cast(cls_arr, C.c_void_p) if cls_arr is not None else C.c_void_p(0), n_cls, int(bool(agnostic)), int(multi),
-                max_det, _MAX_NMS, float(_MAX_WH), _lib.ptr(extra), n_extra, cap, _lib.ptr(out), _lib.ptr(meta),
+                max_det, _MAX_NMS, float(_MAX_WH), _lib.ptr(extra), n_extra, cap, int(_cand_memo.get(key, 0)), _lib.ptr(out), _lib.ptr(meta),
                 C.c_void_p(meta.data_ptr() + 8 * bs), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev))
         _lib.check(rc, "obb_non_max_suppression_obb")
         m = meta.tolist()                                             # the single device->host sync of the call
@@ -106,4 +107,5 @@ def non_max_suppression_obb(prediction, conf_thres=0.25, iou_thres=0.45, classes
             continue
         break
     _cap_memo[key] = cap
+    _cand_memo[key] = int(m[bs + 1])
     return [out[b, :m[b]] for b in range(bs)]
