@@ -253,11 +253,20 @@ static int carve(void* base, int64_t n, int64_t nseg, int recq, int C, Carve* cv
   cv->keep_cnt = (int*)take(ns * 4);
   // scratch that only the segment a team is working on needs: one copy per team, not per segment
   size_t nteams = ns < (size_t)cu_count() ? ns : (size_t)cu_count();
-  cv->rows = (uint32_t*)take(nteams * (size_t)C * 4);
+  cv->rows = (uint32_t*)take(nn * 4);
   cv->ecap = (long long)C * (C - 1) / 2; if (cv->ecap < 1) cv->ecap = 1;
   cv->edges = (uint32_t*)take(nteams * (size_t)cv->ecap * 4);
   cv->total = off;
   return OBB_OK;
+}
+
+// window of positions opened at a time when the caller limits the number of kept boxes (nms_core.h)
+static int nms_window(long long max_keep) {
+  if (max_keep <= 0) return 0;
+  long long w = 4 * max_keep;
+  if (w < 8192) w = 8192;
+  if (w > (1 << 30)) w = 1 << 30;
+  return (int)((w + 63) / 64 * 64);
 }
 
 constexpr size_t kPersistLdsMax = 152 * 1024;   // of the 160 KB per CU: exactly one workgroup per CU
@@ -310,7 +319,7 @@ static int nms_steps(int kind, NmsArgs& a, const Carve& cv, int64_t nseg, int64_
   if (nb > cus) nb = cus;
   if (nb < 1) nb = 1;
   a.plan = nullptr;
-  if (nseg > 1 && nseg * 2 <= nb) {                    // room to hand out: workgroups in proportion to the segment sizes
+  if (nseg > 1) {                                      // workgroups in proportion to the (non-empty) segments' sizes
     int c1 = a.cap_first < a.capmax ? a.cap_first : a.capmax;
     k_plan_teams<<<1, 1024, 0, st>>>(a.seg_begin, a.seg_end, (int)nseg, (int)nb, c1, cv.plan);
     a.plan = cv.plan;
@@ -379,6 +388,7 @@ static int run_nms(int kind, const float* boxes, int stride, const float* scores
   a.rows = cv.rows; a.nrows = cv.nrows; a.edges = cv.edges; a.nedges = cv.nedges;
   a.ecap = cv.ecap; a.n = (int)n; a.capmax = C;
   a.max_keep = (int)(max_keep > 0x7fffffffLL ? 0x7fffffffLL : (max_keep < 0 ? 0 : max_keep));
+  a.window = nms_window(a.max_keep);
   a.thr = thr;
   a.cull = (thr >= 0.f) ? 1 : 0;      // rejects predict IoU <= 0 or IoU <= thr; with thr < 0 even IoU == 0 suppresses
 

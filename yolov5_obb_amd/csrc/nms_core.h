@@ -46,8 +46,8 @@ struct NmsArgs {
   const int* seg_end;        // [nseg] one past the last position considered (top-k cap applied)
   int* keep_cnt;             // [nseg] (output)
   int64_t* keep_out;         // segment g writes at keep_out[seg_begin[g] + k]
-  uint32_t* rows;            // [nteams][capmax] kept rows of the team's current chunk (positions)
-  int* nrows;                // [nteams]
+  uint32_t* rows;            // [n] kept rows (sorted positions) of segment g at rows[seg_begin[g] + k], k = kept index
+  int* nrows;                // [nteams] rows kept in the team's current chunk
   uint32_t* edges;           // [nteams][ecap] (i << 16 | j), chunk-local indices, i < j
   int* nedges;               // [nteams]   (a team works on one segment at a time: scratch is per team)
   int* bar;                  // [nteams][2][64] arrive / go counters, one 256-byte line each
@@ -59,6 +59,7 @@ struct NmsArgs {
   int n, nseg;
   int capmax, cap_first;
   int max_keep;              // 0 = unlimited
+  int window;                // 0: a segment is one window; > 0 (used with max_keep): positions are opened window by window
   float thr;
   int cull;                  // 1: conservative rejects allowed (thr >= 0)
 };
@@ -435,7 +436,7 @@ __device__ __forceinline__ int nms_resolve(const NmsArgs& a, int g, int tm, int 
   for (int k = 0; k < kNmsWaves; k++) { const int t = s_i[k]; if (k < (tid >> 6)) wpre += t; total += t; }
   int rank = wpre + incl - mine;
   const int sb = a.seg_begin[g];
-  uint32_t* rows = a.rows + (size_t)tm * a.capmax;
+  uint32_t* rows = a.rows + (size_t)sb + kept_before;         // appended to the segment's kept-row list
   for (int q = 0; q < per_n; q++) {
     const int j = tid * per_n + q;
     if (j < cn && state[j] == 1) {
@@ -458,7 +459,7 @@ __device__ __forceinline__ int nms_resolve(const NmsArgs& a, int g, int tm, int 
 
 // ------------------------------------------------------------------ B: kept rows x still-alive later positions
 template <class G>
-__device__ __forceinline__ void nms_cross(const NmsArgs& a, int tm, int nr, int c0, int se, int tw, int ntw, WaveLds<G>& L) {
+__device__ __forceinline__ void nms_cross(const NmsArgs& a, const uint32_t* rows, int nr, int c0, int se, int tw, int ntw, WaveLds<G>& L) {
   const int lane = threadIdx.x & 63;
   const int w0 = c0 >> 6, w1 = (se - 1) >> 6;
   const int ncw = w1 - w0 + 1, nrt = (nr + 63) >> 6;
@@ -469,7 +470,7 @@ __device__ __forceinline__ void nms_cross(const NmsArgs& a, int tm, int nr, int 
   if (rgn > nrt) rgn = nrt;
   const int rt_per = (nrt + rgn - 1) / rgn;
   const long long items = (long long)ncw * rgn;
-  const uint32_t* rows = a.rows + (size_t)tm * a.capmax;   // plain loads: acquired after the serial section
+  // rows: plain loads -- published write-through by the resolver, acquired after the serial section
   const bool cull = a.cull != 0;
   PairQueue Q{L.qbuf, 0, 0}, Q2{L.qbuf2, 0, 0};
   const bool cprof = a.prof != nullptr && blockIdx.x == 0 && threadIdx.x == 0;
@@ -622,13 +623,28 @@ __global__ __launch_bounds__(kNmsThreads) __attribute__((amdgpu_waves_per_eu(1, 
   };
 
   for (int g = g_first; g < a.nseg; g += g_step) {
-    const int se = a.seg_end[g];
-    int cur = a.seg_begin[g], kept = 0;
+    const int sb = a.seg_begin[g], se = a.seg_end[g];
+    int cur = sb, kept = 0;
     int cap = a.cap_first < a.capmax ? a.cap_first : a.capmax;
+    // Windows (only with max_keep): positions are opened a window at a time -- a new window is first tested against every
+    // row kept so far, then processed like a segment of its own.  The greedy result is unchanged (every (kept row, later
+    // box) pair is still tested before the box can be selected), but once max_keep rows are kept the remaining windows
+    // are never touched: with max_det = 1500 and 30000 candidates most of the cross work disappears.
+    int wend = (a.window > 0 && sb + a.window < se) ? sb + a.window : se;
     while (cur < se && !(a.max_keep > 0 && kept >= a.max_keep)) {
-      const int cn = nms_select(a, se, cur, cap, cidx, s_i);
+      if (cur >= wend) {                                   // open the next window
+        const int wnew = (cur + a.window < se) ? cur + a.window : se;
+        if (kept > 0) {
+          nms_cross<G>(a, a.rows + sb, kept, cur, wnew, tw, ntw, L);
+          lap(5);
+          if (!team_barrier(bar, &s_flag)) return;
+          lap(0);
+        }
+        wend = wnew;
+      }
+      const int cn = nms_select(a, wend, cur, cap, cidx, s_i);
       lap(1);
-      if (cn == 0) break;
+      if (cn == 0) continue;                               // nothing alive in the rest of the window (cur == wend now)
       nms_pairs<G>(a, team, cn, cidx, tw, ntw, L);
       lap(2);
       // ---- all edges are out: the last arriver resolves the chunk, the others wait for its rows
@@ -644,14 +660,14 @@ __global__ __launch_bounds__(kNmsThreads) __attribute__((amdgpu_waves_per_eu(1, 
         lap(3);
       }
       const int nr = ldg_agent(a.nrows + team);
-      kept += nr;
-      const bool more = cur < se && !(a.max_keep > 0 && kept >= a.max_keep);
+      const bool more = cur < wend && !(a.max_keep > 0 && kept + nr >= a.max_keep);
       if (nr > 0 && more) {
-        nms_cross<G>(a, team, nr, cur, se, tw, ntw, L);
+        nms_cross<G>(a, a.rows + sb + kept, nr, cur, wend, tw, ntw, L);
         lap(5);
         if (!team_barrier(bar, &s_flag)) return;       // the kills are visible before anybody selects again
         lap(0);
       }
+      kept += nr;
       if (prof) a.prof[6] += 1;
       if (cap < a.capmax) { cap *= 2; if (cap > a.capmax) cap = a.capmax; }
     }
@@ -682,9 +698,10 @@ __global__ __launch_bounds__(1024) void k_plan_teams(const int* __restrict__ seg
   for (int k = 0; k < per; k++) { const long long c = cost_of(tid * per + k); myc += c; myn += c > 0 ? 1 : 0; }
   s_cost[tid] = myc; s_cnt[tid] = myn;
   __syncthreads();
+  const int used_thr = (nseg + per - 1) / per;              // threads that own segments
   if (tid == 0) {
     long long tc = 0; int tn = 0;
-    for (int i = 0; i < 1024; i++) { tc += s_cost[i]; tn += s_cnt[i]; }
+    for (int i = 0; i < used_thr; i++) { tc += s_cost[i]; tn += s_cnt[i]; }
     s_total = tc; s_nne = tn;
   }
   __syncthreads();
@@ -711,7 +728,7 @@ __global__ __launch_bounds__(1024) void k_plan_teams(const int* __restrict__ seg
   __syncthreads();
   if (tid == 0) {
     int accw = 0, accn = 0;
-    for (int i = 0; i < 1024; i++) { const int t = s_t[i], n = s_cnt[i]; s_t[i] = accw; s_cnt[i] = accn; accw += t; accn += n; }
+    for (int i = 0; i < used_thr; i++) { const int t = s_t[i], n = s_cnt[i]; s_t[i] = accw; s_cnt[i] = accn; accw += t; accn += n; }
     s_nne = accw;                                             // workgroups in use
   }
   __syncthreads();

@@ -268,9 +268,14 @@ __global__ void k_append_extra(const float* __restrict__ extra8, int m, long lon
   a.vals[g] = (uint32_t)slot;
 }
 
-// per image: sort range, mode (1 = one NMS segment per class), number of positions that take part
+// per image: sort range, number of positions that take part, mode:
+//   0  single list (the reference's formulation)
+//   1  one NMS segment per class, class in the top key byte (k_rekey) -- needs <= max_nms candidates
+//   2  more than max_nms candidates: single-list sort first (the top max_nms by confidence must be cut, :845-846), then one
+//      stable pass groups the survivors by class (seg_group_by_class); segments per class as in mode 1
 __global__ void k_cand_segments(const int* __restrict__ cnt, const int* __restrict__ tiny, int bs, long long cap_img, long long max_nms,
-                                int class_ok, int* sort_begin, int* sort_end, int* img_end, int* mode) {
+                                int class_ok, int group_ok, int* sort_begin, int* sort_end, int* img_end, int* mode, int* grp_begin,
+                                int* grp_end) {
   int g = blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= bs) return;
   long long c = cnt[g * kCntPad];
@@ -281,7 +286,9 @@ __global__ void k_cand_segments(const int* __restrict__ cnt, const int* __restri
   const bool over_nms = max_nms > 0 && c > max_nms;
   if (over_nms) c = max_nms;                                 // :845-846 top max_nms by confidence
   img_end[g] = b0 + (int)c;
-  mode[g] = (class_ok && !over_cap && !over_nms && !tiny[g]) ? 1 : 0;
+  const int m = (class_ok && !over_cap && !tiny[g]) ? (over_nms ? (group_ok ? 2 : 0) : 1) : 0;   // group_ok: the host launches the pass
+  mode[g] = m;
+  grp_begin[g] = b0; grp_end[g] = (m == 2) ? b0 + (int)c : b0;      // range of the class-grouping pass (empty unless mode 2)
 }
 
 // class-segmented images: key (score_desc << 32 | anchor*nc + cls)  ->  (cls << 56 | score_desc << 24 | anchor)
@@ -289,7 +296,7 @@ __global__ void k_cand_segments(const int* __restrict__ cnt, const int* __restri
 __global__ void k_rekey(const float4* __restrict__ cand, unsigned long long* __restrict__ keys, const int* __restrict__ sort_begin,
                         const int* __restrict__ sort_end, const int* __restrict__ mode, long long A, int nc) {
   const int g = blockIdx.y;
-  if (!mode[g]) return;
+  if (mode[g] != 1) return;
   const int p = sort_begin[g] + blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= sort_end[g]) return;
   const unsigned long long k = keys[p];
@@ -310,20 +317,33 @@ __device__ __forceinline__ int key_lower_bound_range(const unsigned long long* k
 
 // segment table: ncs segments per image (ncs = nc, or 1 when the call is class-agnostic)
 __global__ void k_class_bounds(const unsigned long long* __restrict__ keys_sorted, const int* __restrict__ sort_begin,
-                               const int* __restrict__ img_end, const int* __restrict__ mode, int bs, int ncs, int* __restrict__ seg_begin,
-                               int* __restrict__ seg_end, int* __restrict__ keep_cnt) {
+                               const int* __restrict__ img_end, const int* __restrict__ mode, const uint32_t* __restrict__ digit_base,
+                               int bs, int ncs, int* __restrict__ seg_begin, int* __restrict__ seg_end, int* __restrict__ keep_cnt) {
   const int s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= bs * ncs) return;
   const int g = s / ncs, c = s - g * ncs;
   const int b0 = sort_begin[g], e0 = img_end[g];
   int lo = b0, hi = b0;
-  if (mode[g]) {
+  if (mode[g] == 1) {
     lo = key_lower_bound_range(keys_sorted, b0, e0, (unsigned long long)c << 56);
     hi = (c >= 255) ? e0 : key_lower_bound_range(keys_sorted, b0, e0, (unsigned long long)(c + 1) << 56);
+  } else if (mode[g] == 2) {                                   // class runs of the grouping pass
+    lo = b0 + (int)digit_base[(size_t)g * 256 + c];
+    hi = (c + 1 < ncs && c + 1 < 256) ? b0 + (int)digit_base[(size_t)g * 256 + c + 1] : e0;
   } else if (c == 0) {
     hi = e0;                                                   // single list: everything in segment 0 of the image
   }
   seg_begin[s] = lo; seg_end[s] = hi; keep_cnt[s] = 0;
+}
+
+// mode-2 images: the grouped range comes back from the ping buffers
+__global__ void k_copy_grouped(const unsigned long long* __restrict__ ksrc, unsigned long long* __restrict__ kdst,
+                               const uint32_t* __restrict__ vsrc, uint32_t* __restrict__ vdst, const int* __restrict__ grp_begin,
+                               const int* __restrict__ grp_end) {
+  const int g = blockIdx.y;
+  const int p = grp_begin[g] + blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= grp_end[g]) return;
+  kdst[p] = ksrc[p]; vdst[p] = vsrc[p];
 }
 
 __global__ void k_prep_cand(const float4* __restrict__ cand, const uint32_t* __restrict__ vals_sorted,
@@ -384,10 +404,15 @@ __global__ __launch_bounds__(256) void k_gather_out(const float4* __restrict__ c
     if (cnt[g * kCntPad] > cap_img) atomicMax((unsigned long long*)status, (unsigned long long)cnt[g * kCntPad]);   // overflow: caller retries
     atomicMax((unsigned long long*)status + 1, (unsigned long long)cnt[g * kCntPad]);   // feedback for the caller's next call
   }
-  const bool single = !mode[g];
-  // merge key of entry e = (class c, index k): class-mode key rotated so that it orders by (score, anchor, class)
+  const int md = mode[g];
+  const bool single = md == 0;
+  // merge key of entry e = (class c, index k): the mode-1 key rotated so that it orders by (score, anchor, class);
+  // mode 2 keeps the single-list key (score, anchor*nc + class), which already is the global order
   auto entry_pos = [&](int c, int k) -> uint32_t { return (uint32_t)keep[(size_t)seg_begin[g * ncs + c] + k]; };
-  auto mkey_at = [&](uint32_t p) -> unsigned long long { const unsigned long long k = keys_sorted[p]; return (k << 8) | (k >> 56); };
+  auto mkey_at = [&](uint32_t p) -> unsigned long long {
+    const unsigned long long k = keys_sorted[p];
+    return md == 1 ? ((k << 8) | (k >> 56)) : k;
+  };
   const bool in_lds = total <= kMergeLds;
   if (!single && in_lds) {
     for (int e = tid; e < total; e += 256) {
@@ -426,8 +451,8 @@ __global__ __launch_bounds__(256) void k_gather_out(const float4* __restrict__ c
 
 struct ObbCarve {
   float4* cand; unsigned long long *keys_a, *keys_b; uint32_t *vals_a, *vals_b; int* cnt; int *sort_begin, *sort_end;
-  int *img_end, *mode, *tiny;
-  uint32_t* srs_hist;
+  int *img_end, *mode, *tiny, *grp_begin, *grp_end;
+  uint32_t *srs_hist, *digit_base;
   void* sort_tmp; size_t sort_tmp_bytes;
   int64_t* keep;
   Carve nms;          // rec/dead/segment state reuse the NMS carve (keys/vals/sort_tmp of it unused)
@@ -454,6 +479,8 @@ static int obb_carve(void* base, int64_t bs, int64_t cap_img, int64_t ncs, ObbCa
   cv->vals_a = (uint32_t*)take(n * 4); cv->vals_b = (uint32_t*)take(n * 4);
   cv->cnt = (int*)take(bs * 4 * kCntPad); cv->sort_begin = (int*)take(bs * 4); cv->sort_end = (int*)take(bs * 4);
   cv->img_end = (int*)take(bs * 4); cv->mode = (int*)take(bs * 4); cv->tiny = (int*)take(bs * 4);
+  cv->grp_begin = (int*)take(bs * 4); cv->grp_end = (int*)take(bs * 4);
+  cv->digit_base = (uint32_t*)take((size_t)bs * 256 * 4);
   cv->srs_hist = (uint32_t*)take((size_t)bs * ((size_t)(cap_img + kSrsTile - 1) / kSrsTile) * 256 * 4);
   if (seg_sort_tmp_query(n, (int)bs, &cv->sort_tmp_bytes) != hipSuccess) return OBB_ERR_INTERNAL;
   cv->sort_tmp = take(cv->sort_tmp_bytes ? cv->sort_tmp_bytes : 16);
@@ -482,6 +509,12 @@ static int run_nms_obb(const void* pred, int dtype, int64_t bs, int64_t A, int64
   static int no_class_seg = -1;                                    // OBB_NO_CLASS_SEG=1: A/B switch for measurements
   if (no_class_seg < 0) { const char* e = getenv("OBB_NO_CLASS_SEG"); no_class_seg = (e && atoi(e)) ? 1 : 0; }
   const int class_ok = (!no_class_seg && !agnostic && nc > 1 && A + n_extra < (1ll << 24)) ? 1 : 0;
+  // the class-grouping pass for images with more than max_nms candidates is only worth launching when such images are expected
+  // (off by default: per-class segments cannot share the max_det early stop of the single list, which usually ends the
+  //  NMS of such images after the first ~2000 of 30000 candidates; OBB_NMS_GROUP_AFTER_CUT=1 enables it)
+  static int group_cut = -1;
+  if (group_cut < 0) { const char* e = getenv("OBB_NMS_GROUP_AFTER_CUT"); group_cut = (e && atoi(e)) ? 1 : 0; }
+  const int group_ok = (group_cut && class_ok && max_nms > 0 && expected_cand > max_nms) ? 1 : 0;
   ObbCarve cv;
   int rc = obb_carve(ws, bs, cap_img, ncs, &cv);
   if (rc) return rc;
@@ -513,8 +546,8 @@ static int run_nms_obb(const void* pred, int dtype, int64_t bs, int64_t A, int64
   const int64_t max_seg = (max_nms > 0 && max_nms < cap_img) ? max_nms : cap_img;
   {
     ProfScope ps(PROF_SEGSORT, st);
-    k_cand_segments<<<gs, 256, 0, st>>>(cv.cnt, cv.tiny, (int)bs, cap_img, max_nms, class_ok, cv.sort_begin, cv.sort_end, cv.img_end,
-                                        cv.mode);
+    k_cand_segments<<<gs, 256, 0, st>>>(cv.cnt, cv.tiny, (int)bs, cap_img, max_nms, class_ok, group_ok, cv.sort_begin, cv.sort_end,
+                                        cv.img_end, cv.mode, cv.grp_begin, cv.grp_end);
     if (class_ok) {
       dim3 gr((unsigned)((cap_img + 255) / 256), (unsigned)bs);
       k_rekey<<<gr, 256, 0, st>>>(cv.cand, cv.keys_a, cv.sort_begin, cv.sort_end, cv.mode, A, nc);
@@ -536,9 +569,17 @@ static int run_nms_obb(const void* pred, int dtype, int64_t bs, int64_t A, int64
                                               st, false) != hipSuccess)
         return OBB_ERR_LAUNCH;
     }
+    if (group_ok) {
+      // images with more than max_nms candidates: group the top max_nms (now in score order) by class, one stable pass
+      rc = seg_group_by_class(cv.keys_b, cv.keys_a, cv.vals_b, cv.vals_a, cv.grp_begin, cv.grp_end, (int)bs, cap_img, cv.cand, cv.srs_hist,
+                              cv.digit_base, st);
+      if (rc) return rc;
+      dim3 gc((unsigned)((max_nms + 255) / 256), (unsigned)bs);
+      k_copy_grouped<<<gc, 256, 0, st>>>(cv.keys_a, cv.keys_b, cv.vals_a, cv.vals_b, cv.grp_begin, cv.grp_end);
+    }
     const int64_t nseg = bs * ncs;
-    k_class_bounds<<<(unsigned)((nseg + 255) / 256), 256, 0, st>>>(cv.keys_b, cv.sort_begin, cv.img_end, cv.mode, (int)bs, ncs,
-                                                                   nv.seg_begin, nv.seg_end, nv.keep_cnt);
+    k_class_bounds<<<(unsigned)((nseg + 255) / 256), 256, 0, st>>>(cv.keys_b, cv.sort_begin, cv.img_end, cv.mode, cv.digit_base, (int)bs,
+                                                                   ncs, nv.seg_begin, nv.seg_end, nv.keep_cnt);
   }
   dim3 gp((unsigned)((max_seg + 255) / 256), (unsigned)bs);
   {
@@ -552,7 +593,7 @@ static int run_nms_obb(const void* pred, int dtype, int64_t bs, int64_t A, int64
   a.keep_cnt = nv.keep_cnt; a.keep_out = cv.keep;
   a.rows = nv.rows; a.nrows = nv.nrows; a.edges = nv.edges; a.nedges = nv.nedges;
   a.ecap = nv.ecap; a.n = (int)(bs * cap_img); a.capmax = cap_max(bs * ncs);
-  a.max_keep = (int)max_det; a.thr = iou_thres; a.cull = (iou_thres >= 0.f) ? 1 : 0;
+  a.max_keep = (int)max_det; a.window = nms_window(max_det); a.thr = iou_thres; a.cull = (iou_thres >= 0.f) ? 1 : 0;
   {
     ProfScope ps(PROF_STEPS, st);
     rc = nms_steps(0, a, nv, bs * ncs, bs * max_seg, st);

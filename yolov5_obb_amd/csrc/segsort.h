@@ -21,7 +21,14 @@ struct SrsArgs {
   uint32_t* hist;                               // [nseg][tiles][256] tile histograms, then tile offsets
   int tiles;                                    // tiles per segment (capacity / kSrsTile)
   int shift;
+  const float4* cand; long long cap_img;        // cand != NULL: the digit is the class of the candidate the value points to
+  uint32_t* digit_base;                         // optional [nseg][256]: start of every digit's run inside the segment
 };
+
+__device__ __forceinline__ uint32_t srs_digit(const SrsArgs& a, unsigned long long key, uint32_t val, int g) {
+  if (a.cand) return (uint32_t)(int)a.cand[((size_t)g * a.cap_img + val) * 2 + 1].z & 255u;
+  return (uint32_t)(key >> a.shift) & 255u;
+}
 
 __global__ __launch_bounds__(kSrsThreads) void k_srs_hist(SrsArgs a) {
   __shared__ uint32_t s_h[256];
@@ -32,7 +39,7 @@ __global__ __launch_bounds__(kSrsThreads) void k_srs_hist(SrsArgs a) {
   s_h[tid] = 0u;
   __syncthreads();
   const int e0 = min(se, b0 + kSrsTile);
-  for (int p = b0 + tid; p < e0; p += kSrsThreads) atomicAdd(&s_h[(uint32_t)(a.kin[p] >> a.shift) & 255u], 1u);
+  for (int p = b0 + tid; p < e0; p += kSrsThreads) atomicAdd(&s_h[srs_digit(a, a.kin[p], a.vin[p], g)], 1u);
   __syncthreads();
   out[tid] = s_h[tid];
 }
@@ -50,6 +57,7 @@ __global__ __launch_bounds__(256) void k_srs_scan(SrsArgs a) {
   uint32_t base = 0;                                         // exclusive prefix over the digits (256 values: a plain loop)
   for (int k = 0; k < d; k++) base += s_tot[k];
   for (int t = 0; t < nt; t++) h[(size_t)t * 256 + d] += base;
+  if (a.digit_base) a.digit_base[(size_t)g * 256 + d] = base;
 }
 
 __global__ __launch_bounds__(kSrsThreads) void k_srs_scatter(SrsArgs a) {
@@ -70,7 +78,7 @@ __global__ __launch_bounds__(kSrsThreads) void k_srs_scatter(SrsArgs a) {
     ok[r] = p < se && p < b0 + kSrsTile;
     key[r] = ok[r] ? a.kin[p] : ~0ull;
     val[r] = ok[r] ? a.vin[p] : 0u;
-    const uint32_t dg = (uint32_t)(key[r] >> a.shift) & 255u;
+    const uint32_t dg = ok[r] ? srs_digit(a, key[r], val[r], g) : 255u;
     unsigned long long peers = __ballot(ok[r]);
 #pragma unroll
     for (int bit = 0; bit < 8; bit++) {
@@ -93,7 +101,7 @@ __global__ __launch_bounds__(kSrsThreads) void k_srs_scatter(SrsArgs a) {
 #pragma unroll
   for (int r = 0; r < 8; r++) {
     if (!ok[r]) continue;
-    const uint32_t dg = (uint32_t)(key[r] >> a.shift) & 255u;
+    const uint32_t dg = srs_digit(a, key[r], val[r], g);
     uint32_t pos = off[dg] + rnk[r];
     for (int w = 0; w < wv; w++) pos += s_run[w][dg];
     a.kout[(size_t)sb + pos] = key[r];
@@ -109,6 +117,7 @@ static int seg_radix_sort_large(unsigned long long* ka, unsigned long long* kb, 
   SrsArgs a;
   a.seg_begin = seg_begin; a.seg_end = seg_end; a.hist = hist;
   a.tiles = (int)((cap + kSrsTile - 1) / kSrsTile);
+  a.cand = nullptr; a.cap_img = 0; a.digit_base = nullptr;
   bool a_to_b = true;
   dim3 gt((unsigned)a.tiles, (unsigned)nseg);
   for (int d = 0; d < 8; d++) {
@@ -125,6 +134,23 @@ static int seg_radix_sort_large(unsigned long long* ka, unsigned long long* kb, 
     hipMemcpyAsync(kb, ka, (size_t)total * 8, hipMemcpyDeviceToDevice, st);
     hipMemcpyAsync(vb, va, (size_t)total * 4, hipMemcpyDeviceToDevice, st);
   }
+  return hipGetLastError() == hipSuccess ? OBB_OK : OBB_ERR_LAUNCH;
+}
+
+// One stable pass that groups a single-list range (already in score order; values = candidate slots of the image) by the
+// candidates' class: (kin, vin) -> (kout, vout); digit_base[g][c] receives the start of class c inside segment g.
+static int seg_group_by_class(const unsigned long long* kin, unsigned long long* kout, const uint32_t* vin, uint32_t* vout,
+                              const int* seg_begin, const int* seg_end, int nseg, long long cap, const float4* cand, uint32_t* hist,
+                              uint32_t* digit_base, hipStream_t st) {
+  SrsArgs a;
+  a.seg_begin = seg_begin; a.seg_end = seg_end; a.hist = hist;
+  a.tiles = (int)((cap + kSrsTile - 1) / kSrsTile);
+  a.shift = 0; a.cand = cand; a.cap_img = cap; a.digit_base = digit_base;
+  a.kin = kin; a.kout = kout; a.vin = vin; a.vout = vout;
+  dim3 gt((unsigned)a.tiles, (unsigned)nseg);
+  k_srs_hist<<<gt, kSrsThreads, 0, st>>>(a);
+  k_srs_scan<<<(unsigned)nseg, 256, 0, st>>>(a);
+  k_srs_scatter<<<gt, kSrsThreads, 0, st>>>(a);
   return hipGetLastError() == hipSuccess ? OBB_OK : OBB_ERR_LAUNCH;
 }
 
