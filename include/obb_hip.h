@@ -201,6 +201,20 @@ int obb_csl_encode_f32(const float* labels, int64_t n, int num_class, double u, 
  * row_stride >= 5 floats -> poly8 [n][8] and/or hbb4 [n][4] = [xc yc w h] (either may be NULL). */
 int obb_rbox2poly_f32(const float* rboxes, int64_t n, int64_t row_stride, float* poly8, float* hbb4, void* stream);
 
+/* ------------------------------------------------------------------ post-NMS tail of val.py --------- */
+
+/* val.py:226-236 for the detections of one image (n,7) [x y l s theta conf cls] in one kernel: pred_poly (n,10),
+ * pred_hbb (n,6) in model-input space, pred_polyn (n,10) / pred_hbbn (n,6) in native image space
+ * (scale_polys, utils/general.py:636-650: (x - pad_x) / gain, (y - pad_y) / gain).  Any output may be NULL. */
+int obb_val_postprocess_f32(const float* det7, int64_t n, float pad_x, float pad_y, float gain, float* poly10, float* hbb6,
+                            float* polyn10, float* hbbn6, void* stream);
+
+/* process_batch (val.py:69-90): detections (n,6) [x1 y1 x2 y2 conf cls], labels (m,5) [cls x1 y1 x2 y2], iouv (niou) on the
+ * device -> correct (n, niou) bytes (0/1).  No device->host round trip (the reference sorts the matches with numpy). */
+size_t obb_process_batch_workspace_bytes(int64_t n, int64_t m);
+int obb_process_batch_f32(const float* det6, int64_t n, const float* lab5, int64_t m, const float* iouv, int niou, uint8_t* correct,
+                          void* ws, size_t ws_bytes, void* stream);
+
 /* ------------------------------------------------------------------ pairwise IoU --------------------- */
 
 /* out[i] = IoU(a5[i], b5[i]); the device function behind the NMS

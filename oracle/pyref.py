@@ -260,3 +260,51 @@ def compute_loss(spec, p, targets, sort_obj_iou=False):
     lbox = lbox * h['box']; lobj = lobj * h['obj']; lcls = lcls * h['cls']; lth = lth * h['theta']
     bs = p[0].shape[0]
     return (lbox + lobj + lcls + lth) * bs, torch.cat((lbox, lobj, lcls, lth)).detach()
+
+
+# ----------------------------------------------------------------------------- post-NMS tail of val.py
+def xywh2xyxy(x):
+    """utils/general.py:590-597."""
+    y = x.clone()
+    y[:, 0] = x[:, 0] - x[:, 2] / 2
+    y[:, 1] = x[:, 1] - x[:, 3] / 2
+    y[:, 2] = x[:, 0] + x[:, 2] / 2
+    y[:, 3] = x[:, 1] + x[:, 3] / 2
+    return y
+
+
+def val_postprocess(pred, gain, pad):
+    """val.py:226-236 with scale_polys (utils/general.py:636-650)."""
+    poly = rbox2poly(pred[:, :5])
+    pred_poly = torch.cat((poly, pred[:, -2:]), 1)
+    pred_hbb = torch.cat((xywh2xyxy(poly2hbb(pred_poly[:, :8])), pred_poly[:, -2:]), 1)
+    pred_polyn = pred_poly.clone()
+    pred_polyn[:, [0, 2, 4, 6]] -= pad[0]
+    pred_polyn[:, [1, 3, 5, 7]] -= pad[1]
+    pred_polyn[:, :8] /= gain
+    pred_hbbn = torch.cat((xywh2xyxy(poly2hbb(pred_polyn[:, :8])), pred_polyn[:, -2:]), 1)
+    return pred_poly, pred_hbb, pred_polyn, pred_hbbn
+
+
+def box_iou(box1, box2):
+    """utils/metrics.py:246-268."""
+    area1 = (box1[:, 2] - box1[:, 0]) * (box1[:, 3] - box1[:, 1])
+    area2 = (box2[:, 2] - box2[:, 0]) * (box2[:, 3] - box2[:, 1])
+    inter = (torch.min(box1[:, None, 2:], box2[:, 2:]) - torch.max(box1[:, None, :2], box2[:, :2])).clamp(0).prod(2)
+    return inter / (area1[:, None] + area2 - inter)
+
+
+def process_batch(detections, labels, iouv):
+    """val.py:69-90, numpy steps included (argsort()[::-1], two np.unique(return_index=True))."""
+    correct = torch.zeros(detections.shape[0], iouv.shape[0], dtype=torch.bool)
+    iou = box_iou(labels[:, 1:], detections[:, :4])
+    x = torch.where((iou >= iouv[0]) & (labels[:, 0:1] == detections[:, 5]))
+    if x[0].shape[0]:
+        matches = torch.cat((torch.stack(x, 1), iou[x[0], x[1]][:, None]), 1).numpy()
+        if x[0].shape[0] > 1:
+            matches = matches[matches[:, 2].argsort()[::-1]]
+            matches = matches[np.unique(matches[:, 1], return_index=True)[1]]
+            matches = matches[np.unique(matches[:, 0], return_index=True)[1]]
+        matches = torch.Tensor(matches)
+        correct[matches[:, 1].long()] = matches[:, 2:3] >= iouv
+    return correct

@@ -32,6 +32,29 @@ from oracle import pyref           # noqa: E402
 from tests import synth            # noqa: E402
 
 
+VALPOST_CASES = {'a': (300, 40, 0), 'b': (1500, 200, 1), 'c': (7, 90, 3)}
+
+
+def valpost_inputs(n, m, seed):
+    """Detections (n,6) [xyxy conf cls] around labels (m,5) [cls xyxy] -- shared by the generator and the tests."""
+    g = torch.Generator().manual_seed(seed)
+    nc = 5
+    lab_xy = torch.rand(m, 2, generator=g) * 900
+    lab_wh = torch.rand(m, 2, generator=g) * 80 + 10
+    labels = torch.cat((torch.randint(0, nc, (m, 1), generator=g).float(), lab_xy, lab_xy + lab_wh), 1)
+    src = torch.randint(0, m, (n,), generator=g)
+    box = labels[src, 1:] + torch.randn(n, 4, generator=g) * 6
+    cls = torch.where(torch.rand(n, generator=g) < 0.85, labels[src, 0], torch.randint(0, nc, (n,), generator=g).float())
+    det = torch.cat((box, torch.rand(n, 1, generator=g), cls[:, None]), 1)
+    return det, labels, torch.linspace(0.5, 0.95, 10)
+
+
+def valpost_dets(n, seed):
+    d, s = synth.s_uniform(n, seed)
+    g = torch.Generator().manual_seed(seed + 1)
+    return torch.cat((d, s[:, None], torch.randint(0, 15, (n, 1), generator=g).float()), 1), 0.7314, (12.0, 3.5)
+
+
 def load_reference():
     def stub(name, **attrs):
         m = types.ModuleType(name)
@@ -248,6 +271,27 @@ def main():
         out[f'loss_{name}_items'] = items.numpy()
         print(f"loss {name}: loss {loss.item():.6f} items {items.tolist()} n_pos {[len(tg[2][i][0]) for i in range(3)]}")
     torch.Tensor.clamp_ = _orig_clamp_
+
+    # ------------------------------------------------------------------ G. post-NMS tail of val.py (process_batch, scale_polys chain)
+    import val as V                                                   # the reference's val.py (imports with the stubs above)
+    for name, (n, m, seed) in VALPOST_CASES.items():
+        det, labels, iouv = valpost_inputs(n, m, seed)
+        ref = V.process_batch(det.clone(), labels.clone(), iouv)
+        mine = pyref.process_batch(det.clone(), labels.clone(), iouv)
+        assert torch.equal(ref, mine), name
+        out[f'pb_{name}'] = ref.numpy()
+    d7, gain, pad = valpost_dets(600, 5)
+    poly = R.rbox2poly(d7[:, :5])
+    pred_poly = torch.cat((poly, d7[:, -2:]), 1)
+    pred_hbb = torch.cat((G.xywh2xyxy(R.poly2hbb(pred_poly[:, :8])), pred_poly[:, -2:]), 1)
+    pred_polyn = pred_poly.clone()
+    G.scale_polys((1024, 1024), pred_polyn[:, :8], (1, 1), ((gain, gain), pad))
+    pred_hbbn = torch.cat((G.xywh2xyxy(R.poly2hbb(pred_polyn[:, :8])), pred_polyn[:, -2:]), 1)
+    mine = pyref.val_postprocess(d7.clone(), gain, pad)
+    for a_, b_ in zip((pred_poly, pred_hbb, pred_polyn, pred_hbbn), mine):
+        assert torch.equal(a_, b_)
+    out.update(vp_poly=pred_poly.numpy(), vp_hbb=pred_hbb.numpy(), vp_polyn=pred_polyn.numpy(), vp_hbbn=pred_hbbn.numpy())
+    print("val.py tail ok")
 
     np.savez_compressed(os.path.join(HERE, 'reference_outputs.npz'), **out)
     sz = os.path.getsize(os.path.join(HERE, 'reference_outputs.npz'))

@@ -247,3 +247,106 @@ int obb_rbox2poly_f32(const float* rboxes, int64_t n, int64_t row_stride, float*
 }
 
 }  // extern "C"
+
+// ====================================================================== post-NMS tail of val.py
+namespace obb {
+
+// val.py:226-236 for one image's detections (n,7) [x y l s theta conf cls]:
+//   pred_poly  (n,10) = [rbox2poly, conf, cls]                       model-input space
+//   pred_hbb   (n,6)  = [xywh2xyxy(poly2hbb(poly)), conf, cls]
+//   pred_polyn (n,10) = scale_polys(pred_poly): (x - pad_x) / gain, (y - pad_y) / gain     native image space
+//   pred_hbbn  (n,6)  = [xywh2xyxy(poly2hbb(polyn)), conf, cls]
+// (utils/rboxs_utils.py:106-181, utils/general.py:590-597 xywh2xyxy, :636-650 scale_polys)
+__global__ void k_val_post(const float* __restrict__ det7, long long n, float pad_x, float pad_y, float gain,
+                           float* __restrict__ poly10, float* __restrict__ hbb6, float* __restrict__ polyn10,
+                           float* __restrict__ hbbn6) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float* r = det7 + i * 7;
+  const float x = r[0], y = r[1], w = r[2], h = r[3], th = r[4], conf = r[5], cls = r[6];
+  const float Cos = cosf(th), Sin = sinf(th);
+  const float v1x = w / 2 * Cos, v1y = -w / 2 * Sin, v2x = -h / 2 * Sin, v2y = -h / 2 * Cos;
+  float p[8];
+  p[0] = x + v1x + v2x; p[1] = y + v1y + v2y; p[2] = x + v1x - v2x; p[3] = y + v1y - v2y;
+  p[4] = x - v1x - v2x; p[5] = y - v1y - v2y; p[6] = x - v1x + v2x; p[7] = y - v1y + v2y;
+  auto hbb_xyxy = [](const float* q, float* o) {
+    const float xmax = fmaxf(fmaxf(q[0], q[2]), fmaxf(q[4], q[6])), xmin = fminf(fminf(q[0], q[2]), fminf(q[4], q[6]));
+    const float ymax = fmaxf(fmaxf(q[1], q[3]), fmaxf(q[5], q[7])), ymin = fminf(fminf(q[1], q[3]), fminf(q[5], q[7]));
+    const float xc = (xmax + xmin) / 2.0f, yc = (ymax + ymin) / 2.0f, bw = xmax - xmin, bh = ymax - ymin;   // poly2hbb
+    o[0] = xc - bw / 2; o[1] = yc - bh / 2; o[2] = xc + bw / 2; o[3] = yc + bh / 2;                          // xywh2xyxy
+  };
+  float o4[4];
+  if (poly10) { for (int k = 0; k < 8; k++) poly10[i * 10 + k] = p[k]; poly10[i * 10 + 8] = conf; poly10[i * 10 + 9] = cls; }
+  if (hbb6) { hbb_xyxy(p, o4); for (int k = 0; k < 4; k++) hbb6[i * 6 + k] = o4[k]; hbb6[i * 6 + 4] = conf; hbb6[i * 6 + 5] = cls; }
+  float pn[8];
+#pragma unroll
+  for (int k = 0; k < 8; k++) pn[k] = (p[k] - ((k & 1) ? pad_y : pad_x)) / gain;
+  if (polyn10) { for (int k = 0; k < 8; k++) polyn10[i * 10 + k] = pn[k]; polyn10[i * 10 + 8] = conf; polyn10[i * 10 + 9] = cls; }
+  if (hbbn6) { hbb_xyxy(pn, o4); for (int k = 0; k < 4; k++) hbbn6[i * 6 + k] = o4[k]; hbbn6[i * 6 + 4] = conf; hbbn6[i * 6 + 5] = cls; }
+}
+
+// val.py:69-90 process_batch.  The reference keeps, per detection, its highest-IoU label among those with the same class and
+// IoU >= iouv[0]; then, per label, the match with the LOWEST detection index (np.unique after the first de-duplication
+// has re-ordered the matches by detection index; the re-sort by IoU is commented out at val.py:86).
+__global__ void k_pb_best(const float* __restrict__ det6, int n, const float* __restrict__ lab5, int m, const float* __restrict__ iouv,
+                          int* __restrict__ best_label, float* __restrict__ best_iou, int* __restrict__ winner) {
+  const int d = blockIdx.x * blockDim.x + threadIdx.x;
+  if (d >= n) return;
+  const float thr0 = iouv[0];                                            // val.py:81  iou >= iouv[0]
+  const float* b2 = det6 + (size_t)d * 6;
+  const float area2 = (b2[2] - b2[0]) * (b2[3] - b2[1]);
+  int bl = -1; float bi = -1.f;
+  for (int l = 0; l < m; l++) {
+    const float* b1 = lab5 + (size_t)l * 5 + 1;
+    if (lab5[(size_t)l * 5] != b2[5]) continue;
+    const float area1 = (b1[2] - b1[0]) * (b1[3] - b1[1]);
+    const float iw = fmaxf(fminf(b1[2], b2[2]) - fmaxf(b1[0], b2[0]), 0.f);
+    const float ih = fmaxf(fminf(b1[3], b2[3]) - fmaxf(b1[1], b2[1]), 0.f);
+    const float inter = iw * ih;
+    const float iou = inter / (area1 + area2 - inter);                 // utils/metrics.py:265-268
+    if (iou >= thr0 && iou > bi) { bi = iou; bl = l; }
+  }
+  best_label[d] = bl; best_iou[d] = bi;
+  if (bl >= 0) atomicMin(&winner[bl], d);
+}
+__global__ void k_pb_correct(const int* __restrict__ best_label, const float* __restrict__ best_iou, const int* __restrict__ winner,
+                             const float* __restrict__ iouv, int n, int niou, uint8_t* __restrict__ correct) {
+  const int d = blockIdx.x * blockDim.x + threadIdx.x;
+  if (d >= n) return;
+  const int bl = best_label[d];
+  const bool win = bl >= 0 && winner[bl] == d;
+  for (int k = 0; k < niou; k++) correct[(size_t)d * niou + k] = (win && best_iou[d] >= iouv[k]) ? 1 : 0;
+}
+
+}  // namespace obb
+
+extern "C" {
+
+int obb_val_postprocess_f32(const float* det7, int64_t n, float pad_x, float pad_y, float gain, float* poly10, float* hbb6,
+                            float* polyn10, float* hbbn6, void* stream) {
+  if (n < 0 || !(gain > 0.f)) return OBB_ERR_BAD_ARG;
+  if (n == 0) return OBB_OK;
+  if (!det7) return OBB_ERR_BAD_ARG;
+  obb::k_val_post<<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(det7, n, pad_x, pad_y, gain, poly10, hbb6, polyn10, hbbn6);
+  return hipGetLastError() == hipSuccess ? OBB_OK : OBB_ERR_LAUNCH;
+}
+
+size_t obb_process_batch_workspace_bytes(int64_t n, int64_t m) { return (size_t)(n > 0 ? n : 1) * 8 + (size_t)(m > 0 ? m : 1) * 4 + 256; }
+
+int obb_process_batch_f32(const float* det6, int64_t n, const float* lab5, int64_t m, const float* iouv, int niou, uint8_t* correct,
+                          void* ws, size_t ws_bytes, void* stream) {
+  if (n < 0 || m < 0 || niou < 1 || n > 0x7fffffff || m > 0x7fffffff) return OBB_ERR_BAD_ARG;
+  if (n == 0) return OBB_OK;
+  if (!det6 || !iouv || !correct || (m > 0 && !lab5)) return OBB_ERR_BAD_ARG;
+  if (!ws || ws_bytes < obb_process_batch_workspace_bytes(n, m)) return OBB_ERR_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  int* best_label = (int*)ws;
+  float* best_iou = (float*)(best_label + n);
+  int* winner = (int*)(best_iou + n);
+  hipMemsetAsync(winner, 0x7f, (size_t)(m > 0 ? m : 1) * 4, st);
+  obb::k_pb_best<<<(unsigned)((n + 127) / 128), 128, 0, st>>>(det6, (int)n, lab5, (int)m, iouv, best_label, best_iou, winner);
+  obb::k_pb_correct<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(best_label, best_iou, winner, iouv, (int)n, niou, correct);
+  return hipGetLastError() == hipSuccess ? OBB_OK : OBB_ERR_LAUNCH;
+}
+
+}  // extern "C"
