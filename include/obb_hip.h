@@ -52,7 +52,7 @@ int obb_profile_collect(double* ms_sum_host, int64_t* count_host, int n_stages);
 
 /* ------------------------------------------------------------------ NMS ------------------------------ */
 
-/* Scratch bytes for n boxes in nseg segments.  kind: 0 = rotated boxes, 1 = quads. */
+/* Scratch bytes for n boxes in nseg segments.  kind: 0 = rotated boxes, 1 = quads, 2 = double-precision quads (merge NMS). */
 size_t obb_nms_workspace_bytes(int64_t n, int64_t nseg, int kind);
 
 /*
@@ -92,6 +92,23 @@ int obb_nms_rotated_batched_f32(const float* dets5, const float* scores, const i
  */
 int obb_nms_poly_f32(const float* polys, int64_t row_stride, int64_t n, float iou_thr, int64_t max_keep, int64_t* keep_out,
                      int64_t* num_keep, void* ws, size_t ws_bytes, void* stream);
+
+/*
+ * Tile -> full-image merge NMS in double precision.  Replaces py_cpu_nms_poly_fast
+ * (DOTA_devkit/ResultMerge_multi_process.py:62-123; the same function in ResultMerge.py and
+ * ResultEnsembleNMS_multi_process.py) for ALL images of a Task1_<class>.txt file in one call: the horizontal-box
+ * gate (hbb_ovr > 0, :82-98) followed by DOTA_devkit/polyiou.cpp:108-128 (iou_poly) in IEEE double, a box
+ * being dropped unless iou <= thresh (:115; a NaN IoU drops it).
+ *   dets9    (n, 9) doubles  x1 y1 .. x4 y4 score  (only the 8 coordinates are read)
+ *   order    (n) int32       row indices in processing order, segment after segment: the caller applies the reference's
+ *                            `scores.argsort()[::-1]` (:79) per image, so score ties are ordered exactly like numpy's
+ *   seg_off  (nseg + 1) int32  segment g = order[seg_off[g] .. seg_off[g+1])
+ *   keep_out (n) int64       kept ROW indices of segment g at keep_out[seg_off[g] + k], k < num_keep[g], processing order
+ *   num_keep (nseg) int64    (-1 in every entry: the device gave up on an internal barrier)
+ * Workspace: obb_nms_workspace_bytes(n, nseg, 2).
+ */
+int obb_merge_nms_poly_f64(const double* dets9, int64_t n, const int32_t* order, const int32_t* seg_off, int64_t nseg,
+                           double thresh, int64_t* keep_out, int64_t* num_keep, void* ws, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------ fused NMS driver ----------------- */
 
@@ -147,7 +164,7 @@ typedef struct obb_loss_config {
   float gain_box, gain_obj, gain_cls, gain_theta;   /* hyp['box'|'obj'|'cls'|'theta'], utils/loss.py:185-188 */
   float gr;                            /* iou ratio, utils/loss.py:116                                      */
   int32_t sort_obj_iou;                /* utils/loss.py:93,156-158                                          */
-  float csl_radius;                    /* hyp['csl_radius'] (data/hyps/obb/*.yaml; <= 0: 2.0).  Used only when the target
+  float csl_radius;                    /* hyp['csl_radius'] (data/hyps/obb/ yaml files; <= 0: 2.0).  Used only when the target
                                           rows carry no CSL labels (tcols == 7): the 180-bin label is then regenerated on
                                           the device from theta exactly as gaussian_label_cpu rolls its window
                                           (utils/rboxs_utils.py:9-26, utils/datasets.py:639-642) -- SURVEY 8(f) row 3   */

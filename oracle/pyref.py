@@ -308,3 +308,56 @@ def process_batch(detections, labels, iouv):
         matches = torch.Tensor(matches)
         correct[matches[:, 1].long()] = matches[:, 2:3] >= iouv
     return correct
+
+
+# ----------------------------------------------------------------------------- tile -> full-image merge (DOTA_devkit)
+def merge_nms_poly_fast(dets, thresh):
+    """DOTA_devkit/ResultMerge_multi_process.py:62-123 (py_cpu_nms_poly_fast): horizontal-box gate, then
+    polyiou.cpp's iou_poly(kept, candidate) in double (oracle.piou_matrix float64 flavour, pinned to polyiou.cpp)."""
+    import oracle
+    dets = np.asarray(dets, dtype=np.float64).reshape(-1, 9)
+    obbs = dets[:, 0:-1]
+    x1 = np.min(obbs[:, 0::2], axis=1); y1 = np.min(obbs[:, 1::2], axis=1)
+    x2 = np.max(obbs[:, 0::2], axis=1); y2 = np.max(obbs[:, 1::2], axis=1)
+    areas = (x2 - x1 + 1) * (y2 - y1 + 1)
+    order = dets[:, 8].argsort()[::-1]
+    keep = []
+    while order.size > 0:
+        i = order[0]
+        keep.append(int(i))
+        rest = order[1:]
+        w = np.maximum(0.0, np.minimum(x2[i], x2[rest]) - np.maximum(x1[i], x1[rest]))
+        h = np.maximum(0.0, np.minimum(y2[i], y2[rest]) - np.maximum(y1[i], y1[rest]))
+        inter = w * h
+        ovr = inter / (areas[i] + areas[rest] - inter)
+        idx = np.where(ovr > 0)[0]
+        if idx.size:
+            ovr[idx] = oracle.piou_matrix(dets[i:i + 1, :8].copy(), dets[rest[idx], :8].copy())[0]
+        order = rest[np.where(ovr <= thresh)[0]]
+    return keep
+
+
+def merge_result_lines(lines, thresh=0.2):
+    """mergesingle of ResultMerge_multi_process.py:183-234 on the lines of one Task1_<class>.txt: returns the output lines."""
+    import re
+    boxes = {}
+    for line in lines:
+        tok = line.strip().split(' ')
+        sub = tok[0]
+        oriname = sub.split('__')[0]
+        xy = re.findall(r'\d+', re.findall(r'__\d+___\d+', sub)[0])
+        x, y = int(xy[0]), int(xy[1])
+        rate = re.findall(r'__([\d+\.]+)__\d+___', sub)[0]
+        poly = list(map(float, tok[2:]))
+        det = []
+        for i in range(len(poly) // 2):
+            det.append(float(poly[i * 2] + x) / float(rate))
+            det.append(float(poly[i * 2 + 1] + y) / float(rate))
+        det.append(float(tok[1]))
+        boxes.setdefault(oriname, []).append(det)
+    out = []
+    for name, dets in boxes.items():
+        for k in merge_nms_poly_fast(np.array(dets), thresh):
+            det = dets[k]
+            out.append(name + ' ' + str(round(det[-1], 2)) + ' ' + ' '.join(str(round(v, 1)) for v in det[:8]))
+    return out

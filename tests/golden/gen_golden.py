@@ -55,6 +55,47 @@ def valpost_dets(n, seed):
     return torch.cat((d, s[:, None], torch.randint(0, 15, (n, 1), generator=g).float()), 1), 0.7314, (12.0, 3.5)
 
 
+MERGE_CASES = {'a': (6, 40, 0, False), 'b': (3, 400, 1, True), 'c': (40, 12, 2, False)}
+
+
+def merge_input_lines(n_img, n_obj, seed, dense):
+    """Lines of a synthetic Task1_<class>.txt before the merge: `<orig>__<rate>__<x>___<y> score x1 y1 .. x4 y4`
+    (tools/TestJson2VocClassTxt.py:39-47).  Objects of n_img source images are seen from every 1024-px tile (stride 824,
+    rates 1 and 0.5) that contains their centre, each sighting with its own jitter; scores carry 5 decimals
+    (val.py:61-66) and are sometimes duplicated (ties), some boxes are degenerate."""
+    rng = np.random.RandomState(seed)
+    lines = []
+    for im in range(n_img):
+        name = f"P{im:04d}"
+        size = 4000 if not dense else 1500
+        for _ in range(n_obj):
+            cx, cy = rng.rand(2) * size
+            w, h = rng.rand(2) * (120 if not dense else 300) + 6
+            th = (rng.rand() - 0.5) * np.pi
+            for rate in ("1", "0.5"):
+                r = float(rate)
+                for tx in range(0, int(size * r), 824):
+                    for ty in range(0, int(size * r), 824):
+                        px, py = cx * r - tx, cy * r - ty
+                        if not (0 <= px < 1024 and 0 <= py < 1024) or rng.rand() < 0.25:
+                            continue
+                        jx, jy = rng.randn(2) * 2.0
+                        ww, hh = w * r * (1 + rng.randn() * 0.05), h * r * (1 + rng.randn() * 0.05)
+                        t = th + rng.randn() * 0.03
+                        c, s_ = np.cos(t), np.sin(t)
+                        pts = []
+                        for sx, sy in ((1, 1), (1, -1), (-1, -1), (-1, 1)):
+                            pts += [px + jx + sx * ww / 2 * c - sy * hh / 2 * s_, py + jy + sx * ww / 2 * s_ + sy * hh / 2 * c]
+                        kind = rng.rand()
+                        if kind < 0.02:
+                            pts = [pts[0], pts[1]] * 4                     # a point
+                        elif kind < 0.04:
+                            pts = pts[:4] + pts[:4]                        # a segment walked twice
+                        score = round(float(rng.rand()), 5 if rng.rand() < 0.8 else 1)
+                        lines.append(f"{name}__{rate}__{tx}___{ty} {score} " + ' '.join(f"{v:.2f}" for v in pts))
+    return lines
+
+
 def load_reference():
     def stub(name, **attrs):
         m = types.ModuleType(name)
@@ -292,6 +333,32 @@ def main():
         assert torch.equal(a_, b_)
     out.update(vp_poly=pred_poly.numpy(), vp_hbb=pred_hbb.numpy(), vp_polyn=pred_polyn.numpy(), vp_hbbn=pred_hbbn.numpy())
     print("val.py tail ok")
+
+    # ------------------------------------------------------------------ H. ResultMerge (tile -> full image, poly NMS 0.2)
+    import tempfile
+    pol.ref_iou_poly.restype = C.c_double
+    pol.ref_iou_poly.argtypes = [f64p, f64p]
+    sys.modules.setdefault('shapely', types.ModuleType('shapely'))
+    sys.modules['shapely.geometry'] = types.ModuleType('shapely.geometry')
+    stubp = types.ModuleType('DOTA_devkit.polyiou')                    # the SWIG module, backed by polyiou.cpp compiled in place
+    stubp.VectorDouble = lambda v: np.ascontiguousarray(v, dtype=np.float64)
+    stubp.iou_poly = lambda p, q: pol.ref_iou_poly(p, q)
+    sys.modules['DOTA_devkit.polyiou'] = stubp
+    import DOTA_devkit
+    DOTA_devkit.polyiou = stubp
+    import DOTA_devkit.ResultMerge_multi_process as RM
+    for name, cfg in MERGE_CASES.items():
+        lines = merge_input_lines(*cfg)
+        with tempfile.TemporaryDirectory() as td:
+            os.makedirs(os.path.join(td, 'src')); os.makedirs(os.path.join(td, 'dst'))
+            with open(os.path.join(td, 'src', 'Task1_plane.txt'), 'w') as f:
+                f.write('\n'.join(lines) + '\n')
+            RM.mergebase(os.path.join(td, 'src'), os.path.join(td, 'dst'), RM.py_cpu_nms_poly_fast)
+            ref_text = open(os.path.join(td, 'dst', 'Task1_plane.txt')).read()
+        mine = '\n'.join(pyref.merge_result_lines(lines)) + '\n'
+        assert mine == ref_text, name
+        out[f'merge_{name}'] = np.array(ref_text)
+        print(f"merge {name}: {len(lines)} lines in, {ref_text.count(chr(10))} out")
 
     np.savez_compressed(os.path.join(HERE, 'reference_outputs.npz'), **out)
     sz = os.path.getsize(os.path.join(HERE, 'reference_outputs.npz'))

@@ -7,6 +7,7 @@
 #include <random>
 #include "piou_device.h"
 extern "C" float oracle_piou_f32(const float*, const float*);
+extern "C" double oracle_piou_f64(const double*, const double*);
 
 static void mk(std::mt19937& g, float spread, float off, float* q) {
   std::uniform_real_distribution<float> U(0.f, 1.f);
@@ -20,7 +21,8 @@ int main(int argc, char** argv) {
   long n = argc > 1 ? atol(argv[1]) : 100000;
   unsigned seed = argc > 2 ? (unsigned)atol(argv[2]) : 0;
   std::mt19937 g(seed);
-  long mism = 0, nonzero = 0, disjoint = 0;
+  long mism = 0, nonzero = 0, disjoint = 0, mism64 = 0;
+  double d0[10], d1[10], d2[10], d3[10];
   double worst_noise = 0;
   float s0[10], s1[10], s2[10], s3[10];
   for (long i = 0; i < n; i++) {
@@ -37,9 +39,20 @@ int main(int argc, char** argv) {
     float ref = oracle_piou_f32(p, q);
     float got = obb::quad_iou<1>(P, Q, s0, s1, s2, s3);
     if (memcmp(&ref, &got, 4) != 0 && !(ref != ref && got != got)) { if (mism < 5) printf("MISMATCH mode %d ref %.9g got %.9g\n", mode, ref, got); mism++; }
+    {   // double flavour (DOTA_devkit/polyiou.cpp; no degenerate rule: NaN for two empty rings)
+      double pd[8], qd[8];
+      obb::QuadFeatT<double> PD, QD;
+      for (int k = 0; k < 8; k++) { pd[k] = (double)p[k] * 1.000000123 + 0.1; qd[k] = (double)q[k] * 1.000000123 + 0.1; }
+      if (mode == 1) memcpy(qd, pd, sizeof pd);
+      for (int k = 0; k < 4; k++) { PD.x[k] = pd[2 * k]; PD.y[k] = pd[2 * k + 1]; QD.x[k] = qd[2 * k]; QD.y[k] = qd[2 * k + 1]; }
+      double r64 = oracle_piou_f64(pd, qd);
+      double g64 = obb::quad_iou_t<1, false, double>(PD, QD, d0, d1, d2, d3);
+      if (memcmp(&r64, &g64, 8) != 0 && !(r64 != r64 && g64 != g64)) { if (mism64 < 5) printf("MISMATCH64 mode %d ref %.17g got %.17g\n", mode, r64, g64); mism64++; }
+    }
     if (ref > 0) nonzero++;
     if (obb::quad_certainly_disjoint(P, Q)) { disjoint++; if (fabs(ref) > worst_noise && mode != 7) worst_noise = fabs(ref); }
   }
+  printf("mismatches64=%ld\n", mism64);
   printf("mismatches=%ld nonzero=%ld aabb_disjoint=%ld worst_disjoint_iou=%.3g n=%ld\n", mism, nonzero, disjoint, worst_noise, n);
-  return mism ? 1 : 0;
+  return (mism || mism64) ? 1 : 0;
 }

@@ -26,7 +26,7 @@ def test_rotated_iou_device_code_bit_exact(oracle_lib, tmp_path):
 def test_quad_iou_device_code_bit_exact(oracle_lib, tmp_path):
     rc, out = _build_and_run("host_check_piou.cpp", "hc_piou", ["400000", "43"], tmp_path)
     assert rc == 0, out
-    assert "mismatches=0" in out, out
+    assert "mismatches=0" in out and "mismatches64=0" in out, out
 
 
 def test_fast_iou_interval_contains_the_reference_value(oracle_lib, tmp_path):

@@ -1,0 +1,81 @@
+"""GPU parity: the tile -> full-image merge (yolov5_obb_amd/DOTA_devkit/ResultMerge_multi_process.py over
+obb_merge_nms_poly_f64) against the files written by the reference's own ResultMerge (frozen in tests/golden) and against
+the oracle restatement on larger / nastier inputs.  Index and text parity: exact."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import pyref
+from tests.golden.gen_golden import MERGE_CASES, merge_input_lines
+from tests.test_oracle_golden import G
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("name", list(MERGE_CASES))
+def test_merge_files_equal_the_reference_devkit_output(dev, oracle_lib, tmp_path, name):
+    from yolov5_obb_amd.DOTA_devkit import ResultMerge_multi_process as RM
+    src, dst = tmp_path / "src", tmp_path / "dst"
+    src.mkdir()
+    (src / "Task1_plane.txt").write_text('\n'.join(merge_input_lines(*MERGE_CASES[name])) + '\n')
+    RM.mergebypoly(str(src), str(dst))
+    assert (dst / "Task1_plane.txt").read_text() == str(G[f"merge_{name}"])
+
+
+def _dets(n, seed, extent, dup=0.3, ties=True):
+    rng = np.random.RandomState(seed)
+    cx, cy = rng.rand(n) * extent, rng.rand(n) * extent
+    w, h = rng.rand(n) * 80 + 4, rng.rand(n) * 30 + 4
+    t = (rng.rand(n) - 0.5) * np.pi
+    src = rng.randint(0, n, n)
+    d = rng.rand(n) < dup                                  # near-duplicates of other boxes
+    cx[d] = cx[src[d]] + rng.randn(d.sum()); cy[d] = cy[src[d]] + rng.randn(d.sum())
+    w[d] = w[src[d]]; h[d] = h[src[d]]; t[d] = t[src[d]] + rng.randn(d.sum()) * 0.02
+    c, s = np.cos(t), np.sin(t)
+    pts = []
+    for sx, sy in ((1, 1), (1, -1), (-1, -1), (-1, 1)):
+        pts += [cx + sx * w / 2 * c - sy * h / 2 * s, cy + sx * w / 2 * s + sy * h / 2 * c]
+    score = rng.rand(n)
+    if ties:
+        score = np.round(score, 2)
+    return np.stack(pts + [score], 1)
+
+
+@pytest.mark.parametrize("n,extent,seed", [(1, 100, 0), (2, 10, 1), (65, 60, 2), (700, 300, 3), (5000, 900, 4), (3000, 150, 5)])
+def test_single_list_vs_oracle(dev, oracle_lib, n, extent, seed):
+    from yolov5_obb_amd.DOTA_devkit.ResultMerge_multi_process import py_cpu_nms_poly_fast
+    d = _dets(n, seed, extent)
+    for thr in (0.2, 0.5):
+        ref = pyref.merge_nms_poly_fast(d, thr)
+        got = [int(k) for k in py_cpu_nms_poly_fast(d, thr)]
+        assert got == ref, (n, thr)
+    assert py_cpu_nms_poly_fast(np.zeros((0, 9)), 0.2) == []
+
+
+def test_degenerate_rings_follow_the_nan_rule(dev, oracle_lib):
+    """Two empty rings with strictly overlapping horizontal boxes: iou_poly is 0/0 = NaN and `NaN <= thresh` is False, so
+    the later one is dropped; with touching-only horizontal boxes the pair is never looked at."""
+    from yolov5_obb_amd.DOTA_devkit.ResultMerge_multi_process import py_cpu_nms_poly_fast
+    d = np.array([[0, 0, 10, 10, 0, 0, 10, 10, 0.9],        # a diagonal walked twice: zero area, 10 x 10 box
+                  [2, 2, 8, 8, 2, 2, 8, 8, 0.8],            # same, inside the first one's box
+                  [10, 10, 20, 20, 10, 10, 20, 20, 0.7],    # touches the first box in a corner only
+                  [0, 0, 10, 0, 10, 10, 0, 10, 0.6],        # a real square over the first two
+                  [5, 5, 5, 5, 5, 5, 5, 5, 0.5]], float)    # a point: zero-size box, never gated in
+    ref = pyref.merge_nms_poly_fast(d, 0.2)
+    assert [int(k) for k in py_cpu_nms_poly_fast(d, 0.2)] == ref
+    assert 1 not in ref and 2 in ref and 4 in ref
+
+
+def test_many_small_segments_in_one_call(dev, oracle_lib):
+    """More segments than compute units, sizes 0 .. 300, one device call (a class file of a large test set)."""
+    from yolov5_obb_amd.DOTA_devkit import ResultMerge_multi_process as RM
+    rng = np.random.RandomState(7)
+    boxes = {}
+    for g in range(900):
+        n = int(rng.choice([1, 2, 3, 5, 17, 64, 65, 130, 300], p=[.2, .2, .15, .15, .1, .08, .06, .04, .02]))
+        boxes[f"img{g}"] = _dets(n, 1000 + g, 40 + 2 * n).tolist()
+    got = RM.nmsbynamedict(boxes, RM.py_cpu_nms_poly_fast, 0.2)
+    for k, rows in boxes.items():
+        ref = [rows[i] for i in pyref.merge_nms_poly_fast(np.array(rows), 0.2)]
+        assert got[k] == ref, k

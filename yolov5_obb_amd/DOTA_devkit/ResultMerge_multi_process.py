@@ -1,0 +1,166 @@
+"""Tile -> full-image merge of DOTA Task-1 result files on the GPU: the interface of the reference's
+DOTA_devkit/ResultMerge_multi_process.py (`py_cpu_nms_poly_fast`, `nmsbynamedict`, `poly2origpoly`, `mergesingle`,
+`mergebase`, `mergebase_parallel`, `mergebypoly`, `nms_thresh`), same on-disk formats in and out.
+
+The reference runs one Python process per class file (`Pool(16)`, :238-244) and, inside each, a Python double loop over
+SWIG `polyiou.iou_poly` calls per source image (:62-123).  Here a class file is ONE device call
+(`obb_merge_nms_poly_f64`, include/obb_hip.h): every source image is a segment of the persistent NMS kernel, the
+polygon IoU is polyiou.cpp's algorithm in IEEE double, and the host keeps only what is text: parsing, numpy's
+`argsort()[::-1]` per image (so that score ties are ordered exactly like the reference's) and the rounded output lines.
+With several ranks (torch.distributed initialised) the class files are split by rank; there is no collective.
+
+GPU only: no CPU fallback (the reference's own CPU code is the fallback a user already has).
+"""
+import os
+import re
+import shutil
+
+import numpy as np
+import torch
+
+from .. import _lib
+from ..utils import shard
+
+nms_thresh = 0.2                                   # ResultMerge_multi_process.py:22
+
+_TILE_XY = re.compile(r'__\d+___\d+')              # :196
+_TILE_RATE = re.compile(r'__([\d+\.]+)__\d+___')   # :201
+_INT = re.compile(r'\d+')
+
+
+def _device():
+    if not torch.cuda.is_available():
+        raise RuntimeError("yolov5_obb_amd ResultMerge needs a HIP device (no CPU fallback)")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def merge_nms_segments(dets, orders, thresh):
+    """dets (n,9) float64 host array; orders: list of int arrays (row indices in processing order, one per segment).
+    Returns a list of kept row-index arrays (processing order).  One device call for all segments."""
+    dev = _device()
+    dets = np.ascontiguousarray(dets, dtype=np.float64).reshape(-1, 9)
+    nseg = len(orders)
+    if nseg == 0:
+        return []
+    lens = np.array([len(o) for o in orders], dtype=np.int64)
+    off = np.zeros(nseg + 1, dtype=np.int32)
+    off[1:] = np.cumsum(lens)
+    n = int(off[-1])
+    if n == 0:
+        return [np.zeros(0, dtype=np.int64) for _ in orders]
+    order = np.concatenate([np.asarray(o, dtype=np.int32) for o in orders]).astype(np.int32, copy=False)
+    L = _lib.lib()
+    d_dets = torch.from_numpy(dets).to(dev)
+    d_order = torch.from_numpy(order).to(dev)
+    d_off = torch.from_numpy(off).to(dev)
+    keep = torch.empty(n, dtype=torch.int64, device=dev)
+    cnt = torch.empty(nseg, dtype=torch.int64, device=dev)
+    ws = _lib.workspace(L.obb_nms_workspace_bytes(n, nseg, 2), dev)
+    _lib.check(L.obb_merge_nms_poly_f64(_lib.ptr(d_dets), dets.shape[0], _lib.ptr(d_order), _lib.ptr(d_off), nseg, float(thresh),
+                                        _lib.ptr(keep), _lib.ptr(cnt), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev)),
+               "obb_merge_nms_poly_f64")
+    cnt_h = cnt.cpu().numpy()
+    if (cnt_h < 0).any():
+        raise RuntimeError("obb_merge_nms_poly_f64: device-side abort")
+    keep_h = keep.cpu().numpy()
+    return [keep_h[off[g]:off[g] + cnt_h[g]].copy() for g in range(nseg)]
+
+
+def py_cpu_nms_poly_fast(dets, thresh):
+    """Signature of ResultMerge_multi_process.py:62 -- (n,9) [x1 y1 .. x4 y4 score] -> list of kept row indices.
+    (The name is the reference's; the work happens on the GPU.)"""
+    dets = np.asarray(dets, dtype=np.float64).reshape(-1, 9)
+    if len(dets) == 0:
+        return []
+    order = dets[:, 8].argsort()[::-1]             # :79
+    return list(merge_nms_segments(dets, [order], thresh)[0])
+
+
+def nmsbynamedict(nameboxdict, nms, thresh):
+    """:159-174.  With nms = py_cpu_nms_poly_fast all images go to the device in one call."""
+    if nms is py_cpu_nms_poly_fast:
+        names = list(nameboxdict)
+        arrs = [np.asarray(nameboxdict[k], dtype=np.float64).reshape(-1, 9) for k in names]
+        base = np.cumsum([0] + [len(a) for a in arrs])
+        orders = [a[:, 8].argsort()[::-1] + base[i] for i, a in enumerate(arrs)]
+        keeps = merge_nms_segments(np.concatenate(arrs) if arrs else np.zeros((0, 9)), orders, thresh)
+        return {k: [nameboxdict[k][int(j - base[i])] for j in keeps[i]] for i, k in enumerate(names)}
+    return {k: [nameboxdict[k][int(j)] for j in nms(np.array(nameboxdict[k]), thresh)] for k in nameboxdict}
+
+
+def poly2origpoly(poly, x, y, rate):
+    """:175-182: tile coordinates -> source-image coordinates."""
+    r = float(rate)
+    out = []
+    for i in range(len(poly) // 2):
+        out.append(float(poly[2 * i] + x) / r)
+        out.append(float(poly[2 * i + 1] + y) / r)
+    return out
+
+
+def parse_result_file(fullname):
+    """A Task1_<class>.txt file -> dict source image -> list of [8 source-image coordinates, confidence] (:186-213).
+    Lines are `<orig>__<rate>__<x>___<y> score x1 y1 .. x4 y4`."""
+    boxes = {}
+    with open(fullname, 'r') as f:
+        for line in f:
+            tok = line.strip().split(' ')
+            sub = tok[0]
+            oriname = sub.split('__')[0]
+            xy = _INT.findall(_TILE_XY.findall(sub)[0])
+            x, y = int(xy[0]), int(xy[1])
+            rate = _TILE_RATE.findall(sub)[0]
+            det = poly2origpoly(list(map(float, tok[2:])), x, y, rate)
+            det.append(float(tok[1]))
+            boxes.setdefault(oriname, []).append(det)
+    return boxes
+
+
+def format_result_line(imgname, det):
+    """:218-233: confidence to 2 decimals, coordinates to 1, Python's round() and str()."""
+    return imgname + ' ' + str(round(det[-1], 2)) + ' ' + ' '.join(str(round(v, 1)) for v in det[:8])
+
+
+def mergesingle(dstpath, nms, fullname):
+    """:183-234: one class file in, one merged class file out (same base name)."""
+    name = os.path.basename(os.path.splitext(fullname)[0])
+    dstname = os.path.join(dstpath, name + '.txt')
+    merged = nmsbynamedict(parse_result_file(fullname), nms, nms_thresh)
+    with open(dstname, 'w') as f:
+        for imgname, dets in merged.items():
+            for det in dets:
+                f.write(format_result_line(imgname, det) + '\n')
+    return dstname
+
+
+def _files(srcpath):
+    out = []
+    for root, _, files in os.walk(srcpath):
+        out.extend(os.path.join(root, f) for f in files)
+    return out
+
+
+def mergebase(srcpath, dstpath, nms):
+    """:246-249."""
+    for f in _files(srcpath):
+        mergesingle(dstpath, nms, f)
+
+
+def mergebase_parallel(srcpath, dstpath, nms):
+    """:236-244.  The reference's Pool(16) becomes: class files split over the ranks of the default process group (one GPU
+    each); a single process handles all of them."""
+    files = sorted(_files(srcpath))
+    for i in shard.shard_indices(len(files)):
+        mergesingle(dstpath, nms, files[i])
+
+
+def mergebypoly(srcpath, dstpath):
+    """:265-281."""
+    rank, _ = shard.world()
+    if rank == 0:
+        if os.path.exists(dstpath):
+            shutil.rmtree(dstpath)
+        os.makedirs(dstpath)
+    if shard.world()[1] > 1:
+        torch.distributed.barrier()
+    mergebase_parallel(srcpath, dstpath, py_cpu_nms_poly_fast)

@@ -49,6 +49,7 @@ struct RotGeom {
   //             threshold, 2 = undecided (a few % of the pairs);
   //   hit_exact the reference's clip + Graham scan, bit for bit, on the LDS scratch column of the lane.
   static constexpr bool HAS_FAST = true;
+  template <class A> static __device__ __forceinline__ float thr_of(const A& a) { return a.thr; }
   static __device__ __forceinline__ int classify(const float4* ra, const float4* rb, float thr, bool cull) {
     if (!cull) return 2;
     RBoxFeat A = unpack(ra[0], ra[1], ra[2], ra[3]);
@@ -88,9 +89,63 @@ struct QuadGeom {
     return quad_iou<64>(A, B, scr, scr + 10 * 64, scr + 20 * 64, scr + 30 * 64);
   }
   static constexpr bool HAS_FAST = false;      // every pair is undecided: the reference's value is not predictable (see above)
+  template <class A> static __device__ __forceinline__ float thr_of(const A& a) { return a.thr; }
   static __device__ __forceinline__ int classify(const float4*, const float4*, float, bool) { return 2; }
   static __device__ __forceinline__ bool hit_exact(const float4* ra, const float4* rb, float thr, float* scr) {
     return iou(unpack(ra[0], ra[1]), unpack(rb[0], rb[1]), scr) > thr;
+  }
+};
+
+// Double-precision quads for the tile -> full-image merge (DOTA_devkit/ResultMerge_multi_process.py:62-123,
+// py_cpu_nms_poly_fast): a pair is only looked at when the horizontal bounding boxes overlap strictly
+// (hbb_ovr > 0, :82-98), then DOTA_devkit/polyiou.cpp's iou_poly decides; the box survives iff iou <= thresh
+// (:115), so a NaN IoU (two empty rings) suppresses.
+//   q0 = {minx, miny, maxx, maxy} rounded OUTWARD to fp32 (hot-loop reject; never rejects an overlapping pair)
+//   q1..q4 = the 8 double coordinates
+struct QuadGeom64 {
+  static constexpr int RECQ = 5;
+  static constexpr int SCR = 40;   // 32 lanes x 40 doubles: the exact stage runs in two half-wave passes
+  static constexpr bool HAS_FAST = false;
+  template <class A> static __device__ __forceinline__ double thr_of(const A& a) { return a.thr64; }
+  static __device__ __forceinline__ bool cheap_reject(const float4& a, const float4& b) {
+    return !(fminf(a.z, b.z) > fmaxf(a.x, b.x) && fminf(a.w, b.w) > fmaxf(a.y, b.y));
+  }
+  static __device__ __forceinline__ int classify(const float4*, const float4*, double, bool) { return 2; }
+  static __device__ __forceinline__ void hbb(const QuadFeatT<double>& f, double* x1, double* y1, double* x2, double* y2) {
+    *x1 = fmin(fmin(f.x[0], f.x[1]), fmin(f.x[2], f.x[3])); *x2 = fmax(fmax(f.x[0], f.x[1]), fmax(f.x[2], f.x[3]));
+    *y1 = fmin(fmin(f.y[0], f.y[1]), fmin(f.y[2], f.y[3])); *y2 = fmax(fmax(f.y[0], f.y[1]), fmax(f.y[2], f.y[3]));
+  }
+  static __device__ __forceinline__ QuadFeatT<double> unpack(const float4* r) {
+    const double2* d = reinterpret_cast<const double2*>(r + 1);
+    QuadFeatT<double> f;
+#pragma unroll
+    for (int k = 0; k < 4; k++) { double2 v = d[k]; f.x[k] = v.x; f.y[k] = v.y; }
+    f.minx = f.maxx = f.miny = f.maxy = 0.0;
+    return f;
+  }
+  // scr = this lane's column of the wave's scratch (column index = lane); the double flavour shares the 10 KB block
+  // between the two half-waves, one after the other
+  static __device__ __forceinline__ bool hit_exact(const float4* ra, const float4* rb, double thr, float* scr) {
+    const int lane = threadIdx.x & 63;
+    double* base = reinterpret_cast<double*>(scr - lane) + (lane & 31);
+    const QuadFeatT<double> A = unpack(ra), B = unpack(rb);
+    double ax1, ay1, ax2, ay2, bx1, by1, bx2, by2;
+    hbb(A, &ax1, &ay1, &ax2, &ay2); hbb(B, &bx1, &by1, &bx2, &by2);
+    // :70,87-96  areas with the +1 convention, intersection without it
+    const double area_a = (ax2 - ax1 + 1) * (ay2 - ay1 + 1), area_b = (bx2 - bx1 + 1) * (by2 - by1 + 1);
+    const double w = fmax(0.0, fmin(ax2, bx2) - fmax(ax1, bx1)), h = fmax(0.0, fmin(ay2, by2) - fmax(ay1, by1));
+    const double hi = w * h;
+    const bool look = hi / (area_a + area_b - hi) > 0;
+    bool hit = false;
+    int nhalf = 2;
+    asm volatile("" : "+s"(nhalf));   // opaque trip count: the two passes must stay two passes (lanes l and l + 32 share a column)
+    for (int half = 0; half < nhalf; half++) {
+      if (look && (lane >> 5) == half) {
+        const double iou = quad_iou_t<32, false, double>(A, B, base, base + 10 * 32, base + 20 * 32, base + 30 * 32);
+        hit = !(iou <= thr);
+      }
+    }
+    return hit;
   }
 };
 

@@ -151,6 +151,37 @@ __global__ void k_prep_quad(const float* __restrict__ polys, int stride, const u
   if ((threadIdx.x & 63) == 0 && (p & ~63) < n) alive[p >> 6] = m;
 }
 
+// merge NMS (QuadGeom64): rows arrive as (n, 9) doubles, `order` lists the row indices in processing order, segment by
+// segment.  Record = fp32 AABB rounded outward + the 8 doubles.
+__device__ __forceinline__ float f32_down(double v) { float f = (float)v; return ((double)f > v) ? nextafterf(f, -INFINITY) : f; }
+__device__ __forceinline__ float f32_up(double v) { float f = (float)v; return ((double)f < v) ? nextafterf(f, INFINITY) : f; }
+__global__ void k_prep_quad64(const double* __restrict__ dets9, const int32_t* __restrict__ order, int n, float4* __restrict__ rec,
+                              u64* __restrict__ alive) {
+  int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p < n) {
+    const double* d = dets9 + (size_t)order[p] * 9;
+    double v[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) v[k] = d[k];
+    const double x1 = fmin(fmin(v[0], v[2]), fmin(v[4], v[6])), x2 = fmax(fmax(v[0], v[2]), fmax(v[4], v[6]));
+    const double y1 = fmin(fmin(v[1], v[3]), fmin(v[5], v[7])), y2 = fmax(fmax(v[1], v[3]), fmax(v[5], v[7]));
+    float4* r = rec + (size_t)p * QuadGeom64::RECQ;
+    r[0] = make_float4(f32_down(x1), f32_down(y1), f32_up(x2), f32_up(y2));
+    double2* q = reinterpret_cast<double2*>(r + 1);
+#pragma unroll
+    for (int k = 0; k < 4; k++) q[k] = make_double2(v[2 * k], v[2 * k + 1]);
+  }
+  const u64 m = __ballot(p < n);
+  if ((threadIdx.x & 63) == 0 && (p & ~63) < n) alive[p >> 6] = m;
+}
+
+__global__ void k_seg_from_offsets(const int32_t* __restrict__ seg_off, int nseg, int* seg_begin, int* seg_end, int* keep_cnt) {
+  int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= nseg) return;
+  seg_begin[g] = seg_off[g]; seg_end[g] = seg_off[g + 1];
+  keep_cnt[g] = 0;
+}
+
 // num_keep[g] = -1 when the persistent kernel gave up on a barrier (abort flag): the host layer raises
 __global__ void k_finalize(const int* __restrict__ keep_cnt, const int* __restrict__ seg_begin, int nseg, long long max_keep,
                            const int* __restrict__ abort_flag, int64_t* __restrict__ num_keep, int64_t* __restrict__ seg_begin_out) {
@@ -324,6 +355,7 @@ static int nms_steps(int kind, NmsArgs& a, const Carve& cv, int64_t nseg, int64_
     k_plan_teams<<<1, 1024, 0, st>>>(a.seg_begin, a.seg_end, (int)nseg, (int)nb, c1, cv.plan);
     a.plan = cv.plan;
   }
+  if (kind == 2) return launch_persist<QuadGeom64>(a, (unsigned)nb, st);
   return kind == 0 ? launch_persist<RotGeom>(a, (unsigned)nb, st) : launch_persist<QuadGeom>(a, (unsigned)nb, st);
 }
 
@@ -389,7 +421,7 @@ static int run_nms(int kind, const float* boxes, int stride, const float* scores
   a.ecap = cv.ecap; a.n = (int)n; a.capmax = C;
   a.max_keep = (int)(max_keep > 0x7fffffffLL ? 0x7fffffffLL : (max_keep < 0 ? 0 : max_keep));
   a.window = nms_window(a.max_keep);
-  a.thr = thr;
+  a.thr = thr; a.thr64 = thr;
   a.cull = (thr >= 0.f) ? 1 : 0;      // rejects predict IoU <= 0 or IoU <= thr; with thr < 0 even IoU == 0 suppresses
 
   (void)max_seg;   // the step loop is device-driven now: no host-side bound on the segment size is needed
@@ -399,6 +431,41 @@ static int run_nms(int kind, const float* boxes, int stride, const float* scores
     if (rc) return rc;
   }
   k_finalize<<<gseg, T, 0, st>>>(cv.keep_cnt, cv.seg_begin, (int)nseg, max_keep, cv.abort_flag, num_keep, seg_begin_out);
+  return hipGetLastError() == hipSuccess ? OBB_OK : OBB_ERR_LAUNCH;
+}
+
+static int kind_recq(int kind) { return kind == 0 ? RotGeom::RECQ : (kind == 1 ? QuadGeom::RECQ : QuadGeom64::RECQ); }
+
+// Tile -> full-image merge NMS: nseg independent lists, the caller fixes the processing order (numpy's argsort()[::-1] of
+// the reference is not a stable sort: its tie order is the host's business).  keep_out receives ROW indices, the kept rows of
+// segment g at keep_out[seg_off[g] ...], in processing order.
+static int run_merge_nms(const double* dets9, int64_t n, const int32_t* order, const int32_t* seg_off, int64_t nseg, double thr,
+                         int64_t* keep_out, int64_t* num_keep, void* ws, size_t ws_bytes, hipStream_t st) {
+  if (n < 0 || nseg < 1 || n > 0x7fffffffLL || !num_keep || !seg_off) return OBB_ERR_BAD_ARG;
+  if (n > 0 && (!dets9 || !order || !keep_out)) return OBB_ERR_BAD_ARG;
+  const int C = cap_max(nseg);
+  Carve cv;
+  int rc = carve(ws, n, nseg, QuadGeom64::RECQ, C, &cv);
+  if (rc) return rc;
+  if (!ws || ws_bytes < cv.total) return OBB_ERR_WORKSPACE;
+  const int T = 256;
+  const unsigned gseg = (unsigned)((nseg + T - 1) / T);
+  k_seg_from_offsets<<<gseg, T, 0, st>>>(seg_off, (int)nseg, cv.seg_begin, cv.seg_end, cv.keep_cnt);
+  if (n == 0) {
+    k_finalize<<<gseg, T, 0, st>>>(cv.keep_cnt, cv.seg_begin, (int)nseg, 0, nullptr, num_keep, nullptr);
+    return hipGetLastError() == hipSuccess ? OBB_OK : OBB_ERR_LAUNCH;
+  }
+  hipMemsetAsync(cv.alive, 0, cv.alive_bytes, st);
+  k_prep_quad64<<<(unsigned)((n + T - 1) / T), T, 0, st>>>(dets9, order, (int)n, cv.rec, cv.alive);
+  NmsArgs a;
+  a.rec = cv.rec; a.order = reinterpret_cast<const uint32_t*>(order); a.alive = cv.alive;
+  a.seg_begin = cv.seg_begin; a.seg_end = cv.seg_end; a.keep_cnt = cv.keep_cnt; a.keep_out = keep_out;
+  a.rows = cv.rows; a.nrows = cv.nrows; a.edges = cv.edges; a.nedges = cv.nedges;
+  a.ecap = cv.ecap; a.n = (int)n; a.capmax = C; a.max_keep = 0; a.window = 0;
+  a.thr = (float)thr; a.thr64 = thr; a.cull = 1;
+  rc = nms_steps(2, a, cv, nseg, n, st);
+  if (rc) return rc;
+  k_finalize<<<gseg, T, 0, st>>>(cv.keep_cnt, cv.seg_begin, (int)nseg, 0, cv.abort_flag, num_keep, nullptr);
   return hipGetLastError() == hipSuccess ? OBB_OK : OBB_ERR_LAUNCH;
 }
 
@@ -413,7 +480,8 @@ extern "C" {
 size_t obb_nms_workspace_bytes(int64_t n, int64_t nseg, int kind) {
   Carve cv;
   if (n < 0 || nseg < 1) return 0;
-  if (carve(nullptr, n, nseg, kind == 0 ? RotGeom::RECQ : QuadGeom::RECQ, cap_max(nseg), &cv)) return 0;
+  if (kind < 0 || kind > 2) return 0;
+  if (carve(nullptr, n, nseg, kind_recq(kind), cap_max(nseg), &cv)) return 0;
   return cv.total;
 }
 
@@ -438,6 +506,11 @@ int obb_nms_poly_f32(const float* polys, int64_t row_stride, int64_t n, float io
                  0, max_keep, keep_out, num_keep, nullptr, ws, ws_bytes, (hipStream_t)stream);
 }
 
+
+int obb_merge_nms_poly_f64(const double* dets9, int64_t n, const int32_t* order, const int32_t* seg_off, int64_t nseg, double thresh,
+                           int64_t* keep_out, int64_t* num_keep, void* ws, size_t ws_bytes, void* stream) {
+  return run_merge_nms(dets9, n, order, seg_off, nseg, thresh, keep_out, num_keep, ws, ws_bytes, (hipStream_t)stream);
+}
 
 // Devkit host-pointer API (DOTA_devkit/poly_nms_gpu/poly_nms.hpp:9-10, poly_nms_kernel.cu:277-329): the rows
 // arrive pre-sorted by the caller (poly_nms.pyx:18-21) and are scanned in the given order; keep_out receives

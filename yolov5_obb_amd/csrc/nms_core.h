@@ -61,6 +61,7 @@ struct NmsArgs {
   int max_keep;              // 0 = unlimited
   int window;                // 0: a segment is one window; > 0 (used with max_keep): positions are opened window by window
   float thr;
+  double thr64;              // QuadGeom64 only (the merge threshold is a Python float)
   int cull;                  // 1: conservative rejects allowed (thr >= 0)
 };
 
@@ -235,7 +236,7 @@ __device__ __forceinline__ void nms_pairs(const NmsArgs& a, int tm, int cn, cons
     if (lane < cnt) {
       packed = L.qbuf2[(Q2.head + lane) & 127];
       const uint32_t pi = cidx[packed >> 16], pj = cidx[packed & 0xffff];
-      hit = G::hit_exact(a.rec + (size_t)pi * G::RECQ, a.rec + (size_t)pj * G::RECQ, a.thr, L.scr + lane);
+      hit = G::hit_exact(a.rec + (size_t)pi * G::RECQ, a.rec + (size_t)pj * G::RECQ, G::thr_of(a), L.scr + lane);
     }
     const u64 hm = __ballot(hit);
     if (hm) {
@@ -292,7 +293,7 @@ __device__ __forceinline__ void nms_pairs(const NmsArgs& a, int tm, int cn, cons
       if (lane < cnt) {
         const uint32_t it = L.qbuf[(Q.head + lane) & 127];
         const int rr = it >> 8, cc = it & 255;
-        res = G::classify(a.rec + (size_t)L.rowpos[rr] * G::RECQ, a.rec + (size_t)L.colpos[cc] * G::RECQ, a.thr, cull);
+        res = G::classify(a.rec + (size_t)L.rowpos[rr] * G::RECQ, a.rec + (size_t)L.colpos[cc] * G::RECQ, G::thr_of(a), cull);
         packed = ((uint32_t)(rb * 64 + rr) << 16) | (uint32_t)(cb * 64 + cc);
       }
       emit(res == 1, packed);
@@ -506,7 +507,7 @@ __device__ __forceinline__ void nms_cross(const NmsArgs& a, const uint32_t* rows
         const uint32_t rowp = L.qbuf2[slot];
         const int cc = L.q2col[slot];
         if (!L.cdead[cc]) {
-          if (G::hit_exact(a.rec + (size_t)rowp * G::RECQ, a.rec + (size_t)(cbase + cc) * G::RECQ, a.thr, L.scr + lane)) L.cdead[cc] = 1;
+          if (G::hit_exact(a.rec + (size_t)rowp * G::RECQ, a.rec + (size_t)(cbase + cc) * G::RECQ, G::thr_of(a), L.scr + lane)) L.cdead[cc] = 1;
         }
       }
       Q2.head = (Q2.head + cnt) & 127;
@@ -537,7 +538,7 @@ __device__ __forceinline__ void nms_cross(const NmsArgs& a, const uint32_t* rows
           cc = it & 255;
           rowp = L.rowpos[rr];
           if (!L.cdead[cc]) {
-            res = G::classify(a.rec + (size_t)rowp * G::RECQ, a.rec + (size_t)(cbase + cc) * G::RECQ, a.thr, cull);
+            res = G::classify(a.rec + (size_t)rowp * G::RECQ, a.rec + (size_t)(cbase + cc) * G::RECQ, G::thr_of(a), cull);
             if (res == 1) L.cdead[cc] = 1;
           }
         }

@@ -16,10 +16,12 @@
 
 namespace obb {
 
-struct QuadFeat {
-  float x[4], y[4];
-  float minx, maxx, miny, maxy;  // AABB (cull)
+template <typename T>
+struct QuadFeatT {
+  T x[4], y[4];
+  T minx, maxx, miny, maxy;  // AABB (cull)
 };
+typedef QuadFeatT<float> QuadFeat;
 
 OBB_HD QuadFeat quad_make_feat(const float* p8) {
   QuadFeat q;
@@ -32,121 +34,134 @@ OBB_HD QuadFeat quad_make_feat(const float* p8) {
   return q;
 }
 
+// sig(): the reference compares against the double constant 1e-8 (float operands are widened)
 OBB_HD int psgn(float d) {
   constexpr float kHi = f32_floor(1e-8);   // d >  1e-8
   constexpr float kLo = f32_ceil(-1e-8);   // d < -1e-8
   return (int)(d > kHi) - (int)(d < kLo);
 }
+OBB_HD int psgn(double d) { return (int)(d > 1e-8) - (int)(d < -1e-8); }
+OBB_HD float pabs(float v) { return fabsf(v); }
+OBB_HD double pabs(double v) { return fabs(v); }
 
-OBB_HD float ptri(float ox, float oy, float ax, float ay, float bx, float by) {
+template <typename T>
+OBB_HD T ptri(T ox, T oy, T ax, T ay, T bx, T by) {
   return (ax - ox) * (by - oy) - (bx - ox) * (ay - oy);
 }
 
 // keep the part of polygon p (n vertices, scratch stride STRIDE) left of a->b
-template <int STRIDE>
-OBB_HD int pclip(float* px, float* py, int n, float ax, float ay, float bx, float by, float* qx, float* qy) {
+template <int STRIDE, typename T>
+OBB_HD int pclip(T* px, T* py, int n, T ax, T ay, T bx, T by, T* qx, T* qy) {
   int m = 0;
   px[n * STRIDE] = px[0]; py[n * STRIDE] = py[0];
-  float cx = px[0], cy = py[0];
-  float s1 = ptri(ax, ay, bx, by, cx, cy);
+  T cx = px[0], cy = py[0];
+  T s1 = ptri(ax, ay, bx, by, cx, cy);
   int g1 = psgn(s1);
   for (int i = 0; i < n; i++) {
-    float dx = px[(i + 1) * STRIDE], dy = py[(i + 1) * STRIDE];
-    float s2 = ptri(ax, ay, bx, by, dx, dy);
+    T dx = px[(i + 1) * STRIDE], dy = py[(i + 1) * STRIDE];
+    T s2 = ptri(ax, ay, bx, by, dx, dy);
     int g2 = psgn(s2);
     if (g1 > 0) { qx[m * STRIDE] = cx; qy[m * STRIDE] = cy; m++; }
     if (g1 != g2) {
-      float den = s2 - s1;
+      T den = s2 - s1;
       bool ok = psgn(den) != 0;   // (both-zero cannot occur here: the signs differ)
       // unwritten in the reference when !ok (indeterminate); pinned to (0,0) here and in the oracle
-      qx[m * STRIDE] = ok ? (cx * s2 - dx * s1) / den : 0.f;
-      qy[m * STRIDE] = ok ? (cy * s2 - dy * s1) / den : 0.f;
+      qx[m * STRIDE] = ok ? (cx * s2 - dx * s1) / den : T(0);
+      qy[m * STRIDE] = ok ? (cy * s2 - dy * s1) / den : T(0);
       m++;
     }
     cx = dx; cy = dy; s1 = s2; g1 = g2;
   }
   int k = 0;
-  float lx = 0, ly = 0;
+  T lx = 0, ly = 0;
   for (int i = 0; i < m; i++) {
-    float x = qx[i * STRIDE], y = qy[i * STRIDE];
+    T x = qx[i * STRIDE], y = qy[i * STRIDE];
     if (i == 0 || !(psgn(x - lx) == 0 && psgn(y - ly) == 0)) { px[k * STRIDE] = x; py[k * STRIDE] = y; k++; }
     lx = x; ly = y;
   }
-  float fx = px[0], fy = py[0];
+  T fx = px[0], fy = py[0];
   while (k > 1 && psgn(px[(k - 1) * STRIDE] - fx) == 0 && psgn(py[(k - 1) * STRIDE] - fy) == 0) k--;
   return k;
 }
 
 // signed area of triangle(o,a,b) ∩ triangle(o,c,d), o = origin
-template <int STRIDE>
-OBB_HD float ptri_tri(float ax, float ay, float bx, float by, float cx, float cy, float dx, float dy,
-                      float* px, float* py, float* qx, float* qy) {
-  int s1 = psgn(ptri(0.f, 0.f, ax, ay, bx, by));
-  int s2 = psgn(ptri(0.f, 0.f, cx, cy, dx, dy));
-  if (s1 == 0 || s2 == 0) return 0.f;
-  if (s1 == -1) { float t = ax; ax = bx; bx = t; t = ay; ay = by; by = t; }
-  if (s2 == -1) { float t = cx; cx = dx; dx = t; t = cy; cy = dy; dy = t; }
-  px[0] = 0.f; py[0] = 0.f;
+template <int STRIDE, typename T>
+OBB_HD T ptri_tri(T ax, T ay, T bx, T by, T cx, T cy, T dx, T dy, T* px, T* py, T* qx, T* qy) {
+  const T z = 0;
+  int s1 = psgn(ptri(z, z, ax, ay, bx, by));
+  int s2 = psgn(ptri(z, z, cx, cy, dx, dy));
+  if (s1 == 0 || s2 == 0) return z;
+  if (s1 == -1) { T t = ax; ax = bx; bx = t; t = ay; ay = by; by = t; }
+  if (s2 == -1) { T t = cx; cx = dx; dx = t; t = cy; cy = dy; dy = t; }
+  px[0] = z; py[0] = z;
   px[1 * STRIDE] = ax; py[1 * STRIDE] = ay;
   px[2 * STRIDE] = bx; py[2 * STRIDE] = by;
   int n = 3;
-  n = pclip<STRIDE>(px, py, n, 0.f, 0.f, cx, cy, qx, qy);
+  n = pclip<STRIDE>(px, py, n, z, z, cx, cy, qx, qy);
   n = pclip<STRIDE>(px, py, n, cx, cy, dx, dy, qx, qy);
-  n = pclip<STRIDE>(px, py, n, dx, dy, 0.f, 0.f, qx, qy);
+  n = pclip<STRIDE>(px, py, n, dx, dy, z, z, qx, qy);
   // shoelace
   px[n * STRIDE] = px[0]; py[n * STRIDE] = py[0];
-  float acc = 0.f;
-  float x0 = px[0], y0 = py[0];
+  T acc = 0;
+  T x0 = px[0], y0 = py[0];
   for (int i = 0; i < n; i++) {
-    float x1 = px[(i + 1) * STRIDE], y1 = py[(i + 1) * STRIDE];
+    T x1 = px[(i + 1) * STRIDE], y1 = py[(i + 1) * STRIDE];
     acc += x0 * y1 - y0 * x1;
     x0 = x1; y0 = y1;
   }
-  float r = fabsf(acc * 0.5f);
+  T r = pabs(acc * T(0.5));
   return (s1 * s2 == -1) ? -r : r;
 }
 
-OBB_HD float quad_signed_area(const float* x, const float* y) {
-  float acc = 0.f;
+template <typename T>
+OBB_HD T quad_signed_area(const T* x, const T* y) {
+  T acc = 0;
 #pragma unroll
   for (int i = 0; i < 4; i++) acc += x[i] * y[(i + 1) & 3] - y[i] * x[(i + 1) & 3];
-  return acc * 0.5f;
+  return acc * T(0.5);
 }
 
-// px,py,qx,qy: 4 scratch columns of 10 floats each (stride STRIDE)
-template <int STRIDE>
-OBB_HD float quad_iou(const QuadFeat& P, const QuadFeat& Q, float* px, float* py, float* qx, float* qy) {
-  float ax[4], ay[4], bx[4], by[4];
-  float a1 = quad_signed_area(P.x, P.y);
-  float a2 = quad_signed_area(Q.x, Q.y);
+// px,py,qx,qy: 4 scratch columns of 10 values each (stride STRIDE).
+// DEGEN: the float device flavour's union == 0 rule (poly_nms_cuda.cu:136-137); the double host flavour
+// (DOTA_devkit/polyiou.cpp:108-128) has none and returns inter / union as is (NaN for two empty rings).
+template <int STRIDE, bool DEGEN, typename T>
+OBB_HD T quad_iou_t(const QuadFeatT<T>& P, const QuadFeatT<T>& Q, T* px, T* py, T* qx, T* qy) {
+  T ax[4], ay[4], bx[4], by[4];
+  T a1 = quad_signed_area(P.x, P.y);
+  T a2 = quad_signed_area(Q.x, Q.y);
   // reverse to counter-clockwise when the signed area is negative (:108-109)
 #pragma unroll
   for (int i = 0; i < 4; i++) {
     ax[i] = (a1 < 0) ? P.x[3 - i] : P.x[i]; ay[i] = (a1 < 0) ? P.y[3 - i] : P.y[i];
     bx[i] = (a2 < 0) ? Q.x[3 - i] : Q.x[i]; by[i] = (a2 < 0) ? Q.y[3 - i] : Q.y[i];
   }
-  float inter = 0.f;
+  T inter = 0;
 #pragma unroll 1
   for (int i = 0; i < 4; i++) {
 #pragma unroll 1
     for (int j = 0; j < 4; j++) {
       int i1 = (i + 1) & 3, j1 = (j + 1) & 3;
       // select with static indices to keep the vertex arrays in registers
-      float pax = i == 0 ? ax[0] : i == 1 ? ax[1] : i == 2 ? ax[2] : ax[3];
-      float pay = i == 0 ? ay[0] : i == 1 ? ay[1] : i == 2 ? ay[2] : ay[3];
-      float pbx = i1 == 0 ? ax[0] : i1 == 1 ? ax[1] : i1 == 2 ? ax[2] : ax[3];
-      float pby = i1 == 0 ? ay[0] : i1 == 1 ? ay[1] : i1 == 2 ? ay[2] : ay[3];
-      float qcx = j == 0 ? bx[0] : j == 1 ? bx[1] : j == 2 ? bx[2] : bx[3];
-      float qcy = j == 0 ? by[0] : j == 1 ? by[1] : j == 2 ? by[2] : by[3];
-      float qdx = j1 == 0 ? bx[0] : j1 == 1 ? bx[1] : j1 == 2 ? bx[2] : bx[3];
-      float qdy = j1 == 0 ? by[0] : j1 == 1 ? by[1] : j1 == 2 ? by[2] : by[3];
+      T pax = i == 0 ? ax[0] : i == 1 ? ax[1] : i == 2 ? ax[2] : ax[3];
+      T pay = i == 0 ? ay[0] : i == 1 ? ay[1] : i == 2 ? ay[2] : ay[3];
+      T pbx = i1 == 0 ? ax[0] : i1 == 1 ? ax[1] : i1 == 2 ? ax[2] : ax[3];
+      T pby = i1 == 0 ? ay[0] : i1 == 1 ? ay[1] : i1 == 2 ? ay[2] : ay[3];
+      T qcx = j == 0 ? bx[0] : j == 1 ? bx[1] : j == 2 ? bx[2] : bx[3];
+      T qcy = j == 0 ? by[0] : j == 1 ? by[1] : j == 2 ? by[2] : by[3];
+      T qdx = j1 == 0 ? bx[0] : j1 == 1 ? bx[1] : j1 == 2 ? bx[2] : bx[3];
+      T qdy = j1 == 0 ? by[0] : j1 == 1 ? by[1] : j1 == 2 ? by[2] : by[3];
       inter += ptri_tri<STRIDE>(pax, pay, pbx, pby, qcx, qcy, qdx, qdy, px, py, qx, qy);
     }
   }
   // areas of the (possibly reversed) rings, as the reference recomputes them (:134)
-  float ua = fabsf(quad_signed_area(ax, ay)) + fabsf(quad_signed_area(bx, by)) - inter;
-  if (ua == 0.f) return (inter + 1.f) / (ua + 1.f);   // :136-137
+  T ua = pabs(quad_signed_area(ax, ay)) + pabs(quad_signed_area(bx, by)) - inter;
+  if (DEGEN && ua == T(0)) return (inter + T(1)) / (ua + T(1));   // :136-137
   return inter / ua;
+}
+
+template <int STRIDE>
+OBB_HD float quad_iou(const QuadFeat& P, const QuadFeat& Q, float* px, float* py, float* qx, float* qy) {
+  return quad_iou_t<STRIDE, true, float>(P, Q, px, py, qx, qy);
 }
 
 // AABB reject: disjoint bounding boxes with a margin -> every signed triangle
