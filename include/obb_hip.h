@@ -110,6 +110,20 @@ int obb_nms_poly_f32(const float* polys, int64_t row_stride, int64_t n, float io
 int obb_merge_nms_poly_f64(const double* dets9, int64_t n, const int32_t* order, const int32_t* seg_off, int64_t nseg,
                            double thresh, int64_t* keep_out, int64_t* num_keep, void* ws, size_t ws_bytes, void* stream);
 
+/*
+ * DOTA Task-1 evaluation: the detection x ground-truth part of voc_eval (DOTA_devkit/dota_evaluation_task1.py:168-223)
+ * for all detections of a class file in one call.  Per detection, over the ground-truth quads of its own image: the
+ * horizontal-box gate with the +1 convention (:181-204), iou_poly(GT, det) of DOTA_devkit/polyiou.cpp in IEEE double for
+ * the quads that pass (:206-213), then np.max / np.argmax (:215-218).
+ *   dets8   (nd, 8) doubles, in the caller's (confidence-sorted) order      det_img (nd) int32  image index of a detection
+ *   gts8    (ng, 8) doubles, the quads of image i at gt_off[i] .. gt_off[i+1]   gt_off (n_img + 1) int32
+ *   ovmax   (nd) doubles   -inf: no quad passed the gate (:172); NaN: some IoU was NaN
+ *   jmax    (nd) int32     index within the image's list (first maximum; first NaN; -1 with -inf)
+ * The sequential TP/FP marking (:225-233) is a first-occurrence pass over (image, jmax) and stays with the caller.
+ */
+int obb_eval_best_gt_f64(const double* dets8, const int32_t* det_img, int64_t nd, const double* gts8, const int32_t* gt_off,
+                         int64_t n_img, double* ovmax, int32_t* jmax, void* stream);
+
 /* ------------------------------------------------------------------ fused NMS driver ----------------- */
 
 /*

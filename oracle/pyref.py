@@ -361,3 +361,71 @@ def merge_result_lines(lines, thresh=0.2):
             det = dets[k]
             out.append(name + ' ' + str(round(det[-1], 2)) + ' ' + ' '.join(str(round(v, 1)) for v in det[:8]))
     return out
+
+
+# ----------------------------------------------------------------------------- DOTA Task-1 evaluation (DOTA_devkit)
+def task1_best_gt(bb, BBGT):
+    """dota_evaluation_task1.py:172-218 for one detection: (ovmax, jmax); jmax is None when no ground truth passes the gate."""
+    import oracle
+    ovmax, jmax = -np.inf, None
+    if BBGT.size > 0:
+        gx1 = np.min(BBGT[:, 0::2], axis=1); gy1 = np.min(BBGT[:, 1::2], axis=1)
+        gx2 = np.max(BBGT[:, 0::2], axis=1); gy2 = np.max(BBGT[:, 1::2], axis=1)
+        bx1, by1, bx2, by2 = np.min(bb[0::2]), np.min(bb[1::2]), np.max(bb[0::2]), np.max(bb[1::2])
+        iw = np.maximum(np.minimum(gx2, bx2) - np.maximum(gx1, bx1) + 1., 0.)
+        ih = np.maximum(np.minimum(gy2, by2) - np.maximum(gy1, by1) + 1., 0.)
+        inters = iw * ih
+        uni = ((bx2 - bx1 + 1.) * (by2 - by1 + 1.) + (gx2 - gx1 + 1.) * (gy2 - gy1 + 1.) - inters)
+        keep = np.where(inters / uni > 0)[0]
+        if len(keep) > 0:
+            ov = oracle.piou_matrix(np.ascontiguousarray(BBGT[keep]), bb[None, :].copy())[:, 0]     # iou_poly(GT, det)
+            ovmax = np.max(ov)
+            jmax = int(keep[np.argmax(ov)])
+    return ovmax, jmax
+
+
+def task1_voc_eval(gt_by_image, imagenames, det_lines, classname, ovthresh=0.5, use_07_metric=False):
+    """voc_eval of dota_evaluation_task1.py:88-249 on parsed inputs: gt_by_image name -> list of
+    {'name','difficult','bbox'} (parse_gt's records), det_lines = the lines of Task1_<class>.txt."""
+    class_recs, npos = {}, 0
+    for name in imagenames:
+        R = [o for o in gt_by_image[name] if o['name'] == classname]
+        diff = np.array([o['difficult'] for o in R]).astype(np.bool_)
+        npos += int(sum(~diff))
+        class_recs[name] = {'bbox': np.array([o['bbox'] for o in R]), 'difficult': diff, 'det': [False] * len(R)}
+    split = [x.strip().split(' ') for x in det_lines]
+    image_ids = [x[0] for x in split]
+    confidence = np.array([float(x[1]) for x in split])
+    BB = np.array([[float(z) for z in x[2:]] for x in split])
+    sorted_ind = np.argsort(-confidence)
+    BB = BB[sorted_ind, :]
+    image_ids = [image_ids[x] for x in sorted_ind]
+    nd = len(image_ids)
+    tp, fp = np.zeros(nd), np.zeros(nd)
+    for d in range(nd):
+        R = class_recs[image_ids[d]]
+        ovmax, jmax = task1_best_gt(BB[d, :].astype(float), R['bbox'].astype(float))
+        if ovmax > ovthresh:
+            if not R['difficult'][jmax]:
+                if not R['det'][jmax]:
+                    tp[d] = 1.
+                    R['det'][jmax] = 1
+                else:
+                    fp[d] = 1.
+        else:
+            fp[d] = 1.
+    fp, tp = np.cumsum(fp), np.cumsum(tp)
+    rec = tp / float(npos)
+    prec = tp / np.maximum(tp + fp, np.finfo(np.float64).eps)
+    if use_07_metric:
+        ap = 0.
+        for t in np.arange(0., 1.1, 0.1):
+            p = 0 if np.sum(rec >= t) == 0 else np.max(prec[rec >= t])
+            ap = ap + p / 11.
+    else:
+        mrec = np.concatenate(([0.], rec, [1.])); mpre = np.concatenate(([0.], prec, [0.]))
+        for i in range(mpre.size - 1, 0, -1):
+            mpre[i - 1] = np.maximum(mpre[i - 1], mpre[i])
+        i = np.where(mrec[1:] != mrec[:-1])[0]
+        ap = np.sum((mrec[i + 1] - mrec[i]) * mpre[i + 1])
+    return rec, prec, ap

@@ -96,6 +96,68 @@ def merge_input_lines(n_img, n_obj, seed, dense):
     return lines
 
 
+EVAL_CASES = {'a': (5, 30, 0), 'b': (2, 700, 1), 'c': (25, 6, 2)}
+EVAL_CLASSES = ('plane', 'ship')
+
+
+def eval_inputs(n_img, n_gt, seed):
+    """A synthetic Task-1 evaluation set: {image name -> labelTxt lines}, {class -> Task1_<class>.txt lines}.
+    Ground truth `x1 y1 .. x4 y4 name difficult` (dota_evaluation_task1.py:21-53), detections
+    `image score x1 y1 .. x4 y4`: jittered copies of the ground truth (several per object, some of the wrong class),
+    clutter, degenerate quads, repeated scores."""
+    rng = np.random.RandomState(seed)
+
+    def quad(cx, cy, w, h, t):
+        c, s_ = np.cos(t), np.sin(t)
+        pts = []
+        for sx, sy in ((1, 1), (1, -1), (-1, -1), (-1, 1)):
+            pts += [cx + sx * w / 2 * c - sy * h / 2 * s_, cy + sx * w / 2 * s_ + sy * h / 2 * c]
+        return pts
+    gt, det = {}, {c: [] for c in EVAL_CLASSES}
+    extent = 60.0 * np.sqrt(n_gt) + 100
+    for im in range(n_img):
+        name = f"P{im:04d}"
+        lines = []
+        for _ in range(int(n_gt * (0.5 + rng.rand())) if im % 7 != 6 else 0):
+            cls = EVAL_CLASSES[int(rng.rand() < 0.3)]
+            cx, cy = rng.rand(2) * extent
+            w, h, t = rng.rand() * 70 + 8, rng.rand() * 25 + 5, (rng.rand() - 0.5) * np.pi
+            q = quad(cx, cy, w, h, t)
+            tail = f" {cls}" + ("" if rng.rand() < 0.1 else f" {int(rng.rand() < 0.15)}")
+            lines.append(' '.join(f"{v:.1f}" for v in q) + tail)
+            for _ in range(rng.randint(0, 4)):
+                dc = cls if rng.rand() < 0.9 else EVAL_CLASSES[1 - EVAL_CLASSES.index(cls)]
+                j = rng.randn(2) * (1 + 6 * rng.rand())
+                qq = quad(cx + j[0], cy + j[1], w * (1 + rng.randn() * 0.08), h * (1 + rng.randn() * 0.08), t + rng.randn() * 0.05)
+                k = rng.rand()
+                if k < 0.02:
+                    qq = [qq[0], qq[1]] * 4
+                score = round(float(rng.rand()), 2 if rng.rand() < 0.7 else 1)
+                det[dc].append(f"{name} {score} " + ' '.join(f"{v:.1f}" for v in qq))
+        lines.append("imagesource:GoogleEarth")          # short lines are skipped by parse_gt
+        for _ in range(rng.randint(0, 6)):                # clutter
+            q = quad(rng.rand() * extent, rng.rand() * extent, rng.rand() * 70 + 8, rng.rand() * 25 + 5, (rng.rand() - 0.5) * np.pi)
+            det[EVAL_CLASSES[int(rng.rand() < 0.5)]].append(f"{name} {round(float(rng.rand()), 2)} " + ' '.join(f"{v:.1f}" for v in q))
+        gt[name] = lines
+    for c in det:
+        rng.shuffle(det[c])
+    return gt, det
+
+
+def eval_write(root, gt, det):
+    """Lay the set out on disk the way the devkit expects it; returns (detpath, annopath, imagesetfile)."""
+    os.makedirs(os.path.join(root, 'labelTxt')); os.makedirs(os.path.join(root, 'res'))
+    for name, lines in gt.items():
+        with open(os.path.join(root, 'labelTxt', name + '.txt'), 'w') as f:
+            f.write('\n'.join(lines) + '\n')
+    with open(os.path.join(root, 'imgnamefile.txt'), 'w') as f:
+        f.write('\n'.join(gt) + '\n')
+    for c, lines in det.items():
+        with open(os.path.join(root, 'res', f'Task1_{c}.txt'), 'w') as f:
+            f.write('\n'.join(lines) + '\n')
+    return os.path.join(root, 'res', 'Task1_{:s}.txt'), os.path.join(root, 'labelTxt', '{:s}.txt'), os.path.join(root, 'imgnamefile.txt')
+
+
 def load_reference():
     def stub(name, **attrs):
         m = types.ModuleType(name)
@@ -359,6 +421,28 @@ def main():
         assert mine == ref_text, name
         out[f'merge_{name}'] = np.array(ref_text)
         print(f"merge {name}: {len(lines)} lines in, {ref_text.count(chr(10))} out")
+
+    # ------------------------------------------------------------------ I. DOTA Task-1 evaluation (voc_eval with polygon IoU)
+    import contextlib, io
+    sys.modules['polyiou'] = stubp                                     # dota_evaluation_task1.py:18 imports the SWIG module by its bare name
+    sys.modules.setdefault('matplotlib', types.ModuleType('matplotlib'))
+    sys.modules.setdefault('matplotlib.pyplot', types.ModuleType('matplotlib.pyplot'))
+    import DOTA_devkit.dota_evaluation_task1 as EV
+    for name, cfg in EVAL_CASES.items():
+        gt, det = eval_inputs(*cfg)
+        with tempfile.TemporaryDirectory() as td:
+            detpath, annopath, imagesetfile = eval_write(td, gt, det)
+            parsed = {k: EV.parse_gt(annopath.format(k)) for k in gt}
+            for ci, cls in enumerate(EVAL_CLASSES):
+                for m07 in (True, False):
+                    with contextlib.redirect_stdout(io.StringIO()):
+                        rec, prec, ap = EV.voc_eval(detpath, annopath, imagesetfile, cls, ovthresh=0.5, use_07_metric=m07)
+                    rec2, prec2, ap2 = pyref.task1_voc_eval(parsed, list(gt), det[cls], cls, 0.5, m07)
+                    assert np.array_equal(rec, rec2) and np.array_equal(prec, prec2) and ap == ap2, (name, cls)
+                    out[f'eval_{name}_{cls}_ap{int(m07)}'] = np.array(ap)
+                out[f'eval_{name}_{cls}_rec'] = rec
+                out[f'eval_{name}_{cls}_prec'] = prec
+                print(f"eval {name} {cls}: nd {len(rec)} ap {ap:.4f}")
 
     np.savez_compressed(os.path.join(HERE, 'reference_outputs.npz'), **out)
     sz = os.path.getsize(os.path.join(HERE, 'reference_outputs.npz'))

@@ -116,6 +116,79 @@ __global__ __launch_bounds__(64) void k_rbox_overlaps(const float* __restrict__ 
   }
 }
 
+
+// DOTA Task-1 evaluation, the det x GT part of voc_eval (DOTA_devkit/dota_evaluation_task1.py:168-223): for every
+// detection, over the ground-truth quads of ITS image, the horizontal-box gate with the +1 convention (:181-204,
+// overlaps > 0), polyiou.cpp's iou_poly(GT, det) in double for the survivors (:206-213), np.max / np.argmax (:215-218: the
+// first maximum in GT order; any NaN makes the maximum NaN and argmax the first NaN).
+// One wave per detection (grid-stride), lanes over the image's GT list, exact stage in two half-wave passes on a
+// 32-column LDS scratch.
+constexpr int kEvalWaves = 4;
+__global__ __launch_bounds__(64 * kEvalWaves) void k_eval_best_gt(const double* __restrict__ dets8, const int32_t* __restrict__ det_img,
+                                                                 long long nd, const double* __restrict__ gts8,
+                                                                 const int32_t* __restrict__ gt_off, double* __restrict__ ovmax,
+                                                                 int32_t* __restrict__ jmax) {
+  __shared__ double scr_all[kEvalWaves][40 * 32];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  double* base = scr_all[wv] + (lane & 31);
+  for (long long d = (long long)blockIdx.x * kEvalWaves + wv; d < nd; d += (long long)gridDim.x * kEvalWaves) {
+    QuadFeatT<double> D;
+    const double2* dp = reinterpret_cast<const double2*>(dets8 + d * 8);
+#pragma unroll
+    for (int k = 0; k < 4; k++) { double2 v = dp[k]; D.x[k] = v.x; D.y[k] = v.y; }
+    D.minx = D.maxx = D.miny = D.maxy = 0.0;
+    double bx1, by1, bx2, by2;
+    QuadGeom64::hbb(D, &bx1, &by1, &bx2, &by2);
+    const double barea = (bx2 - bx1 + 1.) * (by2 - by1 + 1.);
+    const int img = det_img[d];
+    const int g0 = gt_off[img], g1 = gt_off[img + 1];
+    double best = -INFINITY;
+    int bestj = -1, nanj = 0x7fffffff;
+    for (int gb = g0; gb < g1; gb += 64) {
+      const int j = gb + lane;
+      bool pass = false;
+      QuadFeatT<double> Gq;
+      Gq.minx = Gq.maxx = Gq.miny = Gq.maxy = 0.0;
+      if (j < g1) {
+        const double2* gp = reinterpret_cast<const double2*>(gts8 + (long long)j * 8);
+#pragma unroll
+        for (int k = 0; k < 4; k++) { double2 v = gp[k]; Gq.x[k] = v.x; Gq.y[k] = v.y; }
+        double gx1, gy1, gx2, gy2;
+        QuadGeom64::hbb(Gq, &gx1, &gy1, &gx2, &gy2);
+        const double iw = fmax(fmin(gx2, bx2) - fmax(gx1, bx1) + 1., 0.), ih = fmax(fmin(gy2, by2) - fmax(gy1, by1) + 1., 0.);
+        const double inters = iw * ih;
+        const double uni = barea + (gx2 - gx1 + 1.) * (gy2 - gy1 + 1.) - inters;
+        pass = inters / uni > 0;
+      } else {
+#pragma unroll
+        for (int k = 0; k < 4; k++) { Gq.x[k] = 0.0; Gq.y[k] = 0.0; }
+      }
+      if (__ballot(pass) == 0) continue;
+      int nhalf = 2;
+      asm volatile("" : "+s"(nhalf));   // two passes stay two passes: lanes l and l + 32 share a scratch column
+      for (int half = 0; half < nhalf; half++) {
+        if (pass && (lane >> 5) == half) {
+          const double iou = quad_iou_t<32, false, double>(Gq, D, base, base + 10 * 32, base + 20 * 32, base + 30 * 32);
+          if (iou != iou) { if (j - g0 < nanj) nanj = j - g0; }
+          else if (iou > best) { best = iou; bestj = j - g0; }
+        }
+      }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      const double ob = __shfl_xor(best, off);
+      const int oj = __shfl_xor(bestj, off), on = __shfl_xor(nanj, off);
+      if (oj >= 0 && (bestj < 0 || ob > best || (ob == best && oj < bestj))) { best = ob; bestj = oj; }
+      if (on < nanj) nanj = on;
+    }
+    if (lane == 0) {
+      const bool isn = nanj != 0x7fffffff;
+      ovmax[d] = isn ? (double)NAN : best;
+      jmax[d] = isn ? nanj : bestj;
+    }
+  }
+}
+
 }  // namespace obb
 
 using namespace obb;
@@ -156,6 +229,17 @@ int obb_rbox_overlaps_f32(const float* boxes5, int64_t n, const float* query5, i
   dim3 g((unsigned)((k + 63) / 64), (unsigned)((n + 63) / 64));
   if (g.y > 65535) return OBB_ERR_BAD_ARG;
   k_rbox_overlaps<<<g, 64, 0, (hipStream_t)stream>>>(boxes5, n, query5, k, out);
+  return OBB_CHECK_LAUNCH();
+}
+
+
+int obb_eval_best_gt_f64(const double* dets8, const int32_t* det_img, int64_t nd, const double* gts8, const int32_t* gt_off,
+                         int64_t n_img, double* ovmax, int32_t* jmax, void* stream) {
+  if (nd < 0 || n_img < 0 || (nd > 0 && (!dets8 || !det_img || !gt_off || !ovmax || !jmax))) return OBB_ERR_BAD_ARG;
+  if (nd == 0) return OBB_OK;
+  int64_t nb = (nd + kEvalWaves - 1) / kEvalWaves;
+  if (nb > 256 * 16) nb = 256 * 16;
+  k_eval_best_gt<<<(unsigned)nb, 64 * kEvalWaves, 0, (hipStream_t)stream>>>(dets8, det_img, nd, gts8, gt_off, ovmax, jmax);
   return OBB_CHECK_LAUNCH();
 }
 
