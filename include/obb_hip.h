@@ -140,20 +140,28 @@ int obb_eval_best_gt_f64(const double* dets8, const int32_t* det_img, int64_t nd
  *               `labels` of autolabelling (:807-813), prepared by the host layer; n_extra rows
  *   cap_img     candidate slots reserved per image.  If an image produces more, status[0] receives that count
  *               (> cap_img) and the caller must retry with a larger cap_img (A*nc can never overflow).
- *   expected_cand  performance hint only: candidates per image the caller expects (e.g. status[1] of its previous call;
- *               0 = unknown).  Above ~12k the per-image sort runs on many workgroups per image (csrc/segsort.h) instead
- *               of rocPRIM's one-workgroup-per-segment sort; the result does not depend on the hint.
+ *   expected_cand  candidates per image the caller expects (status[1] of its previous call; 0 = unknown: always valid).
+ *               Selects the sort: 1 .. OBB_NMS_SORT_LDS_HINT -> one workgroup per image sorts in LDS and also builds the
+ *               NMS records (six launches fewer); above ~12k the per-image sort runs on many workgroups per image
+ *               (csrc/segsort.h); otherwise rocPRIM's one-workgroup-per-segment sort.  The in-LDS sort takes at most
+ *               OBB_NMS_SORT_LDS_MAX candidates of an image: with a hint in 1 .. OBB_NMS_SORT_LDS_HINT and
+ *               status[1] > OBB_NMS_SORT_LDS_MAX after the call, such images were left EMPTY -- call again with
+ *               expected_cand = status[1] (the Python layer does).  Otherwise the result does not depend on the hint.
  *   out         [bs][max_det][7] fp32 rows [x y l s theta conf cls];  out_count [bs] int64 (-1: device-side abort);
+ *               out_packed != 0: the rows of image b start right behind those of image b-1 (row sum(out_count[0..b-1]))
+ *               instead of at row b*max_det -- the same buffer size is required, one split instead of bs slices on the host
  *               status [2] int64: [0] overflow count (see cap_img), [1] largest candidate count of any image
  * Score ties are ordered by ascending (anchor*nc + class): deterministic, where the reference inherits the order
  * of torch's unstable sort.
  */
+#define OBB_NMS_SORT_LDS_HINT 6144
+#define OBB_NMS_SORT_LDS_MAX 8192
 size_t obb_nms_obb_workspace_bytes(int64_t bs, int64_t cap_img, int64_t nc, int agnostic);
 int obb_non_max_suppression_obb(const void* pred, int dtype, int64_t bs, int64_t A, int64_t no, float conf_thres,
                                 float iou_thres, const int32_t* classes_host, int n_classes, int agnostic, int multi_label,
                                 int64_t max_det, int64_t max_nms, float max_wh, const float* extra8, int64_t n_extra,
-                                int64_t cap_img, int64_t expected_cand, float* out, int64_t* out_count, int64_t* status, void* ws,
-                                size_t ws_bytes, void* stream);
+                                int64_t cap_img, int64_t expected_cand, float* out, int out_packed, int64_t* out_count,
+                                int64_t* status, void* ws, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------ training loss -------------------- */
 

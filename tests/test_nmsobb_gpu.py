@@ -112,3 +112,29 @@ def test_large_candidate_counts_use_the_multi_workgroup_sort(dev, oracle_lib):
             got = general.non_max_suppression_obb(pred.to(dev), **kw)
             _cmp(got, ref)
     assert max(general._cand_memo.values()) > 12288          # the last calls did take the multi-workgroup sort
+
+
+def test_in_lds_sort_path_and_an_undersold_hint(dev, oracle_lib):
+    """Hints up to 6144 candidates per image select the one-workgroup-per-image path (bitonic sort in LDS + segment table +
+    NMS records in one kernel).  It must give the oracle's rows for full, tiny and empty images, in every mode (class
+    segments / single list for sub-pixel boxes / agnostic), and a hint that undersells the batch (an image with more than
+    8192 candidates) must be repaired by the host layer's second call."""
+    from yolov5_obb_amd.utils import general
+    pred = synth.s_pred(4, 30000, 15, seed=31, n_obj=70, fg_frac=0.04)
+    pred[1, :, 4] = 0.0                                   # an empty image
+    pred[2, 5:, 4] = 0.0                                  # an image with a handful of candidates
+    pred[3, :200, 3] = 0.5                                # sub-pixel short sides: this image falls back to the single list
+    key = (30000, 15, True)
+    for agn in (False, True):
+        kw = dict(conf_thres=0.2, iou_thres=0.45, multi_label=True, max_det=1500, agnostic=agn)
+        ref = pyref.non_max_suppression_obb(pred.clone(), **kw)
+        general._cand_memo.clear()
+        _cmp(general.non_max_suppression_obb(pred.to(dev), **kw), ref)          # hint 0: library sort
+        assert 0 < general._cand_memo[key] <= 6144
+        for rep in range(2):
+            _cmp(general.non_max_suppression_obb(pred.to(dev), **kw), ref)      # hinted: in-LDS path
+    kw = dict(conf_thres=0.001, iou_thres=0.45, multi_label=True, max_det=1500)
+    ref = pyref.non_max_suppression_obb(pred.clone(), **kw)
+    general._cand_memo[key] = 100                                                # far too small for conf 0.001
+    _cmp(general.non_max_suppression_obb(pred.to(dev), **kw), ref)
+    assert general._cand_memo[key] > 8192

@@ -318,9 +318,27 @@ static int launch_persist(const NmsArgs& a, unsigned nb, hipStream_t st) {
   return OBB_OK;
 }
 
-// n_slots: number of sorted positions that can hold a box (bounds the useful parallelism)
-static int nms_steps(int kind, NmsArgs& a, const Carve& cv, int64_t nseg, int64_t n_slots, hipStream_t st) {
-  hipMemsetAsync(cv.bar, 0, cv.bar_bytes, st);
+// grid of the persistent launch.  n_slots: number of sorted positions that can hold a box (bounds the useful parallelism)
+static int nms_grid(int64_t nseg, int64_t n_slots, int cap_first_) {
+  const int cus = cu_count();
+  int64_t nb = (n_slots + 511) / 512;                 // 8 waves x 64 columns per workgroup
+  {                                                   // ... and one wave per tile of the first chunk's triangle
+    const int64_t per_seg = (n_slots + nseg - 1) / nseg;
+    const int64_t c = per_seg < cap_first_ ? per_seg : cap_first_;
+    const int64_t tiles = ((c + 63) / 64) * ((c + 63) / 64 + 1) / 2 * nseg;
+    if (nb < (tiles + 7) / 8) nb = (tiles + 7) / 8;
+  }
+  if (n_slots >= 8192) nb = cus;                      // enough work for the whole chip
+  if (nb < nseg) nb = nseg;
+  if (nb > cus) nb = cus;
+  if (nb < 1) nb = 1;
+  return (int)nb;
+}
+
+constexpr int kNmsBarZeroed = 1;    // the caller has zeroed the barrier block on this stream already
+constexpr int kNmsPlanned = 2;      // the team plan for this launch has been written already (fused sort/prep kernel)
+static int nms_steps(int kind, NmsArgs& a, const Carve& cv, int64_t nseg, int64_t n_slots, hipStream_t st, int pre = 0) {
+  if (!(pre & kNmsBarZeroed)) hipMemsetAsync(cv.bar, 0, cv.bar_bytes, st);
   a.bar = cv.bar; a.abort_flag = cv.abort_flag; a.nseg = (int)nseg;
   a.cap_first = cap_first();
   static int phase_prof = -1;
@@ -331,28 +349,19 @@ static int nms_steps(int kind, NmsArgs& a, const Carve& cv, int64_t nseg, int64_
     if (hipMemcpy(h, cv.prof, sizeof h, hipMemcpyDeviceToHost) == hipSuccess && h[6] > 0 && h[6] < (1ull << 40))
       fprintf(stderr, "[nms phases, wg0, us] select %.1f pairs %.1f wait-resolve %.1f cross %.1f barrier %.1f steps %llu | resolve (any wg) %.1f rounds %llu [first round %.1f other rounds %.1f output %.1f]\n",
               h[1] * 0.01, h[2] * 0.01, h[3] * 0.01, h[5] * 0.01, h[0] * 0.01, h[6], h[9] * 0.01, h[11], h[12] * 0.01, h[13] * 0.01, h[14] * 0.01);
+      fprintf(stderr, "    resolve: edges total %llu, max per chunk %llu, chunk sizes total %llu, chunks resolved from LDS %llu\n", h[25], h[27], h[28], h[26]);
+      fprintf(stderr, "    pairs phase per workgroup (wave 0): longest %.1f us, sum over steps and workgroups / workgroups %.1f us; cross: longest single %.1f us\n", h[29] * 0.01, h[24] ? h[30] * 0.01 / h[24] : 0.0, h[31] * 0.01);
       fprintf(stderr, "    workgroups: %llu, busy time max %.1f us, mean %.1f us\n", h[24], h[22] * 0.01, h[24] ? h[23] * 0.01 / h[24] : 0.0);
       fprintf(stderr, "    cross, wave 0: items %llu row-loops %.1f us, stage-1 drains %llu = %.1f us, stage-2 drains %llu = %.1f us\n", h[21],
               h[16] * 0.01, h[19], h[17] * 0.01, h[20], h[18] * 0.01);
     hipMemsetAsync(cv.prof, 0, 32 * 8, st);
     a.prof = cv.prof;
   }
-  const int cus = cu_count();
-  int64_t nb = (n_slots + 511) / 512;                 // 8 waves x 64 columns per workgroup
-  {                                                   // ... and one wave per tile of the first chunk's triangle
-    const int64_t per_seg = (n_slots + nseg - 1) / nseg;
-    const int64_t c = per_seg < a.cap_first ? per_seg : a.cap_first;
-    const int64_t tiles = ((c + 63) / 64) * ((c + 63) / 64 + 1) / 2 * nseg;
-    if (nb < (tiles + 7) / 8) nb = (tiles + 7) / 8;
-  }
-  if (n_slots >= 8192) nb = cus;                      // enough work for the whole chip
-  if (nb < nseg) nb = nseg;
-  if (nb > cus) nb = cus;
-  if (nb < 1) nb = 1;
+  const int nb = nms_grid(nseg, n_slots, a.cap_first);
   a.plan = nullptr;
   if (nseg > 1) {                                      // workgroups in proportion to the (non-empty) segments' sizes
     int c1 = a.cap_first < a.capmax ? a.cap_first : a.capmax;
-    k_plan_teams<<<1, 1024, 0, st>>>(a.seg_begin, a.seg_end, (int)nseg, (int)nb, c1, cv.plan);
+    if (!(pre & kNmsPlanned)) k_plan_teams<<<1, 1024, 0, st>>>(a.seg_begin, a.seg_end, (int)nseg, (int)nb, c1, cv.plan);
     a.plan = cv.plan;
   }
   if (kind == 2) return launch_persist<QuadGeom64>(a, (unsigned)nb, st);
@@ -562,10 +571,10 @@ size_t obb_nms_obb_workspace_bytes(int64_t bs, int64_t cap_img, int64_t nc, int 
 int obb_non_max_suppression_obb(const void* pred, int dtype, int64_t bs, int64_t A, int64_t no, float conf_thres,
                                 float iou_thres, const int32_t* classes_host, int n_classes, int agnostic, int multi_label,
                                 int64_t max_det, int64_t max_nms, float max_wh, const float* extra8, int64_t n_extra,
-                                int64_t cap_img, int64_t expected_cand, float* out, int64_t* out_count, int64_t* status, void* ws,
-                                size_t ws_bytes, void* stream) {
+                                int64_t cap_img, int64_t expected_cand, float* out, int out_packed, int64_t* out_count,
+                                int64_t* status, void* ws, size_t ws_bytes, void* stream) {
   return run_nms_obb(pred, dtype, bs, A, no, conf_thres, iou_thres, classes_host, n_classes, agnostic, multi_label, max_det,
-                     max_nms, max_wh, extra8, n_extra, cap_img, expected_cand, out, out_count, status, ws, ws_bytes,
+                     max_nms, max_wh, extra8, n_extra, cap_img, expected_cand, out, out_packed ? 1 : 0, out_count, status, ws, ws_bytes,
                      (hipStream_t)stream);
 }
 

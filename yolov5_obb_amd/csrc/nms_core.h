@@ -65,6 +65,15 @@ struct NmsArgs {
   int cull;                  // 1: conservative rejects allowed (thr >= 0)
 };
 
+// ---- cost model shared by the planner (k_plan_teams) and the workgroups that follow its plan
+constexpr int kPlanInfoSlot = 1023;        // the plan buffer has kMaxTeams = 1024 entries, workgroups use the first NB <= #CUs
+__host__ __device__ __forceinline__ long long plan_cost(long long sz, long long chunk) {
+  if (sz <= 0) return 0;
+  const long long c = sz < chunk ? sz : chunk;
+  const long long nb = (c + 63) / 64;
+  return nb * (nb + 1) / 2 * 16 + 48 + (sz > chunk ? (sz - chunk) / 16 : 0);
+}
+
 // ------------------------------------------------------------------ agent-scope accessors
 template <typename T> __device__ __forceinline__ T ldg_agent(const T* p) {
   return __hip_atomic_load(const_cast<T*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -255,7 +264,7 @@ __device__ __forceinline__ void nms_pairs(const NmsArgs& a, int tm, int cn, cons
 
   // small chunks: split every 64-row tile into 2 or 4 row slices so that all waves of the team have work
   const int tri = nb * (nb + 1) / 2;
-  const int nsub = (tri * 2 <= ntw) ? 4 : ((tri <= ntw) ? 2 : 1);
+  const int nsub = (tri < 4 * ntw) ? 4 : ((tri < 8 * ntw) ? 2 : 1);   // fewer than 4 (8) tiles per wave: quarter (half) tiles balance better
   const int rows_sub = 64 / nsub;
   const int items_sub = items * nsub;
   for (int it2 = tw; it2 < items_sub; it2 += ntw) {
@@ -322,9 +331,10 @@ __device__ __forceinline__ void nms_pairs(const NmsArgs& a, int tm, int cn, cons
 // ------------------------------------------------------------------ A2: resolve the chunk (serial section, 512 threads)
 // Greedy NMS inside the chunk == the lexicographically-first maximal independent set of the conflict graph (edges
 // i < j, i the higher score).  Parallel rounds: a node is kept as soon as none of its lower-index neighbours is still
-// undecided; kept nodes kill their higher-index neighbours.  The edge list lives in LDS (when it fits) as one
-// contiguous block per thread and PRUNES itself: an edge is dropped the moment its target is decided or its source
-// is dead / has delivered its kill, so the rounds get cheaper geometrically.
+// undecided; kept nodes kill their higher-index neighbours.  The edge list lives in LDS as one contiguous block per
+// thread and PRUNES itself: an edge is dropped the moment its target is decided or its source is dead / has delivered
+// its kill, so the rounds get cheaper geometrically.  A list too long for LDS is streamed read-only from global memory
+// for the first rounds, until what is left of it fits.
 // LDS (aliasing the wave scratch): state[capmax] | blocked[capmax] | edges[...]
 // returns the number of kept boxes of the chunk (also published in nrows[g])
 __device__ __forceinline__ int nms_resolve(const NmsArgs& a, int g, int tm, int cn, int kept_before, const uint32_t* cidx, uint8_t* smem, size_t smem_bytes,
@@ -338,12 +348,15 @@ __device__ __forceinline__ int nms_resolve(const NmsArgs& a, int g, int tm, int 
   long long E = ldg_agent(a.nedges + tm);
   if (E > a.ecap) E = a.ecap;         // cannot happen: ecap is the worst case capmax*(capmax-1)/2
   const uint32_t* edges = a.edges + (size_t)tm * a.ecap;   // plain loads: acquired in serial_begin
-  const bool in_lds = E <= lcap;
+  // The list fits in LDS when every thread's share does (one contiguous block per thread, odd length: conflict-free banks).
+  const int percap = (int)(((lcap / kNmsThreads) - 1) | 1);
   int per = (int)((E + kNmsThreads - 1) / kNmsThreads);
-  per |= 1;                            // odd block length: conflict-free LDS banks across the lanes
+  per |= 1;
+  bool lds_mode = per <= percap;
+  if (!lds_mode) per = percap;
   int mycnt = 0;
   uint32_t* mine_e = ledges + (size_t)tid * per;
-  if (in_lds && (long long)per * kNmsThreads <= lcap) {
+  if (lds_mode) {
     // thread t takes edges t, t+512, ... (coalesced global reads, 8 in flight) into its own LDS block
     for (long long k0 = tid; k0 < E; k0 += 8 * kNmsThreads) {
       uint32_t v[8];
@@ -353,55 +366,75 @@ __device__ __forceinline__ int nms_resolve(const NmsArgs& a, int g, int tm, int 
       for (int u = 0; u < 8; u++) if (k0 + (long long)u * kNmsThreads < E) mine_e[mycnt++] = v[u];
     }
   }
-  const bool lds_mode = in_lds && (long long)per * kNmsThreads <= lcap;
   __syncthreads();
   u64 tp = 0;
-  if (a.prof && tid == 0) { tp = wall_clock64(); }
+  if (a.prof && tid == 0) { tp = wall_clock64(); atomicAdd(a.prof + 25, (u64)E); atomicMax(a.prof + 27, (u64)E); atomicAdd(a.prof + 28, (u64)cn); atomicAdd(a.prof + 26, (u64)(lds_mode ? 1 : 0)); }
   auto plap = [&](int slot) { if (a.prof && tid == 0) { const u64 t = wall_clock64(); atomicAdd(a.prof + slot, t - tp); tp = t; } };
 
+  // A list that does not fit is first streamed READ-ONLY from global memory (16-byte plain loads, 8 in flight: the
+  // list was published write-through and acquired in serial_begin, nothing writes it during the serial section):
+  // the rounds work exactly as below but nothing is pruned.  Each such round counts the edges that still have two
+  // undecided ends; these can only become fewer, so once every thread's count fits its LDS block the next round
+  // copies the survivors into LDS and the self-pruning rounds take over.
+  bool compact = false;
+  // one edge (i < j) against the states read for it: true = both ends undecided, the edge stays and j waits for i
+  auto decide = [&](uint32_t ed, uint8_t sj, uint8_t si) -> bool {
+    if (sj != 0) return false;                       // target decided: the edge is done
+    if (si == 1) { state[ed & 0xffff] = 2; return false; }   // kept source kills the target
+    if (si == 2) return false;                       // dead source never matters again
+    blocked[ed & 0xffff] = 1;
+    return true;
+  };
   for (int round = 0;; round++) {
+    int remaining = 0;
     if (lds_mode) {
-      int w = 0;
-      for (int k = 0; k < mycnt; k++) {
+      // four edges per trip: their 4 + 8 LDS reads are issued together (the byte reads conflict on banks and would
+      // otherwise serialise edge by edge); deciding on a slightly stale state only delays a decision by a round
+      int w = 0, k = 0;
+      for (; k + 4 <= mycnt; k += 4) {
+        uint32_t ed[4]; uint8_t sj[4], si[4];
+#pragma unroll
+        for (int c = 0; c < 4; c++) ed[c] = mine_e[k + c];
+#pragma unroll
+        for (int c = 0; c < 4; c++) { sj[c] = state[ed[c] & 0xffff]; si[c] = state[ed[c] >> 16]; }
+#pragma unroll
+        for (int c = 0; c < 4; c++) if (decide(ed[c], sj[c], si[c])) mine_e[w++] = ed[c];
+      }
+      for (; k < mycnt; k++) {
         const uint32_t ed = mine_e[k];
-        const int i = ed >> 16, j = ed & 0xffff;
-        const uint8_t sj = state[j];
-        if (sj != 0) continue;                       // target decided: the edge is done
-        const uint8_t si = state[i];
-        if (si == 1) { state[j] = 2; continue; }     // kept source kills the target
-        if (si == 2) continue;                       // dead source never matters again
-        blocked[j] = 1;                              // both undecided: j has to wait for i
-        mine_e[w++] = ed;
+        if (decide(ed, state[ed & 0xffff], state[ed >> 16])) mine_e[w++] = ed;
       }
       mycnt = w;
     } else {
-      // the list does not fit in LDS: same self-pruning pass on the thread's own strided slots of the global list
-      // (slots tid, tid+512, ...: coalesced, nobody else touches them), four loads in flight.  Loads AND stores are
-      // agent-scope (write-through): a plain store would leave a dirty line in this XCD's L2 that can be written back
-      // after the next step's edges have been published by other XCDs, and a plain re-load could hit this CU's L1.
-      uint32_t* gedges = a.edges + (size_t)tm * a.ecap;
-      if (round == 0) mycnt = (int)((E - tid + kNmsThreads - 1) / kNmsThreads);
+      const uint4* e4 = reinterpret_cast<const uint4*>(edges);
+      const long long nvec = (E + 3) >> 2;
       int w = 0;
-      for (int k0 = 0; k0 < mycnt; k0 += 4) {
-        uint32_t v[4];
+      for (long long v0 = tid; v0 < nvec; v0 += 8 * kNmsThreads) {
+        uint4 v[8];
 #pragma unroll
-        for (int u = 0; u < 4; u++) v[u] = (k0 + u < mycnt) ? ldg_agent(gedges + (size_t)tid + (size_t)(k0 + u) * kNmsThreads) : 0u;
+        for (int u = 0; u < 8; u++) {
+          const long long k = v0 + (long long)u * kNmsThreads;
+          v[u] = k < nvec ? e4[k] : make_uint4(0u, 0u, 0u, 0u);
+        }
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-          if (k0 + u >= mycnt) break;
-          const uint32_t ed = v[u];
-          const int i = ed >> 16, j = ed & 0xffff;
-          const uint8_t sj = state[j];
-          if (sj != 0) continue;
-          const uint8_t si = state[i];
-          if (si == 1) { state[j] = 2; continue; }
-          if (si == 2) continue;
-          blocked[j] = 1;
-          stg_agent(gedges + (size_t)tid + (size_t)w * kNmsThreads, ed);
-          w++;
+        for (int u = 0; u < 8; u++) {
+          const long long k = v0 + (long long)u * kNmsThreads;
+          if (k >= nvec) break;
+          const uint32_t e[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+          uint8_t sj[4], si[4];
+#pragma unroll
+          for (int c = 0; c < 4; c++) { sj[c] = state[e[c] & 0xffff]; si[c] = state[e[c] >> 16]; }   // (garbage past E: 16-bit indices, in range of the block)
+#pragma unroll
+          for (int c = 0; c < 4; c++) {
+            if (4 * k + c >= E) break;
+            if (decide(e[c], sj[c], si[c])) {
+              remaining++;
+              if (compact) mine_e[w++] = e[c];
+            }
+          }
         }
       }
-      mycnt = w;
+      if (compact) mycnt = w;
     }
     __syncthreads();
     bool rem = false;
@@ -413,6 +446,10 @@ __device__ __forceinline__ int nms_resolve(const NmsArgs& a, int g, int tm, int 
     }
     const int any = __syncthreads_or(rem ? 1 : 0);     // barrier + "somebody is still undecided" in one
     if (!any) { if (a.prof && tid == 0) atomicAdd(a.prof + 11, (u64)(round + 1)); break; }
+    if (!lds_mode) {
+      if (compact) lds_mode = true;                                        // the survivors are in LDS now
+      else compact = __syncthreads_or(remaining > per ? 1 : 0) == 0;       // block-uniform: next round copies them
+    }
     if (round == 0) plap(12);
   }
 
@@ -603,11 +640,14 @@ __global__ __launch_bounds__(kNmsThreads) __attribute__((amdgpu_waves_per_eu(1, 
   int nteams = a.nseg < NB ? a.nseg : NB;
   int T = NB / nteams;
   int team = blockIdx.x / T, wg = blockIdx.x - team * T;
-  int g_first = team, g_step = nteams;
-  if (a.plan != nullptr && a.plan[0].w > 0) {          // planned teams: exactly one segment per team
+  int g_first = team, g_step = nteams, g_last = a.nseg - 1;
+  long long skip_cost = -1;                            // >= 0: segments at least this expensive belong to a team of their own
+  if (a.plan != nullptr && a.plan[0].w > 0) {          // planned (k_plan_teams): a team on one segment, or one workgroup on a run of small ones
     const int4 pl = a.plan[blockIdx.x];
     if (pl.x < 0) return;
-    g_first = pl.x; g_step = a.nseg; team = pl.y; wg = pl.z; T = pl.w;
+    g_first = pl.x; g_step = 1; team = pl.y; T = pl.w;
+    if (T == 1) { wg = 0; g_last = pl.x + pl.z; skip_cost = (long long)(unsigned)a.plan[kPlanInfoSlot].x; }
+    else { wg = pl.z; g_last = pl.x; }
   } else if (team >= nteams) {
     return;
   }
@@ -623,8 +663,12 @@ __global__ __launch_bounds__(kNmsThreads) __attribute__((amdgpu_waves_per_eu(1, 
     if (prof) { const u64 t1 = wall_clock64(); a.prof[slot] += t1 - t0; t0 = t1; }
   };
 
-  for (int g = g_first; g < a.nseg; g += g_step) {
+  const int plan_chunk = a.cap_first < a.capmax ? a.cap_first : a.capmax;
+  for (int g = g_first; g <= g_last; g += g_step) {
     const int sb = a.seg_begin[g], se = a.seg_end[g];
+    // (the first segment of a plan entry is always the workgroup's own: a run starts with a small segment, and a big
+    //  segment whose team has one member is an entry of its own)
+    if (skip_cost >= 0 && g != g_first && plan_cost(se - sb, plan_chunk) >= skip_cost) continue;
     int cur = sb, kept = 0;
     int cap = a.cap_first < a.capmax ? a.cap_first : a.capmax;
     // Windows (only with max_keep): positions are opened a window at a time -- a new window is first tested against every
@@ -646,7 +690,9 @@ __global__ __launch_bounds__(kNmsThreads) __attribute__((amdgpu_waves_per_eu(1, 
       const int cn = nms_select(a, wend, cur, cap, cidx, s_i);
       lap(1);
       if (cn == 0) continue;                               // nothing alive in the rest of the window (cur == wend now)
+      const u64 tpz = (a.prof && tid == 0) ? wall_clock64() : 0ull;
       nms_pairs<G>(a, team, cn, cidx, tw, ntw, L);
+      if (a.prof && tid == 0) { const u64 d = wall_clock64() - tpz; atomicMax(a.prof + 29, d); atomicAdd(a.prof + 30, d); }
       lap(2);
       // ---- all edges are out: the last arriver resolves the chunk, the others wait for its rows
       if (serial_begin(bar, &s_flag)) {
@@ -663,7 +709,9 @@ __global__ __launch_bounds__(kNmsThreads) __attribute__((amdgpu_waves_per_eu(1, 
       const int nr = ldg_agent(a.nrows + team);
       const bool more = cur < wend && !(a.max_keep > 0 && kept + nr >= a.max_keep);
       if (nr > 0 && more) {
+        const u64 tcz = (a.prof && tid == 0) ? wall_clock64() : 0ull;
         nms_cross<G>(a, a.rows + sb + kept, nr, cur, wend, tw, ntw, L);
+        if (a.prof && tid == 0) { atomicMax(a.prof + 31, wall_clock64() - tcz); }
         lap(5);
         if (!team_barrier(bar, &s_flag)) return;       // the kills are visible before anybody selects again
         lap(0);
@@ -676,78 +724,132 @@ __global__ __launch_bounds__(kNmsThreads) __attribute__((amdgpu_waves_per_eu(1, 
   if (a.prof && tid == 0) { const u64 el = wall_clock64() - t_wg0; atomicMax(a.prof + 22, el); atomicAdd(a.prof + 23, el); atomicAdd(a.prof + 24, 1ull); }
 }
 
-// ------------------------------------------------------------------ team planning for many small segments
-// One workgroup: hands the NB workgroups of the persistent launch to the non-empty segments in proportion to their
-// estimated work (64x64 tiles of the first chunk's triangle + a fixed part), at least one each.  plan[w] = {segment, team,
-// index in team, team size}; plan[0].w == 0 signals "use the static teams" (more non-empty segments than workgroups).
-__global__ __launch_bounds__(1024) void k_plan_teams(const int* __restrict__ seg_begin, const int* __restrict__ seg_end, int nseg, int NB,
-                                                     int chunk, int4* __restrict__ plan) {
-  __shared__ long long s_cost[1024];
-  __shared__ int s_cnt[1024], s_t[1024];
-  __shared__ long long s_total;
-  __shared__ int s_nne;
+// ------------------------------------------------------------------ team planning for multi-segment launches
+// One workgroup decides what the NB workgroups of the persistent launch do.  Segment cost = 64x64 tiles of the first
+// chunk's triangle + a fixed part (plan_cost).  With L = total cost / NB:
+//   big segments   (cost >= 2L) get a team of floor(cost / L') workgroups (L' = their share of the grid), plan[w] =
+//                  {segment, team, index in team, team size};
+//   small segments are packed, in segment order, into the remaining workgroups by equal cuts of their running cost:
+//                  plan[w] = {first segment, team, segments in the run - 1, 1}; a run may enclose empty and big segments,
+//                  which the workgroup skips (plan[kPlanInfoSlot].x = the cost from which a segment is big);
+//   plan[w].x = -1: nothing to do.  plan[0].w == 0: nothing planned (no non-empty segment), the static teams are used.
+// More non-empty segments than workgroups is fine (a class file of a whole test set in the merge NMS: ~900 images).
+// exclusive prefix + total over the 1024 threads of the block (two values at once)
+__device__ __forceinline__ void block_scan2(long long va, long long vb, long long* sa, long long* sb, long long& pa, long long& pb,
+                                            long long& ta, long long& tb) {
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  long long ia = va, ib = vb;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const long long xa = __shfl_up(ia, d), xb = __shfl_up(ib, d);
+    if (lane >= d) { ia += xa; ib += xb; }
+  }
+  __syncthreads();                                  // previous users of sa / sb are done
+  if (lane == 63) { sa[wv] = ia; sb[wv] = ib; }
+  __syncthreads();
+  long long wa = 0, wb = 0; ta = 0; tb = 0;
+#pragma unroll
+  for (int k = 0; k < 16; k++) { const long long xa = sa[k], xb = sb[k]; if (k < wv) { wa += xa; wb += xb; } ta += xa; tb += xb; }
+  pa = wa + ia - va; pb = wb + ib - vb;
+}
+
+struct PlanLds { long long a[16], b[16]; int first[1024], last[1024]; };
+
+// the planner proper: called by all 1024 threads of one workgroup (k_plan_teams, or the last workgroup of the fused
+// sort/prep kernel); seg_begin / seg_end must be visible to the caller
+__device__ __forceinline__ void plan_teams_block(const int* seg_begin, const int* seg_end, int nseg, int NB, int chunk, int4* plan,
+                                                 PlanLds& S) {
+  long long* s_a = S.a; long long* s_b = S.b;
+  int* s_first = S.first; int* s_last = S.last;
   const int tid = threadIdx.x;
   const int per = (nseg + 1023) / 1024;
-  auto cost_of = [&](int g) -> long long {
-    const long long sz = (g < nseg) ? (long long)(seg_end[g] - seg_begin[g]) : 0;
-    if (sz <= 0) return 0;
-    const long long c = sz < chunk ? sz : chunk;
-    const long long nb = (c + 63) / 64;
-    return nb * (nb + 1) / 2 * 8 + 32 + (sz > chunk ? (sz - chunk) / 16 : 0);
-  };
-  long long myc = 0; int myn = 0;
-  for (int k = 0; k < per; k++) { const long long c = cost_of(tid * per + k); myc += c; myn += c > 0 ? 1 : 0; }
-  s_cost[tid] = myc; s_cnt[tid] = myn;
-  __syncthreads();
-  const int used_thr = (nseg + per - 1) / per;              // threads that own segments
-  if (tid == 0) {
-    long long tc = 0; int tn = 0;
-    for (int i = 0; i < used_thr; i++) { tc += s_cost[i]; tn += s_cnt[i]; }
-    s_total = tc; s_nne = tn;
-  }
-  __syncthreads();
-  const int nne = s_nne;
-  const long long total = s_total;
-  if (nne == 0 || nne > NB) {
+  const int g0 = tid * per, g1 = (g0 + per < nseg) ? g0 + per : nseg;
+  auto cost_of = [&](int g) -> long long { return plan_cost((long long)(seg_end[g] - seg_begin[g]), chunk); };
+  // ---- totals
+  long long myc = 0, myn = 0, pa, pb, total, nne;
+  for (int g = g0; g < g1; g++) { const long long c = cost_of(g); myc += c; myn += c > 0 ? 1 : 0; }
+  block_scan2(myc, myn, s_a, s_b, pa, pb, total, nne);
+  if (nne == 0) {
     for (int w = tid; w < NB; w += 1024) plan[w] = make_int4(-1, 0, 0, 0);
     return;
   }
-  const long long spare = NB - nne;
-  // team sizes of this thread's segments, then exclusive prefixes of (workgroups, teams) over the threads
-  int myt = 0;
-  for (int k = 0; k < per; k++) {
-    const long long c = cost_of(tid * per + k);
-    if (c > 0) {
-      long long t = 1 + spare * c / total;
-      const long long useful = (c + 63) / 64;               // more workgroups than ~tiles/8 only add barrier cost
-      if (t > useful) t = useful;
-      if (t < 1) t = 1;
-      myt += (int)t;
+  const long long L = (total + NB - 1) / NB;
+  const long long big_from = 2 * L;
+  // ---- split of the grid: r workgroups for the small segments, NB - r for the teams of the big ones
+  long long mybc = 0, mybn = 0, big_cost, n_big;
+  for (int g = g0; g < g1; g++) { const long long c = cost_of(g); if (c >= big_from) { mybc += c; mybn++; } }
+  long long pbc, pbn;
+  block_scan2(mybc, mybn, s_a, s_b, pbc, pbn, big_cost, n_big);
+  const long long small_cost = total - big_cost, n_small = nne - n_big;
+  long long r = 0;
+  if (n_small > 0) {
+    r = (small_cost + L - 1) / L;
+    if (r < 1) r = 1;
+    if (r > n_small) r = n_small;
+    if (r > NB - n_big) r = NB - n_big;             // (n_big <= NB / 2: every big segment costs at least 2L)
+  }
+  // enough workgroups for everybody: no packing, every small segment gets its own workgroup (piece = its rank)
+  const bool one_each = n_small > 0 && n_small + (n_big > 0 ? (big_cost + L - 1) / L : 0) <= NB;
+  if (one_each) r = n_small;
+  const long long NBb = NB - r;
+  const long long Lb = n_big > 0 ? (big_cost + NBb - 1) / NBb : 1;
+  auto team_size = [&](long long c) -> long long {
+    long long t = c / Lb;
+    const long long useful = (c + 63) / 64;          // more workgroups than ~tiles/8 only add barrier cost
+    if (t > useful) t = useful;
+    return t < 1 ? 1 : t;
+  };
+  // ---- teams of the big segments: workgroups r + [prefix of team sizes), team ids r + [prefix of count)
+  long long myt = 0;
+  for (int g = g0; g < g1; g++) { const long long c = cost_of(g); if (c >= big_from) myt += team_size(c); }
+  long long pt, pcnt, used_big, dummy;
+  block_scan2(myt, mybn, s_a, s_b, pt, pcnt, used_big, dummy);
+  if (r + used_big > NB) {                           // (cannot happen with the bounds above; the static teams are always valid)
+    for (int w = tid; w < NB; w += 1024) plan[w] = make_int4(-1, 0, 0, 0);
+    return;
+  }
+  {
+    long long w0 = r + pt, team = r + pcnt;
+    for (int g = g0; g < g1; g++) {
+      const long long c = cost_of(g);
+      if (c >= big_from) {
+        const long long t = team_size(c);
+        for (int i = 0; i < (int)t; i++) plan[w0 + i] = make_int4(g, (int)team, i, (int)t);
+        w0 += t; team++;
+      }
     }
   }
-  s_t[tid] = myt;
+  for (int w = (int)(r + used_big) + tid; w < NB; w += 1024) plan[w] = make_int4(-1, 0, 0, 0);
+  // ---- runs of small segments: piece = running small cost / Ls
+  long long mysc = 0, mysn = 0, psc, psn, tsc, tsn;
+  for (int g = g0; g < g1; g++) { const long long c = cost_of(g); if (c > 0 && c < big_from) { mysc += c; mysn++; } }
+  block_scan2(mysc, mysn, s_a, s_b, psc, psn, tsc, tsn);
+  const long long Ls = r > 0 ? (small_cost + r - 1) / r : 1;
+  s_first[tid] = 0x7fffffff; s_last[tid] = -1;
   __syncthreads();
-  if (tid == 0) {
-    int accw = 0, accn = 0;
-    for (int i = 0; i < used_thr; i++) { const int t = s_t[i], n = s_cnt[i]; s_t[i] = accw; s_cnt[i] = accn; accw += t; accn += n; }
-    s_nne = accw;                                             // workgroups in use
-  }
-  __syncthreads();
-  int w0 = s_t[tid], team = s_cnt[tid];
-  for (int k = 0; k < per; k++) {
-    const int g = tid * per + k;
-    const long long c = cost_of(g);
-    if (c > 0) {
-      long long t = 1 + spare * c / total;
-      const long long useful = (c + 63) / 64;
-      if (t > useful) t = useful;
-      if (t < 1) t = 1;
-      for (int i = 0; i < (int)t; i++) plan[w0 + i] = make_int4(g, team, i, (int)t);
-      w0 += (int)t; team++;
+  if (r > 0) {
+    long long run = psc, rank = psn;
+    for (int g = g0; g < g1; g++) {
+      const long long c = cost_of(g);
+      if (c > 0 && c < big_from) {
+        const int piece = one_each ? (int)rank : (int)(run / Ls);   // < r: run < small_cost <= r * Ls
+        atomicMin(&s_first[piece], g); atomicMax(&s_last[piece], g);
+        run += c; rank++;
+      }
     }
   }
-  const int used = s_nne;
-  for (int w = used + tid; w < NB; w += 1024) plan[w] = make_int4(-1, 0, 0, 0);
+  __syncthreads();
+  for (int w = tid; w < (int)r; w += 1024) {
+    const int f = s_first[w], l = s_last[w];
+    plan[w] = (l >= f) ? make_int4(f, w, l - f, 1) : make_int4(-1, 0, 0, 0);       // (no segment starts in this piece: idle)
+  }
+  if (tid == 0) plan[kPlanInfoSlot] = make_int4((int)(big_from > 0x7fffffffLL ? 0x7fffffffLL : big_from), 0, 0, 0);
+}
+
+__global__ __launch_bounds__(1024) void k_plan_teams(const int* __restrict__ seg_begin, const int* __restrict__ seg_end, int nseg, int NB,
+                                                     int chunk, int4* __restrict__ plan) {
+  __shared__ PlanLds S;
+  plan_teams_block(seg_begin, seg_end, nseg, NB, chunk, plan, S);
 }
 
 }  // namespace obb

@@ -371,6 +371,201 @@ __global__ void k_prep_cand(const float4* __restrict__ cand, const uint32_t* __r
   if ((threadIdx.x & 63) == 0 && m) alive[p >> 6] = m;           // the bitmap was zeroed before
 }
 
+// One launch instead of four memsets: candidate counters, tiny-box flags, the caller's status words, the fused kernel's
+// ticket and the team-barrier block of the NMS kernel.
+__global__ void k_reset_state(int* __restrict__ cnt, int n_cnt, int* __restrict__ tiny, int bs, int64_t* __restrict__ status,
+                              int* __restrict__ ticket, uint4* __restrict__ bar16, long long n_bar16) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x, n = (long long)gridDim.x * blockDim.x;
+  for (long long k = i; k < n_cnt; k += n) cnt[k] = 0;
+  for (long long k = i; k < bs; k += n) tiny[k] = 0;
+  if (i < 2) status[i] = 0;
+  if (i == 2) *ticket = 0;
+  for (long long k = i; k < n_bar16; k += n) bar16[k] = make_uint4(0u, 0u, 0u, 0u);
+}
+
+// Bitonic sort of npad (a power of two, 64 .. 1024*E) (key, value) pairs that sit in LDS, by 1024 threads holding E
+// consecutive elements each in registers: compare-exchange distances below E stay inside a thread, distances below 64*E are
+// lane shuffles inside a wave, only the longer ones go through LDS with a workgroup barrier (10 of the 66 stages at 2048).
+template <int E>
+__device__ __forceinline__ void bitonic_lds_regs(unsigned long long* s_keys, uint32_t* s_vals, int npad, int tid) {
+  const bool active = tid * E < npad;              // wave-uniform: npad is a multiple of 64
+  unsigned long long k[E];
+  uint32_t v[E];
+#pragma unroll
+  for (int e = 0; e < E; e++) { k[e] = active ? s_keys[tid * E + e] : ~0ull; v[e] = active ? s_vals[tid * E + e] : 0u; }
+  for (int kk = 2; kk <= npad; kk <<= 1) {
+    int j = kk >> 1;
+    if (j >= 64 * E) {                             // (workgroup-uniform)
+      if (active) {
+#pragma unroll
+        for (int e = 0; e < E; e++) { s_keys[tid * E + e] = k[e]; s_vals[tid * E + e] = v[e]; }
+      }
+      __syncthreads();
+      for (; j >= 64 * E; j >>= 1) {
+        for (int t = tid; t < (npad >> 1); t += 1024) {
+          const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+          const int ixj = i | j;
+          const unsigned long long ka = s_keys[i], kb = s_keys[ixj];
+          if ((ka > kb) == ((i & kk) == 0)) {
+            s_keys[i] = kb; s_keys[ixj] = ka;
+            const uint32_t va = s_vals[i], vb = s_vals[ixj];
+            s_vals[i] = vb; s_vals[ixj] = va;
+          }
+        }
+        __syncthreads();
+      }
+      if (active) {
+#pragma unroll
+        for (int e = 0; e < E; e++) { k[e] = s_keys[tid * E + e]; v[e] = s_vals[tid * E + e]; }
+      }
+    }
+    if (active) {
+      for (; j >= E; j >>= 1) {                    // partner element i ^ j lives in lane ^ (j / E), same slot e
+        const int lx = j / E;
+#pragma unroll
+        for (int e = 0; e < E; e++) {
+          const int i = tid * E + e;
+          const unsigned long long ok = __shfl_xor(k[e], lx);
+          const uint32_t ov = __shfl_xor(v[e], lx);
+          const bool take_min = ((i & j) == 0) == ((i & kk) == 0);
+          if (take_min ? (ok < k[e]) : (ok > k[e])) { k[e] = ok; v[e] = ov; }
+        }
+      }
+#pragma unroll
+      for (int jj = E >> 1; jj >= 1; jj >>= 1) {   // distances inside the thread (compile-time slots)
+        if (jj <= (kk >> 1)) {
+#pragma unroll
+          for (int e = 0; e < E; e++) {
+            if ((e & jj) == 0) {
+              const int e2 = e | jj;
+              const bool up = (((tid * E + e) & kk) == 0);
+              if ((k[e] > k[e2]) == up) {
+                const unsigned long long tk = k[e]; k[e] = k[e2]; k[e2] = tk;
+                const uint32_t tv = v[e]; v[e] = v[e2]; v[e2] = tv;
+              }
+            }
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  if (active) {
+#pragma unroll
+    for (int e = 0; e < E; e++) { s_keys[tid * E + e] = k[e]; s_vals[tid * E + e] = v[e]; }
+  }
+  __syncthreads();
+}
+
+// Small and medium images (at most kSortLdsMax candidates each, the regime of the reference's default thresholds): ONE
+// workgroup per image does everything between the decode kernel and the NMS kernel -- segment bookkeeping
+// (k_cand_segments), class keys (k_rekey), the sort (a bitonic network on (key, slot) pairs in LDS instead of rocPRIM's
+// one-small-workgroup-per-segment radix sort), the class segment table (k_class_bounds), the NMS records and the alive
+// bitmap including its zero words (k_prep_cand + memset): six launches become one.  An image with more candidates than
+// the network takes is left empty; the caller sees its count in status[1] and calls again with that hint.
+constexpr int kSortLdsMax = OBB_NMS_SORT_LDS_MAX;
+constexpr int64_t kSortLdsHint = OBB_NMS_SORT_LDS_HINT;   // use the in-LDS path when the previous call's largest image was at most this
+__global__ __launch_bounds__(1024) void k_sort_prep_lds(const float4* __restrict__ cand, const unsigned long long* __restrict__ keys_in,
+                                                        const uint32_t* __restrict__ vals_in, unsigned long long* __restrict__ keys_out,
+                                                        uint32_t* __restrict__ vals_out, const int* __restrict__ cnt,
+                                                        const int* __restrict__ tiny, int bs, long long cap_img, long long max_nms,
+                                                        int class_ok, long long A, int nc, int ncs, float class_offset, int* sort_begin,
+                                                        int* sort_end, int* img_end, int* mode, int* grp_begin, int* grp_end,
+                                                        int* __restrict__ seg_begin, int* __restrict__ seg_end, int* __restrict__ keep_cnt,
+                                                        float4* __restrict__ rec, u64* __restrict__ alive, int* __restrict__ ticket,
+                                                        int plan_nb, int plan_chunk, int4* __restrict__ plan) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+  __shared__ PlanLds s_plan;
+  __shared__ int s_ticket;
+  unsigned long long* s_keys = reinterpret_cast<unsigned long long*>(s_raw);
+  uint32_t* s_vals = reinterpret_cast<uint32_t*>(s_keys + kSortLdsMax);
+  const int g = blockIdx.x, tid = threadIdx.x, T = 1024;
+  long long c = cnt[g * kCntPad];
+  const bool over_cap = c > cap_img;
+  if (over_cap) c = cap_img;
+  const int b0 = (int)(g * cap_img);
+  if (c > kSortLdsMax) c = 0;                                  // not this kernel's regime: reported through status[1]
+  const bool over_nms = max_nms > 0 && c > max_nms;
+  const int e = (int)(over_nms ? max_nms : c);                 // :845-846 top max_nms by confidence
+  const int m = (class_ok && !over_cap && !tiny[g] && !over_nms) ? 1 : 0;
+  const int n = (int)c;
+  if (tid == 0) {
+    sort_begin[g] = b0; sort_end[g] = b0 + n; img_end[g] = b0 + e; mode[g] = m;
+    grp_begin[g] = b0; grp_end[g] = b0;
+  }
+  for (int sgm = tid; sgm < ncs; sgm += T) { seg_begin[g * ncs + sgm] = b0; seg_end[g * ncs + sgm] = b0; keep_cnt[g * ncs + sgm] = 0; }
+  int npad = 64;
+  while (npad < n) npad <<= 1;
+  const unsigned long long lim = (unsigned long long)A * nc;
+  for (int i = tid; i < npad; i += T) {
+    unsigned long long k = ~0ull;
+    uint32_t v = 0;
+    if (i < n) {
+      k = keys_in[b0 + i]; v = vals_in[b0 + i];
+      if (m == 1) {                                            // k_rekey: (cls << 56 | score_desc << 24 | anchor)
+        const unsigned long long score = k >> 32, tie = k & 0xffffffffull;
+        const unsigned long long cls = (unsigned long long)(int)cand[(size_t)(b0 + i) * 2 + 1].z;
+        const unsigned long long anchor = tie < lim ? tie / nc : (unsigned long long)A + (tie - lim);
+        k = (cls << 56) | (score << 24) | (anchor & 0xffffffull);
+      }
+    }
+    s_keys[i] = k; s_vals[i] = v;
+  }
+  __syncthreads();
+  // bitonic network, ascending; keys are unique (the tie word), so the result is the one total order
+  switch (npad >> 10) {
+    case 0: case 1: bitonic_lds_regs<1>(s_keys, s_vals, npad, tid); break;
+    case 2: bitonic_lds_regs<2>(s_keys, s_vals, npad, tid); break;
+    case 4: bitonic_lds_regs<4>(s_keys, s_vals, npad, tid); break;
+    default: bitonic_lds_regs<8>(s_keys, s_vals, npad, tid); break;
+  }
+  for (int i = tid; i < n; i += T) { keys_out[b0 + i] = s_keys[i]; vals_out[b0 + i] = s_vals[i]; }
+  // segment table (k_class_bounds): class runs of the sorted keys, or everything in segment 0
+  if (m == 1) {
+    for (int i = tid; i < e; i += T) {
+      const int cls = (int)(s_keys[i] >> 56);
+      if (i == 0 || cls != (int)(s_keys[i - 1] >> 56)) seg_begin[g * ncs + cls] = b0 + i;
+      if (i == e - 1 || cls != (int)(s_keys[i + 1] >> 56)) seg_end[g * ncs + cls] = b0 + i + 1;
+    }
+  } else if (tid == 0) {
+    seg_end[g * ncs] = b0 + e;
+  }
+  // NMS records + every word of the image's part of the alive bitmap (k_prep_cand; cap_img is a multiple of 64)
+  const int e64 = (e + 63) & ~63;
+  for (long long w = (e64 >> 6) + tid; w < (cap_img >> 6); w += T) alive[((size_t)b0 >> 6) + w] = 0ull;   // words behind the boxes
+  for (int base = 0; base < e64; base += T) {
+    const int i = base + tid;
+    bool ok = false;
+    if (i < e) {
+      const size_t ci = (size_t)b0 + s_vals[i];
+      const float4 c0 = cand[ci * 2], c1 = cand[ci * 2 + 1];
+      const float off = c1.z * class_offset;                     // :849
+      RBoxFeat f = rbox_make_feat(c0.x + off, c0.y + off, c0.z, c0.w, c1.x);
+      float4 q[4];
+      RotGeom::pack(f, q);
+#pragma unroll
+      for (int u = 0; u < 4; u++) rec[(size_t)(b0 + i) * 4 + u] = q[u];
+      const float mn = (c0.w < c0.z) ? c0.w : c0.z;
+      ok = !(mn < 0.001f);                                       // nms_rotated_wrapper.py:32
+    }
+    const u64 bits = __ballot(ok);
+    if ((tid & 63) == 0 && i < e64) alive[(size_t)(b0 + i) >> 6] = bits;
+  }
+  if (g == bs - 1 && tid < 8) alive[(((size_t)bs * cap_img) >> 6) + tid] = 0ull;   // the bitmap's guard words
+  // the workgroup that finishes last plans the NMS launch (k_plan_teams without a launch of its own): every workgroup
+  // publishes its segment table (release), the last ticket holder acquires and reads all of them
+  if (plan != nullptr) {
+    __threadfence();
+    __syncthreads();
+    if (tid == 0) s_ticket = atomicAdd(ticket, 1);
+    __syncthreads();
+    if (s_ticket == bs - 1) {
+      __threadfence();
+      plan_teams_block(seg_begin, seg_end, bs * ncs, plan_nb, plan_chunk, plan, s_plan);
+    }
+  }
+}
+
 // Output: the kept boxes of the image's segments merged into descending-score order (the order of the reference's single
 // greedy pass), first max_det of them.  One workgroup per image.  Each segment's kept list is already in ascending key
 // order; the global rank of an entry = its index in its own list + the number of entries of every other list that
@@ -382,8 +577,9 @@ __global__ __launch_bounds__(256) void k_gather_out(const float4* __restrict__ c
                                                     const int* __restrict__ seg_begin, const int* __restrict__ keep_cnt,
                                                     const int* __restrict__ mode, int ncs, long long max_det, float* __restrict__ out,
                                                     int64_t* __restrict__ out_count, const int* __restrict__ cnt, long long cap_img,
-                                                    int64_t* __restrict__ status, const int* __restrict__ abort_flag) {
+                                                    int64_t* __restrict__ status, const int* __restrict__ abort_flag, int packed) {
   __shared__ int s_pre[257];
+  __shared__ long long s_rows[4];
   __shared__ unsigned long long s_key[kMergeLds];
   const int g = blockIdx.x, tid = threadIdx.x;
   // kept per segment (clipped to max_det: a class contributes at most max_det rows to the first max_det overall)
@@ -403,6 +599,22 @@ __global__ __launch_bounds__(256) void k_gather_out(const float4* __restrict__ c
     out_count[g] = *abort_flag ? -1 : nk;                        // -1: the NMS kernel gave up on a barrier (host raises)
     if (cnt[g * kCntPad] > cap_img) atomicMax((unsigned long long*)status, (unsigned long long)cnt[g * kCntPad]);   // overflow: caller retries
     atomicMax((unsigned long long*)status + 1, (unsigned long long)cnt[g * kCntPad]);   // feedback for the caller's next call
+  }
+  // first output row of the image: g * max_det, or (packed) the number of rows of the images before it
+  long long row0 = (long long)g * max_det;
+  if (packed) {
+    long long mine = 0;
+    for (int b2 = tid; b2 < g; b2 += 256) {
+      long long t = 0;
+      for (int c = 0; c < ncs; c++) { long long k = keep_cnt[b2 * ncs + c]; if (max_det > 0 && k > max_det) k = max_det; t += k; }
+      if (max_det > 0 && t > max_det) t = max_det;
+      mine += t;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) mine += __shfl_xor(mine, d);
+    if ((tid & 63) == 0) s_rows[tid >> 6] = mine;
+    __syncthreads();
+    row0 = s_rows[0] + s_rows[1] + s_rows[2] + s_rows[3];
   }
   const int md = mode[g];
   const bool single = md == 0;
@@ -444,14 +656,14 @@ __global__ __launch_bounds__(256) void k_gather_out(const float4* __restrict__ c
     if (max_det > 0 && rank >= max_det) continue;
     const size_t ci = (size_t)g * cap_img + vals_sorted[p];
     const float4 c0 = cand[ci * 2], c1 = cand[ci * 2 + 1];
-    float* o = out + ((size_t)g * max_det + rank) * 7;
+    float* o = out + ((size_t)row0 + rank) * 7;
     o[0] = c0.x; o[1] = c0.y; o[2] = c0.z; o[3] = c0.w; o[4] = c1.x; o[5] = c1.y; o[6] = c1.z;
   }
 }
 
 struct ObbCarve {
   float4* cand; unsigned long long *keys_a, *keys_b; uint32_t *vals_a, *vals_b; int* cnt; int *sort_begin, *sort_end;
-  int *img_end, *mode, *tiny, *grp_begin, *grp_end;
+  int *img_end, *mode, *tiny, *grp_begin, *grp_end, *ticket;
   uint32_t *srs_hist, *digit_base;
   void* sort_tmp; size_t sort_tmp_bytes;
   int64_t* keep;
@@ -480,6 +692,7 @@ static int obb_carve(void* base, int64_t bs, int64_t cap_img, int64_t ncs, ObbCa
   cv->cnt = (int*)take(bs * 4 * kCntPad); cv->sort_begin = (int*)take(bs * 4); cv->sort_end = (int*)take(bs * 4);
   cv->img_end = (int*)take(bs * 4); cv->mode = (int*)take(bs * 4); cv->tiny = (int*)take(bs * 4);
   cv->grp_begin = (int*)take(bs * 4); cv->grp_end = (int*)take(bs * 4);
+  cv->ticket = (int*)take(64);
   cv->digit_base = (uint32_t*)take((size_t)bs * 256 * 4);
   cv->srs_hist = (uint32_t*)take((size_t)bs * ((size_t)(cap_img + kSrsTile - 1) / kSrsTile) * 256 * 4);
   if (seg_sort_tmp_query(n, (int)bs, &cv->sort_tmp_bytes) != hipSuccess) return OBB_ERR_INTERNAL;
@@ -497,7 +710,7 @@ static int obb_carve(void* base, int64_t bs, int64_t cap_img, int64_t ncs, ObbCa
 static int run_nms_obb(const void* pred, int dtype, int64_t bs, int64_t A, int64_t no, float conf_thres, float iou_thres,
                        const int32_t* classes_host, int n_classes, int agnostic, int multi_label, int64_t max_det, int64_t max_nms,
                        float max_wh, const float* extra8, int64_t n_extra, int64_t cap_img, int64_t expected_cand, float* out,
-                       int64_t* out_count, int64_t* status, void* ws, size_t ws_bytes, hipStream_t st) {
+                       int out_packed, int64_t* out_count, int64_t* status, void* ws, size_t ws_bytes, hipStream_t st) {
   const int nc = (int)(no - 5 - 180);                              // :784
   if (bs < 1 || A < 1 || nc < 1 || nc > 256 || max_det < 1 || cap_img < 1 || !pred || !out || !out_count || !status)
     return OBB_ERR_BAD_ARG;
@@ -531,9 +744,11 @@ static int run_nms_obb(const void* pred, int dtype, int64_t bs, int64_t A, int64
   }
   d.cap_img = cap_img; d.cand = cv.cand; d.keys = cv.keys_a; d.vals = cv.vals_a; d.cnt = cv.cnt; d.tiny = cv.tiny;
 
-  hipMemsetAsync(cv.cnt, 0, bs * 4 * kCntPad, st);
-  hipMemsetAsync(cv.tiny, 0, bs * 4, st);
-  hipMemsetAsync(status, 0, 16, st);
+  {
+    Carve& nv0 = cv.nms;
+    k_reset_state<<<256, 256, 0, st>>>(cv.cnt, (int)(bs * kCntPad), cv.tiny, (int)bs, status, cv.ticket,
+                                       reinterpret_cast<uint4*>(nv0.bar), (long long)(nv0.bar_bytes / 16));
+  }
   dim3 gd((unsigned)((A + 4 * kDecRowsPerWave - 1) / (4 * kDecRowsPerWave)), (unsigned)bs);
   {
     ProfScope ps(PROF_DECODE, st);
@@ -544,7 +759,28 @@ static int run_nms_obb(const void* pred, int dtype, int64_t bs, int64_t A, int64
   const unsigned gs = (unsigned)((bs + 255) / 256);
   Carve& nv = cv.nms;
   const int64_t max_seg = (max_nms > 0 && max_nms < cap_img) ? max_nms : cap_img;
-  {
+  static int no_lds_sort = -1;                                     // OBB_NO_LDS_SORT=1: A/B switch for measurements
+  if (no_lds_sort < 0) { const char* e = getenv("OBB_NO_LDS_SORT"); no_lds_sort = (e && atoi(e)) ? 1 : 0; }
+  const bool lds_sort = !no_lds_sort && expected_cand > 0 && expected_cand <= kSortLdsHint && !group_ok;
+  // grid of the NMS launch (needed by the planner inside the fused kernel)
+  const int nms_capmax = cap_max(bs * ncs);
+  const int plan_chunk = cap_first() < nms_capmax ? cap_first() : nms_capmax;
+  const int plan_nb = (bs * ncs > 1) ? nms_grid(bs * ncs, bs * max_seg, cap_first()) : 0;
+  if (lds_sort) {
+    ProfScope ps(PROF_SEGSORT, st);
+    static bool attr_set = false;
+    const size_t lds = (size_t)kSortLdsMax * 12;
+    if (!attr_set) {
+      if (hipFuncSetAttribute((const void*)k_sort_prep_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return OBB_ERR_LAUNCH;
+      attr_set = true;
+    }
+    k_sort_prep_lds<<<(unsigned)bs, 1024, lds, st>>>(cv.cand, cv.keys_a, cv.vals_a, cv.keys_b, cv.vals_b, cv.cnt, cv.tiny, (int)bs, cap_img,
+                                                   max_nms, class_ok, A, nc, ncs, agnostic ? 0.f : max_wh, cv.sort_begin, cv.sort_end,
+                                                   cv.img_end, cv.mode, cv.grp_begin, cv.grp_end, nv.seg_begin, nv.seg_end, nv.keep_cnt,
+                                                   nv.rec, nv.alive, cv.ticket, plan_nb, plan_chunk, plan_nb > 0 ? nv.plan : nullptr);
+  } else {
+   {
     ProfScope ps(PROF_SEGSORT, st);
     k_cand_segments<<<gs, 256, 0, st>>>(cv.cnt, cv.tiny, (int)bs, cap_img, max_nms, class_ok, group_ok, cv.sort_begin, cv.sort_end,
                                         cv.img_end, cv.mode, cv.grp_begin, cv.grp_end);
@@ -580,12 +816,13 @@ static int run_nms_obb(const void* pred, int dtype, int64_t bs, int64_t A, int64
     const int64_t nseg = bs * ncs;
     k_class_bounds<<<(unsigned)((nseg + 255) / 256), 256, 0, st>>>(cv.keys_b, cv.sort_begin, cv.img_end, cv.mode, cv.digit_base, (int)bs,
                                                                    ncs, nv.seg_begin, nv.seg_end, nv.keep_cnt);
-  }
-  dim3 gp((unsigned)((max_seg + 255) / 256), (unsigned)bs);
-  {
+   }
+   dim3 gp((unsigned)((max_seg + 255) / 256), (unsigned)bs);
+   {
     ProfScope ps(PROF_PREP, st);
     hipMemsetAsync(nv.alive, 0, nv.alive_bytes, st);
     k_prep_cand<<<gp, 256, 0, st>>>(cv.cand, cv.vals_b, cv.sort_begin, cv.img_end, cap_img, agnostic ? 0.f : max_wh, nv.rec, nv.alive);
+   }
   }
 
   NmsArgs a;
@@ -596,13 +833,13 @@ static int run_nms_obb(const void* pred, int dtype, int64_t bs, int64_t A, int64
   a.max_keep = (int)max_det; a.window = nms_window(max_det); a.thr = iou_thres; a.cull = (iou_thres >= 0.f) ? 1 : 0;
   {
     ProfScope ps(PROF_STEPS, st);
-    rc = nms_steps(0, a, nv, bs * ncs, bs * max_seg, st);
+    rc = nms_steps(0, a, nv, bs * ncs, bs * max_seg, st, kNmsBarZeroed | ((lds_sort && plan_nb > 0) ? kNmsPlanned : 0));
     if (rc) return rc;
   }
   {
     ProfScope ps(PROF_GATHER, st);
     k_gather_out<<<(unsigned)bs, 256, 0, st>>>(cv.cand, cv.vals_b, cv.keys_b, cv.keep, nv.seg_begin, nv.keep_cnt, cv.mode, ncs, max_det,
-                                              out, out_count, cv.cnt, cap_img, status, nv.abort_flag);
+                                              out, out_count, cv.cnt, cap_img, status, nv.abort_flag, out_packed);
   }
   return hipGetLastError() == hipSuccess ? OBB_OK : OBB_ERR_LAUNCH;
 }

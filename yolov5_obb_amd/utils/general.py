@@ -16,6 +16,8 @@ _MAX_NMS = 30000    # utils/general.py:794
 _CSL = 180          # utils/general.py:784
 _cap_memo = {}      # (A, nc, multi_label) -> candidate slots per image that sufficed last time
 _cand_memo = {}     # same key -> largest candidate count of an image in the previous call (sort-algorithm hint)
+_SORT_LDS_HINT = 6144   # include/obb_hip.h OBB_NMS_SORT_LDS_HINT: hints up to this select the one-workgroup-per-image sort ...
+_SORT_LDS_MAX = 8192    # ... OBB_NMS_SORT_LDS_MAX: which takes at most this many candidates of an image
 
 
 def _label_rows(labels, bs, nc, device):
@@ -88,15 +90,16 @@ def non_max_suppression_obb(prediction, conf_thres=0.25, iou_thres=0.45, classes
     cap = min(worst, max(_cap_memo.get(key, 0), 65536))
     L = _lib.lib()
     max_det = int(max_det)
-    out = torch.empty((bs, max_det, 7), dtype=torch.float32, device=dev)
+    out = torch.empty((bs * max_det, 7), dtype=torch.float32, device=dev)   # packed: image b's rows follow image b-1's
     meta = torch.empty(bs + 2, dtype=torch.int64, device=dev)        # counts[bs] + status[2]
     while True:
+        hint = int(_cand_memo.get(key, 0))
         with torch.cuda.device(dev):
             ws = _lib.workspace(L.obb_nms_obb_workspace_bytes(bs, cap, nc, int(bool(agnostic))), dev)
             rc = L.obb_non_max_suppression_obb(
                 _lib.ptr(pred), dtype, bs, A, no, float(conf_thres), float(iou_thres),
                 C.cast(cls_arr, C.c_void_p) if cls_arr is not None else C.c_void_p(0), n_cls, int(bool(agnostic)), int(multi),
-                max_det, _MAX_NMS, float(_MAX_WH), _lib.ptr(extra), n_extra, cap, int(_cand_memo.get(key, 0)), _lib.ptr(out), _lib.ptr(meta),
+                max_det, _MAX_NMS, float(_MAX_WH), _lib.ptr(extra), n_extra, cap, hint, _lib.ptr(out), 1, _lib.ptr(meta),
                 C.c_void_p(meta.data_ptr() + 8 * bs), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev))
         _lib.check(rc, "obb_non_max_suppression_obb")
         m = meta.tolist()                                             # the single device->host sync of the call
@@ -105,7 +108,11 @@ def non_max_suppression_obb(prediction, conf_thres=0.25, iou_thres=0.45, classes
         if m[bs] > cap:                                               # an image produced more candidates than slots
             cap = min(worst, max(int(m[bs]), 2 * cap))
             continue
+        if 0 < hint <= _SORT_LDS_HINT and m[bs + 1] > _SORT_LDS_MAX:  # the hint undersold this batch: such images were left out
+            _cand_memo[key] = int(m[bs + 1])
+            continue
         break
     _cap_memo[key] = cap
     _cand_memo[key] = int(m[bs + 1])
-    return [out[b, :m[b]] for b in range(bs)]
+    counts = m[:bs]
+    return list(out.narrow(0, 0, sum(counts)).split_with_sizes(counts))     # one call instead of bs slicing ops
