@@ -97,6 +97,30 @@ def stream_ptr(device):
     return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
+def stream_handle(device):
+    """Raw hipStream_t of the current stream (an int): look it up once per call, it costs a few microseconds."""
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+class _NoGuard:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NO_GUARD = _NoGuard()
+
+
+def guard(device):
+    """`with torch.cuda.device(device)` only when the device is not already current (the context manager itself costs
+    several microseconds per call, comparable to a kernel launch)."""
+    if device.index is None or device.index == torch.cuda.current_device():
+        return _NO_GUARD
+    return torch.cuda.device(device)
+
+
 def ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
 
@@ -113,10 +137,11 @@ def require_cuda(t, name):
 _ws_cache = {}
 
 
-def workspace(nbytes, device):
-    """A reusable scratch buffer per (device, stream); grown geometrically, never shrunk."""
+def workspace(nbytes, device, stream=None):
+    """A reusable scratch buffer per (device, stream); grown geometrically, never shrunk.  `stream`: the raw handle when the
+    caller has looked it up already."""
     key = (device.index if device.index is not None else torch.cuda.current_device(),
-           torch.cuda.current_stream(device).cuda_stream)
+           stream if stream is not None else torch.cuda.current_stream(device).cuda_stream)
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
         size = max(int(nbytes), 1 << 20)

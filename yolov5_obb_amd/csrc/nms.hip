@@ -79,9 +79,13 @@ __global__ void k_make_keys(const float* __restrict__ scores, int score_stride, 
 }
 
 // single list, no explicit tie word: 32-bit keys (half the sort traffic, half the radix passes)
+// (also: the single segment's table and the zeroing of the team-barrier block -- two launches fewer)
 __global__ void k_make_keys32(const float* __restrict__ scores, int score_stride, const float* __restrict__ dets5, int drop_small,
-                              int n, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+                              int n, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, int* seg_begin, int* seg_end,
+                              int* keep_cnt, uint4* __restrict__ bar16, long long n_bar16) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0) { seg_begin[0] = 0; seg_end[0] = n; keep_cnt[0] = 0; }
+  for (long long k = i; k < n_bar16; k += (long long)gridDim.x * blockDim.x) bar16[k] = make_uint4(0u, 0u, 0u, 0u);
   if (i >= n) return;
   uint32_t k = score_desc_key(scores[(size_t)i * score_stride]);
   if (drop_small) {
@@ -91,10 +95,6 @@ __global__ void k_make_keys32(const float* __restrict__ scores, int score_stride
   }
   keys[i] = k;
   vals[i] = (uint32_t)i;
-}
-
-__global__ void k_seg_single(int n, int* seg_begin, int* seg_end, int* keep_cnt) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) { seg_begin[0] = 0; seg_end[0] = n; keep_cnt[0] = 0; }
 }
 
 __device__ __forceinline__ int key_lower_bound(const uint64_t* keys, int n, uint64_t target) {
@@ -137,6 +137,7 @@ __global__ void k_prep_rot(const float* __restrict__ dets5, const uint32_t* __re
   }
   const u64 m = __ballot(ok);
   if ((threadIdx.x & 63) == 0 && (p & ~63) < n) alive[p >> 6] = m;
+  if (p < 8) alive[((n + 63) >> 6) + p] = 0ull;      // guard words behind the last box (the bitmap is not memset)
 }
 
 __global__ void k_prep_quad(const float* __restrict__ polys, int stride, const uint32_t* __restrict__ order, int n,
@@ -149,6 +150,7 @@ __global__ void k_prep_quad(const float* __restrict__ polys, int stride, const u
   }
   const u64 m = __ballot(p < n);
   if ((threadIdx.x & 63) == 0 && (p & ~63) < n) alive[p >> 6] = m;
+  if (p < 8) alive[((n + 63) >> 6) + p] = 0ull;      // guard words behind the last box (the bitmap is not memset)
 }
 
 // merge NMS (QuadGeom64): rows arrive as (n, 9) doubles, `order` lists the row indices in processing order, segment by
@@ -173,6 +175,7 @@ __global__ void k_prep_quad64(const double* __restrict__ dets9, const int32_t* _
   }
   const u64 m = __ballot(p < n);
   if ((threadIdx.x & 63) == 0 && (p & ~63) < n) alive[p >> 6] = m;
+  if (p < 8) alive[((n + 63) >> 6) + p] = 0ull;      // guard words behind the last box (the bitmap is not memset)
 }
 
 __global__ void k_seg_from_offsets(const int32_t* __restrict__ seg_off, int nseg, int* seg_begin, int* seg_end, int* keep_cnt) {
@@ -271,7 +274,7 @@ static int carve(void* base, int64_t n, int64_t nseg, int recq, int C, Carve* cv
   if (sort_tmp_query(nn, &cv->sort_tmp_bytes) != hipSuccess) return OBB_ERR_INTERNAL;
   cv->sort_tmp = take(cv->sort_tmp_bytes ? cv->sort_tmp_bytes : 16);
   cv->rec = (float4*)take(nn * recq * 16);
-  cv->alive_bytes = (nn / 64 + 8) * 8;
+  cv->alive_bytes = (nn / 64 + 10) * 8;      // + guard words (zeroed by the prep kernels)
   cv->alive = (u64*)take(cv->alive_bytes);
   cv->bar_bytes = ((size_t)kMaxTeams * 128 + 64 + 2 * (size_t)kMaxTeams) * 4;
   cv->bar = (int*)take(cv->bar_bytes);
@@ -396,6 +399,7 @@ static int run_nms(int kind, const float* boxes, int stride, const float* scores
   }
 
   const unsigned gb = (unsigned)((n + T - 1) / T);
+  int pre = 0;
   {
     ProfScope ps(PROF_NMS_SORT, st);
     size_t tmp = cv.sort_tmp_bytes;
@@ -403,10 +407,11 @@ static int run_nms(int kind, const float* boxes, int stride, const float* scores
       uint32_t* k32a = reinterpret_cast<uint32_t*>(cv.keys_a);
       uint32_t* k32b = reinterpret_cast<uint32_t*>(cv.keys_b);
       k_make_keys32<<<gb, T, 0, st>>>(scores, score_stride, kind == 0 ? boxes : nullptr, kind == 0 ? drop_small : 0, (int)n, k32a,
-                                      cv.vals_a);
+                                      cv.vals_a, cv.seg_begin, cv.seg_end, cv.keep_cnt, reinterpret_cast<uint4*>(cv.bar),
+                                      (long long)(cv.bar_bytes / 16));
+      pre = kNmsBarZeroed;
       if (rocprim::radix_sort_pairs(cv.sort_tmp, tmp, k32a, k32b, cv.vals_a, cv.vals_b, (size_t)n, 0, 32, st, false) != hipSuccess)
         return OBB_ERR_LAUNCH;
-      k_seg_single<<<1, 64, 0, st>>>((int)n, cv.seg_begin, cv.seg_end, cv.keep_cnt);
     } else {
       k_make_keys<<<gb, T, 0, st>>>(scores, score_stride, seg_id, tie, tie_bits, kind == 0 ? boxes : nullptr,
                                     kind == 0 ? drop_small : 0, (int)n, cv.keys_a, cv.vals_a);
@@ -418,7 +423,6 @@ static int run_nms(int kind, const float* boxes, int stride, const float* scores
   }
   {
     ProfScope ps(PROF_NMS_PREP, st);
-    hipMemsetAsync(cv.alive, 0, cv.alive_bytes, st);
     if (kind == 0) k_prep_rot<<<gb, T, 0, st>>>(boxes, cv.vals_b, drop_small, (int)n, cv.rec, cv.alive);
     else k_prep_quad<<<gb, T, 0, st>>>(boxes, stride, cv.vals_b, (int)n, cv.rec, cv.alive);
   }
@@ -436,7 +440,7 @@ static int run_nms(int kind, const float* boxes, int stride, const float* scores
   (void)max_seg;   // the step loop is device-driven now: no host-side bound on the segment size is needed
   {
     ProfScope ps(PROF_NMS_STEPS, st);
-    rc = nms_steps(kind, a, cv, nseg, n, st);
+    rc = nms_steps(kind, a, cv, nseg, n, st, pre);
     if (rc) return rc;
   }
   k_finalize<<<gseg, T, 0, st>>>(cv.keep_cnt, cv.seg_begin, (int)nseg, max_keep, cv.abort_flag, num_keep, seg_begin_out);
@@ -464,7 +468,6 @@ static int run_merge_nms(const double* dets9, int64_t n, const int32_t* order, c
     k_finalize<<<gseg, T, 0, st>>>(cv.keep_cnt, cv.seg_begin, (int)nseg, 0, nullptr, num_keep, nullptr);
     return hipGetLastError() == hipSuccess ? OBB_OK : OBB_ERR_LAUNCH;
   }
-  hipMemsetAsync(cv.alive, 0, cv.alive_bytes, st);
   k_prep_quad64<<<(unsigned)((n + T - 1) / T), T, 0, st>>>(dets9, order, (int)n, cv.rec, cv.alive);
   NmsArgs a;
   a.rec = cv.rec; a.order = reinterpret_cast<const uint32_t*>(order); a.alive = cv.alive;

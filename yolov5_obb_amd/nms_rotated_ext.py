@@ -9,6 +9,7 @@ import torch
 from . import _lib
 
 __all__ = ["nms_rotated", "nms_poly"]
+_ws_bytes = {}      # n -> obb_nms_workspace_bytes(n, 1, 0)
 
 
 def _run_rotated(dets, scores, iou_threshold, flags=0, max_keep=0):
@@ -17,11 +18,16 @@ def _run_rotated(dets, scores, iou_threshold, flags=0, max_keep=0):
     dev = dets.device
     keep = torch.empty(n, dtype=torch.int64, device=dev)
     cnt = torch.empty(1, dtype=torch.int64, device=dev)
-    with torch.cuda.device(dev):
-        nbytes = L.obb_nms_workspace_bytes(n, 1, 0)
-        ws = _lib.workspace(nbytes, dev)
+    with _lib.guard(dev):
+        st = _lib.stream_handle(dev)
+        nbytes = _ws_bytes.get(n)
+        if nbytes is None:
+            if len(_ws_bytes) > 4096:
+                _ws_bytes.clear()
+            nbytes = _ws_bytes[n] = L.obb_nms_workspace_bytes(n, 1, 0)
+        ws = _lib.workspace(nbytes, dev, st)
         rc = L.obb_nms_rotated_f32(_lib.ptr(dets), _lib.ptr(scores), n, float(iou_threshold), int(flags), int(max_keep),
-                                   _lib.ptr(keep), _lib.ptr(cnt), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev))
+                                   _lib.ptr(keep), _lib.ptr(cnt), _lib.ptr(ws), ws.numel(), _lib.C.c_void_p(st))
     _lib.check(rc, "obb_nms_rotated_f32")
     return keep[: _lib.checked_count(int(cnt.item()), "obb_nms_rotated_f32")]
 

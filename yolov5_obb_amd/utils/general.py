@@ -15,6 +15,7 @@ _MAX_WH = 4096      # utils/general.py:793
 _MAX_NMS = 30000    # utils/general.py:794
 _CSL = 180          # utils/general.py:784
 _cap_memo = {}      # (A, nc, multi_label) -> candidate slots per image that sufficed last time
+_ws_memo = {}       # (bs, cap, nc, agnostic) -> workspace bytes (a ctypes call saved per batch)
 _cand_memo = {}     # same key -> largest candidate count of an image in the previous call (sort-algorithm hint)
 _SORT_LDS_HINT = 6144   # include/obb_hip.h OBB_NMS_SORT_LDS_HINT: hints up to this select the one-workgroup-per-image sort ...
 _SORT_LDS_MAX = 8192    # ... OBB_NMS_SORT_LDS_MAX: which takes at most this many candidates of an image
@@ -92,15 +93,21 @@ def non_max_suppression_obb(prediction, conf_thres=0.25, iou_thres=0.45, classes
     max_det = int(max_det)
     out = torch.empty((bs * max_det, 7), dtype=torch.float32, device=dev)   # packed: image b's rows follow image b-1's
     meta = torch.empty(bs + 2, dtype=torch.int64, device=dev)        # counts[bs] + status[2]
+    agn = int(bool(agnostic))
     while True:
         hint = int(_cand_memo.get(key, 0))
-        with torch.cuda.device(dev):
-            ws = _lib.workspace(L.obb_nms_obb_workspace_bytes(bs, cap, nc, int(bool(agnostic))), dev)
+        with _lib.guard(dev):
+            st = _lib.stream_handle(dev)
+            wkey = (bs, cap, nc, agn)
+            nbytes = _ws_memo.get(wkey)
+            if nbytes is None:
+                nbytes = _ws_memo[wkey] = L.obb_nms_obb_workspace_bytes(bs, cap, nc, agn)
+            ws = _lib.workspace(nbytes, dev, st)
             rc = L.obb_non_max_suppression_obb(
                 _lib.ptr(pred), dtype, bs, A, no, float(conf_thres), float(iou_thres),
-                C.cast(cls_arr, C.c_void_p) if cls_arr is not None else C.c_void_p(0), n_cls, int(bool(agnostic)), int(multi),
+                C.cast(cls_arr, C.c_void_p) if cls_arr is not None else C.c_void_p(0), n_cls, agn, int(multi),
                 max_det, _MAX_NMS, float(_MAX_WH), _lib.ptr(extra), n_extra, cap, hint, _lib.ptr(out), 1, _lib.ptr(meta),
-                C.c_void_p(meta.data_ptr() + 8 * bs), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev))
+                C.c_void_p(meta.data_ptr() + 8 * bs), _lib.ptr(ws), ws.numel(), C.c_void_p(st))
         _lib.check(rc, "obb_non_max_suppression_obb")
         m = meta.tolist()                                             # the single device->host sync of the call
         for b in range(bs):
