@@ -53,6 +53,93 @@ def collect_profile(L, nst=8):
     return list(ms), list(cnt)
 
 
+def bench_next_rows(dev, dets_per_image):
+    """Timings of the rows SURVEY 8(f) ranks behind the hot path, on synthetic inputs of realistic size; the CPU side is the
+    oracle restatement of the reference (numpy + the C port of polyiou.cpp) on a bounded sample."""
+    import tempfile
+    import numpy as np
+    import oracle
+    from oracle import pyref
+    from tests.golden import gen_golden as gg
+    from yolov5_obb_amd import val as V
+    from yolov5_obb_amd.DOTA_devkit import ResultMerge_multi_process as RM
+    from yolov5_obb_amd.DOTA_devkit import dota_evaluation_task1 as EV
+    oracle.build(with_ref=False)
+    res = {}
+
+    def wall(fn, reps):
+        fn(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps * 1e3
+    # ---- val.py:226-250 per image: rbox2poly/poly2hbb/xywh2xyxy/scale_polys + process_batch (the bench step's own detections)
+    iouv = torch.linspace(0.5, 0.95, 10, device=dev)
+    g = torch.Generator().manual_seed(0)
+    labels = []
+    for d in dets_per_image:
+        k = max(1, d.shape[0] // 2)
+        src = d[torch.randperm(d.shape[0], generator=g)[:k].to(dev)]
+        hbb = V.val_postprocess(src, ratio_pad=((1.0, 1.0), (0.0, 0.0)))[1]
+        labels.append(torch.cat((hbb[:, 5:6], hbb[:, :4] + 2.0), 1).contiguous())
+
+    def tail():
+        for d, lb in zip(dets_per_image, labels):
+            poly, hbb, polyn, hbbn = V.val_postprocess(d, ratio_pad=((0.7314, 0.7314), (12.0, 3.5)))
+            V.process_batch(hbbn, lb, iouv)
+    ms = wall(tail, 20)
+    d0, l0 = dets_per_image[0].cpu(), labels[0].cpu()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        pp = pyref.val_postprocess(d0.clone(), 0.7314, (12.0, 3.5))
+        pyref.process_batch(pp[3], l0, iouv.cpu())
+    cms = (time.perf_counter() - t0) / 5 * 1e3
+    res["val_tail"] = {"workload": f"{len(dets_per_image)} images x ~{int(dets_per_image[0].shape[0])} detections: val_postprocess + process_batch",
+                       "ms_per_batch": round(ms, 3), "ms_per_image": round(ms / len(dets_per_image), 4),
+                       "cpu_port_ms_per_image": round(cms, 3)}
+    # ---- ResultMerge: one class file of 300 source images (tiles 1024/824, two rates)
+    lines = gg.merge_input_lines(300, 40, 7, False)
+    with tempfile.TemporaryDirectory() as td:
+        src = os.path.join(td, "Task1_plane.txt")
+        with open(src, "w") as f:
+            f.write("\n".join(lines) + "\n")
+        boxes = RM.parse_result_file(src)
+        names = list(boxes)
+        arrs = [np.asarray(boxes[k], dtype=np.float64) for k in names]
+        base = np.cumsum([0] + [len(a) for a in arrs])
+        orders = [a[:, 8].argsort()[::-1] + base[i] for i, a in enumerate(arrs)]
+        allb = np.concatenate(arrs)
+        ms_dev = wall(lambda: RM.merge_nms_segments(allb, orders, 0.2), 10)
+        dst = os.path.join(td, "merged")
+        os.makedirs(dst)
+        ms_file = wall(lambda: RM.mergesingle(dst, RM.py_cpu_nms_poly_fast, src) and None, 3)
+    sub = [ln for ln in lines if int(ln[1:5]) < 12]
+    t0 = time.perf_counter()
+    pyref.merge_result_lines(sub)
+    cms = (time.perf_counter() - t0) * 1e3
+    res["result_merge"] = {"workload": f"Task1_<class>.txt with {len(lines)} tile detections of 300 source images -> merged file (poly NMS 0.2, double)",
+                           "ms_device_call_incl_copies": round(ms_dev, 3), "ms_whole_file_incl_text": round(ms_file, 2),
+                           "cpu_port_ms": round(cms * len(lines) / max(1, len(sub)), 1),
+                           "cpu_sample": f"{len(sub)} lines (12 images) through oracle.pyref.merge_result_lines, scaled by line count"}
+    # ---- Task-1 evaluation: one class, 200 images
+    gt, det = gg.eval_inputs(200, 60, 5)
+    with tempfile.TemporaryDirectory() as td:
+        detpath, annopath, imagesetfile = gg.eval_write(td, gt, det)
+        ms_eval = wall(lambda: EV.voc_eval(detpath, annopath, imagesetfile, "plane", 0.5, True) and None, 3)
+        parsed = {k: EV.parse_gt(annopath.format(k)) for k in list(gt)[:10]}
+    names10 = list(parsed)
+    det10 = [ln for ln in det["plane"] if ln.split(" ")[0] in parsed]
+    t0 = time.perf_counter()
+    pyref.task1_voc_eval(parsed, names10, det10, "plane", 0.5, True)
+    cms = (time.perf_counter() - t0) * 1e3
+    res["task1_eval"] = {"workload": f"voc_eval of one class: {len(det['plane'])} detections, 200 images x ~60 ground-truth quads",
+                         "ms_whole_incl_text": round(ms_eval, 2),
+                         "cpu_port_ms": round(cms * len(det["plane"]) / max(1, len(det10)), 1),
+                         "cpu_sample": f"{len(det10)} detections (10 images) through oracle.pyref.task1_voc_eval, scaled by detection count"}
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -222,6 +309,15 @@ def main():
         except Exception as e:                                  # secondary figures never fail the bench
             loss_obj = loss_obj or {"error": str(e)}
 
+    # ---------------- SURVEY 8(f) rows behind the NMS (rank 0, N=1 only; not part of `value`): val.py tail, tile->image merge,
+    # Task-1 evaluation -- GPU time of the mirrored call, the oracle port of the reference on a bounded sample beside it
+    next_rows = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        try:
+            next_rows = bench_next_rows(dev, out)
+        except Exception as e:
+            next_rows = {"error": str(e)}
+
     # ---------------- CPU baseline (rank 0, N=1 only): the oracle port of the reference CPU path, bounded sample
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -289,7 +385,7 @@ def main():
                     "note": "kernel time from the rocprofv3 kernel trace in profiles/ (the bench times ComputeLoss fwd+bwd as a whole)"},
             },
             "nms_100k": nms_obj,
-            "loss": loss_obj, "detect": detect_obj,
+            "loss": loss_obj, "detect": detect_obj, "next_rows": next_rows,
             "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)

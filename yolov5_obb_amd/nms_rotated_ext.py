@@ -73,7 +73,7 @@ def nms_poly(dets, iou_threshold):
     dev = dets.device
     keep = torch.empty(n, dtype=torch.int64, device=dev)
     cnt = torch.empty(1, dtype=torch.int64, device=dev)
-    with torch.cuda.device(dev):
+    with _lib.guard(dev):
         ws = _lib.workspace(L.obb_nms_workspace_bytes(n, 1, 1), dev)
         rc = L.obb_nms_poly_f32(_lib.ptr(dets), stride, n, float(iou_threshold), 0, _lib.ptr(keep), _lib.ptr(cnt),
                                 _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev))

@@ -61,7 +61,7 @@ class _ObbLossFn(torch.autograd.Function):
         nt, tcols = int(tg.shape[0]), int(tg.shape[1]) if tg.dim() == 2 else 0
         L = _lib.lib()
         out = torch.empty(5 + _MAX_LV, dtype=torch.float32, device=dev)
-        with torch.cuda.device(dev):
+        with _lib.guard(dev):
             nbytes = L.obb_loss_workspace_bytes(C.byref(cfg), nt)
             if nbytes == 0:
                 raise RuntimeError("ComputeLoss: unsupported head configuration (see obb_loss_config in include/obb_hip.h)")
@@ -81,7 +81,7 @@ class _ObbLossFn(torch.autograd.Function):
         grads = [torch.empty_like(pi) for pi in ps]
         gscale = gloss.reshape(-1)[:1].to(torch.float32).contiguous()
         L = _lib.lib()
-        with torch.cuda.device(dev):
+        with _lib.guard(dev):
             rc = L.obb_loss_backward(C.byref(ctx.cfg), _ptr_array(ps), ctx.code, _lib.ptr(tg), int(tg.shape[0]),
                                      int(tg.shape[1]) if tg.dim() == 2 else 0, _lib.ptr(gscale), _ptr_array(grads),
                                      _lib.ptr(ctx.ws), ctx.ws.numel(), _lib.stream_ptr(dev))
@@ -175,7 +175,7 @@ class ComputeLoss:
         L = _lib.lib()
         counts = torch.zeros(_MAX_LV + 1, dtype=torch.int32, device=dev)
         tcls, tbox, indices, anch, tgt = [], [], [], [], []
-        with torch.cuda.device(dev):
+        with _lib.guard(dev):
             ws = torch.empty(L.obb_loss_workspace_bytes(C.byref(cfg), nt), dtype=torch.uint8, device=dev)
             if nt:
                 _lib.check(L.obb_loss_build_targets(C.byref(cfg), _lib.ptr(tg), nt, tcols, _lib.ptr(counts), _lib.ptr(ws),

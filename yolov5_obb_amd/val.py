@@ -26,7 +26,7 @@ def val_postprocess(pred, ratio_pad=None, img1_shape=None, img0_shape=None):
     hbb = torch.empty((n, 6), dtype=torch.float32, device=dev)
     polyn = torch.empty((n, 10), dtype=torch.float32, device=dev)
     hbbn = torch.empty((n, 6), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
+    with _lib.guard(dev):
         rc = _lib.lib().obb_val_postprocess_f32(_lib.ptr(p), n, float(pad[0]), float(pad[1]), float(gain), _lib.ptr(poly), _lib.ptr(hbb),
                                                 _lib.ptr(polyn), _lib.ptr(hbbn), _lib.stream_ptr(dev))
     _lib.check(rc, "obb_val_postprocess_f32")
@@ -51,7 +51,7 @@ def process_batch(detections, labels, iouv):
     if n == 0:
         return correct
     L = _lib.lib()
-    with torch.cuda.device(dev):
+    with _lib.guard(dev):
         ws = torch.empty(L.obb_process_batch_workspace_bytes(n, m), dtype=torch.uint8, device=dev)
         out = correct.view(torch.uint8)
         rc = L.obb_process_batch_f32(_lib.ptr(det), n, _lib.ptr(lab) if m else 0, m, _lib.ptr(iv), niou, _lib.ptr(out), _lib.ptr(ws),
