@@ -17,6 +17,7 @@ int main(int argc, char** argv) {
   std::normal_distribution<float> N(0.f, 1.f);
   const float thrs[6] = {0.0f, 0.1f, 0.2f, 0.4f, 0.45f, 0.6f};
   long viol = 0, vouched[8] = {0}, tot[8] = {0}, decided[8][6] = {{0}};
+  long qviol = 0, qvouch[8] = {0}, qdec[8][6] = {{0}};
   for (long i = 0; i < n; i++) {
     const int mode = (int)(i % 8);
     float a[5], b[5];
@@ -36,6 +37,19 @@ int main(int argc, char** argv) {
     obb::RBoxFeat A = obb::rbox_make_feat(a[0], a[1], a[2], a[3], a[4]);
     obb::RBoxFeat B = obb::rbox_make_feat(b[0], b[1], b[2], b[3], b[4]);
     tot[mode]++;
+    {   // the cheap lower bound in front of the interval filter: never above the oracle when it vouches
+      const float qlb = obb::rbox_quick_lower_bound(A, B);
+      if (qlb >= 0.f) {
+        const float refq = oracle_riou_f32(a, b);
+        qvouch[mode]++;
+        if (!(qlb <= refq)) {
+          if (qviol < 10) printf("QUICK-LB VIOLATION mode %d ref %.9g lb %.9g  a=(%g %g %g %g %g) b=(%g %g %g %g %g)\n", mode, refq, qlb, a[0], a[1],
+                                 a[2], a[3], a[4], b[0], b[1], b[2], b[3], b[4]);
+          qviol++;
+        }
+        for (int q = 0; q < 6; q++) if (qlb > thrs[q]) qdec[mode][q]++;
+      }
+    }
     obb::IouBounds bd;
     if (!obb::rbox_fast_iou_bounds(A, B, &bd)) continue;
     vouched[mode]++;
@@ -52,6 +66,11 @@ int main(int argc, char** argv) {
     printf("mode %-17s pairs %8ld vouched %5.1f%%  decided@0/.1/.2/.4/.45/.6 = %5.1f %5.1f %5.1f %5.1f %5.1f %5.1f %% of all pairs\n", names[m],
            tot[m], 100.0 * vouched[m] / tot[m], 100.0 * decided[m][0] / tot[m], 100.0 * decided[m][1] / tot[m], 100.0 * decided[m][2] / tot[m],
            100.0 * decided[m][3] / tot[m], 100.0 * decided[m][4] / tot[m], 100.0 * decided[m][5] / tot[m]);
+  for (int m = 0; m < 8; m++)
+    printf("quick lower bound, mode %-17s vouched %5.1f%%  accepts (lb > thr)@0/.1/.2/.4/.45/.6 = %5.1f %5.1f %5.1f %5.1f %5.1f %5.1f %% of all pairs\n",
+           names[m], 100.0 * qvouch[m] / tot[m], 100.0 * qdec[m][0] / tot[m], 100.0 * qdec[m][1] / tot[m], 100.0 * qdec[m][2] / tot[m],
+           100.0 * qdec[m][3] / tot[m], 100.0 * qdec[m][4] / tot[m], 100.0 * qdec[m][5] / tot[m]);
+  printf("quick_lb_violations=%ld\n", qviol);
   printf("violations=%ld n=%ld\n", viol, n);
-  return viol ? 1 : 0;
+  return (viol || qviol) ? 1 : 0;
 }

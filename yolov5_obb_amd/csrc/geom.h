@@ -44,18 +44,28 @@ struct RotGeom {
     return (d2 > rs * rs) && (fminf(a.w, b.w) >= 2.34e-9f * d2);
   }
   // Two-stage decision of "IoU > thr" for the pairs that survive the hot loop.
-  //   classify  registers only: separating-axis reject, area-ratio bound, then the IoU interval of
-  //             rbox_fast_iou_bounds -- answers 0 (no) / 1 (yes) whenever the whole interval lies on one side of the
-  //             threshold, 2 = undecided (a few % of the pairs);
+  //   classify_quick  registers only: separating-axis reject, area-ratio bound, the slab lower bound for near-duplicates
+  //             (rbox_quick_lower_bound) -- decides most pairs of a detector's output;
+  //   classify_full   the IoU interval of rbox_fast_iou_bounds for the rest -- 0 (no) / 1 (yes) whenever the whole interval
+  //             lies on one side of the threshold, 2 = undecided (a few % of the pairs).  The two run as separate queue
+  //             stages so that a wave never executes the expensive one for a handful of lanes;
   //   hit_exact the reference's clip + Graham scan, bit for bit, on the LDS scratch column of the lane.
   static constexpr bool HAS_FAST = true;
   template <class A> static __device__ __forceinline__ float thr_of(const A& a) { return a.thr; }
-  static __device__ __forceinline__ int classify(const float4* ra, const float4* rb, float thr, bool cull) {
+  // stage 1a (cheap, ~150 flops): 0 / 1 = decided, 2 = straight to the exact clip (no shortcuts allowed), 3 = needs the interval
+  static __device__ __forceinline__ int classify_quick(const float4* ra, const float4* rb, float thr, bool cull) {
     if (!cull) return 2;
     RBoxFeat A = unpack(ra[0], ra[1], ra[2], ra[3]);
     RBoxFeat B = unpack(rb[0], rb[1], rb[2], rb[3]);
     if (rbox_certainly_disjoint(A, B)) return 0;
     if (rbox_iou_upper_bound(A, B) <= thr) return 0;
+    if (rbox_quick_lower_bound(A, B) > thr) return 1;      // near-duplicates, the bulk of a detector's pairs
+    return 3;
+  }
+  // stage 1b (~1500 instructions): the IoU interval; 2 = undecided
+  static __device__ __forceinline__ int classify_full(const float4* ra, const float4* rb, float thr) {
+    RBoxFeat A = unpack(ra[0], ra[1], ra[2], ra[3]);
+    RBoxFeat B = unpack(rb[0], rb[1], rb[2], rb[3]);
     IouBounds bd;
     if (rbox_fast_iou_bounds(A, B, &bd)) {
       if (bd.lo > thr) return 1;
@@ -90,7 +100,8 @@ struct QuadGeom {
   }
   static constexpr bool HAS_FAST = false;      // every pair is undecided: the reference's value is not predictable (see above)
   template <class A> static __device__ __forceinline__ float thr_of(const A& a) { return a.thr; }
-  static __device__ __forceinline__ int classify(const float4*, const float4*, float, bool) { return 2; }
+  static __device__ __forceinline__ int classify_quick(const float4*, const float4*, float, bool) { return 2; }
+  static __device__ __forceinline__ int classify_full(const float4*, const float4*, float) { return 2; }
   static __device__ __forceinline__ bool hit_exact(const float4* ra, const float4* rb, float thr, float* scr) {
     return iou(unpack(ra[0], ra[1]), unpack(rb[0], rb[1]), scr) > thr;
   }
@@ -110,7 +121,8 @@ struct QuadGeom64 {
   static __device__ __forceinline__ bool cheap_reject(const float4& a, const float4& b) {
     return !(fminf(a.z, b.z) > fmaxf(a.x, b.x) && fminf(a.w, b.w) > fmaxf(a.y, b.y));
   }
-  static __device__ __forceinline__ int classify(const float4*, const float4*, double, bool) { return 2; }
+  static __device__ __forceinline__ int classify_quick(const float4*, const float4*, double, bool) { return 2; }
+  static __device__ __forceinline__ int classify_full(const float4*, const float4*, double) { return 2; }
   static __device__ __forceinline__ void hbb(const QuadFeatT<double>& f, double* x1, double* y1, double* x2, double* y2) {
     *x1 = fmin(fmin(f.x[0], f.x[1]), fmin(f.x[2], f.x[3])); *x2 = fmax(fmax(f.x[0], f.x[1]), fmax(f.x[2], f.x[3]));
     *y1 = fmin(fmin(f.y[0], f.y[1]), fmin(f.y[2], f.y[3])); *y2 = fmax(fmax(f.y[0], f.y[1]), fmax(f.y[2], f.y[3]));

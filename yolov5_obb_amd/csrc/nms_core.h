@@ -162,7 +162,9 @@ struct WaveLds {
   uint32_t rowpos[64], colpos[64];
   float scr[G::SCR * 64];
   uint32_t qbuf[128];      // stage 1: pairs that passed the hot loop
+  uint32_t qbuf1b[128];    // stage 1b: pairs the cheap tests could not decide (IoU interval)
   uint32_t qbuf2[128];     // stage 2: pairs the register-only classifier could not decide (exact clip)
+  uint8_t q1bcol[128];     // cross phase: column lane of a stage-1b entry
   uint8_t q2col[128];      // cross phase: column lane of a stage-2 entry
   uint8_t cdead[64];
   uint8_t pad[64];
@@ -236,7 +238,19 @@ __device__ __forceinline__ void nms_pairs(const NmsArgs& a, int tm, int cn, cons
   const int items = nb * nb;
   uint32_t* edges = a.edges + (size_t)tm * a.ecap;
   const bool cull = a.cull != 0;
-  PairQueue Q{L.qbuf, 0, 0}, Q2{L.qbuf2, 0, 0};
+  PairQueue Q{L.qbuf, 0, 0}, Q1{L.qbuf1b, 0, 0}, Q2{L.qbuf2, 0, 0};
+  auto emit = [&](bool hit, uint32_t packed) {           // hits -> the segment's edge list
+    const u64 hm = __ballot(hit);
+    if (hm) {
+      int base = 0;
+      if (lane == 0) base = atomicAdd(&a.nedges[tm], __popcll(hm));
+      base = __shfl(base, 0);
+      if (hit) {
+        const long long pos = (long long)base + __popcll(hm & lanemask_lt());
+        if (pos < a.ecap) stg_agent(edges + pos, packed);
+      }
+    }
+  };
   // stage 2: exact clip; entries are chunk-local (i << 16 | j), so the queue lives across tiles
   auto drain2 = [&](int cnt) {
     wave_sync();
@@ -261,6 +275,23 @@ __device__ __forceinline__ void nms_pairs(const NmsArgs& a, int tm, int cn, cons
     Q2.count -= cnt;
     wave_sync();
   };
+  // stage 1b: the IoU interval, on full waves only (entries chunk-local like stage 2)
+  auto drain1b = [&](int cnt) {
+    wave_sync();
+    int res = 0;
+    uint32_t packed = 0;
+    if (lane < cnt) {
+      packed = L.qbuf1b[(Q1.head + lane) & 127];
+      const uint32_t pi = cidx[packed >> 16], pj = cidx[packed & 0xffff];
+      res = G::classify_full(a.rec + (size_t)pi * G::RECQ, a.rec + (size_t)pj * G::RECQ, G::thr_of(a));
+    }
+    emit(res == 1, packed);
+    Q1.head = (Q1.head + cnt) & 127;
+    Q1.count -= cnt;
+    Q2.push(res == 2, packed);
+    wave_sync();
+    if (Q2.count >= 64) drain2(64);
+  };
 
   // small chunks: split every 64-row tile into 2 or 4 row slices so that all waves of the team have work
   const int tri = nb * (nb + 1) / 2;
@@ -283,33 +314,23 @@ __device__ __forceinline__ void nms_pairs(const NmsArgs& a, int tm, int cn, cons
     const bool diag = rb == cb;
     wave_sync();
 
-    auto emit = [&](bool hit, uint32_t packed) {           // hits -> the segment's edge list
-      const u64 hm = __ballot(hit);
-      if (hm) {
-        int base = 0;
-        if (lane == 0) base = atomicAdd(&a.nedges[tm], __popcll(hm));
-        base = __shfl(base, 0);
-        if (hit) {
-          const long long pos = (long long)base + __popcll(hm & lanemask_lt());
-          if (pos < a.ecap) stg_agent(edges + pos, packed);
-        }
-      }
-    };
-    auto drain = [&](int cnt) {   // stage 1, wave-uniform cnt <= 64
+    auto drain = [&](int cnt) {   // stage 1a, wave-uniform cnt <= 64
       wave_sync();
       int res = 0;
       uint32_t packed = 0;
       if (lane < cnt) {
         const uint32_t it = L.qbuf[(Q.head + lane) & 127];
         const int rr = it >> 8, cc = it & 255;
-        res = G::classify(a.rec + (size_t)L.rowpos[rr] * G::RECQ, a.rec + (size_t)L.colpos[cc] * G::RECQ, G::thr_of(a), cull);
+        res = G::classify_quick(a.rec + (size_t)L.rowpos[rr] * G::RECQ, a.rec + (size_t)L.colpos[cc] * G::RECQ, G::thr_of(a), cull);
         packed = ((uint32_t)(rb * 64 + rr) << 16) | (uint32_t)(cb * 64 + cc);
       }
       emit(res == 1, packed);
       Q.head = (Q.head + cnt) & 127;
       Q.count -= cnt;
+      Q1.push(res == 3, packed);
       Q2.push(res == 2, packed);
       wave_sync();
+      if (Q1.count >= 64) drain1b(64);
       if (Q2.count >= 64) drain2(64);
     };
 
@@ -325,6 +346,7 @@ __device__ __forceinline__ void nms_pairs(const NmsArgs& a, int tm, int cn, cons
     }
     if (Q.count > 0) drain(Q.count);
   }
+  if (Q1.count > 0) drain1b(Q1.count);
   if (Q2.count > 0) drain2(Q2.count);
 }
 
@@ -510,7 +532,7 @@ __device__ __forceinline__ void nms_cross(const NmsArgs& a, const uint32_t* rows
   const long long items = (long long)ncw * rgn;
   // rows: plain loads -- published write-through by the resolver, acquired after the serial section
   const bool cull = a.cull != 0;
-  PairQueue Q{L.qbuf, 0, 0}, Q2{L.qbuf2, 0, 0};
+  PairQueue Q{L.qbuf, 0, 0}, Q1{L.qbuf1b, 0, 0}, Q2{L.qbuf2, 0, 0};
   const bool cprof = a.prof != nullptr && blockIdx.x == 0 && threadIdx.x == 0;
   u64 ct0 = 0, c_loop = 0, c_d1 = 0, c_d2 = 0, c_n1 = 0, c_n2 = 0, c_items = 0;
   auto ctick = [&]() { if (cprof) ct0 = wall_clock64(); };
@@ -551,6 +573,34 @@ __device__ __forceinline__ void nms_cross(const NmsArgs& a, const uint32_t* rows
       Q2.count -= cnt;
       wave_sync();
     };
+    auto push2 = [&](bool undecided, uint32_t rowp, uint32_t cc) {   // (row position, column lane) into stage 2
+      const u64 m2 = __ballot(undecided);
+      if (undecided) {
+        const int slot = (Q2.head + Q2.count + __popcll(m2 & lanemask_lt())) & 127;
+        L.qbuf2[slot] = rowp;
+        L.q2col[slot] = (uint8_t)cc;
+      }
+      Q2.count += __popcll(m2);
+    };
+    auto drain1b = [&](int cnt) {                  // stage 1b: the IoU interval, on full waves only
+      wave_sync();
+      int res = 0;
+      uint32_t rowp = 0, cc = 0;
+      if (lane < cnt) {
+        const int slot = (Q1.head + lane) & 127;
+        rowp = L.qbuf1b[slot];
+        cc = L.q1bcol[slot];
+        if (!L.cdead[cc]) {
+          res = G::classify_full(a.rec + (size_t)rowp * G::RECQ, a.rec + (size_t)(cbase + cc) * G::RECQ, G::thr_of(a));
+          if (res == 1) L.cdead[cc] = 1;
+        }
+      }
+      Q1.head = (Q1.head + cnt) & 127;
+      Q1.count -= cnt;
+      push2(res == 2, rowp, cc);
+      wave_sync();
+      if (Q2.count >= 64) drain2(64);
+    };
 
     for (int rt = rt_lo; rt < rt_hi; rt++) {
       if (__ballot(alive) == 0ull) break;
@@ -565,7 +615,7 @@ __device__ __forceinline__ void nms_cross(const NmsArgs& a, const uint32_t* rows
       rp1 = (rt + 2 < rt_hi && (rt + 2) * 64 + lane < nr) ? rows[(rt + 2) * 64 + lane] : 0u;
       wave_sync();
 
-      auto drain = [&](int cnt) {                 // stage 1: register-only classifier
+      auto drain = [&](int cnt) {                 // stage 1a: the cheap register-only tests
         wave_sync();
         int res = 0;
         uint32_t rowp = 0, cc = 0;
@@ -575,22 +625,24 @@ __device__ __forceinline__ void nms_cross(const NmsArgs& a, const uint32_t* rows
           cc = it & 255;
           rowp = L.rowpos[rr];
           if (!L.cdead[cc]) {
-            res = G::classify(a.rec + (size_t)rowp * G::RECQ, a.rec + (size_t)(cbase + cc) * G::RECQ, G::thr_of(a), cull);
+            res = G::classify_quick(a.rec + (size_t)rowp * G::RECQ, a.rec + (size_t)(cbase + cc) * G::RECQ, G::thr_of(a), cull);
             if (res == 1) L.cdead[cc] = 1;
           }
         }
         Q.head = (Q.head + cnt) & 127;
         Q.count -= cnt;
-        {                                          // undecided pairs: (row position, column lane) into stage 2
-          const u64 m2 = __ballot(res == 2);
-          if (res == 2) {
-            const int slot = (Q2.head + Q2.count + __popcll(m2 & lanemask_lt())) & 127;
-            L.qbuf2[slot] = rowp;
-            L.q2col[slot] = (uint8_t)cc;
+        {                                          // needs the interval: (row position, column lane) into stage 1b
+          const u64 m1 = __ballot(res == 3);
+          if (res == 3) {
+            const int slot = (Q1.head + Q1.count + __popcll(m1 & lanemask_lt())) & 127;
+            L.qbuf1b[slot] = rowp;
+            L.q1bcol[slot] = (uint8_t)cc;
           }
-          Q2.count += __popcll(m2);
+          Q1.count += __popcll(m1);
         }
+        push2(res == 2, rowp, cc);
         wave_sync();
+        if (Q1.count >= 64) drain1b(64);
         if (Q2.count >= 64) drain2(64);
       };
 
@@ -613,6 +665,7 @@ __device__ __forceinline__ void nms_cross(const NmsArgs& a, const uint32_t* rows
       ctock(c_loop);
       if (Q.count > 0) { ctick(); drain(Q.count); ctock(c_d1); c_n1++; alive = alive && !L.cdead[lane]; }
     }
+    if (Q1.count > 0) { ctick(); drain1b(Q1.count); ctock(c_d1); c_n1++; alive = alive && !L.cdead[lane]; }
     if (Q2.count > 0) { ctick(); drain2(Q2.count); ctock(c_d2); c_n2++; alive = alive && !L.cdead[lane]; }
     const u64 kill = __ballot(alive0 && !alive);
     if (kill && lane == 0) {
