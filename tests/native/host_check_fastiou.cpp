@@ -37,17 +37,17 @@ int main(int argc, char** argv) {
     obb::RBoxFeat A = obb::rbox_make_feat(a[0], a[1], a[2], a[3], a[4]);
     obb::RBoxFeat B = obb::rbox_make_feat(b[0], b[1], b[2], b[3], b[4]);
     tot[mode]++;
-    {   // the cheap lower bound in front of the interval filter: never above the oracle when it vouches
-      const float qlb = obb::rbox_quick_lower_bound(A, B);
-      if (qlb >= 0.f) {
+    {   // the cheap bounds in front of the interval filter: must contain the oracle's value whenever they vouch
+      obb::IouBounds qb;
+      if (obb::rbox_quick_bounds(A, B, &qb)) {
         const float refq = oracle_riou_f32(a, b);
         qvouch[mode]++;
-        if (!(qlb <= refq)) {
-          if (qviol < 10) printf("QUICK-LB VIOLATION mode %d ref %.9g lb %.9g  a=(%g %g %g %g %g) b=(%g %g %g %g %g)\n", mode, refq, qlb, a[0], a[1],
-                                 a[2], a[3], a[4], b[0], b[1], b[2], b[3], b[4]);
+        if (!(qb.lo <= refq && refq <= qb.hi)) {
+          if (qviol < 10) printf("QUICK-BOUNDS VIOLATION mode %d ref %.9g lo %.9g hi %.9g  a=(%g %g %g %g %g) b=(%g %g %g %g %g)\n", mode, refq, qb.lo,
+                                 qb.hi, a[0], a[1], a[2], a[3], a[4], b[0], b[1], b[2], b[3], b[4]);
           qviol++;
         }
-        for (int q = 0; q < 6; q++) if (qlb > thrs[q]) qdec[mode][q]++;
+        for (int q = 0; q < 6; q++) if (qb.lo > thrs[q] || qb.hi <= thrs[q]) qdec[mode][q]++;
       }
     }
     obb::IouBounds bd;
@@ -67,10 +67,10 @@ int main(int argc, char** argv) {
            tot[m], 100.0 * vouched[m] / tot[m], 100.0 * decided[m][0] / tot[m], 100.0 * decided[m][1] / tot[m], 100.0 * decided[m][2] / tot[m],
            100.0 * decided[m][3] / tot[m], 100.0 * decided[m][4] / tot[m], 100.0 * decided[m][5] / tot[m]);
   for (int m = 0; m < 8; m++)
-    printf("quick lower bound, mode %-17s vouched %5.1f%%  accepts (lb > thr)@0/.1/.2/.4/.45/.6 = %5.1f %5.1f %5.1f %5.1f %5.1f %5.1f %% of all pairs\n",
+    printf("quick bounds, mode %-17s vouched %5.1f%%  decided@0/.1/.2/.4/.45/.6 = %5.1f %5.1f %5.1f %5.1f %5.1f %5.1f %% of all pairs\n",
            names[m], 100.0 * qvouch[m] / tot[m], 100.0 * qdec[m][0] / tot[m], 100.0 * qdec[m][1] / tot[m], 100.0 * qdec[m][2] / tot[m],
            100.0 * qdec[m][3] / tot[m], 100.0 * qdec[m][4] / tot[m], 100.0 * qdec[m][5] / tot[m]);
-  printf("quick_lb_violations=%ld\n", qviol);
+  printf("quick_bounds_violations=%ld\n", qviol);
   printf("violations=%ld n=%ld\n", viol, n);
   return (viol || qviol) ? 1 : 0;
 }

@@ -30,10 +30,10 @@ def test_quad_iou_device_code_bit_exact(oracle_lib, tmp_path):
 
 
 def test_fast_iou_interval_contains_the_reference_value(oracle_lib, tmp_path):
-    """rbox_fast_iou_bounds (the register-only filter in front of the exact clip): whenever it vouches for a pair, the
+    """rbox_quick_bounds and rbox_fast_iou_bounds (the register-only filters in front of the exact clip): whenever one vouches for a pair, the
     oracle's IoU lies inside the interval -- detector-like distributions incl. nearly parallel, thin, class-offset,
     large, abutting and few-pixel boxes.  (The guard against corners that sit within rounding distance of the other
     box's boundary is what keeps the reference's own fragile cases out.)"""
     rc, out = _build_and_run("host_check_fastiou.cpp", "hc_fastiou", ["6000000", "11"], tmp_path)
     assert rc == 0, out
-    assert "violations=0" in out, out
+    assert "\nviolations=0" in out and "quick_bounds_violations=0" in out, out

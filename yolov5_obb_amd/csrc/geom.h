@@ -44,8 +44,8 @@ struct RotGeom {
     return (d2 > rs * rs) && (fminf(a.w, b.w) >= 2.34e-9f * d2);
   }
   // Two-stage decision of "IoU > thr" for the pairs that survive the hot loop.
-  //   classify_quick  registers only: separating-axis reject, area-ratio bound, the slab lower bound for near-duplicates
-  //             (rbox_quick_lower_bound) -- decides most pairs of a detector's output;
+  //   classify_quick  registers only: separating-axis reject, area-ratio bound, the slab / bounding-box bounds
+  //             (rbox_quick_bounds) -- decides most pairs of a detector's output;
   //   classify_full   the IoU interval of rbox_fast_iou_bounds for the rest -- 0 (no) / 1 (yes) whenever the whole interval
   //             lies on one side of the threshold, 2 = undecided (a few % of the pairs).  The two run as separate queue
   //             stages so that a wave never executes the expensive one for a handful of lanes;
@@ -59,7 +59,11 @@ struct RotGeom {
     RBoxFeat B = unpack(rb[0], rb[1], rb[2], rb[3]);
     if (rbox_certainly_disjoint(A, B)) return 0;
     if (rbox_iou_upper_bound(A, B) <= thr) return 0;
-    if (rbox_quick_lower_bound(A, B) > thr) return 1;      // near-duplicates, the bulk of a detector's pairs
+    IouBounds qb;
+    if (rbox_quick_bounds(A, B, &qb)) {
+      if (qb.lo > thr) return 1;                           // near-duplicates, the bulk of a detector's pairs
+      if (qb.hi <= thr) return 0;                          // neighbours that barely touch
+    }
     return 3;
   }
   // stage 1b (~1500 instructions): the IoU interval; 2 = undecided

@@ -199,24 +199,27 @@ OBB_HD bool rbox_fast_iou_bounds(const RBoxFeat& A, const RBoxFeat& B, IouBounds
   return out->lo == out->lo && out->hi == out->hi;
 }
 
-// Cheap LOWER bound on the IoU for the pairs a detector produces most: near-duplicates.  The part of rectangle P that
-// lies outside rectangle Q is covered by four slabs, one per side of Q: thickness = how far P's farthest corner sticks
-// out beyond that side (in Q's frame), length = P's extent along the side.  So  |P n Q| >= |P| - sum(excess * extent);
-// both directions are evaluated and the better one is kept.  ~100 flops, no division chain, no branches on data --
-// against the ~1500 instructions of rbox_fast_iou_bounds, which it spares for every pair it decides.
-// Returns a value that is NOT ABOVE the IoU the reference computes, or -1 when it does not vouch: same conditioning
-// rules as rbox_fast_iou_bounds, in particular never when a corner lies within `tol` of the other rectangle's boundary
-// lines (where the reference itself is fragile).  tests/native/host_check_fastiou.cpp checks it against the oracle.
-OBB_HD float rbox_quick_lower_bound(const RBoxFeat& A, const RBoxFeat& B) {
+// Cheap BOUNDS on the IoU for the pairs a detector produces most: near-duplicates (lower bound) and loosely overlapping
+// neighbours (upper bound).  With P's corners in Q's frame (u, v):
+//   the part of P outside Q is covered by four slabs, one per side of Q: thickness = how far P's farthest corner
+//   sticks out beyond that side, length = P's extent along the side      ->  |P n Q| >= |P| - sum(excess * extent);
+//   P lies inside its own bounding box in Q's frame                      ->  |P n Q| <= overlap_u * overlap_v.
+// Both directions are evaluated and the better one of each kind is kept.  ~150 flops, no division chain, no branches
+// on data -- against the ~1500 instructions of rbox_fast_iou_bounds, which it spares for every pair it decides.
+// Returns false when it does not vouch: same conditioning rules as rbox_fast_iou_bounds, in particular never when a
+// corner lies within `tol` of the other rectangle's boundary lines (where the reference itself is fragile).  Otherwise
+// lo <= (the IoU the reference computes) <= hi; tests/native/host_check_fastiou.cpp checks it against the oracle.
+OBB_HD bool rbox_quick_bounds(const RBoxFeat& A, const RBoxFeat& B, IouBounds* out) {
   const float wA = fabsf(A.w), hA = fabsf(A.h), wB = fabsf(B.w), hB = fabsf(B.h);
   const float mn = fminf(fminf(wA, hA), fminf(wB, hB));
-  if (!(mn >= 1.0f)) return -1.f;
+  if (!(mn >= 1.0f)) return false;
   const float dx = B.x - A.x, dy = B.y - A.y;
   const float R = 0.5f * (fabsf(dx) + fabsf(dy)) + A.r + B.r;
-  if (!(R < 1e6f) || !(mn >= 1e-3f * R)) return -1.f;
+  if (!(R < 1e6f) || !(mn >= 1e-3f * R)) return false;
   const float tol = 1e-4f * R;
   bool safe = true;
-  // area of P outside Q, from P's corners in Q's frame (centre of P relative to Q: (rx, ry))
+  float in_hi = 3.4e38f;
+  // area of P outside Q (upper estimate) from P's corners in Q's frame (centre of P relative to Q: (rx, ry))
   auto outside = [&](float rx, float ry, float pc, float ps, float phw, float phh, float qc, float qs, float qhw, float qhh)
       __attribute__((always_inline)) -> float {
     const float cxq = rx * qc - ry * qs, cyq = rx * qs + ry * qc;            // P's centre in Q's frame
@@ -232,17 +235,22 @@ OBB_HD float rbox_quick_lower_bound(const RBoxFeat& A, const RBoxFeat& B) {
       umax = fmaxf(umax, u); umin = fminf(umin, u); vmax = fmaxf(vmax, v); vmin = fminf(vmin, v);
     }
     const float eu = umax - umin, ev = vmax - vmin;
+    const float ou = fmaxf(fminf(umax, qhw) - fmaxf(umin, -qhw), 0.f), ov = fmaxf(fminf(vmax, qhh) - fmaxf(vmin, -qhh), 0.f);
+    in_hi = fminf(in_hi, ou * ov);
     return (fmaxf(umax - qhw, 0.f) + fmaxf(-qhw - umin, 0.f)) * ev + (fmaxf(vmax - qhh, 0.f) + fmaxf(-qhh - vmin, 0.f)) * eu;
   };
   const float outA = outside(-dx, -dy, A.c, A.s, 0.5f * wA, 0.5f * hA, B.c, B.s, 0.5f * wB, 0.5f * hB);
   const float outB = outside(dx, dy, B.c, B.s, 0.5f * wB, 0.5f * hB, A.c, A.s, 0.5f * wA, 0.5f * hA);
-  if (!safe) return -1.f;
-  const float aA = A.area, aB = B.area;
-  float inter = fmaxf(aA - outA, aB - outB) - 2e-5f * R * R;                  // rounding of products of magnitude R * len
-  if (!(inter > 0.f)) return -1.f;
-  inter = fminf(inter, fminf(aA, aB));
-  const float lb = inter / (aA + aB - inter) - 3e-5f;
-  return lb == lb ? lb : -1.f;
+  if (!safe) return false;
+  const float aA = A.area, aB = B.area, e_area = 2e-5f * R * R;               // rounding of products of magnitude R * len
+  float ilo = fmaxf(aA - outA, aB - outB) - e_area;
+  float ihi = fminf(in_hi + e_area, fminf(aA, aB));
+  if (!(ilo == ilo) || !(ihi == ihi)) return false;
+  ilo = fminf(fmaxf(ilo, 0.f), ihi);
+  const float sum = aA + aB;
+  out->lo = ilo / (sum - ilo) - 3e-5f;
+  out->hi = ihi / (sum - ihi) + 3e-5f;
+  return out->lo == out->lo && out->hi == out->hi;
 }
 
 // Full clip.  A = higher-scored ("row") box, B = lower-scored ("column") box:
