@@ -32,9 +32,18 @@ struct DetectArgs {
 //   xy = (y*2 - 0.5 + grid) * stride     y*2 and -0.5 in the tensor dtype; grid is a float32 tensor -> fp32 from there
 //   wh = (y*2)**2 * anchor_grid          (y*2)**2 in the tensor dtype; anchor_grid is float32 -> fp32 product
 // and the result is rounded to the tensor dtype by the slice assignment.
+// sigmoid in the precision the comparison with the reference allows: fp32 tensors get the correctly rounded expf and
+// division; fp16 tensors are rounded to 11 bits right after, so the hardware exp2 / reciprocal (1 ulp of fp32 each) can
+// only move a result that sits within 2^-12 relative of an fp16 rounding boundary -- the same 1-ulp-of-fp16 freedom the
+// reference's own libm has (tests/test_head_gpu.py states the tolerance)
+template <typename T> __device__ __forceinline__ float detect_sigmoid(float x) { return sigmoid_f(x); }
+template <> __device__ __forceinline__ float detect_sigmoid<__half>(float x) {
+  return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896341f * x));
+}
+
 template <typename T>
 __device__ __forceinline__ float detect_decode_one(float raw, int ch, float gx, float gy, float stride, float aw, float ah) {
-  const float y = round_to_dtype<T>(sigmoid_f(raw));
+  const float y = round_to_dtype<T>(detect_sigmoid<T>(raw));
   if (ch >= 4) return y;
   const float t = round_to_dtype<T>(y * 2.0f);
   if (ch < 2) {
@@ -45,7 +54,8 @@ __device__ __forceinline__ float detect_decode_one(float raw, int ch, float gx, 
   return round_to_dtype<T>(q * (ch == 2 ? aw : ah));
 }
 
-constexpr int kTileHW = 64;
+// positions per tile (template parameter kTileHW): 128 = 256-byte runs of every channel row (fp16) on the read side when
+// the tile fits LDS comfortably, 64 otherwise
 
 template <typename T> struct Pack16;                                   // 16 bytes of T
 template <> struct Pack16<float> { static constexpr int V = 4; };
@@ -53,10 +63,10 @@ template <> struct Pack16<__half> { static constexpr int V = 8; };
 
 // VEC: the input rows are 4-element aligned (HW % 4 == 0) and both outputs are 16-byte aligned at every tile start,
 // so the tile is read with 8/16-byte loads and written with 16-byte stores; otherwise element-wise accesses.
-template <typename T, bool VEC>
+template <typename T, bool VEC, int kTileHW>
 __global__ __launch_bounds__(256) void k_detect_decode(DetectArgs d) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  T* tile = reinterpret_cast<T*>(smem_raw);            // [no][kTileHW + 1]
+  T* tile = reinterpret_cast<T*>(smem_raw);            // [no] rows of 64 positions, skewed (tix)
   const int tid = threadIdx.x;
   const int HW = d.ny * d.nx;
   const int ba = blockIdx.y;                            // b * na + a
@@ -65,28 +75,32 @@ __global__ __launch_bounds__(256) void k_detect_decode(DetectArgs d) {
   const int nhw = min(kTileHW, HW - hw0);
   const int no = d.no;
   const T* in = (const T*)d.in + ((size_t)ba * no) * HW + hw0;
-  constexpr int LD = kTileHW + 1;
+  // LDS layout: channel row c starts at c*64 + 2*(c>>3) elements.  The store phase reads 8 consecutive channels of one
+  // position per lane, i.e. lane stride = 8 rows = 512 + 2 elements: one 32-bit bank further per lane (fp16; two for fp32)
+  // instead of the same eight banks again (8-way conflict with a plain 64 / 65 pitch).
+  auto tix = [](int c, int hw) -> int { return c * kTileHW + ((c >> 3) << 1) + hw; };
 
   // ---- load (coalesced along hw)
   if constexpr (VEC) {
-    // 16 threads x 4 positions cover the 64 positions of one channel row; 16 channel rows per step
-    const int q = tid & 15, c16 = tid >> 4;
+    // kTileHW/4 threads x 4 positions cover the positions of one channel row; 256/(kTileHW/4) channel rows per step
+    constexpr int TPR = kTileHW / 4, RPS = 256 / TPR;
+    const int q = tid % TPR, c16 = tid / TPR;
     const int hw = q * 4;
-    for (int c = c16; c < no; c += 16) {
+    for (int c = c16; c < no; c += RPS) {
       if (hw + 3 < nhw) {
         T v[4];
         if constexpr (sizeof(T) == 2) *reinterpret_cast<uint2*>(v) = *reinterpret_cast<const uint2*>(in + (size_t)c * HW + hw);
         else *reinterpret_cast<float4*>(v) = *reinterpret_cast<const float4*>(in + (size_t)c * HW + hw);
 #pragma unroll
-        for (int j = 0; j < 4; j++) tile[c * LD + hw + j] = v[j];
+        for (int j = 0; j < 4; j++) tile[tix(c, hw + j)] = v[j];
       } else {
-        for (int j = 0; j < 4; j++) if (hw + j < nhw) tile[c * LD + hw + j] = in[(size_t)c * HW + hw + j];
+        for (int j = 0; j < 4; j++) if (hw + j < nhw) tile[tix(c, hw + j)] = in[(size_t)c * HW + hw + j];
       }
     }
   } else {
-    const int hw = tid & 63, c4 = tid >> 6;
-    for (int c = c4; c < no; c += 4)
-      if (hw < nhw) tile[c * LD + hw] = in[(size_t)c * HW + hw];
+    const int hw = tid % kTileHW, c4 = tid / kTileHW;
+    for (int c = c4; c < no; c += 256 / kTileHW)
+      if (hw < nhw) tile[tix(c, hw)] = in[(size_t)c * HW + hw];
   }
   __syncthreads();
 
@@ -96,9 +110,11 @@ __global__ __launch_bounds__(256) void k_detect_decode(DetectArgs d) {
   T* zo = d.z ? (T*)d.z + ((size_t)b * d.a_total + d.a_off + (size_t)a * HW + hw0) * no : nullptr;
   const float aw = d.anchor_px[a][0], ah = d.anchor_px[a][1];
   auto decode_at = [&](T raw, int c, int hw) -> float {
+    const float r = ld_as_float<T>(&raw);
+    if (c >= 4) return round_to_dtype<T>(detect_sigmoid<T>(r));      // 196 of the 200 channels: no grid arithmetic
     const int pos = hw0 + hw;
     const int gyi = pos / d.nx;
-    return detect_decode_one<T>(ld_as_float<T>(&raw), c, (float)(pos - gyi * d.nx), (float)gyi, d.stride, aw, ah);
+    return detect_decode_one<T>(r, c, (float)(pos - gyi * d.nx), (float)gyi, d.stride, aw, ah);
   };
   if constexpr (VEC) {
     constexpr int V = Pack16<T>::V;
@@ -110,7 +126,7 @@ __global__ __launch_bounds__(256) void k_detect_decode(DetectArgs d) {
       alignas(16) T decv[V];
 #pragma unroll
       for (int j = 0; j < V; j++) {
-        const T raw = tile[c * LD + hw];
+        const T raw = tile[tix(c, hw)];
         rawv[j] = raw;
         if (zo) { T o; st_from_float<T>(&o, decode_at(raw, c, hw)); decv[j] = o; }
         if (++c == no) { c = 0; hw++; }
@@ -120,7 +136,7 @@ __global__ __launch_bounds__(256) void k_detect_decode(DetectArgs d) {
     }
     for (int e = nvec * V + tid; e < nel; e += 256) {
       const int hw = e / no, c = e - hw * no;
-      const T raw = tile[c * LD + hw];
+      const T raw = tile[tix(c, hw)];
       if (xo) xo[e] = raw;
       if (zo) st_from_float<T>(zo + e, decode_at(raw, c, hw));
     }
@@ -128,7 +144,7 @@ __global__ __launch_bounds__(256) void k_detect_decode(DetectArgs d) {
     int c = tid % no, hw = tid / no;
     const int dc = 256 % no, dh = 256 / no;
     for (int e = tid; e < nel; e += 256) {
-      const T raw = tile[c * LD + hw];
+      const T raw = tile[tix(c, hw)];
       if (xo) xo[e] = raw;
       if (zo) st_from_float<T>(zo + e, decode_at(raw, c, hw));
       c += dc; hw += dh;
@@ -207,24 +223,33 @@ int obb_detect_decode(const void* conv_out, int dtype, int64_t bs, int64_t na, i
     d.anchor_px[a][1] = a < na ? anchors_px_host[a * 2 + 1] : 0.f;
   }
   const int HW = (int)(ny * nx);
-  dim3 grid((unsigned)((HW + kTileHW - 1) / kTileHW), (unsigned)(bs * na));
   const size_t esz = dtype == 0 ? 4 : 2;
-  const size_t lds = (size_t)no * (kTileHW + 1) * esz;
+  auto lds_of = [&](int tile) { return ((size_t)no * tile + 2 * (size_t)(no / 8 + 2)) * esz; };   // skewed rows (tix in the kernel)
+  // measured on (16, 3*200, 128..32, ..) fp16: 128-position tiles (256-byte read runs, 3 workgroups per CU) 0.419 ms,
+  // 64-position tiles (6 workgroups per CU) 0.308 ms -- occupancy beats the longer runs
+  const int tile_hw = 64;
+  const size_t lds = lds_of(tile_hw);
+  dim3 grid((unsigned)((HW + tile_hw - 1) / tile_hw), (unsigned)(bs * na));
   hipStream_t st = (hipStream_t)stream;
   // vector path: input rows 4-element aligned, every tile of both outputs 16-byte aligned
   auto al16 = [](const void* p) { return p == nullptr || (((uintptr_t)p) & 15) == 0; };
   bool vec = (HW % 4 == 0) && al16(conv_out) && al16(x_perm_out) && al16(z_out);
   vec = vec && ((size_t)HW * no * esz) % 16 == 0 && ((size_t)a_total * no * esz) % 16 == 0 && ((size_t)a_offset * no * esz) % 16 == 0;
   if (lds > 150 * 1024) return OBB_ERR_BAD_ARG;
-#define OBB_LAUNCH_DETECT(T, VEC)                                                                                                  \
+#define OBB_LAUNCH_DETECT(T, VEC, TILE)                                                                                            \
   do {                                                                                                                              \
     if (lds > 48 * 1024 &&                                                                                                          \
-        hipFuncSetAttribute((const void*)k_detect_decode<T, VEC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) \
+        hipFuncSetAttribute((const void*)k_detect_decode<T, VEC, TILE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) \
       return OBB_ERR_LAUNCH;                                                                                                        \
-    k_detect_decode<T, VEC><<<grid, 256, lds, st>>>(d);                                                                             \
+    k_detect_decode<T, VEC, TILE><<<grid, 256, lds, st>>>(d);                                                                       \
   } while (0)
-  if (dtype == 0) { if (vec) OBB_LAUNCH_DETECT(float, true); else OBB_LAUNCH_DETECT(float, false); }
-  else { if (vec) OBB_LAUNCH_DETECT(__half, true); else OBB_LAUNCH_DETECT(__half, false); }
+#define OBB_LAUNCH_DETECT_T(T)                                                                                                      \
+  do {                                                                                                                              \
+    if (tile_hw == 128) { if (vec) OBB_LAUNCH_DETECT(T, true, 128); else OBB_LAUNCH_DETECT(T, false, 128); }                        \
+    else { if (vec) OBB_LAUNCH_DETECT(T, true, 64); else OBB_LAUNCH_DETECT(T, false, 64); }                                         \
+  } while (0)
+  if (dtype == 0) OBB_LAUNCH_DETECT_T(float); else OBB_LAUNCH_DETECT_T(__half);
+#undef OBB_LAUNCH_DETECT_T
 #undef OBB_LAUNCH_DETECT
   return hipGetLastError() == hipSuccess ? OBB_OK : OBB_ERR_LAUNCH;
 }
