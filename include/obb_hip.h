@@ -124,6 +124,21 @@ int obb_merge_nms_poly_f64(const double* dets9, int64_t n, const int32_t* order,
 int obb_eval_best_gt_f64(const double* dets8, const int32_t* det_img, int64_t nd, const double* gts8, const int32_t* gt_off,
                          int64_t n_img, double* ovmax, int32_t* jmax, void* stream);
 
+/*
+ * Host-side text I/O of the merge (no device work; csrc/textio.hip).  obb_task1_parse_tiles restates
+ * DOTA_devkit/ResultMerge_multi_process.py:186-213 for a whole Task1_<class>.txt buffer: per line
+ * `<orig>__<rate>__<x>___<y> score x1 y1 .. x4 y4` -> dets9[line] = [8 source-image coordinates (poly + x|y) / rate,
+ * score] (strtod = Python's float()), the position of <orig> in the text, a group id per distinct <orig> in order of
+ * first appearance and the first line of every group.  Returns the number of lines, or OBB_ERR_BAD_ARG for anything that
+ * is not the plain layout (the Python layer then parses line by line like the reference).
+ * obb_task1_format_rows writes `<orig> <round(score, 2)> <round(c, 1)> x 8\n` for the given lines (:218-233) and returns
+ * the number of bytes (OBB_ERR_WORKSPACE: out_cap too small; 200 bytes per row + the name suffice for |values| < 1e15).
+ */
+int64_t obb_task1_parse_tiles(const char* text_host, int64_t len, int64_t max_lines, double* dets9_host, int32_t* name_off_host,
+                              int32_t* name_len_host, int32_t* group_host, int32_t* group_first_host, int64_t* n_groups_host);
+int64_t obb_task1_format_rows(const char* text_host, const int32_t* name_off_host, const int32_t* name_len_host,
+                              const double* dets9_host, const int64_t* rows_host, int64_t n_rows, char* out_host, int64_t out_cap);
+
 /* ------------------------------------------------------------------ fused NMS driver ----------------- */
 
 /*

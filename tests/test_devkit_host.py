@@ -1,0 +1,63 @@
+"""CPU: the native reader / writer of Task1 files (csrc/textio.hip, host code only) and the column-wise detection reader
+against their line-by-line twins, which follow the reference's text handling statement by statement (DOTA_devkit/ResultMerge_multi_process.py:186-233,
+dota_evaluation_task1.py:152-160).  Bit-equal doubles, identical output lines."""
+import numpy as np
+import pytest
+
+from tests.golden import gen_golden as gg
+
+
+
+@pytest.mark.parametrize("cfg", list(gg.MERGE_CASES.values()) + [(50, 30, 9, True)])
+def test_result_table_equals_line_by_line_parse(tmp_path, cfg):
+    from yolov5_obb_amd.DOTA_devkit import ResultMerge_multi_process as RM
+    src = tmp_path / "Task1_plane.txt"
+    src.write_text("\n".join(gg.merge_input_lines(*cfg)) + "\n")
+    boxes = RM.parse_result_file(str(src))
+    table = RM.parse_result_table(str(src))
+    names, codes, dets = table.names, table.codes, table.dets
+    assert names == list(boxes)
+    for g, nm in enumerate(names):
+        a, b = np.array(boxes[nm]), dets[codes == g]
+        assert a.shape == b.shape and np.array_equal(a.view(np.uint64), b.view(np.uint64))
+    want = [RM.format_result_line(names[c], dets[i].tolist()) for i, c in enumerate(codes)]
+    assert RM.format_result_rows([names[c] for c in codes], dets) == want
+    assert table.format_rows(np.arange(len(dets))).decode().splitlines() == want
+
+
+def test_unusual_lines_send_the_native_reader_back_to_the_line_by_line_path(tmp_path):
+    from yolov5_obb_amd.DOTA_devkit import ResultMerge_multi_process as RM
+    good = "P1__1__0___824 0.5 1 2 3 4 5 6 7 8"
+    for bad in ("P1__1__0___824 0.5 1 2 3 4 5 6 7", "P1__1__0___824  0.5 1 2 3 4 5 6 7 8", "P1_1_0_824 0.5 1 2 3 4 5 6 7 8",
+                "P1__1__0___824 0.5 1 2 3 4 5 6 7 1_0", "P1__1__0___824 0.5 1 2 3 4 5 6 7 nan", ""):
+        f = tmp_path / "t.txt"
+        f.write_text(good + "\n" + bad + "\n" + good + "\n")
+        assert RM.parse_result_table(str(f)) is None
+    f.write_text(good + "\r\n  " + good.replace("P1__1__", "Q__0.5__") + "\t\n" + good)       # CRLF, padding, no final newline
+    t = RM.parse_result_table(str(f))
+    assert t.names == ["P1", "Q"] and t.codes.tolist() == [0, 1, 0]
+    assert np.array_equal(t.dets[1], np.array([(1 + 0) / 0.5, (2 + 824) / 0.5, 6.0, 1656.0, 10.0, 1660.0, 14.0, 1664.0, 0.5]))
+
+
+def test_row_formatter_follows_python_round_and_str():
+    from yolov5_obb_amd.DOTA_devkit import ResultMerge_multi_process as RM
+    v = np.array([[0.15, 0.25, 0.35, 1.0, 2.5, 1234.05, -0.04, 0.05, 0.125], [99.95, 0.049999, 0.005, 7.0, 3.14159, 1e-9, 2.675, 0.5, 1.0],
+                  [0.45, 0.55, 0.65, 0.75, 0.85, 0.95, 1.05, 1.15, 0.995], [10.0, 100.0, 0.0, 5.55, 6.65, 7.75, 8.85, 9.95, 0.3]])
+    assert RM.format_result_rows(['a'] * 4, v) == [RM.format_result_line('a', r.tolist()) for r in v]
+    rng = np.random.RandomState(0)
+    w = np.round(rng.rand(20000, 9) * 3000, 2)
+    w[:, 8] = np.round(rng.rand(20000), 5)
+    assert RM.format_result_rows(['b'] * 20000, w) == [RM.format_result_line('b', r.tolist()) for r in w]
+
+
+def test_detection_reader_equals_line_by_line(tmp_path):
+    pytest.importorskip("pandas")
+    from yolov5_obb_amd.DOTA_devkit import dota_evaluation_task1 as EV
+    _, det = gg.eval_inputs(20, 30, 4)
+    f = tmp_path / "Task1_plane.txt"
+    f.write_text("\n".join(det["plane"]) + "\n")
+    ids, conf, bb = EV.read_detections(str(f))
+    split = [x.strip().split(' ') for x in det["plane"]]
+    assert ids == [x[0] for x in split]
+    assert np.array_equal(conf, np.array([float(x[1]) for x in split]))
+    assert np.array_equal(bb, np.array([[float(z) for z in x[2:]] for x in split]))

@@ -121,10 +121,78 @@ def format_result_line(imgname, det):
     return imgname + ' ' + str(round(det[-1], 2)) + ' ' + ' '.join(str(round(v, 1)) for v in det[:8])
 
 
+class ResultTable:
+    """A parsed Task1_<class>.txt file (native reader, include/obb_hip.h: obb_task1_parse_tiles): `names` of the source
+    images in first-appearance order, `codes` (n) = source image of a line, `dets` (n, 9) float64 [8 source-image
+    coordinates, confidence]; keeps the text so that the writer can copy the names."""
+
+    def __init__(self, text, names, codes, dets, name_off, name_len):
+        self.text, self.names, self.codes, self.dets, self.name_off, self.name_len = text, names, codes, dets, name_off, name_len
+
+    def format_rows(self, rows):
+        """The output lines (one bytes object) of the given input lines, format_result_line's text (obb_task1_format_rows)."""
+        rows = np.ascontiguousarray(rows, dtype=np.int64)
+        cap = 200 * len(rows) + int(self.name_len[rows].sum()) + 64 if len(rows) else 64
+        out = np.empty(cap, dtype=np.uint8)
+        w = _lib.lib().obb_task1_format_rows(self.text, self.name_off.ctypes.data, self.name_len.ctypes.data, self.dets.ctypes.data,
+                                             rows.ctypes.data, len(rows), out.ctypes.data, cap)
+        if w < 0:
+            raise RuntimeError(f"obb_task1_format_rows failed ({w})")
+        return out[:w].tobytes()
+
+
+def parse_result_table(fullname):
+    """The same parse as parse_result_file, one native pass over the file.  None when the file is not the plain layout
+    (then the caller parses line by line, which behaves like the reference on such input)."""
+    with open(fullname, 'rb') as f:
+        text = f.read()
+    max_lines = text.count(b'\n') + 1
+    dets = np.empty((max_lines, 9), dtype=np.float64)
+    name_off = np.empty(max_lines, dtype=np.int32)
+    name_len = np.empty(max_lines, dtype=np.int32)
+    group = np.empty(max_lines, dtype=np.int32)
+    first = np.empty(max_lines, dtype=np.int32)
+    import ctypes
+    ng = ctypes.c_int64(0)
+    n = _lib.lib().obb_task1_parse_tiles(text, len(text), max_lines, dets.ctypes.data, name_off.ctypes.data, name_len.ctypes.data,
+                                         group.ctypes.data, first.ctypes.data, ctypes.addressof(ng))
+    if n <= 0:
+        return None
+    try:
+        names = [text[name_off[i]:name_off[i] + name_len[i]].decode() for i in first[:ng.value]]
+    except UnicodeDecodeError:
+        return None
+    return ResultTable(text, names, group[:n].copy(), dets[:n].copy(), name_off[:n].copy(), name_len[:n].copy())
+
+
+def format_result_rows(names, dets):
+    """format_result_line for many rows at once (native): names per row, dets (n, 9)."""
+    blob = ' '.join(names).encode()
+    lens = np.array([len(x.encode()) for x in names], dtype=np.int32)
+    offs = np.zeros(len(names), dtype=np.int32)
+    if len(names) > 1:
+        offs[1:] = np.cumsum(lens[:-1] + 1)
+    t = ResultTable(blob, None, None, np.ascontiguousarray(dets, dtype=np.float64), offs, lens)
+    return t.format_rows(np.arange(len(names))).decode().splitlines()
+
+
 def mergesingle(dstpath, nms, fullname):
     """:183-234: one class file in, one merged class file out (same base name)."""
     name = os.path.basename(os.path.splitext(fullname)[0])
     dstname = os.path.join(dstpath, name + '.txt')
+    table = parse_result_table(fullname) if nms is py_cpu_nms_poly_fast else None
+    if table is not None and np.isfinite(table.dets).all() and np.abs(table.dets).max() < 1e15:
+        codes, dets = table.codes, table.dets
+        rows = np.argsort(codes, kind='stable')          # lines of one source image together, file order inside
+        bounds = np.searchsorted(codes[rows], np.arange(len(table.names) + 1))
+        orders = []
+        for g in range(len(table.names)):
+            idx = rows[bounds[g]:bounds[g + 1]]
+            orders.append(idx[dets[idx, 8].argsort()[::-1]])          # :79 on this image's rows, numpy's own tie order
+        keeps = merge_nms_segments(dets, orders, nms_thresh)
+        with open(dstname, 'wb') as f:
+            f.write(table.format_rows(np.concatenate(keeps) if keeps else np.zeros(0, dtype=np.int64)))
+        return dstname
     merged = nmsbynamedict(parse_result_file(fullname), nms, nms_thresh)
     with open(dstname, 'w') as f:
         for imgname, dets in merged.items():

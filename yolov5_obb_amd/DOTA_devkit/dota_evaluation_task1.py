@@ -50,6 +50,24 @@ def voc_ap(rec, prec, use_07_metric=False):
     return np.sum((mrec[i + 1] - mrec[i]) * mpre[i + 1])
 
 
+def read_detections(detfile):
+    """`image score x1 y1 .. x4 y4` per line (:152-160) -> (image ids, confidence (n,), BB (n, 8)).  pandas' C reader with
+    the round-trip float parser (= Python's float()) when the file is the plain 10-column layout, line by line otherwise."""
+    try:
+        import pandas as pd
+        df = pd.read_csv(detfile, sep=' ', header=None, float_precision='round_trip', dtype={0: str}, skip_blank_lines=False)
+        if df.shape[1] == 10 and not df.isna().any().any():
+            return df[0].tolist(), df[1].to_numpy(dtype=np.float64), df[[2, 3, 4, 5, 6, 7, 8, 9]].to_numpy(dtype=np.float64)
+    except Exception:
+        pass
+    with open(detfile, 'r') as f:
+        splitlines = [x.strip().split(' ') for x in f.readlines()]
+    image_ids = [x[0] for x in splitlines]
+    confidence = np.array([float(x[1]) for x in splitlines])
+    BB = np.array([[float(z) for z in x[2:]] for x in splitlines])
+    return image_ids, confidence, BB
+
+
 def best_gt(dets8, det_img, gts8, gt_off):
     """(ovmax, jmax) per detection over the ground truth of its image (include/obb_hip.h: obb_eval_best_gt_f64)."""
     if not torch.cuda.is_available():
@@ -85,11 +103,7 @@ def voc_eval(detpath, annopath, imagesetfile, classname, ovthresh=0.5, use_07_me
     npos = int((~difficult).sum())
     gt_off = np.array(gt_off, dtype=np.int64)
 
-    with open(detpath.format(classname), 'r') as f:
-        splitlines = [x.strip().split(' ') for x in f.readlines()]
-    image_ids = [x[0] for x in splitlines]
-    confidence = np.array([float(x[1]) for x in splitlines])
-    BB = np.array([[float(z) for z in x[2:]] for x in splitlines])
+    image_ids, confidence, BB = read_detections(detpath.format(classname))
     sorted_ind = np.argsort(-confidence)                 # :163
     BB = BB[sorted_ind, :]
     det_img = np.array([index[image_ids[x]] for x in sorted_ind], dtype=np.int32)   # KeyError for an unlisted image, as :169

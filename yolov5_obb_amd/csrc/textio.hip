@@ -1,0 +1,182 @@
+// Host-side text I/O of the DOTA devkit mirrors (no device code): the Task1_<class>.txt reader and writer of the tile ->
+// full-image merge, restating what DOTA_devkit/ResultMerge_multi_process.py:186-233 does per line with str.split, two
+// regular expressions, float() and round()/str() -- in one pass over the file instead of ~20 Python calls per line
+// (the merge of a 25k-line class file spent 130 of its 134 ms there).  strtod is correctly rounded like Python's float(),
+// printf's %.1f / %.2f are the correctly rounded decimals Python's round() picks.  Anything that is not the plain layout
+// (10 single-space separated fields, tile name `<orig>__<rate>__<x>___<y>`, plain decimal numbers) makes the reader return
+// OBB_ERR_BAD_ARG and the Python layer takes its line-by-line path, which behaves like the reference on such input.
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <string>
+#include <unordered_map>
+#include "obb_hip.h"
+
+namespace {
+
+inline bool is_space(char c) { return c == ' ' || c == '\t' || c == '\r' || c == '\n' || c == '\v' || c == '\f'; }
+inline bool is_digit(char c) { return c >= '0' && c <= '9'; }
+
+// plain decimal literal (what float() and strtod agree on without exception): [+-] digits [. digits] [e[+-]digits]
+bool parse_double(const char* b, const char* e, double* out) {
+  if (b >= e || e - b > 60) return false;
+  const char* p = b;
+  if (*p == '+' || *p == '-') p++;
+  int nd = 0;
+  while (p < e && is_digit(*p)) { p++; nd++; }
+  if (p < e && *p == '.') { p++; while (p < e && is_digit(*p)) { p++; nd++; } }
+  if (nd == 0) return false;
+  if (p < e && (*p == 'e' || *p == 'E')) {
+    p++;
+    if (p < e && (*p == '+' || *p == '-')) p++;
+    int ne = 0;
+    while (p < e && is_digit(*p)) { p++; ne++; }
+    if (ne == 0) return false;
+  }
+  if (p != e) return false;
+  char buf[64];
+  memcpy(buf, b, (size_t)(e - b));
+  buf[e - b] = 0;
+  char* end = nullptr;
+  *out = strtod(buf, &end);
+  return end == buf + (e - b);
+}
+
+bool parse_int(const char* b, const char* e, long long* out) {
+  if (b >= e || e - b > 18) return false;
+  long long v = 0;
+  for (const char* p = b; p < e; p++) { if (!is_digit(*p)) return false; v = v * 10 + (*p - '0'); }
+  *out = v;
+  return true;
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t obb_task1_parse_tiles(const char* text, int64_t len, int64_t max_lines, double* dets9, int32_t* name_off, int32_t* name_len,
+                              int32_t* group, int32_t* group_first, int64_t* n_groups) {
+  if (!text || len < 0 || max_lines < 0 || !dets9 || !name_off || !name_len || !group || !group_first || !n_groups) return OBB_ERR_BAD_ARG;
+  std::unordered_map<std::string, int32_t> ids;
+  int64_t n = 0;
+  const char* p = text;
+  const char* end = text + len;
+  while (p < end) {
+    const char* le = (const char*)memchr(p, '\n', (size_t)(end - p));
+    const char* next = le ? le + 1 : end;
+    if (!le) le = end;
+    const char* b = p;
+    const char* e = le;
+    while (b < e && is_space(*b)) b++;                    // str.strip()
+    while (e > b && is_space(e[-1])) e--;
+    p = next;
+    if (b == e) return OBB_ERR_BAD_ARG;                   // an empty line: the reference raises on it
+    if (n >= max_lines) return OBB_ERR_BAD_ARG;
+    // ---- 10 fields separated by single spaces
+    const char* fb[10];
+    const char* fe[10];
+    int nf = 0;
+    const char* q = b;
+    while (true) {
+      const char* sp = (const char*)memchr(q, ' ', (size_t)(e - q));
+      if (nf == 10) return OBB_ERR_BAD_ARG;
+      fb[nf] = q; fe[nf] = sp ? sp : e; nf++;
+      if (!sp) break;
+      q = sp + 1;
+    }
+    if (nf != 10) return OBB_ERR_BAD_ARG;
+    for (int k = 0; k < 10; k++) if (fb[k] == fe[k]) return OBB_ERR_BAD_ARG;
+    const char* s = fb[0];
+    const char* se = fe[0];
+    // ---- oriname = subname.split('__')[0]
+    const char* us = nullptr;
+    for (const char* t = s; t + 1 < se; t++) if (t[0] == '_' && t[1] == '_') { us = t; break; }
+    if (!us) return OBB_ERR_BAD_ARG;
+    // ---- re.findall(r'__\d+___\d+', subname)[0]: leftmost "__" digits "___" digits
+    long long x = 0, y = 0;
+    bool have_xy = false;
+    for (const char* t = s; t + 1 < se && !have_xy; t++) {
+      if (t[0] != '_' || t[1] != '_') continue;
+      const char* d0 = t + 2;
+      const char* d1 = d0;
+      while (d1 < se && is_digit(*d1)) d1++;
+      if (d1 == d0 || d1 + 3 > se || d1[0] != '_' || d1[1] != '_' || d1[2] != '_') continue;
+      const char* g0 = d1 + 3;
+      const char* g1 = g0;
+      while (g1 < se && is_digit(*g1)) g1++;
+      if (g1 == g0) continue;
+      if (!parse_int(d0, d1, &x) || !parse_int(g0, g1, &y)) return OBB_ERR_BAD_ARG;
+      have_xy = true;
+    }
+    if (!have_xy) return OBB_ERR_BAD_ARG;
+    // ---- re.findall(r'__([\d+\.]+)__\d+___', subname)[0]
+    double rate = 0.0;
+    bool have_rate = false;
+    for (const char* t = s; t + 1 < se && !have_rate; t++) {
+      if (t[0] != '_' || t[1] != '_') continue;
+      const char* r0 = t + 2;
+      const char* r1 = r0;
+      while (r1 < se && (is_digit(*r1) || *r1 == '+' || *r1 == '.')) r1++;
+      if (r1 == r0 || r1 + 2 > se || r1[0] != '_' || r1[1] != '_') continue;
+      const char* d0 = r1 + 2;
+      const char* d1 = d0;
+      while (d1 < se && is_digit(*d1)) d1++;
+      if (d1 == d0 || d1 + 3 > se || d1[0] != '_' || d1[1] != '_' || d1[2] != '_') continue;
+      if (!parse_double(r0, r1, &rate)) return OBB_ERR_BAD_ARG;   // float(rate) would raise
+      have_rate = true;
+    }
+    if (!have_rate) return OBB_ERR_BAD_ARG;
+    // ---- numbers: float(poly + x) / float(rate), confidence last (:205-209)
+    double* d = dets9 + n * 9;
+    if (!parse_double(fb[1], fe[1], &d[8])) return OBB_ERR_BAD_ARG;
+    for (int k = 0; k < 8; k++) {
+      double v;
+      if (!parse_double(fb[2 + k], fe[2 + k], &v)) return OBB_ERR_BAD_ARG;
+      d[k] = (v + (double)((k & 1) ? y : x)) / rate;
+    }
+    name_off[n] = (int32_t)(s - text);
+    name_len[n] = (int32_t)(us - s);
+    auto ins = ids.emplace(std::string(s, (size_t)(us - s)), (int32_t)ids.size());
+    if (ins.second) group_first[ins.first->second] = (int32_t)n;
+    group[n] = ins.first->second;
+    n++;
+  }
+  *n_groups = (int64_t)ids.size();
+  return n;
+}
+
+// "<name> <conf> <c1> .. <c8>\n" per row: str(round(conf, 2)) and str(round(c, 1)) of :218-233 for |values| < 1e15
+int64_t obb_task1_format_rows(const char* text, const int32_t* name_off, const int32_t* name_len, const double* dets9, const int64_t* rows,
+                              int64_t n_rows, char* out, int64_t out_cap) {
+  if (!text || !name_off || !name_len || !dets9 || (n_rows > 0 && !rows) || !out || out_cap < 0) return OBB_ERR_BAD_ARG;
+  int64_t w = 0;
+  char num[400];
+  for (int64_t i = 0; i < n_rows; i++) {
+    const int64_t r = rows[i];
+    const double* d = dets9 + r * 9;
+    const int nl = name_len[r];
+    if (w + nl + 2 > out_cap) return OBB_ERR_WORKSPACE;
+    memcpy(out + w, text + name_off[r], (size_t)nl);
+    w += nl;
+    out[w++] = ' ';
+    int k = snprintf(num, sizeof num, "%.2f", d[8]);
+    if (k <= 0 || k >= (int)sizeof num) return OBB_ERR_BAD_ARG;
+    if (num[k - 1] == '0') k--;                          // '0.50' -> '0.5', '1.00' -> '1.0' (one decimal always stays)
+    if (w + k + 1 > out_cap) return OBB_ERR_WORKSPACE;
+    memcpy(out + w, num, (size_t)k);
+    w += k;
+    for (int c = 0; c < 8; c++) {
+      k = snprintf(num, sizeof num, "%.1f", d[c]);
+      if (k <= 0 || k >= (int)sizeof num) return OBB_ERR_BAD_ARG;
+      if (w + k + 2 > out_cap) return OBB_ERR_WORKSPACE;
+      out[w++] = ' ';
+      memcpy(out + w, num, (size_t)k);
+      w += k;
+    }
+    out[w++] = '\n';
+  }
+  return w;
+}
+
+}  // extern "C"
