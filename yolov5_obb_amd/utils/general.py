@@ -4,6 +4,7 @@
 kernels, host syncs and a device->host mask copy.
 """
 import ctypes as C
+import threading
 
 import torch
 
@@ -16,6 +17,7 @@ _MAX_NMS = 30000    # utils/general.py:794
 _CSL = 180          # utils/general.py:784
 _cap_memo = {}      # (A, nc, multi_label) -> candidate slots per image that sufficed last time
 _ws_memo = {}       # (bs, cap, nc, agnostic) -> workspace bytes (a ctypes call saved per batch)
+_meta_memo = {}     # (device index, bs, thread) -> the int64 buffer the counters are read back from
 _cand_memo = {}     # same key -> largest candidate count of an image in the previous call (sort-algorithm hint)
 _SORT_LDS_HINT = 6144   # include/obb_hip.h OBB_NMS_SORT_LDS_HINT: hints up to this select the one-workgroup-per-image sort ...
 _SORT_LDS_MAX = 8192    # ... OBB_NMS_SORT_LDS_MAX: which takes at most this many candidates of an image
@@ -92,7 +94,10 @@ def non_max_suppression_obb(prediction, conf_thres=0.25, iou_thres=0.45, classes
     L = _lib.lib()
     max_det = int(max_det)
     out = torch.empty((bs * max_det, 7), dtype=torch.float32, device=dev)   # packed: image b's rows follow image b-1's
-    meta = torch.empty(bs + 2, dtype=torch.int64, device=dev)        # counts[bs] + status[2]
+    mkey = (dev.index, bs, threading.get_ident())
+    meta = _meta_memo.get(mkey)                                       # counts[bs] + status[2]: read back before returning,
+    if meta is None:                                                  # never handed out -> one buffer per (device, bs, thread)
+        meta = _meta_memo[mkey] = torch.empty(bs + 2, dtype=torch.int64, device=dev)
     agn = int(bool(agnostic))
     while True:
         hint = int(_cand_memo.get(key, 0))
@@ -110,8 +115,8 @@ def non_max_suppression_obb(prediction, conf_thres=0.25, iou_thres=0.45, classes
                 C.c_void_p(meta.data_ptr() + 8 * bs), _lib.ptr(ws), ws.numel(), C.c_void_p(st))
         _lib.check(rc, "obb_non_max_suppression_obb")
         m = meta.tolist()                                             # the single device->host sync of the call
-        for b in range(bs):
-            _lib.checked_count(m[b], "obb_non_max_suppression_obb")
+        if min(m[:bs]) < 0:
+            _lib.checked_count(min(m[:bs]), "obb_non_max_suppression_obb")
         if m[bs] > cap:                                               # an image produced more candidates than slots
             cap = min(worst, max(int(m[bs]), 2 * cap))
             continue
