@@ -647,11 +647,7 @@ __device__ __forceinline__ void nms_cross(const NmsArgs& a, const uint32_t* rows
       };
 
       ctick();
-#pragma unroll 2
-      for (int rr = 0; rr < nrow; rr++) {
-        const float4 rq = rdlane4(myrow, rr);
-        bool pass = alive;
-        if (pass && cull) pass = !G::cheap_reject(rq, cq);
+      auto one_row = [&](int rr, bool pass) {
         if (__ballot(pass)) {
           Q.push(pass, ((uint32_t)rr << 8) | (uint32_t)lane);
           if (Q.count >= 64) {
@@ -661,6 +657,28 @@ __device__ __forceinline__ void nms_cross(const NmsArgs& a, const uint32_t* rows
             ctick();
           }
         }
+      };
+      // four rows per trip: their broadcasts and cheap tests are issued together and ONE ballot decides whether any of
+      // them has a pair to queue (most rows of a kept set pass for no column of a given 64-column word); a column that a
+      // drain kills in the middle of a group may still queue its later rows, which the drains skip
+      int rr = 0;
+      for (; rr + 4 <= nrow; rr += 4) {
+        bool ps[4];
+        bool any = false;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const float4 rq = rdlane4(myrow, rr + k);
+          ps[k] = alive && !(cull && G::cheap_reject(rq, cq));
+          any = any || ps[k];
+        }
+        if (__ballot(any)) {
+#pragma unroll
+          for (int k = 0; k < 4; k++) one_row(rr + k, ps[k]);
+        }
+      }
+      for (; rr < nrow; rr++) {
+        const float4 rq = rdlane4(myrow, rr);
+        one_row(rr, alive && !(cull && G::cheap_reject(rq, cq)));
       }
       ctock(c_loop);
       if (Q.count > 0) { ctick(); drain(Q.count); ctock(c_d1); c_n1++; alive = alive && !L.cdead[lane]; }
