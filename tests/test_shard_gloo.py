@@ -67,3 +67,46 @@ def test_single_process_paths():
     assert shard.shard_indices(7, 1, 3) == [1, 4]
     assert shard.gather_results([0, 1], ["a", "b"], 2) == ["a", "b"]
     assert shard.max_over_ranks(0.25) == 0.25
+
+
+def _merge_worker(rank, world_size, port, src, dst, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world_size))
+    dist.init_process_group("gloo", rank=rank, world_size=world_size)
+    try:
+        from oracle import pyref
+        from yolov5_obb_amd.DOTA_devkit import ResultMerge_multi_process as RM
+        # the class files are split over the ranks; the NMS is passed in like in the reference (here: the CPU oracle, so that
+        # the sharding of the merge runs without a GPU -- the device NMS itself is covered by tests/test_merge_gpu.py)
+        RM.mergebase_parallel(src, dst, pyref.merge_nms_poly_fast)
+        dist.barrier()
+        q.put((rank, sorted(os.listdir(dst))))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_merge_splits_the_class_files(tmp_path):
+    """mergebase_parallel under a world of 2: every Task1_<class>.txt is merged by exactly one rank, and the result equals
+    what the oracle restatement of the reference's mergesingle writes."""
+    from oracle import pyref
+    from tests.golden.gen_golden import merge_input_lines
+    src, dst = tmp_path / "src", tmp_path / "dst"
+    src.mkdir(); dst.mkdir()
+    classes = ["plane", "ship", "harbor", "bridge", "helicopter"]
+    want = {}
+    for k, c in enumerate(classes):
+        lines = merge_input_lines(3, 12, 40 + k, False)
+        (src / f"Task1_{c}.txt").write_text("\n".join(lines) + "\n")
+        want[f"Task1_{c}.txt"] = "\n".join(pyref.merge_result_lines(lines)) + "\n"
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_merge_worker, args=(r, 2, port, str(src), str(dst), q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0
+    seen = [q.get(timeout=10) for _ in range(2)]
+    assert all(files == sorted(want) for _, files in seen)
+    for name, text in want.items():
+        assert (dst / name).read_text() == text
