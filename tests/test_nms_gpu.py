@@ -209,3 +209,33 @@ def test_heavy_duplication_is_repeatable(dev, oracle_lib):
         for rep in range(6):
             got = nms_rotated_ext.nms_rotated(dd, ss, thr).cpu().numpy()
             assert np.array_equal(got, ref), (n, k, rep, len(got), len(ref))
+
+
+def test_full_size_100k_properties(dev, oracle_lib):
+    """BASELINE.json configs[3] size (100k candidates, S-clustered, iou 0.4), checked through properties that do not need the
+    oracle's minutes-long scan: (a) the kept indices come in descending score order, (b) kept boxes do not suppress each
+    other (pairwise IoU <= thr, from the bit-exact IoU matrix kernel), (c) idempotence: NMS of the kept set keeps all of it,
+    (d) completeness on a sample: every sampled dropped box has a kept box with a higher score and IoU > thr.  (a)-(d)
+    together characterise the greedy result."""
+    from yolov5_obb_amd import nms_rotated_ext, ops
+    thr = 0.4
+    dets, scores = synth.s_clustered(100000, 300, seed=0)
+    scores = synth.tie_free(scores)
+    d, s = dets.to(dev), scores.to(dev)
+    keep = nms_rotated_ext.nms_rotated(d, s, thr)
+    k = keep.cpu().numpy()
+    assert 100 < len(k) < 5000 and len(np.unique(k)) == len(k)
+    ks = scores.numpy()[k]
+    assert np.all(ks[:-1] > ks[1:])                                            # (a)
+    kd = d[keep]
+    m = ops.rotated_iou_matrix(kd, kd).cpu().numpy()                           # rows = higher score
+    iu = np.triu_indices(len(k), 1)
+    assert (m[iu] <= thr).all()                                                # (b)
+    again = nms_rotated_ext.nms_rotated(kd, s[keep], thr).cpu().numpy()
+    assert np.array_equal(again, np.arange(len(k)))                            # (c)
+    rng = np.random.RandomState(0)
+    dropped = np.setdiff1d(np.arange(len(scores)), k)
+    sample = rng.choice(dropped, 4000, replace=False)
+    iou = ops.rotated_iou_matrix(kd, d[torch.from_numpy(sample).to(dev)]).cpu().numpy()     # (kept, sample)
+    higher = ks[:, None] > scores.numpy()[sample][None, :]
+    assert ((iou > thr) & higher).any(0).all()                                 # (d)
