@@ -138,3 +138,17 @@ def test_in_lds_sort_path_and_an_undersold_hint(dev, oracle_lib):
     general._cand_memo[key] = 100                                                # far too small for conf 0.001
     _cmp(general.non_max_suppression_obb(pred.to(dev), **kw), ref)
     assert general._cand_memo[key] > 8192
+
+
+def test_the_bench_workload_itself_matches_the_oracle(dev, oracle_lib):
+    """BASELINE configs[1] at full size, the exact tensor bench.py times ((16, 64512, 200) fp16, seed 1000): every image's
+    rows against the oracle, for the hint-less first call and the hinted (in-LDS sort) second call."""
+    from yolov5_obb_amd.utils import general
+    pred = synth.s_pred(16, 64512, 15, seed=1000, n_obj=120, fg_frac=0.03, dtype=torch.float16)
+    kw = dict(conf_thres=0.25, iou_thres=0.45, multi_label=True, max_det=1500)
+    ref = pyref.non_max_suppression_obb(pred.clone(), **kw)
+    general._cand_memo.clear()
+    p = pred.to(dev)
+    for rep in range(2):
+        _cmp(general.non_max_suppression_obb(p, **kw), ref, ties=True)
+    assert sum(r.shape[0] for r in ref) > 3000
