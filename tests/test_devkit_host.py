@@ -61,3 +61,44 @@ def test_detection_reader_equals_line_by_line(tmp_path):
     assert ids == [x[0] for x in split]
     assert np.array_equal(conf, np.array([float(x[1]) for x in split]))
     assert np.array_equal(bb, np.array([[float(z) for z in x[2:]] for x in split]))
+
+
+def test_native_reader_never_disagrees_with_the_line_by_line_parse(tmp_path):
+    """Fuzz (hypothesis): for arbitrary mixes of well-formed and odd lines the native reader either declines (None) or
+    returns exactly what the statement-by-statement Python parse returns -- it never invents a different reading."""
+    hyp = pytest.importorskip("hypothesis")
+    from hypothesis import given, settings, strategies as st
+    from yolov5_obb_amd.DOTA_devkit import ResultMerge_multi_process as RM
+
+    good = st.one_of(st.floats(min_value=-5000, max_value=5000, allow_nan=False).map(repr),
+                     st.floats(min_value=0, max_value=4000).map(lambda v: f"{v:.2f}"),
+                     st.sampled_from(["12", "12.5", "-3.25", "1e2", "1E-2", "+4", "007", "0.1", ".5", "5.", "3.141592653589793", "4.9e-324"]))
+    odd = st.sampled_from(["1_0", "nan", "inf", "0x10", "", "1e", "--1", "1e400", "123456789012345678"])
+    num = st.one_of(*([good] * 80 + [odd]))               # mostly well-formed fields, so that whole files get accepted
+    rate = st.sampled_from(["1", "0.5", "1.0", "2", "0.25", "+1", "1.", ".5"] * 3 + ["1+1", ""])
+    stem = st.sampled_from(["P0001", "P0002", "P_1", "a__b", "x", "P0001_", "_P", "图"])
+    tile = st.builds(lambda s, r, x, y, sep: f"{s}__{r}__{x}{sep}{y}", stem, rate, st.sampled_from(["0", "824", "12", "1648"] * 4 + [""]),
+                     st.sampled_from(["0", "1648", "824"] * 5 + [""]), st.sampled_from(["___"] * 30 + ["__", "____"]))
+    sep = st.sampled_from([" "] * 300 + ["  ", "\t"])
+    line = st.builds(lambda t, nums, seps, pad: pad[0] + "".join(a + b for a, b in zip([t] + nums, seps + [""])) + pad[1], tile,
+                     st.integers(0, 19).flatmap(lambda k: st.lists(num, min_size=9 if k else 8, max_size=9 if k else 10)),
+                     st.lists(sep, min_size=10, max_size=10),
+                     st.sampled_from([("", ""), (" ", ""), ("", " \r"), ("\t", "  ")]))
+    f = tmp_path / "t.txt"
+
+    @settings(max_examples=600, deadline=None)
+    @given(st.lists(line, min_size=1, max_size=3), st.booleans())
+    def check(lines, final_newline):
+        f.write_bytes(("\n".join(lines) + ("\n" if final_newline else "")).encode())
+        t = RM.parse_result_table(str(f))
+        seen[t is not None] += 1
+        if t is None:
+            return
+        boxes = RM.parse_result_file(str(f))              # must not raise when the native reader accepted the file
+        assert t.names == list(boxes)
+        for g, nm in enumerate(t.names):
+            a, b = np.array(boxes[nm], dtype=np.float64), t.dets[t.codes == g]
+            assert a.shape == b.shape and np.array_equal(a.view(np.uint64), b.view(np.uint64)), (lines, nm)
+    seen = {True: 0, False: 0}
+    check()
+    assert seen[True] >= 20 and seen[False] >= 20, seen     # both outcomes were exercised
