@@ -368,7 +368,7 @@ int obb_process_batch_f32(const float* det6, int64_t n, const float* lab5, int64
   int* best_label = (int*)ws;
   float* best_iou = (float*)(best_label + n);
   int* winner = (int*)(best_iou + n);
-  hipMemsetAsync(winner, 0x7f, (size_t)(m > 0 ? m : 1) * 4, st);
+  if (hipMemsetAsync(winner, 0x7f, (size_t)(m > 0 ? m : 1) * 4, st) != hipSuccess) return OBB_ERR_LAUNCH;
   obb::k_pb_best<<<(unsigned)((n + 127) / 128), 128, 0, st>>>(det6, (int)n, lab5, (int)m, iouv, best_label, best_iou, winner);
   obb::k_pb_correct<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(best_label, best_iou, winner, iouv, (int)n, niou, correct);
   return hipGetLastError() == hipSuccess ? OBB_OK : OBB_ERR_LAUNCH;

@@ -575,8 +575,8 @@ static void loss_fill(LossDev& d, const obb_loss_config* c, const LossCarve& cv,
 }
 
 static int run_match(const obb_loss_config* c, const LossCarve& cv, const LossDev& d, hipStream_t st) {
-  hipMemsetAsync(cv.counts, 0, (kLv + 2) * 4, st);
-  hipMemsetAsync(cv.head, 0, cv.head_bytes, st);
+  if (hipMemsetAsync(cv.counts, 0, (kLv + 2) * 4, st) != hipSuccess) return OBB_ERR_LAUNCH;
+  if (hipMemsetAsync(cv.head, 0, cv.head_bytes, st) != hipSuccess) return OBB_ERR_LAUNCH;
   k_loss_setup<<<1, 256, 0, st>>>(d, cv.dev);
   if (d.nt > 0) {
     const unsigned nblk = (unsigned)((5LL * c->na * d.nt + 1023) / 1024);

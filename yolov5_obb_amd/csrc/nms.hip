@@ -341,7 +341,7 @@ static int nms_grid(int64_t nseg, int64_t n_slots, int cap_first_) {
 constexpr int kNmsBarZeroed = 1;    // the caller has zeroed the barrier block on this stream already
 constexpr int kNmsPlanned = 2;      // the team plan for this launch has been written already (fused sort/prep kernel)
 static int nms_steps(int kind, NmsArgs& a, const Carve& cv, int64_t nseg, int64_t n_slots, hipStream_t st, int pre = 0) {
-  if (!(pre & kNmsBarZeroed)) hipMemsetAsync(cv.bar, 0, cv.bar_bytes, st);
+  if (!(pre & kNmsBarZeroed) && hipMemsetAsync(cv.bar, 0, cv.bar_bytes, st) != hipSuccess) return OBB_ERR_LAUNCH;
   a.bar = cv.bar; a.abort_flag = cv.abort_flag; a.nseg = (int)nseg;
   a.cap_first = cap_first();
   static int phase_prof = -1;
@@ -349,7 +349,7 @@ static int nms_steps(int kind, NmsArgs& a, const Carve& cv, int64_t nseg, int64_
   a.prof = nullptr;
   if (phase_prof) {   // development aid: print the previous call's phase times (synchronises!)
     u64 h[32];
-    if (hipMemcpy(h, cv.prof, sizeof h, hipMemcpyDeviceToHost) == hipSuccess && h[6] > 0 && h[6] < (1ull << 40))
+    if (hipMemcpy(h, cv.prof, sizeof h, hipMemcpyDeviceToHost) == hipSuccess && h[6] > 0 && h[6] < (1ull << 40)) {
       fprintf(stderr, "[nms phases, wg0, us] select %.1f pairs %.1f wait-resolve %.1f cross %.1f barrier %.1f steps %llu | resolve (any wg) %.1f rounds %llu [first round %.1f other rounds %.1f output %.1f]\n",
               h[1] * 0.01, h[2] * 0.01, h[3] * 0.01, h[5] * 0.01, h[0] * 0.01, h[6], h[9] * 0.01, h[11], h[12] * 0.01, h[13] * 0.01, h[14] * 0.01);
       fprintf(stderr, "    resolve: edges total %llu, max per chunk %llu, chunk sizes total %llu, chunks resolved from LDS %llu\n", h[25], h[27], h[28], h[26]);
@@ -357,7 +357,8 @@ static int nms_steps(int kind, NmsArgs& a, const Carve& cv, int64_t nseg, int64_
       fprintf(stderr, "    workgroups: %llu, busy time max %.1f us, mean %.1f us\n", h[24], h[22] * 0.01, h[24] ? h[23] * 0.01 / h[24] : 0.0);
       fprintf(stderr, "    cross, wave 0: items %llu row-loops %.1f us, stage-1 drains %llu = %.1f us, stage-2 drains %llu = %.1f us\n", h[21],
               h[16] * 0.01, h[19], h[17] * 0.01, h[20], h[18] * 0.01);
-    hipMemsetAsync(cv.prof, 0, 32 * 8, st);
+    }
+    if (hipMemsetAsync(cv.prof, 0, 32 * 8, st) != hipSuccess) return OBB_ERR_LAUNCH;
     a.prof = cv.prof;
   }
   const int nb = nms_grid(nseg, n_slots, a.cap_first);
@@ -392,8 +393,8 @@ static int run_nms(int kind, const float* boxes, int stride, const float* scores
   const unsigned gseg = (unsigned)((nseg + T - 1) / T);
 
   if (n == 0) {
-    hipMemsetAsync(cv.keep_cnt, 0, nseg * 4, st);
-    hipMemsetAsync(cv.seg_begin, 0, nseg * 4, st);
+    if (hipMemsetAsync(cv.keep_cnt, 0, nseg * 4, st) != hipSuccess) return OBB_ERR_LAUNCH;
+    if (hipMemsetAsync(cv.seg_begin, 0, nseg * 4, st) != hipSuccess) return OBB_ERR_LAUNCH;
     k_finalize<<<gseg, T, 0, st>>>(cv.keep_cnt, cv.seg_begin, (int)nseg, max_keep, nullptr, num_keep, seg_begin_out);
     return hipGetLastError() == hipSuccess ? OBB_OK : OBB_ERR_LAUNCH;
   }

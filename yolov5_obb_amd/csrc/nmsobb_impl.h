@@ -822,7 +822,7 @@ static int run_nms_obb(const void* pred, int dtype, int64_t bs, int64_t A, int64
    dim3 gp((unsigned)((max_seg + 255) / 256), (unsigned)bs);
    {
     ProfScope ps(PROF_PREP, st);
-    hipMemsetAsync(nv.alive, 0, nv.alive_bytes, st);
+    if (hipMemsetAsync(nv.alive, 0, nv.alive_bytes, st) != hipSuccess) return OBB_ERR_LAUNCH;
     k_prep_cand<<<gp, 256, 0, st>>>(cv.cand, cv.vals_b, cv.sort_begin, cv.img_end, cap_img, agnostic ? 0.f : max_wh, nv.rec, nv.alive);
    }
   }

@@ -131,8 +131,8 @@ static int seg_radix_sort_large(unsigned long long* ka, unsigned long long* kb, 
     a_to_b = !a_to_b;
   }
   if (a_to_b) {                                              // even number of passes: the result sits in (ka, va)
-    hipMemcpyAsync(kb, ka, (size_t)total * 8, hipMemcpyDeviceToDevice, st);
-    hipMemcpyAsync(vb, va, (size_t)total * 4, hipMemcpyDeviceToDevice, st);
+    if (hipMemcpyAsync(kb, ka, (size_t)total * 8, hipMemcpyDeviceToDevice, st) != hipSuccess) return OBB_ERR_LAUNCH;
+    if (hipMemcpyAsync(vb, va, (size_t)total * 4, hipMemcpyDeviceToDevice, st) != hipSuccess) return OBB_ERR_LAUNCH;
   }
   return hipGetLastError() == hipSuccess ? OBB_OK : OBB_ERR_LAUNCH;
 }
