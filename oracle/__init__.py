@@ -55,6 +55,8 @@ def lib():
     L.oracle_piou_f64.argtypes = [_f64p, _f64p]
     L.oracle_order_desc_f32.restype = None
     L.oracle_order_desc_f32.argtypes = [_f32p, C.c_int64, _i64p]
+    L.oracle_set_threads.restype = None
+    L.oracle_set_threads.argtypes = [C.c_int]
     L.oracle_nms_rotated_f32.restype = C.c_int64
     L.oracle_nms_rotated_f32.argtypes = [_f32p, _f32p, C.c_int64, C.c_float, C.c_int, _i64p]
     L.oracle_nms_rotated_f64.restype = C.c_int64
@@ -119,9 +121,12 @@ def order_desc(scores):
     return out
 
 
-def nms_rotated(dets, scores, thr, ge=False):
-    """Greedy rotated NMS.  ge=False: CUDA semantics (IoU > thr); ge=True: CPU semantics (>=)."""
+def nms_rotated(dets, scores, thr, ge=False, threads=1):
+    """Greedy rotated NMS.  ge=False: CUDA semantics (IoU > thr); ge=True: CPU semantics (>=).
+    threads > 1: the inner loop (one kept box against the later ones) runs on that many OpenMP threads -- same result
+    for any thread count (obb_oracle.c: oracle_set_threads)."""
     dets = np.asarray(dets)
+    lib().oracle_set_threads(int(threads))
     if dets.dtype == np.float64:
         d, s = _c(dets, np.float64), _c(scores, np.float64)
         keep = np.empty(len(d), np.int64)

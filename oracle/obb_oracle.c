@@ -97,6 +97,13 @@ DEFINE_ORDER(oracle_order_desc_f64, double, score_before_f64)
  *   ge == 0 : strict  ">"   -- the CUDA path   (nms_rotated_cuda.cu:60)
  *   ge == 1 : ">="          -- the CPU path    (nms_rotated_cpu.cpp:55)
  * Returns the number kept; keep[] holds original indices in score order. */
+/* oracle_set_threads(t): t > 1 splits the INNER loop (one kept box against the later boxes) over t OpenMP threads.
+ * Every iteration of that loop only reads box a and writes dead[b] of its own b, so the result is the same for any
+ * thread count; the option exists so that the 100k S-uniform case (1.8e9 IoU calls) finishes in a test's time. */
+static int g_threads = 1;
+void oracle_set_threads(int t) { g_threads = t > 1 ? t : 1; }
+int oracle_get_threads(void) { return g_threads; }
+
 #define DEFINE_NMS(NAME, T, ORDER, IOU, STRIDE)                                     \
     int64_t NAME(const T *dets, const T *scores, int64_t n, T thr, int ge,          \
                  int64_t *keep)                                                     \
@@ -106,10 +113,12 @@ DEFINE_ORDER(oracle_order_desc_f64, double, score_before_f64)
         uint8_t *dead = (uint8_t *)calloc((size_t)n, 1);                            \
         ORDER(scores, n, order);                                                    \
         int64_t nk = 0;                                                             \
+        const int nth = g_threads;                                                  \
         for (int64_t a = 0; a < n; a++) {                                           \
             if (dead[a]) continue;                                                  \
             int64_t i = order[a];                                                   \
             keep[nk++] = i;                                                         \
+            _Pragma("omp parallel for schedule(static) num_threads(nth) if (nth > 1 && n - a > 2048)") \
             for (int64_t b = a + 1; b < n; b++) {                                   \
                 if (dead[b]) continue;                                              \
                 T v = IOU(dets + i * STRIDE, dets + order[b] * STRIDE);             \

@@ -211,12 +211,53 @@ def test_heavy_duplication_is_repeatable(dev, oracle_lib):
             assert np.array_equal(got, ref), (n, k, rep, len(got), len(ref))
 
 
+def regime_100k(name, n=100000):
+    """The four N = 100k regimes bench.py reports (SURVEY section 8d distributions; `raw` = the exact tensor bench.py times,
+    scores not made tie-free: ties follow the documented rule, ascending original index)."""
+    if name == "clustered_k300_raw":
+        return synth.s_clustered(n, 300, seed=0)
+    if name == "clustered_k300":
+        d, s = synth.s_clustered(n, 300, seed=0)
+    elif name == "clustered_k300_18cls":                    # the natural shape of BASELINE configs[3] (DOTAv2.0, nc 18)
+        d, s = synth.s_clustered(n, 300, seed=0)
+        d, _ = synth.with_classes(d, 18, 0)
+    elif name == "clustered_k3000":
+        d, s = synth.s_clustered(n, 3000, seed=0)
+    elif name == "uniform":
+        d, s = synth.s_uniform(n, 0)
+    elif name == "uniform_18cls":
+        d, s = synth.s_uniform(n, 0)
+        d, _ = synth.with_classes(d, 18, 0)
+    else:
+        raise KeyError(name)
+    return d, synth.tie_free(s)
+
+
+@pytest.mark.parametrize("regime", ["clustered_k300", "clustered_k300_raw", "clustered_k300_18cls", "clustered_k3000", "uniform",
+                                    "uniform_18cls"])
+def test_full_size_100k_exact(dev, oracle_lib, regime):
+    """BASELINE.json configs[3] size: the kept list of the HIP NMS at N = 100,000, iou 0.4, equals the oracle's -- same
+    indices, same order -- on every regime bench.py times; three device runs each (the kernel's work distribution depends
+    on timing, the result must not).  The oracle needs 2.3 s for S-clustered and about four minutes for S-uniform on one
+    thread; its inner loop is split over the host's cores here (same result for any thread count)."""
+    import os
+    dets, scores = regime_100k(regime)
+    thr = 0.4
+    ref = oracle.nms_rotated(dets.numpy(), scores.numpy(), thr, threads=min(os.cpu_count() or 1, 64))
+    d, s = dets.to(dev), scores.to(dev)
+    from yolov5_obb_amd import nms_rotated_ext
+    for rep in range(3):
+        got = nms_rotated_ext.nms_rotated(d, s, thr).cpu().numpy()
+        assert len(got) == len(ref), (regime, rep, len(got), len(ref))
+        assert np.array_equal(ref, got), (regime, rep)
+
+
 def test_full_size_100k_properties(dev, oracle_lib):
-    """BASELINE.json configs[3] size (100k candidates, S-clustered, iou 0.4), checked through properties that do not need the
-    oracle's minutes-long scan: (a) the kept indices come in descending score order, (b) kept boxes do not suppress each
-    other (pairwise IoU <= thr, from the bit-exact IoU matrix kernel), (c) idempotence: NMS of the kept set keeps all of it,
-    (d) completeness on a sample: every sampled dropped box has a kept box with a higher score and IoU > thr.  (a)-(d)
-    together characterise the greedy result."""
+    """BASELINE.json configs[3] size (100k candidates, S-clustered, iou 0.4), checked through size-independent properties
+    next to the exact comparison above: (a) the kept indices come in descending score order, (b) kept boxes do not suppress
+    each other (pairwise IoU <= thr, from the bit-exact IoU matrix kernel), (c) idempotence: NMS of the kept set keeps all
+    of it, (d) completeness on a sample: every sampled dropped box has a kept box with a higher score and IoU > thr.
+    (a)-(d) together characterise the greedy result."""
     from yolov5_obb_amd import nms_rotated_ext, ops
     thr = 0.4
     dets, scores = synth.s_clustered(100000, 300, seed=0)
