@@ -51,6 +51,7 @@ struct RotGeom {
   //             stages so that a wave never executes the expensive one for a handful of lanes;
   //   hit_exact the reference's clip + Graham scan, bit for bit, on the LDS scratch column of the lane.
   static constexpr bool HAS_FAST = true;
+  static constexpr bool HAS_GRID = true;       // the spatial index of grid.h applies (circle test on quad 0; quad 3.y = brute flag)
   template <class A> static __device__ __forceinline__ float thr_of(const A& a) { return a.thr; }
   // stage 1a (cheap, ~150 flops): 0 / 1 = decided, 2 = straight to the exact clip (no shortcuts allowed), 3 = needs the interval
   static __device__ __forceinline__ int classify_quick(const float4* ra, const float4* rb, float thr, bool cull) {
@@ -103,6 +104,7 @@ struct QuadGeom {
     return quad_iou<64>(A, B, scr, scr + 10 * 64, scr + 20 * 64, scr + 30 * 64);
   }
   static constexpr bool HAS_FAST = false;      // every pair is undecided: the reference's value is not predictable (see above)
+  static constexpr bool HAS_GRID = false;
   template <class A> static __device__ __forceinline__ float thr_of(const A& a) { return a.thr; }
   static __device__ __forceinline__ int classify_quick(const float4*, const float4*, float, bool) { return 2; }
   static __device__ __forceinline__ int classify_full(const float4*, const float4*, float) { return 2; }
@@ -121,6 +123,7 @@ struct QuadGeom64 {
   static constexpr int RECQ = 5;
   static constexpr int SCR = 40;   // 32 lanes x 40 doubles: the exact stage runs in two half-wave passes
   static constexpr bool HAS_FAST = false;
+  static constexpr bool HAS_GRID = false;
   template <class A> static __device__ __forceinline__ double thr_of(const A& a) { return a.thr64; }
   static __device__ __forceinline__ bool cheap_reject(const float4& a, const float4& b) {
     return !(fminf(a.z, b.z) > fmaxf(a.x, b.x) && fminf(a.w, b.w) > fmaxf(a.y, b.y));

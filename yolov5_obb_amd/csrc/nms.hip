@@ -82,10 +82,11 @@ __global__ void k_make_keys(const float* __restrict__ scores, int score_stride, 
 // (also: the single segment's table and the zeroing of the team-barrier block -- two launches fewer)
 __global__ void k_make_keys32(const float* __restrict__ scores, int score_stride, const float* __restrict__ dets5, int drop_small,
                               int n, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, int* seg_begin, int* seg_end,
-                              int* keep_cnt, uint4* __restrict__ bar16, long long n_bar16) {
+                              int* keep_cnt, uint4* __restrict__ bar16, long long n_bar16, uint4* __restrict__ grid16, long long n_grid16) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i == 0) { seg_begin[0] = 0; seg_end[0] = n; keep_cnt[0] = 0; }
   for (long long k = i; k < n_bar16; k += (long long)gridDim.x * blockDim.x) bar16[k] = make_uint4(0u, 0u, 0u, 0u);
+  for (long long k = i; k < n_grid16; k += (long long)gridDim.x * blockDim.x) grid16[k] = make_uint4(0u, 0u, 0u, 0u);   // GridMeta + slot counters
   if (i >= n) return;
   uint32_t k = score_desc_key(scores[(size_t)i * score_stride]);
   if (drop_small) {
@@ -120,10 +121,27 @@ __global__ void k_seg_bounds(const uint64_t* __restrict__ keys, int n, int nseg,
 }
 
 // blockDim.x is a multiple of 64 and p starts at 0: every wave covers one word of the alive bitmap
+// min / max of four ordered ints over the workgroup (<= 1024 threads); every thread returns the result
+__device__ __forceinline__ void block_minmax4(int& a0, int& a1, int& b0, int& b1, int (*s_red)[4]) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    a0 = min(a0, __shfl_xor(a0, d)); a1 = min(a1, __shfl_xor(a1, d));
+    b0 = max(b0, __shfl_xor(b0, d)); b1 = max(b1, __shfl_xor(b1, d));
+  }
+  const int wv = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) { s_red[wv][0] = a0; s_red[wv][1] = a1; s_red[wv][2] = b0; s_red[wv][3] = b1; }
+  __syncthreads();
+  for (int k = 0; k < nw; k++) { a0 = min(a0, s_red[k][0]); a1 = min(a1, s_red[k][1]); b0 = max(b0, s_red[k][2]); b1 = max(b1, s_red[k][3]); }
+}
+
+// bbpart (optional): [gridDim.x][4] bounding box of the block's finite, alive centres as ordered ints (grid.h) -- no atomics
 __global__ void k_prep_rot(const float* __restrict__ dets5, const uint32_t* __restrict__ order, int drop_small, int n,
-                           float4* __restrict__ rec, u64* __restrict__ alive) {
+                           float4* __restrict__ rec, u64* __restrict__ alive, int* __restrict__ bbpart) {
+  __shared__ int s_red[16][4];
   int p = blockIdx.x * blockDim.x + threadIdx.x;
   bool ok = false;
+  int bx0 = 0x7fffffff, by0 = 0x7fffffff, bx1 = (int)0x80000000, by1 = (int)0x80000000;
   if (p < n) {
     const float* d = dets5 + (size_t)order[p] * 5;
     float x = d[0], y = d[1], w = d[2], h = d[3], a = d[4];
@@ -134,10 +152,117 @@ __global__ void k_prep_rot(const float* __restrict__ dets5, const uint32_t* __re
     for (int k = 0; k < 4; k++) rec[(size_t)p * 4 + k] = q[k];
     float mn = (h < w) ? h : w;
     ok = !(drop_small && mn < 0.001f);
+    if (ok && (x - x == 0.f) && (y - y == 0.f)) { bx0 = bx1 = grid_f2o(x); by0 = by1 = grid_f2o(y); }
   }
   const u64 m = __ballot(ok);
   if ((threadIdx.x & 63) == 0 && (p & ~63) < n) alive[p >> 6] = m;
   if (p < 8) alive[((n + 63) >> 6) + p] = 0ull;      // guard words behind the last box (the bitmap is not memset)
+  if (bbpart != nullptr) {
+    block_minmax4(bx0, by0, bx1, by1, s_red);
+    if (threadIdx.x == 0) { int* o = bbpart + (size_t)blockIdx.x * 4; o[0] = bx0; o[1] = by0; o[2] = bx1; o[3] = by1; }
+  }
+}
+
+// ---------------------------------------------------------------- spatial index (grid.h): counting sort by cell
+struct GridDev {
+  GridMeta* meta;
+  int* bbpart; int nparts;     // per-block bounding boxes written by k_prep_rot
+  int* cnt;                    // [M + 4] boxes per table slot (zeroed before), consumed by the scatter
+  int* start;                  // [M + 4] exclusive prefix, start[M] = total
+  float4* sorted;              // [n] {x, y, r, position}
+  uint32_t* slot_of;           // [n] table slot of position p, 0xffffffff: not indexed
+  uint32_t* ulist;             // [n] positions kept out of the index
+  uint32_t mask;               // M - 1
+};
+
+__global__ __launch_bounds__(256) void k_grid_count(float4* __restrict__ rec, const u64* __restrict__ alive, int n, GridDev g) {
+  __shared__ int s_red[16][4];
+  int bx0 = 0x7fffffff, by0 = 0x7fffffff, bx1 = (int)0x80000000, by1 = (int)0x80000000;
+  for (int i = threadIdx.x; i < g.nparts; i += blockDim.x) {
+    const int* q = g.bbpart + (size_t)i * 4;
+    bx0 = min(bx0, q[0]); by0 = min(by0, q[1]); bx1 = max(bx1, q[2]); by1 = max(by1, q[3]);
+  }
+  block_minmax4(bx0, by0, bx1, by1, s_red);
+  const int bb[4] = {bx0, by0, bx1, by1};
+  if (blockIdx.x == 0 && threadIdx.x == 0) { g.meta->bb[0] = bx0; g.meta->bb[1] = by0; g.meta->bb[2] = bx1; g.meta->bb[3] = by1; }
+  const GridPlan gp = grid_plan(bb);
+  const int p = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63;
+  int kind = 0;                // 1 indexed, 2 brute
+  uint32_t slot = 0xffffffffu, lbit = 0u;
+  if (p < n && ((alive[p >> 6] >> (p & 63)) & 1ull)) {
+    const float4 q0 = rec[(size_t)p * 4];
+    if (!gp.ok || grid_is_brute(gp, q0.x, q0.y, q0.z, q0.w)) kind = 2;
+    else {
+      const int lv = grid_level(gp, q0.z);
+      const float inv = grid_level_inv_cell(gp, lv);
+      const int cx = grid_cell(q0.x, gp.x0, inv, grid_last_cell(gp.xr, inv));
+      const int cy = grid_cell(q0.y, gp.y0, inv, grid_last_cell(gp.yr, inv));
+      slot = grid_slot(lv, cx, cy, g.mask);
+      lbit = 1u << lv;
+      kind = 1;
+      atomicAdd(&g.cnt[slot], 1);
+    }
+  }
+  if (p < n) g.slot_of[p] = slot;
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) lbit |= __shfl_xor(lbit, d);
+  if (lane == 0 && lbit) atomicOr(&g.meta->level_mask, lbit);
+  const u64 bm = __ballot(kind == 2);
+  if (bm) {
+    int base = 0;
+    if (lane == 0) base = atomicAdd(&g.meta->n_brute, __popcll(bm));
+    base = __shfl(base, 0);
+    if (kind == 2) {
+      g.ulist[base + __popcll(bm & ((1ull << lane) - 1ull))] = (uint32_t)p;
+      float4* q3 = rec + (size_t)p * 4 + 3;
+      *q3 = make_float4(q3->x, 1.0f, 0.f, 0.f);      // brute flag of the row side (nms_core.h)
+    }
+  }
+}
+
+// exclusive prefix of the slot counters: one workgroup, 4096 slots per trip (16-byte loads, next trip's load in flight)
+__global__ __launch_bounds__(1024) void k_grid_scan(int n, GridDev g) {
+  __shared__ int s_w[16];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int M = (int)g.mask + 1;                      // multiple of 4096
+  const uint4* c4 = reinterpret_cast<const uint4*>(g.cnt);
+  uint4* o4 = reinterpret_cast<uint4*>(g.start);
+  int carry = 0;
+  uint4 v = c4[tid];
+  for (int t0 = 0; t0 < M / 4; t0 += 1024) {
+    const uint4 cur = v;
+    if (t0 + 1024 < M / 4) v = c4[t0 + 1024 + tid];
+    const int s1 = (int)cur.x, s2 = s1 + (int)cur.y, s3 = s2 + (int)cur.z, s4 = s3 + (int)cur.w;
+    int incl = s4;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const int u = __shfl_up(incl, d); if (lane >= d) incl += u; }
+    __syncthreads();
+    if (lane == 63) s_w[wv] = incl;
+    __syncthreads();
+    int wpre = 0, tot = 0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) { const int t = s_w[k]; if (k < wv) wpre += t; tot += t; }
+    const int ex = carry + wpre + incl - s4;
+    o4[t0 + tid] = make_uint4((uint32_t)ex, (uint32_t)(ex + s1), (uint32_t)(ex + s2), (uint32_t)(ex + s3));
+    carry += tot;
+  }
+  if (tid < 4) g.start[M + tid] = carry;
+  if (tid == 0) {
+    g.meta->n_indexed = carry;
+    const GridPlan gp = grid_plan(g.meta->bb);
+    g.meta->on = (gp.ok && carry > 0 && (long long)g.meta->n_brute * 16 <= (long long)n) ? 1 : 0;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_grid_scatter(const float4* __restrict__ rec, int n, GridDev g) {
+  if (g.meta->on == 0) return;
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  const uint32_t slot = g.slot_of[p];
+  if (slot == 0xffffffffu) return;
+  const int k = atomicSub(&g.cnt[slot], 1) - 1;        // the order inside a slot does not matter
+  const float4 q0 = rec[(size_t)p * 4];
+  g.sorted[g.start[slot] + k] = make_float4(q0.x, q0.y, q0.z, __uint_as_float((uint32_t)p));
 }
 
 __global__ void k_prep_quad(const float* __restrict__ polys, int stride, const uint32_t* __restrict__ order, int n,
@@ -236,8 +361,14 @@ struct Carve {
   int4* plan;                          // per-workgroup team plan (k_plan_teams)
   uint32_t *rows, *edges;
   long long ecap;
+  GridDev grid;                        // spatial index (rotated boxes, single list); grid.meta == NULL: not carved
+  size_t grid_zero_bytes;              // GridMeta + slot counters: one contiguous block, zeroed before every build
   size_t total;
 };
+
+// table slots of the spatial index (power of two, multiple of 4096)
+static uint32_t grid_slots(int64_t n) { return n >= 65536 ? 65536u : 16384u; }
+constexpr int64_t kGridMinN = 8192;    // below this the exhaustive cross phase is cheaper than building the index
 
 // One persistent launch runs the whole step loop (nms_core.h).  Grid: one 512-thread workgroup per CU at most --
 // all workgroups must be resident because they meet at team barriers; smaller problems get fewer workgroups
@@ -290,6 +421,21 @@ static int carve(void* base, int64_t n, int64_t nseg, int recq, int C, Carve* cv
   cv->rows = (uint32_t*)take(nn * 4);
   cv->ecap = (long long)C * (C - 1) / 2; if (cv->ecap < 1) cv->ecap = 1;
   cv->edges = (uint32_t*)take(nteams * (size_t)cv->ecap * 4);
+  cv->grid.meta = nullptr; cv->grid_zero_bytes = 0;
+  if (recq == RotGeom::RECQ && nseg == 1 && n >= kGridMinN) {
+    const uint32_t M = grid_slots(n);
+    cv->grid.mask = M - 1;
+    cv->grid_zero_bytes = align_up(sizeof(GridMeta)) + ((size_t)M + 4) * 4;
+    char* z = take(cv->grid_zero_bytes);
+    cv->grid.meta = (GridMeta*)z;
+    cv->grid.cnt = (int*)(z ? z + align_up(sizeof(GridMeta)) : nullptr);
+    cv->grid.start = (int*)take(((size_t)M + 4) * 4);
+    cv->grid.nparts = (int)((nn + 255) / 256);
+    cv->grid.bbpart = (int*)take((size_t)cv->grid.nparts * 16);
+    cv->grid.sorted = (float4*)take(nn * 16);
+    cv->grid.slot_of = (uint32_t*)take(nn * 4);
+    cv->grid.ulist = (uint32_t*)take(nn * 4);
+  }
   cv->total = off;
   return OBB_OK;
 }
@@ -303,7 +449,7 @@ static int nms_window(long long max_keep) {
   return (int)((w + 63) / 64 * 64);
 }
 
-constexpr size_t kPersistLdsMax = 152 * 1024;   // of the 160 KB per CU: exactly one workgroup per CU
+constexpr size_t kPersistLdsMax = 159 * 1024;   // of the 160 KB per CU: exactly one workgroup per CU
 
 template <class G>
 static int launch_persist(const NmsArgs& a, unsigned nb, hipStream_t st) {
@@ -401,6 +547,10 @@ static int run_nms(int kind, const float* boxes, int stride, const float* scores
 
   const unsigned gb = (unsigned)((n + T - 1) / T);
   int pre = 0;
+  // spatial index for the cross phases (grid.h): rotated boxes, one list, conservative rejects allowed (thr >= 0)
+  static int no_grid = -1;                                         // OBB_NMS_NO_GRID=1: A/B switch for measurements
+  if (no_grid < 0) { const char* e = getenv("OBB_NMS_NO_GRID"); no_grid = (e && atoi(e)) ? 1 : 0; }
+  const bool use_grid = !no_grid && kind == 0 && nseg == 1 && tie_bits == 0 && cv.grid.meta != nullptr && thr >= 0.f;
   {
     ProfScope ps(PROF_NMS_SORT, st);
     size_t tmp = cv.sort_tmp_bytes;
@@ -409,7 +559,8 @@ static int run_nms(int kind, const float* boxes, int stride, const float* scores
       uint32_t* k32b = reinterpret_cast<uint32_t*>(cv.keys_b);
       k_make_keys32<<<gb, T, 0, st>>>(scores, score_stride, kind == 0 ? boxes : nullptr, kind == 0 ? drop_small : 0, (int)n, k32a,
                                       cv.vals_a, cv.seg_begin, cv.seg_end, cv.keep_cnt, reinterpret_cast<uint4*>(cv.bar),
-                                      (long long)(cv.bar_bytes / 16));
+                                      (long long)(cv.bar_bytes / 16), reinterpret_cast<uint4*>(cv.grid.meta),
+                                      use_grid ? (long long)(cv.grid_zero_bytes / 16) : 0ll);
       pre = kNmsBarZeroed;
       if (rocprim::radix_sort_pairs(cv.sort_tmp, tmp, k32a, k32b, cv.vals_a, cv.vals_b, (size_t)n, 0, 32, st, false) != hipSuccess)
         return OBB_ERR_LAUNCH;
@@ -424,11 +575,19 @@ static int run_nms(int kind, const float* boxes, int stride, const float* scores
   }
   {
     ProfScope ps(PROF_NMS_PREP, st);
-    if (kind == 0) k_prep_rot<<<gb, T, 0, st>>>(boxes, cv.vals_b, drop_small, (int)n, cv.rec, cv.alive);
+    if (kind == 0) k_prep_rot<<<gb, T, 0, st>>>(boxes, cv.vals_b, drop_small, (int)n, cv.rec, cv.alive, use_grid ? cv.grid.bbpart : nullptr);
     else k_prep_quad<<<gb, T, 0, st>>>(boxes, stride, cv.vals_b, (int)n, cv.rec, cv.alive);
+    if (use_grid) {
+      k_grid_count<<<gb, T, 0, st>>>(cv.rec, cv.alive, (int)n, cv.grid);
+      k_grid_scan<<<1, 1024, 0, st>>>((int)n, cv.grid);
+      k_grid_scatter<<<gb, T, 0, st>>>(cv.rec, (int)n, cv.grid);
+    }
   }
 
-  NmsArgs a;
+  NmsArgs a{};
+  if (use_grid) {
+    a.gmeta = cv.grid.meta; a.gstart = cv.grid.start; a.gsorted = cv.grid.sorted; a.ulist = cv.grid.ulist; a.gmask = cv.grid.mask;
+  }
   a.rec = cv.rec; a.order = cv.vals_b; a.alive = cv.alive; a.seg_begin = cv.seg_begin; a.seg_end = cv.seg_end;
   a.keep_cnt = cv.keep_cnt; a.keep_out = keep_out;
   a.rows = cv.rows; a.nrows = cv.nrows; a.edges = cv.edges; a.nedges = cv.nedges;
@@ -470,7 +629,7 @@ static int run_merge_nms(const double* dets9, int64_t n, const int32_t* order, c
     return hipGetLastError() == hipSuccess ? OBB_OK : OBB_ERR_LAUNCH;
   }
   k_prep_quad64<<<(unsigned)((n + T - 1) / T), T, 0, st>>>(dets9, order, (int)n, cv.rec, cv.alive);
-  NmsArgs a;
+  NmsArgs a{};
   a.rec = cv.rec; a.order = reinterpret_cast<const uint32_t*>(order); a.alive = cv.alive;
   a.seg_begin = cv.seg_begin; a.seg_end = cv.seg_end; a.keep_cnt = cv.keep_cnt; a.keep_out = keep_out;
   a.rows = cv.rows; a.nrows = cv.nrows; a.edges = cv.edges; a.nedges = cv.nedges;

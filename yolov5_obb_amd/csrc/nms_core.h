@@ -33,6 +33,7 @@
 #include <hip/hip_runtime.h>
 #include "obb_device.h"
 #include "geom.h"
+#include "grid.h"
 
 namespace obb {
 
@@ -63,6 +64,12 @@ struct NmsArgs {
   float thr;
   double thr64;              // QuadGeom64 only (the merge threshold is a Python float)
   int cull;                  // 1: conservative rejects allowed (thr >= 0)
+  // spatial index over the boxes (grid.h); gmeta == NULL: none.  Built before the launch, read-only here.
+  const GridMeta* gmeta;
+  const int* gstart;         // [gmask + 2] first entry of every table slot in gsorted (exclusive prefix; [gmask + 1] = total)
+  const float4* gsorted;     // {x, y, r, sorted position as bits} in slot order
+  const uint32_t* ulist;     // [gmeta->n_brute] sorted positions of the boxes kept out of the index
+  uint32_t gmask;            // table size - 1 (power of two)
 };
 
 // ---- cost model shared by the planner (k_plan_teams) and the workgroups that follow its plan
@@ -164,12 +171,25 @@ struct WaveLds {
   uint32_t qbuf[128];      // stage 1: pairs that passed the hot loop
   uint32_t qbuf1b[128];    // stage 1b: pairs the cheap tests could not decide (IoU interval)
   uint32_t qbuf2[128];     // stage 2: pairs the register-only classifier could not decide (exact clip)
+  uint32_t qcol1b[128];    // grid cross: column position of a stage-1b entry
+  uint32_t qcol2[128];     // grid cross: column position of a stage-2 entry
   uint8_t q1bcol[128];     // cross phase: column lane of a stage-1b entry
   uint8_t q2col[128];      // cross phase: column lane of a stage-2 entry
   uint8_t cdead[64];
   uint8_t pad[64];
   float4 align16[0];
 };
+
+// The two expensive decision stages are real functions (one body per geometry): the pair phase and the forms of the
+// cross phase all drain their queues through them.
+template <class G, class TH>
+__device__ __attribute__((noinline)) int nms_stage_full(const float4* ra, const float4* rb, TH thr) {
+  return G::classify_full(ra, rb, thr);
+}
+template <class G, class TH>
+__device__ __attribute__((noinline)) bool nms_stage_exact(const float4* ra, const float4* rb, TH thr, float* scr) {
+  return G::hit_exact(ra, rb, thr, scr);
+}
 
 // Ring queue of pending (row, col) pairs in LDS; all bookkeeping is wave-uniform.
 struct PairQueue {
@@ -259,7 +279,7 @@ __device__ __forceinline__ void nms_pairs(const NmsArgs& a, int tm, int cn, cons
     if (lane < cnt) {
       packed = L.qbuf2[(Q2.head + lane) & 127];
       const uint32_t pi = cidx[packed >> 16], pj = cidx[packed & 0xffff];
-      hit = G::hit_exact(a.rec + (size_t)pi * G::RECQ, a.rec + (size_t)pj * G::RECQ, G::thr_of(a), L.scr + lane);
+      hit = nms_stage_exact<G>(a.rec + (size_t)pi * G::RECQ, a.rec + (size_t)pj * G::RECQ, G::thr_of(a), L.scr + lane);
     }
     const u64 hm = __ballot(hit);
     if (hm) {
@@ -283,7 +303,7 @@ __device__ __forceinline__ void nms_pairs(const NmsArgs& a, int tm, int cn, cons
     if (lane < cnt) {
       packed = L.qbuf1b[(Q1.head + lane) & 127];
       const uint32_t pi = cidx[packed >> 16], pj = cidx[packed & 0xffff];
-      res = G::classify_full(a.rec + (size_t)pi * G::RECQ, a.rec + (size_t)pj * G::RECQ, G::thr_of(a));
+      res = nms_stage_full<G>(a.rec + (size_t)pi * G::RECQ, a.rec + (size_t)pj * G::RECQ, G::thr_of(a));
     }
     emit(res == 1, packed);
     Q1.head = (Q1.head + cnt) & 127;
@@ -518,11 +538,17 @@ __device__ __forceinline__ int nms_resolve(const NmsArgs& a, int g, int tm, int 
 }
 
 // ------------------------------------------------------------------ B: kept rows x still-alive later positions
+// Exhaustive form: every row against every column.  Columns are either the positions [c0, se) (clist == NULL: one wave
+// per 64-position word of the bitmap, one atomicAnd per word) or the entries of a position list that fall into
+// [c0, se) (the boxes the spatial index leaves out, grid.h; one atomicAnd per killed box).
 template <class G>
-__device__ __forceinline__ void nms_cross(const NmsArgs& a, const uint32_t* rows, int nr, int c0, int se, int tw, int ntw, WaveLds<G>& L) {
+__device__ __forceinline__ void nms_cross(const NmsArgs& a, const uint32_t* rows, int nr, int c0, int se, const uint32_t* clist, int ncl,
+                                          int tw, int ntw, WaveLds<G>& L) {
+  const bool LIST = clist != nullptr;            // (wave-uniform; one body serves both forms)
   const int lane = threadIdx.x & 63;
-  const int w0 = c0 >> 6, w1 = (se - 1) >> 6;
+  const int w0 = LIST ? 0 : (c0 >> 6), w1 = LIST ? ((ncl + 63) >> 6) - 1 : ((se - 1) >> 6);
   const int ncw = w1 - w0 + 1, nrt = (nr + 63) >> 6;
+  if (ncw <= 0 || nr <= 0) return;
   // one wave per column word; the row tiles of a word are split over several waves only when there are fewer
   // column words than waves
   int rgn = ntw / ncw;
@@ -542,23 +568,34 @@ __device__ __forceinline__ void nms_cross(const NmsArgs& a, const uint32_t* rows
     c_items++;
     const int cw = (int)(item / rgn), rgi = (int)(item - (long long)cw * rgn);
     const int w = w0 + cw;
-    const int cbase = w * 64;
-    const int c = cbase + lane;
     const int rt_lo = rgi * rt_per, rt_hi = min(nrt, rt_lo + rt_per);
     if (rt_lo >= rt_hi) continue;
     // first row tile's loads are issued before the (slow, write-through) bitmap word arrives
     uint32_t rp0 = (rt_lo * 64 + lane < nr) ? rows[rt_lo * 64 + lane] : 0u;
-    u64 m = ldg_agent(a.alive + w);
-    if (cbase < c0) m &= ~((1ull << (c0 - cbase)) - 1ull);
-    if (cbase + 64 > se) m &= (1ull << (se - cbase)) - 1ull;
-    if (m == 0ull) continue;
-    const bool alive0 = (m >> lane) & 1ull;
+    uint32_t c;                                            // this lane's column position
+    bool alive0;
+    if (LIST) {
+      const int ci = w * 64 + lane;
+      c = ci < ncl ? clist[ci] : 0u;
+      alive0 = ci < ncl && (int)c >= c0 && (int)c < se;
+      if (alive0) alive0 = (ldg_agent(a.alive + (c >> 6)) >> (c & 63)) & 1ull;
+      if (__ballot(alive0) == 0ull) continue;
+    } else {
+      const int cbase = w * 64;
+      c = (uint32_t)(cbase + lane);
+      u64 m = ldg_agent(a.alive + w);
+      if (cbase < c0) m &= ~((1ull << (c0 - cbase)) - 1ull);
+      if (cbase + 64 > se) m &= (1ull << (se - cbase)) - 1ull;
+      if (m == 0ull) continue;
+      alive0 = (m >> lane) & 1ull;
+    }
     const float4 cq = alive0 ? a.rec[(size_t)c * G::RECQ] : make_float4(0.f, 0.f, 0.f, 0.f);
     float4 rq0 = a.rec[(size_t)rp0 * G::RECQ];
     uint32_t rp1 = (rt_lo + 1 < rt_hi && (rt_lo + 1) * 64 + lane < nr) ? rows[(rt_lo + 1) * 64 + lane] : 0u;
     bool alive = alive0;
     wave_sync();
     L.cdead[lane] = alive0 ? 0 : 1;
+    L.colpos[lane] = c;
     auto drain2 = [&](int cnt) {                   // stage 2: exact clip; entries carry the row position itself
       wave_sync();
       if (lane < cnt) {
@@ -566,7 +603,7 @@ __device__ __forceinline__ void nms_cross(const NmsArgs& a, const uint32_t* rows
         const uint32_t rowp = L.qbuf2[slot];
         const int cc = L.q2col[slot];
         if (!L.cdead[cc]) {
-          if (G::hit_exact(a.rec + (size_t)rowp * G::RECQ, a.rec + (size_t)(cbase + cc) * G::RECQ, G::thr_of(a), L.scr + lane)) L.cdead[cc] = 1;
+          if (nms_stage_exact<G>(a.rec + (size_t)rowp * G::RECQ, a.rec + (size_t)L.colpos[cc] * G::RECQ, G::thr_of(a), L.scr + lane)) L.cdead[cc] = 1;
         }
       }
       Q2.head = (Q2.head + cnt) & 127;
@@ -591,7 +628,7 @@ __device__ __forceinline__ void nms_cross(const NmsArgs& a, const uint32_t* rows
         rowp = L.qbuf1b[slot];
         cc = L.q1bcol[slot];
         if (!L.cdead[cc]) {
-          res = G::classify_full(a.rec + (size_t)rowp * G::RECQ, a.rec + (size_t)(cbase + cc) * G::RECQ, G::thr_of(a));
+          res = nms_stage_full<G>(a.rec + (size_t)rowp * G::RECQ, a.rec + (size_t)L.colpos[cc] * G::RECQ, G::thr_of(a));
           if (res == 1) L.cdead[cc] = 1;
         }
       }
@@ -625,7 +662,7 @@ __device__ __forceinline__ void nms_cross(const NmsArgs& a, const uint32_t* rows
           cc = it & 255;
           rowp = L.rowpos[rr];
           if (!L.cdead[cc]) {
-            res = G::classify_quick(a.rec + (size_t)rowp * G::RECQ, a.rec + (size_t)(cbase + cc) * G::RECQ, G::thr_of(a), cull);
+            res = G::classify_quick(a.rec + (size_t)rowp * G::RECQ, a.rec + (size_t)L.colpos[cc] * G::RECQ, G::thr_of(a), cull);
             if (res == 1) L.cdead[cc] = 1;
           }
         }
@@ -685,16 +722,189 @@ __device__ __forceinline__ void nms_cross(const NmsArgs& a, const uint32_t* rows
     }
     if (Q1.count > 0) { ctick(); drain1b(Q1.count); ctock(c_d1); c_n1++; alive = alive && !L.cdead[lane]; }
     if (Q2.count > 0) { ctick(); drain2(Q2.count); ctock(c_d2); c_n2++; alive = alive && !L.cdead[lane]; }
-    const u64 kill = __ballot(alive0 && !alive);
-    if (kill && lane == 0) {
-      // RETURNING atomic whose result is consumed: the wave's vmcnt then covers the completed read-modify-write
-      const u64 old = atomicAnd(a.alive + w, ~kill);
-      asm volatile("; kill applied %0" ::"v"((unsigned)(old >> 32) ^ (unsigned)old));
+    // RETURNING atomics whose result is consumed: the wave's vmcnt then covers the completed read-modify-write
+    if (LIST) {
+      if (alive0 && !alive) {
+        const u64 old = atomicAnd(a.alive + (c >> 6), ~(1ull << (c & 63)));
+        asm volatile("; kill applied %0" ::"v"((unsigned)(old >> 32) ^ (unsigned)old));
+      }
+    } else {
+      const u64 kill = __ballot(alive0 && !alive);
+      if (kill && lane == 0) {
+        const u64 old = atomicAnd(a.alive + w, ~kill);
+        asm volatile("; kill applied %0" ::"v"((unsigned)(old >> 32) ^ (unsigned)old));
+      }
     }
   }
   if (cprof) {
     a.prof[16] += c_loop; a.prof[17] += c_d1; a.prof[18] += c_d2; a.prof[19] += c_n1; a.prof[20] += c_n2; a.prof[21] += c_items;
   }
+}
+
+// Indexed form (grid.h): one wave per kept row walks the cells around the row, level by level.  A query window is a few
+// cell rows; the boxes of one cell row are ONE contiguous range of the cell-sorted array (the slot hash is linear in cx),
+// read coalesced by the 64 lanes.  Candidates that lie behind the chunk (position in [c0, se)) and whose circle touches
+// the row's go to the same staged decision as above -- cheap bounds on full waves, the IoU interval, the exact clip --
+// with explicit (row position, column position) entries; the alive bit is checked when an entry is taken out of a queue
+// (a box is usually dead by the time the second of two overlapping kept rows gets to it), kills are one atomicAnd per box.
+// Brute rows (flag in quad 3) are skipped here: the caller runs the exhaustive form for them.
+template <class G>
+__device__ __forceinline__ void nms_cross_grid(const NmsArgs& a, const GridPlan& gp, uint32_t level_mask, const uint32_t* rows, int nr,
+                                               int c0, int se, int tw, int ntw, WaveLds<G>& L) {
+  const int lane = threadIdx.x & 63;
+  const uint32_t mmask = a.gmask;
+  const int M = (int)mmask + 1;
+  PairQueue Q{L.qbuf, 0, 0}, Q1{L.qbuf1b, 0, 0}, Q2{L.qbuf2, 0, 0};
+  auto col_alive = [&](uint32_t cp) -> bool { return (ldg_agent(a.alive + (cp >> 6)) >> (cp & 63)) & 1ull; };
+  auto kill = [&](bool hit, uint32_t cp) {
+    if (hit) {
+      const u64 old = atomicAnd(a.alive + (cp >> 6), ~(1ull << (cp & 63)));
+      asm volatile("; kill applied %0" ::"v"((unsigned)(old >> 32) ^ (unsigned)old));
+    }
+  };
+  auto drain2 = [&](int cnt) {                     // stage 2: exact clip
+    wave_sync();
+    bool hit = false;
+    uint32_t cp = 0;
+    if (lane < cnt) {
+      const int slot = (Q2.head + lane) & 127;
+      const uint32_t rowp = L.qbuf2[slot];
+      cp = L.qcol2[slot];
+      if (col_alive(cp)) hit = nms_stage_exact<G>(a.rec + (size_t)rowp * G::RECQ, a.rec + (size_t)cp * G::RECQ, G::thr_of(a), L.scr + lane);
+    }
+    kill(hit, cp);
+    Q2.head = (Q2.head + cnt) & 127;
+    Q2.count -= cnt;
+    wave_sync();
+  };
+  auto push2 = [&](bool undecided, uint32_t rowp, uint32_t cp) {
+    const u64 m2 = __ballot(undecided);
+    if (undecided) {
+      const int slot = (Q2.head + Q2.count + __popcll(m2 & lanemask_lt())) & 127;
+      L.qbuf2[slot] = rowp;
+      L.qcol2[slot] = cp;
+    }
+    Q2.count += __popcll(m2);
+  };
+  auto drain1b = [&](int cnt) {                    // stage 1b: the IoU interval
+    wave_sync();
+    int res = 0;
+    uint32_t rowp = 0, cp = 0;
+    if (lane < cnt) {
+      const int slot = (Q1.head + lane) & 127;
+      rowp = L.qbuf1b[slot];
+      cp = L.qcol1b[slot];
+      if (col_alive(cp)) res = nms_stage_full<G>(a.rec + (size_t)rowp * G::RECQ, a.rec + (size_t)cp * G::RECQ, G::thr_of(a));
+    }
+    kill(res == 1, cp);
+    Q1.head = (Q1.head + cnt) & 127;
+    Q1.count -= cnt;
+    push2(res == 2, rowp, cp);
+    wave_sync();
+    if (Q2.count >= 64) drain2(64);
+  };
+
+  for (int item = tw; item < nr; item += ntw) {
+    const uint32_t rp = rows[item];
+    const float4 rq = a.rec[(size_t)rp * G::RECQ];
+    if (a.rec[(size_t)rp * G::RECQ + 3].y != 0.f) continue;      // brute row
+    auto drain = [&](int cnt) {                    // stage 1a: the cheap register-only tests (entries: column positions)
+      wave_sync();
+      int res = 0;
+      uint32_t cp = 0;
+      if (lane < cnt) {
+        cp = L.qbuf[(Q.head + lane) & 127];
+        if (col_alive(cp)) res = G::classify_quick(a.rec + (size_t)rp * G::RECQ, a.rec + (size_t)cp * G::RECQ, G::thr_of(a), true);
+      }
+      kill(res == 1, cp);
+      Q.head = (Q.head + cnt) & 127;
+      Q.count -= cnt;
+      {
+        const u64 m1 = __ballot(res == 3);
+        if (res == 3) {
+          const int slot = (Q1.head + Q1.count + __popcll(m1 & lanemask_lt())) & 127;
+          L.qbuf1b[slot] = rp;
+          L.qcol1b[slot] = cp;
+        }
+        Q1.count += __popcll(m1);
+      }
+      push2(res == 2, rp, cp);
+      wave_sync();
+      if (Q1.count >= 64) drain1b(64);
+      if (Q2.count >= 64) drain2(64);
+    };
+    // the window of every level first: a window with more cells than the table has slots would visit every entry several
+    // times -- then the whole array is scanned once instead (every indexed box is a candidate)
+    bool whole = false;
+    {
+      uint32_t lm = level_mask;
+      while (lm) {
+        const int lv = __builtin_ctz(lm);
+        lm &= lm - 1;
+        const float nc = floorf(2.f * grid_query_halfwidth(gp, lv, rq.x, rq.y, rq.z) * grid_level_inv_cell(gp, lv)) + 2.f;
+        if (!(nc * nc < 0.5f * (float)M)) whole = true;
+      }
+    }
+    // Pieces of the cell-sorted array are walked through ONE loop nest (one inlined copy of the drains): a piece is the
+    // contiguous range of one cell row of a window; the next 64 entries are in flight while the current ones are tested.
+    uint32_t lm = whole ? 1u : level_mask;
+    while (lm) {
+      const int lv = __builtin_ctz(lm);
+      lm &= lm - 1;
+      int nyr = 1, len = 0, cx0 = 0, cy0 = 0;
+      if (!whole) {
+        const float inv = grid_level_inv_cell(gp, lv);
+        const float d = grid_query_halfwidth(gp, lv, rq.x, rq.y, rq.z);
+        const int lastx = grid_last_cell(gp.xr, inv), lasty = grid_last_cell(gp.yr, inv);
+        cx0 = grid_cell(rq.x - d, gp.x0, inv, lastx);
+        cy0 = grid_cell(rq.y - d, gp.y0, inv, lasty);
+        len = grid_cell(rq.x + d, gp.x0, inv, lastx) - cx0 + 1;
+        nyr = grid_cell(rq.y + d, gp.y0, inv, lasty) - cy0 + 1;
+      }
+      for (int yb = 0; yb < nyr; yb += 64) {
+        // lane = one cell row of the window: its slots [i0, i0 + len) (possibly wrapping) -> up to two pieces
+        int s = 0, e = 0, e2 = 0;
+        if (whole) {
+          if (lane == 0) e = a.gstart[M];
+        } else if (yb + lane < nyr) {
+          const uint32_t i0 = grid_slot(lv, cx0, cy0 + yb + lane, mmask);
+          const int e1 = (int)i0 + len;
+          s = a.gstart[i0];
+          e = a.gstart[e1 <= M ? e1 : M];
+          if (e1 > M) e2 = a.gstart[e1 - M];
+        }
+        u64 m1 = __ballot(e > s), m2 = __ballot(e2 > 0);
+        while (m1 | m2) {
+          int ps, pe;
+          if (m1) {
+            const int k = __builtin_ctzll(m1);
+            m1 &= m1 - 1;
+            ps = __builtin_amdgcn_readlane(s, k); pe = __builtin_amdgcn_readlane(e, k);
+          } else {
+            const int k = __builtin_ctzll(m2);
+            m2 &= m2 - 1;
+            ps = 0; pe = __builtin_amdgcn_readlane(e2, k);
+          }
+          float4 nxt = (ps + lane < pe) ? a.gsorted[ps + lane] : make_float4(0.f, 0.f, 0.f, 0.f);
+          for (int k = ps; k < pe; k += 64) {
+            const float4 cq = nxt;
+            const bool valid = k + lane < pe;
+            if (k + 64 < pe) nxt = (k + 64 + lane < pe) ? a.gsorted[k + 64 + lane] : make_float4(0.f, 0.f, 0.f, 0.f);
+            const uint32_t cp = __float_as_uint(cq.w);
+            const float dx = cq.x - rq.x, dy = cq.y - rq.y, rs = rq.z + cq.z;
+            const bool pass = valid && (int)cp >= c0 && (int)cp < se && !(dx * dx + dy * dy > rs * rs);
+            if (__ballot(pass)) {
+              Q.push(pass, cp);
+              if (Q.count >= 64) drain(64);
+            }
+          }
+        }
+      }
+    }
+    if (Q.count > 0) drain(Q.count);
+  }
+  if (Q1.count > 0) drain1b(Q1.count);
+  if (Q2.count > 0) drain2(Q2.count);
 }
 
 // ------------------------------------------------------------------ the persistent kernel
@@ -734,6 +944,48 @@ __global__ __launch_bounds__(kNmsThreads) __attribute__((amdgpu_waves_per_eu(1, 
     if (prof) { const u64 t1 = wall_clock64(); a.prof[slot] += t1 - t0; t0 = t1; }
   };
 
+  // spatial index (grid.h): the cross phases query it instead of scanning every alive position
+  bool grid_on = false;
+  GridPlan gp = {};
+  uint32_t glevels = 0;
+  int n_brute = 0;
+  if constexpr (G::HAS_GRID) {
+    if (a.gmeta != nullptr && a.gmeta->on != 0) {
+      gp = grid_plan(a.gmeta->bb);
+      glevels = a.gmeta->level_mask;
+      n_brute = a.gmeta->n_brute;
+      grid_on = gp.ok != 0;
+    }
+  }
+  // kept rows x alive positions of [c0, c1)
+  auto cross = [&](const uint32_t* rows, int nr, int c0, int c1) {
+    if constexpr (G::HAS_GRID) {
+      if (grid_on) {
+        nms_cross_grid<G>(a, gp, glevels, rows, nr, c0, c1, tw, ntw, L);
+        if (n_brute > 0) {
+          // the boxes the index leaves out: brute kept rows against every column, every kept row against the brute columns
+          // (the chunk list in LDS is free between resolve and the next select: it takes the brute rows, capmax at a time)
+          for (int j0 = 0; j0 < nr; j0 += a.capmax) {
+            const int j1 = min(nr, j0 + a.capmax);
+            __syncthreads();
+            if (tid == 0) s_i[9] = 0;
+            __syncthreads();
+            for (int j = j0 + tid; j < j1; j += kNmsThreads) {
+              const uint32_t rp = rows[j];
+              if (a.rec[(size_t)rp * G::RECQ + 3].y != 0.f) cidx[atomicAdd(&s_i[9], 1)] = rp;
+            }
+            __syncthreads();
+            const int nbr = s_i[9];
+            if (nbr > 0) nms_cross<G>(a, cidx, nbr, c0, c1, nullptr, 0, tw, ntw, L);
+          }
+          nms_cross<G>(a, rows, nr, c0, c1, a.ulist, n_brute, tw, ntw, L);
+        }
+        return;
+      }
+    }
+    nms_cross<G>(a, rows, nr, c0, c1, nullptr, 0, tw, ntw, L);
+  };
+
   const int plan_chunk = a.cap_first < a.capmax ? a.cap_first : a.capmax;
   for (int g = g_first; g <= g_last; g += g_step) {
     const int sb = a.seg_begin[g], se = a.seg_end[g];
@@ -751,7 +1003,7 @@ __global__ __launch_bounds__(kNmsThreads) __attribute__((amdgpu_waves_per_eu(1, 
       if (cur >= wend) {                                   // open the next window
         const int wnew = (cur + a.window < se) ? cur + a.window : se;
         if (kept > 0) {
-          nms_cross<G>(a, a.rows + sb, kept, cur, wnew, tw, ntw, L);
+          cross(a.rows + sb, kept, cur, wnew);
           lap(5);
           if (!team_barrier(bar, &s_flag)) return;
           lap(0);
@@ -781,7 +1033,7 @@ __global__ __launch_bounds__(kNmsThreads) __attribute__((amdgpu_waves_per_eu(1, 
       const bool more = cur < wend && !(a.max_keep > 0 && kept + nr >= a.max_keep);
       if (nr > 0 && more) {
         const u64 tcz = (a.prof && tid == 0) ? wall_clock64() : 0ull;
-        nms_cross<G>(a, a.rows + sb + kept, nr, cur, wend, tw, ntw, L);
+        cross(a.rows + sb + kept, nr, cur, wend);
         if (a.prof && tid == 0) { atomicMax(a.prof + 31, wall_clock64() - tcz); }
         lap(5);
         if (!team_barrier(bar, &s_flag)) return;       // the kills are visible before anybody selects again

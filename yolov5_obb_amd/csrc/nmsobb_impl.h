@@ -827,7 +827,7 @@ static int run_nms_obb(const void* pred, int dtype, int64_t bs, int64_t A, int64
    }
   }
 
-  NmsArgs a;
+  NmsArgs a{};
   a.rec = nv.rec; a.order = nullptr; a.alive = nv.alive; a.seg_begin = nv.seg_begin; a.seg_end = nv.seg_end;   // keep_out: sorted positions
   a.keep_cnt = nv.keep_cnt; a.keep_out = cv.keep;
   a.rows = nv.rows; a.nrows = nv.nrows; a.edges = nv.edges; a.nedges = nv.nedges;
