@@ -37,3 +37,15 @@ def test_fast_iou_interval_contains_the_reference_value(oracle_lib, tmp_path):
     rc, out = _build_and_run("host_check_fastiou.cpp", "hc_fastiou", ["6000000", "11"], tmp_path)
     assert rc == 0, out
     assert "\nviolations=0" in out and "quick_bounds_violations=0" in out, out
+
+
+def test_spatial_index_never_skips_a_pair_the_circle_test_keeps(tmp_path):
+    """grid.h (the spatial index of the NMS cross phase), built and queried on the CPU with the kernels' own arithmetic:
+    for sampled rows, every non-brute box that RotGeom::cheap_reject does not reject is among the visited candidates --
+    uniform / clustered / class-offset / unit-square / mixed-size / outlier + degenerate / huge-coordinate sets."""
+    out = tmp_path / "hc_grid"
+    subprocess.run(["g++", "-O2", "-std=c++17", "-ffp-contract=off", f"-I{ROOT}/yolov5_obb_amd/csrc",
+                    f"{ROOT}/tests/native/host_check_grid.cpp", "-o", str(out), "-lm"], check=True)
+    for n, seed in ((20000, 1), (100000, 2)):
+        r = subprocess.run([str(out), str(n), str(seed)], capture_output=True, text=True)
+        assert r.returncode == 0 and "\nviolations=0" in r.stdout, r.stdout
