@@ -37,104 +37,73 @@ static bool cheap_reject(const Box& a, const Box& b) {
   return (d2 > rs * rs) && (fminf(a.ms2, b.ms2) >= 2.34e-9f * d2);
 }
 
-// RotGeom::cheap_reject as nms_cross_blocks applies it to a column of the cell order: the column's short side replaced by +inf
-static bool cheap_reject_indexed_col(const Box& row, const Box& col) {
-  Box c = col; c.ms2 = INFINITY;
-  return cheap_reject(row, c);
-}
+struct Index {
+  GridPlan gp; uint32_t mask; uint32_t level_mask;
+  std::vector<int> start; std::vector<int> sorted; std::vector<uint8_t> brute;
+};
 
-struct Plan { GridPlan gp; };
-
-static GridPlan plan_of(const std::vector<Box>& bx) {
+static Index build(const std::vector<Box>& bx, uint32_t M) {
+  Index ix; ix.mask = M - 1; ix.level_mask = 0;
   int bb[4] = {0x7fffffff, 0x7fffffff, (int)0x80000000, (int)0x80000000};
   for (const Box& b : bx)
     if ((b.x - b.x == 0.f) && (b.y - b.y == 0.f)) {
       bb[0] = std::min(bb[0], grid_f2o(b.x)); bb[1] = std::min(bb[1], grid_f2o(b.y));
       bb[2] = std::max(bb[2], grid_f2o(b.x)); bb[3] = std::max(bb[3], grid_f2o(b.y));
     }
-  return grid_plan(bb);
-}
-
-static uint32_t slot_of(const GridPlan& gp, const Box& b, uint32_t mask, int* level = nullptr) {
-  const int lv = grid_level(gp, b.r);
-  if (lv < 0 || lv >= kGridLevels) { printf("bad level %d\n", lv); exit(2); }
-  const float inv = grid_level_inv_cell(gp, lv);
-  const int cx = grid_cell(b.x, gp.x0, inv, grid_last_cell(gp.xr, inv));
-  const int cy = grid_cell(b.y, gp.y0, inv, grid_last_cell(gp.yr, inv));
-  if (level) *level = lv;
-  return grid_slot(lv, cx, cy, mask);
-}
-
-// the columns in cell order (k_grid_count / k_grid_scan / k_grid_scatter): blocks of <= 64 boxes of one slot
-static std::vector<std::vector<int>> column_blocks(const GridPlan& gp, const std::vector<Box>& bx, uint32_t M, std::vector<uint8_t>& brute) {
+  ix.gp = grid_plan(bb);
   const int n = (int)bx.size();
-  brute.assign(n, 0);
-  std::vector<std::vector<int>> per_slot(M);
+  ix.brute.assign(n, 0);
+  std::vector<uint32_t> slot(n, 0xffffffffu);
+  std::vector<int> cnt(M + 1, 0);
   for (int p = 0; p < n; p++) {
-    if (!gp.ok || grid_is_brute(gp, bx[p].x, bx[p].y, bx[p].r, bx[p].ms2)) { brute[p] = 1; continue; }
-    per_slot[slot_of(gp, bx[p], M - 1)].push_back(p);
+    const Box& b = bx[p];
+    if (!ix.gp.ok || grid_is_brute(ix.gp, b.x, b.y, b.r, b.ms2)) { ix.brute[p] = 1; continue; }
+    const int lv = grid_level(ix.gp, b.r);
+    const float inv = grid_level_inv_cell(ix.gp, lv);
+    const int cx = grid_cell(b.x, ix.gp.x0, inv, grid_last_cell(ix.gp.xr, inv));
+    const int cy = grid_cell(b.y, ix.gp.y0, inv, grid_last_cell(ix.gp.yr, inv));
+    slot[p] = grid_slot(lv, cx, cy, ix.mask);
+    ix.level_mask |= 1u << lv;
+    if (lv < 0 || lv >= kGridLevels) { printf("bad level %d\n", lv); exit(2); }
+    cnt[slot[p]]++;
   }
-  std::vector<std::vector<int>> blocks;
-  for (auto& v : per_slot)
-    for (size_t k = 0; k < v.size(); k += 64) blocks.emplace_back(v.begin() + k, v.begin() + std::min(v.size(), k + 64));
-  return blocks;
+  ix.start.assign(M + 1, 0);
+  for (uint32_t i = 0; i < M; i++) ix.start[i + 1] = ix.start[i] + cnt[i];
+  ix.sorted.assign(ix.start[M], -1);
+  std::vector<int> fill(ix.start.begin(), ix.start.end() - 1);
+  for (int p = 0; p < n; p++) if (slot[p] != 0xffffffffu) ix.sorted[fill[slot[p]]++] = p;
+  return ix;
 }
 
-// the rows' grid of one slab (nms_cross_blocks, build part)
-constexpr int kSlabRows = 1216, kSlabSlots = 2048;
-struct Slab { std::vector<int> ent; std::vector<int> start; uint32_t level_mask; int n_idx, ns; };
-static Slab build_slab(const GridPlan& gp, const std::vector<Box>& bx, const std::vector<int>& rows) {
-  Slab S; S.level_mask = 0; S.ns = (int)rows.size();
-  std::vector<int> slot(rows.size());
-  std::vector<int> cnt(kSlabSlots + 2, 0);
-  for (size_t k = 0; k < rows.size(); k++) {
-    const Box& b = bx[rows[k]];
-    if (grid_is_brute(gp, b.x, b.y, b.r, b.ms2)) slot[k] = kSlabSlots;
-    else { int lv; slot[k] = (int)slot_of(gp, b, kSlabSlots - 1, &lv); S.level_mask |= 1u << lv; }
-    cnt[slot[k]]++;
-  }
-  S.start.assign(kSlabSlots + 2, 0);
-  for (int i = 0; i <= kSlabSlots; i++) S.start[i + 1] = S.start[i] + cnt[i];
-  S.ent.assign(rows.size(), -1);
-  std::vector<int> fill(S.start.begin(), S.start.end());
-  for (size_t k = 0; k < rows.size(); k++) S.ent[fill[slot[k]]++] = rows[k];
-  S.n_idx = S.start[kSlabSlots];
-  return S;
-}
-
-// the rows a block enumerates (nms_cross_blocks, range part): marks them, returns how many entries were enumerated
-static long long block_rows(const GridPlan& gp, const std::vector<Box>& bx, const std::vector<int>& block, const Slab& S, std::vector<int>& mark,
-                            int stamp) {
-  float bx0 = INFINITY, bx1 = -INFINITY, by0 = INFINITY, by1 = -INFINITY, rmax = 0.f;
-  for (int p : block) {
-    bx0 = fminf(bx0, bx[p].x); bx1 = fmaxf(bx1, bx[p].x); by0 = fminf(by0, bx[p].y); by1 = fmaxf(by1, bx[p].y); rmax = fmaxf(rmax, bx[p].r);
-  }
+// the query of nms_cross_grid: marks every visited candidate, returns the number of entries scanned
+static long long query(const Index& ix, const std::vector<Box>& bx, int i, std::vector<int>& mark, int stamp) {
+  const Box& rq = bx[i];
+  const int M = (int)ix.mask + 1;
   long long scanned = 0;
-  auto enumerate = [&](int s, int t) { for (int e = s; e < t; e++) { mark[S.ent[e]] = stamp; scanned++; } };
+  auto scan = [&](int s, int e) { for (int k = s; k < e; k++) { mark[ix.sorted[k]] = stamp; scanned++; } };
+  // (same order of decisions as nms_cross_grid: windows with more cells than half the table -> one scan of everything)
   bool whole = false;
-  struct Comb { int lv, cx0, cy, len; };
-  std::vector<Comb> comb;
-  const float mag = fmaxf(fabsf(bx0), fabsf(bx1)) + fmaxf(fabsf(by0), fabsf(by1));
-  for (uint32_t lm = S.level_mask; lm; lm &= lm - 1) {
+  for (uint32_t lm = ix.level_mask; lm; lm &= lm - 1) {
     const int lv = __builtin_ctz(lm);
-    const float inv = grid_level_inv_cell(gp, lv);
-    const float d = grid_query_halfwidth_mag(gp, lv, mag, rmax);
-    const int lastx = grid_last_cell(gp.xr, inv), lasty = grid_last_cell(gp.yr, inv);
-    const int cx0 = grid_cell(bx0 - d, gp.x0, inv, lastx), cy0 = grid_cell(by0 - d, gp.y0, inv, lasty);
-    const int len = grid_cell(bx1 + d, gp.x0, inv, lastx) - cx0 + 1;
-    const int nyr = grid_cell(by1 + d, gp.y0, inv, lasty) - cy0 + 1;
-    if ((long long)len * nyr >= kSlabSlots / 2) whole = true;
-    for (int dy = 0; dy < nyr && comb.size() <= 64; dy++) comb.push_back({lv, cx0, cy0 + dy, len});
+    const float nc = floorf(2.f * grid_query_halfwidth(ix.gp, lv, rq.x, rq.y, rq.r) * grid_level_inv_cell(ix.gp, lv)) + 2.f;
+    if (!(nc * nc < 0.5f * (float)M)) whole = true;
   }
-  if (comb.size() > 64) whole = true;
-  if (whole) { enumerate(0, S.ns); return scanned; }
-  for (const Comb& c : comb) {
-    const uint32_t i0 = grid_slot(c.lv, c.cx0, c.cy, kSlabSlots - 1);
-    const int e1 = (int)i0 + c.len;
-    enumerate(S.start[i0], S.start[e1 <= kSlabSlots ? e1 : kSlabSlots]);
-    if (e1 > kSlabSlots) enumerate(0, S.start[e1 - kSlabSlots]);
+  if (whole) { scan(0, ix.start[M]); return scanned; }
+  for (uint32_t lm = ix.level_mask; lm; lm &= lm - 1) {
+    const int lv = __builtin_ctz(lm);
+    const float inv = grid_level_inv_cell(ix.gp, lv);
+    const float d = grid_query_halfwidth(ix.gp, lv, rq.x, rq.y, rq.r);
+    const int lastx = grid_last_cell(ix.gp.xr, inv), lasty = grid_last_cell(ix.gp.yr, inv);
+    const int cx0 = grid_cell(rq.x - d, ix.gp.x0, inv, lastx), cx1 = grid_cell(rq.x + d, ix.gp.x0, inv, lastx);
+    const int cy0 = grid_cell(rq.y - d, ix.gp.y0, inv, lasty), cy1 = grid_cell(rq.y + d, ix.gp.y0, inv, lasty);
+    const int len = cx1 - cx0 + 1;
+    for (int cy = cy0; cy <= cy1; cy++) {
+      const uint32_t i0 = grid_slot(lv, cx0, cy, ix.mask);
+      const int e1 = (int)i0 + len;
+      scan(ix.start[i0], ix.start[e1 <= M ? e1 : M]);
+      if (e1 > M) scan(0, ix.start[e1 - M]);
+    }
   }
-  enumerate(S.n_idx, S.ns);                        // the brute rows
   return scanned;
 }
 
@@ -176,38 +145,24 @@ int main(int argc, char** argv) {
       }
       bx.push_back(make_box(x, y, w, h));
     }
-    const uint32_t M = n >= 32768 ? 16384u : 4096u;
-    const GridPlan gp = plan_of(bx);
-    std::vector<uint8_t> brute;
-    const std::vector<std::vector<int>> blocks = column_blocks(gp, bx, M, brute);
-    long long nbrute = 0; for (int p = 0; p < n; p++) nbrute += brute[p];
-    long long scanned = 0, must = 0, v0 = violations, lanes = 0, nblk = 0;
+    const uint32_t M = n >= 65536 ? 65536u : 16384u;
+    const Index ix = build(bx, M);
+    long long nbrute = 0; for (int p = 0; p < n; p++) nbrute += ix.brute[p];
     std::vector<int> mark(n, -1);
-    int stamp = 0;
-    for (int rep = 0; rep < 3 && gp.ok && !blocks.empty(); rep++) {
-      // a slab of "kept rows": a random subset (dense and sparse ones), brute boxes included
-      const int ns = rep == 0 ? kSlabRows : (rep == 1 ? 300 : 97);
-      std::vector<int> rows;
-      for (int k = 0; k < ns; k++) rows.push_back((int)(urand() * n));
-      std::sort(rows.begin(), rows.end()); rows.erase(std::unique(rows.begin(), rows.end()), rows.end());
-      const Slab S = build_slab(gp, bx, rows);
-      for (int q = 0; q < 300; q++) {
-        const std::vector<int>& blk = blocks[(size_t)(urand() * blocks.size())];
-        scanned += block_rows(gp, bx, blk, S, mark, ++stamp);
-        lanes += (long long)blk.size(); nblk++;
-        for (int j : blk)
-          for (int i : rows) {
-            if (i == j) continue;
-            const bool rej = cheap_reject(bx[i], bx[j]);
-            if (rej != cheap_reject_indexed_col(bx[i], bx[j])) violations++;          // the +inf substitution changes nothing
-            if (!rej) { must++; if (mark[i] != stamp) violations++; }
-            checked++;
-          }
+    const int nq = 400;
+    long long scanned = 0, must = 0, v0 = violations;
+    for (int q = 0; q < nq; q++) {
+      const int i = (int)(urand() * n);
+      if (ix.brute[i]) continue;
+      scanned += query(ix, bx, i, mark, q);
+      for (int j = 0; j < n; j++) {
+        if (j == i || ix.brute[j]) continue;
+        if (!cheap_reject(bx[i], bx[j])) { must++; if (mark[j] != q) violations++; }
+        checked++;
       }
     }
-    printf("%-20s n=%d ok=%d e_base=%d brute=%lld blocks=%zu lanes/block=%.1f rows enumerated/block=%.1f must-test/block=%.1f violations=%lld\n",
-           names[dist], n, gp.ok, gp.e_base, nbrute, blocks.size(), nblk ? (double)lanes / nblk : 0.0, nblk ? (double)scanned / nblk : 0.0,
-           nblk ? (double)must / nblk : 0.0, violations - v0);
+    printf("%-20s n=%d ok=%d e_base=%d levels=0x%x brute=%lld scanned/query=%.1f must-test/query=%.1f violations=%lld\n", names[dist], n, ix.gp.ok,
+           ix.gp.e_base, ix.level_mask, nbrute, (double)scanned / nq, (double)must / nq, violations - v0);
   }
   printf("pairs checked=%lld\nviolations=%lld\n", checked, violations);
   return violations ? 1 : 0;

@@ -36,12 +36,10 @@ constexpr uint32_t kGridHashL = 0x85EBCA6Bu;
 constexpr float kGridIllCond = 2.34e-9f;           // the constant of RotGeom::cheap_reject
 
 struct GridMeta {
-  int bb[4];               // ordered-int encodings of min x, min y, max x, max y over the finite, alive boxes
-  int n_brute;             // boxes kept out of the cell order
-  int n_words;             // 64-entry blocks of the cell order (every slot padded to a multiple of 64)
-  int on;                  // 1: the index is complete and worth using (written by the scan kernel)
-  int n_indexed;
-  int pad[8];
+  int bb[4];               // ordered-int encodings of min x, min y, max x, max y over the finite boxes that take part
+  int n_brute;             // boxes kept out of the index
+  uint32_t level_mask;     // levels that hold at least one box
+  int pad[10];
 };
 
 // float <-> int with the same ordering (finite values and infinities; NaN must be filtered by the caller)
@@ -102,12 +100,9 @@ OBB_HD bool grid_is_brute(const GridPlan& p, float x, float y, float r, float ms
 }
 // half width of the query window of a row (x, y, r) at level L: r + R_L, plus the rounding of the fp32 differences
 // that the circle test and the cell arithmetic form (coordinates up to |x| + |x0|)
-OBB_HD float grid_query_halfwidth_mag(const GridPlan& p, int L, float mag_xy, float r) {
-  const float mag = mag_xy + fabsf(p.x0) + fabsf(p.y0) + p.xr + p.yr;
-  return (r + grid_level_radius(p, L)) * 1.0001f + mag * 4e-7f;
-}
 OBB_HD float grid_query_halfwidth(const GridPlan& p, int L, float x, float y, float r) {
-  return grid_query_halfwidth_mag(p, L, fabsf(x) + fabsf(y), r);
+  const float mag = fabsf(x) + fabsf(y) + fabsf(p.x0) + fabsf(p.y0) + p.xr + p.yr;
+  return (r + grid_level_radius(p, L)) * 1.0001f + mag * 4e-7f;
 }
 
 }  // namespace obb

@@ -78,24 +78,53 @@ __global__ void k_make_keys(const float* __restrict__ scores, int score_stride, 
   vals[i] = (uint32_t)i;
 }
 
+// min / max of four ordered ints over the workgroup (<= 1024 threads); every thread returns the result
+__device__ __forceinline__ void block_minmax4(int& a0, int& a1, int& b0, int& b1, int (*s_red)[4]) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    a0 = min(a0, __shfl_xor(a0, d)); a1 = min(a1, __shfl_xor(a1, d));
+    b0 = max(b0, __shfl_xor(b0, d)); b1 = max(b1, __shfl_xor(b1, d));
+  }
+  const int wv = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) { s_red[wv][0] = a0; s_red[wv][1] = a1; s_red[wv][2] = b0; s_red[wv][3] = b1; }
+  __syncthreads();
+  for (int k = 0; k < nw; k++) { a0 = min(a0, s_red[k][0]); a1 = min(a1, s_red[k][1]); b0 = max(b0, s_red[k][2]); b1 = max(b1, s_red[k][3]); }
+}
+
 // single list, no explicit tie word: 32-bit keys (half the sort traffic, half the radix passes)
 // (also: the single segment's table and the zeroing of the team-barrier block -- two launches fewer)
 __global__ void k_make_keys32(const float* __restrict__ scores, int score_stride, const float* __restrict__ dets5, int drop_small,
                               int n, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, int* seg_begin, int* seg_end,
-                              int* keep_cnt, uint4* __restrict__ bar16, long long n_bar16, uint4* __restrict__ grid16, long long n_grid16) {
+                              int* keep_cnt, uint4* __restrict__ bar16, long long n_bar16, uint4* __restrict__ grid16, long long n_grid16,
+                              int* __restrict__ bbpart) {
+  __shared__ int s_red[16][4];
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i == 0) { seg_begin[0] = 0; seg_end[0] = n; keep_cnt[0] = 0; }
   for (long long k = i; k < n_bar16; k += (long long)gridDim.x * blockDim.x) bar16[k] = make_uint4(0u, 0u, 0u, 0u);
   for (long long k = i; k < n_grid16; k += (long long)gridDim.x * blockDim.x) grid16[k] = make_uint4(0u, 0u, 0u, 0u);   // GridMeta + slot counters
-  if (i >= n) return;
-  uint32_t k = score_desc_key(scores[(size_t)i * score_stride]);
-  if (drop_small) {
-    float w = dets5[(size_t)i * 5 + 2], h = dets5[(size_t)i * 5 + 3];
-    float mn = (h < w) ? h : w;
-    if (mn < 0.001f) k = 0xFFFFFFFFu;
+  int bx0 = 0x7fffffff, by0 = 0x7fffffff, bx1 = (int)0x80000000, by1 = (int)0x80000000;
+  if (i < n) {
+    uint32_t k = score_desc_key(scores[(size_t)i * score_stride]);
+    bool ok = true;
+    if (drop_small) {
+      float w = dets5[(size_t)i * 5 + 2], h = dets5[(size_t)i * 5 + 3];
+      float mn = (h < w) ? h : w;
+      if (mn < 0.001f) { k = 0xFFFFFFFFu; ok = false; }
+    }
+    keys[i] = k;
+    vals[i] = (uint32_t)i;
+    if (bbpart != nullptr && ok) {
+      // bounding box of the finite centres of the boxes that take part: the extent of the data for the spatial index
+      // (grid.h), one partial per block, reduced by the blocks of the prep kernel (no atomics)
+      const float x = dets5[(size_t)i * 5], y = dets5[(size_t)i * 5 + 1];
+      if ((x - x == 0.f) && (y - y == 0.f)) { bx0 = bx1 = grid_f2o(x); by0 = by1 = grid_f2o(y); }
+    }
   }
-  keys[i] = k;
-  vals[i] = (uint32_t)i;
+  if (bbpart != nullptr) {
+    block_minmax4(bx0, by0, bx1, by1, s_red);
+    if (threadIdx.x == 0) { int* o = bbpart + (size_t)blockIdx.x * 4; o[0] = bx0; o[1] = by0; o[2] = bx1; o[3] = by1; }
+  }
 }
 
 __device__ __forceinline__ int key_lower_bound(const uint64_t* keys, int n, uint64_t target) {
@@ -120,166 +149,79 @@ __global__ void k_seg_bounds(const uint64_t* __restrict__ keys, int n, int nseg,
   keep_cnt[g] = 0;
 }
 
-// blockDim.x is a multiple of 64 and p starts at 0: every wave covers one word of the alive bitmap
-// bbpart (optional): [gridDim.x][4] bounding box of the block's finite, alive centres as ordered ints (grid.h); the NMS
-// kernel reduces the partials itself (no atomics, no extra launch)
-__global__ void k_prep_rot(const float* __restrict__ dets5, const uint32_t* __restrict__ order, int drop_small, int n,
-                           float4* __restrict__ rec, u64* __restrict__ alive, int* __restrict__ bbpart) {
+// ---------------------------------------------------------------- spatial index (grid.h): counting sort by cell
+struct GridDev {
+  GridMeta* meta;
+  int* bbpart; int nparts;     // per-block bounding boxes written by k_make_keys32
+  int* cnt;                    // [M + 4] boxes per table slot (zeroed before the launch; the in-kernel build leaves zeros)
+  int* start;                  // [M + 4] exclusive prefix, start[M] = total
+  int* wsum;                   // [kMaxTeams] per-workgroup totals of the in-kernel scan
+  float4* sorted;              // [n] {x, y, r, position}
+  uint32_t* slot_of;           // [n] table slot of position p, 0xffffffff: not indexed
+  uint32_t* ulist;             // [n] positions kept out of the index
+  uint32_t mask;               // M - 1
+};
+
+// blockDim.x is a multiple of 64 and p starts at 0: every wave covers one word of the alive bitmap.
+// With the spatial index (g.meta != NULL) the kernel also classifies the boxes for it: every block reduces the
+// bounding-box partials itself, then a box gets its table slot or goes to the brute list (grid.h).  The counting sort by
+// slot runs inside the NMS kernel, and only when a step needs the index (nms_core.h: grid_build).
+__global__ __launch_bounds__(256) void k_prep_rot(const float* __restrict__ dets5, const uint32_t* __restrict__ order, int drop_small, int n,
+                                                  float4* __restrict__ rec, u64* __restrict__ alive, GridDev g) {
   __shared__ int s_red[16][4];
-  int p = blockIdx.x * blockDim.x + threadIdx.x;
-  bool ok = false;
-  int bx0 = 0x7fffffff, by0 = 0x7fffffff, bx1 = (int)0x80000000, by1 = (int)0x80000000;
+  const int p = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63;
+  GridPlan gp = {};
+  if (g.meta != nullptr) {
+    int bx0 = 0x7fffffff, by0 = 0x7fffffff, bx1 = (int)0x80000000, by1 = (int)0x80000000;
+    for (int i = threadIdx.x; i < g.nparts; i += blockDim.x) {
+      const int4 q = reinterpret_cast<const int4*>(g.bbpart)[i];
+      bx0 = min(bx0, q.x); by0 = min(by0, q.y); bx1 = max(bx1, q.z); by1 = max(by1, q.w);
+    }
+    block_minmax4(bx0, by0, bx1, by1, s_red);
+    const int bb[4] = {bx0, by0, bx1, by1};
+    if (blockIdx.x == 0 && threadIdx.x == 0) { g.meta->bb[0] = bx0; g.meta->bb[1] = by0; g.meta->bb[2] = bx1; g.meta->bb[3] = by1; }
+    gp = grid_plan(bb);
+  }
+  bool ok = false, brute = false;
+  uint32_t slot = 0xffffffffu, lbit = 0u;
   if (p < n) {
     const float* d = dets5 + (size_t)order[p] * 5;
     float x = d[0], y = d[1], w = d[2], h = d[3], a = d[4];
     RBoxFeat f = rbox_make_feat(x, y, w, h, a);
     float4 q[4];
     RotGeom::pack(f, q);
-#pragma unroll
-    for (int k = 0; k < 4; k++) rec[(size_t)p * 4 + k] = q[k];
     float mn = (h < w) ? h : w;
     ok = !(drop_small && mn < 0.001f);
-    if (ok && (x - x == 0.f) && (y - y == 0.f)) { bx0 = bx1 = grid_f2o(x); by0 = by1 = grid_f2o(y); }
+    if (g.meta != nullptr && ok) {
+      if (!gp.ok || grid_is_brute(gp, q[0].x, q[0].y, q[0].z, q[0].w)) { brute = true; q[3].y = 1.0f; }   // brute flag of the row side (nms_core.h)
+      else {
+        const int lv = grid_level(gp, q[0].z);
+        const float inv = grid_level_inv_cell(gp, lv);
+        const int cx = grid_cell(q[0].x, gp.x0, inv, grid_last_cell(gp.xr, inv));
+        const int cy = grid_cell(q[0].y, gp.y0, inv, grid_last_cell(gp.yr, inv));
+        slot = grid_slot(lv, cx, cy, g.mask);
+        lbit = 1u << lv;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) rec[(size_t)p * 4 + k] = q[k];
+    if (g.meta != nullptr) g.slot_of[p] = slot;
   }
   const u64 m = __ballot(ok);
-  if ((threadIdx.x & 63) == 0 && (p & ~63) < n) alive[p >> 6] = m;
+  if (lane == 0 && (p & ~63) < n) alive[p >> 6] = m;
   if (p < 8) alive[((n + 63) >> 6) + p] = 0ull;      // guard words behind the last box (the bitmap is not memset)
-  if (bbpart != nullptr) {
+  if (g.meta != nullptr) {
 #pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-      bx0 = min(bx0, __shfl_xor(bx0, d)); by0 = min(by0, __shfl_xor(by0, d));
-      bx1 = max(bx1, __shfl_xor(bx1, d)); by1 = max(by1, __shfl_xor(by1, d));
-    }
-    const int wv = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
-    if ((threadIdx.x & 63) == 0) { s_red[wv][0] = bx0; s_red[wv][1] = by0; s_red[wv][2] = bx1; s_red[wv][3] = by1; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      for (int k = 1; k < nw; k++) { bx0 = min(bx0, s_red[k][0]); by0 = min(by0, s_red[k][1]); bx1 = max(bx1, s_red[k][2]); by1 = max(by1, s_red[k][3]); }
-      int* o = bbpart + (size_t)blockIdx.x * 4;
-      o[0] = bx0; o[1] = by0; o[2] = bx1; o[3] = by1;
+    for (int d = 32; d >= 1; d >>= 1) lbit |= __shfl_xor(lbit, d);
+    if (lane == 0 && lbit) atomicOr(&g.meta->level_mask, lbit);
+    const u64 bm = __ballot(brute);
+    if (bm) {
+      int base = 0;
+      if (lane == 0) base = atomicAdd(&g.meta->n_brute, __popcll(bm));
+      base = __shfl(base, 0);
+      if (brute) g.ulist[base + __popcll(bm & ((1ull << lane) - 1ull))] = (uint32_t)p;
     }
   }
-}
-
-// ---------------------------------------------------------------- spatial index of the cross phase (grid.h, nms_cross_blocks)
-// The boxes once more in CELL order: counting sort by table slot (count, scan, scatter), every slot padded to a multiple
-// of 64 entries so that a wave's block never straddles two slots, plus an alive bitmap in the same order.
-struct GridDev {
-  GridMeta* meta;
-  int* bbpart; int nparts;        // per-block bounding boxes written by k_prep_rot
-  int* cnt;                       // [M] boxes per table slot (zeroed before)
-  int* fill;                      // [M] scatter cursors (zeroed before)
-  int* start;                     // [M + 4] first entry of the slot (multiple of 64); [M] = padded total
-  float4* sorted;                 // [n + 63 * min(n, M)] {x, y, r, sorted position}
-  u64* calive;                    // [(n + 63 * min(n, M)) / 64 + 1]
-  uint32_t* slot_of;              // [n] table slot of position p, 0xffffffff: not in the cell order
-  uint32_t* ulist;                // [n] positions kept out of the cell order (brute boxes, grid.h)
-  uint32_t mask;                  // M - 1
-};
-
-__global__ __launch_bounds__(256) void k_grid_count(const float4* __restrict__ rec, const u64* __restrict__ alive, int n, GridDev g) {
-  __shared__ int s_red[4][4];
-  int bx0 = 0x7fffffff, by0 = 0x7fffffff, bx1 = (int)0x80000000, by1 = (int)0x80000000;
-  for (int i = threadIdx.x; i < g.nparts; i += blockDim.x) {
-    const int4 q = reinterpret_cast<const int4*>(g.bbpart)[i];
-    bx0 = min(bx0, q.x); by0 = min(by0, q.y); bx1 = max(bx1, q.z); by1 = max(by1, q.w);
-  }
-#pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) {
-    bx0 = min(bx0, __shfl_xor(bx0, d)); by0 = min(by0, __shfl_xor(by0, d));
-    bx1 = max(bx1, __shfl_xor(bx1, d)); by1 = max(by1, __shfl_xor(by1, d));
-  }
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  if (lane == 0) { s_red[wv][0] = bx0; s_red[wv][1] = by0; s_red[wv][2] = bx1; s_red[wv][3] = by1; }
-  __syncthreads();
-  int bb[4] = {s_red[0][0], s_red[0][1], s_red[0][2], s_red[0][3]};
-  for (int k = 1; k < 4; k++) { bb[0] = min(bb[0], s_red[k][0]); bb[1] = min(bb[1], s_red[k][1]); bb[2] = max(bb[2], s_red[k][2]); bb[3] = max(bb[3], s_red[k][3]); }
-  if (blockIdx.x == 0 && threadIdx.x == 0) { g.meta->bb[0] = bb[0]; g.meta->bb[1] = bb[1]; g.meta->bb[2] = bb[2]; g.meta->bb[3] = bb[3]; }
-  const GridPlan gp = grid_plan(bb);
-  const int p = blockIdx.x * blockDim.x + threadIdx.x;
-  bool brute = false;
-  uint32_t slot = 0xffffffffu;
-  if (p < n && ((alive[p >> 6] >> (p & 63)) & 1ull)) {
-    const float4 q0 = rec[(size_t)p * 4];
-    if (!gp.ok || grid_is_brute(gp, q0.x, q0.y, q0.z, q0.w)) brute = true;
-    else {
-      const int lv = grid_level(gp, q0.z);
-      const float inv = grid_level_inv_cell(gp, lv);
-      const int cx = grid_cell(q0.x, gp.x0, inv, grid_last_cell(gp.xr, inv));
-      const int cy = grid_cell(q0.y, gp.y0, inv, grid_last_cell(gp.yr, inv));
-      slot = grid_slot(lv, cx, cy, g.mask);
-      atomicAdd(&g.cnt[slot], 1);
-    }
-  }
-  if (p < n) g.slot_of[p] = slot;
-  const u64 bm = __ballot(brute);
-  if (bm) {
-    int base = 0;
-    if (lane == 0) base = atomicAdd(&g.meta->n_brute, __popcll(bm));
-    base = __shfl(base, 0);
-    if (brute) g.ulist[base + __popcll(bm & ((1ull << lane) - 1ull))] = (uint32_t)p;
-  }
-}
-
-// exclusive prefix of the PADDED slot counts: one workgroup, 4096 slots per trip (16-byte loads, next trip's load in flight)
-__global__ __launch_bounds__(1024) void k_grid_scan(int n, GridDev g) {
-  __shared__ int s_w[16];
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int M = (int)g.mask + 1;                      // multiple of 4096
-  const uint4* c4 = reinterpret_cast<const uint4*>(g.cnt);
-  uint4* o4 = reinterpret_cast<uint4*>(g.start);
-  int carry = 0, real = 0;
-  uint4 v = c4[tid];
-  for (int t0 = 0; t0 < M / 4; t0 += 1024) {
-    const uint4 cur = v;
-    if (t0 + 1024 < M / 4) v = c4[t0 + 1024 + tid];
-    real += (int)(cur.x + cur.y + cur.z + cur.w);
-    const int p0 = ((int)cur.x + 63) & ~63, p1 = ((int)cur.y + 63) & ~63, p2 = ((int)cur.z + 63) & ~63, p3 = ((int)cur.w + 63) & ~63;
-    const int s1 = p0, s2 = s1 + p1, s3 = s2 + p2, s4 = s3 + p3;
-    int incl = s4;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) { const int u = __shfl_up(incl, d); if (lane >= d) incl += u; }
-    __syncthreads();
-    if (lane == 63) s_w[wv] = incl;
-    __syncthreads();
-    int wpre = 0, tot = 0;
-#pragma unroll
-    for (int k = 0; k < 16; k++) { const int t = s_w[k]; if (k < wv) wpre += t; tot += t; }
-    const int ex = carry + wpre + incl - s4;
-    o4[t0 + tid] = make_uint4((uint32_t)ex, (uint32_t)(ex + s1), (uint32_t)(ex + s2), (uint32_t)(ex + s3));
-    carry += tot;
-  }
-  if (tid < 4) g.start[M + tid] = carry;
-#pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) real += __shfl_xor(real, d);
-  __syncthreads();
-  if (lane == 0) s_w[wv] = real;
-  __syncthreads();
-  if (tid == 0) {
-    int tot = 0;
-    for (int k = 0; k < 16; k++) tot += s_w[k];
-    g.meta->n_indexed = tot;
-    g.meta->n_words = carry >> 6;
-    const GridPlan gp = grid_plan(g.meta->bb);
-    g.meta->on = (gp.ok && tot > 0 && (long long)g.meta->n_brute * 16 <= (long long)n) ? 1 : 0;
-  }
-}
-
-// thread p: box p into its slot; thread s < M: the alive words of slot s (padding entries: 0, never read)
-__global__ __launch_bounds__(256) void k_grid_scatter(const float4* __restrict__ rec, int n, GridDev g) {
-  if (g.meta->on == 0) return;
-  const int p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p <= (int)g.mask) {
-    const int c = g.cnt[p];
-    const int w0 = g.start[p] >> 6;
-    for (int j = 0; j * 64 < c; j++) g.calive[w0 + j] = (c - j * 64 >= 64) ? ~0ull : ((1ull << (c - j * 64)) - 1ull);
-  }
-  if (p >= n) return;
-  const uint32_t slot = g.slot_of[p];
-  if (slot == 0xffffffffu) return;
-  const int k = atomicAdd(&g.fill[slot], 1);            // the order inside a slot does not matter
-  const float4 q0 = rec[(size_t)p * 4];
-  g.sorted[(size_t)g.start[slot] + k] = make_float4(q0.x, q0.y, q0.z, __uint_as_float((uint32_t)p));
 }
 
 __global__ void k_prep_quad(const float* __restrict__ polys, int stride, const uint32_t* __restrict__ order, int n,
@@ -378,13 +320,13 @@ struct Carve {
   int4* plan;                          // per-workgroup team plan (k_plan_teams)
   uint32_t *rows, *edges;
   long long ecap;
-  GridDev grid;                        // spatial index of the cross phase (rotated boxes, one list); grid.meta == NULL: not carved
-  size_t grid_zero_bytes;              // GridMeta + slot counters + scatter cursors: one contiguous block, zeroed before every build
+  GridDev grid;                        // spatial index (rotated boxes, single list); grid.meta == NULL: not carved
+  size_t grid_zero_bytes;              // GridMeta + slot counters: one contiguous block, zeroed before every build
   size_t total;
 };
 
-// table slots of the cell order (power of two, multiple of 4096)
-static uint32_t grid_slots(int64_t n) { return n >= 32768 ? 16384u : 4096u; }
+// table slots of the spatial index (power of two, multiple of 4096)
+static uint32_t grid_slots(int64_t n) { return n >= 262144 ? 65536u : 16384u; }
 constexpr int64_t kGridMinN = 8192;    // below this the exhaustive cross phase is cheaper than building the index
 
 // One persistent launch runs the whole step loop (nms_core.h).  Grid: one 512-thread workgroup per CU at most --
@@ -440,19 +382,17 @@ static int carve(void* base, int64_t n, int64_t nseg, int recq, int C, Carve* cv
   cv->edges = (uint32_t*)take(nteams * (size_t)cv->ecap * 4);
   cv->grid.meta = nullptr; cv->grid_zero_bytes = 0;
   if (recq == RotGeom::RECQ && nseg == 1 && n >= kGridMinN) {
-    const size_t M = grid_slots(n);
-    const size_t npad = nn + 63 * (nn < M ? nn : M);
-    cv->grid.mask = (uint32_t)(M - 1);
-    cv->grid_zero_bytes = align_up(sizeof(GridMeta)) + 2 * M * 4;
+    const uint32_t M = grid_slots(n);
+    cv->grid.mask = M - 1;
+    cv->grid_zero_bytes = align_up(sizeof(GridMeta)) + ((size_t)M + 4) * 4;
     char* z = take(cv->grid_zero_bytes);
     cv->grid.meta = (GridMeta*)z;
     cv->grid.cnt = (int*)(z ? z + align_up(sizeof(GridMeta)) : nullptr);
-    cv->grid.fill = z ? cv->grid.cnt + M : nullptr;
-    cv->grid.start = (int*)take((M + 4) * 4);
+    cv->grid.start = (int*)take(((size_t)M + 4) * 4);
+    cv->grid.wsum = (int*)take((size_t)1024 * 4);
     cv->grid.nparts = (int)((nn + 255) / 256);
     cv->grid.bbpart = (int*)take((size_t)cv->grid.nparts * 16);
-    cv->grid.sorted = (float4*)take(npad * 16);
-    cv->grid.calive = (u64*)take((npad / 64 + 2) * 8);
+    cv->grid.sorted = (float4*)take(nn * 16);
     cv->grid.slot_of = (uint32_t*)take(nn * 4);
     cv->grid.ulist = (uint32_t*)take(nn * 4);
   }
@@ -469,7 +409,7 @@ static int nms_window(long long max_keep) {
   return (int)((w + 63) / 64 * 64);
 }
 
-constexpr size_t kPersistLdsMax = 156 * 1024;   // of the 160 KB per CU: exactly one workgroup per CU
+constexpr size_t kPersistLdsMax = 159 * 1024;   // of the 160 KB per CU: exactly one workgroup per CU
 
 template <class G>
 static int launch_persist(const NmsArgs& a, unsigned nb, hipStream_t st) {
@@ -521,8 +461,8 @@ static int nms_steps(int kind, NmsArgs& a, const Carve& cv, int64_t nseg, int64_
       fprintf(stderr, "    resolve: edges total %llu, max per chunk %llu, chunk sizes total %llu, chunks resolved from LDS %llu\n", h[25], h[27], h[28], h[26]);
       fprintf(stderr, "    pairs phase per workgroup (wave 0): longest %.1f us, sum over steps and workgroups / workgroups %.1f us; cross: longest single %.1f us\n", h[29] * 0.01, h[24] ? h[30] * 0.01 / h[24] : 0.0, h[31] * 0.01);
       fprintf(stderr, "    workgroups: %llu, busy time max %.1f us, mean %.1f us\n", h[24], h[22] * 0.01, h[24] ? h[23] * 0.01 / h[24] : 0.0);
-      fprintf(stderr, "    cross, wave 0: items %llu row-loops %.1f us, drains %llu = %.1f us | indexed form: slab builds %.1f us, ranges %.1f us, rows enumerated %llu, whole-slab blocks %llu\n",
-              h[21], h[16] * 0.01, h[19], h[17] * 0.01, h[18] * 0.01, h[15] * 0.01, h[20], h[10]);
+      fprintf(stderr, "    cross, wave 0: items %llu row-loops / scans %.1f us, stage-1 drains %llu = %.1f us | exhaustive: stage-2 drains %llu = %.1f us | indexed: per-item setup %.1f us, blocks %llu, queued pairs %llu, parts (sum over steps) %llu\n",
+              h[21], h[16] * 0.01, h[19], h[17] * 0.01, h[20], h[18] * 0.01, h[18] * 0.01, h[20], h[15], h[10]);
     }
     if (hipMemsetAsync(cv.prof, 0, 32 * 8, st) != hipSuccess) return OBB_ERR_LAUNCH;
     a.prof = cv.prof;
@@ -568,9 +508,9 @@ static int run_nms(int kind, const float* boxes, int stride, const float* scores
   const unsigned gb = (unsigned)((n + T - 1) / T);
   int pre = 0;
   // spatial index for the cross phases (grid.h): rotated boxes, one list, conservative rejects allowed (thr >= 0)
-  static int no_index = -1;                                        // OBB_NMS_NO_INDEX=1: A/B switch for measurements
-  if (no_index < 0) { const char* e = getenv("OBB_NMS_NO_INDEX"); no_index = (e && atoi(e)) ? 1 : 0; }
-  const bool use_grid = !no_index && kind == 0 && nseg == 1 && tie_bits == 0 && cv.grid.meta != nullptr && thr >= 0.f;
+  static int no_grid = -1;                                         // OBB_NMS_NO_GRID=1: A/B switch for measurements
+  if (no_grid < 0) { const char* e = getenv("OBB_NMS_NO_GRID"); no_grid = (e && atoi(e)) ? 1 : 0; }
+  const bool use_grid = !no_grid && kind == 0 && nseg == 1 && tie_bits == 0 && cv.grid.meta != nullptr && thr >= 0.f && n < (1ll << 24);
   {
     ProfScope ps(PROF_NMS_SORT, st);
     size_t tmp = cv.sort_tmp_bytes;
@@ -580,7 +520,7 @@ static int run_nms(int kind, const float* boxes, int stride, const float* scores
       k_make_keys32<<<gb, T, 0, st>>>(scores, score_stride, kind == 0 ? boxes : nullptr, kind == 0 ? drop_small : 0, (int)n, k32a,
                                       cv.vals_a, cv.seg_begin, cv.seg_end, cv.keep_cnt, reinterpret_cast<uint4*>(cv.bar),
                                       (long long)(cv.bar_bytes / 16), reinterpret_cast<uint4*>(cv.grid.meta),
-                                      use_grid ? (long long)(cv.grid_zero_bytes / 16) : 0ll);
+                                      use_grid ? (long long)(cv.grid_zero_bytes / 16) : 0ll, (use_grid && kind == 0) ? cv.grid.bbpart : nullptr);
       pre = kNmsBarZeroed;
       if (rocprim::radix_sort_pairs(cv.sort_tmp, tmp, k32a, k32b, cv.vals_a, cv.vals_b, (size_t)n, 0, 32, st, false) != hipSuccess)
         return OBB_ERR_LAUNCH;
@@ -595,18 +535,17 @@ static int run_nms(int kind, const float* boxes, int stride, const float* scores
   }
   {
     ProfScope ps(PROF_NMS_PREP, st);
-    if (kind == 0) k_prep_rot<<<gb, T, 0, st>>>(boxes, cv.vals_b, drop_small, (int)n, cv.rec, cv.alive, use_grid ? cv.grid.bbpart : nullptr);
+    GridDev gd = cv.grid;
+    if (!use_grid) gd.meta = nullptr;
+    if (kind == 0) k_prep_rot<<<gb, T, 0, st>>>(boxes, cv.vals_b, drop_small, (int)n, cv.rec, cv.alive, gd);
     else k_prep_quad<<<gb, T, 0, st>>>(boxes, stride, cv.vals_b, (int)n, cv.rec, cv.alive);
-    if (use_grid) {
-      k_grid_count<<<gb, T, 0, st>>>(cv.rec, cv.alive, (int)n, cv.grid);
-      k_grid_scan<<<1, 1024, 0, st>>>((int)n, cv.grid);
-      const unsigned gsc = (unsigned)(((size_t)(n > (int64_t)cv.grid.mask + 1 ? n : (int64_t)cv.grid.mask + 1) + T - 1) / T);
-      k_grid_scatter<<<gsc, T, 0, st>>>(cv.rec, (int)n, cv.grid);
-    }
   }
 
   NmsArgs a{};
-  if (use_grid) { a.gmeta = cv.grid.meta; a.gsorted = cv.grid.sorted; a.calive = cv.grid.calive; a.ulist = cv.grid.ulist; }
+  if (use_grid) {
+    a.gmeta = cv.grid.meta; a.gslot_of = cv.grid.slot_of; a.gcnt = cv.grid.cnt; a.gstart = cv.grid.start; a.gsorted = cv.grid.sorted;
+    a.gwsum = cv.grid.wsum; a.ulist = cv.grid.ulist; a.gmask = cv.grid.mask;
+  }
   a.rec = cv.rec; a.order = cv.vals_b; a.alive = cv.alive; a.seg_begin = cv.seg_begin; a.seg_end = cv.seg_end;
   a.keep_cnt = cv.keep_cnt; a.keep_out = keep_out;
   a.rows = cv.rows; a.nrows = cv.nrows; a.edges = cv.edges; a.nedges = cv.nedges;

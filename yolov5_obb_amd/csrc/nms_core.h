@@ -64,11 +64,17 @@ struct NmsArgs {
   float thr;
   double thr64;              // QuadGeom64 only (the merge threshold is a Python float)
   int cull;                  // 1: conservative rejects allowed (thr >= 0)
-  // Spatial index of the cross phase (grid.h, nms_cross_blocks); gmeta == NULL: none, the cross phase stays exhaustive.
-  const GridMeta* gmeta;     // built before the launch: extent of the data, number of blocks, number of brute boxes, on / off
-  const float4* gsorted;     // the boxes in cell order {x, y, r, sorted position}, every slot padded to 64 entries
-  u64* calive;               // alive bitmap in cell order (padding: 0)
-  const uint32_t* ulist;     // sorted positions of the boxes kept out of the cell order (brute)
+  // Spatial index over the boxes (grid.h); gmeta == NULL: none.  The prep kernel classifies the boxes (table slot or
+  // brute list); the counting sort itself runs INSIDE this kernel, and only when a step keeps enough rows to need it
+  // (grid_build): a call whose chunks keep a few hundred rows never pays for it.
+  const GridMeta* gmeta;
+  const uint32_t* gslot_of;  // [n] table slot of position p, 0xffffffff: not indexed (brute, or dropped from the start)
+  int* gcnt;                 // [gmask + 1] zero before the launch and after every build
+  int* gstart;               // [gmask + 2] first entry of every table slot in gsorted (exclusive prefix; [gmask + 1] = total)
+  float4* gsorted;           // {x, y, r, sorted position as bits} in slot order
+  int* gwsum;                // [grid size] per-workgroup totals of the distributed scan
+  const uint32_t* ulist;     // [gmeta->n_brute] sorted positions of the boxes kept out of the index
+  uint32_t gmask;            // table size - 1 (power of two)
 };
 
 // ---- cost model shared by the planner (k_plan_teams) and the workgroups that follow its plan
@@ -170,16 +176,17 @@ struct WaveLds {
   uint32_t qbuf[128];      // stage 1: pairs that passed the hot loop
   uint32_t qbuf1b[128];    // stage 1b: pairs the cheap tests could not decide (IoU interval)
   uint32_t qbuf2[128];     // stage 2: pairs the register-only classifier could not decide (exact clip)
+  uint32_t qcol1b[128];    // grid cross: column position of a stage-1b entry
+  uint32_t qcol2[128];     // grid cross: column position of a stage-2 entry
   uint8_t q1bcol[128];     // cross phase: column lane of a stage-1b entry
   uint8_t q2col[128];      // cross phase: column lane of a stage-2 entry
   uint8_t cdead[64];
   uint8_t pad[64];
-  uint32_t ranges[128];    // indexed cross: ranges of slab rows within reach of the block
   float4 align16[0];
 };
 
-// The two expensive decision stages are real functions (one body per geometry) shared by the pair phase and both forms
-// of the cross phase.
+// The two expensive decision stages are real functions (one body per geometry): the pair phase and the forms of the
+// cross phase all drain their queues through them.
 template <class G, class TH>
 __device__ __attribute__((noinline)) int nms_stage_full(const float4* ra, const float4* rb, TH thr) {
   return G::classify_full(ra, rb, thr);
@@ -536,11 +543,17 @@ __device__ __forceinline__ int nms_resolve(const NmsArgs& a, int g, int tm, int 
 }
 
 // ------------------------------------------------------------------ B: kept rows x still-alive later positions
+// Exhaustive form: every row against every column.  Columns are either the positions [c0, se) (clist == NULL: one wave
+// per 64-position word of the bitmap, one atomicAnd per word) or the entries of a position list that fall into
+// [c0, se) (the boxes the spatial index leaves out, grid.h; one atomicAnd per killed box).
 template <class G>
-__device__ __forceinline__ void nms_cross(const NmsArgs& a, const uint32_t* rows, int nr, int c0, int se, int tw, int ntw, WaveLds<G>& L) {
+__device__ __forceinline__ void nms_cross(const NmsArgs& a, const uint32_t* rows, int nr, int c0, int se, const uint32_t* clist, int ncl,
+                                          int tw, int ntw, WaveLds<G>& L) {
+  const bool LIST = clist != nullptr;            // (wave-uniform; one body serves both forms)
   const int lane = threadIdx.x & 63;
-  const int w0 = c0 >> 6, w1 = (se - 1) >> 6;
+  const int w0 = LIST ? 0 : (c0 >> 6), w1 = LIST ? ((ncl + 63) >> 6) - 1 : ((se - 1) >> 6);
   const int ncw = w1 - w0 + 1, nrt = (nr + 63) >> 6;
+  if (ncw <= 0 || nr <= 0) return;
   // one wave per column word; the row tiles of a word are split over several waves only when there are fewer
   // column words than waves
   int rgn = ntw / ncw;
@@ -560,23 +573,34 @@ __device__ __forceinline__ void nms_cross(const NmsArgs& a, const uint32_t* rows
     c_items++;
     const int cw = (int)(item / rgn), rgi = (int)(item - (long long)cw * rgn);
     const int w = w0 + cw;
-    const int cbase = w * 64;
-    const int c = cbase + lane;
     const int rt_lo = rgi * rt_per, rt_hi = min(nrt, rt_lo + rt_per);
     if (rt_lo >= rt_hi) continue;
     // first row tile's loads are issued before the (slow, write-through) bitmap word arrives
     uint32_t rp0 = (rt_lo * 64 + lane < nr) ? rows[rt_lo * 64 + lane] : 0u;
-    u64 m = ldg_agent(a.alive + w);
-    if (cbase < c0) m &= ~((1ull << (c0 - cbase)) - 1ull);
-    if (cbase + 64 > se) m &= (1ull << (se - cbase)) - 1ull;
-    if (m == 0ull) continue;
-    const bool alive0 = (m >> lane) & 1ull;
+    uint32_t c;                                            // this lane's column position
+    bool alive0;
+    if (LIST) {
+      const int ci = w * 64 + lane;
+      c = ci < ncl ? clist[ci] : 0u;
+      alive0 = ci < ncl && (int)c >= c0 && (int)c < se;
+      if (alive0) alive0 = (ldg_agent(a.alive + (c >> 6)) >> (c & 63)) & 1ull;
+      if (__ballot(alive0) == 0ull) continue;
+    } else {
+      const int cbase = w * 64;
+      c = (uint32_t)(cbase + lane);
+      u64 m = ldg_agent(a.alive + w);
+      if (cbase < c0) m &= ~((1ull << (c0 - cbase)) - 1ull);
+      if (cbase + 64 > se) m &= (1ull << (se - cbase)) - 1ull;
+      if (m == 0ull) continue;
+      alive0 = (m >> lane) & 1ull;
+    }
     const float4 cq = alive0 ? a.rec[(size_t)c * G::RECQ] : make_float4(0.f, 0.f, 0.f, 0.f);
     float4 rq0 = a.rec[(size_t)rp0 * G::RECQ];
     uint32_t rp1 = (rt_lo + 1 < rt_hi && (rt_lo + 1) * 64 + lane < nr) ? rows[(rt_lo + 1) * 64 + lane] : 0u;
     bool alive = alive0;
     wave_sync();
     L.cdead[lane] = alive0 ? 0 : 1;
+    L.colpos[lane] = c;
     auto drain2 = [&](int cnt) {                   // stage 2: exact clip; entries carry the row position itself
       wave_sync();
       if (lane < cnt) {
@@ -584,7 +608,7 @@ __device__ __forceinline__ void nms_cross(const NmsArgs& a, const uint32_t* rows
         const uint32_t rowp = L.qbuf2[slot];
         const int cc = L.q2col[slot];
         if (!L.cdead[cc]) {
-          if (nms_stage_exact<G>(a.rec + (size_t)rowp * G::RECQ, a.rec + (size_t)(cbase + cc) * G::RECQ, G::thr_of(a), L.scr + lane)) L.cdead[cc] = 1;
+          if (nms_stage_exact<G>(a.rec + (size_t)rowp * G::RECQ, a.rec + (size_t)L.colpos[cc] * G::RECQ, G::thr_of(a), L.scr + lane)) L.cdead[cc] = 1;
         }
       }
       Q2.head = (Q2.head + cnt) & 127;
@@ -609,7 +633,7 @@ __device__ __forceinline__ void nms_cross(const NmsArgs& a, const uint32_t* rows
         rowp = L.qbuf1b[slot];
         cc = L.q1bcol[slot];
         if (!L.cdead[cc]) {
-          res = nms_stage_full<G>(a.rec + (size_t)rowp * G::RECQ, a.rec + (size_t)(cbase + cc) * G::RECQ, G::thr_of(a));
+          res = nms_stage_full<G>(a.rec + (size_t)rowp * G::RECQ, a.rec + (size_t)L.colpos[cc] * G::RECQ, G::thr_of(a));
           if (res == 1) L.cdead[cc] = 1;
         }
       }
@@ -643,7 +667,7 @@ __device__ __forceinline__ void nms_cross(const NmsArgs& a, const uint32_t* rows
           cc = it & 255;
           rowp = L.rowpos[rr];
           if (!L.cdead[cc]) {
-            res = G::classify_quick(a.rec + (size_t)rowp * G::RECQ, a.rec + (size_t)(cbase + cc) * G::RECQ, G::thr_of(a), cull);
+            res = G::classify_quick(a.rec + (size_t)rowp * G::RECQ, a.rec + (size_t)L.colpos[cc] * G::RECQ, G::thr_of(a), cull);
             if (res == 1) L.cdead[cc] = 1;
           }
         }
@@ -703,11 +727,18 @@ __device__ __forceinline__ void nms_cross(const NmsArgs& a, const uint32_t* rows
     }
     if (Q1.count > 0) { ctick(); drain1b(Q1.count); ctock(c_d1); c_n1++; alive = alive && !L.cdead[lane]; }
     if (Q2.count > 0) { ctick(); drain2(Q2.count); ctock(c_d2); c_n2++; alive = alive && !L.cdead[lane]; }
-    const u64 kill = __ballot(alive0 && !alive);
-    if (kill && lane == 0) {
-      // RETURNING atomic whose result is consumed: the wave's vmcnt then covers the completed read-modify-write
-      const u64 old = atomicAnd(a.alive + w, ~kill);
-      asm volatile("; kill applied %0" ::"v"((unsigned)(old >> 32) ^ (unsigned)old));
+    // RETURNING atomics whose result is consumed: the wave's vmcnt then covers the completed read-modify-write
+    if (LIST) {
+      if (alive0 && !alive) {
+        const u64 old = atomicAnd(a.alive + (c >> 6), ~(1ull << (c & 63)));
+        asm volatile("; kill applied %0" ::"v"((unsigned)(old >> 32) ^ (unsigned)old));
+      }
+    } else {
+      const u64 kill = __ballot(alive0 && !alive);
+      if (kill && lane == 0) {
+        const u64 old = atomicAnd(a.alive + w, ~kill);
+        asm volatile("; kill applied %0" ::"v"((unsigned)(old >> 32) ^ (unsigned)old));
+      }
     }
   }
   if (cprof) {
@@ -715,347 +746,311 @@ __device__ __forceinline__ void nms_cross(const NmsArgs& a, const uint32_t* rows
   }
 }
 
-// ------------------------------------------------------------------ B': the cross phase through two spatial indices
-// The exhaustive form above tests every kept row of a chunk against every still-alive later position: O(kept x alive)
-// circle tests -- cheap with a few hundred kept boxes (S-clustered, K = 300), the whole run time with thousands (class
-// offsets, K = 3000: the natural shape of BASELINE configs[3]) or tens of thousands (S-uniform).  Only pairs whose
-// circumscribed circles touch can have IoU > 0.
+// Indexed form (grid.h): a kept row only needs the boxes of the cells around it.  The boxes of the call sit once more in
+// CELL order (built before the launch: count, scan, scatter); a query window is a few cell rows per level, and the boxes of
+// one cell row are ONE contiguous range of that array (the slot hash is linear in cx), read coalesced by the 64 lanes
+// in blocks of 64 entries.  Candidates that lie behind the chunk (position in [c0, se)) and whose circle touches the
+// row's go to the same staged decision as above -- cheap bounds on full waves, the IoU interval, the exact clip -- with
+// explicit (row position, column position) entries; the alive bit is checked when an entry is taken out of a queue (a
+// box is usually dead by the time the second of two overlapping kept rows gets to it), kills are one atomicAnd per box.
+// Brute rows (flag in quad 3) are skipped here: the caller runs the exhaustive form for them.
 //
-// COLUMNS: the boxes of the call are stored once more in CELL order (grid.h: levels by circumradius, square cells of
-// side 2 x the level's largest radius, slot = hash of (level, cx, cy); built before the launch: count, scan, scatter),
-// every slot padded to a multiple of 64 entries, with an alive bitmap in the same order.  A wave takes one 64-entry block
-// = boxes of similar size out of one cell: their bounding box is about one cell.
-// ROWS: per slab of <= kSlabRows kept rows every workgroup builds its own copy of a small hashed grid over the rows'
-// centres in LDS (the chunk list's 32 KB are free between resolve and the next select), same levels and hash.
-// The wave then enumerates only the rows of the cells within reach of its block's bounding box -- a handful of contiguous
-// LDS ranges (the slot hash is linear in cx) -- and tests each of them against its 64 columns exactly as the exhaustive
-// form does: wave-uniform control flow, the row record an LDS broadcast, full lanes.
-//
-// Exactness: the indices decide which pairs get RotGeom::cheap_reject at all; a pair they skip is one that test would
-// have rejected.  That holds for pairs of well-conditioned boxes (grid.h "brute" rule: the conditioning part of
-// cheap_reject cannot fail anywhere inside the data's bounding box).  Brute rows sit in an extra slot that every block
-// enumerates; brute columns are not in the cell order at all: they come as a plain list whose blocks enumerate every row.
-// Both see the full cheap_reject.  tests/native/host_check_grid.cpp checks the window arithmetic on the CPU.
-constexpr int kSlabRows = 1216;
-constexpr int kSlabSlots = 2048;                   // power of two; slot kSlabSlots = the brute rows
-constexpr int kSlabMinRows = 96;                   // fewer kept rows: the exhaustive form is cheaper than building the index
-struct SlabLds {
-  float4 q0[kSlabRows];                            // {x, y, r, short side^2} in slot order
-  uint32_t pos[kSlabRows];                         // sorted position of the row
-  uint32_t start[kSlabSlots + 2];                  // first entry of slot i; [kSlabSlots + 1] = number of rows in the slab
-};
-
+// Work distribution: an item is (row, part): part j of kw takes every kw-th block of the row's candidate ranges, so that
+// a step with few kept rows still occupies every wave of the team; items go round-robin over the team's waves.  Per item
+// the blocks are first listed in LDS (lanes = cell rows of a window, in parallel), then read four at a time -- four
+// independent 16-byte loads per lane in flight: the phase is bound by memory latency, not by arithmetic.
 template <class G>
-__device__ __forceinline__ void nms_cross_blocks(const NmsArgs& a, const GridPlan& gp, const uint32_t* rows, int nr, int c0, int se, int tw,
-                                                 int ntw, WaveLds<G>& L, SlabLds& S, int* s_i) {
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const bool cull = a.cull != 0;
-  constexpr uint32_t kMask = kSlabSlots - 1;
-  const int nwords = a.gmeta->n_words, n_brute = a.gmeta->n_brute;
-  const int nitems = nwords + ((n_brute + 63) >> 6);
-  const float inf = __builtin_inff();
+__device__ __forceinline__ void nms_cross_grid(const NmsArgs& a, const GridPlan& gp, uint32_t level_mask, const uint32_t* rows, int nr,
+                                               int c0, int se, int tw, int ntw, WaveLds<G>& L) {
+  const int lane = threadIdx.x & 63;
+  const uint32_t mmask = a.gmask;
+  const int M = (int)mmask + 1;
+  int kw = (3 * ntw + nr - 1) / nr;                // (measured: ~3 items per wave balance best; fewer, larger items were slower)
+  kw = kw < 1 ? 1 : (kw > 16 ? 16 : kw);
+  const int n_items = nr * kw;
   const bool cprof = a.prof != nullptr && blockIdx.x == 0 && threadIdx.x == 0;
-  u64 ct0 = 0, c_enum = 0, c_drain = 0, c_build = 0, c_rng = 0, c_nd = 0, c_items = 0, c_rows = 0, c_whole = 0;
+  u64 ct0 = 0, c_pro = 0, c_scan = 0, c_drain = 0, c_nd = 0, c_items = 0, c_blocks = 0, c_pass = 0;
   auto ctick = [&]() { if (cprof) ct0 = wall_clock64(); };
   auto ctock = [&](u64& acc) { if (cprof) acc += wall_clock64() - ct0; };
-  for (int r0 = 0; r0 < nr; r0 += kSlabRows) {
-    const int ns = min(kSlabRows, nr - r0);
-    // ---- build the rows' grid: every workgroup its own copy (identical content; the order inside a slot does not matter)
-    ctick();
-    __syncthreads();                               // the previous slab's readers / the chunk list's readers are done
-    for (int i = tid; i < kSlabSlots + 2; i += kNmsThreads) S.start[i] = 0u;
-    if (tid == 0) s_i[10] = 0;
-    __syncthreads();
-    constexpr int kPer = (kSlabRows + kNmsThreads - 1) / kNmsThreads;
-    float4 rq[kPer];
-    uint32_t rpos[kPer];
-    int rslot[kPer];
-    uint32_t lbits = 0u;
-#pragma unroll
-    for (int k = 0; k < kPer; k++) {
-      const int j = tid + k * kNmsThreads;
-      rslot[k] = -1;
-      if (j < ns) {
-        rpos[k] = rows[r0 + j];
-        rq[k] = a.rec[(size_t)rpos[k] * G::RECQ];
-        if (grid_is_brute(gp, rq[k].x, rq[k].y, rq[k].z, rq[k].w)) rslot[k] = kSlabSlots;
-        else {
-          const int lv = grid_level(gp, rq[k].z);
-          const float inv = grid_level_inv_cell(gp, lv);
-          const int cx = grid_cell(rq[k].x, gp.x0, inv, grid_last_cell(gp.xr, inv));
-          const int cy = grid_cell(rq[k].y, gp.y0, inv, grid_last_cell(gp.yr, inv));
-          rslot[k] = (int)grid_slot(lv, cx, cy, kMask);
-          lbits |= 1u << lv;
-        }
-        atomicAdd(&S.start[rslot[k] + 1], 1u);
-      }
+  uint32_t* blist = L.rowpos;                      // rowpos[64] | colpos[64]: 128 block entries (first entry << 7 | entries)
+  PairQueue Q{L.qbuf, 0, 0}, Q1{L.qbuf1b, 0, 0}, Q2{L.qbuf2, 0, 0};
+  auto col_alive = [&](uint32_t cp) -> bool { return (ldg_agent(a.alive + (cp >> 6)) >> (cp & 63)) & 1ull; };
+  // kills: RETURNING atomics whose results are consumed at the end of the phase -- the wave's vmcnt then covers the
+  // completed read-modify-writes, and no drain waits for its own
+  u64 seen = 0ull;
+  auto kill = [&](bool hit, uint32_t cp) {
+    if (hit) seen ^= atomicAnd(a.alive + (cp >> 6), ~(1ull << (cp & 63)));
+  };
+  auto drain2 = [&](int cnt) {                     // stage 2: exact clip
+    wave_sync();
+    bool hit = false;
+    uint32_t cp = 0;
+    if (lane < cnt) {
+      const int slot = (Q2.head + lane) & 127;
+      const uint32_t rowp = L.qbuf2[slot];
+      cp = L.qcol2[slot];
+      if (col_alive(cp)) hit = nms_stage_exact<G>(a.rec + (size_t)rowp * G::RECQ, a.rec + (size_t)cp * G::RECQ, G::thr_of(a), L.scr + lane);
     }
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) lbits |= __shfl_xor(lbits, d);
-    if (lane == 0 && lbits) atomicOr(&s_i[10], (int)lbits);
-    __syncthreads();
-    {                                              // exclusive prefix over start[1 .. kSlabSlots + 1], in place
-      constexpr int kEach = (kSlabSlots + 1 + kNmsThreads - 1) / kNmsThreads;
-      uint32_t v[kEach], sum = 0u;
-#pragma unroll
-      for (int k = 0; k < kEach; k++) {
-        const int i = 1 + tid * kEach + k;
-        v[k] = i <= kSlabSlots + 1 ? S.start[i] : 0u;
-        sum += v[k];
-      }
-      uint32_t incl = sum;
-#pragma unroll
-      for (int d = 1; d < 64; d <<= 1) { const uint32_t u = __shfl_up(incl, d); if (lane >= d) incl += u; }
-      if (lane == 63) s_i[wv] = (int)incl;
-      __syncthreads();
-      uint32_t run = incl - sum;
-#pragma unroll
-      for (int k = 0; k < kNmsWaves; k++) if (k < wv) run += (uint32_t)s_i[k];
-#pragma unroll
-      for (int k = 0; k < kEach; k++) {
-        const int i = 1 + tid * kEach + k;
-        if (i <= kSlabSlots + 1) S.start[i] = run;
-        run += v[k];
-      }
+    kill(hit, cp);
+    Q2.head = (Q2.head + cnt) & 127;
+    Q2.count -= cnt;
+    wave_sync();
+  };
+  auto push2 = [&](bool undecided, uint32_t rowp, uint32_t cp) {
+    const u64 m2 = __ballot(undecided);
+    if (undecided) {
+      const int slot = (Q2.head + Q2.count + __popcll(m2 & lanemask_lt())) & 127;
+      L.qbuf2[slot] = rowp;
+      L.qcol2[slot] = cp;
     }
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < kPer; k++) {
-      if (rslot[k] >= 0) {
-        const uint32_t at = atomicAdd(&S.start[rslot[k] + 1], 1u);     // start[s + 1] walks from begin(s) to end(s) = begin(s + 1)
-        S.q0[at] = rq[k];
-        S.pos[at] = rpos[k];
-      }
+    Q2.count += __popcll(m2);
+  };
+  auto drain1b = [&](int cnt) {                    // stage 1b: the IoU interval
+    wave_sync();
+    int res = 0;
+    uint32_t rowp = 0, cp = 0;
+    if (lane < cnt) {
+      const int slot = (Q1.head + lane) & 127;
+      rowp = L.qbuf1b[slot];
+      cp = L.qcol1b[slot];
+      if (col_alive(cp)) res = nms_stage_full<G>(a.rec + (size_t)rowp * G::RECQ, a.rec + (size_t)cp * G::RECQ, G::thr_of(a));
     }
-    __syncthreads();
-    const uint32_t level_mask = (uint32_t)s_i[10];
-    const int n_idx = (int)S.start[kSlabSlots];    // indexed rows: entries [0, n_idx); brute rows: [n_idx, ns)
-    ctock(c_build);
+    kill(res == 1, cp);
+    Q1.head = (Q1.head + cnt) & 127;
+    Q1.count -= cnt;
+    push2(res == 2, rowp, cp);
+    wave_sync();
+    if (Q2.count >= 64) drain2(64);
+  };
 
-    // ---- columns: one wave per 64-entry block of the cell order, then per 64 entries of the brute list
-    PairQueue Q{L.qbuf, 0, 0}, Q1{L.qbuf1b, 0, 0}, Q2{L.qbuf2, 0, 0};
-    for (int item = tw; item < nitems; item += ntw) {
-      const bool listed = item >= nwords;          // a block of the brute list
-      uint32_t cpos = 0u;
-      bool alive0 = false;
-      float4 cq = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (!listed) {
-        const u64 m = ldg_agent(a.calive + item);
-        if (m == 0ull) continue;
-        if ((m >> lane) & 1ull) {
-          const float4 ent = a.gsorted[(size_t)item * 64 + lane];
-          cpos = __float_as_uint(ent.w);
-          alive0 = (int)cpos >= c0 && (int)cpos < se;
-          cq = make_float4(ent.x, ent.y, ent.z, inf);      // indexed = well conditioned: the short side never decides
-        }
-      } else {
-        const int ui = (item - nwords) * 64 + lane;
-        if (ui < n_brute) {
-          cpos = a.ulist[ui];
-          alive0 = (int)cpos >= c0 && (int)cpos < se && ((ldg_agent(a.alive + (cpos >> 6)) >> (cpos & 63)) & 1ull);
-          if (alive0) cq = a.rec[(size_t)cpos * G::RECQ];
-        }
-      }
-      if (__ballot(alive0) == 0ull) continue;
-      c_items++;
-      ctick();
-      bool alive = alive0;
+  for (int item = tw; item < n_items; item += ntw) {
+    const int row = item / kw, part = item - row * kw;
+    c_items++;
+    ctick();
+    const uint32_t rp = rows[row];
+    const float4 rq = a.rec[(size_t)rp * G::RECQ];
+    if (a.rec[(size_t)rp * G::RECQ + 3].y != 0.f) continue;      // brute row
+    auto drain = [&](int cnt) {                    // stage 1a: the cheap register-only tests (entries: column positions)
       wave_sync();
-      L.cdead[lane] = alive0 ? 0 : 1;
-      L.colpos[lane] = cpos;
-      // ---- the rows within reach of the block: ranges of slab entries, packed (first | end << 16) in L.ranges
-      int nranges = 0;
+      int res = 0;
+      uint32_t cp = 0;
+      if (lane < cnt) {
+        cp = L.qbuf[(Q.head + lane) & 127];              // (alive when it was queued: checked in the scan)
+        res = G::classify_quick(a.rec + (size_t)rp * G::RECQ, a.rec + (size_t)cp * G::RECQ, G::thr_of(a), true);
+      }
+      kill(res == 1, cp);
+      Q.head = (Q.head + cnt) & 127;
+      Q.count -= cnt;
       {
-        float bx0 = alive0 ? cq.x : inf, bx1 = alive0 ? cq.x : -inf, by0 = alive0 ? cq.y : inf, by1 = alive0 ? cq.y : -inf;
-        float rmax = alive0 ? cq.z : 0.f;
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) {
-          bx0 = fminf(bx0, __shfl_xor(bx0, d)); bx1 = fmaxf(bx1, __shfl_xor(bx1, d));
-          by0 = fminf(by0, __shfl_xor(by0, d)); by1 = fmaxf(by1, __shfl_xor(by1, d));
-          rmax = fmaxf(rmax, __shfl_xor(rmax, d));
+        const u64 m1 = __ballot(res == 3);
+        if (res == 3) {
+          const int slot = (Q1.head + Q1.count + __popcll(m1 & lanemask_lt())) & 127;
+          L.qbuf1b[slot] = rp;
+          L.qcol1b[slot] = cp;
         }
-        bool whole = listed;
-        int ncomb = 0, my_lv = -1, my_cx0 = 0, my_cy = 0, my_len = 0;
-        if (!whole) {
-          const float mag = fmaxf(fabsf(bx0), fabsf(bx1)) + fmaxf(fabsf(by0), fabsf(by1));
-          for (uint32_t lm = level_mask; lm; lm &= lm - 1) {
-            const int lv = __builtin_ctz(lm);
-            const float inv = grid_level_inv_cell(gp, lv);
-            const float d = grid_query_halfwidth_mag(gp, lv, mag, rmax);
-            const int lastx = grid_last_cell(gp.xr, inv), lasty = grid_last_cell(gp.yr, inv);
-            const int cx0 = grid_cell(bx0 - d, gp.x0, inv, lastx), cy0 = grid_cell(by0 - d, gp.y0, inv, lasty);
-            const int len = grid_cell(bx1 + d, gp.x0, inv, lastx) - cx0 + 1;
-            const int nyr = grid_cell(by1 + d, gp.y0, inv, lasty) - cy0 + 1;
-            if ((long long)len * nyr >= kSlabSlots / 2) whole = true;      // would visit entries several times over
-            if (lane >= ncomb && lane < ncomb + nyr) { my_lv = lv; my_cx0 = cx0; my_cy = cy0 + (lane - ncomb); my_len = len; }
-            ncomb += nyr;
-          }
-          if (ncomb > 64) whole = true;
-        }
-        wave_sync();
-        if (whole) {
-          c_whole++;
-          if (lane == 0) L.ranges[0] = 0u | ((uint32_t)ns << 16);
-          nranges = 1;
-        } else {
-          int s = 0, t = 0, t2 = 0;
-          if (my_lv >= 0) {                        // lane = one cell row of one level's window: its slots [i0, i0 + len)
-            const uint32_t i0 = grid_slot(my_lv, my_cx0, my_cy, kMask);
-            const int e1 = (int)i0 + my_len;
-            s = (int)S.start[i0];
-            t = (int)S.start[e1 <= kSlabSlots ? e1 : kSlabSlots];
-            if (e1 > kSlabSlots) t2 = (int)S.start[e1 - kSlabSlots];       // the slots wrap: second piece [0, e1 - M)
-          }
-          const u64 m1 = __ballot(t > s), m2 = __ballot(t2 > 0);
-          const int n1 = __popcll(m1), n2 = __popcll(m2);
-          if (t > s) L.ranges[__popcll(m1 & lanemask_lt())] = (uint32_t)s | ((uint32_t)t << 16);
-          if (t2 > 0) L.ranges[n1 + __popcll(m2 & lanemask_lt())] = 0u | ((uint32_t)t2 << 16);
-          nranges = n1 + n2;
-          if (ns > n_idx) { if (lane == 0) L.ranges[nranges] = (uint32_t)n_idx | ((uint32_t)ns << 16); nranges++; }   // the brute rows
-        }
-        wave_sync();
+        Q1.count += __popcll(m1);
       }
-      auto drain2 = [&](int cnt) {                 // stage 2: exact clip; entries (row position, column lane)
-        wave_sync();
-        if (lane < cnt) {
-          const int slot = (Q2.head + lane) & 127;
-          const uint32_t rowp = L.qbuf2[slot];
-          const int cc = L.q2col[slot];
-          if (!L.cdead[cc]) {
-            if (nms_stage_exact<G>(a.rec + (size_t)rowp * G::RECQ, a.rec + (size_t)L.colpos[cc] * G::RECQ, G::thr_of(a), L.scr + lane)) L.cdead[cc] = 1;
-          }
+      push2(res == 2, rp, cp);
+      wave_sync();
+      if (Q1.count >= 64) drain1b(64);
+      if (Q2.count >= 64) drain2(64);
+    };
+    // the window of every level first: a window with more cells than half the table has slots would visit every entry
+    // several times -- then the whole array is scanned once instead (every indexed box is a candidate)
+    bool whole = false;
+    for (uint32_t lm = level_mask; lm; lm &= lm - 1) {
+      const int lv = __builtin_ctz(lm);
+      const float nc = floorf(2.f * grid_query_halfwidth(gp, lv, rq.x, rq.y, rq.z) * grid_level_inv_cell(gp, lv)) + 2.f;
+      if (!(nc * nc < 0.5f * (float)M)) whole = true;
+    }
+    // Lanes = the cell rows of the windows of ALL levels (one table look-up round trip for the whole row, not one per
+    // level); more than 64 of them: several passes.
+    int ncomb = 0;
+    if (whole) ncomb = 1;
+    else
+      for (uint32_t lm = level_mask; lm; lm &= lm - 1) {
+        const int lv = __builtin_ctz(lm);
+        const float inv = grid_level_inv_cell(gp, lv);
+        const float d = grid_query_halfwidth(gp, lv, rq.x, rq.y, rq.z);
+        const int lasty = grid_last_cell(gp.yr, inv);
+        ncomb += grid_cell(rq.y + d, gp.y0, inv, lasty) - grid_cell(rq.y - d, gp.y0, inv, lasty) + 1;
+      }
+    int bc = 0;                                    // blocks of this row listed so far (all parts)
+    for (int cb = 0; cb < ncomb; cb += 64) {
+      // this lane's cell row: its slots [i0, i0 + len) (possibly wrapping) -> up to two pieces [s, e), [0, e2)
+      int s = 0, e = 0, e2 = 0;
+      if (whole) {
+        if (lane == 0) e = a.gstart[M];
+      } else {
+        const int my = cb + lane;
+        int before = 0, my_lv = -1, my_cx0 = 0, my_cy = 0, my_len = 0;
+        for (uint32_t lm = level_mask; lm; lm &= lm - 1) {
+          const int lv = __builtin_ctz(lm);
+          const float inv = grid_level_inv_cell(gp, lv);
+          const float d = grid_query_halfwidth(gp, lv, rq.x, rq.y, rq.z);
+          const int lastx = grid_last_cell(gp.xr, inv), lasty = grid_last_cell(gp.yr, inv);
+          const int cx0 = grid_cell(rq.x - d, gp.x0, inv, lastx), cy0 = grid_cell(rq.y - d, gp.y0, inv, lasty);
+          const int len = grid_cell(rq.x + d, gp.x0, inv, lastx) - cx0 + 1;
+          const int nyr = grid_cell(rq.y + d, gp.y0, inv, lasty) - cy0 + 1;
+          if (my >= before && my < before + nyr) { my_lv = lv; my_cx0 = cx0; my_cy = cy0 + (my - before); my_len = len; }
+          before += nyr;
         }
-        Q2.head = (Q2.head + cnt) & 127;
-        Q2.count -= cnt;
-        wave_sync();
-      };
-      auto push2 = [&](bool undecided, uint32_t rowp, uint32_t cc) {
-        const u64 m2 = __ballot(undecided);
-        if (undecided) {
-          const int slot = (Q2.head + Q2.count + __popcll(m2 & lanemask_lt())) & 127;
-          L.qbuf2[slot] = rowp;
-          L.q2col[slot] = (uint8_t)cc;
-        }
-        Q2.count += __popcll(m2);
-      };
-      auto drain1b = [&](int cnt) {                // stage 1b: the IoU interval
-        wave_sync();
-        int res = 0;
-        uint32_t rowp = 0, cc = 0;
-        if (lane < cnt) {
-          const int slot = (Q1.head + lane) & 127;
-          rowp = L.qbuf1b[slot];
-          cc = L.q1bcol[slot];
-          if (!L.cdead[cc]) {
-            res = nms_stage_full<G>(a.rec + (size_t)rowp * G::RECQ, a.rec + (size_t)L.colpos[cc] * G::RECQ, G::thr_of(a));
-            if (res == 1) L.cdead[cc] = 1;
-          }
-        }
-        Q1.head = (Q1.head + cnt) & 127;
-        Q1.count -= cnt;
-        push2(res == 2, rowp, cc);
-        wave_sync();
-        if (Q2.count >= 64) drain2(64);
-      };
-      auto drain = [&](int cnt) {                  // stage 1a: the cheap register-only tests; entries (slab entry << 8 | column lane)
-        wave_sync();
-        int res = 0;
-        uint32_t rowp = 0, cc = 0;
-        if (lane < cnt) {
-          const uint32_t it = L.qbuf[(Q.head + lane) & 127];
-          cc = it & 255;
-          rowp = S.pos[it >> 8];
-          if (!L.cdead[cc]) {
-            res = G::classify_quick(a.rec + (size_t)rowp * G::RECQ, a.rec + (size_t)L.colpos[cc] * G::RECQ, G::thr_of(a), cull);
-            if (res == 1) L.cdead[cc] = 1;
-          }
-        }
-        Q.head = (Q.head + cnt) & 127;
-        Q.count -= cnt;
-        {
-          const u64 m1 = __ballot(res == 3);
-          if (res == 3) {
-            const int slot = (Q1.head + Q1.count + __popcll(m1 & lanemask_lt())) & 127;
-            L.qbuf1b[slot] = rowp;
-            L.q1bcol[slot] = (uint8_t)cc;
-          }
-          Q1.count += __popcll(m1);
-        }
-        push2(res == 2, rowp, cc);
-        wave_sync();
-        if (Q1.count >= 64) drain1b(64);
-        if (Q2.count >= 64) drain2(64);
-        alive = alive && !L.cdead[lane];
-      };
-      ctock(c_rng);
-      ctick();
-      // every range is walked in tiles of 64 rows exactly like the exhaustive form walks its row tiles: lane k holds row k of
-      // the tile (one conflict-free LDS read), the rows are broadcast with v_readlane, four rows per trip; the next range's
-      // first tile is in flight while the current one is processed
-      auto one_row = [&](int e, bool pass) {
-        if (__ballot(pass)) {
-          Q.push(pass, ((uint32_t)e << 8) | (uint32_t)lane);
-          if (Q.count >= 64) { ctock(c_enum); ctick(); drain(64); ctock(c_drain); c_nd++; ctick(); }
-        }
-      };
-      uint32_t pr_next = nranges > 0 ? (uint32_t)__builtin_amdgcn_readfirstlane((int)L.ranges[0]) : 0u;
-      float4 tile_next = S.q0[min((int)(pr_next & 0xffffu) + lane, kSlabRows - 1)];
-      for (int ri = 0; ri < nranges; ri++) {
-        if (__ballot(alive) == 0ull) break;
-        const int e_begin = (int)(pr_next & 0xffffu), e_end = (int)(pr_next >> 16);
-        float4 myrow = tile_next;
-        if (ri + 1 < nranges) {
-          pr_next = (uint32_t)__builtin_amdgcn_readfirstlane((int)L.ranges[ri + 1]);
-          tile_next = S.q0[min((int)(pr_next & 0xffffu) + lane, kSlabRows - 1)];
-        }
-        c_rows += (u64)(e_end - e_begin);
-        for (int e0 = e_begin; e0 < e_end; e0 += 64) {
-          if (e0 != e_begin) myrow = S.q0[min(e0 + lane, kSlabRows - 1)];
-          const int nrow = min(64, e_end - e0);
-          int rr = 0;
-          for (; rr + 4 <= nrow; rr += 4) {
-            bool ps[4];
-            bool any = false;
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-              const float4 rq1 = rdlane4(myrow, rr + k);
-              ps[k] = alive && !(cull && G::cheap_reject(rq1, cq));
-              any = any || ps[k];
-            }
-            if (__ballot(any)) {
-#pragma unroll
-              for (int k = 0; k < 4; k++) one_row(e0 + rr + k, ps[k]);
-            }
-          }
-          for (; rr < nrow; rr++) {
-            const float4 rq1 = rdlane4(myrow, rr);
-            one_row(e0 + rr, alive && !(cull && G::cheap_reject(rq1, cq)));
-          }
+        if (my_lv >= 0) {
+          const uint32_t i0 = grid_slot(my_lv, my_cx0, my_cy, mmask);
+          const int e1 = (int)i0 + my_len;
+          s = a.gstart[i0];
+          e = a.gstart[e1 <= M ? e1 : M];
+          if (e1 > M) e2 = a.gstart[e1 - M];
         }
       }
-      ctock(c_enum);
-      ctick();
-      if (Q.count > 0) { drain(Q.count); c_nd++; }
-      if (Q1.count > 0) drain1b(Q1.count);
-      if (Q2.count > 0) drain2(Q2.count);
-      ctock(c_drain);
-      alive = alive && !L.cdead[lane];
-      // RETURNING atomics whose result is consumed: the wave's vmcnt then covers the completed read-modify-write.
-      // A box dies once: its bit of the score-order bitmap (select reads that one) and, for a block of the cell order,
-      // the block's word.
-      const bool killed = alive0 && !alive;
-      u64 seen = 0ull;
-      if (killed) seen = atomicAnd(a.alive + (cpos >> 6), ~(1ull << (cpos & 63)));
-      const u64 kill = __ballot(killed);
-      if (kill && !listed && lane == 0) seen ^= atomicAnd(a.calive + item, ~kill);
-      asm volatile("; kills applied %0" ::"v"((unsigned)(seen >> 32) ^ (unsigned)seen));
+      {
+        const int nb1 = e > s ? (e - s + 63) >> 6 : 0, nb2 = (e2 + 63) >> 6;
+        int incl = nb1 + nb2;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const int u = __shfl_up(incl, d); if (lane >= d) incl += u; }
+        const int tot = __builtin_amdgcn_readlane(incl, 63);
+        const int o0 = bc + incl - (nb1 + nb2);    // ordinal of this lane's first block
+        bc += tot;
+        // owned ordinals: o % kw == part; their ranks (o - part) / kw run on from the previous batch without gaps
+        const int first_rank = (o0 - part + kw - 1) / kw;                        // (>= 0: o0 >= 0, part < kw)
+        const int rank_lo = (bc - tot - part + kw - 1) / kw, rank_hi = (bc - part + kw - 1) / kw;   // ranks [rank_lo, rank_hi) belong to this batch
+        for (int base = rank_lo; base < rank_hi; base += 128) {
+          wave_sync();
+          {
+            int o = first_rank * kw + part;        // this lane's first owned ordinal
+            for (; o < o0 + nb1 + nb2; o += kw) {
+              const int rk = (o - part) / kw - base;
+              if (rk < 0) continue;
+              if (rk >= 128) break;
+              const int b = o - o0;
+              const int k0 = b < nb1 ? s + b * 64 : (b - nb1) * 64, kend = b < nb1 ? e : e2;
+              blist[rk] = ((uint32_t)k0 << 7) | (uint32_t)(min(64, kend - k0));
+            }
+          }
+          wave_sync();
+          const int cnt = min(128, rank_hi - base);
+          c_blocks += (u64)cnt;
+          ctock(c_pro);
+          ctick();
+          for (int i = 0; i < cnt; i += 4) {
+            uint32_t be[4];
+            float4 cq[4];
+            bool val[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+              be[u] = (i + u < cnt) ? (uint32_t)__builtin_amdgcn_readfirstlane((int)blist[i + u]) : 0u;
+              val[u] = lane < (int)(be[u] & 127u);
+              cq[u] = val[u] ? a.gsorted[(size_t)(be[u] >> 7) + lane] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            // circle test, then the alive bits of what passed (four independent gathers in flight): most candidates
+            // of a later step are dead already and never reach a queue
+            bool pass[4];
+            u64 aw[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+              const uint32_t cp = __float_as_uint(cq[u].w);
+              const float dx = cq[u].x - rq.x, dy = cq[u].y - rq.y, rs = rq.z + cq[u].z;
+              pass[u] = val[u] && (int)cp >= c0 && (int)cp < se && !(dx * dx + dy * dy > rs * rs);
+              // (a plain, cacheable load: a stale word can only show a dead box as alive -- bits go 1 -> 0 -- which costs a
+              //  redundant test, never a missed one; the coherent load takes about twice as long)
+              aw[u] = pass[u] ? a.alive[cp >> 6] : 0ull;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+              const uint32_t cp = __float_as_uint(cq[u].w);
+              const bool go = pass[u] && ((aw[u] >> (cp & 63)) & 1ull);
+              if (__ballot(go)) {
+                c_pass += (u64)__popcll(__ballot(go));
+                Q.push(go, cp);
+                if (Q.count >= 64) { ctock(c_scan); ctick(); drain(64); ctock(c_drain); c_nd++; ctick(); }
+              }
+            }
+          }
+          ctock(c_scan);
+          ctick();
+        }
+      }
+    }
+    ctock(c_pro);
+    ctick();
+    if (Q.count > 0) { drain(Q.count); c_nd++; }
+    ctock(c_drain);
+  }
+  if (cprof) {
+    a.prof[16] += c_scan; a.prof[17] += c_drain; a.prof[18] += c_pro; a.prof[19] += c_nd; a.prof[20] += c_blocks; a.prof[21] += c_items;
+    a.prof[15] += c_pass; a.prof[10] += (u64)kw;
+  }
+  if (Q1.count > 0) drain1b(Q1.count);
+  if (Q2.count > 0) drain2(Q2.count);
+  asm volatile("; kills applied %0" ::"v"((unsigned)(seen >> 32) ^ (unsigned)seen));
+}
+
+constexpr int kGridMinRows = 512;
+
+// Counting sort of the still-alive positions [c0, n) by table slot, by the whole team (= the whole grid: one segment):
+// count -> barrier -> distributed scan (every workgroup a slice of the table, then the prefix of the workgroup totals)
+// -> barrier -> scatter -> barrier.  Everything another workgroup reads afterwards is written through (agent scope);
+// the readers take ONE agent acquire after the last barrier and use plain loads from then on (guideline 16).  The slot
+// counters are back to zero when the scatter is done.  Returns false on a barrier abort.
+template <class G>
+__device__ __forceinline__ bool grid_build(const NmsArgs& a, int c0, int wg, int T, TeamBar& bar, int* s_flag, int* s_i) {
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int M = (int)a.gmask + 1;
+  const int per = (M + T - 1) / T;                 // table slots of one workgroup (<= kNmsThreads, checked by the caller)
+  auto indexed_alive = [&](int p, uint32_t& slot) -> bool {
+    slot = a.gslot_of[p];
+    return slot != 0xffffffffu && ((ldg_agent(a.alive + (p >> 6)) >> (p & 63)) & 1ull);   // coherent: count and scatter must agree
+  };
+  for (int p = c0 + wg * kNmsThreads + tid; p < a.n; p += T * kNmsThreads) {
+    uint32_t slot;
+    if (indexed_alive(p, slot)) __hip_atomic_fetch_add(a.gcnt + slot, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  if (!team_barrier(bar, s_flag)) return false;
+  // exclusive prefix of this workgroup's slice + its total
+  auto block_excl = [&](int v, int& total) -> int {
+    int incl = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const int u = __shfl_up(incl, d); if (lane >= d) incl += u; }
+    __syncthreads();
+    if (lane == 63) s_i[wv] = incl;
+    __syncthreads();
+    int pre = 0;
+    total = 0;
+#pragma unroll
+    for (int k = 0; k < kNmsWaves; k++) { const int t = s_i[k]; if (k < wv) pre += t; total += t; }
+    return pre + incl - v;
+  };
+  const int slot_i = wg * per + tid;
+  const bool mine = tid < per && slot_i < M;
+  int tot_wg = 0;
+  const int excl = block_excl(mine ? ldg_agent(a.gcnt + slot_i) : 0, tot_wg);
+  if (tid == 0) stg_agent(a.gwsum + wg, tot_wg);
+  if (!team_barrier(bar, s_flag)) return false;
+  int grand = 0, base = 0;
+  {
+    const int v = tid < T ? ldg_agent(a.gwsum + tid) : 0;       // T <= kNmsThreads
+    const int ex = block_excl(v, grand);
+    __syncthreads();
+    if (tid == wg) s_i[11] = ex;
+    __syncthreads();
+    base = s_i[11];
+  }
+  if (mine) stg_agent(a.gstart + slot_i, base + excl);
+  if (wg == 0 && tid < 2) stg_agent(a.gstart + M + tid, grand);
+  if (!team_barrier(bar, s_flag)) return false;
+  for (int p = c0 + wg * kNmsThreads + tid; p < a.n; p += T * kNmsThreads) {
+    uint32_t slot;
+    if (indexed_alive(p, slot)) {
+      const int k = __hip_atomic_fetch_sub(a.gcnt + slot, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - 1;   // the order inside a slot does not matter
+      const float4 q0 = a.rec[(size_t)p * G::RECQ];
+      u64* o = reinterpret_cast<u64*>(a.gsorted + (size_t)ldg_agent(a.gstart + slot) + k);
+      stg_agent(o, ((u64)__float_as_uint(q0.y) << 32) | (u64)__float_as_uint(q0.x));
+      stg_agent(o + 1, ((u64)(uint32_t)p << 32) | (u64)__float_as_uint(q0.z));
     }
   }
-  __syncthreads();                                 // the slab is read until here; the caller's next select reuses the memory
-  if (cprof) {
-    a.prof[16] += c_enum; a.prof[17] += c_drain; a.prof[18] += c_build; a.prof[19] += c_nd; a.prof[20] += c_rows; a.prof[21] += c_items;
-    a.prof[15] += c_rng; a.prof[10] += c_whole;
-  }
+  if (!team_barrier(bar, s_flag)) return false;
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  return true;
 }
 
 // ------------------------------------------------------------------ the persistent kernel
@@ -1095,24 +1090,50 @@ __global__ __launch_bounds__(kNmsThreads) __attribute__((amdgpu_waves_per_eu(1, 
     if (prof) { const u64 t1 = wall_clock64(); a.prof[slot] += t1 - t0; t0 = t1; }
   };
 
-  // Spatial index for the cross phase: built before the launch (grid.h); the rows' side needs the chunk list's LDS
+  // spatial index (grid.h): the cross phases query it instead of scanning every alive position
+  bool grid_on = false, grid_built = false, aborted = false;
   GridPlan gp = {};
-  bool slab_on = false;
+  uint32_t glevels = 0;
+  int n_brute = 0;
   if constexpr (G::HAS_GRID) {
-    if (a.gmeta != nullptr && a.cull != 0 && (size_t)a.capmax * 4 >= sizeof(SlabLds) && a.gmeta->on != 0) {
+    if (a.gmeta != nullptr && a.nseg == 1 && T == NB && ((int)a.gmask + T) / T <= kNmsThreads && T <= kNmsThreads) {
       gp = grid_plan(a.gmeta->bb);
-      slab_on = gp.ok != 0;
+      glevels = a.gmeta->level_mask;
+      n_brute = a.gmeta->n_brute;
+      grid_on = gp.ok != 0 && glevels != 0u && (long long)n_brute * 16 <= (long long)a.n;   // (many brute boxes: not worth it)
     }
   }
-  // kept rows x alive positions of [c0, c1): through the index of the rows when it pays (a handful of rows: exhaustive)
+  // kept rows x alive positions of [c0, c1)
   auto cross = [&](const uint32_t* rows, int nr, int c0, int c1) {
     if constexpr (G::HAS_GRID) {
-      if (slab_on && nr >= kSlabMinRows) {
-        nms_cross_blocks<G>(a, gp, rows, nr, c0, c1, tw, ntw, L, *reinterpret_cast<SlabLds*>(cidx), s_i);
+      if (grid_on && nr >= kGridMinRows) {           // (a few hundred kept rows: the exhaustive form is the cheaper one)
+        if (!grid_built) {                           // first use: sort what is still alive behind the chunk into its cells
+          if (!grid_build<G>(a, c0, wg, T, bar, &s_flag, s_i)) { aborted = true; return; }
+          grid_built = true;
+        }
+        nms_cross_grid<G>(a, gp, glevels, rows, nr, c0, c1, tw, ntw, L);
+        if (n_brute > 0) {
+          // the boxes the index leaves out: brute kept rows against every column, every kept row against the brute columns
+          // (the chunk list in LDS is free between resolve and the next select: it takes the brute rows, capmax at a time)
+          for (int j0 = 0; j0 < nr; j0 += a.capmax) {
+            const int j1 = min(nr, j0 + a.capmax);
+            __syncthreads();
+            if (tid == 0) s_i[9] = 0;
+            __syncthreads();
+            for (int j = j0 + tid; j < j1; j += kNmsThreads) {
+              const uint32_t rp = rows[j];
+              if (a.rec[(size_t)rp * G::RECQ + 3].y != 0.f) cidx[atomicAdd(&s_i[9], 1)] = rp;
+            }
+            __syncthreads();
+            const int nbr = s_i[9];
+            if (nbr > 0) nms_cross<G>(a, cidx, nbr, c0, c1, nullptr, 0, tw, ntw, L);
+          }
+          nms_cross<G>(a, rows, nr, c0, c1, a.ulist, n_brute, tw, ntw, L);
+        }
         return;
       }
     }
-    nms_cross<G>(a, rows, nr, c0, c1, tw, ntw, L);
+    nms_cross<G>(a, rows, nr, c0, c1, nullptr, 0, tw, ntw, L);
   };
 
   const int plan_chunk = a.cap_first < a.capmax ? a.cap_first : a.capmax;
@@ -1136,6 +1157,7 @@ __global__ __launch_bounds__(kNmsThreads) __attribute__((amdgpu_waves_per_eu(1, 
       if (jnr > 0) {
         const u64 tcz = (a.prof && tid == 0) ? wall_clock64() : 0ull;
         cross(jrows, jnr, jc0, jc1);
+        if (aborted) return;
         if (a.prof && tid == 0) { atomicMax(a.prof + 31, wall_clock64() - tcz); }
         lap(5);
         if (!team_barrier(bar, &s_flag)) return;           // the kills are visible before anybody selects again
