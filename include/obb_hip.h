@@ -205,6 +205,8 @@ typedef struct obb_loss_config {
                                           rows carry no CSL labels (tcols == 7): the 180-bin label is then regenerated on
                                           the device from theta exactly as gaussian_label_cpu rolls its window
                                           (utils/rboxs_utils.py:9-26, utils/datasets.py:639-642) -- SURVEY 8(f) row 3   */
+  float fl_gamma;                      /* hyp['fl_gamma']: > 0 wraps the class, angle and objectness BCE in FocalLoss(gamma,
+                                          alpha = 0.25) like utils/loss.py:107-110 (35-62); 0: plain BCE                */
 } obb_loss_config;
 
 size_t obb_loss_workspace_bytes(const obb_loss_config* cfg, int64_t nt);

@@ -220,10 +220,26 @@ def build_targets(spec, p, targets):
     return out
 
 
+def focal_bce(pred, true, pos_weight, gamma, alpha=0.25):
+    """utils/loss.py:35-62 FocalLoss(nn.BCEWithLogitsLoss(pos_weight), gamma) with the wrapped loss's 'mean' reduction."""
+    loss = torch.nn.functional.binary_cross_entropy_with_logits(pred, true, pos_weight=pos_weight, reduction='none')
+    pred_prob = torch.sigmoid(pred)
+    p_t = true * pred_prob + (1 - true) * (1 - pred_prob)
+    alpha_factor = true * alpha + (1 - true) * (1 - alpha)
+    modulating_factor = (1.0 - p_t) ** gamma
+    return (loss * alpha_factor * modulating_factor).mean()
+
+
 def compute_loss(spec, p, targets, sort_obj_iou=False):
-    """utils/loss.py:122-192 (fl_gamma == 0, autobalance off; sort_obj_iou :156-158 with a stable sort).  p[i]: (bs, na, ny, nx, no) logits (requires_grad ok)."""
+    """utils/loss.py:122-192 (autobalance off; sort_obj_iou :156-158 with a stable sort; hyp['fl_gamma'] > 0 wraps the three
+    BCE terms in FocalLoss, :107-110).  p[i]: (bs, na, ny, nx, no) logits (requires_grad ok)."""
     h = spec.hyp
-    bce = torch.nn.functional.binary_cross_entropy_with_logits
+    fg = float(h.get('fl_gamma', 0.0))
+    if fg > 0:
+        def bce(pred, true, pos_weight):
+            return focal_bce(pred, true, pos_weight, fg)
+    else:
+        bce = torch.nn.functional.binary_cross_entropy_with_logits
     pw_cls, pw_th, pw_obj = (torch.tensor([h[k]], dtype=torch.float32) for k in ('cls_pw', 'theta_pw', 'obj_pw'))
     lbox = torch.zeros(1); lobj = torch.zeros(1); lcls = torch.zeros(1); lth = torch.zeros(1)
     tg = build_targets(spec, p, targets)

@@ -12,6 +12,12 @@ void hc_ciou(const float* in, long n, float* out) {
   }
 }
 // in: n x (x, t); out: n x (loss, dloss/dx)
+void hc_focal(const float* in, long n, float pw, float gamma, float* out) {
+  for (long i = 0; i < n; i++) {
+    out[i * 2] = obb::bce_focal(in[i * 2], in[i * 2 + 1], pw, gamma);
+    out[i * 2 + 1] = obb::bce_focal_grad(in[i * 2], in[i * 2 + 1], pw, gamma);
+  }
+}
 void hc_bce(const float* in, long n, float pw, float* out) {
   for (long i = 0; i < n; i++) {
     out[i * 2] = obb::bce_logits(in[i * 2], in[i * 2 + 1], pw);

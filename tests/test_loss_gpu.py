@@ -177,27 +177,59 @@ def test_out_of_range_target_is_loud(dev):
     cl, spec, p, t = make(dev, nt=20, seed=2)
     t = t.clone()
     t[3, 0] = 7          # image index outside the batch of 2: the reference raises IndexError
-    loss, _ = cl([x.to(dev) for x in p], t.to(dev))
+    pg = [x.clone().to(dev).requires_grad_(True) for x in p]
+    loss, _ = cl(pg, t.to(dev))
     assert torch.isnan(loss).all()
+    loss.backward()                                 # NaN gradients too: a GradScaler skips the step
+    assert all(torch.isnan(x.grad).any() for x in pg)          # (every level: GradScaler.unscale_ finds them)
     with pytest.raises(IndexError):
         cl.build_targets([x.to(dev) for x in p], t.to(dev))
 
 
-def test_rejects_cpu_and_focal(dev):
+def test_rejects_cpu_and_mixed_dtypes(dev):
     cl, spec, p, t = make(dev, nt=5)
     with pytest.raises(RuntimeError):
         cl(p, t)                                    # CPU tensors
-    from yolov5_obb_amd.utils.loss import ComputeLoss
-    hyp = synth.scaled_hyp(16)
-    hyp['fl_gamma'] = 1.5
-    with pytest.raises(NotImplementedError):
-        ComputeLoss(synth.FakeModel(16, hyp, dev))
+    pg = [x.to(dev) for x in p]
+    pg[1] = pg[1].half()
+    with pytest.raises(RuntimeError, match="share dtype"):
+        cl(pg, t.to(dev))                           # the kernels read every level with p[0]'s element size
+
+
+@pytest.mark.parametrize("gamma", [1.5, 2.0])
+def test_focal_loss(dev, gamma):
+    """hyp['fl_gamma'] > 0: FocalLoss(BCE, gamma) around the class, angle and objectness terms (utils/loss.py:35-62,107-110),
+    forward and gradients vs the oracle's restatement."""
+    cl, spec, p, t = make(dev, nt=120, seed=51, hyp_over=dict(fl_gamma=gamma, cls_pw=1.3, obj_pw=0.8))
+    assert cl.fl_gamma == gamma
+    check(*run_both(cl, spec, p, t, dev), rtol=2e-5, grtol=2e-4)
+
+
+def test_anchor_update_after_construction_is_seen(dev):
+    """autoanchor writes m.anchors[:] = ... in place after the loss object may exist: the reference reads the tensor on every
+    call (utils/loss.py:120), so must this class."""
+    cl, spec, p, t = make(dev, nt=80, seed=3)
+    l0, _ = cl([x.to(dev) for x in p], t.to(dev))
+    with torch.no_grad():
+        cl._det.anchors[:] = cl._det.anchors * 1.7
+    spec.anchors = spec.anchors * 1.7
+    (lo, io, pc), (lg, ig, pg) = run_both(cl, spec, p, t, dev)
+    assert not torch.allclose(lg.detach().cpu(), l0.detach().cpu())
+    check((lo, io, pc), (lg, ig, pg))
 
 
 def test_targets_without_csl_columns_are_encoded_on_the_device(dev):
     """(nt,7) targets -- the 180-bin CSL rows are regenerated inside the loss kernels from theta with
     hyp['csl_radius'], exactly as gaussian_label_cpu rolls its window; same loss / gradients as the (nt,187) wire format."""
     cl, spec, p, t = make(dev, nt=200, seed=44)
+    # anchored on the ORACLE: its (nt,187) rows carry gaussian_label_cpu's labels (tests/synth.py), the HIP path only gets (nt,7)
+    pc = [x.clone().requires_grad_(True) for x in p]
+    lo, io = pyref.compute_loss(spec, pc, t.clone())
+    lo.backward()
+    pg0 = [x.clone().to(dev).requires_grad_(True) for x in p]
+    lg0, ig0 = cl(pg0, t[:, :7].contiguous().to(dev))
+    lg0.backward()
+    check((lo, io, pc), (lg0, ig0, pg0))
     pg1 = [x.clone().to(dev).requires_grad_(True) for x in p]
     l1, i1 = cl(pg1, t.to(dev))
     l1.backward()

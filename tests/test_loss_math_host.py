@@ -23,6 +23,7 @@ def hl(tmp_path_factory):
     fp = np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS")
     L.hc_ciou.argtypes = [fp, C.c_long, fp]
     L.hc_bce.argtypes = [fp, C.c_long, C.c_float, fp]
+    L.hc_focal.argtypes = [fp, C.c_long, C.c_float, C.c_float, fp]
     L.hc_pred.argtypes = [fp, C.c_long, fp]
     L.hc_rem1.argtypes = [fp, C.c_long, fp]
     return L
@@ -75,3 +76,24 @@ def test_pred_box_decode_and_remainder(hl):
     r = np.zeros(4000, np.float32)
     hl.hc_rem1(np.ascontiguousarray(x.numpy()), 4000, r)
     assert np.array_equal(r, (x % 1).numpy())
+
+
+@pytest.mark.parametrize("pw,gamma", [(1.0, 1.5), (2.5, 2.0), (1.0, 0.0)])
+def test_focal_bce_forward_and_gradient(hl, pw, gamma):
+    """FocalLoss around BCEWithLogitsLoss (utils/loss.py:35-62): element values and hand-written derivative vs torch autograd
+    of the restatement; gamma = 0 is the plain BCE."""
+    g = torch.Generator().manual_seed(7)
+    n = 20000
+    x = (torch.randn(n, generator=g) * 5).requires_grad_(True)
+    t = torch.rand(n, generator=g)
+    t[: n // 3] = (t[: n // 3] > 0.5).float()
+    pwt = torch.tensor([pw])
+    if gamma > 0:
+        loss = pyref.focal_bce(x, t, pwt, gamma) * n          # (mean * n = sum of the element losses)
+    else:
+        loss = torch.nn.functional.binary_cross_entropy_with_logits(x, t, pos_weight=pwt, reduction='sum')
+    loss.backward()
+    out = np.zeros((n, 2), np.float32)
+    hl.hc_focal(np.ascontiguousarray(torch.stack((x.detach(), t), 1).numpy()), n, pw, gamma, out)
+    assert abs(out[:, 0].astype(np.float64).sum() - float(loss)) <= 1e-5 * abs(float(loss))
+    assert np.allclose(out[:, 1], x.grad.numpy(), rtol=2e-5, atol=2e-6), np.abs(out[:, 1] - x.grad.numpy()).max()

@@ -104,6 +104,26 @@ def test_obb_nms_wrapper_small_box_filter(dev, oracle_lib):
     assert isinstance(inds4, np.ndarray) and np.array_equal(inds4, ref)
 
 
+def test_nms_rotated_float64_rule(dev, oracle_lib):
+    """float64 boxes (nms_rotated_cuda.cu:96 dispatches double): order = the double scores' (stable), IoU decisions in float32
+    on the rounded boxes.  Exact against the float32 oracle under that rule; equal to the double-precision scan on this
+    seeded, well-conditioned set (the two can differ only for an IoU within float32 rounding of the threshold)."""
+    from yolov5_obb_amd import nms_rotated_ext
+    dets, scores = synth.s_clustered(6000, 120, 9)
+    d64 = dets.double() + 1e-9 * torch.randn(dets.shape, dtype=torch.float64, generator=torch.Generator().manual_seed(1))
+    s64 = synth.tie_free(scores).double()
+    s64[100] = s64[200] + 1e-12                                   # equal in float32, ordered in double
+    got = nms_rotated_ext.nms_rotated(d64.to(dev), s64.to(dev), 0.4).cpu().numpy()
+    order = np.argsort(-s64.numpy(), kind="stable")
+    n = len(order)
+    ref32 = oracle.nms_rotated(d64.float().numpy()[order], np.arange(n, 0, -1, dtype=np.float32), 0.4)
+    assert np.array_equal(got, order[ref32])
+    ref64 = oracle.nms_rotated(d64.numpy(), s64.numpy(), 0.4)
+    assert np.array_equal(got, ref64)
+    _, inds = __import__("yolov5_obb_amd.utils.nms_rotated", fromlist=["obb_nms"]).obb_nms(d64.to(dev), s64.to(dev), 0.4)
+    assert inds.dtype == torch.int64 and len(inds) == len(got)
+
+
 def test_nms_rotated_errors(dev):
     from yolov5_obb_amd import nms_rotated_ext
     from yolov5_obb_amd.utils.nms_rotated import obb_nms, poly_nms

@@ -44,7 +44,7 @@ struct LossDev {
   long long rows[kLv], cell_off[kLv];
   float anchors[kLv][kNa][2];
   float stride[kLv], balance[kLv];
-  float anchor_t, cp, cn, cls_pw, theta_pw, obj_pw, g_box, g_obj, g_cls, g_theta, gr;
+  float anchor_t, cp, cn, cls_pw, theta_pw, obj_pw, g_box, g_obj, g_cls, g_theta, gr, fl_gamma;
   int csl_from_theta;       // 1: targets are (nt,7): the CSL row is regenerated from theta (column 6)
   float csl_radius;
   float csl_lut[kCslBins];  // gaussian window y_sig[j], j = 0..179 (utils/rboxs_utils.py:22-23), filled by k_loss_setup
@@ -233,7 +233,7 @@ __global__ __launch_bounds__(256) void k_loss_dense_fwd(const LossDev* __restric
   const long long rows = d.rows[lv];
   const T* p = (const T*)d.p[lv];
   const int no = d.no;
-  const float pw = d.obj_pw;
+  const float pw = d.obj_pw, fg = d.fl_gamma;
   float acc = 0.f;
   const long long step = (long long)gridDim.x * 256;
   long long r = (long long)blockIdx.x * 256 + tid;
@@ -242,9 +242,9 @@ __global__ __launch_bounds__(256) void k_loss_dense_fwd(const LossDev* __restric
     const float x1 = ld_as_float<T>(p + (size_t)(r + step) * no + 4);
     const float x2 = ld_as_float<T>(p + (size_t)(r + 2 * step) * no + 4);
     const float x3 = ld_as_float<T>(p + (size_t)(r + 3 * step) * no + 4);
-    acc += bce_logits(x0, 0.f, pw); acc += bce_logits(x1, 0.f, pw); acc += bce_logits(x2, 0.f, pw); acc += bce_logits(x3, 0.f, pw);
+    acc += bce_focal(x0, 0.f, pw, fg); acc += bce_focal(x1, 0.f, pw, fg); acc += bce_focal(x2, 0.f, pw, fg); acc += bce_focal(x3, 0.f, pw, fg);
   }
-  for (; r < rows; r += step) acc += bce_logits(ld_as_float<T>(p + (size_t)r * no + 4), 0.f, pw);
+  for (; r < rows; r += step) acc += bce_focal(ld_as_float<T>(p + (size_t)r * no + 4), 0.f, pw, fg);
   const double w = wave_sum_d((double)acc);
   if ((tid & 63) == 0) s_part[tid >> 6] = w;
   __syncthreads();
@@ -291,8 +291,8 @@ __global__ __launch_bounds__(256) void k_loss_entries_fwd(const LossDev* __restr
 #pragma unroll
     for (int k = 0; k < kChunks; k++) {
       const int ch = lane + 64 * k;
-      if (ch >= 5 && ch < 5 + nc) scls += bce_logits(R.x[k], (ch - 5 == tc) ? d.cp : d.cn, d.cls_pw);   // :162-168
-      else if (ch >= 5 + nc && ch < no) sth += bce_logits(R.x[k], csl.at(ch - 5 - nc), d.theta_pw);     // :171-172
+      if (ch >= 5 && ch < 5 + nc) scls += bce_focal(R.x[k], (ch - 5 == tc) ? d.cp : d.cn, d.cls_pw, d.fl_gamma);   // :162-168
+      else if (ch >= 5 + nc && ch < no) sth += bce_focal(R.x[k], csl.at(ch - 5 - nc), d.theta_pw, d.fl_gamma);     // :171-172
     }
     scls = wave_sum_f(scls); sth = wave_sum_f(sth);
     float corr = 0.f;
@@ -314,7 +314,7 @@ __global__ __launch_bounds__(256) void k_loss_entries_fwd(const LossDev* __restr
         iw = ciou_fwd_bwd(pb.x, pb.y, pb.w, pb.h, tj.x, tj.y, tj.z, tj.w).ciou;
       }
       const float tobj = round_to_dtype<T>((1.0f - d.gr) + d.gr * round_to_dtype<T>(fmaxf(iw, 0.f)));   // :155,159
-      corr = bce_logits(x4, tobj, d.obj_pw) - bce_logits(x4, 0.f, d.obj_pw);
+      corr = bce_focal(x4, tobj, d.obj_pw, d.fl_gamma) - bce_focal(x4, 0.f, d.obj_pw, d.fl_gamma);
     }
     if (lane == 0) {
       d.part_box[eg] = 1.0f - co.ciou;                                                           // :152
@@ -400,13 +400,16 @@ __global__ __launch_bounds__(256) void k_loss_bwd_dense(const LossDev* __restric
   const T* p = (const T*)d.p[lv];
   T* g = (T*)d.grad[lv];
   const float inv_no = 1.0f / (float)no;
-  const float gs = d.gscale[0] * d.g_obj * (float)d.bs * d.balance[lv] / (float)rows;
+  // a target row that named an image or class outside the batch (the reference raises IndexError) made the loss NaN in
+  // the forward pass; the gradient is NaN as well, so that a GradScaler skips the step instead of applying a partial one
+  const float gin = d.counts[kLv] ? __builtin_nanf("") : d.gscale[0];
+  const float gs = gin * d.g_obj * (float)d.bs * d.balance[lv] / (float)rows;
   const long long nreg = (rows + 63) >> 6;
   for (long long rg = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); rg < nreg; rg += (long long)gridDim.x * 4) {
     const long long R0 = rg << 6;
     const int nr = (int)((rows - R0) < 64 ? (rows - R0) : 64);
-    // d BCE(x, 0)/dx = sigmoid(x) for every pos_weight
-    const float gv = (lane < nr) ? sigmoid_f(ld_as_float<T>(p + (size_t)(R0 + lane) * no + 4)) * gs : 0.f;
+    // d BCE(x, 0)/dx = sigmoid(x) for every pos_weight (FocalLoss: the general form)
+    const float gv = (lane < nr) ? bce_focal_grad(ld_as_float<T>(p + (size_t)(R0 + lane) * no + 4), 0.f, d.obj_pw, d.fl_gamma) * gs : 0.f;
     const int nel = nr * no;
     T* gb = g + (size_t)R0 * no;                      // 64*no*sizeof(T) bytes per region: 16-byte aligned
     const int nch = (nel + V - 1) / V;
@@ -451,7 +454,7 @@ __global__ __launch_bounds__(256) void k_loss_entries_bwd(const LossDev* __restr
   const int nw = gridDim.x * 4;
   const int cap_tot = d.nl * d.cap;
   const int no = d.no, nc = d.nc;
-  const float gsc = d.gscale[0];
+  const float gsc = d.counts[kLv] ? __builtin_nanf("") : d.gscale[0];      // (bad target rows: NaN, see k_loss_bwd_dense)
   for (int eg = blockIdx.x * 4 + (threadIdx.x >> 6); eg < cap_tot; eg += nw) {
     const int lv = eg / d.cap, pos = eg - lv * d.cap;
     const int n = d.counts[lv];
@@ -492,13 +495,13 @@ __global__ __launch_bounds__(256) void k_loss_entries_bwd(const LossDev* __restr
       for (int k = 0; k < kChunks; k++) {
         const int ch = lane + 64 * k;
         if (k == 0 && ch < 4) acc[k] += gbox * s_box;
-        else if (ch >= 5 && ch < 5 + nc) { if (nc > 1) acc[k] += bce_logits_grad(R.x[k], (ch - 5 == tc) ? d.cp : d.cn, d.cls_pw) * s_cls; }
-        else if (ch >= 5 + nc && ch < no) acc[k] += bce_logits_grad(R.x[k], csl.at(ch - 5 - nc), d.theta_pw) * s_th;
+        else if (ch >= 5 && ch < 5 + nc) { if (nc > 1) acc[k] += bce_focal_grad(R.x[k], (ch - 5 == tc) ? d.cp : d.cn, d.cls_pw, d.fl_gamma) * s_cls; }
+        else if (ch >= 5 + nc && ch < no) acc[k] += bce_focal_grad(R.x[k], csl.at(ch - 5 - nc), d.theta_pw, d.fl_gamma) * s_th;
       }
     }
     (void)w;
     const float tobj = round_to_dtype<T>((1.0f - d.gr) + d.gr * round_to_dtype<T>(fmaxf(iou_w, 0.f)));
-    const float g4 = bce_logits_grad(x4, tobj, d.obj_pw) * s_obj;
+    const float g4 = bce_focal_grad(x4, tobj, d.obj_pw, d.fl_gamma) * s_obj;
     T* grow = (T*)d.grad[lv] + (size_t)cell * no;
 #pragma unroll
     for (int k = 0; k < kChunks; k++) {
@@ -566,6 +569,7 @@ static void loss_fill(LossDev& d, const obb_loss_config* c, const LossCarve& cv,
   }
   d.anchor_t = c->anchor_t; d.cp = c->cp; d.cn = c->cn; d.cls_pw = c->cls_pw; d.theta_pw = c->theta_pw; d.obj_pw = c->obj_pw;
   d.g_box = c->gain_box; d.g_obj = c->gain_obj; d.g_cls = c->gain_cls; d.g_theta = c->gain_theta; d.gr = c->gr;
+  d.fl_gamma = c->fl_gamma > 0.f ? c->fl_gamma : 0.f;
   d.csl_from_theta = (tcols < 7 + kCslBins) ? 1 : 0;
   d.csl_radius = c->csl_radius > 0.f ? c->csl_radius : 2.0f;
   d.targets = targets;

@@ -28,6 +28,33 @@ OBB_HD float bce_logits_grad(float x, float t, float pw) {
   return (1.0f - t) - lw * (1.0f - sigmoid_f(x));
 }
 
+// FocalLoss around BCEWithLogitsLoss (utils/loss.py:35-62, wrapped around BCEcls / BCEtheta / BCEobj when hyp['fl_gamma'] > 0,
+// :107-110; alpha = 0.25, the constructor default):
+//   loss = bce * af * (1 - p_t)^gamma,   p = sigmoid(x),  p_t = t p + (1-t)(1-p),  af = t alpha + (1-t)(1-alpha)
+// gamma <= 0: the plain BCE (the reference does not wrap then).
+constexpr float kFocalAlpha = 0.25f;
+OBB_HD float bce_focal(float x, float t, float pw, float gamma) {
+  const float b = bce_logits(x, t, pw);
+  if (!(gamma > 0.0f)) return b;
+  const float p = sigmoid_f(x);
+  const float pt = t * p + (1.0f - t) * (1.0f - p);
+  const float af = t * kFocalAlpha + (1.0f - t) * (1.0f - kFocalAlpha);
+  return b * (af * powf(1.0f - pt, gamma));
+}
+// d loss / d x = af * (bce' * m + bce * m'),  m = (1 - p_t)^gamma,  m' = -gamma (1 - p_t)^(gamma-1) (2t - 1) p (1 - p)
+OBB_HD float bce_focal_grad(float x, float t, float pw, float gamma) {
+  const float db = bce_logits_grad(x, t, pw);
+  if (!(gamma > 0.0f)) return db;
+  const float b = bce_logits(x, t, pw);
+  const float p = sigmoid_f(x);
+  const float pt = t * p + (1.0f - t) * (1.0f - p);
+  const float af = t * kFocalAlpha + (1.0f - t) * (1.0f - kFocalAlpha);
+  const float u = 1.0f - pt;
+  const float m = powf(u, gamma);
+  const float dm = -gamma * powf(u, gamma - 1.0f) * ((2.0f * t - 1.0f) * p * (1.0f - p));
+  return af * (db * m + b * dm);
+}
+
 struct CiouOut {
   float ciou;        // utils/metrics.py:237
   float d[4];        // d ciou / d (px, py, pw, ph) of box1 (the prediction), alpha held constant

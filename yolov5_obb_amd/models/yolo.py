@@ -18,6 +18,12 @@ from .. import _lib
 class Detect(nn.Module):
     stride = None  # strides computed during build
     onnx_dynamic = False  # ONNX export parameter
+    # host copy of anchors * stride as plain Python lists (picklable; absent in checkpoints written by the reference: the
+    # class default makes such modules work without a cast first)
+    _anchor_px = None
+    # inference on CPU tensors: this package has no CPU path.  yolov5_obb_amd.dropin.install() points this at the
+    # reference's own Detect.forward (models/yolo.py:50-81), so that `detect.py --device cpu` keeps running its code.
+    _cpu_forward = None
 
     def __init__(self, nc=80, anchors=(), ch=(), inplace=True):  # detection layer
         super().__init__()
@@ -30,15 +36,15 @@ class Detect(nn.Module):
         self.register_buffer('anchors', torch.tensor(anchors).float().view(self.nl, -1, 2))  # shape(nl,na,2)
         self.m = nn.ModuleList(nn.Conv2d(x, self.no * self.na, 1) for x in ch)  # output conv
         self.inplace = inplace  # use in-place ops (e.g. slice assignment)
-        self._anchor_px = None  # host copy of anchors * stride, built on first inference call
 
     def _host_tables(self):
         if self._anchor_px is None:
             st = [float(s) for s in torch.as_tensor(self.stride).float().cpu().tolist()]
             an = self.anchors.detach().float().cpu()
             px = [(an[i] * st[i]).reshape(-1).tolist() for i in range(self.nl)]      # anchor_grid values (:90-91)
-            self._anchor_px = ([(C.c_float * len(p))(*p) for p in px], st)
-        return self._anchor_px
+            self._anchor_px = (px, st)
+        px, st = self._anchor_px
+        return [(C.c_float * len(p))(*p) for p in px], st      # ctypes arrays are built per call: they do not pickle
 
     def _apply(self, fn):  # anchors / stride may change (Model._apply, autoanchor): drop the host cache
         self._anchor_px = None
@@ -62,10 +68,13 @@ class Detect(nn.Module):
                 x[i] = x[i].view(bs, self.na, self.no, ny, nx).permute(0, 1, 3, 4, 2).contiguous()
             return x
 
+        if not x[0].is_cuda:
+            if type(self)._cpu_forward is None:
+                raise RuntimeError("Detect (inference): yolov5_obb_amd is compiled for MI355X only (no CPU path, by design); "
+                                   "under yolov5_obb_amd.dropin.install() CPU tensors run the reference's own Detect.forward")
+            return type(self)._cpu_forward(self, x)
         convs = [self.m[i](x[i]).contiguous() for i in range(self.nl)]
         c0 = convs[0]
-        if not c0.is_cuda:
-            raise RuntimeError("Detect (inference): yolov5_obb_amd is compiled for MI355X only (no CPU path, by design)")
         if c0.dtype == torch.float32:
             code = 0
         elif c0.dtype == torch.float16:

@@ -42,15 +42,31 @@ def nms_rotated(dets, scores, iou_threshold):
         raise RuntimeError("dets and scores must be on the same device")  # bare assert in the reference (:29)
     if dets.dtype != scores.dtype:
         raise RuntimeError("dets should have the same type as scores")  # nms_rotated_cpu.cpp:19-21
-    if dets.dtype != torch.float32:
-        # the reference dispatches float and double (nms_rotated_cuda.cu:96); every caller in the repository
-        # passes float32 (utils/general.py:849-853), which is what the HIP kernels implement
-        raise RuntimeError(f"nms_rotated: only float32 is implemented on MI355X, got {dets.dtype}")
+    if dets.dtype not in (torch.float32, torch.float64):
+        # AT_DISPATCH_FLOATING_TYPES (nms_rotated_cuda.cu:96): float and double, no half
+        raise RuntimeError(f"nms_rotated: float32 or float64 expected, got {dets.dtype}")
     if dets.dim() != 2 or dets.shape[1] != 5 or scores.dim() != 1 or scores.shape[0] != dets.shape[0]:
         raise RuntimeError(f"nms_rotated: expected dets (N,5) and scores (N), got {tuple(dets.shape)} {tuple(scores.shape)}")
     if dets.numel() == 0:
         return torch.empty(0, dtype=torch.int64, device=dets.device)
+    if dets.dtype == torch.float64:
+        return _run_rotated_f64(dets, scores, iou_threshold)
     return _run_rotated(dets.contiguous(), scores.contiguous(), iou_threshold)
+
+
+def _run_rotated_f64(dets, scores, iou_threshold):
+    """float64 input (nms_rotated_cuda.cu:96 dispatches double).  The HIP kernels compute the IoU in float32, so the rule
+    is explicit: the processing ORDER is the one of the double scores (stable descending sort: ties keep ascending index,
+    NaN first, like the float32 path), the BOXES are rounded to float32 and go through the float32 kernel in that order.
+    The kept list therefore equals the float32 path's on the rounded boxes; against a true double-precision scan it can
+    differ for pairs whose IoU lies within float32 rounding (~1e-6) of the threshold (tests/test_nms_gpu.py)."""
+    n = dets.shape[0]
+    if n >= (1 << 24):
+        raise RuntimeError("nms_rotated (float64): at most 2^24 - 1 boxes")
+    order = torch.argsort(scores, descending=True, stable=True)
+    d32 = dets.index_select(0, order).float().contiguous()
+    rank = torch.arange(n, 0, -1, device=dets.device, dtype=torch.float32)     # strictly decreasing: keeps the given order
+    return order[_run_rotated(d32, rank, iou_threshold)]
 
 
 def nms_poly(dets, iou_threshold):

@@ -24,7 +24,7 @@ class _LossConfig(C.Structure):
                 ("anchor_t", C.c_float), ("cp", C.c_float), ("cn", C.c_float),
                 ("cls_pw", C.c_float), ("theta_pw", C.c_float), ("obj_pw", C.c_float),
                 ("gain_box", C.c_float), ("gain_obj", C.c_float), ("gain_cls", C.c_float), ("gain_theta", C.c_float),
-                ("gr", C.c_float), ("sort_obj_iou", C.c_int32), ("csl_radius", C.c_float)]
+                ("gr", C.c_float), ("sort_obj_iou", C.c_int32), ("csl_radius", C.c_float), ("fl_gamma", C.c_float)]
 
 
 def smooth_BCE(eps=0.1):  # utils/loss.py:13-15
@@ -55,6 +55,10 @@ class _ObbLossFn(torch.autograd.Function):
     def forward(ctx, owner, targets, *p):
         dev = p[0].device
         code = _dtype_code(p[0])
+        for i, pi in enumerate(p):       # the kernels read every level with p[0]'s element size and on p[0]'s device
+            if pi.dtype != p[0].dtype or pi.device != dev:
+                raise RuntimeError(f"ComputeLoss: p[{i}] is {pi.dtype} on {pi.device}, p[0] is {p[0].dtype} on {dev}: "
+                                   "all head outputs must share dtype and device")
         ps = [pi.contiguous() for pi in p]
         tg = targets.to(device=dev, dtype=torch.float32).contiguous()
         cfg = owner._config(ps)
@@ -102,10 +106,8 @@ class ComputeLoss:
         # Class label smoothing https://arxiv.org/pdf/1902.04103.pdf eqn 3
         self.cp, self.cn = smooth_BCE(eps=h.get('label_smoothing', 0.0))  # positive, negative BCE targets
 
-        # Focal loss (utils/loss.py:107-110)
-        if h.get('fl_gamma', 0.0) > 0:
-            raise NotImplementedError("ComputeLoss: fl_gamma > 0 (FocalLoss) is not implemented in the HIP loss kernels; "
-                                      "all hyp files under data/hyps/obb use fl_gamma: 0.0")
+        # Focal loss (utils/loss.py:107-110): FocalLoss(BCE, g) around the class, angle and objectness terms, inside the kernels
+        self.fl_gamma = float(h.get('fl_gamma', 0.0))
 
         det = model.module.model[-1] if _is_parallel(model) else model.model[-1]  # Detect() module
         self.stride = det.stride  # tensor([8., 16., 32., ...])
@@ -116,12 +118,26 @@ class ComputeLoss:
             setattr(self, k, getattr(det, k))
         if self.nl > _MAX_LV or self.na > _MAX_NA:
             raise RuntimeError(f"ComputeLoss: at most {_MAX_LV} levels x {_MAX_NA} anchors supported")
-        self._anchors_host = self.anchors.detach().float().cpu().reshape(self.nl, self.na, 2).tolist()
-        self._stride_host = [float(s) for s in self.stride.detach().float().cpu().tolist()]
+        self._det = det
+        self._host_key = None
+        self._refresh_host_tables()
+
+    def _refresh_host_tables(self):
+        """Host copies of det.anchors / det.stride for the kernel configuration.  The reference reads the tensors on every
+        call, so an in-place update after construction (autoanchor's `m.anchors[:] = ...`, check_anchor_order) is picked
+        up there; here the copy is rebuilt whenever the tensors' version counters or storage change."""
+        a, st = self._det.anchors, self._det.stride
+        key = (a._version, a.data_ptr(), st._version, st.data_ptr())
+        if key != self._host_key:
+            self.anchors, self.stride = a, st
+            self._anchors_host = a.detach().float().cpu().reshape(self.nl, self.na, 2).tolist()
+            self._stride_host = [float(s) for s in st.detach().float().cpu().tolist()]
+            self._host_key = key
 
     # ---- plumbing
     def _config(self, p):
         h = self.hyp
+        self._refresh_host_tables()
         cfg = _LossConfig()
         cfg.nl, cfg.na, cfg.nc = int(self.nl), int(self.na), int(self.nc)
         cfg.no = int(p[0].shape[-1])
@@ -143,6 +159,7 @@ class ComputeLoss:
         cfg.gr = float(self.gr)
         cfg.sort_obj_iou = int(bool(self.sort_obj_iou))
         cfg.csl_radius = float(h.get('csl_radius', 2.0))      # only used for (nt,7) targets: labels regenerated on the device
+        cfg.fl_gamma = self.fl_gamma if self.fl_gamma > 0 else 0.0
         return cfg
 
     def __call__(self, p, targets):  # predictions, targets, model
