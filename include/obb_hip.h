@@ -41,6 +41,12 @@ extern "C" {
 /* Library / device identification: returns OBB_OK and fills the fields when a gfx950-class device is usable. */
 const char* obb_version(void);
 int obb_device_info(int* cu_count, int* wave_size, char* arch_name, int arch_name_len);
+/* The persistent NMS kernel launches one workgroup per CU and its workgroups meet at spin barriers: they must all be
+ * resident.  Where that cannot be taken for granted (CU masking, a partition that exposes fewer CUs than it reports, a
+ * long kernel of another process holding CUs) a barrier times out and the call reports -1 kept boxes instead of hanging.
+ * max_workgroups > 0 caps the grid of the following launches of this process (the host layer retries an aborted call
+ * once with 8 workgroups); 0 restores the default (the CU count). */
+int obb_nms_set_max_grid(int max_workgroups);
 
 /* Optional per-stage timing with HIP events recorded on the caller's stream (used by bench.py for the roofline
  * object).  Stage ids: 0 decode/filter kernel, 1 per-image sort, 2 candidate prep, 3 NMS steps, 4 output gather of

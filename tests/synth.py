@@ -51,6 +51,28 @@ def tie_free(scores):
     return s
 
 
+def regime_100k(name, n=100000):
+    """The four N = 100k regimes bench.py reports (SURVEY section 8d distributions; `raw` = the exact tensor bench.py times,
+    scores not made tie-free: ties follow the documented rule, ascending original index)."""
+    if name == "clustered_k300_raw":
+        return s_clustered(n, 300, seed=0)
+    if name == "clustered_k300":
+        d, s = s_clustered(n, 300, seed=0)
+    elif name == "clustered_k300_18cls":                    # the natural shape of BASELINE configs[3] (DOTAv2.0, nc 18)
+        d, s = s_clustered(n, 300, seed=0)
+        d, _ = with_classes(d, 18, 0)
+    elif name == "clustered_k3000":
+        d, s = s_clustered(n, 3000, seed=0)
+    elif name == "uniform":
+        d, s = s_uniform(n, 0)
+    elif name == "uniform_18cls":
+        d, s = s_uniform(n, 0)
+        d, _ = with_classes(d, 18, 0)
+    else:
+        raise KeyError(name)
+    return d, tie_free(s)
+
+
 def rbox_to_quad(dets):
     """(n,5) -> (n,8) corners (float64 math, cast to float32) for poly fixtures."""
     d = dets.double()

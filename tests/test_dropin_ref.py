@@ -68,6 +68,13 @@ assert type(det) is Y.Detect
 with torch.no_grad():
     z, xs = m(torch.zeros(1, 3, 64, 64))
 assert z.shape == (1, 3 * (8 * 8 + 4 * 4 + 2 * 2), 16 + 185) and len(xs) == 3
+# the oracle's restatement of this network (bench.py's `detect.py --device cpu` baseline on the GPU box, where the reference
+# tree does not exist) has the reference model's parameter count and output shape
+from oracle import pyref_model
+pm = pyref_model.YoloV5nObb(16).eval()
+assert sum(q.numel() for q in pm.parameters()) == sum(q.numel() for q in m.parameters())
+with torch.no_grad():
+    assert pm(torch.zeros(1, 3, 64, 64)).shape == z.shape
 # ADVICE r1: a module that has run inference pickles, and the pickle names models.yolo.Detect (loadable by a plain checkout)
 import io, pickle, pickletools
 det._host_tables()

@@ -124,6 +124,29 @@ def test_nms_rotated_float64_rule(dev, oracle_lib):
     assert inds.dtype == torch.int64 and len(inds) == len(got)
 
 
+def test_small_grid_fallback_gives_the_same_result(dev, oracle_lib):
+    """obb_nms_set_max_grid(8): the grid the host layer retries with after a barrier abort (workgroups not co-resident);
+    same kept list with 8 workgroups as with one per CU -- single list with the in-kernel index build, and the fused driver."""
+    from yolov5_obb_amd import _lib, nms_rotated_ext
+    from yolov5_obb_amd.utils.general import non_max_suppression_obb
+    from oracle import pyref
+    dets, scores = synth.s_clustered(40000, 2500, seed=5)
+    scores = synth.tie_free(scores)
+    ref = oracle.nms_rotated(dets.numpy(), scores.numpy(), 0.4, threads=8)
+    pred = synth.s_pred(2, 4000, 15, seed=3)
+    kw = dict(conf_thres=0.25, iou_thres=0.45, multi_label=True, max_det=300)
+    want = pyref.non_max_suppression_obb(pred.clone(), **kw)
+    L = _lib.lib()
+    try:
+        L.obb_nms_set_max_grid(8)
+        got = nms_rotated_ext.nms_rotated(dets.to(dev), scores.to(dev), 0.4).cpu().numpy()
+        out = non_max_suppression_obb(pred.to(dev), **kw)
+    finally:
+        L.obb_nms_set_max_grid(0)
+    assert np.array_equal(ref, got)
+    assert all(torch.equal(g.cpu(), w) for g, w in zip(out, want))
+
+
 def test_nms_rotated_errors(dev):
     from yolov5_obb_amd import nms_rotated_ext
     from yolov5_obb_amd.utils.nms_rotated import obb_nms, poly_nms
@@ -231,26 +254,7 @@ def test_heavy_duplication_is_repeatable(dev, oracle_lib):
             assert np.array_equal(got, ref), (n, k, rep, len(got), len(ref))
 
 
-def regime_100k(name, n=100000):
-    """The four N = 100k regimes bench.py reports (SURVEY section 8d distributions; `raw` = the exact tensor bench.py times,
-    scores not made tie-free: ties follow the documented rule, ascending original index)."""
-    if name == "clustered_k300_raw":
-        return synth.s_clustered(n, 300, seed=0)
-    if name == "clustered_k300":
-        d, s = synth.s_clustered(n, 300, seed=0)
-    elif name == "clustered_k300_18cls":                    # the natural shape of BASELINE configs[3] (DOTAv2.0, nc 18)
-        d, s = synth.s_clustered(n, 300, seed=0)
-        d, _ = synth.with_classes(d, 18, 0)
-    elif name == "clustered_k3000":
-        d, s = synth.s_clustered(n, 3000, seed=0)
-    elif name == "uniform":
-        d, s = synth.s_uniform(n, 0)
-    elif name == "uniform_18cls":
-        d, s = synth.s_uniform(n, 0)
-        d, _ = synth.with_classes(d, 18, 0)
-    else:
-        raise KeyError(name)
-    return d, synth.tie_free(s)
+regime_100k = synth.regime_100k
 
 
 @pytest.mark.parametrize("regime", ["clustered_k300", "clustered_k300_raw", "clustered_k300_18cls", "clustered_k3000", "uniform",

@@ -28,6 +28,7 @@ _vp, _i64, _i32, _f32, _sz = C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_size
 SIGNATURES = {
     "obb_version": (C.c_char_p, []),
     "obb_device_info": (_i32, [C.POINTER(_i32), C.POINTER(_i32), C.c_char_p, _i32]),
+    "obb_nms_set_max_grid": (_i32, [_i32]),
     "obb_profile_enable": (_i32, [_i32]),
     "obb_profile_collect": (_i32, [_vp, _vp, _i32]),
     "obb_nms_workspace_bytes": (_sz, [_i64, _i64, _i32]),
@@ -88,11 +89,29 @@ def check(rc, what):
         raise RuntimeError(f"{what} failed: {_ERR.get(rc, 'error')} (code {rc})")
 
 
+class NmsAborted(RuntimeError):
+    pass
+
+
 def checked_count(n, what):
     """A negative kept-count is the device-side abort signal of the persistent NMS kernel (a team barrier timed out)."""
     if n < 0:
-        raise RuntimeError(f"{what}: the NMS kernel aborted (a workgroup barrier timed out); results are invalid")
+        raise NmsAborted(f"{what}: the NMS kernel aborted (a workgroup barrier timed out); results are invalid")
     return n
+
+
+def retry_on_abort(run):
+    """The persistent NMS kernel needs all its workgroups resident (include/obb_hip.h: obb_nms_set_max_grid).  When a call
+    aborts on a barrier, run it once more with a grid of 8 workgroups -- resident under any CU mask -- before giving up."""
+    try:
+        return run()
+    except NmsAborted:
+        L = lib()
+        L.obb_nms_set_max_grid(8)
+        try:
+            return run()
+        finally:
+            L.obb_nms_set_max_grid(0)
 
 
 def stream_ptr(device):

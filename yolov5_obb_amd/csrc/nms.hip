@@ -332,7 +332,13 @@ constexpr int64_t kGridMinN = 8192;    // below this the exhaustive cross phase 
 // One persistent launch runs the whole step loop (nms_core.h).  Grid: one 512-thread workgroup per CU at most --
 // all workgroups must be resident because they meet at team barriers; smaller problems get fewer workgroups
 // (cheaper barriers).
+static int g_max_grid = 0;            // obb_nms_set_max_grid
+static int hw_cu_count();
 static int cu_count() {
+  const int c = hw_cu_count();
+  return (g_max_grid > 0 && g_max_grid < c) ? g_max_grid : c;
+}
+static int hw_cu_count() {
   static int cus = 0;
   if (!cus) {
     int dev = 0; hipDeviceProp_t p;
@@ -718,7 +724,12 @@ int obb_profile_collect(double* ms_sum, int64_t* count, int n_stages) {
   return OBB_OK;
 }
 
-const char* obb_version(void) { return "obb_hip 0.1 (gfx950)"; }
+int obb_nms_set_max_grid(int max_workgroups) {
+  g_max_grid = max_workgroups > 0 ? max_workgroups : 0;
+  return OBB_OK;
+}
+
+const char* obb_version(void) { return "obb_hip 0.2 (gfx950)"; }
 
 int obb_device_info(int* cu_count, int* wave_size, char* arch_name, int arch_name_len) {
   int dev = 0;

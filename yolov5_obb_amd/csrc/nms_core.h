@@ -940,7 +940,17 @@ __device__ __forceinline__ void nms_cross_grid(const NmsArgs& a, const GridPlan&
             for (int u = 0; u < 4; u++) {
               be[u] = (i + u < cnt) ? (uint32_t)__builtin_amdgcn_readfirstlane((int)blist[i + u]) : 0u;
               val[u] = lane < (int)(be[u] & 127u);
-              cq[u] = val[u] ? a.gsorted[(size_t)(be[u] >> 7) + lane] : make_float4(0.f, 0.f, 0.f, 0.f);
+              cq[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+              if (val[u]) {
+#ifdef OBB_GRID_COHERENT_LOADS
+                const u64* src = reinterpret_cast<const u64*>(a.gsorted + (size_t)(be[u] >> 7) + lane);
+                const u64 lo = ldg_agent(src), hi = ldg_agent(src + 1);
+                cq[u] = make_float4(__uint_as_float((uint32_t)lo), __uint_as_float((uint32_t)(lo >> 32)), __uint_as_float((uint32_t)hi),
+                                    __uint_as_float((uint32_t)(hi >> 32)));
+#else
+                cq[u] = a.gsorted[(size_t)(be[u] >> 7) + lane];
+#endif
+              }
             }
             // circle test, then the alive bits of what passed (four independent gathers in flight): most candidates
             // of a later step are dead already and never reach a queue
@@ -1115,18 +1125,29 @@ __global__ __launch_bounds__(kNmsThreads) __attribute__((amdgpu_waves_per_eu(1, 
         if (n_brute > 0) {
           // the boxes the index leaves out: brute kept rows against every column, every kept row against the brute columns
           // (the chunk list in LDS is free between resolve and the next select: it takes the brute rows, capmax at a time)
+          // (every workgroup builds the SAME list in the SAME order -- ordered compaction, no atomics: the exhaustive form
+          //  splits the row list over waves of different workgroups)
           for (int j0 = 0; j0 < nr; j0 += a.capmax) {
             const int j1 = min(nr, j0 + a.capmax);
-            __syncthreads();
-            if (tid == 0) s_i[9] = 0;
-            __syncthreads();
-            for (int j = j0 + tid; j < j1; j += kNmsThreads) {
-              const uint32_t rp = rows[j];
-              if (a.rec[(size_t)rp * G::RECQ + 3].y != 0.f) cidx[atomicAdd(&s_i[9], 1)] = rp;
+            int nbr = 0;
+            for (int jb = j0; jb < j1; jb += kNmsThreads) {
+              const int j = jb + tid;
+              uint32_t rp = 0u;
+              bool flag = false;
+              if (j < j1) { rp = rows[j]; flag = a.rec[(size_t)rp * G::RECQ + 3].y != 0.f; }
+              const u64 fm = __ballot(flag);
+              __syncthreads();                                   // previous users of s_i / readers of the list are done
+              if ((tid & 63) == 0) s_i[wv] = __popcll(fm);
+              __syncthreads();
+              int pre = 0, tot = 0;
+#pragma unroll
+              for (int k = 0; k < kNmsWaves; k++) { const int t = s_i[k]; if (k < wv) pre += t; tot += t; }
+              if (flag) cidx[nbr + pre + __popcll(fm & lanemask_lt())] = rp;
+              nbr += tot;
             }
             __syncthreads();
-            const int nbr = s_i[9];
             if (nbr > 0) nms_cross<G>(a, cidx, nbr, c0, c1, nullptr, 0, tw, ntw, L);
+            __syncthreads();                                     // the list is read until here
           }
           nms_cross<G>(a, rows, nr, c0, c1, a.ulist, n_brute, tw, ntw, L);
         }

@@ -13,6 +13,10 @@ _ws_bytes = {}      # n -> obb_nms_workspace_bytes(n, 1, 0)
 
 
 def _run_rotated(dets, scores, iou_threshold, flags=0, max_keep=0):
+    return _lib.retry_on_abort(lambda: _run_rotated_once(dets, scores, iou_threshold, flags, max_keep))
+
+
+def _run_rotated_once(dets, scores, iou_threshold, flags, max_keep):
     L = _lib.lib()
     n = dets.shape[0]
     dev = dets.device

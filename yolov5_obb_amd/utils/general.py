@@ -99,6 +99,7 @@ def non_max_suppression_obb(prediction, conf_thres=0.25, iou_thres=0.45, classes
     if meta is None:                                                  # never handed out -> one buffer per (device, bs, thread)
         meta = _meta_memo[mkey] = torch.empty(bs + 2, dtype=torch.int64, device=dev)
     agn = int(bool(agnostic))
+    aborted_once = False
     while True:
         hint = int(_cand_memo.get(key, 0))
         with _lib.guard(dev):
@@ -115,8 +116,13 @@ def non_max_suppression_obb(prediction, conf_thres=0.25, iou_thres=0.45, classes
                 C.c_void_p(meta.data_ptr() + 8 * bs), _lib.ptr(ws), ws.numel(), C.c_void_p(st))
         _lib.check(rc, "obb_non_max_suppression_obb")
         m = meta.tolist()                                             # the single device->host sync of the call
-        if min(m[:bs]) < 0:
-            _lib.checked_count(min(m[:bs]), "obb_non_max_suppression_obb")
+        if min(m[:bs]) < 0:                                           # a team barrier of the NMS kernel timed out
+            if aborted_once:
+                L.obb_nms_set_max_grid(0)
+                _lib.checked_count(min(m[:bs]), "obb_non_max_suppression_obb")
+            aborted_once = True
+            L.obb_nms_set_max_grid(8)                                 # once more with a grid that is resident under any CU mask
+            continue
         if m[bs] > cap:                                               # an image produced more candidates than slots
             cap = min(worst, max(int(m[bs]), 2 * cap))
             continue
@@ -124,6 +130,8 @@ def non_max_suppression_obb(prediction, conf_thres=0.25, iou_thres=0.45, classes
             _cand_memo[key] = int(m[bs + 1])
             continue
         break
+    if aborted_once:
+        L.obb_nms_set_max_grid(0)
     _cap_memo[key] = cap
     _cand_memo[key] = int(m[bs + 1])
     counts = m[:bs]
