@@ -424,6 +424,7 @@ def main():
             cpu["nms_1thread_note"] = "oracle port of nms_rotated_cpu (>=), iou 0.4, one thread; null = skipped by the time box"
             # (ii) detect.py --device cpu equivalent: model forward + NMS + rbox2poly + scale_polys per image, all host cores
             net = pyref_model.YoloV5nObb(16).eval()
+            torch.set_num_threads(min(ncores, 32))               # (intra-op threads: hundreds of them slow torch's CPU convolutions down)
             img = torch.rand(1, 3, 1024, 1024)
             buckets = [0.0, 0.0, 0.0]
             nimg2 = 0

@@ -79,6 +79,12 @@ class YoloV5nObb(nn.Module):
         self.m = nn.ModuleList(nn.Conv2d(c, self.no * self.na, 1) for c in (w[2], w[3], w[4]))   # Detect.m (models/yolo.py:46)
         self.anchors = torch.tensor(ANCHORS).float().view(3, 3, 2) / torch.tensor(STRIDES).view(3, 1, 1)
         self.strides = torch.tensor(STRIDES)
+        import math
+        for mi, st in zip(self.m, STRIDES):                  # Model._initialize_biases (models/yolo.py:224-231)
+            b = mi.bias.view(self.na, -1)
+            b.data[:, 4] += math.log(8 / (640 / st) ** 2)    # obj (8 objects per 640 image)
+            b.data[:, 5:] += math.log(0.6 / (nc - 0.999999))     # (the reference adds the class prior to the CSL channels as well)
+            mi.bias = torch.nn.Parameter(b.view(-1), requires_grad=True)
 
     def forward(self, x):
         x = self.b2(self.b1(self.b0(x)))

@@ -1215,6 +1215,8 @@ __global__ __launch_bounds__(kNmsThreads) __attribute__((amdgpu_waves_per_eu(1, 
       if (nr > 0 && more) { jrows = a.rows + sb + kept; jnr = nr; jc0 = cur; jc1 = wend; }   // the chunk's kept rows against what is left of the window
       kept += nr;
       if (prof) a.prof[6] += 1;
+      // (measured: jumping to the largest chunk when most of a chunk is kept -- sparse data -- is slower, 0.78 -> 0.96 ms at
+      //  100k with 18 class offsets: the pair phase grows with the square of the chunk)
       if (cap < a.capmax) { cap *= 2; if (cap > a.capmax) cap = a.capmax; }
     }
   }
