@@ -110,3 +110,108 @@ def test_two_rank_merge_splits_the_class_files(tmp_path):
     assert all(files == sorted(want) for _, files in seen)
     for name, text in want.items():
         assert (dst / name).read_text() == text
+
+
+# ---------------------------------------------------------------------------- the sharded validation runner
+class _FakeSet(torch.utils.data.Dataset):
+    """23 'images': content and labels are functions of the index (stand-in for LoadImagesAndLabels)."""
+
+    def __len__(self):
+        return 23
+
+    def __getitem__(self, i):
+        g = torch.Generator().manual_seed(500 + i)
+        im = torch.randint(0, 256, (3, 32, 32), dtype=torch.uint8, generator=g)
+        nl = i % 4
+        lab = torch.zeros(nl, 7)
+        if nl:
+            lab[:, 1] = torch.randint(0, 3, (nl,), generator=g).float()
+            lab[:, 2:4] = torch.rand(nl, 2, generator=g) * 32
+            lab[:, 4:6] = torch.rand(nl, 2, generator=g) * 8 + 2
+        return im, lab, f"img{i}.png", ((40, 40), ((0.8, 0.8), (0.0, 0.0)))
+
+    @staticmethod
+    def collate_fn(batch):
+        im, lab, path, shapes = zip(*batch)
+        for k, l in enumerate(lab):
+            l[:, 0] = k
+        return torch.stack(im, 0), torch.cat(lab, 0), path, shapes
+
+
+def _fake_model(im):
+    s = im.float().mean((1, 2, 3))                                   # one number per image
+    return (s[:, None, None].expand(-1, 5, 7) * torch.arange(1, 36).view(1, 5, 7).float(),)
+
+
+def _fake_nms(out, conf, iou, multi_label=True, agnostic=False):
+    res = []
+    for o in out:
+        k = int(o[0, 0] * 1000) % 4                                  # 0..3 "detections"
+        d = o[:k].clone()
+        d[:, 6] = (d[:, 6] * 10).floor() % 3
+        res.append(d)
+    return res
+
+
+def _fake_post(pred, ratio_pad=None):
+    n = pred.shape[0]
+    poly = torch.cat((pred[:, :4].repeat(1, 2), pred[:, 5:7]), 1)
+    hbb = torch.cat((pred[:, :2], pred[:, :2] + pred[:, 2:4].abs(), pred[:, 5:7]), 1)
+    return poly, hbb, poly / ratio_pad[0][0], hbb / ratio_pad[0][0]
+
+
+def _fake_match(det, lab, iouv):
+    return (det[:, 5:6] == lab[:, 0].view(1, -1)).any(1, keepdim=True) & (iouv.view(1, -1) < 0.8)
+
+
+def _run_fake(loader, n_total):
+    from yolov5_obb_amd import val_sharded
+    seen_ap = {}
+
+    def fake_ap(tp, conf, pcls, tcls, plot=False, save_dir=".", names=None):
+        seen_ap["n"] = (len(tp), len(tcls))
+        return float(tp.sum())
+    r = val_sharded.run(_fake_model, loader, n_total=n_total, device="cpu", half=False, ap_per_class=fake_ap,
+                        nms=_fake_nms, postprocess=_fake_post, match=_fake_match)
+    return r, seen_ap
+
+
+def _val_worker(rank, world_size, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world_size))
+    dist.init_process_group("gloo", rank=rank, world_size=world_size)
+    try:
+        from yolov5_obb_amd import val_sharded
+        ds = _FakeSet()
+        full = torch.utils.data.DataLoader(ds, batch_size=4, collate_fn=_FakeSet.collate_fn)
+        r, ap = _run_fake(val_sharded.shard_loader(full), len(ds))
+        if rank == 0:
+            q.put(("ok", [c.tolist() for c in r["stats"]], r["seen"], r["metrics"]))
+        else:
+            assert r["stats"] is None and r["metrics"] is None and r["seen"] == len(ds)
+            q.put(("peer",))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_validation_equals_single_process():
+    """val_sharded.run over two ranks (gloo) returns, on rank 0, exactly the statistics of a single-process run over the whole
+    list, in the original image order, and the metric callable sees the same arrays (the reference's ap_per_class in a real
+    run).  The hot-path callables are stand-ins here; the HIP ones are covered by the -m gpu tests."""
+    ds = _FakeSet()
+    full = torch.utils.data.DataLoader(ds, batch_size=4, collate_fn=_FakeSet.collate_fn)
+    single, ap1 = _run_fake(full, len(ds))
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_val_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0
+    got = sorted((q.get(timeout=10) for _ in range(2)), key=lambda t: t[0])
+    assert got[0][0] == "ok" and got[1][0] == "peer"
+    _, stats2, seen2, metric2 = got[0]
+    assert seen2 == len(ds) == single["seen"]
+    assert [c.tolist() for c in single["stats"]] == stats2 and len(stats2) == 4 and len(stats2[0]) > 5
+    assert metric2 == single["metrics"]

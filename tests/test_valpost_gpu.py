@@ -66,3 +66,52 @@ def test_against_outputs_frozen_from_the_reference_val_py(dev):
     got = val_postprocess(d7.to(dev), ratio_pad=((gain, gain), pad))
     for g_, key in zip(got, ("vp_poly", "vp_hbb", "vp_polyn", "vp_hbbn")):
         assert np.allclose(g_.cpu().numpy(), G[key], rtol=1e-6, atol=2e-4)
+
+
+def test_sharded_val_loop_hip_vs_oracle(dev):
+    """yolov5_obb_amd.val_sharded.run (the per-batch loop of val.py:180-250, single process here) on the HIP hot path equals
+    the same loop with the oracle's restatements as the three callables -- same (correct, conf, pcls, tcls) statistics."""
+    from yolov5_obb_amd import val_sharded
+
+    class Set(torch.utils.data.Dataset):
+        def __len__(self):
+            return 6
+
+        def __getitem__(self, i):
+            g = torch.Generator().manual_seed(70 + i)
+            im = torch.randint(0, 256, (3, 64, 64), dtype=torch.uint8, generator=g)
+            nl = 12
+            lab = torch.zeros(nl, 7)
+            lab[:, 1] = torch.randint(0, 15, (nl,), generator=g).float()
+            lab[:, 2:4] = torch.rand(nl, 2, generator=g) * 1000
+            lab[:, 4] = torch.rand(nl, generator=g) * 120 + 20
+            lab[:, 5] = torch.rand(nl, generator=g) * 30 + 8
+            lab[:, 6] = (torch.rand(nl, generator=g) - 0.5) * 3.0
+            return im, lab, f"i{i}", ((1300, 1400), ((0.7314, 0.7314), (12.0, 3.5)))
+
+        @staticmethod
+        def collate_fn(batch):
+            im, lab, path, shapes = zip(*batch)
+            for k, l in enumerate(lab):
+                l[:, 0] = k
+            return torch.stack(im, 0), torch.cat(lab, 0), path, shapes
+
+    preds = {}
+
+    def model_for(device):
+        def model(im):
+            key = int(im.float().sum().item()) % 100000
+            if key not in preds:
+                preds[key] = synth.s_pred(im.shape[0], 3000, 15, seed=key % 1000, n_obj=30)
+            return (preds[key].to(device),)
+        return model
+    loader = torch.utils.data.DataLoader(Set(), batch_size=3, collate_fn=Set.collate_fn)
+    hip = val_sharded.run(model_for(dev), loader, conf_thres=0.25, iou_thres=0.45, half=False, device=dev)
+    ora = val_sharded.run(model_for("cpu"), loader, conf_thres=0.25, iou_thres=0.45, half=False, device="cpu",
+                          nms=lambda o, c, i, multi_label=True, agnostic=False: pyref.non_max_suppression_obb(o, c, i, multi_label=multi_label, agnostic=agnostic),
+                          postprocess=lambda p, ratio_pad=None: pyref.val_postprocess(p.clone(), ratio_pad[0][0], ratio_pad[1]),
+                          match=pyref.process_batch)
+    assert hip["seen"] == ora["seen"] == 6 and len(hip["stats"]) == 4 and len(hip["stats"][1]) > 20
+    assert np.array_equal(hip["stats"][0], ora["stats"][0])                       # correct (n, 10) bool
+    assert np.allclose(hip["stats"][1], ora["stats"][1], rtol=0, atol=0)          # conf: copied through
+    assert np.array_equal(hip["stats"][2], ora["stats"][2]) and np.array_equal(hip["stats"][3], ora["stats"][3])

@@ -417,11 +417,11 @@ static int nms_window(long long max_keep) {
 
 constexpr size_t kPersistLdsMax = 159 * 1024;   // of the 160 KB per CU: exactly one workgroup per CU
 
-template <class G>
+template <class G, bool GRID>
 static int launch_persist(const NmsArgs& a, unsigned nb, hipStream_t st) {
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)k_nms_persist<G>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPersistLdsMax) != hipSuccess)
+    if (hipFuncSetAttribute((const void*)k_nms_persist<G, GRID>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPersistLdsMax) != hipSuccess)
       return OBB_ERR_LAUNCH;
     attr_set = true;
   }
@@ -429,7 +429,7 @@ static int launch_persist(const NmsArgs& a, unsigned nb, hipStream_t st) {
   if (lds < (size_t)2 * a.capmax) return OBB_ERR_INTERNAL;    // (aliased by resolve: state + blocked bytes of one chunk)
   lds += (size_t)a.capmax * 4;                                // + this workgroup's copy of the chunk list
   if (lds > kPersistLdsMax) return OBB_ERR_INTERNAL;
-  k_nms_persist<G><<<nb, kNmsThreads, lds, st>>>(a);
+  k_nms_persist<G, GRID><<<nb, kNmsThreads, lds, st>>>(a);
   return OBB_OK;
 }
 
@@ -480,8 +480,9 @@ static int nms_steps(int kind, NmsArgs& a, const Carve& cv, int64_t nseg, int64_
     if (!(pre & kNmsPlanned)) k_plan_teams<<<1, 1024, 0, st>>>(a.seg_begin, a.seg_end, (int)nseg, (int)nb, c1, cv.plan);
     a.plan = cv.plan;
   }
-  if (kind == 2) return launch_persist<QuadGeom64>(a, (unsigned)nb, st);
-  return kind == 0 ? launch_persist<RotGeom>(a, (unsigned)nb, st) : launch_persist<QuadGeom>(a, (unsigned)nb, st);
+  if (kind == 2) return launch_persist<QuadGeom64, false>(a, (unsigned)nb, st);
+  if (kind == 1) return launch_persist<QuadGeom, false>(a, (unsigned)nb, st);
+  return a.gmeta != nullptr ? launch_persist<RotGeom, true>(a, (unsigned)nb, st) : launch_persist<RotGeom, false>(a, (unsigned)nb, st);
 }
 
 // kind: 0 rotated (5 floats + score array), 1 quad (rows of `stride` floats, score in column 8)

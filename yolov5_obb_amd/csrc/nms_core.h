@@ -185,15 +185,32 @@ struct WaveLds {
   float4 align16[0];
 };
 
+#ifndef OBB_STAGE_ATTR
+#define OBB_STAGE_ATTR __attribute__((noinline))
+#endif
 // The two expensive decision stages are real functions (one body per geometry): the pair phase and the forms of the
 // cross phase all drain their queues through them.
 template <class G, class TH>
-__device__ __attribute__((noinline)) int nms_stage_full(const float4* ra, const float4* rb, TH thr) {
+__device__ OBB_STAGE_ATTR int nms_stage_full(const float4* ra, const float4* rb, TH thr) {
   return G::classify_full(ra, rb, thr);
 }
 template <class G, class TH>
-__device__ __attribute__((noinline)) bool nms_stage_exact(const float4* ra, const float4* rb, TH thr, float* scr) {
+__device__ OBB_STAGE_ATTR bool nms_stage_exact(const float4* ra, const float4* rb, TH thr, float* scr) {
   return G::hit_exact(ra, rb, thr, scr);
+}
+
+// FN = true: through the shared functions (the single-list kernel with the indexed cross phase, which is at the register
+// limit); false: inlined into the drains (the multi-segment kernel of the fused driver: no index code, registers to spare,
+// and its ~100-box segments are bound by the latency of exactly these stages).
+template <class G, bool FN, class TH>
+__device__ __forceinline__ int stage_full(const float4* ra, const float4* rb, TH thr) {
+  if constexpr (FN) return nms_stage_full<G>(ra, rb, thr);
+  else return G::classify_full(ra, rb, thr);
+}
+template <class G, bool FN, class TH>
+__device__ __forceinline__ bool stage_exact(const float4* ra, const float4* rb, TH thr, float* scr) {
+  if constexpr (FN) return nms_stage_exact<G>(ra, rb, thr, scr);
+  else return G::hit_exact(ra, rb, thr, scr);
 }
 
 // Ring queue of pending (row, col) pairs in LDS; all bookkeeping is wave-uniform.
@@ -256,7 +273,7 @@ __device__ __forceinline__ int nms_select(const NmsArgs& a, int se, int& cur, in
 }
 
 // ------------------------------------------------------------------ A1: pairs inside the chunk (all waves of the team)
-template <class G>
+template <class G, bool FN>
 __device__ __forceinline__ void nms_pairs(const NmsArgs& a, int tm, int cn, const uint32_t* cidx, int tw, int ntw, WaveLds<G>& L) {
   const int lane = threadIdx.x & 63;
   const int nb = (cn + 63) >> 6;
@@ -284,7 +301,7 @@ __device__ __forceinline__ void nms_pairs(const NmsArgs& a, int tm, int cn, cons
     if (lane < cnt) {
       packed = L.qbuf2[(Q2.head + lane) & 127];
       const uint32_t pi = cidx[packed >> 16], pj = cidx[packed & 0xffff];
-      hit = nms_stage_exact<G>(a.rec + (size_t)pi * G::RECQ, a.rec + (size_t)pj * G::RECQ, G::thr_of(a), L.scr + lane);
+      hit = stage_exact<G, FN>(a.rec + (size_t)pi * G::RECQ, a.rec + (size_t)pj * G::RECQ, G::thr_of(a), L.scr + lane);
     }
     const u64 hm = __ballot(hit);
     if (hm) {
@@ -308,7 +325,7 @@ __device__ __forceinline__ void nms_pairs(const NmsArgs& a, int tm, int cn, cons
     if (lane < cnt) {
       packed = L.qbuf1b[(Q1.head + lane) & 127];
       const uint32_t pi = cidx[packed >> 16], pj = cidx[packed & 0xffff];
-      res = nms_stage_full<G>(a.rec + (size_t)pi * G::RECQ, a.rec + (size_t)pj * G::RECQ, G::thr_of(a));
+      res = stage_full<G, FN>(a.rec + (size_t)pi * G::RECQ, a.rec + (size_t)pj * G::RECQ, G::thr_of(a));
     }
     emit(res == 1, packed);
     Q1.head = (Q1.head + cnt) & 127;
@@ -546,7 +563,7 @@ __device__ __forceinline__ int nms_resolve(const NmsArgs& a, int g, int tm, int 
 // Exhaustive form: every row against every column.  Columns are either the positions [c0, se) (clist == NULL: one wave
 // per 64-position word of the bitmap, one atomicAnd per word) or the entries of a position list that fall into
 // [c0, se) (the boxes the spatial index leaves out, grid.h; one atomicAnd per killed box).
-template <class G>
+template <class G, bool FN>
 __device__ __forceinline__ void nms_cross(const NmsArgs& a, const uint32_t* rows, int nr, int c0, int se, const uint32_t* clist, int ncl,
                                           int tw, int ntw, WaveLds<G>& L) {
   const bool LIST = clist != nullptr;            // (wave-uniform; one body serves both forms)
@@ -608,7 +625,7 @@ __device__ __forceinline__ void nms_cross(const NmsArgs& a, const uint32_t* rows
         const uint32_t rowp = L.qbuf2[slot];
         const int cc = L.q2col[slot];
         if (!L.cdead[cc]) {
-          if (nms_stage_exact<G>(a.rec + (size_t)rowp * G::RECQ, a.rec + (size_t)L.colpos[cc] * G::RECQ, G::thr_of(a), L.scr + lane)) L.cdead[cc] = 1;
+          if (stage_exact<G, FN>(a.rec + (size_t)rowp * G::RECQ, a.rec + (size_t)L.colpos[cc] * G::RECQ, G::thr_of(a), L.scr + lane)) L.cdead[cc] = 1;
         }
       }
       Q2.head = (Q2.head + cnt) & 127;
@@ -633,7 +650,7 @@ __device__ __forceinline__ void nms_cross(const NmsArgs& a, const uint32_t* rows
         rowp = L.qbuf1b[slot];
         cc = L.q1bcol[slot];
         if (!L.cdead[cc]) {
-          res = nms_stage_full<G>(a.rec + (size_t)rowp * G::RECQ, a.rec + (size_t)L.colpos[cc] * G::RECQ, G::thr_of(a));
+          res = stage_full<G, FN>(a.rec + (size_t)rowp * G::RECQ, a.rec + (size_t)L.colpos[cc] * G::RECQ, G::thr_of(a));
           if (res == 1) L.cdead[cc] = 1;
         }
       }
@@ -746,6 +763,10 @@ __device__ __forceinline__ void nms_cross(const NmsArgs& a, const uint32_t* rows
   }
 }
 
+#ifndef OBB_SCAN_BATCH
+#define OBB_SCAN_BATCH 4
+#endif
+constexpr int kScanBatch = OBB_SCAN_BATCH;          // blocks of candidates in flight per wave
 // Indexed form (grid.h): a kept row only needs the boxes of the cells around it.  The boxes of the call sit once more in
 // CELL order (built before the launch: count, scan, scatter); a query window is a few cell rows per level, and the boxes of
 // one cell row are ONE contiguous range of that array (the slot hash is linear in cx), read coalesced by the 64 lanes
@@ -932,12 +953,12 @@ __device__ __forceinline__ void nms_cross_grid(const NmsArgs& a, const GridPlan&
           c_blocks += (u64)cnt;
           ctock(c_pro);
           ctick();
-          for (int i = 0; i < cnt; i += 4) {
-            uint32_t be[4];
-            float4 cq[4];
-            bool val[4];
+          for (int i = 0; i < cnt; i += kScanBatch) {
+            uint32_t be[kScanBatch];
+            float4 cq[kScanBatch];
+            bool val[kScanBatch];
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
+            for (int u = 0; u < kScanBatch; u++) {
               be[u] = (i + u < cnt) ? (uint32_t)__builtin_amdgcn_readfirstlane((int)blist[i + u]) : 0u;
               val[u] = lane < (int)(be[u] & 127u);
               cq[u] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -954,10 +975,10 @@ __device__ __forceinline__ void nms_cross_grid(const NmsArgs& a, const GridPlan&
             }
             // circle test, then the alive bits of what passed (four independent gathers in flight): most candidates
             // of a later step are dead already and never reach a queue
-            bool pass[4];
-            u64 aw[4];
+            bool pass[kScanBatch];
+            u64 aw[kScanBatch];
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
+            for (int u = 0; u < kScanBatch; u++) {
               const uint32_t cp = __float_as_uint(cq[u].w);
               const float dx = cq[u].x - rq.x, dy = cq[u].y - rq.y, rs = rq.z + cq[u].z;
               pass[u] = val[u] && (int)cp >= c0 && (int)cp < se && !(dx * dx + dy * dy > rs * rs);
@@ -966,7 +987,7 @@ __device__ __forceinline__ void nms_cross_grid(const NmsArgs& a, const GridPlan&
               aw[u] = pass[u] ? a.alive[cp >> 6] : 0ull;
             }
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
+            for (int u = 0; u < kScanBatch; u++) {
               const uint32_t cp = __float_as_uint(cq[u].w);
               const bool go = pass[u] && ((aw[u] >> (cp & 63)) & 1ull);
               if (__ballot(go)) {
@@ -1067,7 +1088,8 @@ __device__ __forceinline__ bool grid_build(const NmsArgs& a, int c0, int wg, int
 // dynamic LDS: [kNmsWaves x WaveLds<G>] (aliased by the resolve state) | chunk list [capmax] u32
 // One workgroup per CU (the LDS footprint allows no second one) = 2 waves per SIMD: let the compiler use the whole
 // 256-register budget of such a wave instead of spilling to scratch (measured: 20 MB of scratch writes per launch).
-template <class G>
+// GRID: with the indexed cross phase (single list); without it the kernel is the exhaustive one only.
+template <class G, bool GRID>
 __global__ __launch_bounds__(kNmsThreads) __attribute__((amdgpu_waves_per_eu(1, 2))) void k_nms_persist(NmsArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __shared__ int s_i[16];
@@ -1105,7 +1127,7 @@ __global__ __launch_bounds__(kNmsThreads) __attribute__((amdgpu_waves_per_eu(1, 
   GridPlan gp = {};
   uint32_t glevels = 0;
   int n_brute = 0;
-  if constexpr (G::HAS_GRID) {
+  if constexpr (G::HAS_GRID && GRID) {
     if (a.gmeta != nullptr && a.nseg == 1 && T == NB && ((int)a.gmask + T) / T <= kNmsThreads && T <= kNmsThreads) {
       gp = grid_plan(a.gmeta->bb);
       glevels = a.gmeta->level_mask;
@@ -1115,7 +1137,7 @@ __global__ __launch_bounds__(kNmsThreads) __attribute__((amdgpu_waves_per_eu(1, 
   }
   // kept rows x alive positions of [c0, c1)
   auto cross = [&](const uint32_t* rows, int nr, int c0, int c1) {
-    if constexpr (G::HAS_GRID) {
+    if constexpr (G::HAS_GRID && GRID) {
       if (grid_on && nr >= kGridMinRows) {           // (a few hundred kept rows: the exhaustive form is the cheaper one)
         if (!grid_built) {                           // first use: sort what is still alive behind the chunk into its cells
           if (!grid_build<G>(a, c0, wg, T, bar, &s_flag, s_i)) { aborted = true; return; }
@@ -1146,15 +1168,15 @@ __global__ __launch_bounds__(kNmsThreads) __attribute__((amdgpu_waves_per_eu(1, 
               nbr += tot;
             }
             __syncthreads();
-            if (nbr > 0) nms_cross<G>(a, cidx, nbr, c0, c1, nullptr, 0, tw, ntw, L);
+            if (nbr > 0) nms_cross<G, GRID>(a, cidx, nbr, c0, c1, nullptr, 0, tw, ntw, L);
             __syncthreads();                                     // the list is read until here
           }
-          nms_cross<G>(a, rows, nr, c0, c1, a.ulist, n_brute, tw, ntw, L);
+          nms_cross<G, GRID>(a, rows, nr, c0, c1, a.ulist, n_brute, tw, ntw, L);
         }
         return;
       }
     }
-    nms_cross<G>(a, rows, nr, c0, c1, nullptr, 0, tw, ntw, L);
+    nms_cross<G, GRID>(a, rows, nr, c0, c1, nullptr, 0, tw, ntw, L);
   };
 
   const int plan_chunk = a.cap_first < a.capmax ? a.cap_first : a.capmax;
@@ -1195,7 +1217,7 @@ __global__ __launch_bounds__(kNmsThreads) __attribute__((amdgpu_waves_per_eu(1, 
       lap(1);
       if (cn == 0) continue;                               // nothing alive in the rest of the window (cur == wend now)
       const u64 tpz = (a.prof && tid == 0) ? wall_clock64() : 0ull;
-      nms_pairs<G>(a, team, cn, cidx, tw, ntw, L);
+      nms_pairs<G, GRID>(a, team, cn, cidx, tw, ntw, L);
       if (a.prof && tid == 0) { const u64 d = wall_clock64() - tpz; atomicMax(a.prof + 29, d); atomicAdd(a.prof + 30, d); }
       lap(2);
       // ---- all edges are out: the last arriver resolves the chunk, the others wait for its rows
