@@ -118,6 +118,11 @@ def stream_ptr(device):
     return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
+def stream_sync(device, handle=None):
+    """Block until the current stream of `device` has finished (hipStreamSynchronize through torch)."""
+    torch.cuda.current_stream(device).synchronize()
+
+
 def stream_handle(device):
     """Raw hipStream_t of the current stream (an int): look it up once per call, it costs a few microseconds."""
     return torch.cuda.current_stream(device).cuda_stream

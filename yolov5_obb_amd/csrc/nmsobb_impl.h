@@ -378,7 +378,7 @@ __global__ void k_reset_state(int* __restrict__ cnt, int n_cnt, int* __restrict_
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x, n = (long long)gridDim.x * blockDim.x;
   for (long long k = i; k < n_cnt; k += n) cnt[k] = 0;
   for (long long k = i; k < bs; k += n) tiny[k] = 0;
-  if (i < 2) status[i] = 0;
+  (void)status;                                                 // (both status words are written by k_gather_out)
   if (i == 2) *ticket = 0;
   for (long long k = i; k < n_bar16; k += n) bar16[k] = make_uint4(0u, 0u, 0u, 0u);
 }
@@ -599,8 +599,23 @@ __global__ __launch_bounds__(256) void k_gather_out(const float4* __restrict__ c
     long long nk = total;
     if (max_det > 0 && nk > max_det) nk = max_det;
     out_count[g] = *abort_flag ? -1 : nk;                        // -1: the NMS kernel gave up on a barrier (host raises)
-    if (cnt[g * kCntPad] > cap_img) atomicMax((unsigned long long*)status, (unsigned long long)cnt[g * kCntPad]);   // overflow: caller retries
-    atomicMax((unsigned long long*)status + 1, (unsigned long long)cnt[g * kCntPad]);   // feedback for the caller's next call
+  }
+  // status[0]: the largest candidate count if an image overflowed its slots (the caller retries), else 0; status[1]: the largest
+  // candidate count (feedback for the caller's next call).  Plain stores by one workgroup -- out_count and status may be pinned
+  // host memory (the host layer reads them without a device->host copy).
+  if (g == 0) {
+    long long mx = 0;
+    for (int b2 = tid; b2 < (int)gridDim.x; b2 += 256) { const long long c = cnt[b2 * kCntPad]; if (c > mx) mx = c; }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { const long long o = __shfl_xor(mx, d); if (o > mx) mx = o; }
+    if ((tid & 63) == 0) s_rows[tid >> 6] = mx;
+    __syncthreads();
+    if (tid == 0) {
+      for (int k = 1; k < 4; k++) if (s_rows[k] > mx) mx = s_rows[k];
+      status[0] = mx > cap_img ? mx : 0;
+      status[1] = mx;
+    }
+    __syncthreads();
   }
   // first output row of the image: g * max_det, or (packed) the number of rows of the images before it
   long long row0 = (long long)g * max_det;

@@ -97,6 +97,8 @@ def non_max_suppression_obb(prediction, conf_thres=0.25, iou_thres=0.45, classes
     mkey = (dev.index, bs, threading.get_ident())
     meta = _meta_memo.get(mkey)                                       # counts[bs] + status[2]: read back before returning,
     if meta is None:                                                  # never handed out -> one buffer per (device, bs, thread)
+        # (device memory + one blocking copy; having the last kernel write the counts into pinned host memory and
+        #  synchronising the stream instead was measured slower: 0.282 vs 0.254 ms per bs16 step)
         meta = _meta_memo[mkey] = torch.empty(bs + 2, dtype=torch.int64, device=dev)
     agn = int(bool(agnostic))
     aborted_once = False
