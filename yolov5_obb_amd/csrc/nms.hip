@@ -150,78 +150,37 @@ __global__ void k_seg_bounds(const uint64_t* __restrict__ keys, int n, int nseg,
 }
 
 // ---------------------------------------------------------------- spatial index (grid.h): counting sort by cell
+// (everything except the bounding-box partials is produced inside the NMS kernel, when a step needs the index: nms_core.h grid_build)
 struct GridDev {
-  GridMeta* meta;
+  GridMeta* meta;              // zeroed before the launch
   int* bbpart; int nparts;     // per-block bounding boxes written by k_make_keys32
   int* cnt;                    // [M + 4] boxes per table slot (zeroed before the launch; the in-kernel build leaves zeros)
   int* start;                  // [M + 4] exclusive prefix, start[M] = total
   int* wsum;                   // [kMaxTeams] per-workgroup totals of the in-kernel scan
   float4* sorted;              // [n] {x, y, r, position}
-  uint32_t* slot_of;           // [n] table slot of position p, 0xffffffff: not indexed
   uint32_t* ulist;             // [n] positions kept out of the index
   uint32_t mask;               // M - 1
 };
 
-// blockDim.x is a multiple of 64 and p starts at 0: every wave covers one word of the alive bitmap.
-// With the spatial index (g.meta != NULL) the kernel also classifies the boxes for it: every block reduces the
-// bounding-box partials itself, then a box gets its table slot or goes to the brute list (grid.h).  The counting sort by
-// slot runs inside the NMS kernel, and only when a step needs the index (nms_core.h: grid_build).
+// blockDim.x is a multiple of 64 and p starts at 0: every wave covers one word of the alive bitmap
 __global__ __launch_bounds__(256) void k_prep_rot(const float* __restrict__ dets5, const uint32_t* __restrict__ order, int drop_small, int n,
-                                                  float4* __restrict__ rec, u64* __restrict__ alive, GridDev g) {
-  __shared__ int s_red[16][4];
-  const int p = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63;
-  GridPlan gp = {};
-  if (g.meta != nullptr) {
-    int bx0 = 0x7fffffff, by0 = 0x7fffffff, bx1 = (int)0x80000000, by1 = (int)0x80000000;
-    for (int i = threadIdx.x; i < g.nparts; i += blockDim.x) {
-      const int4 q = reinterpret_cast<const int4*>(g.bbpart)[i];
-      bx0 = min(bx0, q.x); by0 = min(by0, q.y); bx1 = max(bx1, q.z); by1 = max(by1, q.w);
-    }
-    block_minmax4(bx0, by0, bx1, by1, s_red);
-    const int bb[4] = {bx0, by0, bx1, by1};
-    if (blockIdx.x == 0 && threadIdx.x == 0) { g.meta->bb[0] = bx0; g.meta->bb[1] = by0; g.meta->bb[2] = bx1; g.meta->bb[3] = by1; }
-    gp = grid_plan(bb);
-  }
-  bool ok = false, brute = false;
-  uint32_t slot = 0xffffffffu, lbit = 0u;
+                                                  float4* __restrict__ rec, u64* __restrict__ alive) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  bool ok = false;
   if (p < n) {
     const float* d = dets5 + (size_t)order[p] * 5;
     float x = d[0], y = d[1], w = d[2], h = d[3], a = d[4];
     RBoxFeat f = rbox_make_feat(x, y, w, h, a);
     float4 q[4];
     RotGeom::pack(f, q);
-    float mn = (h < w) ? h : w;
-    ok = !(drop_small && mn < 0.001f);
-    if (g.meta != nullptr && ok) {
-      if (!gp.ok || grid_is_brute(gp, q[0].x, q[0].y, q[0].z, q[0].w)) { brute = true; q[3].y = 1.0f; }   // brute flag of the row side (nms_core.h)
-      else {
-        const int lv = grid_level(gp, q[0].z);
-        const float inv = grid_level_inv_cell(gp, lv);
-        const int cx = grid_cell(q[0].x, gp.x0, inv, grid_last_cell(gp.xr, inv));
-        const int cy = grid_cell(q[0].y, gp.y0, inv, grid_last_cell(gp.yr, inv));
-        slot = grid_slot(lv, cx, cy, g.mask);
-        lbit = 1u << lv;
-      }
-    }
 #pragma unroll
     for (int k = 0; k < 4; k++) rec[(size_t)p * 4 + k] = q[k];
-    if (g.meta != nullptr) g.slot_of[p] = slot;
+    float mn = (h < w) ? h : w;
+    ok = !(drop_small && mn < 0.001f);
   }
   const u64 m = __ballot(ok);
-  if (lane == 0 && (p & ~63) < n) alive[p >> 6] = m;
+  if ((threadIdx.x & 63) == 0 && (p & ~63) < n) alive[p >> 6] = m;
   if (p < 8) alive[((n + 63) >> 6) + p] = 0ull;      // guard words behind the last box (the bitmap is not memset)
-  if (g.meta != nullptr) {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) lbit |= __shfl_xor(lbit, d);
-    if (lane == 0 && lbit) atomicOr(&g.meta->level_mask, lbit);
-    const u64 bm = __ballot(brute);
-    if (bm) {
-      int base = 0;
-      if (lane == 0) base = atomicAdd(&g.meta->n_brute, __popcll(bm));
-      base = __shfl(base, 0);
-      if (brute) g.ulist[base + __popcll(bm & ((1ull << lane) - 1ull))] = (uint32_t)p;
-    }
-  }
 }
 
 __global__ void k_prep_quad(const float* __restrict__ polys, int stride, const uint32_t* __restrict__ order, int n,
@@ -399,7 +358,6 @@ static int carve(void* base, int64_t n, int64_t nseg, int recq, int C, Carve* cv
     cv->grid.nparts = (int)((nn + 255) / 256);
     cv->grid.bbpart = (int*)take((size_t)cv->grid.nparts * 16);
     cv->grid.sorted = (float4*)take(nn * 16);
-    cv->grid.slot_of = (uint32_t*)take(nn * 4);
     cv->grid.ulist = (uint32_t*)take(nn * 4);
   }
   cv->total = off;
@@ -542,16 +500,14 @@ static int run_nms(int kind, const float* boxes, int stride, const float* scores
   }
   {
     ProfScope ps(PROF_NMS_PREP, st);
-    GridDev gd = cv.grid;
-    if (!use_grid) gd.meta = nullptr;
-    if (kind == 0) k_prep_rot<<<gb, T, 0, st>>>(boxes, cv.vals_b, drop_small, (int)n, cv.rec, cv.alive, gd);
+    if (kind == 0) k_prep_rot<<<gb, T, 0, st>>>(boxes, cv.vals_b, drop_small, (int)n, cv.rec, cv.alive);
     else k_prep_quad<<<gb, T, 0, st>>>(boxes, stride, cv.vals_b, (int)n, cv.rec, cv.alive);
   }
 
   NmsArgs a{};
   if (use_grid) {
-    a.gmeta = cv.grid.meta; a.gslot_of = cv.grid.slot_of; a.gcnt = cv.grid.cnt; a.gstart = cv.grid.start; a.gsorted = cv.grid.sorted;
-    a.gwsum = cv.grid.wsum; a.ulist = cv.grid.ulist; a.gmask = cv.grid.mask;
+    a.gmeta = cv.grid.meta; a.bbpart = cv.grid.bbpart; a.nparts = cv.grid.nparts; a.gcnt = cv.grid.cnt; a.gstart = cv.grid.start;
+    a.gsorted = cv.grid.sorted; a.gwsum = cv.grid.wsum; a.ulist = cv.grid.ulist; a.gmask = cv.grid.mask;
   }
   a.rec = cv.rec; a.order = cv.vals_b; a.alive = cv.alive; a.seg_begin = cv.seg_begin; a.seg_end = cv.seg_end;
   a.keep_cnt = cv.keep_cnt; a.keep_out = keep_out;

@@ -64,16 +64,17 @@ struct NmsArgs {
   float thr;
   double thr64;              // QuadGeom64 only (the merge threshold is a Python float)
   int cull;                  // 1: conservative rejects allowed (thr >= 0)
-  // Spatial index over the boxes (grid.h); gmeta == NULL: none.  The prep kernel classifies the boxes (table slot or
-  // brute list); the counting sort itself runs INSIDE this kernel, and only when a step keeps enough rows to need it
-  // (grid_build): a call whose chunks keep a few hundred rows never pays for it.
-  const GridMeta* gmeta;
-  const uint32_t* gslot_of;  // [n] table slot of position p, 0xffffffff: not indexed (brute, or dropped from the start)
+  // Spatial index over the boxes (grid.h); gmeta == NULL: none.  Everything about it happens INSIDE this kernel, and only
+  // when a step keeps enough rows to need it (grid_build): a call whose chunks keep a few hundred rows pays nothing but
+  // the bounding-box partials of the key kernel.
+  GridMeta* gmeta;           // zero before the launch: n_brute / level_mask are counted by grid_build
+  const int* bbpart;         // [nparts][4] bounding box of the centres, one partial per workgroup of the key kernel (ordered ints)
+  int nparts;
   int* gcnt;                 // [gmask + 1] zero before the launch and after every build
   int* gstart;               // [gmask + 2] first entry of every table slot in gsorted (exclusive prefix; [gmask + 1] = total)
   float4* gsorted;           // {x, y, r, sorted position as bits} in slot order
   int* gwsum;                // [grid size] per-workgroup totals of the distributed scan
-  const uint32_t* ulist;     // [gmeta->n_brute] sorted positions of the boxes kept out of the index
+  uint32_t* ulist;           // [gmeta->n_brute] sorted positions of the boxes kept out of the index (filled by grid_build)
   uint32_t gmask;            // table size - 1 (power of two)
 };
 
@@ -850,7 +851,7 @@ __device__ __forceinline__ void nms_cross_grid(const NmsArgs& a, const GridPlan&
     ctick();
     const uint32_t rp = rows[row];
     const float4 rq = a.rec[(size_t)rp * G::RECQ];
-    if (a.rec[(size_t)rp * G::RECQ + 3].y != 0.f) continue;      // brute row
+    if (grid_is_brute(gp, rq.x, rq.y, rq.z, rq.w)) continue;     // brute row: the caller runs the exhaustive form for it
     auto drain = [&](int cnt) {                    // stage 1a: the cheap register-only tests (entries: column positions)
       wave_sync();
       int res = 0;
@@ -1019,24 +1020,51 @@ __device__ __forceinline__ void nms_cross_grid(const NmsArgs& a, const GridPlan&
 constexpr int kGridMinRows = 512;
 
 // Counting sort of the still-alive positions [c0, n) by table slot, by the whole team (= the whole grid: one segment):
-// count -> barrier -> distributed scan (every workgroup a slice of the table, then the prefix of the workgroup totals)
-// -> barrier -> scatter -> barrier.  Everything another workgroup reads afterwards is written through (agent scope);
-// the readers take ONE agent acquire after the last barrier and use plain loads from then on (guideline 16).  The slot
-// counters are back to zero when the scatter is done.  Returns false on a barrier abort.
+// classify + count -> barrier -> distributed scan (every workgroup a slice of the table, then the prefix of the workgroup
+// totals) -> barrier -> scatter -> barrier.  A box is classified on the fly from quad 0 (grid.h): brute boxes are appended
+// to the brute list, the others counted into their table slot.  Everything another workgroup reads afterwards is written
+// through (agent scope); the readers take ONE agent acquire after the last barrier and use plain loads from then on
+// (guideline 16).  The slot counters are back to zero when the scatter is done.
+// Returns 0: built; 1: barrier abort; 2: not worth using (no usable extent, or more than 1/16 of the boxes are brute).
 template <class G>
-__device__ __forceinline__ bool grid_build(const NmsArgs& a, int c0, int wg, int T, TeamBar& bar, int* s_flag, int* s_i) {
+__device__ __forceinline__ int grid_build(const NmsArgs& a, const GridPlan& gp, int c0, int wg, int T, TeamBar& bar, int* s_flag, int* s_i,
+                                          uint32_t& level_mask, int& n_brute) {
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int M = (int)a.gmask + 1;
   const int per = (M + T - 1) / T;                 // table slots of one workgroup (<= kNmsThreads, checked by the caller)
-  auto indexed_alive = [&](int p, uint32_t& slot) -> bool {
-    slot = a.gslot_of[p];
-    return slot != 0xffffffffu && ((ldg_agent(a.alive + (p >> 6)) >> (p & 63)) & 1ull);   // coherent: count and scatter must agree
+  // 0: not a column any more (dead), 1: indexed (slot), 2: brute.  Coherent alive read: count and scatter must agree.
+  auto classify = [&](int p, uint32_t& slot, float4& q0, int& lv) -> int {
+    if (!((ldg_agent(a.alive + (p >> 6)) >> (p & 63)) & 1ull)) return 0;
+    q0 = a.rec[(size_t)p * G::RECQ];
+    if (grid_is_brute(gp, q0.x, q0.y, q0.z, q0.w)) return 2;
+    lv = grid_level(gp, q0.z);
+    const float inv = grid_level_inv_cell(gp, lv);
+    slot = grid_slot(lv, grid_cell(q0.x, gp.x0, inv, grid_last_cell(gp.xr, inv)), grid_cell(q0.y, gp.y0, inv, grid_last_cell(gp.yr, inv)), a.gmask);
+    return 1;
   };
-  for (int p = c0 + wg * kNmsThreads + tid; p < a.n; p += T * kNmsThreads) {
-    uint32_t slot;
-    if (indexed_alive(p, slot)) __hip_atomic_fetch_add(a.gcnt + slot, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  uint32_t lbits = 0u;
+  for (int p0 = c0 + wg * kNmsThreads; p0 < a.n; p0 += T * kNmsThreads) {
+    const int p = p0 + tid;
+    uint32_t slot = 0u;
+    float4 q0;
+    int lv = 0;
+    const int kind = p < a.n ? classify(p, slot, q0, lv) : 0;
+    if (kind == 1) { __hip_atomic_fetch_add(a.gcnt + slot, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); lbits |= 1u << lv; }
+    const u64 bm = __ballot(kind == 2);
+    if (bm) {
+      int base = 0;
+      if (lane == 0) base = __hip_atomic_fetch_add(&a.gmeta->n_brute, __popcll(bm), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      base = __shfl(base, 0);
+      if (kind == 2) stg_agent(a.ulist + base + __popcll(bm & lanemask_lt()), (uint32_t)p);
+    }
   }
-  if (!team_barrier(bar, s_flag)) return false;
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) lbits |= __shfl_xor(lbits, d);
+  if (lane == 0 && lbits) __hip_atomic_fetch_or(&a.gmeta->level_mask, lbits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (!team_barrier(bar, s_flag)) return 1;
+  level_mask = ldg_agent(&a.gmeta->level_mask);
+  n_brute = ldg_agent(&a.gmeta->n_brute);
+  if (level_mask == 0u || (long long)n_brute * 16 > (long long)(a.n - c0)) return 2;     // (uniform decision: same values everywhere)
   // exclusive prefix of this workgroup's slice + its total
   auto block_excl = [&](int v, int& total) -> int {
     int incl = v;
@@ -1056,7 +1084,7 @@ __device__ __forceinline__ bool grid_build(const NmsArgs& a, int c0, int wg, int
   int tot_wg = 0;
   const int excl = block_excl(mine ? ldg_agent(a.gcnt + slot_i) : 0, tot_wg);
   if (tid == 0) stg_agent(a.gwsum + wg, tot_wg);
-  if (!team_barrier(bar, s_flag)) return false;
+  if (!team_barrier(bar, s_flag)) return 1;
   int grand = 0, base = 0;
   {
     const int v = tid < T ? ldg_agent(a.gwsum + tid) : 0;       // T <= kNmsThreads
@@ -1068,20 +1096,21 @@ __device__ __forceinline__ bool grid_build(const NmsArgs& a, int c0, int wg, int
   }
   if (mine) stg_agent(a.gstart + slot_i, base + excl);
   if (wg == 0 && tid < 2) stg_agent(a.gstart + M + tid, grand);
-  if (!team_barrier(bar, s_flag)) return false;
+  if (!team_barrier(bar, s_flag)) return 1;
   for (int p = c0 + wg * kNmsThreads + tid; p < a.n; p += T * kNmsThreads) {
-    uint32_t slot;
-    if (indexed_alive(p, slot)) {
+    uint32_t slot = 0u;
+    float4 q0;
+    int lv = 0;
+    if (classify(p, slot, q0, lv) == 1) {
       const int k = __hip_atomic_fetch_sub(a.gcnt + slot, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - 1;   // the order inside a slot does not matter
-      const float4 q0 = a.rec[(size_t)p * G::RECQ];
       u64* o = reinterpret_cast<u64*>(a.gsorted + (size_t)ldg_agent(a.gstart + slot) + k);
       stg_agent(o, ((u64)__float_as_uint(q0.y) << 32) | (u64)__float_as_uint(q0.x));
       stg_agent(o + 1, ((u64)(uint32_t)p << 32) | (u64)__float_as_uint(q0.z));
     }
   }
-  if (!team_barrier(bar, s_flag)) return false;
+  if (!team_barrier(bar, s_flag)) return 1;
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-  return true;
+  return 0;
 }
 
 // ------------------------------------------------------------------ the persistent kernel
@@ -1094,6 +1123,7 @@ __global__ __launch_bounds__(kNmsThreads) __attribute__((amdgpu_waves_per_eu(1, 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __shared__ int s_i[16];
   __shared__ int s_flag;
+  __shared__ int s_bb[kNmsWaves][4];
   const int tid = threadIdx.x, wv = tid >> 6;
   const int NB = gridDim.x;
   int nteams = a.nseg < NB ? a.nseg : NB;
@@ -1128,21 +1158,39 @@ __global__ __launch_bounds__(kNmsThreads) __attribute__((amdgpu_waves_per_eu(1, 
   uint32_t glevels = 0;
   int n_brute = 0;
   if constexpr (G::HAS_GRID && GRID) {
-    if (a.gmeta != nullptr && a.nseg == 1 && T == NB && ((int)a.gmask + T) / T <= kNmsThreads && T <= kNmsThreads) {
-      gp = grid_plan(a.gmeta->bb);
-      glevels = a.gmeta->level_mask;
-      n_brute = a.gmeta->n_brute;
-      grid_on = gp.ok != 0 && glevels != 0u && (long long)n_brute * 16 <= (long long)a.n;   // (many brute boxes: not worth it)
-    }
+    grid_on = a.gmeta != nullptr && a.nseg == 1 && T == NB && ((int)a.gmask + T) / T <= kNmsThreads && T <= kNmsThreads && a.cull != 0;
   }
   // kept rows x alive positions of [c0, c1)
   auto cross = [&](const uint32_t* rows, int nr, int c0, int c1) {
     if constexpr (G::HAS_GRID && GRID) {
       if (grid_on && nr >= kGridMinRows) {           // (a few hundred kept rows: the exhaustive form is the cheaper one)
         if (!grid_built) {                           // first use: sort what is still alive behind the chunk into its cells
-          if (!grid_build<G>(a, c0, wg, T, bar, &s_flag, s_i)) { aborted = true; return; }
+          // the extent of the data from the key kernel's per-workgroup partials (every workgroup reduces them itself)
+          int bx0 = 0x7fffffff, by0 = 0x7fffffff, bx1 = (int)0x80000000, by1 = (int)0x80000000;
+          for (int i = tid; i < a.nparts; i += kNmsThreads) {
+            const int4 q = reinterpret_cast<const int4*>(a.bbpart)[i];
+            bx0 = min(bx0, q.x); by0 = min(by0, q.y); bx1 = max(bx1, q.z); by1 = max(by1, q.w);
+          }
+#pragma unroll
+          for (int d = 32; d >= 1; d >>= 1) {
+            bx0 = min(bx0, __shfl_xor(bx0, d)); by0 = min(by0, __shfl_xor(by0, d));
+            bx1 = max(bx1, __shfl_xor(bx1, d)); by1 = max(by1, __shfl_xor(by1, d));
+          }
+          __syncthreads();
+          if ((tid & 63) == 0) { s_bb[wv][0] = bx0; s_bb[wv][1] = by0; s_bb[wv][2] = bx1; s_bb[wv][3] = by1; }
+          __syncthreads();
+          int bb[4] = {s_bb[0][0], s_bb[0][1], s_bb[0][2], s_bb[0][3]};
+          for (int k = 1; k < kNmsWaves; k++) {
+            bb[0] = min(bb[0], s_bb[k][0]); bb[1] = min(bb[1], s_bb[k][1]); bb[2] = max(bb[2], s_bb[k][2]); bb[3] = max(bb[3], s_bb[k][3]);
+          }
+          gp = grid_plan(bb);
+          const int st = gp.ok ? grid_build<G>(a, gp, c0, wg, T, bar, &s_flag, s_i, glevels, n_brute) : 2;
+          if (st == 1) { aborted = true; return; }
           grid_built = true;
+          if (st == 2) grid_on = false;                // no usable extent / too many brute boxes: exhaustive from here on
         }
+      }
+      if (grid_on && nr >= kGridMinRows) {
         nms_cross_grid<G>(a, gp, glevels, rows, nr, c0, c1, tw, ntw, L);
         if (n_brute > 0) {
           // the boxes the index leaves out: brute kept rows against every column, every kept row against the brute columns
@@ -1156,7 +1204,11 @@ __global__ __launch_bounds__(kNmsThreads) __attribute__((amdgpu_waves_per_eu(1, 
               const int j = jb + tid;
               uint32_t rp = 0u;
               bool flag = false;
-              if (j < j1) { rp = rows[j]; flag = a.rec[(size_t)rp * G::RECQ + 3].y != 0.f; }
+              if (j < j1) {
+                rp = rows[j];
+                const float4 q0 = a.rec[(size_t)rp * G::RECQ];
+                flag = grid_is_brute(gp, q0.x, q0.y, q0.z, q0.w);
+              }
               const u64 fm = __ballot(flag);
               __syncthreads();                                   // previous users of s_i / readers of the list are done
               if ((tid & 63) == 0) s_i[wv] = __popcll(fm);
