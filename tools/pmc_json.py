@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """profiles/<tag>_pmc_fetch.md + <tag>_pmc_write.md (tools/rocpd_pmc.py output of the two --pmc passes over
 tools/prof_kernels.py) -> the per-launch HBM byte counts bench.py reports as `traffic`.
-usage: python tools/pmc_json.py profiles/r1_pmc_fetch.md profiles/r1_pmc_write.md [profiles/r1_hotpath_kernel_stats.md] > profiles/r1_pmc.json
+usage: python tools/pmc_json.py profiles/r2_pmc_fetch.md profiles/r2_pmc_write.md [profiles/r2_hotpath_kernel_stats.md] > profiles/r2_pmc.json
 
 bytes per launch = 2 * FETCH_SIZE[KB] * 1024 + WRITE_SIZE[KB] * 1024: MI355X_MICROARCH.md -- FETCH_SIZE tallies 128-byte
 requests at 64 bytes on gfx950; the 256 MiB calibration copy at the start of prof_kernels.py must read FETCH 131072 KB,
@@ -57,12 +57,18 @@ def main():
         fk, wk = mean(find(f, key)), mean(find(w, key))
         out[name] = bytes_(fk, wk)
         out[name + "_raw_kb"] = {"FETCH_SIZE": round(fk, 1), "WRITE_SIZE": round(wk, 1)}
-    fn, wn = find(f, "obb::k_nms_persist<obb::RotGeom>"), find(w, "obb::k_nms_persist<obb::RotGeom>")
-    h = len(fn) // 2                                    # prof_kernels.py: REPS bs16 steps, then REPS 100k calls
-    for name, sl in (("k_nms_persist_bs16", slice(0, h)), ("k_nms_persist_100k", slice(h, None))):
+    # prof_kernels.py: REPS bs16 steps (the multi-segment kernel), then REPS 100k calls of S-clustered K=300 and REPS of the same
+    # with 18 class offsets (the single-list kernel with the indexed cross phase)
+    fb, wb = find(f, "obb::k_nms_persist<obb::RotGeom, false>"), find(w, "obb::k_nms_persist<obb::RotGeom, false>")
+    out["k_nms_persist_bs16"] = bytes_(mean(fb), mean(wb))
+    out["k_nms_persist_bs16_raw_kb"] = {"FETCH_SIZE": round(mean(fb), 1), "WRITE_SIZE": round(mean(wb), 1)}
+    fn, wn = find(f, "obb::k_nms_persist<obb::RotGeom, true>"), find(w, "obb::k_nms_persist<obb::RotGeom, true>")
+    h = len(fn) // 2
+    for name, sl in (("k_nms_persist_100k_clustered_k300_raw", slice(0, h)), ("k_nms_persist_100k_clustered_k300_18cls", slice(h, None))):
         fk, wk = mean(fn[sl]), mean(wn[sl])
         out[name] = bytes_(fk, wk)
         out[name + "_raw_kb"] = {"FETCH_SIZE": round(fk, 1), "WRITE_SIZE": round(wk, 1)}
+    out["k_nms_persist_100k"] = out["k_nms_persist_100k_clustered_k300_raw"]
     fd, wd = find(f, "obb::k_detect_decode<"), find(w, "obb::k_detect_decode<")
     lv_f = [mean(fd[i::3]) for i in range(3)]
     lv_w = [mean(wd[i::3]) for i in range(3)]

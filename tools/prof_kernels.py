@@ -24,12 +24,14 @@ for _ in range(REPS):
     out = non_max_suppression_obb(pred, conf_thres=0.25, iou_thres=0.45, multi_label=True, max_det=1500)
 torch.cuda.synchronize()
 del pred
-# ---- rotated NMS at 100k candidates
-d, s = synth.s_clustered(100000, 300, 0)
-d, s = d.to(dev), s.to(dev)
-for _ in range(REPS):
-    k = nms_rotated_ext.nms_rotated(d, s, 0.4)
-torch.cuda.synchronize()
+# ---- rotated NMS at 100k candidates: S-clustered (K = 300), then the same with 18 class offsets (the two regimes bench.py's
+#      roofline object chooses between; tools/pmc_json.py splits the dispatches of k_nms_persist<RotGeom, true> in this order)
+for regime in ("clustered_k300_raw", "clustered_k300_18cls"):
+    d, s = synth.regime_100k(regime)
+    d, s = d.to(dev), s.to(dev)
+    for _ in range(REPS):
+        k = nms_rotated_ext.nms_rotated(d, s, 0.4)
+    torch.cuda.synchronize()
 # ---- loss forward + backward, BASELINE configs[2] per-GPU shape, fp32
 nc = 16
 hyp = synth.scaled_hyp(nc, 1024)
