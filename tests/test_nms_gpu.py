@@ -79,6 +79,49 @@ def test_nms_rotated_degenerate_boxes(dev, oracle_lib):
     assert np.array_equal(ref, got)
 
 
+@pytest.mark.parametrize("variant", ["needles", "far_outlier", "non_finite", "dropped_small"])
+def test_index_path_with_degenerate_boxes(dev, oracle_lib, variant):
+    """The indexed cross phase (n >= 8192 and a step that keeps >= 512 rows) with the boxes it must keep OUT of the index:
+    needle boxes (ill-conditioned far pairs: brute list), a far outlier that stretches the extent until most boxes are
+    brute (the build gives up after its counting pass), non-finite coordinates / sizes, oversized boxes, and boxes
+    dropped by the small-box filter.  Same kept list as the oracle in every case, twice (the build order is not fixed)."""
+    import os
+    from yolov5_obb_amd import _lib, nms_rotated_ext
+    n = 24000
+    dets, scores = synth.s_uniform(n, 21, extent=2048.0)
+    g = torch.Generator().manual_seed(5)
+    pick = torch.randperm(n, generator=g)
+    flags = 0
+    if variant == "needles":
+        dets[pick[:300], 2] = torch.rand(300, generator=g) * 0.05 + 0.002       # short side far below the conditioning bound
+        dets[pick[300:330], 2:4] = torch.tensor([3000.0, 900.0])                # larger than the data: too large for the top level
+        dets[pick[330:400]] = dets[pick[400:470]]                               # exact duplicates
+    elif variant == "far_outlier":
+        dets[pick[0], 0] = 3.0e6
+        dets[pick[1], 1] = -2.0e6
+    elif variant == "non_finite":
+        dets[pick[:20], 0] = float("nan")
+        dets[pick[20:40], 1] = float("inf")
+        dets[pick[40:60], 2] = float("inf")
+        dets[pick[60:80], 4] = float("nan")
+        dets[pick[80:100], 2:4] = 0.0
+    else:
+        dets[pick[:2000], 3] = 0.0005                                           # obb_nms drops them (min side < 0.001)
+        flags = _lib.OBB_NMS_DROP_SMALL
+    scores = synth.tie_free(scores)
+    d, s = dets.to(dev), scores.to(dev)
+    if variant == "dropped_small":
+        keep_mask = dets[:, 2:4].min(1)[0] >= 0.001
+        idx = torch.nonzero(keep_mask).squeeze(1).numpy()
+        ref = idx[oracle.nms_rotated(dets[keep_mask].numpy(), scores[keep_mask].numpy(), 0.4, threads=min(os.cpu_count() or 1, 32))]
+    else:
+        ref = oracle.nms_rotated(dets.numpy(), scores.numpy(), 0.4, threads=min(os.cpu_count() or 1, 32))
+    assert len(ref) > 5000                                                      # chunks keep thousands of rows: the indexed form runs
+    for _ in range(2):
+        got = nms_rotated_ext._run_rotated(d, s, 0.4, flags=flags).cpu().numpy()
+        assert np.array_equal(ref, got), (variant, len(ref), len(got))
+
+
 def test_obb_nms_wrapper_small_box_filter(dev, oracle_lib):
     """obb_nms drops boxes with min(w,h) < 0.001 before NMS (nms_rotated_wrapper.py:32-39)."""
     from yolov5_obb_amd.utils.nms_rotated import obb_nms
