@@ -1,11 +1,13 @@
-// Static spatial index over the boxes of one NMS call (rotated boxes, single score-ordered list).
+// Spatial index over the boxes of one NMS call (rotated boxes, single score-ordered list) -- the arithmetic shared by the
+// build and the queries (nms_core.h: grid_build, nms_cross_grid) and by the CPU check (tests/native/host_check_grid.cpp).
 //
 // Why: the cross phase of the lazy chunked NMS (nms_core.h) tests every kept row of a chunk against every still-alive
 // later position -- O(kept x alive) circle tests.  With a few hundred kept boxes (S-clustered, K = 300) that is cheap;
 // with thousands (class offsets, K = 3000: the natural shape of BASELINE configs[3]) or tens of thousands (S-uniform) it
 // is the whole run time.  Only pairs whose circumscribed circles touch can have IoU > 0, so a kept row only needs the
-// boxes of the cells around it.  The set of boxes never changes during a call: the index is built ONCE (count, scan,
-// scatter: a counting sort by cell) and every cross phase queries it.
+// boxes of the cells around it.  The index is built INSIDE the persistent kernel, once, the first time a step keeps
+// enough rows to need it, from the boxes that are still alive behind that chunk (classify + count, scan, scatter: a
+// counting sort by cell); every later cross phase queries it.
 //
 // Layout.  Level L (0..kGridLevels-1) holds the boxes whose inflated circumradius r is below R_L = 2^(e_base + L) (and
 // not below R_(L-1)); its cells are squares of side S_L = 2 R_L, so a query for a row of radius r_i looks at the cells
@@ -23,7 +25,7 @@
 // 2.34e-9 * diagonal^2), when a coordinate or the radius is not finite, or when it is too large for the top level.
 // Brute boxes are kept out of the index and go through the exhaustive path (every kept row x brute columns, brute kept
 // rows x every column): the result is bit-identical to the exhaustive scan by construction.  When more than 1/16 of the
-// boxes are brute the index is switched off for the call.
+// boxes are brute the build stops after its counting pass and the call stays exhaustive.
 #pragma once
 #include <stdint.h>
 #include "obb_device.h"
