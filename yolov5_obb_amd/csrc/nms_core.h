@@ -340,11 +340,19 @@ __device__ __forceinline__ void nms_pairs(const NmsArgs& a, int tm, int cn, cons
   const int tri = nb * (nb + 1) / 2;
   const int nsub = (tri < 4 * ntw) ? 4 : ((tri < 8 * ntw) ? 2 : 1);   // fewer than 4 (8) tiles per wave: quarter (half) tiles balance better
   const int rows_sub = 64 / nsub;
-  const int items_sub = items * nsub;
+  // Only the tiles of the upper triangle are enumerated (t = 0 .. tri-1, row-major: row tile rb starts at off(rb) =
+  // rb * nb - rb (rb - 1) / 2): walking all nb x nb tiles and skipping rb > cb gave a wave a FIXED column (the number of
+  // waves is a multiple of nb for the usual chunk sizes), i.e. between 0 and 2x the average number of real tiles.
+  const int items_sub = tri * nsub;
+  (void)items;
+  auto row_off = [&](int rb) { return rb * nb - ((rb * (rb - 1)) >> 1); };
   for (int it2 = tw; it2 < items_sub; it2 += ntw) {
     const int item = it2 / nsub, sub = it2 - item * nsub;
-    const int rb = item / nb, cb = item - rb * nb;
-    if (rb > cb) continue;
+    int rb = (int)(((float)(2 * nb + 1) - sqrtf((float)((2 * nb + 1) * (2 * nb + 1) - 8 * item))) * 0.5f);
+    rb = rb < 0 ? 0 : (rb > nb - 1 ? nb - 1 : rb);
+    while (rb + 1 < nb && row_off(rb + 1) <= item) rb++;       // (float square root: fix the estimate up)
+    while (row_off(rb) > item) rb--;
+    const int cb = rb + (item - row_off(rb));
     const int r = rb * 64 + lane, c = cb * 64 + lane;
     const bool rvalid = r < cn, cvalid = c < cn;
     const uint32_t rp = rvalid ? cidx[r] : 0u, cp = cvalid ? cidx[c] : 0u;
