@@ -385,15 +385,32 @@ __device__ __forceinline__ void nms_pairs(const NmsArgs& a, int tm, int cn, cons
       if (Q2.count >= 64) drain2(64);
     };
 
-#pragma unroll 2
-    for (int rr = rr_lo; rr < rr_hi; rr++) {
-      const float4 rq = rdlane4(myrow, rr);
-      bool pass = cvalid && (!diag || lane > rr);
-      if (pass && cull) pass = !G::cheap_reject(rq, cq);
+    // four rows per trip: their broadcasts and cheap tests are issued together and ONE ballot decides whether any of them
+    // has a pair to queue (in a sparse chunk most rows pass for no column of the tile)
+    auto one_row = [&](int rr, bool pass) {
       if (__ballot(pass)) {
         Q.push(pass, ((uint32_t)rr << 8) | (uint32_t)lane);
         if (Q.count >= 64) drain(64);
       }
+    };
+    int rr = rr_lo;
+    for (; rr + 4 <= rr_hi; rr += 4) {
+      bool ps[4];
+      bool any = false;
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const float4 rq = rdlane4(myrow, rr + k);
+        ps[k] = cvalid && (!diag || lane > rr + k) && !(cull && G::cheap_reject(rq, cq));
+        any = any || ps[k];
+      }
+      if (__ballot(any)) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) one_row(rr + k, ps[k]);
+      }
+    }
+    for (; rr < rr_hi; rr++) {
+      const float4 rq = rdlane4(myrow, rr);
+      one_row(rr, cvalid && (!diag || lane > rr) && !(cull && G::cheap_reject(rq, cq)));
     }
     if (Q.count > 0) drain(Q.count);
   }
