@@ -78,7 +78,15 @@ __device__ __forceinline__ bool class_allowed(const ClassMask& cm, int c) {
 // (MI355X_MICROARCH.md "fanin"/"dequeue"), and 16 counters packed in one line would share one L2 channel.
 constexpr int kCntPad = 64;   // ints
 
-constexpr int kDecRowsPerWave = 128;   // 2 strided objectness loads in flight per lane
+#ifndef OBB_DEC_GROUPS
+#define OBB_DEC_GROUPS 1
+#endif
+// 64-row groups per wave = strided objectness loads in flight per lane.  Measured on the configs[1] batch: 1 group 52 us,
+// 2 groups 58 us, 4 groups 77 us, 8 groups 96 us -- the passing rows of a wave are processed one after the other by the
+// whole wave, so more rows per wave lengthen that serial tail faster than the extra loads in flight shorten the first phase
+// (with one group the 16k waves of the grid already keep ~60 strided loads per CU in flight).
+constexpr int kDecGroups = OBB_DEC_GROUPS;
+constexpr int kDecRowsPerWave = 64 * kDecGroups;
 constexpr int kDecStage = 128;         // staged candidates per wave (LDS) before a flush
 
 // Per-row registers of one lane: everything the row needs is requested up front (one memory latency per row,
@@ -151,17 +159,21 @@ __global__ __launch_bounds__(256) void k_decode(DecodeArgs a) {
   };
 
   // ---- phase 1: objectness column                                     :785  xc = prediction[..., 4] > conf_thres
-  static_assert(kDecRowsPerWave == 128, "two 64-row groups per wave are written out explicitly below");
-  const long long row0 = r0 + lane, row1 = r0 + 64 + lane;
-  const float obj0 = (row0 < a.A) ? ld_as_float<T>(img + (size_t)row0 * a.no + 4) : 0.f;
-  const float obj1 = (row1 < a.A) ? ld_as_float<T>(img + (size_t)row1 * a.no + 4) : 0.f;
-  unsigned long long m0 = __ballot(row0 < a.A && obj0 > thr);
-  unsigned long long m1 = __ballot(row1 < a.A && obj1 > thr);
+  float obj[kDecGroups];
+  unsigned long long mk[kDecGroups];
+#pragma unroll
+  for (int q = 0; q < kDecGroups; q++) {
+    const long long row = r0 + q * 64 + lane;
+    obj[q] = (row < a.A) ? ld_as_float<T>(img + (size_t)row * a.no + 4) : 0.f;
+  }
+#pragma unroll
+  for (int q = 0; q < kDecGroups; q++) mk[q] = __ballot(r0 + q * 64 + lane < a.A && obj[q] > thr);
 
   // ---- phase 2: passing rows, software-pipelined
   auto pop = [&](int& k_out, int& rr_out) -> bool {
-    if (m0) { rr_out = __builtin_ctzll(m0); m0 &= m0 - 1; k_out = 0; return true; }
-    if (m1) { rr_out = __builtin_ctzll(m1); m1 &= m1 - 1; k_out = 1; return true; }
+#pragma unroll
+    for (int q = 0; q < kDecGroups; q++)
+      if (mk[q]) { rr_out = __builtin_ctzll(mk[q]); mk[q] &= mk[q] - 1; k_out = q; return true; }
     return false;
   };
   int ck = 0, crr = 0;
@@ -175,7 +187,10 @@ __global__ __launch_bounds__(256) void k_decode(DecodeArgs a) {
     if (have_next) nxt = dec_load_row<T>(img + (size_t)(r0 + nk * 64 + nrr) * a.no, a.nc, lane);
 
     const long long rw = r0 + ck * 64 + crr;
-    const float o = __shfl(ck == 0 ? obj0 : obj1, crr);
+    float osel = obj[0];
+#pragma unroll
+    for (int q = 1; q < kDecGroups; q++) osel = (ck == q) ? obj[q] : osel;
+    const float o = __shfl(osel, crr);
 
     // class confidences (:820 conf = obj * cls in the input dtype)
     float bestv = -__builtin_inff(); int besti = 0x7fffffff;
