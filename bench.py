@@ -234,6 +234,9 @@ def main():
         for _ in range(3):
             k100 = nms_rotated_ext.nms_rotated(d100, s100, 0.4)
         torch.cuda.synchronize()
+        time.sleep(0.3)                          # profiles/r2_stall_env.md: a ~86 ms stall of ANY kernel follows host-side data preparation by up to ~40 ms
+        k100 = nms_rotated_ext.nms_rotated(d100, s100, 0.4)
+        torch.cuda.synchronize()
         per_call = []                            # the call as a user sees it (no stage events inside the timed region)
         for _ in range(reps):
             e0.record()
