@@ -27,6 +27,8 @@ The JSON line also carries
   nmsobb_nc16, nmsobb_tta   the fused driver on the DOTAv1.5 batch (nc = 16, what `metric` names) and on the TTA stress
                 tensor (1, 114627, 203) of models/yolo.py:149-161 with conf 0.01 / iou 0.4 (configs[3])
   loss, detect  secondary timings of the other rows of the hot path, not part of `value`
+  detect_nms_chain   Detect decode -> non_max_suppression_obb per batch, with and without the objectness column Detect hands to
+                the filter; same detections either way
   cpu_baseline  the CPU oracle (port of the reference's CPU path) on the host cores, bounded samples: the NMS bucket of the
                 step, the single-thread rotated NMS at N = 1k..30k on both distributions, and the
                 `detect.py --device cpu`-equivalent buckets with a random-init yolov5n (8d(ii))
@@ -319,7 +321,7 @@ def main():
             nc16_obj = nc16_obj or {"error": str(e)}
 
     # ---------------- secondary rows of the hot path (rank 0 reports; not part of `value`)
-    loss_obj = detect_obj = None
+    loss_obj = detect_obj = coupled_obj = None
     if rank == 0:
         try:
             import ctypes as C2
@@ -378,6 +380,47 @@ def main():
             del convs, z, xs
         except Exception as e:                                  # secondary figures never fail the bench
             loss_obj = loss_obj or {"error": str(e)}
+        # Detect -> NMS as val.py chains them (val.py:197-206): Detect's decode pass also stores z[..., 4] densely and the
+        # filter of non_max_suppression_obb reads that column instead of one line of every row (models/yolo.py mirror)
+        try:
+            from yolov5_obb_amd.models.yolo import Detect
+            det = Detect(nc=nc, anchors=synth.DEFAULT_ANCHORS, ch=(8, 8, 8))
+            det.stride = torch.tensor(synth.DEFAULT_STRIDES)
+            det.anchors /= det.stride.view(-1, 1, 1)
+            det = det.to(dev).half().eval()
+            det.m = torch.nn.ModuleList([torch.nn.Identity() for _ in range(3)])      # the conv outputs are the input here
+            heads = [h.to(dev) for h in synth.s_head(bs, nc, (128, 64, 32), seed=2000 + rank, n_obj=120, dtype=torch.float16)]
+            chain = {}
+            for mode in ("plain", "coupled"):
+                det.couple_nms = mode == "coupled"
+
+                def chain_step():
+                    with torch.no_grad():
+                        zc, _ = det(list(heads))
+                    return non_max_suppression_obb(zc, **kw)
+                for _ in range(10):
+                    oc = chain_step()
+                torch.cuda.synchronize()
+                L.obb_profile_enable(1)
+                t0c = time.perf_counter()
+                for _ in range(50):
+                    oc = chain_step()
+                torch.cuda.synchronize()
+                chain[mode] = (time.perf_counter() - t0c) / 50 * 1e3
+                pm, pcn = collect_profile(L)
+                L.obb_profile_enable(0)
+                chain[mode + "_decode_ms"] = pm[0] / max(1, pcn[0])
+                chain[mode + "_det"] = sum(int(o.shape[0]) for o in oc)
+            coupled_obj = {"workload": "Detect decode of synthetic conv outputs (16, 3*200, {128,64,32}^2) fp16 with 120 planted objects per "
+                                       "image (tests/synth.py s_head) -> non_max_suppression_obb, per batch of 16 (val.py:197-206)",
+                           "ms_plain": round(chain["plain"], 4), "ms_coupled": round(chain["coupled"], 4),
+                           "k_decode_ms_plain": round(chain["plain_decode_ms"], 4), "k_decode_ms_coupled": round(chain["coupled_decode_ms"], 4),
+                           "detections": chain["coupled_det"], "same_detections": chain["coupled_det"] == chain["plain_det"],
+                           "note": "plain = the NMS scans z[..., 4] (one 128-byte line per 400-byte row, freshly written by Detect); "
+                                   "coupled = it reads the dense (16, 64512) column Detect stored in the same pass"}
+            del heads
+        except Exception as e:
+            coupled_obj = {"error": str(e)}
 
     # ---------------- SURVEY 8(f) rows behind the NMS (rank 0, N=1 only; not part of `value`): val.py tail, tile->image merge,
     # Task-1 evaluation -- GPU time of the mirrored call, the oracle port of the reference on a bounded sample beside it
@@ -498,7 +541,7 @@ def main():
                     "note": "kernel time from the rocprofv3 kernel trace in profiles/ (the bench times ComputeLoss fwd+bwd as a whole)"},
             },
             "nms_100k": nms_obj, "nmsobb_nc16": nc16_obj, "nmsobb_tta": tta_obj,
-            "loss": loss_obj, "detect": detect_obj, "next_rows": next_rows,
+            "loss": loss_obj, "detect": detect_obj, "detect_nms_chain": coupled_obj, "next_rows": next_rows,
             "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)

@@ -183,6 +183,16 @@ int obb_non_max_suppression_obb(const void* pred, int dtype, int64_t bs, int64_t
                                 int64_t max_det, int64_t max_nms, float max_wh, const float* extra8, int64_t n_extra,
                                 int64_t cap_img, int64_t expected_cand, float* out, int out_packed, int64_t* out_count,
                                 int64_t* status, void* ws, size_t ws_bytes, void* stream);
+/* The same call for a `pred` whose producer also stored the objectness column densely: objcol [bs][A] in pred's dtype,
+ * objcol[b][i] == pred[b][i][4] bit for bit (obb_detect_decode_col writes it next to z).  The confidence filter
+ * (utils/general.py:785 xc = prediction[..., 4] > conf_thres) then reads bs*A elements instead of one 128-byte line of
+ * every 400-800-byte row; rows that pass are read from `pred` as before, so the result is the one of the plain call.
+ * objcol == NULL is the plain call. */
+int obb_non_max_suppression_obb_col(const void* pred, const void* objcol, int dtype, int64_t bs, int64_t A, int64_t no,
+                                    float conf_thres, float iou_thres, const int32_t* classes_host, int n_classes, int agnostic,
+                                    int multi_label, int64_t max_det, int64_t max_nms, float max_wh, const float* extra8,
+                                    int64_t n_extra, int64_t cap_img, int64_t expected_cand, float* out, int out_packed,
+                                    int64_t* out_count, int64_t* status, void* ws, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------ training loss -------------------- */
 
@@ -255,6 +265,11 @@ int obb_loss_backward(const obb_loss_config* cfg, const void* const* p_levels_ho
 int obb_detect_decode(const void* conv_out, int dtype, int64_t bs, int64_t na, int64_t no, int64_t ny, int64_t nx,
                       const float* anchors_px_host, float stride, void* x_perm_out, void* z_out, int64_t a_total,
                       int64_t a_offset, void* stream);
+/* obb_detect_decode that also writes objcol_out [bs][a_total] (same dtype) = z[..., 4] of the level's rows: the column the
+ * confidence filter of obb_non_max_suppression_obb_col reads.  Any of x_perm_out / z_out / objcol_out may be NULL. */
+int obb_detect_decode_col(const void* conv_out, int dtype, int64_t bs, int64_t na, int64_t no, int64_t ny, int64_t nx,
+                          const float* anchors_px_host, float stride, void* x_perm_out, void* z_out, int64_t a_total,
+                          int64_t a_offset, void* objcol_out, void* stream);
 
 /* gaussian_label_cpu (utils/rboxs_utils.py:9-26) for n angles at once: out [n][num_class] fp32, evaluated in double. */
 int obb_csl_encode_f32(const float* labels, int64_t n, int num_class, double u, double sig, float* out, void* stream);

@@ -136,6 +136,58 @@ def grid_anchors():
     return a / torch.tensor(DEFAULT_STRIDES).view(3, 1, 1)
 
 
+def s_head(bs, nc, sizes=(128, 64, 32), seed=0, n_obj=120, device="cpu", dtype=torch.float32):
+    """S-head: synthetic conv outputs of the three Detect levels, [(bs, na*no, n, n)] -- what `Detect.m[i]` would produce
+    (models/yolo.py:62) -- with `n_obj` planted objects per image that are SPATIALLY consistent: an object fires on the 3x3
+    cells around its centre at the level whose anchors fit its size, on two of the three anchors, with xy / wh logits that
+    decode (models/yolo.py:71-74) to the object's box plus jitter, its class and a CSL bump at its angle.  Everything else is
+    background: objectness logit ~ N(-6, 1.5) (the bias init of models/yolo.py:230), class / angle logits ~ N(-4, .)."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    R = lambda *s: torch.rand(*s, generator=g, device=device)
+    N = lambda *s: torch.randn(*s, generator=g, device=device)
+    na, no = 3, 5 + nc + 180
+    lv = torch.randint(0, 3, (bs, n_obj), generator=g, device=device)
+    ocls = torch.randint(0, nc, (bs, n_obj), generator=g, device=device)
+    obin = torch.randint(0, 180, (bs, n_obj), generator=g, device=device)
+    ouv = R(bs, n_obj, 2)                                                                      # centre in [0,1]^2
+    oscale = R(bs, n_obj, 2) * 2.0 + 0.5                                                       # size / anchor
+    bins = torch.arange(180, device=device)
+    out = []
+    for i, n in enumerate(sizes):
+        x = torch.empty(bs, na, n, n, no, device=device)
+        x[..., 0:4] = N(bs, na, n, n, 4) * 0.5
+        x[..., 4] = N(bs, na, n, n) * 1.5 - 6.0
+        x[..., 5:5 + nc] = N(bs, na, n, n, nc) - 4.0
+        x[..., 5 + nc:] = 0.5 * N(bs, na, n, n, 180) - 4.0
+        for b in range(bs):
+            sel = (lv[b] == i).nonzero().flatten()
+            if sel.numel() == 0:
+                continue
+            c = ouv[b, sel] * n                                                                # centre in cells
+            cell = c.floor().long()
+            for dy in (-1, 0, 1):
+                for dx in (-1, 0, 1):
+                    gx, gy = (cell[:, 0] + dx).clamp(0, n - 1), (cell[:, 1] + dy).clamp(0, n - 1)
+                    for a in (0, 1, 2):
+                        if (a + dy + dx) % 3 == 0:
+                            continue                                                           # two of the three anchors
+                        m = sel.numel()
+                        t = torch.stack((c[:, 0] - gx, c[:, 1] - gy), -1) + 0.02 * N(m, 2)     # (sig*2 - 0.5) must give t
+                        sxy = ((t + 0.5) / 2).clamp(0.02, 0.98)
+                        swh = (oscale[b, sel] * (1 + 0.05 * N(m, 2))).clamp(0.05, 3.9).sqrt() / 2
+                        x[b, a, gy, gx, 0:2] = torch.logit(sxy)
+                        x[b, a, gy, gx, 2:4] = torch.logit(swh.clamp(0.02, 0.98))
+                        x[b, a, gy, gx, 4] = N(m) * 1.5 + 1.0
+                        cl = N(m, nc) - 4.0
+                        cl[torch.arange(m, device=device), ocls[b, sel]] = N(m) + 2.0
+                        x[b, a, gy, gx, 5:5 + nc] = cl
+                        d = (bins[None, :] - obin[b, sel][:, None]).abs()
+                        d = torch.minimum(d, 180 - d).float()
+                        x[b, a, gy, gx, 5 + nc:] = 5.0 * torch.exp(-d * d / 8.0) - 4.0 + 0.5 * N(m, 180)
+        out.append(x.permute(0, 1, 4, 2, 3).contiguous().view(bs, na * no, n, n).to(dtype))
+    return out
+
+
 HYP_DOTA = dict(box=0.05, cls=0.5, cls_pw=1.0, theta=0.5, theta_pw=1.0, obj=1.0, obj_pw=1.0, anchor_t=4.0, fl_gamma=0.0,
                 label_smoothing=0.0, cls_theta=180, csl_radius=2.0)       # data/hyps/obb/hyp.finetune_dota.yaml
 

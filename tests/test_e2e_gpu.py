@@ -80,3 +80,41 @@ def test_detect_nms_valtail_chain_matches_the_oracle_chain(dev, oracle_lib, nc, 
         got = process_batch(out[3], labels.to(dev), iouv.to(dev))
         assert torch.equal(got.cpu(), pyref.process_batch(ref[3], labels, iouv))
     assert n_total >= 3 * bs
+
+
+@pytest.mark.parametrize("dtype,nc", [(torch.float32, 15), (torch.float16, 16), (torch.float16, 15)])
+def test_detect_hands_its_objectness_column_to_the_nms(dev, dtype, nc):
+    """Detect stores z[..., 4] densely next to z; non_max_suppression_obb reads its confidence filter from that column
+    when it gets the very tensor Detect returned, untouched -- and must return exactly what the plain path returns."""
+    from yolov5_obb_amd.utils import general as G
+    sizes, bs, ch = (32, 16, 8), 3, (8, 16, 32)
+    det = make_detect(nc, ch, dev, dtype, seed=nc)
+    raw = _planted_head(bs, det.na, det.no, sizes, nc, seed=7 + nc)
+    # feed the conv outputs directly: Detect.m replaced by identities over pre-made conv-layout tensors
+    convs = [r.permute(0, 1, 4, 2, 3).contiguous().view(bs, det.na * det.no, r.shape[2], r.shape[3]).to(dev).to(dtype) for r in raw]
+    det.m = torch.nn.ModuleList([torch.nn.Identity() for _ in convs])
+    with torch.no_grad():
+        z, _ = det(list(convs))
+    tag = getattr(z, "_obb_objcol", None)
+    assert tag is not None and torch.equal(tag[0], z[..., 4]) and tag[0].is_contiguous()      # bit-identical column
+    kw = dict(conf_thres=0.25, iou_thres=0.45, multi_label=True, max_det=300)
+    assert G._objectness_column(z, z) is tag[0]
+    coupled = G.non_max_suppression_obb(z, **kw)
+    plain = G.non_max_suppression_obb(z.clone(), **kw)                                         # a clone carries no column
+    assert G._objectness_column(z.clone(), z.clone()) is None
+    assert sum(o.shape[0] for o in plain) >= 3 * bs
+    for a, b in zip(coupled, plain):
+        assert torch.equal(a, b)
+    # a column that no longer describes the tensor must not be used: zero every objectness in place -> no detections
+    z[..., 4] = 0
+    assert G._objectness_column(z, z) is None
+    assert all(o.shape[0] == 0 for o in G.non_max_suppression_obb(z, **kw))
+    # and the C entry point with a column that passes NOTHING returns nothing (the column is what the filter reads)
+    with torch.no_grad():
+        z2, _ = det(list(convs))
+    z2._obb_objcol = (torch.zeros_like(z2._obb_objcol[0]), z2._version)
+    assert all(o.shape[0] == 0 for o in G.non_max_suppression_obb(z2, **kw))
+    det.couple_nms = False
+    with torch.no_grad():
+        z3, _ = det(list(convs))
+    assert not hasattr(z3, "_obb_objcol") and torch.equal(z3, z2)

@@ -43,12 +43,15 @@ SIGNATURES = {
     "obb_nms_obb_workspace_bytes": (_sz, [_i64, _i64, _i64, _i32]),
     "obb_non_max_suppression_obb": (_i32, [_vp, _i32, _i64, _i64, _i64, _f32, _f32, _vp, _i32, _i32, _i32, _i64, _i64, _f32,
                                            _vp, _i64, _i64, _i64, _vp, _i32, _vp, _vp, _vp, _sz, _vp]),
+    "obb_non_max_suppression_obb_col": (_i32, [_vp, _vp, _i32, _i64, _i64, _i64, _f32, _f32, _vp, _i32, _i32, _i32, _i64, _i64, _f32,
+                                               _vp, _i64, _i64, _i64, _vp, _i32, _vp, _vp, _vp, _sz, _vp]),
     "obb_loss_workspace_bytes": (_sz, [_vp, _i64]),
     "obb_loss_build_targets": (_i32, [_vp, _vp, _i64, _i64, _vp, _vp, _sz, _vp]),
     "obb_loss_export_targets": (_i32, [_vp, _i64, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "obb_loss_forward": (_i32, [_vp, _vp, _i32, _vp, _i64, _i64, _vp, _vp, _sz, _vp]),
     "obb_loss_backward": (_i32, [_vp, _vp, _i32, _vp, _i64, _i64, _vp, _vp, _vp, _sz, _vp]),
     "obb_detect_decode": (_i32, [_vp, _i32, _i64, _i64, _i64, _i64, _i64, _vp, _f32, _vp, _vp, _i64, _i64, _vp]),
+    "obb_detect_decode_col": (_i32, [_vp, _i32, _i64, _i64, _i64, _i64, _i64, _vp, _f32, _vp, _vp, _i64, _i64, _vp, _vp]),
     "obb_csl_encode_f32": (_i32, [_vp, _i64, _i32, C.c_double, C.c_double, _vp, _vp]),
     "obb_rbox2poly_f32": (_i32, [_vp, _i64, _i64, _vp, _vp, _vp]),
     "obb_val_postprocess_f32": (_i32, [_vp, _i64, _f32, _f32, _f32, _vp, _vp, _vp, _vp, _vp]),

@@ -22,6 +22,7 @@ struct DetectArgs {
   const void* in;      // (bs, na*no, ny, nx) conv output
   void* xperm;         // (bs, na, ny, nx, no) or null
   void* z;             // (bs, a_total, no) or null
+  void* objcol;        // (bs, a_total) or null: z[..., 4] once more, densely (what the confidence filter of the NMS reads first)
   int bs, na, no, ny, nx;
   long long a_total, a_off;
   float stride;
@@ -106,6 +107,9 @@ __global__ __launch_bounds__(256) void k_detect_decode(DetectArgs d) {
 
   // ---- store: the tile's nhw*no output elements are contiguous in both outputs
   const int nel = nhw * no;
+  if (d.objcol && tid < nhw)   // the objectness of the tile's positions, bit-identical to z[..., 4]
+    st_from_float<T>((T*)d.objcol + (size_t)b * d.a_total + d.a_off + (size_t)a * HW + hw0 + tid,
+                     round_to_dtype<T>(detect_sigmoid<T>(ld_as_float<T>(&tile[tix(4, tid)]))));
   T* xo = d.xperm ? (T*)d.xperm + ((size_t)ba * HW + hw0) * no : nullptr;
   T* zo = d.z ? (T*)d.z + ((size_t)b * d.a_total + d.a_off + (size_t)a * HW + hw0) * no : nullptr;
   const float aw = d.anchor_px[a][0], ah = d.anchor_px[a][1];
@@ -208,14 +212,21 @@ extern "C" {
 int obb_detect_decode(const void* conv_out, int dtype, int64_t bs, int64_t na, int64_t no, int64_t ny, int64_t nx,
                       const float* anchors_px_host, float stride, void* x_perm_out, void* z_out, int64_t a_total,
                       int64_t a_offset, void* stream) {
+  return obb_detect_decode_col(conv_out, dtype, bs, na, no, ny, nx, anchors_px_host, stride, x_perm_out, z_out, a_total, a_offset,
+                               nullptr, stream);
+}
+
+int obb_detect_decode_col(const void* conv_out, int dtype, int64_t bs, int64_t na, int64_t no, int64_t ny, int64_t nx,
+                          const float* anchors_px_host, float stride, void* x_perm_out, void* z_out, int64_t a_total,
+                          int64_t a_offset, void* objcol_out, void* stream) {
   if (!conv_out || bs < 1 || na < 1 || na > OBB_LOSS_MAX_ANCHORS || no < 6 || no > 5 + 256 + 180 || ny < 1 || nx < 1 ||
       (dtype != 0 && dtype != 1) || !anchors_px_host)
     return OBB_ERR_BAD_ARG;
-  if (!x_perm_out && !z_out) return OBB_OK;
-  if (z_out && (a_offset < 0 || a_offset + na * ny * nx > a_total)) return OBB_ERR_BAD_ARG;
+  if (!x_perm_out && !z_out && !objcol_out) return OBB_OK;
+  if ((z_out || objcol_out) && (a_offset < 0 || a_offset + na * ny * nx > a_total)) return OBB_ERR_BAD_ARG;
   if (bs * na > 65535 || ny * nx > 0x7fffffffLL) return OBB_ERR_BAD_ARG;
   DetectArgs d;
-  d.in = conv_out; d.xperm = x_perm_out; d.z = z_out;
+  d.in = conv_out; d.xperm = x_perm_out; d.z = z_out; d.objcol = objcol_out;
   d.bs = (int)bs; d.na = (int)na; d.no = (int)no; d.ny = (int)ny; d.nx = (int)nx;
   d.a_total = a_total; d.a_off = a_offset; d.stride = stride;
   for (int a = 0; a < OBB_LOSS_MAX_ANCHORS; a++) {

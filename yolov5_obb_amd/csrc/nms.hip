@@ -657,7 +657,17 @@ int obb_non_max_suppression_obb(const void* pred, int dtype, int64_t bs, int64_t
                                 int64_t max_det, int64_t max_nms, float max_wh, const float* extra8, int64_t n_extra,
                                 int64_t cap_img, int64_t expected_cand, float* out, int out_packed, int64_t* out_count,
                                 int64_t* status, void* ws, size_t ws_bytes, void* stream) {
-  return run_nms_obb(pred, dtype, bs, A, no, conf_thres, iou_thres, classes_host, n_classes, agnostic, multi_label, max_det,
+  return obb_non_max_suppression_obb_col(pred, nullptr, dtype, bs, A, no, conf_thres, iou_thres, classes_host, n_classes, agnostic,
+                                         multi_label, max_det, max_nms, max_wh, extra8, n_extra, cap_img, expected_cand, out,
+                                         out_packed, out_count, status, ws, ws_bytes, stream);
+}
+
+int obb_non_max_suppression_obb_col(const void* pred, const void* objcol, int dtype, int64_t bs, int64_t A, int64_t no,
+                                    float conf_thres, float iou_thres, const int32_t* classes_host, int n_classes, int agnostic,
+                                    int multi_label, int64_t max_det, int64_t max_nms, float max_wh, const float* extra8,
+                                    int64_t n_extra, int64_t cap_img, int64_t expected_cand, float* out, int out_packed,
+                                    int64_t* out_count, int64_t* status, void* ws, size_t ws_bytes, void* stream) {
+  return run_nms_obb(pred, objcol, dtype, bs, A, no, conf_thres, iou_thres, classes_host, n_classes, agnostic, multi_label, max_det,
                      max_nms, max_wh, extra8, n_extra, cap_img, expected_cand, out, out_packed ? 1 : 0, out_count, status, ws, ws_bytes,
                      (hipStream_t)stream);
 }

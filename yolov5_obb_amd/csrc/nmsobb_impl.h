@@ -3,12 +3,12 @@
 // Replaces the per-image Python loop of utils/general.py:772-862 (>= 10 tiny ATen kernels and >= 3 host
 // syncs per image, then obb_nms with a device->host mask copy) by ONE stream-ordered call for the whole batch:
 //
-//   k_decode      one wave per 64 anchors: strided read of the objectness column only (2-4 B of each 400-800 B
-//                 row); rows that pass `obj > conf` are then processed by the whole wave -- coalesced class
-//                 scores, conf = obj*cls rounded in the input dtype, multi-label expansion by ballot, CSL
-//                 decode = wave arg-max over the 180 angle bins (first maximum), theta = (idx-90)/180*3.141592,
-//                 class filter -- and appended to the image's candidate region together with a 64-bit sort key
-//                 (descending conf, then ascending anchor*nc+class: a deterministic tie rule).
+//   k_decode      workgroup = 256..1024 anchors: objectness of every row (the dense column a coupled Detect decode left, or
+//                 2-4 B of each 400-800 B row), rows that pass `obj > conf` compacted into LDS; each listed row is then
+//                 processed by a whole wave -- coalesced class scores, conf = obj*cls rounded in the input dtype,
+//                 multi-label expansion by ballot, CSL decode = wave arg-max over the 180 angle bins (first maximum),
+//                 theta = (idx-90)/180*3.141592, class filter -- and appended to the image's candidate region together
+//                 with a 64-bit sort key (descending conf, then ascending anchor*nc+class: a deterministic tie rule).
 //   segmented radix sort (rocPRIM) per image, top max_nms (30000) kept           (:845-846)
 //   k_prep_cand   class offset xy += cls*max_wh (:849-851), rotated-box records, too-small filter of obb_nms
 //   LC-NMS        (nms_core.h) with max_keep = max_det                           (:853-855)
@@ -43,22 +43,53 @@ template <typename T> __device__ __forceinline__ float thr_in_dtype(float t);
 template <> __device__ __forceinline__ float thr_in_dtype<float>(float t) { return t; }
 template <> __device__ __forceinline__ float thr_in_dtype<__half>(float t) { return __half2float(__float2half_rn(t)); }
 
-// wave arg-max with "first maximum" tie rule
-__device__ __forceinline__ void wave_argmax_first(float& v, int& i) {
+// wave arg-max with "first maximum" tie rule (torch.max over a dimension: utils/general.py:822, :830).  Value and index
+// travel as ONE 64-bit key -- order-preserving image of the float in the high word (-0 counts as +0; a NaN ranks above
+// everything, as in torch), ~index in the low word -- so the reduction is a plain unsigned max: four DPP steps inside the
+// 16-lane rows (quad swaps, half-row and row mirrors: a few cycles each, where ds_bpermute costs an LDS round trip per
+// step), then the four row results meet through v_readlane.
+__device__ __forceinline__ unsigned long long argmax_key(float v, int i) {
+  const uint32_t b = __float_as_uint(v + 0.0f);
+  const uint32_t m = (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+  return ((unsigned long long)m << 32) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)i);
+}
+template <int CTRL>
+__device__ __forceinline__ unsigned long long dpp_max_u64(unsigned long long k) {
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)k, CTRL, 0xF, 0xF, true);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(k >> 32), CTRL, 0xF, 0xF, true);
+  const unsigned long long o = ((unsigned long long)hi << 32) | lo;
+  return o > k ? o : k;
+}
+__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long k) {   // all 64 lanes active
+  k = dpp_max_u64<0xB1>(k);      // quad_perm [1,0,3,2]
+  k = dpp_max_u64<0x4E>(k);      // quad_perm [2,3,0,1]
+  k = dpp_max_u64<0x141>(k);     // row_half_mirror
+  k = dpp_max_u64<0x140>(k);     // row_mirror: every lane holds the max of its 16-lane row
+  unsigned long long r[4];
 #pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) {
-    float ov = __shfl_xor(v, d);
-    int oi = __shfl_xor(i, d);
-    if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
-  }
+  for (int j = 0; j < 4; j++)
+    r[j] = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(k >> 32), j * 16) << 32) |
+           (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)k, j * 16);
+  const unsigned long long a = r[0] > r[1] ? r[0] : r[1], b = r[2] > r[3] ? r[2] : r[3];
+  return a > b ? a : b;
+}
+__device__ __forceinline__ void argmax_unkey(unsigned long long k, float& v, int& i) {
+  const uint32_t m = (uint32_t)(k >> 32);
+  v = __uint_as_float((m & 0x80000000u) ? (m ^ 0x80000000u) : ~m);
+  i = (int)(0xFFFFFFFFu - (uint32_t)k);
+}
+__device__ __forceinline__ void wave_argmax_first(float& v, int& i) {
+  argmax_unkey(wave_max_u64(argmax_key(v, i)), v, i);
 }
 
 struct DecodeArgs {
   const void* pred;          // [bs][A][no]
+  const void* objcol;        // [bs][A] = pred[..., 4] stored densely by the producer (obb_detect_decode_col), or null
   long long A;
   int no, nc, bs;
   float conf_thres;
   int multi_label;
+  int rows_per_thread;       // G: a workgroup of k_decode covers 256 * G rows
   ClassMask cm;
   long long cap_img;         // candidate slots per image
   float4* cand;              // [bs*cap_img][2]: {x,y,l,s} {theta,conf,cls,0}
@@ -78,15 +109,14 @@ __device__ __forceinline__ bool class_allowed(const ClassMask& cm, int c) {
 // (MI355X_MICROARCH.md "fanin"/"dequeue"), and 16 counters packed in one line would share one L2 channel.
 constexpr int kCntPad = 64;   // ints
 
-#ifndef OBB_DEC_GROUPS
-#define OBB_DEC_GROUPS 1
-#endif
-// 64-row groups per wave = strided objectness loads in flight per lane.  Measured on the configs[1] batch: 1 group 52 us,
-// 2 groups 58 us, 4 groups 77 us, 8 groups 96 us -- the passing rows of a wave are processed one after the other by the
-// whole wave, so more rows per wave lengthen that serial tail faster than the extra loads in flight shorten the first phase
-// (with one group the 16k waves of the grid already keep ~60 strided loads per CU in flight).
-constexpr int kDecGroups = OBB_DEC_GROUPS;
-constexpr int kDecRowsPerWave = 64 * kDecGroups;
+// Rows of a workgroup = 256 * G (G = 1, 2 or 4 rows per thread, chosen by the host so that small batches still fill the
+// chip).  History: with one wave per 64 consecutive rows that also processed ITS passing rows one after the other, the
+// kernel took 52 us on a warm and 78-91 us on a freshly written configs[1] tensor -- even with the dense objectness column:
+// detector output is clustered (an object fires on neighbouring cells), so a few waves carried long serial chains of cold
+// row reads while most had none.  Now the workgroup compacts its passing rows into LDS and its four waves take them
+// round-robin, kDecDepth rows in flight per wave.
+constexpr int kDecMaxG = 4;
+constexpr int kDecDepth = 4;
 constexpr int kDecStage = 128;         // staged candidates per wave (LDS) before a flush
 
 // Per-row registers of one lane: everything the row needs is requested up front (one memory latency per row,
@@ -114,22 +144,24 @@ __device__ __forceinline__ DecRow<T> dec_load_row(const T* base, int nc, int lan
   return r;
 }
 
-// k_decode: workgroup = 4 waves x 128 rows.  Phase 1 reads only the objectness column (one 2-4 byte element of
-// each 400-800 byte row; every lane keeps 2 strided loads in flight) and ballots `obj > conf`.  Phase 2 walks the
-// passing rows: the whole wave loads the row (classes, 180 angle bins, box) with the next row prefetched, reduces
-// it, and stages its candidates in LDS.  Slots in the image's candidate region are claimed with ONE atomic per
-// workgroup (plus one per wave whenever its 128-entry stage fills up) and the staged records are written out
-// coalesced.
+// k_decode: workgroup = 256 threads x G rows.  Phase 1 reads the objectness of every row -- from the dense column when the
+// producer stored one (obb_detect_decode_col), else one 2-4 byte element of each 400-800 byte row -- and compacts the rows
+// with obj > conf into an LDS list (wave ballot + one LDS atomic per wave).  Phase 2: the four waves take the listed rows
+// round-robin, kDecDepth rows in flight per wave: the whole wave loads a row (classes, 180 angle bins, box), reduces it
+// and stages its candidates in LDS.  Slots in the image's candidate region are claimed with ONE atomic per workgroup (plus
+// one per wave whenever its 128-entry stage fills up) and the staged records are written out coalesced.
 template <typename T>
 __global__ __launch_bounds__(256) void k_decode(DecodeArgs a) {
   __shared__ float4 s_c0[4][kDecStage], s_c1[4][kDecStage];
   __shared__ unsigned long long s_key[4][kDecStage];
-  __shared__ int s_cnt[4], s_base;
+  __shared__ int s_cnt[4], s_base, s_n;
+  __shared__ uint32_t s_row[256 * kDecMaxG];
+  __shared__ float s_obj[256 * kDecMaxG];
 
   const T* pred = (const T*)a.pred;
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int b = blockIdx.y;
-  const long long r0 = ((long long)blockIdx.x * 4 + wv) * kDecRowsPerWave;
+  const int G = a.rows_per_thread;
   const float thr = thr_in_dtype<T>(a.conf_thres);
   const T* img = pred + (size_t)b * a.A * a.no;
   float4* cand = a.cand + (size_t)b * a.cap_img * 2;
@@ -138,6 +170,8 @@ __global__ __launch_bounds__(256) void k_decode(DecodeArgs a) {
   float4* c0s = s_c0[wv]; float4* c1s = s_c1[wv]; unsigned long long* kys = s_key[wv];
   int staged = 0;   // wave-uniform
   bool tiny_seen = false;
+  if (tid == 0) s_n = 0;
+  __syncthreads();
 
   auto write_out = [&](long long base, int count) {
     for (int i = lane; i < count; i += 64) {
@@ -158,40 +192,40 @@ __global__ __launch_bounds__(256) void k_decode(DecodeArgs a) {
     staged = 0;
   };
 
-  // ---- phase 1: objectness column                                     :785  xc = prediction[..., 4] > conf_thres
-  float obj[kDecGroups];
-  unsigned long long mk[kDecGroups];
+  // ---- phase 1: objectness of the workgroup's rows                    :785  xc = prediction[..., 4] > conf_thres
+  float obj[kDecMaxG];
+  // 64-row chunks are dealt to the workgroups of the image round-robin (chunk c -> workgroup c % gridDim.x): detector output
+  // is clustered -- a coarse level holds hundreds of passing rows in a few thousand consecutive rows -- and contiguous
+  // 1024-row blocks left a handful of workgroups with ten times the average number of rows to reduce
+  auto row_of = [&](int q) -> long long { return ((long long)(q * 4 + wv) * gridDim.x + blockIdx.x) * 64 + lane; };
 #pragma unroll
-  for (int q = 0; q < kDecGroups; q++) {
-    const long long row = r0 + q * 64 + lane;
-    obj[q] = (row < a.A) ? ld_as_float<T>(img + (size_t)row * a.no + 4) : 0.f;
+  for (int q = 0; q < kDecMaxG; q++) {
+    const long long row = row_of(q);
+    obj[q] = (q >= G || row >= a.A) ? 0.f
+             : a.objcol ? ld_as_float<T>((const T*)a.objcol + (size_t)b * a.A + row)       // 128 bytes per wave
+                        : ld_as_float<T>(img + (size_t)row * a.no + 4);                     // one line per row
   }
 #pragma unroll
-  for (int q = 0; q < kDecGroups; q++) mk[q] = __ballot(r0 + q * 64 + lane < a.A && obj[q] > thr);
+  for (int q = 0; q < kDecMaxG; q++) {
+    const bool p = q < G && row_of(q) < a.A && obj[q] > thr;
+    const unsigned long long mk = __ballot(p);
+    if (mk) {
+      int base = 0;
+      if (lane == 0) base = atomicAdd(&s_n, __popcll(mk));
+      base = __shfl(base, 0);
+      if (p) {
+        const int i = base + __popcll(mk & lanemask_lt());
+        s_row[i] = (uint32_t)row_of(q);
+        s_obj[i] = obj[q];
+      }
+    }
+  }
+  __syncthreads();
+  const int n_rows = s_n;
 
-  // ---- phase 2: passing rows, software-pipelined
-  auto pop = [&](int& k_out, int& rr_out) -> bool {
-#pragma unroll
-    for (int q = 0; q < kDecGroups; q++)
-      if (mk[q]) { rr_out = __builtin_ctzll(mk[q]); mk[q] &= mk[q] - 1; k_out = q; return true; }
-    return false;
-  };
-  int ck = 0, crr = 0;
-  bool have = pop(ck, crr);
-  DecRow<T> cur;
-  if (have) cur = dec_load_row<T>(img + (size_t)(r0 + ck * 64 + crr) * a.no, a.nc, lane);
-  while (have) {
-    int nk = 0, nrr = 0;
-    const bool have_next = pop(nk, nrr);
-    DecRow<T> nxt;
-    if (have_next) nxt = dec_load_row<T>(img + (size_t)(r0 + nk * 64 + nrr) * a.no, a.nc, lane);
-
-    const long long rw = r0 + ck * 64 + crr;
-    float osel = obj[0];
-#pragma unroll
-    for (int q = 1; q < kDecGroups; q++) osel = (ck == q) ? obj[q] : osel;
-    const float o = __shfl(osel, crr);
-
+  // ---- phase 2: the listed rows, wave wv takes entries wv, wv + 4, ...; kDecDepth rows requested before the first is reduced
+  const int nq = (a.nc + 63) >> 6;
+  auto reduce_row = [&](const DecRow<T>& cur, float o, long long rw) {
     // class confidences (:820 conf = obj * cls in the input dtype)
     float bestv = -__builtin_inff(); int besti = 0x7fffffff;
     unsigned long long pass_bits[4] = {0ull, 0ull, 0ull, 0ull};
@@ -199,6 +233,7 @@ __global__ __launch_bounds__(256) void k_decode(DecodeArgs a) {
     int npass = 0;
 #pragma unroll
     for (int q = 0; q < 4; q++) {
+      if (q >= nq) { myconf[q] = -__builtin_inff(); continue; }      // wave-uniform: nc <= 64 needs one of the four passes
       const int c = q * 64 + lane;
       const float v = (c < a.nc) ? mul_in_dtype<T>(cur.cls[q], o) : -__builtin_inff();
       myconf[q] = v;
@@ -212,44 +247,56 @@ __global__ __launch_bounds__(256) void k_decode(DecodeArgs a) {
       wave_argmax_first(bestv, besti);                                                                    // :830
       npass = (bestv > thr && class_allowed(a.cm, besti)) ? 1 : 0;                                        // :831, :835
     }
-    if (npass) {
-      // CSL decode: first arg-max over the 180 bins (:822-823)
-      float tv = cur.csl[0]; int ti = lane;
-      if (cur.csl[1] > tv) { tv = cur.csl[1]; ti = 64 + lane; }
-      if (cur.csl[2] > tv) { tv = cur.csl[2]; ti = 128 + lane; }
-      wave_argmax_first(tv, ti);
-      const float theta = ((float)(ti - 90) / 180.0f) * 3.141592f;
-      const float bx = __shfl(cur.box, 0), by = __shfl(cur.box, 1), bl = __shfl(cur.box, 2), bs_ = __shfl(cur.box, 3);
-      { const float mn = (bs_ < bl) ? bs_ : bl; if (mn >= 0.001f && mn < 1.0f) tiny_seen = true; }
-      if (a.multi_label) {
+    if (!npass) return;
+    // CSL decode: first arg-max over the 180 bins (:822-823)
+    unsigned long long tk = argmax_key(cur.csl[0], lane);
+    { const unsigned long long k1 = argmax_key(cur.csl[1], 64 + lane); tk = k1 > tk ? k1 : tk; }
+    { const unsigned long long k2 = argmax_key(cur.csl[2], 128 + lane); tk = k2 > tk ? k2 : tk; }   // lanes >= 52: -inf
+    float tv; int ti;
+    argmax_unkey(wave_max_u64(tk), tv, ti);
+    const float theta = ((float)(ti - 90) / 180.0f) * 3.141592f;
+    const float bx = __shfl(cur.box, 0), by = __shfl(cur.box, 1), bl = __shfl(cur.box, 2), bs_ = __shfl(cur.box, 3);
+    { const float mn = (bs_ < bl) ? bs_ : bl; if (mn >= 0.001f && mn < 1.0f) tiny_seen = true; }
+    if (a.multi_label) {
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-          const int c0 = q * 64;
-          const unsigned long long pb = pass_bits[q];
-          const int np = __popcll(pb);
-          if (np == 0) continue;
-          if (staged + np > kDecStage) flush_wave();
-          if ((pb >> lane) & 1ull) {
-            const int i = staged + __popcll(pb & lanemask_lt());
-            const int c = c0 + lane;
-            const float conf = myconf[q];
-            c0s[i] = make_float4(bx, by, bl, bs_);
-            c1s[i] = make_float4(theta, conf, (float)c, 0.f);
-            kys[i] = ((unsigned long long)score_desc_key(conf) << 32) | (unsigned long long)(uint32_t)(rw * a.nc + c);
-          }
-          staged += np;
+      for (int q = 0; q < 4; q++) {
+        const int c0 = q * 64;
+        const unsigned long long pb = pass_bits[q];
+        const int np = __popcll(pb);
+        if (np == 0) continue;
+        if (staged + np > kDecStage) flush_wave();
+        if ((pb >> lane) & 1ull) {
+          const int i = staged + __popcll(pb & lanemask_lt());
+          const int c = c0 + lane;
+          const float conf = myconf[q];
+          c0s[i] = make_float4(bx, by, bl, bs_);
+          c1s[i] = make_float4(theta, conf, (float)c, 0.f);
+          kys[i] = ((unsigned long long)score_desc_key(conf) << 32) | (unsigned long long)(uint32_t)(rw * a.nc + c);
         }
-      } else {
-        if (staged + 1 > kDecStage) flush_wave();
-        if (lane == 0) {
-          c0s[staged] = make_float4(bx, by, bl, bs_);
-          c1s[staged] = make_float4(theta, bestv, (float)besti, 0.f);
-          kys[staged] = ((unsigned long long)score_desc_key(bestv) << 32) | (unsigned long long)(uint32_t)(rw * a.nc + besti);
-        }
-        staged += 1;
+        staged += np;
       }
+    } else {
+      if (staged + 1 > kDecStage) flush_wave();
+      if (lane == 0) {
+        c0s[staged] = make_float4(bx, by, bl, bs_);
+        c1s[staged] = make_float4(theta, bestv, (float)besti, 0.f);
+        kys[staged] = ((unsigned long long)score_desc_key(bestv) << 32) | (unsigned long long)(uint32_t)(rw * a.nc + besti);
+      }
+      staged += 1;
     }
-    have = have_next; ck = nk; crr = nrr; cur = nxt;
+  };
+  for (int j0 = wv; j0 < n_rows; j0 += 4 * kDecDepth) {
+    DecRow<T> rows[kDecDepth];
+#pragma unroll
+    for (int i = 0; i < kDecDepth; i++) {
+      const int j = j0 + 4 * i;
+      if (j < n_rows) rows[i] = dec_load_row<T>(img + (size_t)s_row[j] * a.no, a.nc, lane);
+    }
+#pragma unroll
+    for (int i = 0; i < kDecDepth; i++) {
+      const int j = j0 + 4 * i;
+      if (j < n_rows) reduce_row(rows[i], s_obj[j], (long long)s_row[j]);
+    }
   }
 
   if (tiny_seen && lane == 0) atomicOr(&a.tiny[b], 1);
@@ -739,7 +786,7 @@ static int obb_carve(void* base, int64_t bs, int64_t cap_img, int64_t ncs, ObbCa
   return OBB_OK;
 }
 
-static int run_nms_obb(const void* pred, int dtype, int64_t bs, int64_t A, int64_t no, float conf_thres, float iou_thres,
+static int run_nms_obb(const void* pred, const void* objcol, int dtype, int64_t bs, int64_t A, int64_t no, float conf_thres, float iou_thres,
                        const int32_t* classes_host, int n_classes, int agnostic, int multi_label, int64_t max_det, int64_t max_nms,
                        float max_wh, const float* extra8, int64_t n_extra, int64_t cap_img, int64_t expected_cand, float* out,
                        int out_packed, int64_t* out_count, int64_t* status, void* ws, size_t ws_bytes, hipStream_t st) {
@@ -766,7 +813,7 @@ static int run_nms_obb(const void* pred, int dtype, int64_t bs, int64_t A, int64
   if (!ws || ws_bytes < cv.total) return OBB_ERR_WORKSPACE;
 
   DecodeArgs d;
-  d.pred = pred; d.A = A; d.no = (int)no; d.nc = nc; d.bs = (int)bs; d.conf_thres = conf_thres;
+  d.pred = pred; d.objcol = objcol; d.A = A; d.no = (int)no; d.nc = nc; d.bs = (int)bs; d.conf_thres = conf_thres;
   d.multi_label = (multi_label && nc > 1) ? 1 : 0;                 // :797
   d.cm.all = (classes_host == nullptr || n_classes <= 0) ? 1 : 0;
   for (int i = 0; i < 4; i++) d.cm.w[i] = 0ull;
@@ -781,7 +828,9 @@ static int run_nms_obb(const void* pred, int dtype, int64_t bs, int64_t A, int64
     k_reset_state<<<256, 256, 0, st>>>(cv.cnt, (int)(bs * kCntPad), cv.tiny, (int)bs, status, cv.ticket,
                                        reinterpret_cast<uint4*>(nv0.bar), (long long)(nv0.bar_bytes / 16));
   }
-  dim3 gd((unsigned)((A + 4 * kDecRowsPerWave - 1) / (4 * kDecRowsPerWave)), (unsigned)bs);
+  // rows per workgroup: 1024 when that still gives ~4 workgroups per CU, else 512 / 256 (small batches, the TTA tensor)
+  d.rows_per_thread = (bs * A >= 4 * 256 * 1024) ? 4 : (bs * A >= 2 * 256 * 1024) ? 2 : 1;
+  dim3 gd((unsigned)((A + 256 * d.rows_per_thread - 1) / (256 * d.rows_per_thread)), (unsigned)bs);
   {
     ProfScope ps(PROF_DECODE, st);
     if (dtype == 0) k_decode<float><<<gd, 256, 0, st>>>(d);

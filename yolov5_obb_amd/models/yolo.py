@@ -4,8 +4,14 @@ Only the head is mirrored: ``Model`` / ``parse_model`` / the CSP backbone stay t
 PyTorch-ROCm unchanged).  This class keeps the reference's constructor, attributes (``nc no nl na anchors m grid
 anchor_grid stride inplace onnx_dynamic``), parameter names and return values, so checkpoints and ``parse_model`` can use it
 in place of the reference's ``Detect``.  In inference mode on the GPU the per-level chain
-``view -> permute -> contiguous -> sigmoid -> 2 slice updates -> cat`` is ONE pass of ``obb_detect_decode``
+``view -> permute -> contiguous -> sigmoid -> 2 slice updates -> cat`` is ONE pass of ``obb_detect_decode_col``
 (libobb_hip.so, csrc/head.hip) per level.
+
+Coupling with the NMS (the next stage of val.py / detect.py): the same pass stores the objectness column ``z[..., 4]`` once
+more as a dense (bs, A) tensor and hangs it on the returned ``z`` (``z._obb_objcol = (column, z._version)``).
+``utils.general.non_max_suppression_obb`` reads its confidence filter from that column -- 2 bytes per anchor instead of one
+128-byte line of every 400-byte row -- when it is handed this very tensor object, unmodified (same ``_version``); any other
+tensor (a clone, a cast, the TTA concatenation, an in-place edit) takes the plain path.  The results are identical.
 """
 import ctypes as C
 
@@ -24,6 +30,8 @@ class Detect(nn.Module):
     # inference on CPU tensors: this package has no CPU path.  yolov5_obb_amd.dropin.install() points this at the
     # reference's own Detect.forward (models/yolo.py:50-81), so that `detect.py --device cpu` keeps running its code.
     _cpu_forward = None
+    # store z[..., 4] densely next to z for the confidence filter of non_max_suppression_obb (module docstring)
+    couple_nms = True
 
     def __init__(self, nc=80, anchors=(), ch=(), inplace=True):  # detection layer
         super().__init__()
@@ -86,6 +94,7 @@ class Detect(nn.Module):
         shapes = [(c.shape[2], c.shape[3]) for c in convs]
         a_total = sum(self.na * ny * nx for ny, nx in shapes)
         z = torch.empty((bs, a_total, self.no), dtype=c0.dtype, device=c0.device)
+        col = torch.empty((bs, a_total), dtype=c0.dtype, device=c0.device) if self.couple_nms else None
         L = _lib.lib()
         off = 0
         with torch.cuda.device(c0.device):
@@ -95,11 +104,13 @@ class Detect(nn.Module):
                 if self.onnx_dynamic or self.grid[i].shape[2:4] != (ny, nx):
                     self.grid[i], self.anchor_grid[i] = self._make_grid(nx, ny, i)      # kept for attribute compatibility
                 xp = torch.empty((bs, self.na, ny, nx, self.no), dtype=c0.dtype, device=c0.device)
-                rc = L.obb_detect_decode(_lib.ptr(convs[i]), code, bs, self.na, self.no, ny, nx, C.cast(anchor_px[i], C.c_void_p),
-                                         strides[i], _lib.ptr(xp), _lib.ptr(z), a_total, off, st)
-                _lib.check(rc, "obb_detect_decode")
+                rc = L.obb_detect_decode_col(_lib.ptr(convs[i]), code, bs, self.na, self.no, ny, nx, C.cast(anchor_px[i], C.c_void_p),
+                                             strides[i], _lib.ptr(xp), _lib.ptr(z), a_total, off, _lib.ptr(col), st)
+                _lib.check(rc, "obb_detect_decode_col")
                 x[i] = xp
                 off += self.na * ny * nx
+        if col is not None:
+            z._obb_objcol = (col, z._version)            # read by utils.general.non_max_suppression_obb (see the module docstring)
         return z, x
 
     def _make_grid(self, nx=20, ny=20, i=0):  # models/yolo.py:83-92

@@ -41,6 +41,20 @@ def _label_rows(labels, bs, nc, device):
     return torch.cat(rows, 0).contiguous() if rows else None
 
 
+def _objectness_column(prediction, pred):
+    """The dense copy of prediction[..., 4] that this package's Detect hangs on its output (models/yolo.py), or None.
+    Only trusted for the very tensor object Detect returned, unchanged since: same object (the attribute lives on it), same
+    version counter (any in-place write through the tensor or a view of it bumps it), same geometry."""
+    tag = getattr(prediction, "_obb_objcol", None)
+    if tag is None or pred is not prediction:
+        return None
+    col, version = tag
+    if (version != prediction._version or not isinstance(col, torch.Tensor) or col.shape != prediction.shape[:2]
+            or col.dtype != prediction.dtype or col.device != prediction.device or not col.is_contiguous()):
+        return None
+    return col
+
+
 def non_max_suppression_obb(prediction, conf_thres=0.25, iou_thres=0.45, classes=None, agnostic=False, multi_label=False,
                             labels=(), max_det=1500):
     """Runs Non-Maximum Suppression (NMS) on inference results_obb (utils/general.py:772-862).
@@ -70,6 +84,7 @@ def non_max_suppression_obb(prediction, conf_thres=0.25, iou_thres=0.45, classes
     pred = prediction.contiguous()
     bs, A, no = pred.shape
     dev = pred.device
+    col = _objectness_column(prediction, pred)
     multi = bool(multi_label) and nc > 1
     if bs == 0:
         return []
@@ -111,8 +126,8 @@ def non_max_suppression_obb(prediction, conf_thres=0.25, iou_thres=0.45, classes
             if nbytes is None:
                 nbytes = _ws_memo[wkey] = L.obb_nms_obb_workspace_bytes(bs, cap, nc, agn)
             ws = _lib.workspace(nbytes, dev, st)
-            rc = L.obb_non_max_suppression_obb(
-                _lib.ptr(pred), dtype, bs, A, no, float(conf_thres), float(iou_thres),
+            rc = L.obb_non_max_suppression_obb_col(
+                _lib.ptr(pred), _lib.ptr(col), dtype, bs, A, no, float(conf_thres), float(iou_thres),
                 C.cast(cls_arr, C.c_void_p) if cls_arr is not None else C.c_void_p(0), n_cls, agn, int(multi),
                 max_det, _MAX_NMS, float(_MAX_WH), _lib.ptr(extra), n_extra, cap, hint, _lib.ptr(out), 1, _lib.ptr(meta),
                 C.c_void_p(meta.data_ptr() + 8 * bs), _lib.ptr(ws), ws.numel(), C.c_void_p(st))
