@@ -45,6 +45,21 @@ def test_fused_nms_obb_vs_pyref_larger(dev, oracle_lib, bs, A, nc, conf, half):
     _cmp(got, ref, ties=half)
 
 
+@pytest.mark.parametrize("nc,multi,half", [(40, True, False), (80, True, True), (80, False, False), (200, True, False), (33, False, True)])
+def test_many_classes(dev, oracle_lib, nc, multi, half):
+    """The filter keeps two class groups of 16 per row in registers and fetches the others on demand: nc > 32 exercises that,
+    with the multi-label expansion and with the best-class rule (utils/general.py:826-832)."""
+    from yolov5_obb_amd.utils.general import non_max_suppression_obb
+    pred = synth.s_pred(2, 3000, nc, seed=300 + nc, fg_frac=0.05, dtype=torch.float16 if half else torch.float32)
+    if multi:                                           # several classes above the threshold on the planted rows
+        pred[..., 5:5 + nc:7] = torch.maximum(pred[..., 5:5 + nc:7], pred[..., 4:5] * 0.9)
+    kw = dict(conf_thres=0.05, iou_thres=0.4, multi_label=multi, max_det=1500)
+    ref = pyref.non_max_suppression_obb(pred.clone(), **kw)
+    assert sum(r.shape[0] for r in ref) > 20
+    got = non_max_suppression_obb(pred.to(dev), **kw)
+    _cmp(got, ref, ties=half)
+
+
 def test_fused_nms_obb_labels_and_empty(dev, oracle_lib):
     from yolov5_obb_amd.utils.general import non_max_suppression_obb
     pred = synth.s_pred(2, 3000, 15, seed=5)

@@ -60,11 +60,14 @@ __device__ __forceinline__ unsigned long long dpp_max_u64(unsigned long long k) 
   const unsigned long long o = ((unsigned long long)hi << 32) | lo;
   return o > k ? o : k;
 }
-__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long k) {   // all 64 lanes active
+__device__ __forceinline__ unsigned long long row_max_u64(unsigned long long k) {    // all 64 lanes active
   k = dpp_max_u64<0xB1>(k);      // quad_perm [1,0,3,2]
   k = dpp_max_u64<0x4E>(k);      // quad_perm [2,3,0,1]
   k = dpp_max_u64<0x141>(k);     // row_half_mirror
-  k = dpp_max_u64<0x140>(k);     // row_mirror: every lane holds the max of its 16-lane row
+  return dpp_max_u64<0x140>(k);  // row_mirror: every lane holds the max of its 16-lane row
+}
+__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long k) {   // all 64 lanes active
+  k = row_max_u64(k);
   unsigned long long r[4];
 #pragma unroll
   for (int j = 0; j < 4; j++)
@@ -89,7 +92,7 @@ struct DecodeArgs {
   int no, nc, bs;
   float conf_thres;
   int multi_label;
-  int rows_per_thread;       // G: a workgroup of k_decode covers 256 * G rows
+  int rows_per_thread;       // G: a workgroup of k_decode covers kDecThreads * G rows
   ClassMask cm;
   long long cap_img;         // candidate slots per image
   float4* cand;              // [bs*cap_img][2]: {x,y,l,s} {theta,conf,cls,0}
@@ -109,54 +112,70 @@ __device__ __forceinline__ bool class_allowed(const ClassMask& cm, int c) {
 // (MI355X_MICROARCH.md "fanin"/"dequeue"), and 16 counters packed in one line would share one L2 channel.
 constexpr int kCntPad = 64;   // ints
 
-// Rows of a workgroup = 256 * G (G = 1, 2 or 4 rows per thread, chosen by the host so that small batches still fill the
+// Rows of a workgroup = kDecThreads * G (G = 1, 2 or 4 rows per thread, chosen by the host so that small batches still fill the
 // chip).  History: with one wave per 64 consecutive rows that also processed ITS passing rows one after the other, the
 // kernel took 52 us on a warm and 78-91 us on a freshly written configs[1] tensor -- even with the dense objectness column:
 // detector output is clustered (an object fires on neighbouring cells), so a few waves carried long serial chains of cold
 // row reads while most had none.  Now the workgroup compacts its passing rows into LDS and its four waves take them
 // round-robin, kDecDepth rows in flight per wave.
+constexpr int kDecThreads = 512;      // 8 waves: a workgroup whose share of rows is three times the median still needs one pass
+constexpr int kDecWaves = kDecThreads / 64;
 constexpr int kDecMaxG = 4;
-constexpr int kDecDepth = 4;
+constexpr int kDecDepth = 2;          // groups of four rows in flight per wave
 constexpr int kDecStage = 128;         // staged candidates per wave (LDS) before a flush
 
-// Per-row registers of one lane: everything the row needs is requested up front (one memory latency per row,
-// and the next row's loads are issued before the current row is reduced).
+// Phase 2 of k_decode works on FOUR rows per wave, one per 16-lane DPP row: a row of the head output holds ~200 elements,
+// and with a whole wave per row most of every instruction was bookkeeping (measured: ~450 wave instructions per row,
+// VALU-bound).  Lane l16 of a group holds angle bins l16, l16+16, ... (12 registers), classes l16 and 16+l16 (further
+// class groups of 16 are loaded on demand: nc > 32), and the box.  Everything a group needs is requested up front.
+constexpr int kDecCslRegs = 12;          // ceil(180 / 16)
+constexpr int kDecClsRegs = 2;           // class groups of 16 that travel with the row
 template <typename T>
-struct DecRow {
-  float cls[4];      // class scores c = q*64 + lane (raw, not yet multiplied by obj)
-  float csl[3];      // angle bins lane, 64+lane, 128+lane
-  float box;         // lanes 0..3: x y l s
+struct DecQuad {
+  float csl[kDecCslRegs];
+  float cls[kDecClsRegs];
+  float box[4];
+  float obj;
+  uint32_t row;
+  bool valid;
 };
 
 template <typename T>
-__device__ __forceinline__ DecRow<T> dec_load_row(const T* base, int nc, int lane) {
-  DecRow<T> r;
-#pragma unroll
-  for (int q = 0; q < 4; q++) {
-    const int c = q * 64 + lane;
-    r.cls[q] = (c < nc) ? ld_as_float<T>(base + 5 + c) : 0.f;
-  }
+__device__ __forceinline__ DecQuad<T> dec_load_quad(const T* img, int no, int nc, const uint32_t* s_row, const float* s_obj,
+                                                    int j, int n_rows, int l16) {
+  DecQuad<T> r;
+  r.valid = j < n_rows;
+  r.row = r.valid ? s_row[j] : 0u;
+  r.obj = r.valid ? s_obj[j] : 0.f;
+  const T* base = img + (size_t)r.row * no;
   const T* csl = base + 5 + nc;
-  r.csl[0] = ld_as_float<T>(csl + lane);
-  r.csl[1] = ld_as_float<T>(csl + 64 + lane);
-  r.csl[2] = (lane < 180 - 128) ? ld_as_float<T>(csl + 128 + lane) : -__builtin_inff();
-  r.box = (lane < 4) ? ld_as_float<T>(base + lane) : 0.f;
+#pragma unroll
+  for (int k = 0; k < kDecCslRegs; k++) {
+    const int bin = k * 16 + l16;
+    r.csl[k] = (r.valid && bin < 180) ? ld_as_float<T>(csl + bin) : -__builtin_inff();
+  }
+#pragma unroll
+  for (int g = 0; g < kDecClsRegs; g++) {
+    const int c = g * 16 + l16;
+    r.cls[g] = (r.valid && c < nc) ? ld_as_float<T>(base + 5 + c) : 0.f;
+  }
+#pragma unroll
+  for (int k = 0; k < 4; k++) r.box[k] = r.valid ? ld_as_float<T>(base + k) : 0.f;
   return r;
 }
 
-// k_decode: workgroup = 256 threads x G rows.  Phase 1 reads the objectness of every row -- from the dense column when the
+// k_decode: workgroup = 512 threads x G rows.  Phase 1 reads the objectness of every row -- from the dense column when the
 // producer stored one (obb_detect_decode_col), else one 2-4 byte element of each 400-800 byte row -- and compacts the rows
 // with obj > conf into an LDS list (wave ballot + one LDS atomic per wave).  Phase 2: the four waves take the listed rows
-// round-robin, kDecDepth rows in flight per wave: the whole wave loads a row (classes, 180 angle bins, box), reduces it
-// and stages its candidates in LDS.  Slots in the image's candidate region are claimed with ONE atomic per workgroup (plus
+// round-robin in groups of four (DecQuad above), kDecDepth groups in flight per wave, and stage the candidates in LDS.  Slots in the image's candidate region are claimed with ONE atomic per workgroup (plus
 // one per wave whenever its 128-entry stage fills up) and the staged records are written out coalesced.
 template <typename T>
-__global__ __launch_bounds__(256) void k_decode(DecodeArgs a) {
-  __shared__ float4 s_c0[4][kDecStage], s_c1[4][kDecStage];
-  __shared__ unsigned long long s_key[4][kDecStage];
-  __shared__ int s_cnt[4], s_base, s_n;
-  __shared__ uint32_t s_row[256 * kDecMaxG];
-  __shared__ float s_obj[256 * kDecMaxG];
+__global__ __launch_bounds__(kDecThreads) void k_decode(DecodeArgs a) {
+  __shared__ float4 s_c0[kDecWaves][kDecStage], s_c1[kDecWaves][kDecStage];
+  __shared__ unsigned long long s_key[kDecWaves][kDecStage];
+  __shared__ int s_cnt[kDecWaves], s_base, s_n;
+  __shared__ uint32_t s_row[kDecThreads * kDecMaxG];
+  __shared__ float s_obj[kDecThreads * kDecMaxG];
 
   const T* pred = (const T*)a.pred;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -194,10 +213,12 @@ __global__ __launch_bounds__(256) void k_decode(DecodeArgs a) {
 
   // ---- phase 1: objectness of the workgroup's rows                    :785  xc = prediction[..., 4] > conf_thres
   float obj[kDecMaxG];
-  // 64-row chunks are dealt to the workgroups of the image round-robin (chunk c -> workgroup c % gridDim.x): detector output
-  // is clustered -- a coarse level holds hundreds of passing rows in a few thousand consecutive rows -- and contiguous
-  // 1024-row blocks left a handful of workgroups with ten times the average number of rows to reduce
-  auto row_of = [&](int q) -> long long { return ((long long)(q * 4 + wv) * gridDim.x + blockIdx.x) * 64 + lane; };
+  // 16-row chunks are dealt to the workgroups of the image round-robin (chunk c -> workgroup c % gridDim.x): detector output
+  // is clustered -- a coarse level holds hundreds of passing rows in a few thousand consecutive rows.  Contiguous 1024-row
+  // blocks left a handful of workgroups with ten times the average number of rows to reduce, 64-row chunks still three
+  // times (0 / 14 / 44 rows: min / median / max on the planted-object batch); the objectness reads do not care (a strided
+  // read is one line per row anyway, the dense column is read in 32-byte pieces).
+  auto row_of = [&](int q) -> long long { return ((long long)(q * (kDecThreads / 16) + (tid >> 4)) * gridDim.x + blockIdx.x) * 16 + (tid & 15); };
 #pragma unroll
   for (int q = 0; q < kDecMaxG; q++) {
     const long long row = row_of(q);
@@ -223,88 +244,75 @@ __global__ __launch_bounds__(256) void k_decode(DecodeArgs a) {
   __syncthreads();
   const int n_rows = s_n;
 
-  // ---- phase 2: the listed rows, wave wv takes entries wv, wv + 4, ...; kDecDepth rows requested before the first is reduced
-  const int nq = (a.nc + 63) >> 6;
-  auto reduce_row = [&](const DecRow<T>& cur, float o, long long rw) {
+  // ---- phase 2: the listed rows in groups of four (one per 16-lane row); wave wv takes groups wv, wv + 8, ...,
+  // kDecDepth groups requested before the first is reduced
+  const int l16 = lane & 15, sub = lane >> 4;
+  const int ncg = (a.nc + 15) >> 4;
+  auto reduce_quad = [&](const DecQuad<T>& cur) {
+    // CSL decode: first arg-max over the 180 bins (:822-823), inside the 16-lane row
+    unsigned long long tk = argmax_key(cur.csl[0], l16);
+#pragma unroll
+    for (int k = 1; k < kDecCslRegs; k++) { const unsigned long long kk = argmax_key(cur.csl[k], k * 16 + l16); tk = kk > tk ? kk : tk; }
+    float tv; int ti;
+    argmax_unkey(row_max_u64(tk), tv, ti);
+    const float theta = ((float)(ti - 90) / 180.0f) * 3.141592f;
+    const float bx = cur.box[0], by = cur.box[1], bl = cur.box[2], bs_ = cur.box[3];
+    const float mn = (bs_ < bl) ? bs_ : bl;
+    const bool tiny = mn >= 0.001f && mn < 1.0f;
+    const long long rw = (long long)cur.row;
+    auto stage = [&](bool p, float conf, int c) {        // one candidate per lane with p set
+      const unsigned long long pb = __ballot(p);
+      const int np = __popcll(pb);
+      if (np == 0) return;
+      if (staged + np > kDecStage) flush_wave();
+      if (p) {
+        const int i = staged + __popcll(pb & lanemask_lt());
+        c0s[i] = make_float4(bx, by, bl, bs_);
+        c1s[i] = make_float4(theta, conf, (float)c, 0.f);
+        kys[i] = ((unsigned long long)score_desc_key(conf) << 32) | (unsigned long long)(uint32_t)(rw * a.nc + c);
+        if (tiny) tiny_seen = true;
+      }
+      staged += np;
+    };
     // class confidences (:820 conf = obj * cls in the input dtype)
     float bestv = -__builtin_inff(); int besti = 0x7fffffff;
-    unsigned long long pass_bits[4] = {0ull, 0ull, 0ull, 0ull};
-    float myconf[4];
-    int npass = 0;
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-      if (q >= nq) { myconf[q] = -__builtin_inff(); continue; }      // wave-uniform: nc <= 64 needs one of the four passes
-      const int c = q * 64 + lane;
-      const float v = (c < a.nc) ? mul_in_dtype<T>(cur.cls[q], o) : -__builtin_inff();
-      myconf[q] = v;
-      if (a.multi_label) {
-        const bool p = (c < a.nc) && (v > thr) && (a.cm.all || ((a.cm.w[q] >> lane) & 1ull));               // :827, :835
-        pass_bits[q] = __ballot(p);
-        npass += __popcll(pass_bits[q]);
-      } else if (c < a.nc && (v > bestv)) { bestv = v; besti = c; }   // lanes see ascending c: first max kept
+    for (int g = 0; g < ncg; g++) {
+      const int c = g * 16 + l16;
+      float raw;
+      if (g < kDecClsRegs) raw = (g == 0) ? cur.cls[0] : cur.cls[1];
+      else raw = (cur.valid && c < a.nc) ? ld_as_float<T>(img + (size_t)cur.row * a.no + 5 + c) : 0.f;
+      const float v = (cur.valid && c < a.nc) ? mul_in_dtype<T>(raw, cur.obj) : -__builtin_inff();
+      if (a.multi_label) stage(cur.valid && c < a.nc && v > thr && class_allowed(a.cm, c), v, c);             // :827, :835
+      else if (c < a.nc && v > bestv) { bestv = v; besti = c; }            // a lane sees ascending c: first max kept
     }
     if (!a.multi_label) {
-      wave_argmax_first(bestv, besti);                                                                    // :830
-      npass = (bestv > thr && class_allowed(a.cm, besti)) ? 1 : 0;                                        // :831, :835
-    }
-    if (!npass) return;
-    // CSL decode: first arg-max over the 180 bins (:822-823)
-    unsigned long long tk = argmax_key(cur.csl[0], lane);
-    { const unsigned long long k1 = argmax_key(cur.csl[1], 64 + lane); tk = k1 > tk ? k1 : tk; }
-    { const unsigned long long k2 = argmax_key(cur.csl[2], 128 + lane); tk = k2 > tk ? k2 : tk; }   // lanes >= 52: -inf
-    float tv; int ti;
-    argmax_unkey(wave_max_u64(tk), tv, ti);
-    const float theta = ((float)(ti - 90) / 180.0f) * 3.141592f;
-    const float bx = __shfl(cur.box, 0), by = __shfl(cur.box, 1), bl = __shfl(cur.box, 2), bs_ = __shfl(cur.box, 3);
-    { const float mn = (bs_ < bl) ? bs_ : bl; if (mn >= 0.001f && mn < 1.0f) tiny_seen = true; }
-    if (a.multi_label) {
-#pragma unroll
-      for (int q = 0; q < 4; q++) {
-        const int c0 = q * 64;
-        const unsigned long long pb = pass_bits[q];
-        const int np = __popcll(pb);
-        if (np == 0) continue;
-        if (staged + np > kDecStage) flush_wave();
-        if ((pb >> lane) & 1ull) {
-          const int i = staged + __popcll(pb & lanemask_lt());
-          const int c = c0 + lane;
-          const float conf = myconf[q];
-          c0s[i] = make_float4(bx, by, bl, bs_);
-          c1s[i] = make_float4(theta, conf, (float)c, 0.f);
-          kys[i] = ((unsigned long long)score_desc_key(conf) << 32) | (unsigned long long)(uint32_t)(rw * a.nc + c);
-        }
-        staged += np;
-      }
-    } else {
-      if (staged + 1 > kDecStage) flush_wave();
-      if (lane == 0) {
-        c0s[staged] = make_float4(bx, by, bl, bs_);
-        c1s[staged] = make_float4(theta, bestv, (float)besti, 0.f);
-        kys[staged] = ((unsigned long long)score_desc_key(bestv) << 32) | (unsigned long long)(uint32_t)(rw * a.nc + besti);
-      }
-      staged += 1;
+      float bv; int bi;
+      argmax_unkey(row_max_u64(argmax_key(bestv, besti)), bv, bi);                                            // :830
+      stage(cur.valid && l16 == 0 && bv > thr && class_allowed(a.cm, bi), bv, bi);                            // :831, :835
     }
   };
-  for (int j0 = wv; j0 < n_rows; j0 += 4 * kDecDepth) {
-    DecRow<T> rows[kDecDepth];
+  static_assert(kDecClsRegs == 2, "reduce_quad selects cls[0] / cls[1] explicitly");
+  for (int g0 = wv; g0 * 4 < n_rows; g0 += kDecWaves * kDecDepth) {
+    DecQuad<T> quads[kDecDepth];
 #pragma unroll
     for (int i = 0; i < kDecDepth; i++) {
-      const int j = j0 + 4 * i;
-      if (j < n_rows) rows[i] = dec_load_row<T>(img + (size_t)s_row[j] * a.no, a.nc, lane);
+      const int g = g0 + kDecWaves * i;
+      if (g * 4 < n_rows) quads[i] = dec_load_quad<T>(img, a.no, a.nc, s_row, s_obj, g * 4 + sub, n_rows, l16);
     }
 #pragma unroll
     for (int i = 0; i < kDecDepth; i++) {
-      const int j = j0 + 4 * i;
-      if (j < n_rows) reduce_row(rows[i], s_obj[j], (long long)s_row[j]);
+      const int g = g0 + kDecWaves * i;
+      if (g * 4 < n_rows) reduce_quad(quads[i]);
     }
   }
 
-  if (tiny_seen && lane == 0) atomicOr(&a.tiny[b], 1);
+  if (__ballot(tiny_seen) && lane == 0) atomicOr(&a.tiny[b], 1);
   // ---- one atomic per workgroup for whatever is still staged
   if (lane == 0) s_cnt[wv] = staged;
   __syncthreads();
   if (threadIdx.x == 0) {
-    const int tot = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+    int tot = 0;
+    for (int w = 0; w < kDecWaves; w++) tot += s_cnt[w];
     s_base = tot ? atomicAdd(&a.cnt[b * kCntPad], tot) : 0;
   }
   __syncthreads();
@@ -828,13 +836,13 @@ static int run_nms_obb(const void* pred, const void* objcol, int dtype, int64_t 
     k_reset_state<<<256, 256, 0, st>>>(cv.cnt, (int)(bs * kCntPad), cv.tiny, (int)bs, status, cv.ticket,
                                        reinterpret_cast<uint4*>(nv0.bar), (long long)(nv0.bar_bytes / 16));
   }
-  // rows per workgroup: 1024 when that still gives ~4 workgroups per CU, else 512 / 256 (small batches, the TTA tensor)
-  d.rows_per_thread = (bs * A >= 4 * 256 * 1024) ? 4 : (bs * A >= 2 * 256 * 1024) ? 2 : 1;
-  dim3 gd((unsigned)((A + 256 * d.rows_per_thread - 1) / (256 * d.rows_per_thread)), (unsigned)bs);
+  // rows per workgroup: 2048 when that still gives two workgroups per CU, else 1024 / 512 (small batches, the TTA tensor)
+  d.rows_per_thread = (bs * A >= 4LL * kDecThreads * 480) ? 4 : (bs * A >= 2LL * kDecThreads * 480) ? 2 : 1;
+  dim3 gd((unsigned)((A + kDecThreads * d.rows_per_thread - 1) / (kDecThreads * d.rows_per_thread)), (unsigned)bs);
   {
     ProfScope ps(PROF_DECODE, st);
-    if (dtype == 0) k_decode<float><<<gd, 256, 0, st>>>(d);
-    else k_decode<__half><<<gd, 256, 0, st>>>(d);
+    if (dtype == 0) k_decode<float><<<gd, kDecThreads, 0, st>>>(d);
+    else k_decode<__half><<<gd, kDecThreads, 0, st>>>(d);
   }
   if (n_extra > 0 && extra8) k_append_extra<<<(unsigned)((n_extra + 255) / 256), 256, 0, st>>>(extra8, (int)n_extra, A, nc, d);
   const unsigned gs = (unsigned)((bs + 255) / 256);
