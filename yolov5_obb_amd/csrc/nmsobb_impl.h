@@ -453,43 +453,30 @@ __global__ void k_reset_state(int* __restrict__ cnt, int n_cnt, int* __restrict_
   for (long long k = i; k < n_bar16; k += n) bar16[k] = make_uint4(0u, 0u, 0u, 0u);
 }
 
-// Bitonic sort of npad (a power of two, 64 .. 1024*E) (key, value) pairs that sit in LDS, by 1024 threads holding E
-// consecutive elements each in registers: compare-exchange distances below E stay inside a thread, distances below 64*E are
-// lane shuffles inside a wave, only the longer ones go through LDS with a workgroup barrier (10 of the 66 stages at 2048).
+// Sort of npad (a power of two, 64 .. 1024*E) (key, value) pairs that sit in LDS, ascending, by 1024 threads holding E
+// consecutive elements each in registers.
+//   1. every wave sorts its run of 64*E elements with a bitonic network that never leaves the wave: compare-exchange
+//      distances below E stay inside a thread, the others are lane shuffles;
+//   2. the runs are merged pairwise, log2(npad / (64*E)) levels: every element finds its rank in the sibling run with a
+//      binary search in LDS (strict on one side, non-strict on the other: equal keys -- the padding -- keep distinct
+//      ranks) and is written to its place; in place, two workgroup barriers per level.
+// (The first version ran the whole bitonic network, 10 of its 66 stages at 2048 elements through LDS with a barrier each:
+// 21.7 us on the configs[1] batch, 19.3 us now.  Replacing the lane shuffles of step 1 by DPP modifiers and the gfx950
+// permlane swaps -- no LDS crossbar at all -- was measured SLOWER, 22.6 us: the phase is bound by VALU issue with 16 waves
+// per CU, not by ds_bpermute.)
 template <int E>
-__device__ __forceinline__ void bitonic_lds_regs(unsigned long long* s_keys, uint32_t* s_vals, int npad, int tid) {
+__device__ __forceinline__ void sort_lds_regs(unsigned long long* s_keys, uint32_t* s_vals, int npad, int tid) {
+  constexpr int R = 64 * E;                        // run length of a wave
   const bool active = tid * E < npad;              // wave-uniform: npad is a multiple of 64
   unsigned long long k[E];
   uint32_t v[E];
 #pragma unroll
   for (int e = 0; e < E; e++) { k[e] = active ? s_keys[tid * E + e] : ~0ull; v[e] = active ? s_vals[tid * E + e] : 0u; }
-  for (int kk = 2; kk <= npad; kk <<= 1) {
-    int j = kk >> 1;
-    if (j >= 64 * E) {                             // (workgroup-uniform)
-      if (active) {
-#pragma unroll
-        for (int e = 0; e < E; e++) { s_keys[tid * E + e] = k[e]; s_vals[tid * E + e] = v[e]; }
-      }
-      __syncthreads();
-      for (; j >= 64 * E; j >>= 1) {
-        for (int t = tid; t < (npad >> 1); t += 1024) {
-          const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
-          const int ixj = i | j;
-          const unsigned long long ka = s_keys[i], kb = s_keys[ixj];
-          if ((ka > kb) == ((i & kk) == 0)) {
-            s_keys[i] = kb; s_keys[ixj] = ka;
-            const uint32_t va = s_vals[i], vb = s_vals[ixj];
-            s_vals[i] = vb; s_vals[ixj] = va;
-          }
-        }
-        __syncthreads();
-      }
-      if (active) {
-#pragma unroll
-        for (int e = 0; e < E; e++) { k[e] = s_keys[tid * E + e]; v[e] = s_vals[tid * E + e]; }
-      }
-    }
-    if (active) {
+  const int kk_top = npad < R ? npad : R;
+  if (active) {
+    for (int kk = 2; kk <= kk_top; kk <<= 1) {
+      const bool last = kk == R;                   // the run's final phase: every run ascending
+      int j = kk >> 1;
       for (; j >= E; j >>= 1) {                    // partner element i ^ j lives in lane ^ (j / E), same slot e
         const int lx = j / E;
 #pragma unroll
@@ -497,7 +484,7 @@ __device__ __forceinline__ void bitonic_lds_regs(unsigned long long* s_keys, uin
           const int i = tid * E + e;
           const unsigned long long ok = __shfl_xor(k[e], lx);
           const uint32_t ov = __shfl_xor(v[e], lx);
-          const bool take_min = ((i & j) == 0) == ((i & kk) == 0);
+          const bool take_min = ((i & j) == 0) == (last || (i & kk) == 0);
           if (take_min ? (ok < k[e]) : (ok > k[e])) { k[e] = ok; v[e] = ov; }
         }
       }
@@ -508,7 +495,7 @@ __device__ __forceinline__ void bitonic_lds_regs(unsigned long long* s_keys, uin
           for (int e = 0; e < E; e++) {
             if ((e & jj) == 0) {
               const int e2 = e | jj;
-              const bool up = (((tid * E + e) & kk) == 0);
+              const bool up = last || (((tid * E + e) & kk) == 0);
               if ((k[e] > k[e2]) == up) {
                 const unsigned long long tk = k[e]; k[e] = k[e2]; k[e2] = tk;
                 const uint32_t tv = v[e]; v[e] = v[e2]; v[e2] = tv;
@@ -525,6 +512,47 @@ __device__ __forceinline__ void bitonic_lds_regs(unsigned long long* s_keys, uin
     for (int e = 0; e < E; e++) { s_keys[tid * E + e] = k[e]; s_vals[tid * E + e] = v[e]; }
   }
   __syncthreads();
+  for (int len = R; len < npad; len <<= 1) {       // (workgroup-uniform)
+    int dst[E];
+    if (active) {
+      int lo[E], hi[E];
+#pragma unroll
+      for (int e = 0; e < E; e++) {
+        const int idx = tid * E + e;
+        const int sib = ((idx / len) ^ 1) * len;   // first element of the sibling run
+        lo[e] = sib; hi[e] = sib + len;
+      }
+      const bool right = ((tid * E) / len) & 1;    // (all E elements of a thread sit in the same run: E divides len)
+      for (int step = len; step > 0; step >>= 1) { // len is a power of two: log2(len) + 1 probes close every interval
+#pragma unroll
+        for (int e = 0; e < E; e++) {
+          if (lo[e] < hi[e]) {
+            const int mid = (lo[e] + hi[e]) >> 1;
+            const unsigned long long km = s_keys[mid];
+            const bool below = right ? (km <= k[e]) : (km < k[e]);     // sibling entries that precede mine
+            if (below) lo[e] = mid + 1; else hi[e] = mid;
+          }
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < E; e++) {
+        const int idx = tid * E + e;
+        const int run = idx / len, pos = idx - run * len;
+        const int sib = (run ^ 1) * len;
+        dst[e] = (run >> 1) * 2 * len + pos + (lo[e] - sib);
+      }
+    }
+    __syncthreads();                               // every search has read the old arrangement
+    if (active) {
+#pragma unroll
+      for (int e = 0; e < E; e++) { s_keys[dst[e]] = k[e]; s_vals[dst[e]] = v[e]; }
+    }
+    __syncthreads();
+    if (active && (len << 1) < npad) {
+#pragma unroll
+      for (int e = 0; e < E; e++) { k[e] = s_keys[tid * E + e]; v[e] = s_vals[tid * E + e]; }
+    }
+  }
 }
 
 // Small and medium images (at most kSortLdsMax candidates each, the regime of the reference's default thresholds): ONE
@@ -564,6 +592,13 @@ __global__ __launch_bounds__(1024) void k_sort_prep_lds(const float4* __restrict
     grp_begin[g] = b0; grp_end[g] = b0;
   }
   for (int sgm = tid; sgm < ncs; sgm += T) { seg_begin[g * ncs + sgm] = b0; seg_end[g * ncs + sgm] = b0; keep_cnt[g * ncs + sgm] = 0; }
+#ifdef OBB_SORT_TRACE
+  unsigned long long tt[8]; int ti_ = 0;
+#define TSTAMP() do { __syncthreads(); tt[ti_++] = wall_clock64(); } while (0)
+#else
+#define TSTAMP() do {} while (0)
+#endif
+  TSTAMP();
   int npad = 64;
   while (npad < n) npad <<= 1;
   const unsigned long long lim = (unsigned long long)A * nc;
@@ -582,15 +617,17 @@ __global__ __launch_bounds__(1024) void k_sort_prep_lds(const float4* __restrict
     s_keys[i] = k; s_vals[i] = v;
   }
   __syncthreads();
-  // bitonic network, ascending; keys are unique (the tie word), so the result is the one total order
+  TSTAMP();
+  // ascending; keys are unique (the tie word), so the result is the one total order
   // elements per thread: as few as the 1024 threads allow (measured: 8 per thread with 256 busy threads moves four more
   // levels into registers but is 16 us slower at 2048 candidates -- the lane shuffles become the bottleneck)
   switch (npad >> 10) {
-    case 0: case 1: bitonic_lds_regs<1>(s_keys, s_vals, npad, tid); break;
-    case 2: bitonic_lds_regs<2>(s_keys, s_vals, npad, tid); break;
-    case 4: bitonic_lds_regs<4>(s_keys, s_vals, npad, tid); break;
-    default: bitonic_lds_regs<8>(s_keys, s_vals, npad, tid); break;
+    case 0: case 1: sort_lds_regs<1>(s_keys, s_vals, npad, tid); break;
+    case 2: sort_lds_regs<2>(s_keys, s_vals, npad, tid); break;
+    case 4: sort_lds_regs<4>(s_keys, s_vals, npad, tid); break;
+    default: sort_lds_regs<8>(s_keys, s_vals, npad, tid); break;
   }
+  TSTAMP();
   for (int i = tid; i < n; i += T) { keys_out[b0 + i] = s_keys[i]; vals_out[b0 + i] = s_vals[i]; }
   // segment table (k_class_bounds): class runs of the sorted keys, or everything in segment 0
   if (m == 1) {
@@ -602,6 +639,7 @@ __global__ __launch_bounds__(1024) void k_sort_prep_lds(const float4* __restrict
   } else if (tid == 0) {
     seg_end[g * ncs] = b0 + e;
   }
+  TSTAMP();
   // NMS records + every word of the image's part of the alive bitmap (k_prep_cand; cap_img is a multiple of 64)
   const int e64 = (e + 63) & ~63;
   for (long long w = (e64 >> 6) + tid; w < (cap_img >> 6); w += T) alive[((size_t)b0 >> 6) + w] = 0ull;   // words behind the boxes
@@ -623,6 +661,7 @@ __global__ __launch_bounds__(1024) void k_sort_prep_lds(const float4* __restrict
     const u64 bits = __ballot(ok);
     if ((tid & 63) == 0 && i < e64) alive[(size_t)(b0 + i) >> 6] = bits;
   }
+  TSTAMP();
   if (g == bs - 1 && tid < 8) alive[(((size_t)bs * cap_img) >> 6) + tid] = 0ull;   // the bitmap's guard words
   // the workgroup that finishes last plans the NMS launch (k_plan_teams without a launch of its own): every workgroup
   // publishes its segment table (release), the last ticket holder acquires and reads all of them
@@ -636,6 +675,11 @@ __global__ __launch_bounds__(1024) void k_sort_prep_lds(const float4* __restrict
       plan_teams_block(seg_begin, seg_end, bs * ncs, plan_nb, plan_chunk, plan, s_plan);
     }
   }
+#ifdef OBB_SORT_TRACE
+  TSTAMP();
+  if (tid == 0 && (g == 0 || s_ticket == bs - 1)) printf("sortprep g %d ticket %d n %d: load %llu sort %llu write+seg %llu rec %llu plan %llu (x10 ns)\n", g, s_ticket, n, tt[1]-tt[0], tt[2]-tt[1], tt[3]-tt[2], tt[4]-tt[3], tt[5]-tt[4]);
+#endif
+#undef TSTAMP
 }
 
 // Output: the kept boxes of the image's segments merged into descending-score order (the order of the reference's single
