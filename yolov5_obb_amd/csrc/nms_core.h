@@ -1353,16 +1353,16 @@ __device__ __forceinline__ void block_scan2(long long va, long long vb, long lon
 
 struct PlanLds { long long a[16], b[16]; int first[1024], last[1024]; };
 
-// the planner proper: called by all 1024 threads of one workgroup (k_plan_teams, or the last workgroup of the fused
-// sort/prep kernel); seg_begin / seg_end must be visible to the caller
-__device__ __forceinline__ void plan_teams_block(const int* seg_begin, const int* seg_end, int nseg, int NB, int chunk, int4* plan,
-                                                 PlanLds& S) {
+// the planner proper: called by all 1024 threads of one workgroup (k_plan_teams, or the planner block of the fused
+// sort/prep kernel); seg_begin / seg_end -- or the segment sizes, when seg_size is given -- must be visible to the caller
+__device__ __forceinline__ void plan_teams_block(const int* seg_begin, const int* seg_end, const int* seg_size, int nseg, int NB, int chunk,
+                                                 int4* plan, PlanLds& S) {
   long long* s_a = S.a; long long* s_b = S.b;
   int* s_first = S.first; int* s_last = S.last;
   const int tid = threadIdx.x;
   const int per = (nseg + 1023) / 1024;
   const int g0 = tid * per, g1 = (g0 + per < nseg) ? g0 + per : nseg;
-  auto cost_of = [&](int g) -> long long { return plan_cost((long long)(seg_end[g] - seg_begin[g]), chunk); };
+  auto cost_of = [&](int g) -> long long { return plan_cost((long long)(seg_size ? seg_size[g] : seg_end[g] - seg_begin[g]), chunk); };
   // ---- totals
   long long myc = 0, myn = 0, pa, pb, total, nne;
   for (int g = g0; g < g1; g++) { const long long c = cost_of(g); myc += c; myn += c > 0 ? 1 : 0; }
@@ -1447,7 +1447,7 @@ __device__ __forceinline__ void plan_teams_block(const int* seg_begin, const int
 __global__ __launch_bounds__(1024) void k_plan_teams(const int* __restrict__ seg_begin, const int* __restrict__ seg_end, int nseg, int NB,
                                                      int chunk, int4* __restrict__ plan) {
   __shared__ PlanLds S;
-  plan_teams_block(seg_begin, seg_end, nseg, NB, chunk, plan, S);
+  plan_teams_block(seg_begin, seg_end, nullptr, nseg, NB, chunk, plan, S);
 }
 
 }  // namespace obb

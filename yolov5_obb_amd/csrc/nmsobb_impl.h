@@ -571,13 +571,25 @@ __global__ __launch_bounds__(1024) void k_sort_prep_lds(const float4* __restrict
                                                         int* sort_end, int* img_end, int* mode, int* grp_begin, int* grp_end,
                                                         int* __restrict__ seg_begin, int* __restrict__ seg_end, int* __restrict__ keep_cnt,
                                                         float4* __restrict__ rec, u64* __restrict__ alive, int* __restrict__ ticket,
-                                                        int plan_nb, int plan_chunk, int4* __restrict__ plan) {
+                                                        int plan_nb, int plan_chunk, int4* __restrict__ plan, int* __restrict__ seg_size) {
   extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
   __shared__ PlanLds s_plan;
-  __shared__ int s_ticket;
+  __shared__ int s_hist[256];
   unsigned long long* s_keys = reinterpret_cast<unsigned long long*>(s_raw);
   uint32_t* s_vals = reinterpret_cast<uint32_t*>(s_keys + kSortLdsMax);
   const int g = blockIdx.x, tid = threadIdx.x, T = 1024;
+  if (g == bs) {
+    // The planner block (launched only when there is a plan to make): the NMS launch is planned from the segment SIZES,
+    // which every image's workgroup knows after its first pass over the keys -- long before its sort is done.  This block
+    // waits for the bs size tables (the other workgroups never wait for anything, so it cannot hang however the blocks
+    // are scheduled) and plans while they sort: the 16 us of plan_teams_block used to be the tail of the last workgroup.
+    if (tid == 0) {
+      while (__hip_atomic_load(ticket, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < bs) __builtin_amdgcn_s_sleep(4);
+    }
+    __syncthreads();
+    plan_teams_block(nullptr, nullptr, seg_size, bs * ncs, plan_nb, plan_chunk, plan, s_plan);
+    return;
+  }
   long long c = cnt[g * kCntPad];
   const bool over_cap = c > cap_img;
   if (over_cap) c = cap_img;
@@ -592,6 +604,8 @@ __global__ __launch_bounds__(1024) void k_sort_prep_lds(const float4* __restrict
     grp_begin[g] = b0; grp_end[g] = b0;
   }
   for (int sgm = tid; sgm < ncs; sgm += T) { seg_begin[g * ncs + sgm] = b0; seg_end[g * ncs + sgm] = b0; keep_cnt[g * ncs + sgm] = 0; }
+  if (tid < 256) s_hist[tid] = 0;
+  __syncthreads();
 #ifdef OBB_SORT_TRACE
   unsigned long long tt[8]; int ti_ = 0;
 #define TSTAMP() do { __syncthreads(); tt[ti_++] = wall_clock64(); } while (0)
@@ -612,11 +626,18 @@ __global__ __launch_bounds__(1024) void k_sort_prep_lds(const float4* __restrict
         const unsigned long long cls = (unsigned long long)(int)cand[(size_t)(b0 + i) * 2 + 1].z;
         const unsigned long long anchor = tie < lim ? tie / nc : (unsigned long long)A + (tie - lim);
         k = (cls << 56) | (score << 24) | (anchor & 0xffffffull);
+        if (plan != nullptr) atomicAdd(&s_hist[(int)cls & 255], 1);
       }
     }
     s_keys[i] = k; s_vals[i] = v;
   }
   __syncthreads();
+  if (plan != nullptr) {                                       // the size table of this image, for the planner block
+    for (int sgm = tid; sgm < ncs; sgm += T) seg_size[g * ncs + sgm] = (m == 1) ? s_hist[sgm] : (sgm == 0 ? e : 0);
+    __threadfence();
+    __syncthreads();
+    if (tid == 0) __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  }
   TSTAMP();
   // ascending; keys are unique (the tie word), so the result is the one total order
   // elements per thread: as few as the 1024 threads allow (measured: 8 per thread with 256 busy threads moves four more
@@ -663,21 +684,9 @@ __global__ __launch_bounds__(1024) void k_sort_prep_lds(const float4* __restrict
   }
   TSTAMP();
   if (g == bs - 1 && tid < 8) alive[(((size_t)bs * cap_img) >> 6) + tid] = 0ull;   // the bitmap's guard words
-  // the workgroup that finishes last plans the NMS launch (k_plan_teams without a launch of its own): every workgroup
-  // publishes its segment table (release), the last ticket holder acquires and reads all of them
-  if (plan != nullptr) {
-    __threadfence();
-    __syncthreads();
-    if (tid == 0) s_ticket = atomicAdd(ticket, 1);
-    __syncthreads();
-    if (s_ticket == bs - 1) {
-      __threadfence();
-      plan_teams_block(seg_begin, seg_end, bs * ncs, plan_nb, plan_chunk, plan, s_plan);
-    }
-  }
 #ifdef OBB_SORT_TRACE
   TSTAMP();
-  if (tid == 0 && (g == 0 || s_ticket == bs - 1)) printf("sortprep g %d ticket %d n %d: load %llu sort %llu write+seg %llu rec %llu plan %llu (x10 ns)\n", g, s_ticket, n, tt[1]-tt[0], tt[2]-tt[1], tt[3]-tt[2], tt[4]-tt[3], tt[5]-tt[4]);
+  if (tid == 0 && g == 0) printf("sortprep g %d n %d: load %llu sort %llu write+seg %llu rec %llu (x10 ns)\n", g, n, tt[1]-tt[0], tt[2]-tt[1], tt[3]-tt[2], tt[4]-tt[3]);
 #endif
 #undef TSTAMP
 }
@@ -908,10 +917,11 @@ static int run_nms_obb(const void* pred, const void* objcol, int dtype, int64_t 
         return OBB_ERR_LAUNCH;
       attr_set = true;
     }
-    k_sort_prep_lds<<<(unsigned)bs, 1024, lds, st>>>(cv.cand, cv.keys_a, cv.vals_a, cv.keys_b, cv.vals_b, cv.cnt, cv.tiny, (int)bs, cap_img,
+    k_sort_prep_lds<<<(unsigned)bs + (plan_nb > 0 ? 1u : 0u), 1024, lds, st>>>(cv.cand, cv.keys_a, cv.vals_a, cv.keys_b, cv.vals_b, cv.cnt, cv.tiny, (int)bs, cap_img,
                                                    max_nms, class_ok, A, nc, ncs, agnostic ? 0.f : max_wh, cv.sort_begin, cv.sort_end,
                                                    cv.img_end, cv.mode, cv.grp_begin, cv.grp_end, nv.seg_begin, nv.seg_end, nv.keep_cnt,
-                                                   nv.rec, nv.alive, cv.ticket, plan_nb, plan_chunk, plan_nb > 0 ? nv.plan : nullptr);
+                                                   nv.rec, nv.alive, cv.ticket, plan_nb, plan_chunk, plan_nb > 0 ? nv.plan : nullptr,
+                                                   reinterpret_cast<int*>(cv.digit_base));   // (the class-bounds table of the other sort paths: free here)
   } else {
    {
     ProfScope ps(PROF_SEGSORT, st);
