@@ -1,4 +1,9 @@
-"""Development aid: run the configs[1] step on a traced build of the library (libobb_trace.so, built with -DOBB_..._TRACE)."""
+"""Development aid: run the configs[1] step on a traced build of the library.
+
+    cd yolov5_obb_amd/csrc && hipcc <CXXFLAGS of the Makefile> -DOBB_SORT_TRACE -c nms.hip -o /tmp/nms_trace.o && \
+        hipcc --offload-arch=gfx950 -shared -fPIC -o ../libobb_trace.so /tmp/nms_trace.o $(ls *.o | grep -v '^nms.o')
+
+OBB_SORT_TRACE makes workgroup 0 of k_sort_prep_lds print its phase times (load / sort / write+segments / records)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from yolov5_obb_amd import _lib
