@@ -703,17 +703,36 @@ __global__ __launch_bounds__(256) void k_gather_out(const float4* __restrict__ c
                                                     const int* __restrict__ mode, int ncs, long long max_det, float* __restrict__ out,
                                                     int64_t* __restrict__ out_count, const int* __restrict__ cnt, long long cap_img,
                                                     int64_t* __restrict__ status, const int* __restrict__ abort_flag, int packed) {
-  __shared__ int s_pre[257];
-  __shared__ long long s_rows[4];
+  __shared__ int s_pre[257], s_seg[256];
+  __shared__ long long s_rows[4], s_mx[4];
   __shared__ unsigned long long s_key[kMergeLds];
+  __shared__ uint32_t s_val[kMergeLds];
   const int g = blockIdx.x, tid = threadIdx.x;
+  // The kernel is a chain of dependent global reads (counts -> kept positions -> keys / slots -> candidate rows); everything
+  // that does not depend on an earlier read is requested up front: seven latencies became four.
   // kept per segment (clipped to max_det: a class contributes at most max_det rows to the first max_det overall)
   for (int c = tid; c < ncs; c += 256) {
     long long k = keep_cnt[g * ncs + c];
     if (max_det > 0 && k > max_det) k = max_det;
     s_pre[c + 1] = (int)k;
+    s_seg[c] = seg_begin[g * ncs + c];
   }
   if (tid == 0) s_pre[0] = 0;
+  // (packed) rows of the images before this one; (workgroup 0) the largest candidate count -- same round trip as above
+  long long mine = 0, mx = 0;
+  if (packed) {
+    for (int b2 = tid; b2 < g; b2 += 256) {
+      long long t = 0;
+      for (int c = 0; c < ncs; c++) { long long k = keep_cnt[b2 * ncs + c]; if (max_det > 0 && k > max_det) k = max_det; t += k; }
+      if (max_det > 0 && t > max_det) t = max_det;
+      mine += t;
+    }
+  }
+  if (g == 0)
+    for (int b2 = tid; b2 < (int)gridDim.x; b2 += 256) { const long long c = cnt[b2 * kCntPad]; if (c > mx) mx = c; }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) { mine += __shfl_xor(mine, d); const long long o = __shfl_xor(mx, d); if (o > mx) mx = o; }
+  if ((tid & 63) == 0) { s_rows[tid >> 6] = mine; s_mx[tid >> 6] = mx; }
   __syncthreads();
   if (tid == 0) for (int c = 0; c < ncs; c++) s_pre[c + 1] += s_pre[c];
   __syncthreads();
@@ -726,41 +745,19 @@ __global__ __launch_bounds__(256) void k_gather_out(const float4* __restrict__ c
   // status[0]: the largest candidate count if an image overflowed its slots (the caller retries), else 0; status[1]: the largest
   // candidate count (feedback for the caller's next call).  Plain stores by one workgroup -- out_count and status may be pinned
   // host memory (the host layer reads them without a device->host copy).
-  if (g == 0) {
-    long long mx = 0;
-    for (int b2 = tid; b2 < (int)gridDim.x; b2 += 256) { const long long c = cnt[b2 * kCntPad]; if (c > mx) mx = c; }
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) { const long long o = __shfl_xor(mx, d); if (o > mx) mx = o; }
-    if ((tid & 63) == 0) s_rows[tid >> 6] = mx;
-    __syncthreads();
-    if (tid == 0) {
-      for (int k = 1; k < 4; k++) if (s_rows[k] > mx) mx = s_rows[k];
-      status[0] = mx > cap_img ? mx : 0;
-      status[1] = mx;
-    }
-    __syncthreads();
+  if (g == 0 && tid == 0) {
+    long long m4 = s_mx[0];
+    for (int k = 1; k < 4; k++) if (s_mx[k] > m4) m4 = s_mx[k];
+    status[0] = m4 > cap_img ? m4 : 0;
+    status[1] = m4;
   }
   // first output row of the image: g * max_det, or (packed) the number of rows of the images before it
-  long long row0 = (long long)g * max_det;
-  if (packed) {
-    long long mine = 0;
-    for (int b2 = tid; b2 < g; b2 += 256) {
-      long long t = 0;
-      for (int c = 0; c < ncs; c++) { long long k = keep_cnt[b2 * ncs + c]; if (max_det > 0 && k > max_det) k = max_det; t += k; }
-      if (max_det > 0 && t > max_det) t = max_det;
-      mine += t;
-    }
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) mine += __shfl_xor(mine, d);
-    if ((tid & 63) == 0) s_rows[tid >> 6] = mine;
-    __syncthreads();
-    row0 = s_rows[0] + s_rows[1] + s_rows[2] + s_rows[3];
-  }
+  const long long row0 = packed ? s_rows[0] + s_rows[1] + s_rows[2] + s_rows[3] : (long long)g * max_det;
   const int md = mode[g];
   const bool single = md == 0;
   // merge key of entry e = (class c, index k): the mode-1 key rotated so that it orders by (score, anchor, class);
   // mode 2 keeps the single-list key (score, anchor*nc + class), which already is the global order
-  auto entry_pos = [&](int c, int k) -> uint32_t { return (uint32_t)keep[(size_t)seg_begin[g * ncs + c] + k]; };
+  auto entry_pos = [&](int c, int k) -> uint32_t { return (uint32_t)keep[(size_t)s_seg[c] + k]; };
   auto mkey_at = [&](uint32_t p) -> unsigned long long {
     const unsigned long long k = keys_sorted[p];
     return md == 1 ? ((k << 8) | (k >> 56)) : k;
@@ -770,7 +767,9 @@ __global__ __launch_bounds__(256) void k_gather_out(const float4* __restrict__ c
     for (int e = tid; e < total; e += 256) {
       int c = 0;
       while (s_pre[c + 1] <= e) c++;
-      s_key[e] = mkey_at(entry_pos(c, e - s_pre[c]));
+      const uint32_t p = entry_pos(c, e - s_pre[c]);
+      s_key[e] = mkey_at(p);
+      s_val[e] = vals_sorted[p];
     }
     __syncthreads();
   }
@@ -778,7 +777,8 @@ __global__ __launch_bounds__(256) void k_gather_out(const float4* __restrict__ c
     int c = 0;
     while (s_pre[c + 1] <= e) c++;
     const int k = e - s_pre[c];
-    const uint32_t p = entry_pos(c, k);
+    const bool staged = !single && in_lds;                      // key and slot of the entry are in LDS
+    const uint32_t p = staged ? 0u : entry_pos(c, k);
     long long rank = k;
     if (!single) {
       const unsigned long long mk = in_lds ? s_key[e] : mkey_at(p);
@@ -794,7 +794,7 @@ __global__ __launch_bounds__(256) void k_gather_out(const float4* __restrict__ c
       }
     }
     if (max_det > 0 && rank >= max_det) continue;
-    const size_t ci = (size_t)g * cap_img + vals_sorted[p];
+    const size_t ci = (size_t)g * cap_img + (staged ? s_val[e] : vals_sorted[p]);
     const float4 c0 = cand[ci * 2], c1 = cand[ci * 2 + 1];
     float* o = out + ((size_t)row0 + rank) * 7;
     o[0] = c0.x; o[1] = c0.y; o[2] = c0.z; o[3] = c0.w; o[4] = c1.x; o[5] = c1.y; o[6] = c1.z;
