@@ -1372,13 +1372,13 @@ __device__ __forceinline__ void plan_teams_block(const int* seg_begin, const int
     return;
   }
   const long long L = (total + NB - 1) / NB;
-  const long long big_from = 2 * L;
+  long long big_from = 2 * L;
   // ---- split of the grid: r workgroups for the small segments, NB - r for the teams of the big ones
   long long mybc = 0, mybn = 0, big_cost, n_big;
   for (int g = g0; g < g1; g++) { const long long c = cost_of(g); if (c >= big_from) { mybc += c; mybn++; } }
   long long pbc, pbn;
   block_scan2(mybc, mybn, s_a, s_b, pbc, pbn, big_cost, n_big);
-  const long long small_cost = total - big_cost, n_small = nne - n_big;
+  long long small_cost = total - big_cost, n_small = nne - n_big;
   long long r = 0;
   if (n_small > 0) {
     r = (small_cost + L - 1) / L;
@@ -1387,12 +1387,42 @@ __device__ __forceinline__ void plan_teams_block(const int* seg_begin, const int
     if (r > NB - n_big) r = NB - n_big;             // (n_big <= NB / 2: every big segment costs at least 2L)
   }
   // enough workgroups for everybody: no packing, every small segment gets its own workgroup (piece = its rank)
-  const bool one_each = n_small > 0 && n_small + (n_big > 0 ? (big_cost + L - 1) / L : 0) <= NB;
+  bool one_each = n_small > 0 && n_small + (n_big > 0 ? (big_cost + L - 1) / L : 0) <= NB;
+  // Spare workgroups.  With one workgroup per segment and none big, the launch lasts as long as its heaviest segment
+  // (the configs[1] step: 240 class segments, busiest workgroup 80 us, mean 49) while NB - nne workgroups idle.  The
+  // heaviest segments get a second workgroup each: "big" starts at the smallest cost that leaves at most NB - nne
+  // segments at or above it (and is at least 1.25 L: a team pays ~10 us of barriers).
+  long long forced_team = 0;
+  if (one_each && n_big == 0 && per == 1 && nne < NB) {
+    const long long spare = NB - nne;
+    const long long myc1 = g0 < g1 ? cost_of(g0) : 0;
+    __syncthreads();
+    s_first[tid] = (int)(myc1 > 0x7fffffffLL ? 0x7fffffffLL : myc1);
+    if (tid == 0) s_last[0] = 0x7fffffff;
+    __syncthreads();
+    if (myc1 >= L + L / 4 && myc1 >= 128) {
+      int at_or_above = 0;
+      for (int h = 0; h < nseg; h++) at_or_above += s_first[h] >= s_first[tid] ? 1 : 0;
+      if (at_or_above <= spare) atomicMin(&s_last[0], s_first[tid]);
+    }
+    __syncthreads();
+    const int thr_cost = s_last[0];
+    __syncthreads();
+    if (thr_cost != 0x7fffffff) {
+      big_from = thr_cost;
+      forced_team = 2;
+      mybc = (myc1 >= big_from) ? myc1 : 0; mybn = (myc1 >= big_from) ? 1 : 0;
+      block_scan2(mybc, mybn, s_a, s_b, pbc, pbn, big_cost, n_big);
+      small_cost = total - big_cost; n_small = nne - n_big;
+      one_each = n_small > 0;                        // n_small + 2 n_big = nne + n_big <= NB
+      r = n_small;
+    }
+  }
   if (one_each) r = n_small;
   const long long NBb = NB - r;
   const long long Lb = n_big > 0 ? (big_cost + NBb - 1) / NBb : 1;
   auto team_size = [&](long long c) -> long long {
-    long long t = c / Lb;
+    long long t = forced_team ? forced_team : c / Lb;
     const long long useful = (c + 63) / 64;          // more workgroups than ~tiles/8 only add barrier cost
     if (t > useful) t = useful;
     return t < 1 ? 1 : t;
