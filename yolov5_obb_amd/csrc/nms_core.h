@@ -1390,34 +1390,45 @@ __device__ __forceinline__ void plan_teams_block(const int* seg_begin, const int
   bool one_each = n_small > 0 && n_small + (n_big > 0 ? (big_cost + L - 1) / L : 0) <= NB;
   // Spare workgroups.  With one workgroup per segment and none big, the launch lasts as long as its heaviest segment
   // (the configs[1] step: 240 class segments, busiest workgroup 80 us, mean 49) while NB - nne workgroups idle.  The
-  // heaviest segments get a second workgroup each: "big" starts at the smallest cost that leaves at most NB - nne
-  // segments at or above it (and is at least 1.25 L: a team pays ~10 us of barriers).
+  // NB - nne heaviest segments whose cost is above the average (a team pays ~10 us of barriers) get a second workgroup
+  // each.  Costs are coarse (a function of the tile count), so "heaviest" is decided on the unique key cost * 1024 +
+  // (1023 - segment): `big` is then a per-segment property, not a cost threshold -- which is fine here, because with one
+  // segment per run no workgroup ever has to recognise somebody else's big segment (plan[kPlanInfoSlot] = "none").
   long long forced_team = 0;
-  if (one_each && n_big == 0 && per == 1 && nne < NB) {
+  bool spare_mode = false;
+  long long big_key = 0;
+  auto ekey = [&](int g, long long c) -> long long { return c * 1024 + (1023 - g); };
+  if (one_each && n_big == 0 && per == 1 && nne < NB && nseg <= 1024) {
     const long long spare = NB - nne;
     const long long myc1 = g0 < g1 ? cost_of(g0) : 0;
+    unsigned long long* s_min = reinterpret_cast<unsigned long long*>(s_last);
     __syncthreads();
     s_first[tid] = (int)(myc1 > 0x7fffffffLL ? 0x7fffffffLL : myc1);
-    if (tid == 0) s_last[0] = 0x7fffffff;
+    if (tid == 0) *s_min = ~0ull;
     __syncthreads();
-    if (myc1 >= L + L / 4 && myc1 >= 128) {
+    if (g0 < g1 && myc1 >= L + L / 16 && myc1 >= 128) {
+      const long long mine_k = ekey(g0, myc1);
       int at_or_above = 0;
-      for (int h = 0; h < nseg; h++) at_or_above += s_first[h] >= s_first[tid] ? 1 : 0;
-      if (at_or_above <= spare) atomicMin(&s_last[0], s_first[tid]);
+      for (int h = 0; h < nseg; h++) at_or_above += ekey(h, (long long)s_first[h]) >= mine_k ? 1 : 0;
+      if (at_or_above <= spare) atomicMin(s_min, (unsigned long long)mine_k);
     }
     __syncthreads();
-    const int thr_cost = s_last[0];
+    const unsigned long long kmin = *s_min;
     __syncthreads();
-    if (thr_cost != 0x7fffffff) {
-      big_from = thr_cost;
+    if (kmin != ~0ull) {
+      spare_mode = true;
+      big_key = (long long)kmin;
       forced_team = 2;
-      mybc = (myc1 >= big_from) ? myc1 : 0; mybn = (myc1 >= big_from) ? 1 : 0;
+      const bool mb = g0 < g1 && ekey(g0, myc1) >= big_key;
+      mybc = mb ? myc1 : 0; mybn = mb ? 1 : 0;
       block_scan2(mybc, mybn, s_a, s_b, pbc, pbn, big_cost, n_big);
       small_cost = total - big_cost; n_small = nne - n_big;
       one_each = n_small > 0;                        // n_small + 2 n_big = nne + n_big <= NB
       r = n_small;
+      big_from = 0x7fffffffLL;                       // what the workgroups are told: nobody skips by cost
     }
   }
+  auto is_big = [&](int g, long long c) -> bool { return spare_mode ? (c > 0 && ekey(g, c) >= big_key) : (c >= big_from); };
   if (one_each) r = n_small;
   const long long NBb = NB - r;
   const long long Lb = n_big > 0 ? (big_cost + NBb - 1) / NBb : 1;
@@ -1429,7 +1440,7 @@ __device__ __forceinline__ void plan_teams_block(const int* seg_begin, const int
   };
   // ---- teams of the big segments: workgroups r + [prefix of team sizes), team ids r + [prefix of count)
   long long myt = 0;
-  for (int g = g0; g < g1; g++) { const long long c = cost_of(g); if (c >= big_from) myt += team_size(c); }
+  for (int g = g0; g < g1; g++) { const long long c = cost_of(g); if (is_big(g, c)) myt += team_size(c); }
   long long pt, pcnt, used_big, dummy;
   block_scan2(myt, mybn, s_a, s_b, pt, pcnt, used_big, dummy);
   if (r + used_big > NB) {                           // (cannot happen with the bounds above; the static teams are always valid)
@@ -1440,7 +1451,7 @@ __device__ __forceinline__ void plan_teams_block(const int* seg_begin, const int
     long long w0 = r + pt, team = r + pcnt;
     for (int g = g0; g < g1; g++) {
       const long long c = cost_of(g);
-      if (c >= big_from) {
+      if (is_big(g, c)) {
         const long long t = team_size(c);
         for (int i = 0; i < (int)t; i++) plan[w0 + i] = make_int4(g, (int)team, i, (int)t);
         w0 += t; team++;
@@ -1450,7 +1461,7 @@ __device__ __forceinline__ void plan_teams_block(const int* seg_begin, const int
   for (int w = (int)(r + used_big) + tid; w < NB; w += 1024) plan[w] = make_int4(-1, 0, 0, 0);
   // ---- runs of small segments: piece = running small cost / Ls
   long long mysc = 0, mysn = 0, psc, psn, tsc, tsn;
-  for (int g = g0; g < g1; g++) { const long long c = cost_of(g); if (c > 0 && c < big_from) { mysc += c; mysn++; } }
+  for (int g = g0; g < g1; g++) { const long long c = cost_of(g); if (c > 0 && !is_big(g, c)) { mysc += c; mysn++; } }
   block_scan2(mysc, mysn, s_a, s_b, psc, psn, tsc, tsn);
   const long long Ls = r > 0 ? (small_cost + r - 1) / r : 1;
   s_first[tid] = 0x7fffffff; s_last[tid] = -1;
@@ -1459,7 +1470,7 @@ __device__ __forceinline__ void plan_teams_block(const int* seg_begin, const int
     long long run = psc, rank = psn;
     for (int g = g0; g < g1; g++) {
       const long long c = cost_of(g);
-      if (c > 0 && c < big_from) {
+      if (c > 0 && !is_big(g, c)) {
         const int piece = one_each ? (int)rank : (int)(run / Ls);   // < r: run < small_cost <= r * Ls
         atomicMin(&s_first[piece], g); atomicMax(&s_last[piece], g);
         run += c; rank++;
