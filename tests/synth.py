@@ -172,18 +172,24 @@ def s_head(bs, nc, sizes=(128, 64, 32), seed=0, n_obj=120, device="cpu", dtype=t
                         if (a + dy + dx) % 3 == 0:
                             continue                                                           # two of the three anchors
                         m = sel.numel()
+                        # two objects on one cell: the later one wins, decided here (an index assignment with duplicate
+                        # indices has no defined order)
+                        lin, ar = gy * n + gx, torch.arange(m, device=device)
+                        win = torch.full((n * n,), -1, dtype=torch.long, device=device).scatter_reduce(0, lin, ar, "amax")
+                        own = win[lin] == ar
+                        gyo, gxo = gy[own], gx[own]
                         t = torch.stack((c[:, 0] - gx, c[:, 1] - gy), -1) + 0.02 * N(m, 2)     # (sig*2 - 0.5) must give t
                         sxy = ((t + 0.5) / 2).clamp(0.02, 0.98)
                         swh = (oscale[b, sel] * (1 + 0.05 * N(m, 2))).clamp(0.05, 3.9).sqrt() / 2
-                        x[b, a, gy, gx, 0:2] = torch.logit(sxy)
-                        x[b, a, gy, gx, 2:4] = torch.logit(swh.clamp(0.02, 0.98))
-                        x[b, a, gy, gx, 4] = N(m) * 1.5 + 1.0
+                        x[b, a, gyo, gxo, 0:2] = torch.logit(sxy)[own]
+                        x[b, a, gyo, gxo, 2:4] = torch.logit(swh.clamp(0.02, 0.98))[own]
+                        x[b, a, gyo, gxo, 4] = (N(m) * 1.5 + 1.0)[own]
                         cl = N(m, nc) - 4.0
                         cl[torch.arange(m, device=device), ocls[b, sel]] = N(m) + 2.0
-                        x[b, a, gy, gx, 5:5 + nc] = cl
+                        x[b, a, gyo, gxo, 5:5 + nc] = cl[own]
                         d = (bins[None, :] - obin[b, sel][:, None]).abs()
                         d = torch.minimum(d, 180 - d).float()
-                        x[b, a, gy, gx, 5 + nc:] = 5.0 * torch.exp(-d * d / 8.0) - 4.0 + 0.5 * N(m, 180)
+                        x[b, a, gyo, gxo, 5 + nc:] = (5.0 * torch.exp(-d * d / 8.0) - 4.0 + 0.5 * N(m, 180))[own]
         out.append(x.permute(0, 1, 4, 2, 3).contiguous().view(bs, na * no, n, n).to(dtype))
     return out
 
