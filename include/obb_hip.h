@@ -172,6 +172,8 @@ int64_t obb_task1_format_rows(const char* text_host, const int32_t* name_off_hos
  *               out_packed != 0: the rows of image b start right behind those of image b-1 (row sum(out_count[0..b-1]))
  *               instead of at row b*max_det -- the same buffer size is required, one split instead of bs slices on the host
  *               status [2] int64: [0] overflow count (see cap_img), [1] largest candidate count of any image
+ *               out_count and status are written with plain 8-byte stores by the last kernel of the call: they may live in
+ *               device memory or in pinned host memory (hipHostMalloc) that the caller polls instead of copying back
  * Score ties are ordered by ascending (anchor*nc + class): deterministic, where the reference inherits the order
  * of torch's unstable sort.
  */
