@@ -12,6 +12,10 @@ not exist on this path.
 N > 1: launched by torch.distributed.run, one rank per GPU; images shard across ranks (pure data parallel, no
 collective on the data path; RCCL is only used for the timing barrier / max-reduce).  value = whole-job images/s.
 
+The timed K steps run with the library's stage events on (`obb_profile_enable`: ten HIP event records per step on the
+kernels' stream, what `roofline` / `kernels` / `stages_ms` are computed from); `ms_per_step_without_stage_events` is the same
+K steps once more without them.
+
 The JSON line also carries
   roofline      BASELINE.json's target figure: rotated NMS at N = 100k candidates, SURVEY.md section 8d's algorithmic bytes
                 bytes_nms(N) = 24N + 8N + 8N*ceil(N/64) over the time of the WHOLE call (sort + prep + the persistent
