@@ -138,7 +138,8 @@ int obb_eval_best_gt_f64(const double* dets8, const int32_t* det_img, int64_t nd
  * first appearance and the first line of every group.  Returns the number of lines, or OBB_ERR_BAD_ARG for anything that
  * is not the plain layout (the Python layer then parses line by line like the reference).
  * obb_task1_format_rows writes `<orig> <round(score, 2)> <round(c, 1)> x 8\n` for the given lines (:218-233) and returns
- * the number of bytes (OBB_ERR_WORKSPACE: out_cap too small; 200 bytes per row + the name suffice for |values| < 1e15).
+ * the number of bytes (OBB_ERR_WORKSPACE: out_cap too small; 200 bytes per row + the name suffice for |values| < 1e15;
+ * the text equals Python's str(round(..)) for |confidence| < 1e13 and |coordinates| < 1e14, the domain the Python layer checks).
  */
 int64_t obb_task1_parse_tiles(const char* text_host, int64_t len, int64_t max_lines, double* dets9_host, int32_t* name_off_host,
                               int32_t* name_len_host, int32_t* group_host, int32_t* group_first_host, int64_t* n_groups_host);

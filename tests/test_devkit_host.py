@@ -102,3 +102,37 @@ def test_native_reader_never_disagrees_with_the_line_by_line_parse(tmp_path):
     seen = {True: 0, False: 0}
     check()
     assert seen[True] >= 20 and seen[False] >= 20, seen     # both outcomes were exercised
+
+
+def test_fast_paths_of_the_number_conversions_agree_with_python(tmp_path):
+    """csrc/textio.hip converts the usual numbers without strtod / snprintf (exact integer arithmetic): 400k values across all
+    magnitudes, binary fractions that are exact rounding ties, signed zeros, subnormals, values next to the fast path's limits
+    -- against Python's own round()/str() and float()."""
+    from yolov5_obb_amd.DOTA_devkit import ResultMerge_multi_process as RM
+    rng = np.random.RandomState(7)
+    # (str(round(v, d)) is the d-decimal string as long as that string has at most 15 significant digits: |v| < 10^(15-d))
+    mags = 10.0 ** rng.uniform(-14, 12.99, 200000) * rng.choice([-1.0, 1.0], 200000)
+    ties = (rng.randint(-4000000, 4000000, 150000) + rng.choice([0.5, 0.25, 0.75, 0.125, 0.375, 0.625, 0.875, 0.0625, 0.03125], 150000)) / \
+        rng.choice([1.0, 2.0, 4.0, 8.0, 16.0, 64.0, 1024.0], 150000)
+    special = np.array([0.0, -0.0, 5e-324, -5e-324, 2.2250738585072014e-308, 0.05, 0.15, 0.25, 0.35, 0.45, 0.005, 0.015, 0.025, 0.995,
+                        0.9999999, 9.95, 99.95, 999.95, 9999999999999.994, 9999999999999.996, 8796093022207.995, 4398046511103.125,
+                        0.049999999999999996, 0.05000000000000001, 1e-3, 4.35, 2.675, 1.005, 1234567890123.455, 0.994999999999999996])
+    vals = np.concatenate([mags, ties, special, -special])
+    vals = np.concatenate([vals, np.zeros((-len(vals)) % 9)]).reshape(-1, 9)
+    got = RM.format_result_rows(['n'] * len(vals), vals)
+    assert got == [RM.format_result_line('n', r.tolist()) for r in vals]
+    # ---- decimal -> double: literals of every shape the fast path takes or must decline
+    lits = [f"{v:.{d}f}" for v, d in zip(10.0 ** rng.uniform(-6, 13, 60000) * rng.choice([-1.0, 1.0], 60000), rng.randint(0, 8, 60000))]
+    lits += [repr(float(v)) for v in 10.0 ** rng.uniform(-5, 6, 20000)]                       # 17 significant digits: the general path
+    lits += [f"{rng.randint(0, 10 ** 15)}" for _ in range(5000)] + [f"0.{rng.randint(0, 10 ** 15):022d}" for _ in range(5000)]
+    lits += ["999999999999999", "1000000000000000", "0.0000000000000000000001", "0.00000000000000000000001", "-0.0", "+0", "007.50", ".5",
+             "5.", "123456789012345.6", "12345678901234.56", "9007199254740993", "0.1", "0.2", "0.3", "179769313486231570000", "1e22", "1e23",
+             "4.9e-324", "8.5", "-8.25", "000000000000000000001", "100000000000000000000.5"]
+    lits = [x for x in lits if len(x) <= 60]
+    rows = [lits[i:i + 9] for i in range(0, len(lits) - 8, 9)]
+    f = tmp_path / "Task1_x.txt"
+    f.write_text("\n".join("P0__1__0___0 " + " ".join(r) for r in rows) + "\n")
+    t = RM.parse_result_table(str(f))
+    assert t is not None and len(t.dets) == len(rows)
+    want = np.array([[(float(x) + 0.0) / 1.0 for x in r[1:]] + [float(r[0])] for r in rows])   # poly2origpoly with x = y = 0, rate 1
+    assert np.array_equal(t.dets.view(np.uint64), want.view(np.uint64))

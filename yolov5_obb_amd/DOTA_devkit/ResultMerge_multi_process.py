@@ -181,7 +181,9 @@ def mergesingle(dstpath, nms, fullname):
     name = os.path.basename(os.path.splitext(fullname)[0])
     dstname = os.path.join(dstpath, name + '.txt')
     table = parse_result_table(fullname) if nms is py_cpu_nms_poly_fast else None
-    if table is not None and np.isfinite(table.dets).all() and np.abs(table.dets).max() < 1e15:
+    # (str(round(v, d)) is the d-decimal string of the native writer while that string has <= 15 significant digits)
+    if table is not None and np.isfinite(table.dets).all() and np.abs(table.dets[:, :8]).max(initial=0.0) < 1e14 \
+            and np.abs(table.dets[:, 8]).max(initial=0.0) < 1e13:
         codes, dets = table.codes, table.dets
         rows = np.argsort(codes, kind='stable')          # lines of one source image together, file order inside
         bounds = np.searchsorted(codes[rows], np.arange(len(table.names) + 1))

@@ -2,7 +2,8 @@
 // full-image merge, restating what DOTA_devkit/ResultMerge_multi_process.py:186-233 does per line with str.split, two
 // regular expressions, float() and round()/str() -- in one pass over the file instead of ~20 Python calls per line
 // (the merge of a 25k-line class file spent 130 of its 134 ms there).  strtod is correctly rounded like Python's float(),
-// printf's %.1f / %.2f are the correctly rounded decimals Python's round() picks.  Anything that is not the plain layout
+// printf's %.1f / %.2f are the correctly rounded decimals Python's round() picks; both have an exact fast path for the numbers
+// such files hold (fast_decimal, fast_fixed), with strtod / snprintf behind it.  Anything that is not the plain layout
 // (10 single-space separated fields, tile name `<orig>__<rate>__<x>___<y>`, plain decimal numbers) makes the reader return
 // OBB_ERR_BAD_ARG and the Python layer takes its line-by-line path, which behaves like the reference on such input.
 #include <stdint.h>
@@ -10,6 +11,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <string>
+#include <string_view>
 #include <unordered_map>
 #include "obb_hip.h"
 
@@ -17,6 +19,67 @@ namespace {
 
 inline bool is_space(char c) { return c == ' ' || c == '\t' || c == '\r' || c == '\n' || c == '\v' || c == '\f'; }
 inline bool is_digit(char c) { return c >= '0' && c <= '9'; }
+
+// Exact fast path of the decimal -> double conversion (Clinger): a literal without exponent whose digits, read as one
+// integer, stay below 2^53 and whose fraction has at most 22 digits is integer / 10^k with BOTH operands exactly
+// representable, so the one IEEE division is the correctly rounded result -- the value strtod and Python's float() return.
+// (Every number of a Task1 file is of this kind; strtod took 60 % of the reader's time.)
+const double kPow10[23] = {1e0, 1e1, 1e2, 1e3, 1e4, 1e5, 1e6, 1e7, 1e8, 1e9, 1e10, 1e11, 1e12, 1e13, 1e14, 1e15, 1e16, 1e17, 1e18, 1e19,
+                           1e20, 1e21, 1e22};
+bool fast_decimal(const char* b, const char* e, double* out) {
+  const char* p = b;
+  bool neg = false;
+  if (*p == '+' || *p == '-') { neg = *p == '-'; p++; }
+  unsigned long long m = 0;
+  int sig = 0, frac = 0;
+  bool dot = false;
+  for (; p < e; p++) {
+    const char c = *p;
+    if (c == '.') { if (dot) return false; dot = true; continue; }
+    if (!is_digit(c)) return false;                       // an exponent: the general path
+    if (m != 0 || c != '0') { if (++sig > 15) return false; }
+    m = m * 10 + (unsigned long long)(c - '0');           // < 10^15 < 2^53
+    if (dot && ++frac > 22) return false;
+  }
+  const double v = (double)m / kPow10[frac];
+  *out = neg ? -v : v;
+  return true;
+}
+
+// Exact fast path of printf("%.<D>f") for D = 1, 2 and finite |v| < 1e15: v = m * 2^e exactly, so round-half-even of
+// v * 10^D is integer arithmetic on m * 10^D (below 2^60) -- the digits glibc's correctly rounded printf and Python's
+// round() produce.  Returns the number of characters, 0 when the value is outside the fast path.
+int fast_fixed(double v, int D, char* out) {
+  unsigned long long bits;
+  memcpy(&bits, &v, 8);
+  const bool neg = (bits >> 63) != 0;
+  const int ex = (int)((bits >> 52) & 0x7ff);
+  unsigned long long m = bits & ((1ull << 52) - 1);
+  if (ex == 0x7ff) return 0;
+  int e2;
+  if (ex == 0) e2 = -1074; else { m |= 1ull << 52; e2 = ex - 1075; }
+  if (e2 > -3) return 0;                                 // |v| >= 2^50 ~ 1.1e15: the general path
+  const unsigned long long scale = D == 1 ? 10ull : 100ull;
+  const unsigned long long P = m * scale;                // < 2^53 * 100 < 2^60
+  const int s = -e2;
+  unsigned long long q = 0;
+  if (s < 61) {
+    q = P >> s;
+    const unsigned long long rem = P & ((1ull << s) - 1), half = 1ull << (s - 1);
+    if (rem > half || (rem == half && (q & 1ull))) q++;
+  }                                                      // (s >= 61: P < 2^60 <= half, the value rounds to zero)
+  unsigned long long ip = q / scale, fp = q % scale;
+  char tmp[24];
+  int n = 0;
+  do { tmp[n++] = (char)('0' + ip % 10); ip /= 10; } while (ip);
+  int w = 0;
+  if (neg) out[w++] = '-';
+  while (n) out[w++] = tmp[--n];
+  out[w++] = '.';
+  if (D == 2) out[w++] = (char)('0' + fp / 10);
+  out[w++] = (char)('0' + fp % 10);
+  return w;
+}
 
 // plain decimal literal (what float() and strtod agree on without exception): [+-] digits [. digits] [e[+-]digits]
 bool parse_double(const char* b, const char* e, double* out) {
@@ -35,6 +98,7 @@ bool parse_double(const char* b, const char* e, double* out) {
     if (ne == 0) return false;
   }
   if (p != e) return false;
+  if (fast_decimal(b, e, out)) return true;
   char buf[64];
   memcpy(buf, b, (size_t)(e - b));
   buf[e - b] = 0;
@@ -58,7 +122,9 @@ extern "C" {
 int64_t obb_task1_parse_tiles(const char* text, int64_t len, int64_t max_lines, double* dets9, int32_t* name_off, int32_t* name_len,
                               int32_t* group, int32_t* group_first, int64_t* n_groups) {
   if (!text || len < 0 || max_lines < 0 || !dets9 || !name_off || !name_len || !group || !group_first || !n_groups) return OBB_ERR_BAD_ARG;
-  std::unordered_map<std::string, int32_t> ids;
+  std::unordered_map<std::string_view, int32_t> ids;          // keys point into `text`: no copies
+  std::string_view prev_name;
+  int32_t prev_id = -1;
   int64_t n = 0;
   const char* p = text;
   const char* end = text + len;
@@ -137,16 +203,21 @@ int64_t obb_task1_parse_tiles(const char* text, int64_t len, int64_t max_lines, 
     }
     name_off[n] = (int32_t)(s - text);
     name_len[n] = (int32_t)(us - s);
-    auto ins = ids.emplace(std::string(s, (size_t)(us - s)), (int32_t)ids.size());
-    if (ins.second) group_first[ins.first->second] = (int32_t)n;
-    group[n] = ins.first->second;
+    const std::string_view nm(s, (size_t)(us - s));
+    if (prev_id < 0 || nm != prev_name) {                  // (the tiles of one source image usually follow each other)
+      auto ins = ids.emplace(nm, (int32_t)ids.size());
+      if (ins.second) group_first[ins.first->second] = (int32_t)n;
+      prev_name = nm; prev_id = ins.first->second;
+    }
+    group[n] = prev_id;
     n++;
   }
   *n_groups = (int64_t)ids.size();
   return n;
 }
 
-// "<name> <conf> <c1> .. <c8>\n" per row: str(round(conf, 2)) and str(round(c, 1)) of :218-233 for |values| < 1e15
+// "<name> <conf> <c1> .. <c8>\n" per row: str(round(conf, 2)) and str(round(c, 1)) of :218-233 for |conf| < 1e13, |c| < 1e14
+// (while the fixed-point string has at most 15 significant digits it IS the shortest repr of the rounded double)
 int64_t obb_task1_format_rows(const char* text, const int32_t* name_off, const int32_t* name_len, const double* dets9, const int64_t* rows,
                               int64_t n_rows, char* out, int64_t out_cap) {
   if (!text || !name_off || !name_len || !dets9 || (n_rows > 0 && !rows) || !out || out_cap < 0) return OBB_ERR_BAD_ARG;
@@ -160,14 +231,16 @@ int64_t obb_task1_format_rows(const char* text, const int32_t* name_off, const i
     memcpy(out + w, text + name_off[r], (size_t)nl);
     w += nl;
     out[w++] = ' ';
-    int k = snprintf(num, sizeof num, "%.2f", d[8]);
+    int k = fast_fixed(d[8], 2, num);
+    if (k == 0) k = snprintf(num, sizeof num, "%.2f", d[8]);
     if (k <= 0 || k >= (int)sizeof num) return OBB_ERR_BAD_ARG;
     if (num[k - 1] == '0') k--;                          // '0.50' -> '0.5', '1.00' -> '1.0' (one decimal always stays)
     if (w + k + 1 > out_cap) return OBB_ERR_WORKSPACE;
     memcpy(out + w, num, (size_t)k);
     w += k;
     for (int c = 0; c < 8; c++) {
-      k = snprintf(num, sizeof num, "%.1f", d[c]);
+      k = fast_fixed(d[c], 1, num);
+      if (k == 0) k = snprintf(num, sizeof num, "%.1f", d[c]);
       if (k <= 0 || k >= (int)sizeof num) return OBB_ERR_BAD_ARG;
       if (w + k + 2 > out_cap) return OBB_ERR_WORKSPACE;
       out[w++] = ' ';
