@@ -143,6 +143,14 @@ int obb_eval_best_gt_f64(const double* dets8, const int32_t* det_img, int64_t nd
  */
 int64_t obb_task1_parse_tiles(const char* text_host, int64_t len, int64_t max_lines, double* dets9_host, int32_t* name_off_host,
                               int32_t* name_len_host, int32_t* group_host, int32_t* group_first_host, int64_t* n_groups_host);
+/* The two readers of the Task-1 evaluation (dota_evaluation_task1.py): detections `image score x1 y1 .. x4 y4` (:152-160)
+ * -> conf[line], bb8[line][8], position of the image id; ground truth `x1 .. y4 name [difficult]` (:21-53; lines with fewer
+ * than 9 fields skipped, difficult = 0 when absent) -> bbox8, position of the class name, the flag.  Same contract as
+ * obb_task1_parse_tiles: the number of records, or OBB_ERR_BAD_ARG for a buffer that is not the plain layout. */
+int64_t obb_task1_parse_dets(const char* text_host, int64_t len, int64_t max_lines, double* conf_host, double* bb8_host,
+                             int32_t* name_off_host, int32_t* name_len_host);
+int64_t obb_task1_parse_gt(const char* text_host, int64_t len, int64_t max_lines, double* bbox8_host, int32_t* name_off_host,
+                           int32_t* name_len_host, int32_t* difficult_host);
 int64_t obb_task1_format_rows(const char* text_host, const int32_t* name_off_host, const int32_t* name_len_host,
                               const double* dets9_host, const int64_t* rows_host, int64_t n_rows, char* out_host, int64_t out_cap);
 

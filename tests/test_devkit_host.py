@@ -86,7 +86,7 @@ def test_native_reader_never_disagrees_with_the_line_by_line_parse(tmp_path):
                      st.sampled_from([("", ""), (" ", ""), ("", " \r"), ("\t", "  ")]))
     f = tmp_path / "t.txt"
 
-    @settings(max_examples=600, deadline=None)
+    @settings(max_examples=1500, deadline=None)
     @given(st.lists(line, min_size=1, max_size=3), st.booleans())
     def check(lines, final_newline):
         f.write_bytes(("\n".join(lines) + ("\n" if final_newline else "")).encode())
@@ -101,7 +101,7 @@ def test_native_reader_never_disagrees_with_the_line_by_line_parse(tmp_path):
             assert a.shape == b.shape and np.array_equal(a.view(np.uint64), b.view(np.uint64)), (lines, nm)
     seen = {True: 0, False: 0}
     check()
-    assert seen[True] >= 20 and seen[False] >= 20, seen     # both outcomes were exercised
+    assert seen[True] >= 10 and seen[False] >= 20, seen     # both outcomes were exercised (about 3 % of the files are accepted)
 
 
 def test_fast_paths_of_the_number_conversions_agree_with_python(tmp_path):
@@ -136,3 +136,89 @@ def test_fast_paths_of_the_number_conversions_agree_with_python(tmp_path):
     assert t is not None and len(t.dets) == len(rows)
     want = np.array([[(float(x) + 0.0) / 1.0 for x in r[1:]] + [float(r[0])] for r in rows])   # poly2origpoly with x = y = 0, rate 1
     assert np.array_equal(t.dets.view(np.uint64), want.view(np.uint64))
+
+
+def _gt_arrays_from_records(EV, annopath, imagenames, classname):
+    gts, gt_off, difficult = [], [0], []
+    for imagename in imagenames:
+        objs = [o for o in EV.parse_gt(annopath.format(imagename)) if o['name'] == classname]
+        gts.extend(o['bbox'] for o in objs)
+        difficult.extend(bool(o['difficult']) for o in objs)
+        gt_off.append(len(gts))
+    return np.array(gts, dtype=np.float64).reshape(-1, 8), np.array(difficult, dtype=np.bool_), np.array(gt_off, dtype=np.int64)
+
+
+def test_native_ground_truth_reader_equals_parse_gt(tmp_path):
+    from yolov5_obb_amd.DOTA_devkit import dota_evaluation_task1 as EV
+    gt, det = gg.eval_inputs(25, 20, 6)
+    detpath, annopath, imagesetfile = gg.eval_write(str(tmp_path), gt, det)
+    names = [x.strip() for x in open(imagesetfile)]
+    # odd but legal files: short lines and blank lines are skipped, CRLF, no difficult flag, names in another script, a class
+    # that is a prefix of another one, padding, a file without records
+    (tmp_path / "odd").mkdir()
+    odd = str(tmp_path / "odd" / "{:s}.txt")
+    files = {
+        "a": "imagesource:GoogleEarth\ngsd:0.1\n1 2 3 4 5 6 7 8 plane 0\n1.5 2.5 3 4 5 6 7 8 plane 1\n\n9 8 7 6 5 4 3 2 planes 0\n",
+        "b": "1 2 3 4 5 6 7 8 plane\r\n  10 20 30 40 50 60 70 80 plane 2  \r\n1 2 3 4 5 6 7 8 船 0\r\n",
+        "c": "",
+        "d": "0.1 0.2 0.3 0.4 0.5 0.6 0.7 0.8 plane 0",
+        "e": "1 2 3 4 5 6 7 8 ship 1\n1e2 2E1 +3 .4 5. 006 7 8 plane 0\n",
+    }
+    for k, v in files.items():
+        with open(odd.format(k), "w", newline="") as f:
+            f.write(v)
+    for ap, nm, classes in ((annopath, names, ("plane", "ship", "nothing")), (odd, list(files) + ["a"], ("plane", "planes", "船", "ship"))):
+        for cls in classes:
+            got = EV.load_gt(ap, nm, cls)
+            assert got is not None
+            want = _gt_arrays_from_records(EV, ap, nm, cls)
+            assert np.array_equal(got[0].view(np.uint64), want[0].view(np.uint64)) and np.array_equal(got[1], want[1]) and np.array_equal(got[2], want[2])
+    assert len(EV.load_gt(odd, list(files), "plane")[0]) == 6
+    # declined (the record-by-record path then behaves like the reference, including its exceptions)
+    for bad in ("1 2 3 4 5 6 7 8 plane 0 extra\n", "1 2 3 4 5 6 7 x plane 0\n", "1 2 3 4 5 6 7 8  plane 0\n", "1 2 3 4 5 6 7 8 plane 1_0\n",
+                "1 2 3 4 5 6 7 8 plane +1\n", "1 2 3 4 5 6 7 8 plane 0\rnext line\n", "1 2 3 4 5 6 7 8 plane nan\n", "\x1c1 2 3 4 5 6 7 8 plane 0\n",
+                "1 2 3 4 5 6 7 8 plane 0 \n", "1 2 3 4 5 6 7 8 plane 0　\n"):
+        with open(odd.format("z"), "w", newline="") as f:
+            f.write(bad)
+        assert EV.load_gt(odd, ["a", "z"], "plane") is None, bad
+
+
+def test_native_detection_reader_declines_what_it_should(tmp_path):
+    from yolov5_obb_amd.DOTA_devkit import dota_evaluation_task1 as EV
+    f = tmp_path / "Task1_plane.txt"
+    good = "P0001 0.5 1 2 3 4 5 6 7 8"
+    f.write_text(good + "\n  图片__1 1e-3 1.5 2.5 3 4 5 6 7 8  \r\n" + good)
+    ids, conf, bb = EV._read_detections_native(str(f))
+    assert ids == ["P0001", "图片__1", "P0001"] and conf.tolist() == [0.5, 0.001, 0.5] and bb[1].tolist() == [1.5, 2.5, 3, 4, 5, 6, 7, 8]
+    for bad in (good + " 9", good[:-2], good.replace(" 0.5", "  0.5"), good.replace("0.5", "nan"), good.replace("0.5", "1_0"), "",
+                good + "\rP2 0.5 1 2 3 4 5 6 7 8", "\x1d" + good, good + " "):
+        f.write_text(good + "\n" + bad + "\n", newline="")
+        assert EV._read_detections_native(str(f)) is None, bad
+
+
+def test_voc_eval_host_logic_with_a_cpu_stand_in_for_the_device_call(tmp_path, monkeypatch, oracle_lib):
+    """voc_eval end to end on the CPU: the device call (best_gt) is replaced by the oracle's per-detection routine, everything
+    around it -- the native readers, the index arithmetic, the TP/FP pass, AP -- is the shipped code.  Against the restated
+    reference evaluation (oracle/pyref.py) on the same files."""
+    from oracle import pyref
+    from yolov5_obb_amd.DOTA_devkit import dota_evaluation_task1 as EV
+    gt, det = gg.eval_inputs(30, 25, 5)
+    detpath, annopath, imagesetfile = gg.eval_write(str(tmp_path), gt, det)
+
+    def best_gt_cpu(dets8, det_img, gts8, gt_off):
+        ov = np.empty(len(dets8)); jm = np.empty(len(dets8), dtype=np.int32)
+        for d in range(len(dets8)):
+            g = gts8[gt_off[det_img[d]]:gt_off[det_img[d] + 1]]
+            o, j = pyref.task1_best_gt(np.asarray(dets8[d], dtype=float), np.asarray(g, dtype=float))
+            ov[d], jm[d] = o, (-1 if j is None else j)
+        return ov, jm
+    monkeypatch.setattr(EV, "best_gt", best_gt_cpu)
+    names = [x.strip() for x in open(imagesetfile)]
+    parsed = {k: EV.parse_gt(annopath.format(k)) for k in names}
+    for cls in ("plane", "ship"):
+        if cls not in det:
+            continue
+        for use07 in (True, False):
+            rec, prec, ap = EV.voc_eval(detpath, annopath, imagesetfile, cls, 0.5, use07)
+            r2, p2, a2 = pyref.task1_voc_eval(parsed, names, det[cls], cls, 0.5, use07)
+            assert np.array_equal(rec, r2) and np.array_equal(prec, p2) and ap == a2

@@ -50,9 +50,82 @@ def voc_ap(rec, prec, use_07_metric=False):
     return np.sum((mrec[i + 1] - mrec[i]) * mpre[i + 1])
 
 
+def _names(text, off, length):
+    """str of text[off[i] : off[i] + length[i]] for every i (None: not UTF-8, the caller takes the path that raises)."""
+    try:
+        if text.isascii():
+            t = text.decode('ascii')
+            return [t[o:o + l] for o, l in zip(off.tolist(), length.tolist())]
+        return [text[o:o + l].decode() for o, l in zip(off.tolist(), length.tolist())]
+    except UnicodeDecodeError:
+        return None
+
+
+def _read_detections_native(detfile):
+    """obb_task1_parse_dets (csrc/textio.hip): one pass over the file, exact decimal -> double; None when declined."""
+    with open(detfile, 'rb') as f:
+        text = f.read()
+    cap = text.count(b'\n') + 1
+    conf = np.empty(cap, dtype=np.float64)
+    bb = np.empty((cap, 8), dtype=np.float64)
+    off = np.empty(cap, dtype=np.int32)
+    ln = np.empty(cap, dtype=np.int32)
+    n = _lib.lib().obb_task1_parse_dets(text, len(text), cap, conf.ctypes.data, bb.ctypes.data, off.ctypes.data, ln.ctypes.data)
+    if n <= 0:
+        return None
+    ids = _names(text, off[:n], ln[:n])
+    if ids is None:
+        return None
+    return ids, conf[:n].copy(), bb[:n].copy()
+
+
+def load_gt(annopath, imagenames, classname):
+    """The ground truth of one class over the listed images, as arrays: (gts (k, 8) float64, difficult (k,) bool, gt_off
+    (len(imagenames) + 1,) int64 -- the records of image i are gts[gt_off[i]:gt_off[i + 1]]), what voc_eval builds from
+    parse_gt's records (:131-149).  One native pass per file (obb_task1_parse_gt); None when any file is not the plain
+    layout (voc_eval then goes through parse_gt, which behaves like the reference on such input)."""
+    texts, cap = [], 0
+    for imagename in imagenames:
+        with open(annopath.format(imagename), 'rb') as f:
+            t = f.read()
+        texts.append(t)
+        cap += t.count(b'\n') + 1
+    bbox = np.empty((max(cap, 1), 8), dtype=np.float64)
+    off = np.empty(max(cap, 1), dtype=np.int32)
+    ln = np.empty(max(cap, 1), dtype=np.int32)
+    diff = np.empty(max(cap, 1), dtype=np.int32)
+    L = _lib.lib()
+    n, base, rec0 = 0, 0, [0]
+    for t in texts:
+        k = L.obb_task1_parse_gt(t, len(t), cap - n, bbox.ctypes.data + 64 * n, off.ctypes.data + 4 * n, ln.ctypes.data + 4 * n,
+                                 diff.ctypes.data + 4 * n)
+        if k < 0:
+            return None
+        off[n:n + k] += base
+        n += k
+        base += len(t)
+        rec0.append(n)
+    big = b''.join(texts)
+    try:
+        big.decode()                                     # the reference reads text: undecodable bytes make it raise
+        cls = classname.encode()
+    except UnicodeError:
+        return None
+    arr = np.frombuffer(big, dtype=np.uint8)
+    cand = np.nonzero(ln[:n] == len(cls))[0]
+    if len(cls) and len(cand):
+        same = (arr[off[cand, None].astype(np.int64) + np.arange(len(cls))] == np.frombuffer(cls, dtype=np.uint8)).all(1)
+        cand = cand[same]
+    gt_off = np.searchsorted(cand, np.asarray(rec0, dtype=np.int64)).astype(np.int64)
+    return bbox[cand], diff[cand] != 0, gt_off
+
+
 def read_detections(detfile):
-    """`image score x1 y1 .. x4 y4` per line (:152-160) -> (image ids, confidence (n,), BB (n, 8)).  pandas' C reader with
-    the round-trip float parser (= Python's float()) when the file is the plain 10-column layout, line by line otherwise."""
+    """`image score x1 y1 .. x4 y4` per line (:152-160) -> (image ids, confidence (n,), BB (n, 8)).  The native reader when the
+    file is the plain 10-column layout (then pandas' C reader with the round-trip float parser), line by line otherwise."""
+    got = _read_detections_native(detfile)
+    if got is not None:
+        return got
     try:
         import pandas as pd
         df = pd.read_csv(detfile, sep=' ', header=None, float_precision='round_trip', dtype={0: str}, skip_blank_lines=False)
@@ -90,18 +163,21 @@ def voc_eval(detpath, annopath, imagesetfile, classname, ovthresh=0.5, use_07_me
     """:88-249.  rec, prec, ap of one class."""
     with open(imagesetfile, 'r') as f:
         imagenames = [x.strip() for x in f.readlines()]
-    index = {}
-    gts, gt_off, difficult = [], [0], []
-    for imagename in imagenames:
-        objs = [o for o in parse_gt(annopath.format(imagename)) if o['name'] == classname]
-        index[imagename] = len(gt_off) - 1              # a name listed twice: the last record wins, as in the reference's dict
-        gts.extend(o['bbox'] for o in objs)
-        difficult.extend(bool(o['difficult']) for o in objs)
-        gt_off.append(len(gts))
-    difficult = np.array(difficult, dtype=np.bool_)
+    index = {imagename: i for i, imagename in enumerate(imagenames)}   # a name listed twice: the last record wins, as in the reference's dict
+    fast = load_gt(annopath, imagenames, classname)
+    if fast is not None:
+        gts, difficult, gt_off = fast
+    else:
+        gts, gt_off, difficult = [], [0], []
+        for imagename in imagenames:
+            objs = [o for o in parse_gt(annopath.format(imagename)) if o['name'] == classname]
+            gts.extend(o['bbox'] for o in objs)
+            difficult.extend(bool(o['difficult']) for o in objs)
+            gt_off.append(len(gts))
+        difficult = np.array(difficult, dtype=np.bool_)
+        gt_off = np.array(gt_off, dtype=np.int64)
     # npos counts every listed record (:140-149 adds per imagename, duplicates included)
     npos = int((~difficult).sum())
-    gt_off = np.array(gt_off, dtype=np.int64)
 
     image_ids, confidence, BB = read_detections(detpath.format(classname))
     sorted_ind = np.argsort(-confidence)                 # :163

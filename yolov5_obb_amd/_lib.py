@@ -39,6 +39,8 @@ SIGNATURES = {
     "obb_merge_nms_poly_f64": (_i32, [_vp, _i64, _vp, _vp, _i64, C.c_double, _vp, _vp, _vp, _sz, _vp]),
     "obb_task1_parse_tiles": (_i64, [_vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "obb_task1_format_rows": (_i64, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64]),
+    "obb_task1_parse_dets": (_i64, [_vp, _i64, _i64, _vp, _vp, _vp, _vp]),
+    "obb_task1_parse_gt": (_i64, [_vp, _i64, _i64, _vp, _vp, _vp, _vp]),
     "obb_eval_best_gt_f64": (_i32, [_vp, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp]),
     "obb_nms_obb_workspace_bytes": (_sz, [_i64, _i64, _i64, _i32]),
     "obb_non_max_suppression_obb": (_i32, [_vp, _i32, _i64, _i64, _i64, _f32, _f32, _vp, _i32, _i32, _i32, _i64, _i64, _f32,

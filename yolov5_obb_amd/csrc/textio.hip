@@ -107,6 +107,40 @@ bool parse_double(const char* b, const char* e, double* out) {
   return end == buf + (e - b);
 }
 
+// Python reads these files in text mode: "\r\n" and a lone "\r" end a line too, and str.strip() also removes the separators
+// 0x1c-0x1f and a few non-ASCII spaces.  The native readers split at "\n" and strip ASCII blanks only, so they decline
+// a buffer with a lone "\r", and a line whose ends could be such a character.
+bool plain_newlines(const char* text, int64_t len) {
+  const char* p = text;
+  const char* end = text + len;
+  while ((p = (const char*)memchr(p, '\r', (size_t)(end - p))) != nullptr) {
+    if (p + 1 >= end) return true;                       // a "\r" that ends the buffer only ends the last line
+    if (p[1] != '\n') return false;
+    p++;
+  }
+  return true;
+}
+inline bool odd_edge(const char* b, const char* e) {     // [b, e) non-empty, already stripped of ASCII blanks
+  const unsigned char f = (unsigned char)b[0], l = (unsigned char)e[-1];
+  if ((f >= 0x1c && f <= 0x1f) || (l >= 0x1c && l <= 0x1f)) return true;
+  // UTF-8 of U+0085, U+00A0, U+1680, U+2000-200A, U+2028, U+2029, U+202F, U+205F, U+3000 starts with C2 / E1 / E2 / E3; at the
+  // end of a line their last byte is 0x80-0xBF after such a lead byte: names in other scripts are common, so look closer
+  auto ws_at = [](const unsigned char* q, const unsigned char* lim) -> int {   // length of a Unicode space starting at q, or 0
+    if (q + 1 < lim && q[0] == 0xC2 && (q[1] == 0x85 || q[1] == 0xA0)) return 2;
+    if (q + 2 < lim && q[0] == 0xE1 && q[1] == 0x9A && q[2] == 0x80) return 3;
+    if (q + 2 < lim && q[0] == 0xE2 && q[1] == 0x80 && ((q[2] >= 0x80 && q[2] <= 0x8A) || q[2] == 0xA8 || q[2] == 0xA9 || q[2] == 0xAF)) return 3;
+    if (q + 2 < lim && q[0] == 0xE2 && q[1] == 0x81 && q[2] == 0x9F) return 3;
+    if (q + 2 < lim && q[0] == 0xE3 && q[1] == 0x80 && q[2] == 0x80) return 3;
+    return 0;
+  };
+  const unsigned char* ub = (const unsigned char*)b;
+  const unsigned char* ue = (const unsigned char*)e;
+  if (ws_at(ub, ue)) return true;
+  if (e - b >= 2 && ws_at(ue - 2, ue) == 2) return true;
+  if (e - b >= 3 && ws_at(ue - 3, ue) == 3) return true;
+  return false;
+}
+
 bool parse_int(const char* b, const char* e, long long* out) {
   if (b >= e || e - b > 18) return false;
   long long v = 0;
@@ -122,6 +156,7 @@ extern "C" {
 int64_t obb_task1_parse_tiles(const char* text, int64_t len, int64_t max_lines, double* dets9, int32_t* name_off, int32_t* name_len,
                               int32_t* group, int32_t* group_first, int64_t* n_groups) {
   if (!text || len < 0 || max_lines < 0 || !dets9 || !name_off || !name_len || !group || !group_first || !n_groups) return OBB_ERR_BAD_ARG;
+  if (!plain_newlines(text, len)) return OBB_ERR_BAD_ARG;
   std::unordered_map<std::string_view, int32_t> ids;          // keys point into `text`: no copies
   std::string_view prev_name;
   int32_t prev_id = -1;
@@ -138,7 +173,7 @@ int64_t obb_task1_parse_tiles(const char* text, int64_t len, int64_t max_lines, 
     while (e > b && is_space(e[-1])) e--;
     p = next;
     if (b == e) return OBB_ERR_BAD_ARG;                   // an empty line: the reference raises on it
-    if (n >= max_lines) return OBB_ERR_BAD_ARG;
+    if (n >= max_lines || odd_edge(b, e)) return OBB_ERR_BAD_ARG;
     // ---- 10 fields separated by single spaces
     const char* fb[10];
     const char* fe[10];
@@ -213,6 +248,84 @@ int64_t obb_task1_parse_tiles(const char* text, int64_t len, int64_t max_lines, 
     n++;
   }
   *n_groups = (int64_t)ids.size();
+  return n;
+}
+
+// `image score x1 y1 .. x4 y4` per line (dota_evaluation_task1.py:152-160: strip, split(' '), float()): the plain layout only
+int64_t obb_task1_parse_dets(const char* text, int64_t len, int64_t max_lines, double* conf, double* bb8, int32_t* name_off,
+                             int32_t* name_len) {
+  if (!text || len < 0 || max_lines < 0 || !conf || !bb8 || !name_off || !name_len) return OBB_ERR_BAD_ARG;
+  if (!plain_newlines(text, len)) return OBB_ERR_BAD_ARG;
+  int64_t n = 0;
+  const char* p = text;
+  const char* end = text + len;
+  while (p < end) {
+    const char* le = (const char*)memchr(p, '\n', (size_t)(end - p));
+    const char* next = le ? le + 1 : end;
+    if (!le) le = end;
+    const char* b = p;
+    const char* e = le;
+    while (b < e && is_space(*b)) b++;
+    while (e > b && is_space(e[-1])) e--;
+    p = next;
+    if (b == e || n >= max_lines || odd_edge(b, e)) return OBB_ERR_BAD_ARG;   // (an empty line makes the reference raise)
+    const char* q = b;
+    for (int k = 0; k < 10; k++) {
+      const char* sp = (const char*)memchr(q, ' ', (size_t)(e - q));
+      const char* fe = sp ? sp : e;
+      if (fe == q || (k < 9) != (sp != nullptr)) return OBB_ERR_BAD_ARG;      // an empty field, too few or too many fields
+      if (k == 0) { name_off[n] = (int32_t)(q - text); name_len[n] = (int32_t)(fe - q); }
+      else if (!parse_double(q, fe, k == 1 ? &conf[n] : &bb8[n * 8 + (k - 2)])) return OBB_ERR_BAD_ARG;
+      q = fe + 1;
+    }
+    n++;
+  }
+  return n;
+}
+
+// `x1 y1 x2 y2 x3 y3 x4 y4 name [difficult]` per line (dota_evaluation_task1.py:21-53): lines with fewer than 9 fields are
+// skipped like there; difficult = 0 without the tenth field.  More than 10 fields, an empty field, a difficult flag that is
+// not plain digits: declined.
+int64_t obb_task1_parse_gt(const char* text, int64_t len, int64_t max_lines, double* bbox8, int32_t* name_off, int32_t* name_len,
+                           int32_t* difficult) {
+  if (!text || len < 0 || max_lines < 0 || !bbox8 || !name_off || !name_len || !difficult) return OBB_ERR_BAD_ARG;
+  if (!plain_newlines(text, len)) return OBB_ERR_BAD_ARG;
+  int64_t n = 0;
+  const char* p = text;
+  const char* end = text + len;
+  while (p < end) {
+    const char* le = (const char*)memchr(p, '\n', (size_t)(end - p));
+    const char* next = le ? le + 1 : end;
+    if (!le) le = end;
+    const char* b = p;
+    const char* e = le;
+    while (b < e && is_space(*b)) b++;
+    while (e > b && is_space(e[-1])) e--;
+    p = next;
+    if (b == e) continue;                                 // '' -> [''] : fewer than 9 fields, skipped
+    if (odd_edge(b, e)) return OBB_ERR_BAD_ARG;
+    const char* fb[10];
+    const char* fe[10];
+    int nf = 0;
+    const char* q = b;
+    while (true) {
+      const char* sp = (const char*)memchr(q, ' ', (size_t)(e - q));
+      if (nf == 10) return OBB_ERR_BAD_ARG;               // an eleventh field: the reference's record has no 'difficult' key
+      fb[nf] = q; fe[nf] = sp ? sp : e; nf++;
+      if (!sp) break;
+      q = sp + 1;
+    }
+    if (nf < 9) continue;                                 // (:26-27; empty fields count as fields there too)
+    for (int k = 0; k < nf; k++) if (fb[k] == fe[k]) return OBB_ERR_BAD_ARG;
+    if (n >= max_lines) return OBB_ERR_BAD_ARG;
+    for (int k = 0; k < 8; k++) if (!parse_double(fb[k], fe[k], &bbox8[n * 8 + k])) return OBB_ERR_BAD_ARG;
+    name_off[n] = (int32_t)(fb[8] - text);
+    name_len[n] = (int32_t)(fe[8] - fb[8]);
+    long long dv = 0;
+    if (nf == 10 && (!parse_int(fb[9], fe[9], &dv) || dv > 0x7fffffffLL)) return OBB_ERR_BAD_ARG;   // int('1_0'), int('+1'), int(' 1'): the general path
+    difficult[n] = (int32_t)dv;
+    n++;
+  }
   return n;
 }
 
