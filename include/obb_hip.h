@@ -44,8 +44,10 @@ int obb_device_info(int* cu_count, int* wave_size, char* arch_name, int arch_nam
 /* The persistent NMS kernel launches one workgroup per CU and its workgroups meet at spin barriers: they must all be
  * resident.  Where that cannot be taken for granted (CU masking, a partition that exposes fewer CUs than it reports, a
  * long kernel of another process holding CUs) a barrier times out and the call reports -1 kept boxes instead of hanging.
- * max_workgroups > 0 caps the grid of the following launches of this process (the host layer retries an aborted call
- * once with 8 workgroups); 0 restores the default (the CU count). */
+ * max_workgroups > 0 caps the grid of the following launches of the CALLING THREAD (thread-local state: the host layer
+ * retries an aborted call once with 8 workgroups and restores the default in a finally block; concurrent callers on other
+ * threads are not affected, and one call sizes its workspace and its grid from the same value); 0 restores the default
+ * (the CU count). */
 int obb_nms_set_max_grid(int max_workgroups);
 
 /* Optional per-stage timing with HIP events recorded on the caller's stream (used by bench.py for the roofline

@@ -48,3 +48,33 @@ def test_planted_heads_are_deterministic_and_decode_to_overlapping_detections():
     out = pyref.non_max_suppression_obb(z.clone(), conf_thres=0.25, iou_thres=0.45, multi_label=True, max_det=300)
     kept = sum(o.shape[0] for o in out)
     assert 12 <= kept < passing                                               # neighbours of an object suppress each other
+
+
+def test_inference_tensors_carry_no_column_and_do_not_raise():
+    """under torch.inference_mode() a tensor tracks no version counter (`._version` raises), so the trust rule
+    cannot be checked: the column is neither attached (models/yolo.py) nor trusted (utils/general.py)."""
+    with torch.inference_mode():
+        z = torch.rand(2, 50, 5 + 3 + 180)
+        assert torch.is_inference(z)
+        col = z[..., 4].contiguous()
+        z._obb_objcol = (col, 0)                       # as if somebody had attached one anyway
+        assert G._objectness_column(z, z) is None      # ... it is not trusted, and nothing raises
+
+
+def test_detect_host_tables_follow_in_place_anchor_updates():
+    """autoanchor / check_anchor_order rewrite m.anchors in place after the first inference call; the host copy
+    Detect's kernel launch reads must follow (keyed on version + storage like ComputeLoss._refresh_host_tables)."""
+    from yolov5_obb_amd.models.yolo import Detect
+    det = Detect(nc=3, anchors=synth.DEFAULT_ANCHORS, ch=(8, 8, 8))
+    det.stride = torch.tensor(synth.DEFAULT_STRIDES)
+    det.anchors /= det.stride.view(-1, 1, 1)
+    px0, st0 = det._host_tables()
+    assert [round(v) for v in px0[0]] == synth.DEFAULT_ANCHORS[0] and st0 == synth.DEFAULT_STRIDES
+    px1, _ = det._host_tables()
+    assert list(px1[2]) == list(px0[2])                # unchanged tensors: the cached copy
+    det.anchors[:] = det.anchors.flip(0)               # check_anchor_order (utils/autoanchor.py:17-25) does exactly this
+    px2, _ = det._host_tables()
+    assert [round(v / 8.0 * 32.0) for v in px2[0]] == synth.DEFAULT_ANCHORS[2]
+    import pickle
+    det2 = pickle.loads(pickle.dumps(det))             # the cache holds plain lists + ints: still picklable
+    assert [round(v) for v in det2._host_tables()[0][1]] == [round(v) for v in px2[1]]

@@ -291,7 +291,7 @@ constexpr int64_t kGridMinN = 8192;    // below this the exhaustive cross phase 
 // One persistent launch runs the whole step loop (nms_core.h).  Grid: one 512-thread workgroup per CU at most --
 // all workgroups must be resident because they meet at team barriers; smaller problems get fewer workgroups
 // (cheaper barriers).
-static int g_max_grid = 0;            // obb_nms_set_max_grid
+static thread_local int g_max_grid = 0;   // obb_nms_set_max_grid: per calling thread (a retry of one thread never shrinks another thread's launches)
 static int hw_cu_count();
 static int cu_count() {
   const int c = hw_cu_count();

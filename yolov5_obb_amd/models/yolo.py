@@ -45,13 +45,26 @@ class Detect(nn.Module):
         self.m = nn.ModuleList(nn.Conv2d(x, self.no * self.na, 1) for x in ch)  # output conv
         self.inplace = inplace  # use in-place ops (e.g. slice assignment)
 
+    @staticmethod
+    def _tensor_key(t):
+        """(version, storage address) of a tensor; inference tensors track no version counter: their address alone."""
+        try:
+            return (t._version, t.data_ptr())
+        except RuntimeError:
+            return (None, t.data_ptr())
+
     def _host_tables(self):
-        if self._anchor_px is None:
-            st = [float(s) for s in torch.as_tensor(self.stride).float().cpu().tolist()]
+        # The reference reads anchors / stride on every call (models/yolo.py:90-91), so an in-place update after the first
+        # inference (autoanchor's `m.anchors[:] = ...`, check_anchor_order) is picked up there; the host copy here is keyed
+        # on the tensors' version counters and storage, like ComputeLoss._refresh_host_tables.
+        stride_t = torch.as_tensor(self.stride)
+        key = (self._tensor_key(self.anchors), self._tensor_key(stride_t))
+        if self._anchor_px is None or self._anchor_px[2] != key:
+            st = [float(s) for s in stride_t.float().cpu().tolist()]
             an = self.anchors.detach().float().cpu()
             px = [(an[i] * st[i]).reshape(-1).tolist() for i in range(self.nl)]      # anchor_grid values (:90-91)
-            self._anchor_px = (px, st)
-        px, st = self._anchor_px
+            self._anchor_px = (px, st, key)
+        px, st = self._anchor_px[0], self._anchor_px[1]
         return [(C.c_float * len(p))(*p) for p in px], st      # ctypes arrays are built per call: they do not pickle
 
     def _apply(self, fn):  # anchors / stride may change (Model._apply, autoanchor): drop the host cache
@@ -109,8 +122,11 @@ class Detect(nn.Module):
                 _lib.check(rc, "obb_detect_decode_col")
                 x[i] = xp
                 off += self.na * ny * nx
-        if col is not None:
-            z._obb_objcol = (col, z._version)            # read by utils.general.non_max_suppression_obb (see the module docstring)
+        if col is not None and not torch.is_inference(z):
+            # read by utils.general.non_max_suppression_obb (module docstring).  Under torch.inference_mode() tensors carry no
+            # version counter, so "unchanged since Detect wrote it" cannot be checked: the column is not attached and the NMS
+            # scans z[..., 4] itself (same results).
+            z._obb_objcol = (col, z._version)
         return z, x
 
     def _make_grid(self, nx=20, ny=20, i=0):  # models/yolo.py:83-92

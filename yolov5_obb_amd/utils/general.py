@@ -6,6 +6,7 @@ kernels, host syncs and a device->host mask copy.
 import ctypes as C
 import os
 import threading
+import time
 
 import torch
 
@@ -16,7 +17,8 @@ pi = 3.141592  # utils/general.py:34 (truncated on purpose: it is the constant t
 _MAX_WH = 4096      # utils/general.py:793
 _POLL_COUNTS = os.environ.get("OBB_NMS_POLL_COUNTS", "1") != "0"      # counts through polled pinned memory (see below)
 _PENDING = -(1 << 62)
-_POLL_SPINS = 400000
+_POLL_SECONDS = 2e-3  # busy-poll this long (a bs16 step is ~0.2 ms), then yield the GIL between polls, then give up polling
+_POLL_GIVE_UP = 1.0   # ... after this many seconds: fall back to a stream synchronise
 _MAX_NMS = 30000    # utils/general.py:794
 _CSL = 180          # utils/general.py:784
 _cap_memo = {}      # (A, nc, multi_label) -> candidate slots per image that sufficed last time
@@ -53,7 +55,11 @@ def _objectness_column(prediction, pred):
     if tag is None or pred is not prediction:
         return None
     col, version = tag
-    if (version != prediction._version or not isinstance(col, torch.Tensor) or col.shape != prediction.shape[:2]
+    try:
+        current = prediction._version      # inference tensors (torch.inference_mode) track no version: nothing to trust
+    except RuntimeError:
+        return None
+    if (version != current or not isinstance(col, torch.Tensor) or col.shape != prediction.shape[:2]
             or col.dtype != prediction.dtype or col.device != prediction.device or not col.is_contiguous()):
         return None
     return col
@@ -123,50 +129,53 @@ def non_max_suppression_obb(prediction, conf_thres=0.25, iou_thres=0.45, classes
         _meta_memo[mkey] = meta = (meta, meta.numpy() if _POLL_COUNTS else None)
     meta, meta_np = meta
     agn = int(bool(agnostic))
-    aborted_once = False
-    while True:
-        hint = int(_cand_memo.get(key, 0))
-        if meta_np is not None:
-            meta_np.fill(_PENDING)
-        with _lib.guard(dev):
-            st = _lib.stream_handle(dev)
-            wkey = (bs, cap, nc, agn)
-            nbytes = _ws_memo.get(wkey)
-            if nbytes is None:
-                nbytes = _ws_memo[wkey] = L.obb_nms_obb_workspace_bytes(bs, cap, nc, agn)
-            ws = _lib.workspace(nbytes, dev, st)
-            rc = L.obb_non_max_suppression_obb_col(
-                _lib.ptr(pred), _lib.ptr(col), dtype, bs, A, no, float(conf_thres), float(iou_thres),
-                C.cast(cls_arr, C.c_void_p) if cls_arr is not None else C.c_void_p(0), n_cls, agn, int(multi),
-                max_det, _MAX_NMS, float(_MAX_WH), _lib.ptr(extra), n_extra, cap, hint, _lib.ptr(out), 1, _lib.ptr(meta),
-                C.c_void_p(meta.data_ptr() + 8 * bs), _lib.ptr(ws), ws.numel(), C.c_void_p(st))
-        _lib.check(rc, "obb_non_max_suppression_obb")
-        if meta_np is not None:                                       # every entry is one aligned 8-byte store of the last kernel
-            spins = 0
-            while meta_np.min() == _PENDING:
-                spins += 1
-                if spins > _POLL_SPINS:                               # ~ a second: something is badly wrong, or a very long call
-                    _lib.stream_sync(dev)
-                    break
-            m = meta_np.tolist()
-        else:
-            m = meta.tolist()                                         # the single device->host sync of the call
-        if min(m[:bs]) < 0:                                           # a team barrier of the NMS kernel timed out
-            if aborted_once:
-                L.obb_nms_set_max_grid(0)
-                _lib.checked_count(min(m[:bs]), "obb_non_max_suppression_obb")
-            aborted_once = True
-            L.obb_nms_set_max_grid(8)                                 # once more with a grid that is resident under any CU mask
-            continue
-        if m[bs] > cap:                                               # an image produced more candidates than slots
-            cap = min(worst, max(int(m[bs]), 2 * cap))
-            continue
-        if 0 < hint <= _SORT_LDS_HINT and m[bs + 1] > _SORT_LDS_MAX:  # the hint undersold this batch: such images were left out
-            _cand_memo[key] = int(m[bs + 1])
-            continue
-        break
-    if aborted_once:
-        L.obb_nms_set_max_grid(0)
+    capped = False                # obb_nms_set_max_grid is per calling thread (thread_local in the library): no other thread sees it
+    try:
+        while True:
+            hint = int(_cand_memo.get(key, 0))
+            if meta_np is not None:
+                meta_np.fill(_PENDING)
+            with _lib.guard(dev):
+                st = _lib.stream_handle(dev)
+                wkey = (bs, cap, nc, agn)
+                nbytes = _ws_memo.get(wkey)
+                if nbytes is None:
+                    nbytes = _ws_memo[wkey] = L.obb_nms_obb_workspace_bytes(bs, cap, nc, agn)
+                ws = _lib.workspace(nbytes, dev, st)
+                rc = L.obb_non_max_suppression_obb_col(
+                    _lib.ptr(pred), _lib.ptr(col), dtype, bs, A, no, float(conf_thres), float(iou_thres),
+                    C.cast(cls_arr, C.c_void_p) if cls_arr is not None else C.c_void_p(0), n_cls, agn, int(multi),
+                    max_det, _MAX_NMS, float(_MAX_WH), _lib.ptr(extra), n_extra, cap, hint, _lib.ptr(out), 1, _lib.ptr(meta),
+                    C.c_void_p(meta.data_ptr() + 8 * bs), _lib.ptr(ws), ws.numel(), C.c_void_p(st))
+            _lib.check(rc, "obb_non_max_suppression_obb")
+            if meta_np is not None:                                   # every entry is one aligned 8-byte store of the last kernel
+                t_poll = time.perf_counter()
+                while meta_np.min() == _PENDING:
+                    waited = time.perf_counter() - t_poll
+                    if waited > _POLL_GIVE_UP:                        # something is badly wrong, or a very long call
+                        _lib.stream_sync(dev)
+                        break
+                    if waited > _POLL_SECONDS:                        # the stream still holds earlier work (the model's forward):
+                        time.sleep(0)                                 # let other Python threads (DataLoader, pin-memory) run
+                m = meta_np.tolist()
+            else:
+                m = meta.tolist()                                     # the single device->host sync of the call
+            if min(m[:bs]) < 0:                                       # a team barrier of the NMS kernel timed out
+                if capped:
+                    _lib.checked_count(min(m[:bs]), "obb_non_max_suppression_obb")
+                capped = True
+                L.obb_nms_set_max_grid(8)                             # once more with a grid that is resident under any CU mask
+                continue
+            if m[bs] > cap:                                           # an image produced more candidates than slots
+                cap = min(worst, max(int(m[bs]), 2 * cap))
+                continue
+            if 0 < hint <= _SORT_LDS_HINT and m[bs + 1] > _SORT_LDS_MAX:   # the hint undersold this batch: such images were left out
+                _cand_memo[key] = int(m[bs + 1])
+                continue
+            break
+    finally:
+        if capped:
+            L.obb_nms_set_max_grid(0)
     _cap_memo[key] = cap
     _cand_memo[key] = int(m[bs + 1])
     counts = m[:bs]

@@ -92,9 +92,17 @@ def run(model, loader, n_total=None, conf_thres=0.001, iou_thres=0.4, half=True,
                     pred[:, 6] = 0
                 poly, hbb, polyn, hbbn = postprocess(pred, ratio_pad=ratio_pad)               # val.py:226-236
                 if nl:
+                    # val.py:238-241 in the reference's operation order: rbox2poly -> poly2hbb -> xywh2xyxy on the UNSCALED
+                    # labels (output [1] of the tail kernel: boxes in the letterboxed frame), THEN scale_coords (pad, gain,
+                    # clip; utils/general.py:621-633) -- scaling the polygon first rounds differently in fp32 and could flip
+                    # a borderline IoU match
                     lab7 = torch.cat((labels[:, 1:6], torch.zeros_like(labels[:, :1]), labels[:, :1]), 1)   # [x y l s theta 0 cls]
-                    tb = postprocess(lab7.float(), ratio_pad=ratio_pad)[3][:, :4].clone()    # rbox2poly -> poly2hbb -> xywh2xyxy -> scale
-                    tb[:, [0, 2]] = tb[:, [0, 2]].clamp(0, float(shape[1]))                   # scale_coords clips (utils/general.py:621-633)
+                    tb = postprocess(lab7.float(), ratio_pad=ratio_pad)[1][:, :4].clone()
+                    gain, pad = ratio_pad[0][0], ratio_pad[1]
+                    tb[:, [0, 2]] -= pad[0]
+                    tb[:, [1, 3]] -= pad[1]
+                    tb[:, :4] /= gain
+                    tb[:, [0, 2]] = tb[:, [0, 2]].clamp(0, float(shape[1]))
                     tb[:, [1, 3]] = tb[:, [1, 3]].clamp(0, float(shape[0]))
                     correct = match(hbbn, torch.cat((labels[:, 0:1].float(), tb), 1), iouv)   # val.py:244
                 else:
