@@ -347,3 +347,67 @@ def test_full_size_100k_properties(dev, oracle_lib):
     iou = ops.rotated_iou_matrix(kd, d[torch.from_numpy(sample).to(dev)]).cpu().numpy()     # (kept, sample)
     higher = ks[:, None] > scores.numpy()[sample][None, :]
     assert ((iou > thr) & higher).any(0).all()                                 # (d)
+
+
+def _slab_case(variant, n=30000):
+    """Lists that fall apart into groups that cannot overlap (the callers' cls * 4096 offsets, utils/general.py:849-851)."""
+    g = torch.Generator().manual_seed(11)
+    flags = 0
+    if variant in ("cls18", "cls2", "cls90", "ties", "dropped"):
+        nc = {"cls18": 18, "cls2": 2, "cls90": 90}.get(variant, 7)
+        dets, scores = synth.s_clustered(n, 200, seed=3)
+        dets, _ = synth.with_classes(dets, nc, 3)
+        if variant == "ties":
+            scores = scores.half().float()                                      # heavy ties: ascending-index rule across slabs
+        if variant == "dropped":
+            pick = torch.randperm(n, generator=g)[:1500]
+            dets[pick, 3] = 0.0005
+    elif variant == "x_only":                                                   # offsets on x alone, uneven groups
+        dets, scores = synth.s_clustered(n, 150, seed=4)
+        cls = (torch.rand(n, generator=g) ** 2 * 5).long()
+        dets[:, 0] += cls.float() * 3000.0
+    elif variant == "y_only":                                                   # groups apart on y only: one slab on x, the list stays whole
+        dets, scores = synth.s_clustered(n, 150, seed=4)
+        dets[:, 1] += torch.randint(0, 6, (n,), generator=g).float() * 5000.0
+    elif variant == "big_slab":                                                 # one group above the slab limit: the call stays one list
+        dets, scores = synth.s_clustered(n + 30000, 300, seed=5)
+        dets[:8000, 0] += 9000.0
+    elif variant == "needle":                                                   # one ill-conditioned box switches the decomposition off
+        dets, scores = synth.s_clustered(n, 200, seed=6)
+        dets, _ = synth.with_classes(dets, 9, 6)
+        dets[17, 2] = 0.004
+    elif variant == "touching":                                                 # groups whose circles just touch / just do not
+        dets, scores = synth.s_uniform(n, 8, extent=600.0)
+        dets[:, 0] = (dets[:, 0] % 150.0) + torch.randint(0, 12, (n,), generator=g).float() * 236.0
+    else:
+        raise KeyError(variant)
+    if variant != "ties":
+        scores = synth.tie_free(scores)
+    if variant == "dropped":
+        from yolov5_obb_amd import _lib
+        flags = _lib.OBB_NMS_DROP_SMALL
+    return dets, scores, flags
+
+
+@pytest.mark.parametrize("variant", ["cls18", "cls2", "cls90", "ties", "dropped", "x_only", "y_only", "big_slab", "needle", "touching"])
+def test_independent_slabs_same_result(dev, oracle_lib, variant):
+    """Slab mode of the single-list kernel (csrc/grid.h "independent slabs", nms_core.h slab_setup / slab_merge): the list
+    is re-laid out slab by slab inside the kernel and run as concurrent segments; the kept list must be the oracle's,
+    index for index, in global score order -- for 2 / 18 / more than 64 groups, ties, boxes dropped by the small-box
+    filter, uneven groups, and for the inputs that must NOT be decomposed (no gap on x, a group above the limit, an
+    ill-conditioned box).  Three runs each: the work distribution depends on timing, the result must not."""
+    import os
+    from yolov5_obb_amd import nms_rotated_ext
+    dets, scores, flags = _slab_case(variant)
+    thr = 0.4
+    if variant == "dropped":
+        keep_mask = dets[:, 2:4].min(1)[0] >= 0.001
+        idx = torch.nonzero(keep_mask).squeeze(1).numpy()
+        ref = idx[oracle.nms_rotated(dets[keep_mask].numpy(), scores[keep_mask].numpy(), thr, threads=min(os.cpu_count() or 1, 32))]
+    else:
+        ref = oracle.nms_rotated(dets.numpy(), scores.numpy(), thr, threads=min(os.cpu_count() or 1, 32))
+    d, s = dets.to(dev), scores.to(dev)
+    for rep in range(3):
+        got = nms_rotated_ext._run_rotated(d, s, thr, flags=flags).cpu().numpy()
+        assert len(got) == len(ref), (variant, rep, len(got), len(ref))
+        assert np.array_equal(ref, got), (variant, rep)

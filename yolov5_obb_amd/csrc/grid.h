@@ -107,4 +107,33 @@ OBB_HD float grid_query_halfwidth(const GridPlan& p, int L, float x, float y, fl
   return (r + grid_level_radius(p, L)) * 1.0001f + mag * 4e-7f;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Independent slabs (nms_core.h: slab_setup).  The callers of the reference keep classes apart by adding cls * 4096 to the
+// box centres before ONE nms_rotated call (utils/general.py:849-851): the list then consists of groups of boxes that cannot
+// overlap each other.  Groups are found on the x axis: every box marks the bins its (slightly widened) circle interval
+// [x - r, x + r] touches in a bitmap of kSlabBins bins over the extent of the centres; a maximal run of marked bins is a
+// slab.  Two boxes in different slabs have an unmarked bin between their centres, so their circles are apart by more than
+// the margin RotGeom::cheap_reject needs -- the exhaustive scan would reject the pair in its hot loop, provided both boxes
+// are well conditioned for ANY partner inside the data's bounding box (the first half of grid_is_brute).  One box that is
+// not (or is not finite) switches the decomposition off for the call.
+constexpr int kSlabBins = 4096;
+constexpr int kSlabWords = kSlabBins / 32;
+constexpr int kMaxSlabs = 64;
+constexpr int kSlabMaxSeg = 16384;                 // a slab larger than this: the call stays one list (index path)
+
+OBB_HD float slab_inv_bin(const GridPlan& p) { return (p.ok && p.xr > 0.f) ? (float)kSlabBins / p.xr : 0.f; }
+OBB_HD int slab_bin(float v, float x0, float inv) {            // monotone in v; NaN -> 0 (such boxes raise the flag anyway)
+  const float f = floorf((v - x0) * inv);
+  return f > 0.f ? (f < (float)(kSlabBins - 1) ? (int)f : kSlabBins - 1) : 0;
+}
+// half width of the interval a box marks: its inflated circumradius plus the rounding of the fp32 differences involved
+OBB_HD float slab_halfwidth(const GridPlan& p, float x, float r) {
+  return r * 1.0001f + (fabsf(x) + fabsf(p.x0) + p.xr) * 4e-7f;
+}
+// false: this box forbids the decomposition (not finite, or an ill-conditioned far pair is possible: kGridIllCond)
+OBB_HD bool slab_box_ok(const GridPlan& p, float x, float y, float r, float ms2) {
+  const bool finite = (x - x == 0.f) && (y - y == 0.f) && (r - r == 0.f);
+  return finite && (ms2 >= kGridIllCond * p.dmax2);
+}
+
 }  // namespace obb

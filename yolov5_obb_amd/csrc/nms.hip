@@ -160,13 +160,43 @@ struct GridDev {
   float4* sorted;              // [n] {x, y, r, position}
   uint32_t* ulist;             // [n] positions kept out of the index
   uint32_t mask;               // M - 1
+  // independent slabs (grid.h; nms_core.h slab_setup): coverage bitmap + flag live in the zeroed block behind GridMeta
+  uint32_t* slab_cover; int* slab_flag;
+  int* slab_cnt;               // [kMaxTeams][kMaxSlabs] boxes per (workgroup, slab)
+  int* slab_keep;              // [kMaxSlabs] kept boxes per slab
+  float4* rec2; uint32_t* order2; uint32_t* pos_old; u64* alive2; u64* kept_bits;   // the slab-major copy of the list
+  size_t alive2_words, kept_words;
 };
 
+// the extent of the data from the key kernel's per-block partials (every block reduces them itself: a few hundred int4)
+__device__ __forceinline__ GridPlan plan_from_partials(const int* __restrict__ bbpart, int nparts, int (*s_red)[4]) {
+  int bx0 = 0x7fffffff, by0 = 0x7fffffff, bx1 = (int)0x80000000, by1 = (int)0x80000000;
+  for (int i = threadIdx.x; i < nparts; i += blockDim.x) {
+    const int4 q = reinterpret_cast<const int4*>(bbpart)[i];
+    bx0 = min(bx0, q.x); by0 = min(by0, q.y); bx1 = max(bx1, q.z); by1 = max(by1, q.w);
+  }
+  block_minmax4(bx0, by0, bx1, by1, s_red);
+  const int bb[4] = {bx0, by0, bx1, by1};
+  return grid_plan(bb);
+}
+
 // blockDim.x is a multiple of 64 and p starts at 0: every wave covers one word of the alive bitmap
+// slab_cover != NULL: every box that takes part also marks the x bins its circle interval touches (grid.h, "independent
+// slabs"), first in a bitmap of the block in LDS, then with one atomicOr per non-zero word.
 __global__ __launch_bounds__(256) void k_prep_rot(const float* __restrict__ dets5, const uint32_t* __restrict__ order, int drop_small, int n,
-                                                  float4* __restrict__ rec, u64* __restrict__ alive) {
+                                                  float4* __restrict__ rec, u64* __restrict__ alive, const int* __restrict__ bbpart,
+                                                  int nparts, uint32_t* __restrict__ slab_cover, int* __restrict__ slab_flag) {
+  __shared__ int s_red[16][4];
+  __shared__ uint32_t s_cover[kSlabWords];
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
-  bool ok = false;
+  GridPlan gp = {};
+  float inv = 0.f;
+  if (slab_cover != nullptr) {
+    for (int k = threadIdx.x; k < kSlabWords; k += blockDim.x) s_cover[k] = 0u;
+    gp = plan_from_partials(bbpart, nparts, s_red);          // (contains the barriers that order the zeroing above)
+    inv = slab_inv_bin(gp);
+  }
+  bool ok = false, bad = false;
   if (p < n) {
     const float* d = dets5 + (size_t)order[p] * 5;
     float x = d[0], y = d[1], w = d[2], h = d[3], a = d[4];
@@ -177,10 +207,30 @@ __global__ __launch_bounds__(256) void k_prep_rot(const float* __restrict__ dets
     for (int k = 0; k < 4; k++) rec[(size_t)p * 4 + k] = q[k];
     float mn = (h < w) ? h : w;
     ok = !(drop_small && mn < 0.001f);
+    if (slab_cover != nullptr && ok) {
+      if (!slab_box_ok(gp, q[0].x, q[0].y, q[0].z, q[0].w)) bad = true;
+      else {
+        const float hw = slab_halfwidth(gp, x, f.r);
+        const int b0 = slab_bin(x - hw, gp.x0, inv), b1 = slab_bin(x + hw, gp.x0, inv);
+        for (int wd = b0 >> 5; wd <= (b1 >> 5); wd++) {
+          const int lo = max(b0, wd * 32) & 31, hi = min(b1, wd * 32 + 31) & 31;
+          const uint32_t m = (hi == 31 ? 0xffffffffu : ((1u << (hi + 1)) - 1u)) & ~((1u << lo) - 1u);
+          if ((s_cover[wd] & m) != m) atomicOr(&s_cover[wd], m);
+        }
+      }
+    }
   }
   const u64 m = __ballot(ok);
   if ((threadIdx.x & 63) == 0 && (p & ~63) < n) alive[p >> 6] = m;
   if (p < 8) alive[((n + 63) >> 6) + p] = 0ull;      // guard words behind the last box (the bitmap is not memset)
+  if (slab_cover != nullptr) {
+    const int anybad = __syncthreads_or(bad ? 1 : 0);
+    if (anybad && threadIdx.x == 0) atomicOr(slab_flag, 1);
+    for (int k = threadIdx.x; k < kSlabWords; k += blockDim.x) {
+      const uint32_t v = s_cover[k];
+      if (v && (__hip_atomic_load(slab_cover + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & v) != v) atomicOr(slab_cover + k, v);
+    }
+  }
 }
 
 __global__ void k_prep_quad(const float* __restrict__ polys, int stride, const uint32_t* __restrict__ order, int n,
@@ -342,23 +392,36 @@ static int carve(void* base, int64_t n, int64_t nseg, int recq, int C, Carve* cv
   cv->keep_cnt = (int*)take(ns * 4);
   // scratch that only the segment a team is working on needs: one copy per team, not per segment
   size_t nteams = ns < (size_t)cu_count() ? ns : (size_t)cu_count();
-  cv->rows = (uint32_t*)take(nn * 4);
+  cv->rows = (uint32_t*)take((nn + 64 * kMaxSlabs) * 4);      // (+ the padding of the slab-major layout)
   cv->ecap = (long long)C * (C - 1) / 2; if (cv->ecap < 1) cv->ecap = 1;
   cv->edges = (uint32_t*)take(nteams * (size_t)cv->ecap * 4);
-  cv->grid.meta = nullptr; cv->grid_zero_bytes = 0;
+  cv->grid = GridDev{}; cv->grid_zero_bytes = 0;
   if (recq == RotGeom::RECQ && nseg == 1 && n >= kGridMinN) {
     const uint32_t M = grid_slots(n);
     cv->grid.mask = M - 1;
-    cv->grid_zero_bytes = align_up(sizeof(GridMeta)) + ((size_t)M + 4) * 4;
+    const size_t slab_zero = align_up((size_t)kSlabWords * 4 + 64);
+    cv->grid_zero_bytes = align_up(sizeof(GridMeta)) + slab_zero + ((size_t)M + 4) * 4;
     char* z = take(cv->grid_zero_bytes);
     cv->grid.meta = (GridMeta*)z;
-    cv->grid.cnt = (int*)(z ? z + align_up(sizeof(GridMeta)) : nullptr);
+    cv->grid.slab_cover = (uint32_t*)(z ? z + align_up(sizeof(GridMeta)) : nullptr);
+    cv->grid.slab_flag = (int*)(z ? z + align_up(sizeof(GridMeta)) + (size_t)kSlabWords * 4 : nullptr);
+    cv->grid.cnt = (int*)(z ? z + align_up(sizeof(GridMeta)) + slab_zero : nullptr);
     cv->grid.start = (int*)take(((size_t)M + 4) * 4);
     cv->grid.wsum = (int*)take((size_t)1024 * 4);
     cv->grid.nparts = (int)((nn + 255) / 256);
     cv->grid.bbpart = (int*)take((size_t)cv->grid.nparts * 16);
     cv->grid.sorted = (float4*)take(nn * 16);
     cv->grid.ulist = (uint32_t*)take(nn * 4);
+    const size_t n2 = nn + 64 * (size_t)kMaxSlabs;            // every slab starts on a 64-position boundary
+    cv->grid.slab_cnt = (int*)take((size_t)kMaxTeams * kMaxSlabs * 4);
+    cv->grid.slab_keep = (int*)take((size_t)kMaxSlabs * 4);
+    cv->grid.rec2 = (float4*)take(n2 * RotGeom::RECQ * 16);
+    cv->grid.order2 = (uint32_t*)take(n2 * 4);
+    cv->grid.pos_old = (uint32_t*)take(n2 * 4);
+    cv->grid.alive2_words = n2 / 64 + 10;
+    cv->grid.alive2 = (u64*)take(cv->grid.alive2_words * 8);
+    cv->grid.kept_words = nn / 64 + 2;
+    cv->grid.kept_bits = (u64*)take(cv->grid.kept_words * 8);
   }
   cv->total = off;
   return OBB_OK;
@@ -476,6 +539,9 @@ static int run_nms(int kind, const float* boxes, int stride, const float* scores
   static int no_grid = -1;                                         // OBB_NMS_NO_GRID=1: A/B switch for measurements
   if (no_grid < 0) { const char* e = getenv("OBB_NMS_NO_GRID"); no_grid = (e && atoi(e)) ? 1 : 0; }
   const bool use_grid = !no_grid && kind == 0 && nseg == 1 && tie_bits == 0 && cv.grid.meta != nullptr && thr >= 0.f && n < (1ll << 24);
+  static int no_slabs = -1;                                        // OBB_NMS_NO_SLABS=1: A/B switch for measurements
+  if (no_slabs < 0) { const char* e = getenv("OBB_NMS_NO_SLABS"); no_slabs = (e && atoi(e)) ? 1 : 0; }
+  const bool use_slabs = use_grid && !no_slabs && max_keep <= 0;   // (a limit on the kept boxes keeps the call one list: the windows are per list)
   {
     ProfScope ps(PROF_NMS_SORT, st);
     size_t tmp = cv.sort_tmp_bytes;
@@ -500,7 +566,8 @@ static int run_nms(int kind, const float* boxes, int stride, const float* scores
   }
   {
     ProfScope ps(PROF_NMS_PREP, st);
-    if (kind == 0) k_prep_rot<<<gb, T, 0, st>>>(boxes, cv.vals_b, drop_small, (int)n, cv.rec, cv.alive);
+    if (kind == 0) k_prep_rot<<<gb, T, 0, st>>>(boxes, cv.vals_b, drop_small, (int)n, cv.rec, cv.alive, cv.grid.bbpart, cv.grid.nparts,
+                                                use_slabs ? cv.grid.slab_cover : nullptr, cv.grid.slab_flag);
     else k_prep_quad<<<gb, T, 0, st>>>(boxes, stride, cv.vals_b, (int)n, cv.rec, cv.alive);
   }
 
@@ -508,6 +575,11 @@ static int run_nms(int kind, const float* boxes, int stride, const float* scores
   if (use_grid) {
     a.gmeta = cv.grid.meta; a.bbpart = cv.grid.bbpart; a.nparts = cv.grid.nparts; a.gcnt = cv.grid.cnt; a.gstart = cv.grid.start;
     a.gsorted = cv.grid.sorted; a.gwsum = cv.grid.wsum; a.ulist = cv.grid.ulist; a.gmask = cv.grid.mask;
+  }
+  if (use_slabs) {
+    a.slab_cover = cv.grid.slab_cover; a.slab_flag = cv.grid.slab_flag; a.slab_cnt = cv.grid.slab_cnt; a.slab_keep = cv.grid.slab_keep;
+    a.rec2 = cv.grid.rec2; a.order2 = cv.grid.order2; a.pos_old = cv.grid.pos_old; a.alive2 = cv.grid.alive2; a.kept_bits = cv.grid.kept_bits;
+    a.alive2_words = (int)cv.grid.alive2_words; a.kept_words = (int)cv.grid.kept_words;
   }
   a.rec = cv.rec; a.order = cv.vals_b; a.alive = cv.alive; a.seg_begin = cv.seg_begin; a.seg_end = cv.seg_end;
   a.keep_cnt = cv.keep_cnt; a.keep_out = keep_out;

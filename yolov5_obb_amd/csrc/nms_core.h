@@ -76,6 +76,16 @@ struct NmsArgs {
   int* gwsum;                // [grid size] per-workgroup totals of the distributed scan
   uint32_t* ulist;           // [gmeta->n_brute] sorted positions of the boxes kept out of the index (filled by grid_build)
   uint32_t gmask;            // table size - 1 (power of two)
+  // Independent slabs (grid.h): slab_cover == NULL: none.  One list whose boxes fall into groups that cannot overlap each
+  // other (the callers' cls * 4096 offsets) is re-laid out slab by slab INSIDE this kernel (slab_setup) and run as that many
+  // concurrent segments, one team each; the kept boxes meet again in score order through a bitmap over the original
+  // positions (slab_merge).
+  const uint32_t* slab_cover; // [kSlabWords] x bins touched by a box (written by the prep kernel)
+  const int* slab_flag;       // [1] != 0: a box that cannot be placed (not finite / ill conditioned): no decomposition
+  int* slab_cnt;              // [gridDim.x][kMaxSlabs]
+  int* slab_keep;             // [kMaxSlabs]
+  float4* rec2; uint32_t* order2; uint32_t* pos_old; u64* alive2; u64* kept_bits;
+  int alive2_words, kept_words;
 };
 
 // ---- cost model shared by the planner (k_plan_teams) and the workgroups that follow its plan
@@ -427,8 +437,8 @@ __device__ __forceinline__ void nms_pairs(const NmsArgs& a, int tm, int cn, cons
 // for the first rounds, until what is left of it fits.
 // LDS (aliasing the wave scratch): state[capmax] | blocked[capmax] | edges[...]
 // returns the number of kept boxes of the chunk (also published in nrows[g])
-__device__ __forceinline__ int nms_resolve(const NmsArgs& a, int g, int tm, int cn, int kept_before, const uint32_t* cidx, uint8_t* smem, size_t smem_bytes,
-                           int* s_i) {
+__device__ __forceinline__ int nms_resolve(const NmsArgs& a, int g, int sb, int tm, int cn, int kept_before, const uint32_t* cidx, uint8_t* smem,
+                           size_t smem_bytes, int* s_i) {
   const int tid = threadIdx.x;
   uint8_t* state = smem;              // 0 undecided, 1 kept, 2 dead
   uint8_t* blocked = smem + a.capmax;
@@ -563,7 +573,6 @@ __device__ __forceinline__ int nms_resolve(const NmsArgs& a, int g, int tm, int 
 #pragma unroll
   for (int k = 0; k < kNmsWaves; k++) { const int t = s_i[k]; if (k < (tid >> 6)) wpre += t; total += t; }
   int rank = wpre + incl - mine;
-  const int sb = a.seg_begin[g];
   uint32_t* rows = a.rows + (size_t)sb + kept_before;         // appended to the segment's kept-row list
   for (int q = 0; q < per_n; q++) {
     const int j = tid * per_n + q;
@@ -571,7 +580,15 @@ __device__ __forceinline__ int nms_resolve(const NmsArgs& a, int g, int tm, int 
       const uint32_t pos = cidx[j];
       stg_agent(rows + rank, pos);
       const long long o = (long long)kept_before + rank;
-      if (a.max_keep <= 0 || o < a.max_keep) a.keep_out[(size_t)sb + o] = a.order ? (int64_t)a.order[pos] : (int64_t)pos;
+      if (a.keep_out != nullptr) {
+        if (a.max_keep <= 0 || o < a.max_keep) a.keep_out[(size_t)sb + o] = a.order ? (int64_t)a.order[pos] : (int64_t)pos;
+      } else {
+        // slab mode: the kept boxes of all slabs meet again in score order through a bitmap over the ORIGINAL sorted
+        // positions (slab_merge); a returning atomic whose result is consumed: the wave's vmcnt covers the completed update
+        const uint32_t po = a.pos_old[pos];
+        const u64 old = atomicOr(a.kept_bits + (po >> 6), 1ull << (po & 63));
+        asm volatile("; kept bit set %0" ::"v"((unsigned)(old >> 32) ^ (unsigned)old));
+      }
       rank++;
     }
   }
@@ -1138,6 +1155,214 @@ __device__ __forceinline__ int grid_build(const NmsArgs& a, const GridPlan& gp, 
   return 0;
 }
 
+
+// ------------------------------------------------------------------ independent slabs (grid.h): set-up and merge
+// What the set-up leaves behind for the rest of the kernel (static LDS, a few hundred bytes)
+struct SlabLds {
+  int segb[kMaxSlabs], sege[kMaxSlabs];   // positions [segb, sege) of slab s in the slab-major layout
+  int nslab;                              // 0: the call stays one list
+  int my_seg, my_team, my_idx, my_T;      // this workgroup's slab (-1: none), team id, index in the team, team size
+  int cap; long long ecap;                // chunk capacity / edge-list capacity of one team (the single list's buffer is shared out)
+};
+
+// Runs at the very start of the single-list kernel, by all workgroups.  Returns 0: one list (nothing changed); 1: slab mode
+// (SL filled in, the slab-major copy of the list is complete and visible); -1: barrier abort.
+//   1. runs of marked x bins -> slab of a bin (every workgroup from the same bitmap: same result);
+//   2. every workgroup counts the alive boxes of its contiguous block of positions per slab          -> team barrier
+//   3. totals, this workgroup's offsets, the 64-aligned start of every slab; uniform decision (>= 2 non-empty slabs, none
+//      larger than kSlabMaxSeg, one workgroup per slab available, a useful chunk capacity);
+//   4. STABLE scatter of records / original indices / original positions / alive bits: the order inside a slab is the
+//      score order of the list                                                                      -> team barrier
+template <class G>
+__device__ __forceinline__ int slab_setup(const NmsArgs& a, const GridPlan& gp, unsigned char* smem, TeamBar& gbar, int* s_flag, SlabLds& SL) {
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int NB = gridDim.x, wg = blockIdx.x;
+  uint32_t* starts = reinterpret_cast<uint32_t*>(smem);       // [kSlabWords] bins where a run starts
+  int* wpre = reinterpret_cast<int*>(starts + kSlabWords);    // [kSlabWords] runs that start before the word
+  int* cnt = wpre + kSlabWords;                               // [kMaxSlabs] this workgroup's boxes per slab
+  int* tot = cnt + kMaxSlabs;                                 // [kMaxSlabs] all boxes of the slab
+  int* pre = tot + kMaxSlabs;                                 // [kMaxSlabs] ... in workgroups below this one
+  int* base = pre + kMaxSlabs;                                // [kMaxSlabs] first position of the slab
+  int* run = base + kMaxSlabs;                                // [kMaxSlabs] ... placed by earlier tiles of this workgroup
+  int* wcnt = run + kMaxSlabs;                                // [kNmsWaves][kMaxSlabs] per wave of the current tile
+  int* misc = wcnt + kNmsWaves * kMaxSlabs;                   // [4]
+  if (tid == 0) SL.nslab = 0;
+  if (*a.slab_flag != 0 || NB > kNmsThreads) return 0;        // (written by the prep kernel: uniform)
+  const float inv = slab_inv_bin(gp);
+  __syncthreads();
+  int mypre = 0;
+  if (tid < kSlabWords) {
+    const uint32_t w = a.slab_cover[tid];
+    const uint32_t prev_msb = tid > 0 ? (a.slab_cover[tid - 1] >> 31) : 0u;
+    starts[tid] = w & ~((w << 1) | prev_msb);
+  }
+  __syncthreads();
+  if (tid < kSlabWords) for (int k = 0; k < tid; k++) mypre += __popc(starts[k]);
+  if (tid < kSlabWords) wpre[tid] = mypre;
+  if (tid == kSlabWords - 1) misc[0] = mypre + __popc(starts[tid]);
+  __syncthreads();
+  const int nruns = misc[0];
+  if (nruns < 2) return 0;
+  const int S = nruns < kMaxSlabs ? nruns : kMaxSlabs;        // (the runs beyond the last id share it: still independent of the others)
+  auto slab_of = [&](float x) -> int {
+    const int b = slab_bin(x, gp.x0, inv);
+    int r = wpre[b >> 5] + __popc(starts[b >> 5] & (0xffffffffu >> (31 - (b & 31)))) - 1;
+    return r < 0 ? 0 : (r < S ? r : S - 1);
+  };
+  // ---- 2: counts of this workgroup's block of positions (a multiple of 64 positions: whole words of the bitmap)
+  const int chunk = (((a.n + NB - 1) / NB) + 63) & ~63;
+  const int p0 = wg * chunk < a.n ? wg * chunk : a.n, p1 = (p0 + chunk < a.n) ? p0 + chunk : a.n;
+  if (tid < kMaxSlabs) { cnt[tid] = 0; run[tid] = 0; tot[tid] = 0; pre[tid] = 0; }
+  for (int k = wg * kNmsThreads + tid; k < a.alive2_words; k += NB * kNmsThreads) stg_agent(a.alive2 + k, 0ull);
+  for (int k = wg * kNmsThreads + tid; k < a.kept_words; k += NB * kNmsThreads) stg_agent(a.kept_bits + k, 0ull);
+  if (wg == 0 && tid < kMaxSlabs) stg_agent(a.slab_keep + tid, 0);
+  __syncthreads();
+  for (int pb = p0; pb < p1; pb += kNmsThreads) {
+    const int p = pb + tid;
+    int sl = -1;
+    if (p < p1 && ((a.alive[p >> 6] >> (p & 63)) & 1ull)) sl = slab_of(a.rec[(size_t)p * G::RECQ].x);
+    u64 todo = __ballot(sl >= 0);
+    while (todo) {                                             // one LDS atomic per (wave, slab present in it)
+      const int l0 = __builtin_ctzll(todo);
+      const int s0 = __shfl(sl, l0);
+      const u64 m = __ballot(sl == s0);
+      if (lane == l0) atomicAdd(&cnt[s0], __popcll(m));
+      todo &= ~m;
+    }
+  }
+  __syncthreads();
+  if (tid < kMaxSlabs) stg_agent(a.slab_cnt + (size_t)wg * kMaxSlabs + tid, cnt[tid]);
+  if (!team_barrier(gbar, s_flag)) return -1;
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  // ---- 3: totals and offsets (thread t reads the row of workgroup t)
+  for (int s0 = 0; s0 < S; s0++) {
+    int v = tid < NB ? a.slab_cnt[(size_t)tid * kMaxSlabs + s0] : 0;
+    int below = tid < wg ? v : 0;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { v += __shfl_xor(v, d); below += __shfl_xor(below, d); }
+    if (lane == 0 && v) { atomicAdd(&tot[s0], v); if (below) atomicAdd(&pre[s0], below); }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int acc = 0, mx = 0, nonempty = 0;
+    for (int s0 = 0; s0 < S; s0++) { base[s0] = acc; acc += (tot[s0] + 63) & ~63; mx = mx > tot[s0] ? mx : tot[s0]; nonempty += tot[s0] > 0 ? 1 : 0; }
+    // chunk capacity of a team: the single list's edge buffer shared out, cap (cap - 1) / 2 <= ecap / teams
+    const long long e = nonempty > 0 ? a.ecap / nonempty : 0;
+    int c = (int)((1.0 + sqrt(1.0 + 8.0 * (double)e)) * 0.5);
+    while (c > 0 && (long long)c * (c - 1) / 2 > e) c--;
+    c &= ~63;
+    if (c > a.capmax) c = a.capmax;
+    misc[1] = (mx <= kSlabMaxSeg && nonempty >= 2 && nonempty <= NB && c >= 512) ? 1 : 0;
+    misc[2] = nonempty; misc[3] = c;
+    SL.cap = c; SL.ecap = (long long)c * (c - 1) / 2;
+  }
+  __syncthreads();
+  if (!misc[1]) return 0;                                      // (uniform: every workgroup read the same table)
+  // ---- 4: stable scatter, tile by tile
+  for (int pb = p0; pb < p1; pb += kNmsThreads) {
+    const int p = pb + tid;
+    int sl = -1;
+    float4 q[G::RECQ];
+    if (p < p1 && ((a.alive[p >> 6] >> (p & 63)) & 1ull)) {
+#pragma unroll
+      for (int k = 0; k < G::RECQ; k++) q[k] = a.rec[(size_t)p * G::RECQ + k];
+      sl = slab_of(q[0].x);
+    }
+    __syncthreads();                                           // the previous tile's readers of wcnt / writers of run are done
+    for (int k = tid; k < kNmsWaves * kMaxSlabs; k += kNmsThreads) wcnt[k] = 0;
+    __syncthreads();
+    int rank_in_wave = 0;
+    u64 todo = __ballot(sl >= 0);
+    while (todo) {
+      const int l0 = __builtin_ctzll(todo);
+      const int s0 = __shfl(sl, l0);
+      const u64 m = __ballot(sl == s0);
+      if (sl == s0) rank_in_wave = __popcll(m & lanemask_lt());
+      if (lane == l0) wcnt[wv * kMaxSlabs + s0] = __popcll(m);
+      todo &= ~m;
+    }
+    __syncthreads();
+    if (sl >= 0) {
+      int off = run[sl];
+      for (int w2 = 0; w2 < wv; w2++) off += wcnt[w2 * kMaxSlabs + sl];
+      const int qn = base[sl] + pre[sl] + off + rank_in_wave;
+      u64* dst = reinterpret_cast<u64*>(a.rec2 + (size_t)qn * G::RECQ);
+#pragma unroll
+      for (int k = 0; k < G::RECQ; k++) {
+        stg_agent(dst + 2 * k, ((u64)__float_as_uint(q[k].y) << 32) | (u64)__float_as_uint(q[k].x));
+        stg_agent(dst + 2 * k + 1, ((u64)__float_as_uint(q[k].w) << 32) | (u64)__float_as_uint(q[k].z));
+      }
+      stg_agent(a.order2 + qn, a.order[p]);
+      stg_agent(a.pos_old + qn, (uint32_t)p);
+      const u64 old = atomicOr(a.alive2 + (qn >> 6), 1ull << (qn & 63));      // (returning: covered by the wave's vmcnt)
+      asm volatile("; alive bit set %0" ::"v"((unsigned)(old >> 32) ^ (unsigned)old));
+    }
+    __syncthreads();
+    if (tid < kMaxSlabs) {
+      int add = 0;
+      for (int w2 = 0; w2 < kNmsWaves; w2++) add += wcnt[w2 * kMaxSlabs + tid];
+      run[tid] += add;
+    }
+  }
+  // ---- the plan: one team per non-empty slab, the spare workgroups in proportion to the sizes
+  __syncthreads();
+  if (tid < kMaxSlabs) { SL.segb[tid] = tid < S ? base[tid] : 0; SL.sege[tid] = tid < S ? base[tid] + tot[tid] : 0; }
+  if (tid == 0) {
+    long long total = 0;
+    for (int s0 = 0; s0 < S; s0++) total += tot[s0];
+    const int spare = NB - misc[2];
+    int w = 0, team = 0;
+    SL.my_seg = -1; SL.my_team = 0; SL.my_idx = 0; SL.my_T = 1;
+    for (int s0 = 0; s0 < S; s0++) {
+      if (tot[s0] <= 0) continue;
+      const int T = 1 + (int)((long long)spare * tot[s0] / total);
+      if (wg >= w && wg < w + T) { SL.my_seg = s0; SL.my_team = team; SL.my_idx = wg - w; SL.my_T = T; }
+      w += T; team++;
+    }
+    SL.nslab = S;
+  }
+  if (!team_barrier(gbar, s_flag)) return -1;                  // (its __syncthreads also publish SL to the workgroup)
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  return 1;
+}
+
+// After every team has finished its slab (and one more barrier of the whole grid): the kept boxes are the set bits of a
+// bitmap over the ORIGINAL sorted positions; position order is score order, so the output is an ordered compaction of
+// that bitmap.  Every workgroup scans all words for the ranks (n / 64 words: 1563 at N = 100k) and emits its share.
+__device__ __forceinline__ void slab_merge(const u64* kept_bits, int n, const uint32_t* order, int64_t* keep_out, int* keep_cnt, int* s_i) {
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int NB = gridDim.x, wg = blockIdx.x;
+  const int W = (n + 63) >> 6;
+  const int per = (W + kNmsThreads - 1) / kNmsThreads;
+  const int k0 = tid * per < W ? tid * per : W, k1 = (k0 + per < W) ? k0 + per : W;
+  int mine = 0;
+  for (int k = k0; k < k1; k++) mine += __popcll(kept_bits[k]);
+  int incl = mine;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) { const int v = __shfl_up(incl, d); if (lane >= d) incl += v; }
+  __syncthreads();
+  if (lane == 63) s_i[wv] = incl;
+  __syncthreads();
+  int wpre = 0, total = 0;
+#pragma unroll
+  for (int k = 0; k < kNmsWaves; k++) { const int t = s_i[k]; if (k < wv) wpre += t; total += t; }
+  int rank = wpre + incl - mine;
+  for (int k = k0; k < k1; k++) {
+    u64 m = kept_bits[k];
+    if ((k % NB) == wg) {
+      int r = rank;
+      while (m) {
+        const int b = __builtin_ctzll(m);
+        m &= m - 1;
+        const uint32_t p = (uint32_t)(k * 64 + b);
+        keep_out[r++] = order ? (int64_t)order[p] : (int64_t)p;
+      }
+    }
+    rank += __popcll(kept_bits[k]);
+  }
+  if (wg == 0 && tid == 0) stg_agent(keep_cnt, total);
+}
+
 // ------------------------------------------------------------------ the persistent kernel
 // dynamic LDS: [kNmsWaves x WaveLds<G>] (aliased by the resolve state) | chunk list [capmax] u32
 // One workgroup per CU (the LDS footprint allows no second one) = 2 waves per SIMD: let the compiler use the whole
@@ -1149,26 +1374,75 @@ __global__ __launch_bounds__(kNmsThreads) __attribute__((amdgpu_waves_per_eu(1, 
   __shared__ int s_i[16];
   __shared__ int s_flag;
   __shared__ int s_bb[kNmsWaves][4];
+  __shared__ SlabLds s_slab;
   const int tid = threadIdx.x, wv = tid >> 6;
   const int NB = gridDim.x;
+  // the extent of the data from the key kernel's per-workgroup partials (every workgroup reduces them itself)
+  auto data_extent = [&]() -> GridPlan {
+    int bx0 = 0x7fffffff, by0 = 0x7fffffff, bx1 = (int)0x80000000, by1 = (int)0x80000000;
+    for (int i = tid; i < a.nparts; i += kNmsThreads) {
+      const int4 q = reinterpret_cast<const int4*>(a.bbpart)[i];
+      bx0 = min(bx0, q.x); by0 = min(by0, q.y); bx1 = max(bx1, q.z); by1 = max(by1, q.w);
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+      bx0 = min(bx0, __shfl_xor(bx0, d)); by0 = min(by0, __shfl_xor(by0, d));
+      bx1 = max(bx1, __shfl_xor(bx1, d)); by1 = max(by1, __shfl_xor(by1, d));
+    }
+    __syncthreads();
+    if ((tid & 63) == 0) { s_bb[wv][0] = bx0; s_bb[wv][1] = by0; s_bb[wv][2] = bx1; s_bb[wv][3] = by1; }
+    __syncthreads();
+    int bb[4] = {s_bb[0][0], s_bb[0][1], s_bb[0][2], s_bb[0][3]};
+    for (int k = 1; k < kNmsWaves; k++) {
+      bb[0] = min(bb[0], s_bb[k][0]); bb[1] = min(bb[1], s_bb[k][1]); bb[2] = max(bb[2], s_bb[k][2]); bb[3] = max(bb[3], s_bb[k][3]);
+    }
+    return grid_plan(bb);
+  };
+  // ---- independent slabs (grid.h): a single list that falls apart into groups that cannot overlap runs as that many segments
+  TeamBar gbar{a.bar, a.bar + 64, NB, 0, a.abort_flag};      // the whole grid (the barrier line of team 0)
+  bool slab_mode = false;
+  const uint32_t* order0 = a.order;
+  int64_t* keep_out0 = a.keep_out;
+  int* keep_cnt0 = a.keep_cnt;
+  const int n0 = a.n;
+  if constexpr (G::HAS_GRID && GRID) {
+    if (a.slab_cover != nullptr && a.nseg == 1 && a.max_keep <= 0 && a.cull != 0 && a.plan == nullptr && a.bbpart != nullptr) {
+      const GridPlan sp = data_extent();
+      const int st = sp.ok ? slab_setup<G>(a, sp, smem, gbar, &s_flag, s_slab) : 0;
+      if (st < 0) return;
+      if (st > 0) {
+        slab_mode = true;
+        a.rec = a.rec2; a.order = a.order2; a.alive = a.alive2; a.keep_out = nullptr; a.keep_cnt = a.slab_keep;
+        a.nseg = s_slab.nslab; a.capmax = s_slab.cap; a.ecap = s_slab.ecap;
+      }
+      __syncthreads();                                       // the set-up's LDS scratch is free from here on
+    }
+  }
   int nteams = a.nseg < NB ? a.nseg : NB;
   int T = NB / nteams;
   int team = blockIdx.x / T, wg = blockIdx.x - team * T;
   int g_first = team, g_step = nteams, g_last = a.nseg - 1;
+  int bar_line = team;
   long long skip_cost = -1;                            // >= 0: segments at least this expensive belong to a team of their own
-  if (a.plan != nullptr && a.plan[0].w > 0) {          // planned (k_plan_teams): a team on one segment, or one workgroup on a run of small ones
+  bool idle = false;
+  if (slab_mode) {                                     // one team per slab (slab_setup); barrier lines 64.. (line 0 is the grid's)
+    g_step = 1; team = s_slab.my_team; wg = s_slab.my_idx; T = s_slab.my_T; bar_line = 64 + team;
+    if (s_slab.my_seg < 0) { idle = true; g_first = 0; g_last = -1; } else { g_first = g_last = s_slab.my_seg; }
+  } else if (a.plan != nullptr && a.plan[0].w > 0) {   // planned (k_plan_teams): a team on one segment, or one workgroup on a run of small ones
     const int4 pl = a.plan[blockIdx.x];
     if (pl.x < 0) return;
-    g_first = pl.x; g_step = 1; team = pl.y; T = pl.w;
+    g_first = pl.x; g_step = 1; team = pl.y; T = pl.w; bar_line = team;
     if (T == 1) { wg = 0; g_last = pl.x + pl.z; skip_cost = (long long)(unsigned)a.plan[kPlanInfoSlot].x; }
     else { wg = pl.z; g_last = pl.x; }
   } else if (team >= nteams) {
     return;
   }
+  (void)idle;
   WaveLds<G>& L = reinterpret_cast<WaveLds<G>*>(smem)[wv];
   uint32_t* cidx = reinterpret_cast<uint32_t*>(smem + sizeof(WaveLds<G>) * kNmsWaves);
   const int tw = wg * kNmsWaves + wv, ntw = T * kNmsWaves;
-  TeamBar bar{a.bar + (size_t)team * 128, a.bar + (size_t)team * 128 + 64, T, 0, a.abort_flag};
+  TeamBar bar{a.bar + (size_t)bar_line * 128, a.bar + (size_t)bar_line * 128 + 64, T, 0, a.abort_flag};
+  if (!slab_mode && bar_line == 0) bar.epoch = gbar.epoch;   // (a set-up that decided against slabs has used the grid's line already)
 
   const bool prof = a.prof != nullptr && blockIdx.x == 0 && tid == 0;
   u64 t0 = prof ? wall_clock64() : 0ull;
@@ -1190,25 +1464,7 @@ __global__ __launch_bounds__(kNmsThreads) __attribute__((amdgpu_waves_per_eu(1, 
     if constexpr (G::HAS_GRID && GRID) {
       if (grid_on && nr >= kGridMinRows) {           // (a few hundred kept rows: the exhaustive form is the cheaper one)
         if (!grid_built) {                           // first use: sort what is still alive behind the chunk into its cells
-          // the extent of the data from the key kernel's per-workgroup partials (every workgroup reduces them itself)
-          int bx0 = 0x7fffffff, by0 = 0x7fffffff, bx1 = (int)0x80000000, by1 = (int)0x80000000;
-          for (int i = tid; i < a.nparts; i += kNmsThreads) {
-            const int4 q = reinterpret_cast<const int4*>(a.bbpart)[i];
-            bx0 = min(bx0, q.x); by0 = min(by0, q.y); bx1 = max(bx1, q.z); by1 = max(by1, q.w);
-          }
-#pragma unroll
-          for (int d = 32; d >= 1; d >>= 1) {
-            bx0 = min(bx0, __shfl_xor(bx0, d)); by0 = min(by0, __shfl_xor(by0, d));
-            bx1 = max(bx1, __shfl_xor(bx1, d)); by1 = max(by1, __shfl_xor(by1, d));
-          }
-          __syncthreads();
-          if ((tid & 63) == 0) { s_bb[wv][0] = bx0; s_bb[wv][1] = by0; s_bb[wv][2] = bx1; s_bb[wv][3] = by1; }
-          __syncthreads();
-          int bb[4] = {s_bb[0][0], s_bb[0][1], s_bb[0][2], s_bb[0][3]};
-          for (int k = 1; k < kNmsWaves; k++) {
-            bb[0] = min(bb[0], s_bb[k][0]); bb[1] = min(bb[1], s_bb[k][1]); bb[2] = max(bb[2], s_bb[k][2]); bb[3] = max(bb[3], s_bb[k][3]);
-          }
-          gp = grid_plan(bb);
+          gp = data_extent();
           const int st = gp.ok ? grid_build<G>(a, gp, c0, wg, T, bar, &s_flag, s_i, glevels, n_brute) : 2;
           if (st == 1) { aborted = true; return; }
           grid_built = true;
@@ -1258,7 +1514,7 @@ __global__ __launch_bounds__(kNmsThreads) __attribute__((amdgpu_waves_per_eu(1, 
 
   const int plan_chunk = a.cap_first < a.capmax ? a.cap_first : a.capmax;
   for (int g = g_first; g <= g_last; g += g_step) {
-    const int sb = a.seg_begin[g], se = a.seg_end[g];
+    const int sb = slab_mode ? s_slab.segb[g] : a.seg_begin[g], se = slab_mode ? s_slab.sege[g] : a.seg_end[g];
     // (the first segment of a plan entry is always the workgroup's own: a run starts with a small segment, and a big
     //  segment whose team has one member is an entry of its own)
     if (skip_cost >= 0 && g != g_first && plan_cost(se - sb, plan_chunk) >= skip_cost) continue;
@@ -1301,7 +1557,7 @@ __global__ __launch_bounds__(kNmsThreads) __attribute__((amdgpu_waves_per_eu(1, 
       if (serial_begin(bar, &s_flag)) {
         lap(3);
         const u64 ts = (a.prof && tid == 0) ? wall_clock64() : 0ull;
-        nms_resolve(a, g, team, cn, kept, cidx, smem, sizeof(WaveLds<G>) * kNmsWaves, s_i);
+        nms_resolve(a, g, sb, team, cn, kept, cidx, smem, sizeof(WaveLds<G>) * kNmsWaves, s_i);
         serial_end(bar);
         if (a.prof && tid == 0) { atomicAdd(a.prof + 9, wall_clock64() - ts); }
         lap(4);
@@ -1317,6 +1573,15 @@ __global__ __launch_bounds__(kNmsThreads) __attribute__((amdgpu_waves_per_eu(1, 
       // (measured: jumping to the largest chunk when most of a chunk is kept -- sparse data -- is slower, 0.78 -> 0.96 ms at
       //  100k with 18 class offsets: the pair phase grows with the square of the chunk)
       if (cap < a.capmax) { cap *= 2; if (cap > a.capmax) cap = a.capmax; }
+    }
+  }
+  if constexpr (G::HAS_GRID && GRID) {
+    if (slab_mode) {                                   // every slab is done: the kept boxes meet again in score order
+      lap(7);
+      if (!team_barrier(gbar, &s_flag)) return;
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      slab_merge(a.kept_bits, n0, order0, keep_out0, keep_cnt0, s_i);
+      lap(8);
     }
   }
   if (a.prof && tid == 0) { const u64 el = wall_clock64() - t_wg0; atomicMax(a.prof + 22, el); atomicAdd(a.prof + 23, el); atomicAdd(a.prof + 24, 1ull); }
