@@ -60,7 +60,8 @@ int obb_profile_collect(double* ms_sum_host, int64_t* count_host, int n_stages);
 
 /* ------------------------------------------------------------------ NMS ------------------------------ */
 
-/* Scratch bytes for n boxes in nseg segments.  kind: 0 = rotated boxes, 1 = quads, 2 = double-precision quads (merge NMS). */
+/* Scratch bytes for n boxes in nseg segments.  kind: 0 = rotated boxes, 1 = quads, 2 = double-precision quads (merge NMS),
+ * 3 = double-precision rotated boxes (obb_nms_rotated_f64). */
 size_t obb_nms_workspace_bytes(int64_t n, int64_t nseg, int kind);
 
 /*
@@ -81,17 +82,13 @@ int obb_nms_rotated_f32(const float* dets5, const float* scores, int64_t n, floa
                         int64_t* keep_out, int64_t* num_keep, void* ws, size_t ws_bytes, void* stream);
 
 /*
- * The same for a batch of independent segments (images) in one call: what the per-image loop of
- * non_max_suppression_obb (utils/general.py:801-857) does with bs separate obb_nms calls.
- *   seg_id   [n] int32 in [0, nseg)          tie / tie_bits: optional explicit tie-break word (ascending)
- *   max_seg  host-side upper bound on the size of any segment (<= 0: n)
- *   keep_out [n]: segment g's kept indices start at seg_begin_out[g]
- *   num_keep [nseg], seg_begin_out [nseg+1] (may be NULL)
+ * The same for float64 tensors: the reference dispatches double to a double-precision instantiation of the kernel
+ * (AT_DISPATCH_FLOATING_TYPES, nms_rotated_cuda.cu:96; box_iou_rotated_utils.h:333-360 with T = double).  dets5 / scores
+ * are doubles; every IoU is computed in double and compared with the FLOAT threshold of the kernel's signature
+ * (nms_rotated_cuda.cu:14,60).  Workspace: obb_nms_workspace_bytes(n, 1, 3).
  */
-int obb_nms_rotated_batched_f32(const float* dets5, const float* scores, const int32_t* seg_id, const uint32_t* tie,
-                                int tie_bits, int64_t n, int64_t nseg, int64_t max_seg, float iou_thr, int flags,
-                                int64_t max_keep, int64_t* keep_out, int64_t* num_keep, int64_t* seg_begin_out, void* ws,
-                                size_t ws_bytes, void* stream);
+int obb_nms_rotated_f64(const double* dets5, const double* scores, int64_t n, float iou_thr, int flags, int64_t max_keep,
+                        int64_t* keep_out, int64_t* num_keep, void* ws, size_t ws_bytes, void* stream);
 
 /*
  * Quadrilateral NMS.  Replaces nms_rotated_ext.nms_poly (nms_rotated_ext.cpp:42-55 -> poly_nms_cuda,

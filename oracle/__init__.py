@@ -130,7 +130,9 @@ def nms_rotated(dets, scores, thr, ge=False, threads=1):
     if dets.dtype == np.float64:
         d, s = _c(dets, np.float64), _c(scores, np.float64)
         keep = np.empty(len(d), np.int64)
-        k = lib().oracle_nms_rotated_f64(d.reshape(-1), s, len(d), float(thr), int(ge), keep)
+        # the reference's kernels take `const float iou_threshold` (nms_rotated_cuda.cu:15, nms_rotated_cpu.cpp:12): the
+        # double IoU is compared with the FLOAT value of the threshold
+        k = lib().oracle_nms_rotated_f64(d.reshape(-1), s, len(d), float(np.float32(thr)), int(ge), keep)
         return keep[:k].copy()
     d, s = _c(dets, np.float32), _c(scores, np.float32)
     keep = np.empty(len(d), np.int64)

@@ -23,6 +23,13 @@ def test_rotated_iou_device_code_bit_exact(oracle_lib, tmp_path):
     assert "mismatches=0 cull_violations=0 ub_violations=0" in out, out
 
 
+def test_rotated_iou_double_device_code_bit_exact(oracle_lib, tmp_path):
+    """csrc/riou64_device.h (the float64 NMS policy RotGeom64) against the oracle's double flavour, bit for bit."""
+    rc, out = _build_and_run("host_check_riou64.cpp", "hc_riou64", ["600000", "44"], tmp_path)
+    assert rc == 0, out
+    assert "mismatches64=0" in out, out
+
+
 def test_quad_iou_device_code_bit_exact(oracle_lib, tmp_path):
     rc, out = _build_and_run("host_check_piou.cpp", "hc_piou", ["400000", "43"], tmp_path)
     assert rc == 0, out

@@ -147,24 +147,50 @@ def test_obb_nms_wrapper_small_box_filter(dev, oracle_lib):
     assert isinstance(inds4, np.ndarray) and np.array_equal(inds4, ref)
 
 
-def test_nms_rotated_float64_rule(dev, oracle_lib):
-    """float64 boxes (nms_rotated_cuda.cu:96 dispatches double): order = the double scores' (stable), IoU decisions in float32
-    on the rounded boxes.  Exact against the float32 oracle under that rule; equal to the double-precision scan on this
-    seeded, well-conditioned set (the two can differ only for an IoU within float32 rounding of the threshold)."""
+def test_nms_rotated_float64_is_double_precision(dev, oracle_lib):
+    """float64 boxes (nms_rotated_cuda.cu:96 dispatches double): obb_nms_rotated_f64 orders by the double scores and decides
+    every pair with the double-precision IoU (policy RotGeom64) -- the oracle's double scan (pinned to the reference's own
+    header: golden riou_ref_dev_f64), index for index.  (a) a well-conditioned detector-like set; (b) a set where float32
+    cannot work: coordinates around 3e7 (one float32 ulp = 2 px) with sub-pixel structure, near-identical boxes whose IoU
+    differs from the threshold in the 9th digit, scores that are equal in float32 -- the float32 scan of the rounded boxes
+    gives a DIFFERENT kept list there (asserted), the double path must still equal the double oracle; (c) the wrapper's
+    small-box filter and empty / all-small inputs in float64."""
     from yolov5_obb_amd import nms_rotated_ext
+    from yolov5_obb_amd.utils.nms_rotated import obb_nms
+    g = torch.Generator().manual_seed(1)
     dets, scores = synth.s_clustered(6000, 120, 9)
-    d64 = dets.double() + 1e-9 * torch.randn(dets.shape, dtype=torch.float64, generator=torch.Generator().manual_seed(1))
+    d64 = dets.double() + 1e-9 * torch.randn(dets.shape, dtype=torch.float64, generator=g)
     s64 = synth.tie_free(scores).double()
     s64[100] = s64[200] + 1e-12                                   # equal in float32, ordered in double
-    got = nms_rotated_ext.nms_rotated(d64.to(dev), s64.to(dev), 0.4).cpu().numpy()
-    order = np.argsort(-s64.numpy(), kind="stable")
-    n = len(order)
-    ref32 = oracle.nms_rotated(d64.float().numpy()[order], np.arange(n, 0, -1, dtype=np.float32), 0.4)
-    assert np.array_equal(got, order[ref32])
-    ref64 = oracle.nms_rotated(d64.numpy(), s64.numpy(), 0.4)
-    assert np.array_equal(got, ref64)
-    _, inds = __import__("yolov5_obb_amd.utils.nms_rotated", fromlist=["obb_nms"]).obb_nms(d64.to(dev), s64.to(dev), 0.4)
-    assert inds.dtype == torch.int64 and len(inds) == len(got)
+    for thr in (0.4, 0.1):
+        got = nms_rotated_ext.nms_rotated(d64.to(dev), s64.to(dev), thr).cpu().numpy()
+        assert np.array_equal(got, oracle.nms_rotated(d64.numpy(), s64.numpy(), thr, threads=8)), thr
+    # (b)
+    n = 5000
+    base, sc = synth.s_clustered(n, 60, 13, extent=300.0)
+    hard = base.double()
+    hard[:, :2] += 3.0e7 + torch.rand(n, 2, dtype=torch.float64, generator=g)            # sub-ulp structure at 3e7
+    hard[:, 2:4] *= 1.0 + 1e-9 * torch.randn(n, 2, dtype=torch.float64, generator=g)
+    hs = synth.tie_free(sc).double() * (1.0 + 1e-13 * torch.arange(n, dtype=torch.float64))
+    ref64 = oracle.nms_rotated(hard.numpy(), hs.numpy(), 0.4, threads=8)
+    order = np.argsort(-hs.numpy(), kind="stable")
+    ref32 = order[oracle.nms_rotated(hard.float().numpy()[order], np.arange(n, 0, -1, dtype=np.float32), 0.4, threads=8)]
+    assert not np.array_equal(ref64, ref32)                        # the set discriminates: float32 decides differently here
+    for _ in range(2):
+        got = nms_rotated_ext.nms_rotated(hard.to(dev), hs.to(dev), 0.4).cpu().numpy()
+        assert np.array_equal(got, ref64)
+    # (c)
+    small = d64.clone()
+    pick = torch.randperm(len(small), generator=g)[:500]
+    small[pick, 3] = 0.0005
+    keep_mask = small[:, 2:4].min(1)[0] >= 0.001
+    idx = torch.nonzero(keep_mask).squeeze(1).numpy()
+    want = idx[oracle.nms_rotated(small[keep_mask].numpy(), s64[keep_mask].numpy(), 0.4, threads=8)]
+    _, inds = obb_nms(small.to(dev), s64.to(dev), 0.4)
+    assert inds.dtype == torch.int64 and np.array_equal(inds.cpu().numpy(), want)
+    small[:, 3] = 0.0001
+    assert len(obb_nms(small.to(dev), s64.to(dev), 0.4)[1]) == 0
+    assert len(nms_rotated_ext.nms_rotated(d64[:0].to(dev), s64[:0].to(dev), 0.4)) == 0
 
 
 def test_small_grid_fallback_gives_the_same_result(dev, oracle_lib):

@@ -2,9 +2,17 @@
 Development aid; bench.py is the contract."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import ctypes as C
 import torch
 from tests import synth
-from yolov5_obb_amd import nms_rotated_ext
+from yolov5_obb_amd import _lib, nms_rotated_ext
+L = _lib.lib()
+
+
+def stages():
+    ms = (C.c_double * 8)(); cnt = (C.c_int64 * 8)()
+    L.obb_profile_collect(C.cast(ms, C.c_void_p), C.cast(cnt, C.c_void_p), 8)
+    return [ms[i] / max(1, cnt[i]) for i in range(8)]
 
 dev = torch.device("cuda:0")
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 100000
@@ -22,8 +30,14 @@ for name, d, s in regimes(N):
     k = nms_rotated_ext.nms_rotated(d, s, 0.4)
     torch.cuda.synchronize()
     ts = []
-    for _ in range(5):
+    for _ in range(15):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(); k = nms_rotated_ext.nms_rotated(d, s, 0.4); e1.record(); torch.cuda.synchronize()
         ts.append(e0.elapsed_time(e1))
-    print(f"{name:24s} n={len(d):7d} kept={len(k):6d}  min {min(ts):8.3f} ms  med {sorted(ts)[len(ts)//2]:8.3f} ms", flush=True)
+    L.obb_profile_enable(1)
+    for _ in range(5):
+        k = nms_rotated_ext.nms_rotated(d, s, 0.4)
+    torch.cuda.synchronize()
+    st = stages()
+    L.obb_profile_enable(0)
+    print(f"{name:24s} n={len(d):7d} kept={len(k):6d}  min {min(ts):8.3f} ms  med {sorted(ts)[len(ts)//2]:8.3f} ms | sort {st[5]*1e3:6.1f} prep {st[6]*1e3:6.1f} steps {st[7]*1e3:7.1f} us", flush=True)

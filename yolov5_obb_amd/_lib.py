@@ -33,8 +33,7 @@ SIGNATURES = {
     "obb_profile_collect": (_i32, [_vp, _vp, _i32]),
     "obb_nms_workspace_bytes": (_sz, [_i64, _i64, _i32]),
     "obb_nms_rotated_f32": (_i32, [_vp, _vp, _i64, _f32, _i32, _i64, _vp, _vp, _vp, _sz, _vp]),
-    "obb_nms_rotated_batched_f32": (_i32, [_vp, _vp, _vp, _vp, _i32, _i64, _i64, _i64, _f32, _i32, _i64, _vp, _vp, _vp,
-                                           _vp, _sz, _vp]),
+    "obb_nms_rotated_f64": (_i32, [_vp, _vp, _i64, _f32, _i32, _i64, _vp, _vp, _vp, _sz, _vp]),
     "obb_nms_poly_f32": (_i32, [_vp, _i64, _i64, _f32, _i64, _vp, _vp, _vp, _sz, _vp]),
     "obb_merge_nms_poly_f64": (_i32, [_vp, _i64, _vp, _vp, _i64, C.c_double, _vp, _vp, _vp, _sz, _vp]),
     "obb_task1_parse_tiles": (_i64, [_vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -9,9 +9,21 @@
 #include <hip/hip_runtime.h>
 #include "obb_device.h"
 #include "riou_device.h"
+#include "riou64_device.h"
 #include "piou_device.h"
 
 namespace obb {
+
+// Two rows of the hot pair loops per instruction: gfx950 issues v_pk_{add,mul}_f32 on a pair of fp32 values at the rate of
+// the scalar forms (the loops are VALU-issue bound: ~16 instructions per row test, 64 columns wide).  ColPk = the column
+// box of a lane with every component doubled, built once per tile; the row values arrive as pairs of v_readlane results.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+struct ColPk { f32x2 x, y, z, w; };
+__device__ __forceinline__ ColPk col_splat(const float4& c) {
+  ColPk p;
+  p.x = f32x2{c.x, c.x}; p.y = f32x2{c.y, c.y}; p.z = f32x2{c.z, c.z}; p.w = f32x2{c.w, c.w};
+  return p;
+}
 
 struct RotGeom {
   static constexpr int RECQ = 4;
@@ -42,6 +54,18 @@ struct RotGeom {
     const float rs = a.z + b.z;
     const float d2 = dx * dx + dy * dy;
     return (d2 > rs * rs) && (fminf(a.w, b.w) >= 2.34e-9f * d2);
+  }
+  // the same test for two row boxes (components interleaved: ax = {row0.x, row1.x}, ...) against the column box c: the
+  // same operations in the same order on each half, no contraction -- bit-identical decisions
+  static constexpr bool PACKED = true;
+  static __device__ __forceinline__ void cheap_reject2(f32x2 ax, f32x2 ay, f32x2 az, f32x2 aw, const ColPk& c, bool& r0, bool& r1) {
+    const f32x2 dx = c.x - ax, dy = c.y - ay;
+    const f32x2 rs = az + c.z;
+    const f32x2 d2 = dx * dx + dy * dy;
+    const f32x2 r2 = rs * rs;
+    const f32x2 lim = d2 * 2.34e-9f;
+    r0 = (d2.x > r2.x) && (fminf(aw.x, c.w.x) >= lim.x);
+    r1 = (d2.y > r2.y) && (fminf(aw.y, c.w.y) >= lim.y);
   }
   // Two-stage decision of "IoU > thr" for the pairs that survive the hot loop.
   //   classify_quick  registers only: separating-axis reject, area-ratio bound, the slab / bounding-box bounds
@@ -93,6 +117,7 @@ struct QuadGeom {
   // disjoint quads the terms cancel only up to rounding (measured up to 0.06 at |coord| ~ 5000),
   // so "IoU == 0" cannot be predicted from a bounding-box test.  No reject: every pair is clipped.
   static __device__ __forceinline__ bool cheap_reject(const float4&, const float4&) { return false; }
+  static constexpr bool PACKED = false;
   static OBB_HD QuadFeat unpack(const float4& q0, const float4& q1) {
     QuadFeat f;
     f.x[0] = q0.x; f.y[0] = q0.y; f.x[1] = q0.z; f.y[1] = q0.w;
@@ -128,6 +153,7 @@ struct QuadGeom64 {
   static __device__ __forceinline__ bool cheap_reject(const float4& a, const float4& b) {
     return !(fminf(a.z, b.z) > fmaxf(a.x, b.x) && fminf(a.w, b.w) > fmaxf(a.y, b.y));
   }
+  static constexpr bool PACKED = false;
   static __device__ __forceinline__ int classify_quick(const float4*, const float4*, double, bool) { return 2; }
   static __device__ __forceinline__ int classify_full(const float4*, const float4*, double) { return 2; }
   static __device__ __forceinline__ void hbb(const QuadFeatT<double>& f, double* x1, double* y1, double* x2, double* y2) {
@@ -163,6 +189,61 @@ struct QuadGeom64 {
         const double iou = quad_iou_t<32, false, double>(A, B, base, base + 10 * 32, base + 20 * 32, base + 30 * 32);
         hit = !(iou <= thr);
       }
+    }
+    return hit;
+  }
+};
+
+// Double-precision rotated boxes: float64 tensors (nms_rotated_cuda.cu:96 dispatches double; the kernel compares the double
+// IoU with the FLOAT threshold of its signature, nms_rotated_cuda.cu:14,60).
+//   q0 = {x, y, r, ms^2} in fp32 for the hot loop -- the centre rounded to fp32, r = the inflated circumradius rounded UP
+//        plus the rounding of the centre, ms^2 = short side squared rounded DOWN: the circle test never rejects a pair the
+//        double-precision test of the same kind would keep, and its conditioning guard is the float flavour's (stricter
+//        than double arithmetic needs: it only ever rejects less);
+//   q1..q4 = the doubles {x, y, sh, cw, ch, sw, area, 0} (riou64_device.h).
+// No cheap decision stages: every pair that passes the circle test runs the exact double clip (two half-wave passes over
+// the wave's 12 KB scratch block, like QuadGeom64).
+struct RotGeom64 {
+  static constexpr int RECQ = 5;
+  static constexpr int SCR = 48;   // 32 lanes x 48 doubles
+  static constexpr bool HAS_FAST = false;
+  static constexpr bool HAS_GRID = false;
+  template <class A> static __device__ __forceinline__ double thr_of(const A& a) { return a.thr64; }
+  static __device__ __forceinline__ bool cheap_reject(const float4& a, const float4& b) { return RotGeom::cheap_reject(a, b); }
+  static constexpr bool PACKED = true;
+  static __device__ __forceinline__ void cheap_reject2(f32x2 ax, f32x2 ay, f32x2 az, f32x2 aw, const ColPk& c, bool& r0, bool& r1) {
+    RotGeom::cheap_reject2(ax, ay, az, aw, c, r0, r1);
+  }
+  static __device__ __forceinline__ int classify_quick(const float4*, const float4*, double, bool) { return 2; }
+  static __device__ __forceinline__ int classify_full(const float4*, const float4*, double) { return 2; }
+  static __device__ __forceinline__ void pack(double x, double y, double w, double h, double a, float4* q) {
+    const RBoxFeat64 f = rbox_make_feat64(x, y, w, h, a);
+    const double r = sqrt(w * w + h * h) * 0.5005 + (fabs(x) + fabs(y)) * 1.2e-7;
+    float rf = (float)r;
+    if ((double)rf < r) rf = f32_next_up(rf);
+    const double ms = fmin(fabs(w), fabs(h)), ms2 = ms * ms;
+    float mf = (float)ms2;
+    if ((double)mf > ms2) mf = f32_next_down(mf);
+    q[0] = make_float4((float)x, (float)y, rf, mf);
+    double2* d = reinterpret_cast<double2*>(q + 1);
+    d[0] = make_double2(f.x, f.y); d[1] = make_double2(f.sh, f.cw); d[2] = make_double2(f.ch, f.sw); d[3] = make_double2(f.area, 0.0);
+  }
+  static __device__ __forceinline__ RBoxFeat64 unpack(const float4* r) {
+    const double2* d = reinterpret_cast<const double2*>(r + 1);
+    RBoxFeat64 f;
+    const double2 a = d[0], b = d[1], c = d[2], e = d[3];
+    f.x = a.x; f.y = a.y; f.sh = b.x; f.cw = b.y; f.ch = c.x; f.sw = c.y; f.area = e.x;
+    return f;
+  }
+  static __device__ __forceinline__ bool hit_exact(const float4* ra, const float4* rb, double thr, float* scr) {
+    const int lane = threadIdx.x & 63;
+    double* base = reinterpret_cast<double*>(scr - lane) + (lane & 31);
+    const RBoxFeat64 A = unpack(ra), B = unpack(rb);
+    bool hit = false;
+    int nhalf = 2;
+    asm volatile("" : "+s"(nhalf));   // opaque trip count: the two passes must stay two passes (lanes l and l + 32 share a column)
+    for (int half = 0; half < nhalf; half++) {
+      if ((lane >> 5) == half) hit = rbox_iou_f64<32>(A, B, base, base + 24 * 32) > thr;   // strict, nms_rotated_cuda.cu:60
     }
     return hit;
   }

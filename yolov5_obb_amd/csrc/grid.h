@@ -115,10 +115,16 @@ OBB_HD float grid_query_halfwidth(const GridPlan& p, int L, float x, float y, fl
 // slab.  Two boxes in different slabs have an unmarked bin between their centres, so their circles are apart by more than
 // the margin RotGeom::cheap_reject needs -- the exhaustive scan would reject the pair in its hot loop, provided both boxes
 // are well conditioned for ANY partner inside the data's bounding box (the first half of grid_is_brute).  One box that is
-// not (or is not finite) switches the decomposition off for the call.
-constexpr int kSlabBins = 4096;
+// not (or is not finite) switches the decomposition off for the call.  With the gate below a box touches at most
+// kSlabBins / 32 + 2 bins.
+constexpr int kSlabBins = 1024;
 constexpr int kSlabWords = kSlabBins / 32;
+constexpr int kSlabCopies = 4;                     // the prep kernel's blocks OR into copy (block & 3): a quarter of the same-address traffic
 constexpr int kMaxSlabs = 64;
+constexpr int kBbInts = 8;                         // per-block partial of the key kernel: min x, min y, max x, max y (ordered ints), max w^2+h^2 (float bits), 3 spare
+// The decomposition is only looked for when the data is much wider than its largest box (xr > 64 half-diagonals): a single
+// image's detections never qualify and pay nothing; two classes 4096 px apart do unless their boxes are huge.
+OBB_HD bool slab_gate(const GridPlan& p, float max_w2h2) { return p.ok && (p.xr * p.xr > 1024.f * max_w2h2); }
 constexpr int kSlabMaxSeg = 16384;                 // a slab larger than this: the call stays one list (index path)
 
 OBB_HD float slab_inv_bin(const GridPlan& p) { return (p.ok && p.xr > 0.f) ? (float)kSlabBins / p.xr : 0.f; }

@@ -104,11 +104,13 @@ __global__ void k_make_keys32(const float* __restrict__ scores, int score_stride
   for (long long k = i; k < n_bar16; k += (long long)gridDim.x * blockDim.x) bar16[k] = make_uint4(0u, 0u, 0u, 0u);
   for (long long k = i; k < n_grid16; k += (long long)gridDim.x * blockDim.x) grid16[k] = make_uint4(0u, 0u, 0u, 0u);   // GridMeta + slot counters
   int bx0 = 0x7fffffff, by0 = 0x7fffffff, bx1 = (int)0x80000000, by1 = (int)0x80000000;
+  int d2 = 0;                                          // largest w^2 + h^2 of the block, as float bits (>= 0: ordered like ints)
   if (i < n) {
     uint32_t k = score_desc_key(scores[(size_t)i * score_stride]);
     bool ok = true;
+    float w = 0.f, h = 0.f;
+    if (drop_small || bbpart != nullptr) { w = dets5[(size_t)i * 5 + 2]; h = dets5[(size_t)i * 5 + 3]; }
     if (drop_small) {
-      float w = dets5[(size_t)i * 5 + 2], h = dets5[(size_t)i * 5 + 3];
       float mn = (h < w) ? h : w;
       if (mn < 0.001f) { k = 0xFFFFFFFFu; ok = false; }
     }
@@ -119,11 +121,18 @@ __global__ void k_make_keys32(const float* __restrict__ scores, int score_stride
       // (grid.h), one partial per block, reduced by the blocks of the prep kernel (no atomics)
       const float x = dets5[(size_t)i * 5], y = dets5[(size_t)i * 5 + 1];
       if ((x - x == 0.f) && (y - y == 0.f)) { bx0 = bx1 = grid_f2o(x); by0 = by1 = grid_f2o(y); }
+      const float q = w * w + h * h;
+      if (q - q == 0.f) d2 = __float_as_int(q);
     }
   }
   if (bbpart != nullptr) {
+    int d2b = d2, dummy = d2;
     block_minmax4(bx0, by0, bx1, by1, s_red);
-    if (threadIdx.x == 0) { int* o = bbpart + (size_t)blockIdx.x * 4; o[0] = bx0; o[1] = by0; o[2] = bx1; o[3] = by1; }
+    { int lo0 = 0x7fffffff, lo1 = 0x7fffffff; block_minmax4(lo0, lo1, d2b, dummy, s_red); }
+    if (threadIdx.x == 0) {
+      int* o = bbpart + (size_t)blockIdx.x * kBbInts;
+      o[0] = bx0; o[1] = by0; o[2] = bx1; o[3] = by1; o[4] = d2b; o[5] = o[6] = o[7] = 0;
+    }
   }
 }
 
@@ -169,13 +178,16 @@ struct GridDev {
 };
 
 // the extent of the data from the key kernel's per-block partials (every block reduces them itself: a few hundred int4)
-__device__ __forceinline__ GridPlan plan_from_partials(const int* __restrict__ bbpart, int nparts, int (*s_red)[4]) {
-  int bx0 = 0x7fffffff, by0 = 0x7fffffff, bx1 = (int)0x80000000, by1 = (int)0x80000000;
+__device__ __forceinline__ GridPlan plan_from_partials(const int* __restrict__ bbpart, int nparts, int (*s_red)[4], float* max_w2h2) {
+  int bx0 = 0x7fffffff, by0 = 0x7fffffff, bx1 = (int)0x80000000, by1 = (int)0x80000000, d2 = 0, d2b = 0;
   for (int i = threadIdx.x; i < nparts; i += blockDim.x) {
-    const int4 q = reinterpret_cast<const int4*>(bbpart)[i];
+    const int4 q = reinterpret_cast<const int4*>(bbpart)[2 * i];
     bx0 = min(bx0, q.x); by0 = min(by0, q.y); bx1 = max(bx1, q.z); by1 = max(by1, q.w);
+    d2 = max(d2, bbpart[(size_t)i * kBbInts + 4]);
   }
   block_minmax4(bx0, by0, bx1, by1, s_red);
+  { int lo0 = 0x7fffffff, lo1 = 0x7fffffff; d2b = d2; block_minmax4(lo0, lo1, d2, d2b, s_red); }
+  *max_w2h2 = __int_as_float(d2);
   const int bb[4] = {bx0, by0, bx1, by1};
   return grid_plan(bb);
 }
@@ -189,17 +201,12 @@ __global__ __launch_bounds__(256) void k_prep_rot(const float* __restrict__ dets
   __shared__ int s_red[16][4];
   __shared__ uint32_t s_cover[kSlabWords];
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
-  GridPlan gp = {};
-  float inv = 0.f;
-  if (slab_cover != nullptr) {
-    for (int k = threadIdx.x; k < kSlabWords; k += blockDim.x) s_cover[k] = 0u;
-    gp = plan_from_partials(bbpart, nparts, s_red);          // (contains the barriers that order the zeroing above)
-    inv = slab_inv_bin(gp);
-  }
   bool ok = false, bad = false;
+  float x = 0.f, y = 0.f, r = 0.f, ms2 = 0.f;
   if (p < n) {
     const float* d = dets5 + (size_t)order[p] * 5;
-    float x = d[0], y = d[1], w = d[2], h = d[3], a = d[4];
+    float w = d[2], h = d[3], a = d[4];
+    x = d[0]; y = d[1];
     RBoxFeat f = rbox_make_feat(x, y, w, h, a);
     float4 q[4];
     RotGeom::pack(f, q);
@@ -207,30 +214,86 @@ __global__ __launch_bounds__(256) void k_prep_rot(const float* __restrict__ dets
     for (int k = 0; k < 4; k++) rec[(size_t)p * 4 + k] = q[k];
     float mn = (h < w) ? h : w;
     ok = !(drop_small && mn < 0.001f);
-    if (slab_cover != nullptr && ok) {
-      if (!slab_box_ok(gp, q[0].x, q[0].y, q[0].z, q[0].w)) bad = true;
-      else {
-        const float hw = slab_halfwidth(gp, x, f.r);
-        const int b0 = slab_bin(x - hw, gp.x0, inv), b1 = slab_bin(x + hw, gp.x0, inv);
-        for (int wd = b0 >> 5; wd <= (b1 >> 5); wd++) {
-          const int lo = max(b0, wd * 32) & 31, hi = min(b1, wd * 32 + 31) & 31;
-          const uint32_t m = (hi == 31 ? 0xffffffffu : ((1u << (hi + 1)) - 1u)) & ~((1u << lo) - 1u);
-          if ((s_cover[wd] & m) != m) atomicOr(&s_cover[wd], m);
-        }
-      }
-    }
+    r = q[0].z; ms2 = q[0].w;
   }
   const u64 m = __ballot(ok);
   if ((threadIdx.x & 63) == 0 && (p & ~63) < n) alive[p >> 6] = m;
   if (p < 8) alive[((n + 63) >> 6) + p] = 0ull;      // guard words behind the last box (the bitmap is not memset)
-  if (slab_cover != nullptr) {
-    const int anybad = __syncthreads_or(bad ? 1 : 0);
-    if (anybad && threadIdx.x == 0) atomicOr(slab_flag, 1);
-    for (int k = threadIdx.x; k < kSlabWords; k += blockDim.x) {
-      const uint32_t v = s_cover[k];
-      if (v && (__hip_atomic_load(slab_cover + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & v) != v) atomicOr(slab_cover + k, v);
+  if (slab_cover == nullptr) return;
+  // ---- independent slabs (grid.h): is the data wide enough to look for them at all (slab_flag[2], written by block 0;
+  // every block derives the same answer from the same partials)?  If so, the x bins this block's boxes touch, first in
+  // a bitmap of the block in LDS, then OR-ed into one of kSlabCopies global copies
+  float max_w2h2 = 0.f;
+  const GridPlan gp = plan_from_partials(bbpart, nparts, s_red, &max_w2h2);
+  const bool gate = slab_gate(gp, max_w2h2);
+  if (blockIdx.x == 0 && threadIdx.x == 0) slab_flag[2] = gate ? 1 : 0;
+  if (!gate) return;
+  for (int k = threadIdx.x; k < kSlabWords; k += blockDim.x) s_cover[k] = 0u;
+  __syncthreads();
+  const float inv = slab_inv_bin(gp);
+  if (ok) {
+    if (!slab_box_ok(gp, x, y, r, ms2)) bad = true;
+    else {
+      const float hw = slab_halfwidth(gp, x, r);
+      const int b0 = slab_bin(x - hw, gp.x0, inv), b1 = slab_bin(x + hw, gp.x0, inv);
+      for (int wd = b0 >> 5; wd <= (b1 >> 5); wd++) {
+        const int lo = max(b0, wd * 32) & 31, hi = min(b1, wd * 32 + 31) & 31;
+        const uint32_t mk = (hi == 31 ? 0xffffffffu : ((1u << (hi + 1)) - 1u)) & ~((1u << lo) - 1u);
+        if ((s_cover[wd] & mk) != mk) atomicOr(&s_cover[wd], mk);
+      }
     }
   }
+  const int anybad = __syncthreads_or(bad ? 1 : 0);
+  if (anybad && threadIdx.x == 0) atomicOr(slab_flag, 1);
+  uint32_t* dst = slab_cover + (size_t)(blockIdx.x % kSlabCopies) * kSlabWords;
+  for (int k = threadIdx.x; k < kSlabWords; k += blockDim.x) {
+    const uint32_t v = s_cover[k];
+    if (v && (__hip_atomic_load(dst + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & v) != v) atomicOr(dst + k, v);
+  }
+}
+
+// ---- float64 rotated boxes (RotGeom64): 64-bit keys from the double scores, records from the double boxes
+__device__ __forceinline__ uint64_t score_desc_key64(double s) {
+  uint64_t u = (uint64_t)__double_as_longlong(s);
+  uint64_t k;
+  if (s != s) k = ~0ull;                                   // NaN first (torch's order), as score_desc_key
+  else {
+    if (s == 0.0) u = 0ull;                                // -0 == +0
+    k = (u & 0x8000000000000000ull) ? ~u : (u | 0x8000000000000000ull);
+  }
+  return ~k;
+}
+__global__ void k_make_keys_f64(const double* __restrict__ scores, const double* __restrict__ dets5, int drop_small, int n,
+                                uint64_t* __restrict__ keys, uint32_t* __restrict__ vals, int* seg_begin, int* seg_end, int* keep_cnt) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0) { seg_begin[0] = 0; seg_end[0] = n; keep_cnt[0] = 0; }
+  if (i >= n) return;
+  uint64_t k = score_desc_key64(scores[i]);
+  if (drop_small) {
+    const double w = dets5[(size_t)i * 5 + 2], h = dets5[(size_t)i * 5 + 3];
+    const double mn = (h < w) ? h : w;
+    if (mn < 0.001) k = ~0ull;                             // nms_rotated_wrapper.py:32, compared in the tensor's dtype
+  }
+  keys[i] = k;
+  vals[i] = (uint32_t)i;
+}
+__global__ __launch_bounds__(256) void k_prep_rot64(const double* __restrict__ dets5, const uint32_t* __restrict__ order, int drop_small, int n,
+                                                    float4* __restrict__ rec, u64* __restrict__ alive) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  bool ok = false;
+  if (p < n) {
+    const double* d = dets5 + (size_t)order[p] * 5;
+    const double x = d[0], y = d[1], w = d[2], h = d[3], a = d[4];
+    float4 q[RotGeom64::RECQ];
+    RotGeom64::pack(x, y, w, h, a, q);
+#pragma unroll
+    for (int k = 0; k < RotGeom64::RECQ; k++) rec[(size_t)p * RotGeom64::RECQ + k] = q[k];
+    const double mn = (h < w) ? h : w;
+    ok = !(drop_small && mn < 0.001);
+  }
+  const u64 m = __ballot(ok);
+  if ((threadIdx.x & 63) == 0 && (p & ~63) < n) alive[p >> 6] = m;
+  if (p < 8) alive[((n + 63) >> 6) + p] = 0ull;      // guard words behind the last box (the bitmap is not memset)
 }
 
 __global__ void k_prep_quad(const float* __restrict__ polys, int stride, const uint32_t* __restrict__ order, int n,
@@ -386,7 +449,7 @@ static int carve(void* base, int64_t n, int64_t nseg, int recq, int C, Carve* cv
   cv->abort_flag = cv->bar + (size_t)kMaxTeams * 128;
   cv->nrows = cv->abort_flag + 64;
   cv->nedges = cv->nrows + kMaxTeams;
-  cv->prof = (u64*)take(32 * 8);
+  cv->prof = (u64*)take(48 * 8);
   cv->plan = (int4*)take((size_t)kMaxTeams * 16);
   cv->seg_begin = (int*)take(ns * 4); cv->seg_end = (int*)take(ns * 4);
   cv->keep_cnt = (int*)take(ns * 4);
@@ -399,17 +462,17 @@ static int carve(void* base, int64_t n, int64_t nseg, int recq, int C, Carve* cv
   if (recq == RotGeom::RECQ && nseg == 1 && n >= kGridMinN) {
     const uint32_t M = grid_slots(n);
     cv->grid.mask = M - 1;
-    const size_t slab_zero = align_up((size_t)kSlabWords * 4 + 64);
+    const size_t slab_zero = align_up((size_t)kSlabCopies * kSlabWords * 4 + 64);
     cv->grid_zero_bytes = align_up(sizeof(GridMeta)) + slab_zero + ((size_t)M + 4) * 4;
     char* z = take(cv->grid_zero_bytes);
     cv->grid.meta = (GridMeta*)z;
     cv->grid.slab_cover = (uint32_t*)(z ? z + align_up(sizeof(GridMeta)) : nullptr);
-    cv->grid.slab_flag = (int*)(z ? z + align_up(sizeof(GridMeta)) + (size_t)kSlabWords * 4 : nullptr);
+    cv->grid.slab_flag = (int*)(z ? z + align_up(sizeof(GridMeta)) + (size_t)kSlabCopies * kSlabWords * 4 : nullptr);
     cv->grid.cnt = (int*)(z ? z + align_up(sizeof(GridMeta)) + slab_zero : nullptr);
     cv->grid.start = (int*)take(((size_t)M + 4) * 4);
     cv->grid.wsum = (int*)take((size_t)1024 * 4);
     cv->grid.nparts = (int)((nn + 255) / 256);
-    cv->grid.bbpart = (int*)take((size_t)cv->grid.nparts * 16);
+    cv->grid.bbpart = (int*)take((size_t)cv->grid.nparts * kBbInts * 4);
     cv->grid.sorted = (float4*)take(nn * 16);
     cv->grid.ulist = (uint32_t*)take(nn * 4);
     const size_t n2 = nn + 64 * (size_t)kMaxSlabs;            // every slab starts on a 64-position boundary
@@ -481,7 +544,7 @@ static int nms_steps(int kind, NmsArgs& a, const Carve& cv, int64_t nseg, int64_
   if (phase_prof < 0) { const char* e = getenv("OBB_NMS_PHASE_PROF"); phase_prof = (e && atoi(e)) ? 1 : 0; }
   a.prof = nullptr;
   if (phase_prof) {   // development aid: print the previous call's phase times (synchronises!)
-    u64 h[32];
+    u64 h[48];
     if (hipMemcpy(h, cv.prof, sizeof h, hipMemcpyDeviceToHost) == hipSuccess && h[6] > 0 && h[6] < (1ull << 40)) {
       fprintf(stderr, "[nms phases, wg0, us] select %.1f pairs %.1f wait-resolve %.1f cross %.1f barrier %.1f steps %llu | resolve (any wg) %.1f rounds %llu [first round %.1f other rounds %.1f output %.1f]\n",
               h[1] * 0.01, h[2] * 0.01, h[3] * 0.01, h[5] * 0.01, h[0] * 0.01, h[6], h[9] * 0.01, h[11], h[12] * 0.01, h[13] * 0.01, h[14] * 0.01);
@@ -490,8 +553,10 @@ static int nms_steps(int kind, NmsArgs& a, const Carve& cv, int64_t nseg, int64_
       fprintf(stderr, "    workgroups: %llu, busy time max %.1f us, mean %.1f us\n", h[24], h[22] * 0.01, h[24] ? h[23] * 0.01 / h[24] : 0.0);
       fprintf(stderr, "    cross, wave 0: items %llu row-loops / scans %.1f us, stage-1 drains %llu = %.1f us | exhaustive: stage-2 drains %llu = %.1f us | indexed: per-item setup %.1f us, blocks %llu, queued pairs %llu, parts (sum over steps) %llu\n",
               h[21], h[16] * 0.01, h[19], h[17] * 0.01, h[20], h[18] * 0.01, h[18] * 0.01, h[20], h[15], h[10]);
+      fprintf(stderr, "    pairs, wg0 wave 0: items %llu = %.1f us (loads %.1f), stage-1a drains %llu = %.1f us, stage-1b drains %llu = %.1f us, exact drains %llu = %.1f us | slab set-up %.1f us, merge %.1f us (wg0)\n",
+              h[32], h[33] * 0.01, h[40] * 0.01, h[34], h[35] * 0.01, h[36], h[37] * 0.01, h[38], h[39] * 0.01, h[41] * 0.01, h[8] * 0.01);
     }
-    if (hipMemsetAsync(cv.prof, 0, 32 * 8, st) != hipSuccess) return OBB_ERR_LAUNCH;
+    if (hipMemsetAsync(cv.prof, 0, 48 * 8, st) != hipSuccess) return OBB_ERR_LAUNCH;
     a.prof = cv.prof;
   }
   const int nb = nms_grid(nseg, n_slots, a.cap_first);
@@ -501,6 +566,7 @@ static int nms_steps(int kind, NmsArgs& a, const Carve& cv, int64_t nseg, int64_
     if (!(pre & kNmsPlanned)) k_plan_teams<<<1, 1024, 0, st>>>(a.seg_begin, a.seg_end, (int)nseg, (int)nb, c1, cv.plan);
     a.plan = cv.plan;
   }
+  if (kind == 3) return launch_persist<RotGeom64, false>(a, (unsigned)nb, st);
   if (kind == 2) return launch_persist<QuadGeom64, false>(a, (unsigned)nb, st);
   if (kind == 1) return launch_persist<QuadGeom, false>(a, (unsigned)nb, st);
   return a.gmeta != nullptr ? launch_persist<RotGeom, true>(a, (unsigned)nb, st) : launch_persist<RotGeom, false>(a, (unsigned)nb, st);
@@ -580,6 +646,9 @@ static int run_nms(int kind, const float* boxes, int stride, const float* scores
     a.slab_cover = cv.grid.slab_cover; a.slab_flag = cv.grid.slab_flag; a.slab_cnt = cv.grid.slab_cnt; a.slab_keep = cv.grid.slab_keep;
     a.rec2 = cv.grid.rec2; a.order2 = cv.grid.order2; a.pos_old = cv.grid.pos_old; a.alive2 = cv.grid.alive2; a.kept_bits = cv.grid.kept_bits;
     a.alive2_words = (int)cv.grid.alive2_words; a.kept_words = (int)cv.grid.kept_words;
+    static int slab_cap = -1;
+    if (slab_cap < 0) { const char* e = getenv("OBB_NMS_SLAB_CAP"); slab_cap = e ? atoi(e) : 0; if (slab_cap < 0) slab_cap = 0; }
+    a.slab_cap = slab_cap ? (slab_cap + 63) / 64 * 64 : 0;
   }
   a.rec = cv.rec; a.order = cv.vals_b; a.alive = cv.alive; a.seg_begin = cv.seg_begin; a.seg_end = cv.seg_end;
   a.keep_cnt = cv.keep_cnt; a.keep_out = keep_out;
@@ -600,7 +669,7 @@ static int run_nms(int kind, const float* boxes, int stride, const float* scores
   return hipGetLastError() == hipSuccess ? OBB_OK : OBB_ERR_LAUNCH;
 }
 
-static int kind_recq(int kind) { return kind == 0 ? RotGeom::RECQ : (kind == 1 ? QuadGeom::RECQ : QuadGeom64::RECQ); }
+static int kind_recq(int kind) { return kind == 0 ? RotGeom::RECQ : (kind == 1 ? QuadGeom::RECQ : (kind == 2 ? QuadGeom64::RECQ : RotGeom64::RECQ)); }
 
 // Tile -> full-image merge NMS: nseg independent lists, the caller fixes the processing order (numpy's argsort()[::-1] of
 // the reference is not a stable sort: its tie order is the host's business).  keep_out receives ROW indices, the kept rows of
@@ -634,6 +703,43 @@ static int run_merge_nms(const double* dets9, int64_t n, const int32_t* order, c
   return hipGetLastError() == hipSuccess ? OBB_OK : OBB_ERR_LAUNCH;
 }
 
+// float64 rotated NMS (one list): the reference's double instantiation (nms_rotated_cuda.cu:96), RotGeom64
+static int run_nms_rot64(const double* dets5, const double* scores, int64_t n, float thr, int flags, int64_t max_keep, int64_t* keep_out,
+                         int64_t* num_keep, void* ws, size_t ws_bytes, hipStream_t st) {
+  if (n < 0 || n > 0x7fffffffLL || !num_keep || (n > 0 && (!dets5 || !scores || !keep_out))) return OBB_ERR_BAD_ARG;
+  const int C = cap_max(1);
+  Carve cv;
+  int rc = carve(ws, n, 1, RotGeom64::RECQ, C, &cv);
+  if (rc) return rc;
+  if (!ws || ws_bytes < cv.total) return OBB_ERR_WORKSPACE;
+  const int T = 256;
+  if (n == 0) {
+    if (hipMemsetAsync(cv.keep_cnt, 0, 4, st) != hipSuccess || hipMemsetAsync(cv.seg_begin, 0, 4, st) != hipSuccess) return OBB_ERR_LAUNCH;
+    k_finalize<<<1, T, 0, st>>>(cv.keep_cnt, cv.seg_begin, 1, max_keep, nullptr, num_keep, nullptr);
+    return hipGetLastError() == hipSuccess ? OBB_OK : OBB_ERR_LAUNCH;
+  }
+  const unsigned gb = (unsigned)((n + T - 1) / T);
+  const int drop_small = (flags & OBB_NMS_DROP_SMALL) ? 1 : 0;
+  k_make_keys_f64<<<gb, T, 0, st>>>(scores, dets5, drop_small, (int)n, cv.keys_a, cv.vals_a, cv.seg_begin, cv.seg_end, cv.keep_cnt);
+  size_t tmp = cv.sort_tmp_bytes;
+  if (rocprim::radix_sort_pairs(cv.sort_tmp, tmp, cv.keys_a, cv.keys_b, cv.vals_a, cv.vals_b, (size_t)n, 0, 64, st, false) != hipSuccess)
+    return OBB_ERR_LAUNCH;
+  k_prep_rot64<<<gb, T, 0, st>>>(dets5, cv.vals_b, drop_small, (int)n, cv.rec, cv.alive);
+  NmsArgs a{};
+  a.rec = cv.rec; a.order = cv.vals_b; a.alive = cv.alive; a.seg_begin = cv.seg_begin; a.seg_end = cv.seg_end;
+  a.keep_cnt = cv.keep_cnt; a.keep_out = keep_out;
+  a.rows = cv.rows; a.nrows = cv.nrows; a.edges = cv.edges; a.nedges = cv.nedges;
+  a.ecap = cv.ecap; a.n = (int)n; a.capmax = C;
+  a.max_keep = (int)(max_keep > 0x7fffffffLL ? 0x7fffffffLL : (max_keep < 0 ? 0 : max_keep));
+  a.window = nms_window(a.max_keep);
+  a.thr = thr; a.thr64 = (double)thr;                      // the kernel's threshold is a float (nms_rotated_cuda.cu:14)
+  a.cull = (thr >= 0.f) ? 1 : 0;
+  rc = nms_steps(3, a, cv, 1, n, st);
+  if (rc) return rc;
+  k_finalize<<<1, T, 0, st>>>(cv.keep_cnt, cv.seg_begin, 1, max_keep, cv.abort_flag, num_keep, nullptr);
+  return hipGetLastError() == hipSuccess ? OBB_OK : OBB_ERR_LAUNCH;
+}
+
 }  // namespace obb
 
 #include "nmsobb_impl.h"
@@ -645,7 +751,7 @@ extern "C" {
 size_t obb_nms_workspace_bytes(int64_t n, int64_t nseg, int kind) {
   Carve cv;
   if (n < 0 || nseg < 1) return 0;
-  if (kind < 0 || kind > 2) return 0;
+  if (kind < 0 || kind > 3) return 0;
   if (carve(nullptr, n, nseg, kind_recq(kind), cap_max(nseg), &cv)) return 0;
   return cv.total;
 }
@@ -656,12 +762,9 @@ int obb_nms_rotated_f32(const float* dets5, const float* scores, int64_t n, floa
                  ws, ws_bytes, (hipStream_t)stream);
 }
 
-int obb_nms_rotated_batched_f32(const float* dets5, const float* scores, const int32_t* seg_id, const uint32_t* tie,
-                                int tie_bits, int64_t n, int64_t nseg, int64_t max_seg, float iou_thr, int flags,
-                                int64_t max_keep, int64_t* keep_out, int64_t* num_keep, int64_t* seg_begin_out, void* ws,
-                                size_t ws_bytes, void* stream) {
-  return run_nms(0, dets5, 5, scores, 1, seg_id, tie, tie_bits, n, nseg, max_seg, iou_thr, flags, max_keep, keep_out,
-                 num_keep, seg_begin_out, ws, ws_bytes, (hipStream_t)stream);
+int obb_nms_rotated_f64(const double* dets5, const double* scores, int64_t n, float iou_thr, int flags, int64_t max_keep,
+                        int64_t* keep_out, int64_t* num_keep, void* ws, size_t ws_bytes, void* stream) {
+  return run_nms_rot64(dets5, scores, n, iou_thr, flags, max_keep, keep_out, num_keep, ws, ws_bytes, (hipStream_t)stream);
 }
 
 int obb_nms_poly_f32(const float* polys, int64_t row_stride, int64_t n, float iou_thr, int64_t max_keep, int64_t* keep_out,

@@ -53,7 +53,7 @@ struct NmsArgs {
   int* nedges;               // [nteams]   (a team works on one segment at a time: scratch is per team)
   int* bar;                  // [nteams][2][64] arrive / go counters, one 256-byte line each
   int* abort_flag;           // [1] set when a spin gave up
-  u64* prof;                 // optional [32]: wall-clock ticks (10 ns) per phase (development aid)
+  u64* prof;                 // optional [48]: wall-clock ticks (10 ns) per phase (development aid)
   const int4* plan;          // optional [gridDim.x] {segment, team, index in team, team size} per workgroup (k_plan_teams):
                              // workgroups in proportion to the segment sizes; NULL or plan[0].w == 0: static teams
   long long ecap;
@@ -68,7 +68,7 @@ struct NmsArgs {
   // when a step keeps enough rows to need it (grid_build): a call whose chunks keep a few hundred rows pays nothing but
   // the bounding-box partials of the key kernel.
   GridMeta* gmeta;           // zero before the launch: n_brute / level_mask are counted by grid_build
-  const int* bbpart;         // [nparts][4] bounding box of the centres, one partial per workgroup of the key kernel (ordered ints)
+  const int* bbpart;         // [nparts][kBbInts] bounding box of the centres (+ largest w^2+h^2), one partial per workgroup of the key kernel
   int nparts;
   int* gcnt;                 // [gmask + 1] zero before the launch and after every build
   int* gstart;               // [gmask + 2] first entry of every table slot in gsorted (exclusive prefix; [gmask + 1] = total)
@@ -80,12 +80,14 @@ struct NmsArgs {
   // other (the callers' cls * 4096 offsets) is re-laid out slab by slab INSIDE this kernel (slab_setup) and run as that many
   // concurrent segments, one team each; the kept boxes meet again in score order through a bitmap over the original
   // positions (slab_merge).
-  const uint32_t* slab_cover; // [kSlabWords] x bins touched by a box (written by the prep kernel)
-  const int* slab_flag;       // [1] != 0: a box that cannot be placed (not finite / ill conditioned): no decomposition
+  const uint32_t* slab_cover; // [kSlabCopies][kSlabWords] x bins touched by a box (written by the prep kernel; OR the copies)
+  const int* slab_flag;       // [0] != 0: a box that cannot be placed (not finite / ill conditioned): no decomposition;
+                              // [2] != 0: the data is wide enough to look for slabs (slab_gate) and the bins are marked
   int* slab_cnt;              // [gridDim.x][kMaxSlabs]
   int* slab_keep;             // [kMaxSlabs]
   float4* rec2; uint32_t* order2; uint32_t* pos_old; u64* alive2; u64* kept_bits;
   int alive2_words, kept_words;
+  int slab_cap;               // > 0: upper limit of a slab team's chunk capacity
 };
 
 // ---- cost model shared by the planner (k_plan_teams) and the workgroups that follow its plan
@@ -112,6 +114,14 @@ __device__ __forceinline__ float rdlane(float v, int l) {
 }
 __device__ __forceinline__ float4 rdlane4(const float4& v, int l) {
   return make_float4(rdlane(v.x, l), rdlane(v.y, l), rdlane(v.z, l), rdlane(v.w, l));
+}
+
+// rows r and r + 1 of a tile's row records (one per lane) against the splatted column box: the packed circle test
+template <class G>
+__device__ __forceinline__ void rows_reject2(const float4& myrow, int r, const ColPk& c, bool& r0, bool& r1) {
+  const f32x2 ax = {rdlane(myrow.x, r), rdlane(myrow.x, r + 1)}, ay = {rdlane(myrow.y, r), rdlane(myrow.y, r + 1)};
+  const f32x2 az = {rdlane(myrow.z, r), rdlane(myrow.z, r + 1)}, aw = {rdlane(myrow.w, r), rdlane(myrow.w, r + 1)};
+  G::cheap_reject2(ax, ay, az, aw, c, r0, r1);
 }
 
 constexpr int kNmsThreads = 512;
@@ -292,6 +302,10 @@ __device__ __forceinline__ void nms_pairs(const NmsArgs& a, int tm, int cn, cons
   uint32_t* edges = a.edges + (size_t)tm * a.ecap;
   const bool cull = a.cull != 0;
   PairQueue Q{L.qbuf, 0, 0}, Q1{L.qbuf1b, 0, 0}, Q2{L.qbuf2, 0, 0};
+  const bool pprof = a.prof != nullptr && blockIdx.x == 0 && threadIdx.x == 0;
+  u64 pt0 = 0, p_items = 0, p_loop = 0, p_load = 0, p_n1a = 0, p_t1a = 0, p_n1b = 0, p_t1b = 0, p_n2 = 0, p_t2 = 0;
+  auto ptick = [&]() { if (pprof) pt0 = wall_clock64(); };
+  auto ptock = [&](u64& acc) { if (pprof) { const u64 t = wall_clock64(); acc += t - pt0; pt0 = t; } };
   auto emit = [&](bool hit, uint32_t packed) {           // hits -> the segment's edge list
     const u64 hm = __ballot(hit);
     if (hm) {
@@ -356,6 +370,27 @@ __device__ __forceinline__ void nms_pairs(const NmsArgs& a, int tm, int cn, cons
   const int items_sub = tri * nsub;
   (void)items;
   auto row_off = [&](int rb) { return rb * nb - ((rb * (rb - 1)) >> 1); };
+  // stage 1a: the cheap register-only tests.  Entries are chunk-local (i << 16 | j) like those of the later stages, so
+  // the queue lives ACROSS tiles: a sparse chunk (a few passing pairs per tile) pays the latency of a drain -- LDS look-up,
+  // two record fetches, the edge counter's atomic -- once per 64 pairs instead of once per tile.
+  auto drain = [&](int cnt) {   // wave-uniform cnt <= 64
+    wave_sync();
+    int res = 0;
+    uint32_t packed = 0;
+    if (lane < cnt) {
+      packed = L.qbuf[(Q.head + lane) & 127];
+      const uint32_t pi = cidx[packed >> 16], pj = cidx[packed & 0xffff];
+      res = G::classify_quick(a.rec + (size_t)pi * G::RECQ, a.rec + (size_t)pj * G::RECQ, G::thr_of(a), cull);
+    }
+    emit(res == 1, packed);
+    Q.head = (Q.head + cnt) & 127;
+    Q.count -= cnt;
+    Q1.push(res == 3, packed);
+    Q2.push(res == 2, packed);
+    wave_sync();
+    if (Q1.count >= 64) drain1b(64);
+    if (Q2.count >= 64) drain2(64);
+  };
   for (int it2 = tw; it2 < items_sub; it2 += ntw) {
     const int item = it2 / nsub, sub = it2 - item * nsub;
     int rb = (int)(((float)(2 * nb + 1) - sqrtf((float)((2 * nb + 1) * (2 * nb + 1) - 8 * item))) * 0.5f);
@@ -366,52 +401,45 @@ __device__ __forceinline__ void nms_pairs(const NmsArgs& a, int tm, int cn, cons
     const int r = rb * 64 + lane, c = cb * 64 + lane;
     const bool rvalid = r < cn, cvalid = c < cn;
     const uint32_t rp = rvalid ? cidx[r] : 0u, cp = cvalid ? cidx[c] : 0u;
-    wave_sync();
-    L.rowpos[lane] = rp; L.colpos[lane] = cp;
+    ptick();
     const float4 myrow = rvalid ? a.rec[(size_t)rp * G::RECQ] : make_float4(0.f, 0.f, 0.f, 0.f);
     const float4 cq = cvalid ? a.rec[(size_t)cp * G::RECQ] : make_float4(0.f, 0.f, 0.f, 0.f);
+    if (pprof) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); ptock(p_load); p_items++; }
     const int nrow = min(64, cn - rb * 64);
     const int rr_lo = sub * rows_sub, rr_hi = min(nrow, rr_lo + rows_sub);
     const bool diag = rb == cb;
-    wave_sync();
-
-    auto drain = [&](int cnt) {   // stage 1a, wave-uniform cnt <= 64
-      wave_sync();
-      int res = 0;
-      uint32_t packed = 0;
-      if (lane < cnt) {
-        const uint32_t it = L.qbuf[(Q.head + lane) & 127];
-        const int rr = it >> 8, cc = it & 255;
-        res = G::classify_quick(a.rec + (size_t)L.rowpos[rr] * G::RECQ, a.rec + (size_t)L.colpos[cc] * G::RECQ, G::thr_of(a), cull);
-        packed = ((uint32_t)(rb * 64 + rr) << 16) | (uint32_t)(cb * 64 + cc);
-      }
-      emit(res == 1, packed);
-      Q.head = (Q.head + cnt) & 127;
-      Q.count -= cnt;
-      Q1.push(res == 3, packed);
-      Q2.push(res == 2, packed);
-      wave_sync();
-      if (Q1.count >= 64) drain1b(64);
-      if (Q2.count >= 64) drain2(64);
-    };
+    const uint32_t pk_col = (uint32_t)(cb * 64 + lane), pk_row0 = (uint32_t)(rb * 64) << 16;
 
     // four rows per trip: their broadcasts and cheap tests are issued together and ONE ballot decides whether any of them
     // has a pair to queue (in a sparse chunk most rows pass for no column of the tile)
     auto one_row = [&](int rr, bool pass) {
       if (__ballot(pass)) {
-        Q.push(pass, ((uint32_t)rr << 8) | (uint32_t)lane);
-        if (Q.count >= 64) drain(64);
+        Q.push(pass, (pk_row0 + ((uint32_t)rr << 16)) | pk_col);
+        if (Q.count >= 64) { ptock(p_loop); drain(64); ptock(p_t1a); p_n1a++; }
       }
     };
     int rr = rr_lo;
+    [[maybe_unused]] ColPk cpk;
+    if constexpr (G::PACKED) cpk = col_splat(cq);
     for (; rr + 4 <= rr_hi; rr += 4) {
       bool ps[4];
       bool any = false;
+      if constexpr (G::PACKED) {                 // two rows per packed instruction (geom.h)
 #pragma unroll
-      for (int k = 0; k < 4; k++) {
-        const float4 rq = rdlane4(myrow, rr + k);
-        ps[k] = cvalid && (!diag || lane > rr + k) && !(cull && G::cheap_reject(rq, cq));
-        any = any || ps[k];
+        for (int k = 0; k < 4; k += 2) {
+          bool r0, r1;
+          rows_reject2<G>(myrow, rr + k, cpk, r0, r1);
+          ps[k] = cvalid && (!diag || lane > rr + k) && !(cull && r0);
+          ps[k + 1] = cvalid && (!diag || lane > rr + k + 1) && !(cull && r1);
+          any = any || ps[k] || ps[k + 1];
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const float4 rq = rdlane4(myrow, rr + k);
+          ps[k] = cvalid && (!diag || lane > rr + k) && !(cull && G::cheap_reject(rq, cq));
+          any = any || ps[k];
+        }
       }
       if (__ballot(any)) {
 #pragma unroll
@@ -422,10 +450,16 @@ __device__ __forceinline__ void nms_pairs(const NmsArgs& a, int tm, int cn, cons
       const float4 rq = rdlane4(myrow, rr);
       one_row(rr, cvalid && (!diag || lane > rr) && !(cull && G::cheap_reject(rq, cq)));
     }
-    if (Q.count > 0) drain(Q.count);
+    ptock(p_loop);
   }
-  if (Q1.count > 0) drain1b(Q1.count);
-  if (Q2.count > 0) drain2(Q2.count);
+  ptick();
+  if (Q.count > 0) { drain(Q.count); ptock(p_t1a); p_n1a++; }
+  if (Q1.count > 0) { drain1b(Q1.count); ptock(p_t1b); p_n1b++; }
+  if (Q2.count > 0) { drain2(Q2.count); ptock(p_t2); p_n2++; }
+  if (pprof) {
+    a.prof[32] += p_items; a.prof[33] += p_loop + p_load; a.prof[40] += p_load; a.prof[34] += p_n1a; a.prof[35] += p_t1a; a.prof[36] += p_n1b;
+    a.prof[37] += p_t1b; a.prof[38] += p_n2; a.prof[39] += p_t2;
+  }
 }
 
 // ------------------------------------------------------------------ A2: resolve the chunk (serial section, 512 threads)
@@ -450,21 +484,29 @@ __device__ __forceinline__ int nms_resolve(const NmsArgs& a, int g, int sb, int 
   const uint32_t* edges = a.edges + (size_t)tm * a.ecap;   // plain loads: acquired in serial_begin
   // The list fits in LDS when every thread's share does (one contiguous block per thread, odd length: conflict-free banks).
   const int percap = (int)(((lcap / kNmsThreads) - 1) | 1);
-  int per = (int)((E + kNmsThreads - 1) / kNmsThreads);
+  int per = (int)((E + kNmsThreads - 1) / kNmsThreads) + 5;   // (+ the slack of dealing the list out four edges at a time)
   per |= 1;
   bool lds_mode = per <= percap;
   if (!lds_mode) per = percap;
   int mycnt = 0;
   uint32_t* mine_e = ledges + (size_t)tid * per;
   if (lds_mode) {
-    // thread t takes edges t, t+512, ... (coalesced global reads, 8 in flight) into its own LDS block
-    for (long long k0 = tid; k0 < E; k0 += 8 * kNmsThreads) {
-      uint32_t v[8];
+    // thread t takes the 16-byte groups t, t+512, ... (coalesced global reads, four groups = 16 edges in flight) into its
+    // own LDS block; the list was written by every workgroup of the team and sits in L2 / memory: this is a latency chain
+    const uint4* e4 = reinterpret_cast<const uint4*>(edges);      // (every team's list starts on a 16-byte boundary)
+    const long long nvec = E >> 2;
+    for (long long v0 = tid; v0 < nvec; v0 += 4 * kNmsThreads) {
+      uint4 v[4];
 #pragma unroll
-      for (int u = 0; u < 8; u++) { const long long k = k0 + (long long)u * kNmsThreads; v[u] = k < E ? edges[k] : 0u; }
+      for (int u = 0; u < 4; u++) { const long long k = v0 + (long long)u * kNmsThreads; v[u] = k < nvec ? e4[k] : make_uint4(0u, 0u, 0u, 0u); }
 #pragma unroll
-      for (int u = 0; u < 8; u++) if (k0 + (long long)u * kNmsThreads < E) mine_e[mycnt++] = v[u];
+      for (int u = 0; u < 4; u++)
+        if (v0 + (long long)u * kNmsThreads < nvec) {
+          mine_e[mycnt] = v[u].x; mine_e[mycnt + 1] = v[u].y; mine_e[mycnt + 2] = v[u].z; mine_e[mycnt + 3] = v[u].w;
+          mycnt += 4;
+        }
     }
+    if (tid < (int)(E & 3)) mine_e[mycnt++] = edges[(nvec << 2) + tid];
   }
   __syncthreads();
   u64 tp = 0;
@@ -614,11 +656,19 @@ __device__ __forceinline__ void nms_cross(const NmsArgs& a, const uint32_t* rows
   const int w0 = LIST ? 0 : (c0 >> 6), w1 = LIST ? ((ncl + 63) >> 6) - 1 : ((se - 1) >> 6);
   const int ncw = w1 - w0 + 1, nrt = (nr + 63) >> 6;
   if (ncw <= 0 || nr <= 0) return;
-  // one wave per column word; the row tiles of a word are split over several waves only when there are fewer
-  // column words than waves
-  int rgn = ntw / ncw;
-  if (rgn < 1) rgn = 1;
-  if (rgn > nrt) rgn = nrt;
+  // one wave per column word; the row tiles of a word are split over rgn waves when that shortens the longest wave:
+  // rounds of items per wave x (row tiles per item x ~3 + 1 for the item's own loads), smallest over rgn = 1 .. 16
+  // (a slab team of 14 workgroups with 57 column words and 5 row tiles: 1 round x 5 tiles -> 3 rounds x 1 tile)
+  int rgn = 1;
+  {
+    long long best = -1;
+    const int rmax = nrt < 16 ? nrt : 16;
+    for (int r = 1; r <= rmax; r++) {
+      const long long rounds = ((long long)ncw * r + ntw - 1) / ntw;
+      const long long cost = rounds * ((long long)((nrt + r - 1) / r) * 3 + 1);
+      if (best < 0 || cost < best) { best = cost; rgn = r; }
+    }
+  }
   const int rt_per = (nrt + rgn - 1) / rgn;
   const long long items = (long long)ncw * rgn;
   // rows: plain loads -- published write-through by the resolver, acquired after the serial section
@@ -655,6 +705,8 @@ __device__ __forceinline__ void nms_cross(const NmsArgs& a, const uint32_t* rows
       alive0 = (m >> lane) & 1ull;
     }
     const float4 cq = alive0 ? a.rec[(size_t)c * G::RECQ] : make_float4(0.f, 0.f, 0.f, 0.f);
+    [[maybe_unused]] ColPk cpk;
+    if constexpr (G::PACKED) cpk = col_splat(cq);
     float4 rq0 = a.rec[(size_t)rp0 * G::RECQ];
     uint32_t rp1 = (rt_lo + 1 < rt_hi && (rt_lo + 1) * 64 + lane < nr) ? rows[(rt_lo + 1) * 64 + lane] : 0u;
     bool alive = alive0;
@@ -767,11 +819,22 @@ __device__ __forceinline__ void nms_cross(const NmsArgs& a, const uint32_t* rows
       for (; rr + 4 <= nrow; rr += 4) {
         bool ps[4];
         bool any = false;
+        if constexpr (G::PACKED) {               // two rows per packed instruction (geom.h)
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-          const float4 rq = rdlane4(myrow, rr + k);
-          ps[k] = alive && !(cull && G::cheap_reject(rq, cq));
-          any = any || ps[k];
+          for (int k = 0; k < 4; k += 2) {
+            bool r0, r1;
+            rows_reject2<G>(myrow, rr + k, cpk, r0, r1);
+            ps[k] = alive && !(cull && r0);
+            ps[k + 1] = alive && !(cull && r1);
+            any = any || ps[k] || ps[k + 1];
+          }
+        } else {
+#pragma unroll
+          for (int k = 0; k < 4; k++) {
+            const float4 rq = rdlane4(myrow, rr + k);
+            ps[k] = alive && !(cull && G::cheap_reject(rq, cq));
+            any = any || ps[k];
+          }
         }
         if (__ballot(any)) {
 #pragma unroll
@@ -1191,9 +1254,15 @@ __device__ __forceinline__ int slab_setup(const NmsArgs& a, const GridPlan& gp, 
   const float inv = slab_inv_bin(gp);
   __syncthreads();
   int mypre = 0;
+  auto cover = [&](int k) -> uint32_t {                       // the OR of the prep kernel's kSlabCopies copies
+    uint32_t w = 0u;
+#pragma unroll
+    for (int c = 0; c < kSlabCopies; c++) w |= a.slab_cover[c * kSlabWords + k];
+    return w;
+  };
   if (tid < kSlabWords) {
-    const uint32_t w = a.slab_cover[tid];
-    const uint32_t prev_msb = tid > 0 ? (a.slab_cover[tid - 1] >> 31) : 0u;
+    const uint32_t w = cover(tid);
+    const uint32_t prev_msb = tid > 0 ? (cover(tid - 1) >> 31) : 0u;
     starts[tid] = w & ~((w << 1) | prev_msb);
   }
   __syncthreads();
@@ -1234,13 +1303,25 @@ __device__ __forceinline__ int slab_setup(const NmsArgs& a, const GridPlan& gp, 
   if (tid < kMaxSlabs) stg_agent(a.slab_cnt + (size_t)wg * kMaxSlabs + tid, cnt[tid]);
   if (!team_barrier(gbar, s_flag)) return -1;
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-  // ---- 3: totals and offsets (thread t reads the row of workgroup t)
-  for (int s0 = 0; s0 < S; s0++) {
-    int v = tid < NB ? a.slab_cnt[(size_t)tid * kMaxSlabs + s0] : 0;
-    int below = tid < wg ? v : 0;
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) { v += __shfl_xor(v, d); below += __shfl_xor(below, d); }
-    if (lane == 0 && v) { atomicAdd(&tot[s0], v); if (below) atomicAdd(&pre[s0], below); }
+  // ---- 3: totals and offsets.  The table first travels into LDS with independent 16-byte loads (thread t: the row of
+  // workgroup t), then thread (slab, part) adds up an eighth of a column -- no load waits for a reduction
+  {
+    int* tab = misc + 4;                                       // [NB][kMaxSlabs]
+    const int nq = (S + 3) >> 2;
+    if (tid < NB) {
+      const int4* row = reinterpret_cast<const int4*>(a.slab_cnt + (size_t)tid * kMaxSlabs);
+      int4* dst = reinterpret_cast<int4*>(tab + tid * kMaxSlabs);
+      for (int j = 0; j < nq; j++) dst[j] = row[j];
+    }
+    __syncthreads();
+    const int s0 = tid & (kMaxSlabs - 1), part = tid >> 6;     // kNmsThreads / kMaxSlabs = 8 parts
+    if (s0 < S) {
+      const int per = (NB + kNmsWaves - 1) / kNmsWaves;
+      int v = 0, below = 0;
+      for (int w = part * per; w < (part + 1) * per && w < NB; w++) { const int c = tab[w * kMaxSlabs + s0]; v += c; if (w < wg) below += c; }
+      if (v) atomicAdd(&tot[s0], v);
+      if (below) atomicAdd(&pre[s0], below);
+    }
   }
   __syncthreads();
   if (tid == 0) {
@@ -1252,6 +1333,7 @@ __device__ __forceinline__ int slab_setup(const NmsArgs& a, const GridPlan& gp, 
     while (c > 0 && (long long)c * (c - 1) / 2 > e) c--;
     c &= ~63;
     if (c > a.capmax) c = a.capmax;
+    if (a.slab_cap > 0 && c > a.slab_cap) c = a.slab_cap;      // (OBB_NMS_SLAB_CAP: measurements)
     misc[1] = (mx <= kSlabMaxSeg && nonempty >= 2 && nonempty <= NB && c >= 512) ? 1 : 0;
     misc[2] = nonempty; misc[3] = c;
     SL.cap = c; SL.ecap = (long long)c * (c - 1) / 2;
@@ -1381,7 +1463,7 @@ __global__ __launch_bounds__(kNmsThreads) __attribute__((amdgpu_waves_per_eu(1, 
   auto data_extent = [&]() -> GridPlan {
     int bx0 = 0x7fffffff, by0 = 0x7fffffff, bx1 = (int)0x80000000, by1 = (int)0x80000000;
     for (int i = tid; i < a.nparts; i += kNmsThreads) {
-      const int4 q = reinterpret_cast<const int4*>(a.bbpart)[i];
+      const int4 q = reinterpret_cast<const int4*>(a.bbpart)[2 * i];          // (kBbInts = 8 ints per partial)
       bx0 = min(bx0, q.x); by0 = min(by0, q.y); bx1 = max(bx1, q.z); by1 = max(by1, q.w);
     }
 #pragma unroll
@@ -1406,10 +1488,13 @@ __global__ __launch_bounds__(kNmsThreads) __attribute__((amdgpu_waves_per_eu(1, 
   int* keep_cnt0 = a.keep_cnt;
   const int n0 = a.n;
   if constexpr (G::HAS_GRID && GRID) {
-    if (a.slab_cover != nullptr && a.nseg == 1 && a.max_keep <= 0 && a.cull != 0 && a.plan == nullptr && a.bbpart != nullptr) {
+    // (slab_flag[2] != 0: the prep kernel found the data wide enough to look for slabs and marked the x bins: one word decides)
+    if (a.slab_cover != nullptr && a.nseg == 1 && a.max_keep <= 0 && a.cull != 0 && a.plan == nullptr && a.bbpart != nullptr && a.slab_flag[2] != 0) {
+      const u64 t_su = (a.prof && blockIdx.x == 0 && tid == 0) ? wall_clock64() : 0ull;
       const GridPlan sp = data_extent();
       const int st = sp.ok ? slab_setup<G>(a, sp, smem, gbar, &s_flag, s_slab) : 0;
       if (st < 0) return;
+      if (a.prof && blockIdx.x == 0 && tid == 0) a.prof[41] += wall_clock64() - t_su;
       if (st > 0) {
         slab_mode = true;
         a.rec = a.rec2; a.order = a.order2; a.alive = a.alive2; a.keep_out = nullptr; a.keep_cnt = a.slab_keep;

@@ -58,19 +58,27 @@ def nms_rotated(dets, scores, iou_threshold):
     return _run_rotated(dets.contiguous(), scores.contiguous(), iou_threshold)
 
 
-def _run_rotated_f64(dets, scores, iou_threshold):
-    """float64 input (nms_rotated_cuda.cu:96 dispatches double).  The HIP kernels compute the IoU in float32, so the rule
-    is explicit: the processing ORDER is the one of the double scores (stable descending sort: ties keep ascending index,
-    NaN first, like the float32 path), the BOXES are rounded to float32 and go through the float32 kernel in that order.
-    The kept list therefore equals the float32 path's on the rounded boxes; against a true double-precision scan it can
-    differ for pairs whose IoU lies within float32 rounding (~1e-6) of the threshold (tests/test_nms_gpu.py)."""
+def _run_rotated_f64(dets, scores, iou_threshold, flags=0, max_keep=0):
+    """float64 input: the reference dispatches double to a double-precision instantiation of its kernel
+    (nms_rotated_cuda.cu:96).  ``obb_nms_rotated_f64`` does the same on the device: double scores decide the order (ties:
+    ascending index, NaN first), every IoU is evaluated in double (csrc/riou64_device.h, the policy RotGeom64 of the
+    persistent NMS kernel) and compared with the float threshold of the kernel's signature (nms_rotated_cuda.cu:14,60)."""
+    return _lib.retry_on_abort(lambda: _run_rotated_f64_once(dets.contiguous(), scores.contiguous(), iou_threshold, flags, max_keep))
+
+
+def _run_rotated_f64_once(dets, scores, iou_threshold, flags, max_keep):
+    L = _lib.lib()
     n = dets.shape[0]
-    if n >= (1 << 24):
-        raise RuntimeError("nms_rotated (float64): at most 2^24 - 1 boxes")
-    order = torch.argsort(scores, descending=True, stable=True)
-    d32 = dets.index_select(0, order).float().contiguous()
-    rank = torch.arange(n, 0, -1, device=dets.device, dtype=torch.float32)     # strictly decreasing: keeps the given order
-    return order[_run_rotated(d32, rank, iou_threshold)]
+    dev = dets.device
+    keep = torch.empty(n, dtype=torch.int64, device=dev)
+    cnt = torch.empty(1, dtype=torch.int64, device=dev)
+    with _lib.guard(dev):
+        st = _lib.stream_handle(dev)
+        ws = _lib.workspace(L.obb_nms_workspace_bytes(n, 1, 3), dev, st)
+        rc = L.obb_nms_rotated_f64(_lib.ptr(dets), _lib.ptr(scores), n, float(iou_threshold), int(flags), int(max_keep),
+                                   _lib.ptr(keep), _lib.ptr(cnt), _lib.ptr(ws), ws.numel(), _lib.C.c_void_p(st))
+    _lib.check(rc, "obb_nms_rotated_f64")
+    return keep[: _lib.checked_count(int(cnt.item()), "obb_nms_rotated_f64")]
 
 
 def nms_poly(dets, iou_threshold):

@@ -42,9 +42,12 @@ def obb_nms(dets, scores, iou_thr, device_id=None):
         inds = dets_th.new_zeros(0, dtype=torch.int64)
     else:
         _lib.require_cuda(dets_th, "dets")
-        d = dets_th.float() if dets_th.dtype != torch.float32 else dets_th
-        s = scores.float() if scores.dtype != torch.float32 else scores
-        inds = nms_rotated_ext._run_rotated(d.contiguous(), s.contiguous(), iou_thr, flags=_lib.OBB_NMS_DROP_SMALL)
+        if dets_th.dtype == torch.float64:      # the reference hands the tensors on as they are: double kernel (nms_rotated_cuda.cu:96)
+            inds = nms_rotated_ext._run_rotated_f64(dets_th, scores.double(), iou_thr, flags=_lib.OBB_NMS_DROP_SMALL)
+        else:
+            d = dets_th.float() if dets_th.dtype != torch.float32 else dets_th
+            s = scores.float() if scores.dtype != torch.float32 else scores
+            inds = nms_rotated_ext._run_rotated(d.contiguous(), s.contiguous(), iou_thr, flags=_lib.OBB_NMS_DROP_SMALL)
     if is_numpy:
         inds = inds.cpu().numpy()
     return dets[inds, :], inds
