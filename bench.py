@@ -502,7 +502,7 @@ def main():
     if not args.no_extras:
         try:
             from tools import conv_standin
-            val_obj = conv_standin.val_buckets(dev, n_images=64, batch=16, nc=nc, conf_thres=0.25, iou_thres=0.45, half=True, seed=rank)
+            val_obj = conv_standin.val_buckets(dev, n_images=160, batch=16, nc=nc, conf_thres=0.25, iou_thres=0.45, half=True, seed=rank)
             val_obj["n_gpus"] = world
             val_obj["note"] = ("dt buckets are the slowest rank's, img/s = images of ALL ranks / sum(dt) (val.py:286-291); secondary to `value`: "
                                "the convolutions are PyTorch-ROCm's, not this repository's")

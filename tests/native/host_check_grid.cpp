@@ -42,6 +42,7 @@ struct Index {
   std::vector<int> start; std::vector<int> sorted; std::vector<uint8_t> brute;
 };
 
+static int g_fine = 0;    // GridPlan::fine (argv[3]): cells of side 2 R_L / 2^fine
 static Index build(const std::vector<Box>& bx, uint32_t M) {
   Index ix; ix.mask = M - 1; ix.level_mask = 0;
   int bb[4] = {0x7fffffff, 0x7fffffff, (int)0x80000000, (int)0x80000000};
@@ -51,6 +52,7 @@ static Index build(const std::vector<Box>& bx, uint32_t M) {
       bb[2] = std::max(bb[2], grid_f2o(b.x)); bb[3] = std::max(bb[3], grid_f2o(b.y));
     }
   ix.gp = grid_plan(bb);
+  ix.gp.fine = g_fine;
   const int n = (int)bx.size();
   ix.brute.assign(n, 0);
   std::vector<uint32_t> slot(n, 0xffffffffu);
@@ -109,6 +111,7 @@ static long long query(const Index& ix, const std::vector<Box>& bx, int i, std::
 
 int main(int argc, char** argv) {
   const int n = argc > 1 ? atoi(argv[1]) : 20000;
+  g_fine = argc > 3 ? atoi(argv[3]) : 0;
   g_rng ^= (uint64_t)(argc > 2 ? atoll(argv[2]) : 1) * 0x9E3779B97F4A7C15ull;
   long long violations = 0, checked = 0;
   const char* names[] = {"uniform", "clustered", "clustered+18cls", "uniform+18cls", "unit-square", "mixed-sizes", "outliers+degenerate", "huge-coords"};

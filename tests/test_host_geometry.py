@@ -53,6 +53,6 @@ def test_spatial_index_never_skips_a_pair_the_circle_test_keeps(tmp_path):
     out = tmp_path / "hc_grid"
     subprocess.run(["g++", "-O2", "-std=c++17", "-ffp-contract=off", f"-I{ROOT}/yolov5_obb_amd/csrc",
                     f"{ROOT}/tests/native/host_check_grid.cpp", "-o", str(out), "-lm"], check=True)
-    for n, seed in ((20000, 1), (100000, 2)):
-        r = subprocess.run([str(out), str(n), str(seed)], capture_output=True, text=True)
+    for n, seed, fine in ((20000, 1, 0), (100000, 2, 0), (100000, 3, 1), (20000, 4, 2)):      # fine: cells of side 2 R_L / 2^fine
+        r = subprocess.run([str(out), str(n), str(seed), str(fine)], capture_output=True, text=True)
         assert r.returncode == 0 and "\nviolations=0" in r.stdout, r.stdout

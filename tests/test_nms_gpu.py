@@ -245,6 +245,43 @@ def test_nms_poly(dev, oracle_lib, n, seed, thr):
     assert np.array_equal(inds.cpu().numpy(), ref) and torch.equal(kept.cpu(), polys[ref])
 
 
+def test_nms_poly_30k(dev, oracle_lib):
+    """the quad NMS at the reference's max_nms size (30,000 candidates, utils/general.py:794), the
+    S-clustered quads bench.py times, against the oracle's restatement of poly_nms_cuda.cu:197-261 (14 M devPolyIoU
+    evaluations on the host); twice."""
+    from yolov5_obb_amd import nms_rotated_ext
+    dq, sq = synth.s_clustered(30000, 300, seed=0)
+    sq = synth.tie_free(sq)
+    polys = torch.cat([synth.rbox_to_quad(dq), sq[:, None]], 1).contiguous()
+    ref = oracle.nms_poly(polys.numpy(), 0.4)
+    assert 300 < len(ref) < 3000
+    for _ in range(2):
+        got = nms_rotated_ext.nms_poly(polys.to(dev), 0.4).cpu().numpy()
+        assert np.array_equal(ref, got)
+
+
+def test_ops_rbox_overlaps_device_tensors(dev, oracle_lib):
+    """ops.rbox_overlaps -> obb_rbox_overlaps_f32 (the device-pointer form of the devkit's overlaps_kernel,
+    poly_overlaps_kernel.cu:280-353): same matrix as the host-pointer `_overlaps`, bit for bit, and as the oracle up to the
+    one thing no build can pin: the kernel evaluates cosf / sinf in FLOAT like the reference (poly_overlaps_kernel.cu:281-282),
+    ocml's and glibc's results differ in the last bit for some angles, the corner moves by an ulp of its coordinate (3e-5 px
+    at 300 px) and a 4-pixel box turns that into up to ~5e-5 of IoU (measured: max 4.8e-5 over 233k pairs, 99.9 % within
+    1e-5).  Shapes incl. empty and one row."""
+    from yolov5_obb_amd import ops
+    from yolov5_obb_amd.DOTA_devkit.poly_nms_gpu import poly_overlaps
+    a, _ = synth.s_uniform(700, 17, extent=300.0)
+    b, _ = synth.s_uniform(333, 18, extent=300.0)
+    got = ops.rbox_overlaps(a.to(dev), b.to(dev)).cpu().numpy()
+    ref = oracle.devkit_overlaps(a.numpy(), b.numpy())
+    assert got.shape == (700, 333) and got.dtype == np.float32
+    err = np.abs(got - ref)
+    assert err.max() <= 1e-4 and (err <= 1e-5).mean() >= 0.999, (err.max(), (err <= 1e-5).mean())
+    assert np.array_equal(got, poly_overlaps(a.numpy(), b.numpy()))          # the two entry points share the kernel
+    assert ops.rbox_overlaps(a[:1].to(dev), b.to(dev)).shape == (1, 333)
+    assert ops.rbox_overlaps(a[:0].to(dev), b.to(dev)).shape == (0, 333)
+    assert (got > 0).sum() > 1000 and got.max() <= 1.0 + 1e-6
+
+
 def test_rotated_iou_pairs_bit_exact(dev, oracle_lib):
     from yolov5_obb_amd import ops
     a, _ = synth.s_uniform(200000, 1, extent=120.0)

@@ -53,11 +53,12 @@ struct GridPlan {          // derived from GridMeta::bb by every thread that nee
   float dmax2;             // upper bound of any squared centre distance
   int e_base;              // R_L = 2^(e_base + L)
   int ok;                  // 0: no usable extent (no finite box, zero or infinite extent)
+  int fine;                // cells of side 2 R_L / 2^fine (0: the original 2 R_L)
 };
 
 OBB_HD GridPlan grid_plan(const int* bb) {
   GridPlan p;
-  p.ok = 0; p.x0 = p.y0 = p.xr = p.yr = p.dmax2 = 0.f; p.e_base = 0;
+  p.ok = 0; p.x0 = p.y0 = p.xr = p.yr = p.dmax2 = 0.f; p.e_base = 0; p.fine = 0;
   if (bb[0] > bb[2] || bb[1] > bb[3]) return p;                 // no box seen
   const float x0 = grid_o2f(bb[0]), y0 = grid_o2f(bb[1]), x1 = grid_o2f(bb[2]), y1 = grid_o2f(bb[3]);
   const float xr = x1 - x0, yr = y1 - y0;
@@ -79,7 +80,7 @@ OBB_HD int grid_level(const GridPlan& p, float r) {
   return L < 0 ? 0 : L;
 }
 OBB_HD float grid_level_radius(const GridPlan& p, int L) { return ldexpf(1.0f, p.e_base + L); }
-OBB_HD float grid_level_inv_cell(const GridPlan& p, int L) { return ldexpf(1.0f, -(p.e_base + L + 1)); }   // 1 / (2 R_L)
+OBB_HD float grid_level_inv_cell(const GridPlan& p, int L) { return ldexpf(1.0f, -(p.e_base + L + 1 - p.fine)); }   // 2^fine / (2 R_L)
 // cell coordinate along one axis (v0 = origin, vmax_cell = last cell of the level on that axis)
 OBB_HD int grid_cell(float v, float v0, float inv_cell, int last) {
   const float f = floorf((v - v0) * inv_cell);

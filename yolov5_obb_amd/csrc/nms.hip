@@ -226,7 +226,11 @@ __global__ __launch_bounds__(256) void k_prep_rot(const float* __restrict__ dets
   float max_w2h2 = 0.f;
   const GridPlan gp = plan_from_partials(bbpart, nparts, s_red, &max_w2h2);
   const bool gate = slab_gate(gp, max_w2h2);
-  if (blockIdx.x == 0 && threadIdx.x == 0) slab_flag[2] = gate ? 1 : 0;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    slab_flag[2] = gate ? 1 : 0;
+    slab_flag[4] = __float_as_int(gp.x0);                    // the bins' origin and scale: the NMS kernel reads them instead of
+    slab_flag[5] = __float_as_int(slab_inv_bin(gp));         // reducing the partials once more
+  }
   if (!gate) return;
   for (int k = threadIdx.x; k < kSlabWords; k += blockDim.x) s_cover[k] = 0u;
   __syncthreads();
@@ -398,7 +402,9 @@ struct Carve {
 };
 
 // table slots of the spatial index (power of two, multiple of 4096)
-static uint32_t grid_slots(int64_t n) { return n >= 262144 ? 65536u : 16384u; }
+// cells of side 2 R_L / 2^fine (grid.h): 1 measured best at 100k (K=3000: 716 -> 648 us, uniform 2361 -> 2138; 2: no further gain)
+static int grid_fine() { static int f = -1; if (f < 0) { const char* e = getenv("OBB_GRID_FINE"); f = e ? atoi(e) : 1; if (f < 0 || f > 2) f = 1; } return f; }
+static uint32_t grid_slots(int64_t n) { return (n >= 262144 || (grid_fine() > 0 && n >= 32768)) ? 65536u : 16384u; }
 constexpr int64_t kGridMinN = 8192;    // below this the exhaustive cross phase is cheaper than building the index
 
 // One persistent launch runs the whole step loop (nms_core.h).  Grid: one 512-thread workgroup per CU at most --
@@ -429,7 +435,7 @@ static hipError_t sort_tmp_query(size_t n, size_t* bytes) {
   if (e != hipSuccess) return e;
   e = rocprim::radix_sort_pairs(nullptr, b32, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, n, 0,
                                 32, (hipStream_t)0, false);
-  *bytes = b64 > b32 ? b64 : b32;
+  *bytes = (b64 > b32 ? b64 : b32) + 65536;      // (+ slack for the alternative merge-sort configurations of OBB_SORT_CFG)
   return e;
 }
 
@@ -513,6 +519,17 @@ static int launch_persist(const NmsArgs& a, unsigned nb, hipStream_t st) {
   if (lds < (size_t)2 * a.capmax) return OBB_ERR_INTERNAL;    // (aliased by resolve: state + blocked bytes of one chunk)
   lds += (size_t)a.capmax * 4;                                // + this workgroup's copy of the chunk list
   if (lds > kPersistLdsMax) return OBB_ERR_INTERNAL;
+  // OBB_NMS_COOP=1: cooperative launch -- the runtime guarantees that all workgroups are resident together (what the
+  // kernel's spin barriers need) instead of the kernel finding out by a barrier time-out; measured switch
+  static int coop = -1;
+  if (coop < 0) { const char* e = getenv("OBB_NMS_COOP"); coop = (e && atoi(e)) ? 1 : 0; }
+  if (coop) {
+    NmsArgs tmp = a;
+    void* params[] = {(void*)&tmp};
+    if (hipLaunchCooperativeKernel((const void*)k_nms_persist<G, GRID>, dim3(nb), dim3(kNmsThreads), params, (unsigned)lds, st) != hipSuccess)
+      return OBB_ERR_LAUNCH;
+    return OBB_OK;
+  }
   k_nms_persist<G, GRID><<<nb, kNmsThreads, lds, st>>>(a);
   return OBB_OK;
 }
@@ -555,6 +572,8 @@ static int nms_steps(int kind, NmsArgs& a, const Carve& cv, int64_t nseg, int64_
               h[21], h[16] * 0.01, h[19], h[17] * 0.01, h[20], h[18] * 0.01, h[18] * 0.01, h[20], h[15], h[10]);
       fprintf(stderr, "    pairs, wg0 wave 0: items %llu = %.1f us (loads %.1f), stage-1a drains %llu = %.1f us, stage-1b drains %llu = %.1f us, exact drains %llu = %.1f us | slab set-up %.1f us, merge %.1f us (wg0)\n",
               h[32], h[33] * 0.01, h[40] * 0.01, h[34], h[35] * 0.01, h[36], h[37] * 0.01, h[38], h[39] * 0.01, h[41] * 0.01, h[8] * 0.01);
+      if (h[41]) fprintf(stderr, "    slab set-up (wg0): runs %.1f, count %.1f, barrier %.1f, table %.1f, scatter+plan %.1f, barrier %.1f us\n", h[42] * 0.01, h[43] * 0.01,
+                         h[44] * 0.01, h[45] * 0.01, h[46] * 0.01, h[47] * 0.01);
     }
     if (hipMemsetAsync(cv.prof, 0, 48 * 8, st) != hipSuccess) return OBB_ERR_LAUNCH;
     a.prof = cv.prof;
@@ -619,8 +638,24 @@ static int run_nms(int kind, const float* boxes, int stride, const float* scores
                                       (long long)(cv.bar_bytes / 16), reinterpret_cast<uint4*>(cv.grid.meta),
                                       use_grid ? (long long)(cv.grid_zero_bytes / 16) : 0ll, (use_grid && kind == 0) ? cv.grid.bbpart : nullptr);
       pre = kNmsBarZeroed;
-      if (rocprim::radix_sort_pairs(cv.sort_tmp, tmp, k32a, k32b, cv.vals_a, cv.vals_b, (size_t)n, 0, 32, st, false) != hipSuccess)
-        return OBB_ERR_LAUNCH;
+      // OBB_SORT_CFG: rocPRIM merge-sort configurations (measurements): 0 = the library's default (58 us at 100k: block
+      // sort + 7 odd-even merge passes), 1..4 = larger sorted blocks / merge-path merges
+      static int scfg = -1;
+      if (scfg < 0) { const char* e = getenv("OBB_SORT_CFG"); scfg = e ? atoi(e) : 0; if (scfg < 0 || scfg > 4) scfg = 0; }
+      hipError_t se;
+      using rocprim::default_config;
+      using rocprim::merge_sort_config;
+      using rocprim::radix_sort_config;
+      if (scfg == 1) se = rocprim::radix_sort_pairs<radix_sort_config<default_config, merge_sort_config<512, 512, 8, 128, 128, 4, 0>>>(
+                         cv.sort_tmp, tmp, k32a, k32b, cv.vals_a, cv.vals_b, (size_t)n, 0, 32, st, false);
+      else if (scfg == 2) se = rocprim::radix_sort_pairs<radix_sort_config<default_config, merge_sort_config<512, 512, 8, 128, 128, 4, (1u << 30)>>>(
+                              cv.sort_tmp, tmp, k32a, k32b, cv.vals_a, cv.vals_b, (size_t)n, 0, 32, st, false);
+      else if (scfg == 3) se = rocprim::radix_sort_pairs<radix_sort_config<default_config, merge_sort_config<256, 256, 8, 128, 128, 4, (1u << 30)>>>(
+                              cv.sort_tmp, tmp, k32a, k32b, cv.vals_a, cv.vals_b, (size_t)n, 0, 32, st, false);
+      else if (scfg == 4) se = rocprim::radix_sort_pairs<radix_sort_config<default_config, merge_sort_config<1024, 1024, 4, 128, 256, 8, 0>>>(
+                              cv.sort_tmp, tmp, k32a, k32b, cv.vals_a, cv.vals_b, (size_t)n, 0, 32, st, false);
+      else se = rocprim::radix_sort_pairs(cv.sort_tmp, tmp, k32a, k32b, cv.vals_a, cv.vals_b, (size_t)n, 0, 32, st, false);
+      if (se != hipSuccess) return OBB_ERR_LAUNCH;
     } else {
       k_make_keys<<<gb, T, 0, st>>>(scores, score_stride, seg_id, tie, tie_bits, kind == 0 ? boxes : nullptr,
                                     kind == 0 ? drop_small : 0, (int)n, cv.keys_a, cv.vals_a);
@@ -640,14 +675,16 @@ static int run_nms(int kind, const float* boxes, int stride, const float* scores
   NmsArgs a{};
   if (use_grid) {
     a.gmeta = cv.grid.meta; a.bbpart = cv.grid.bbpart; a.nparts = cv.grid.nparts; a.gcnt = cv.grid.cnt; a.gstart = cv.grid.start;
-    a.gsorted = cv.grid.sorted; a.gwsum = cv.grid.wsum; a.ulist = cv.grid.ulist; a.gmask = cv.grid.mask;
+    a.gsorted = cv.grid.sorted; a.gwsum = cv.grid.wsum; a.ulist = cv.grid.ulist; a.gmask = cv.grid.mask; a.gfine = grid_fine();
   }
   if (use_slabs) {
     a.slab_cover = cv.grid.slab_cover; a.slab_flag = cv.grid.slab_flag; a.slab_cnt = cv.grid.slab_cnt; a.slab_keep = cv.grid.slab_keep;
     a.rec2 = cv.grid.rec2; a.order2 = cv.grid.order2; a.pos_old = cv.grid.pos_old; a.alive2 = cv.grid.alive2; a.kept_bits = cv.grid.kept_bits;
     a.alive2_words = (int)cv.grid.alive2_words; a.kept_words = (int)cv.grid.kept_words;
     static int slab_cap = -1;
-    if (slab_cap < 0) { const char* e = getenv("OBB_NMS_SLAB_CAP"); slab_cap = e ? atoi(e) : 0; if (slab_cap < 0) slab_cap = 0; }
+    // chunk capacity of a slab team: 1024 measured best at 100k / 18 slabs (512: 363 us, 1024: 330, 1536: 362, 1920: 383 --
+    // a team has ~14 workgroups: the pair phase grows with the square of the chunk, smaller chunks add steps)
+    if (slab_cap < 0) { const char* e = getenv("OBB_NMS_SLAB_CAP"); slab_cap = e ? atoi(e) : 1024; if (slab_cap < 0) slab_cap = 0; }
     a.slab_cap = slab_cap ? (slab_cap + 63) / 64 * 64 : 0;
   }
   a.rec = cv.rec; a.order = cv.vals_b; a.alive = cv.alive; a.seg_begin = cv.seg_begin; a.seg_end = cv.seg_end;

@@ -76,6 +76,7 @@ struct NmsArgs {
   int* gwsum;                // [grid size] per-workgroup totals of the distributed scan
   uint32_t* ulist;           // [gmeta->n_brute] sorted positions of the boxes kept out of the index (filled by grid_build)
   uint32_t gmask;            // table size - 1 (power of two)
+  int gfine;                 // GridPlan::fine
   // Independent slabs (grid.h): slab_cover == NULL: none.  One list whose boxes fall into groups that cannot overlap each
   // other (the callers' cls * 4096 offsets) is re-laid out slab by slab INSIDE this kernel (slab_setup) and run as that many
   // concurrent segments, one team each; the kept boxes meet again in score order through a bitmap over the original
@@ -295,7 +296,7 @@ __device__ __forceinline__ int nms_select(const NmsArgs& a, int se, int& cur, in
 
 // ------------------------------------------------------------------ A1: pairs inside the chunk (all waves of the team)
 template <class G, bool FN>
-__device__ __forceinline__ void nms_pairs(const NmsArgs& a, int tm, int cn, const uint32_t* cidx, int tw, int ntw, WaveLds<G>& L) {
+__device__ __forceinline__ void nms_pairs(const NmsArgs& a, int tm, int cn, const uint32_t* cidx, int tw, int ntw, WaveLds<G>& L, int* s_next) {
   const int lane = threadIdx.x & 63;
   const int nb = (cn + 63) >> 6;
   const int items = nb * nb;
@@ -391,7 +392,19 @@ __device__ __forceinline__ void nms_pairs(const NmsArgs& a, int tm, int cn, cons
     if (Q1.count >= 64) drain1b(64);
     if (Q2.count >= 64) drain2(64);
   };
-  for (int it2 = tw; it2 < items_sub; it2 += ntw) {
+  // (items are dealt to the workgroups of the team, w, w + T, ...; a workgroup's waves take them from a counter in LDS:
+  //  a tile costs between nothing -- no pair passes the circle test -- and several drains)
+  const int wgi = tw / kNmsWaves, Tw = ntw / kNmsWaves;
+  __syncthreads();
+  if (threadIdx.x == 0) *s_next = 0;
+  __syncthreads();
+  for (;;) {
+    int kk = 0;
+    if (lane == 0) kk = atomicAdd(s_next, 1);
+    kk = __builtin_amdgcn_readfirstlane(kk);
+    const long long it_ll = (long long)wgi + (long long)kk * Tw;
+    if (it_ll >= items_sub) break;
+    const int it2 = (int)it_ll;
     const int item = it2 / nsub, sub = it2 - item * nsub;
     int rb = (int)(((float)(2 * nb + 1) - sqrtf((float)((2 * nb + 1) * (2 * nb + 1) - 8 * item))) * 0.5f);
     rb = rb < 0 ? 0 : (rb > nb - 1 ? nb - 1 : rb);
@@ -888,7 +901,7 @@ constexpr int kScanBatch = OBB_SCAN_BATCH;          // blocks of candidates in f
 // independent 16-byte loads per lane in flight: the phase is bound by memory latency, not by arithmetic.
 template <class G>
 __device__ __forceinline__ void nms_cross_grid(const NmsArgs& a, const GridPlan& gp, uint32_t level_mask, const uint32_t* rows, int nr,
-                                               int c0, int se, int tw, int ntw, WaveLds<G>& L) {
+                                               int c0, int se, int tw, int ntw, WaveLds<G>& L, int* s_next) {
   const int lane = threadIdx.x & 63;
   const uint32_t mmask = a.gmask;
   const int M = (int)mmask + 1;
@@ -950,7 +963,23 @@ __device__ __forceinline__ void nms_cross_grid(const NmsArgs& a, const GridPlan&
     if (Q2.count >= 64) drain2(64);
   };
 
-  for (int item = tw; item < n_items; item += ntw) {
+  // Work distribution: workgroup w of the team owns the items w, w + T, w + 2T, ...; its eight waves take them from a
+  // counter in LDS, one at a time.  An item costs between a few and a hundred-odd blocks (small box in an empty corner /
+  // large box in a crowd), a wave gets 3-6 of them: with a fixed deal per wave the slowest of 2048 waves took more than
+  // twice the average (uniform, 100k: 2069 -> 1841 us with the pooled deal).  Tickets of four rows drawn by the
+  // workgroups from one agent-scope counter were measured as well (1847 us): the tail of a phase is one ITEM long
+  // (30-80 us), whoever draws it -- not kept.
+  const int wgi = tw / kNmsWaves, Tw = ntw / kNmsWaves;
+  __syncthreads();
+  if (threadIdx.x == 0) *s_next = 0;
+  __syncthreads();
+  for (;;) {
+    int k = 0;
+    if (lane == 0) k = atomicAdd(s_next, 1);
+    k = __builtin_amdgcn_readfirstlane(k);
+    const long long item_ll = (long long)wgi + (long long)k * Tw;
+    if (item_ll >= n_items) break;
+    const int item = (int)item_ll;
     const int row = item / kw, part = item - row * kw;
     c_items++;
     ctick();
@@ -1237,7 +1266,7 @@ struct SlabLds {
 //   4. STABLE scatter of records / original indices / original positions / alive bits: the order inside a slab is the
 //      score order of the list                                                                      -> team barrier
 template <class G>
-__device__ __forceinline__ int slab_setup(const NmsArgs& a, const GridPlan& gp, unsigned char* smem, TeamBar& gbar, int* s_flag, SlabLds& SL) {
+__device__ __forceinline__ int slab_setup(const NmsArgs& a, float bin_x0, float inv, unsigned char* smem, TeamBar& gbar, int* s_flag, SlabLds& SL) {
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int NB = gridDim.x, wg = blockIdx.x;
   uint32_t* starts = reinterpret_cast<uint32_t*>(smem);       // [kSlabWords] bins where a run starts
@@ -1251,7 +1280,9 @@ __device__ __forceinline__ int slab_setup(const NmsArgs& a, const GridPlan& gp, 
   int* misc = wcnt + kNmsWaves * kMaxSlabs;                   // [4]
   if (tid == 0) SL.nslab = 0;
   if (*a.slab_flag != 0 || NB > kNmsThreads) return 0;        // (written by the prep kernel: uniform)
-  const float inv = slab_inv_bin(gp);
+  const bool sprof = a.prof != nullptr && blockIdx.x == 0 && tid == 0;
+  u64 st0 = sprof ? wall_clock64() : 0ull;
+  auto slap = [&](int slot) { if (sprof) { const u64 t = wall_clock64(); a.prof[slot] += t - st0; st0 = t; } };
   __syncthreads();
   int mypre = 0;
   auto cover = [&](int k) -> uint32_t {                       // the OR of the prep kernel's kSlabCopies copies
@@ -1271,10 +1302,11 @@ __device__ __forceinline__ int slab_setup(const NmsArgs& a, const GridPlan& gp, 
   if (tid == kSlabWords - 1) misc[0] = mypre + __popc(starts[tid]);
   __syncthreads();
   const int nruns = misc[0];
+  slap(42);
   if (nruns < 2) return 0;
   const int S = nruns < kMaxSlabs ? nruns : kMaxSlabs;        // (the runs beyond the last id share it: still independent of the others)
   auto slab_of = [&](float x) -> int {
-    const int b = slab_bin(x, gp.x0, inv);
+    const int b = slab_bin(x, bin_x0, inv);
     int r = wpre[b >> 5] + __popc(starts[b >> 5] & (0xffffffffu >> (31 - (b & 31)))) - 1;
     return r < 0 ? 0 : (r < S ? r : S - 1);
   };
@@ -1301,8 +1333,10 @@ __device__ __forceinline__ int slab_setup(const NmsArgs& a, const GridPlan& gp, 
   }
   __syncthreads();
   if (tid < kMaxSlabs) stg_agent(a.slab_cnt + (size_t)wg * kMaxSlabs + tid, cnt[tid]);
+  slap(43);
   if (!team_barrier(gbar, s_flag)) return -1;
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  slap(44);
   // ---- 3: totals and offsets.  The table first travels into LDS with independent 16-byte loads (thread t: the row of
   // workgroup t), then thread (slab, part) adds up an eighth of a column -- no load waits for a reduction
   {
@@ -1311,7 +1345,13 @@ __device__ __forceinline__ int slab_setup(const NmsArgs& a, const GridPlan& gp, 
     if (tid < NB) {
       const int4* row = reinterpret_cast<const int4*>(a.slab_cnt + (size_t)tid * kMaxSlabs);
       int4* dst = reinterpret_cast<int4*>(tab + tid * kMaxSlabs);
-      for (int j = 0; j < nq; j++) dst[j] = row[j];
+      for (int j0 = 0; j0 < nq; j0 += 8) {                     // eight loads in flight, then their LDS stores
+        int4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) v[u] = (j0 + u < nq) ? row[j0 + u] : make_int4(0, 0, 0, 0);
+#pragma unroll
+        for (int u = 0; u < 8; u++) if (j0 + u < nq) dst[j0 + u] = v[u];
+      }
     }
     __syncthreads();
     const int s0 = tid & (kMaxSlabs - 1), part = tid >> 6;     // kNmsThreads / kMaxSlabs = 8 parts
@@ -1328,19 +1368,18 @@ __device__ __forceinline__ int slab_setup(const NmsArgs& a, const GridPlan& gp, 
     int acc = 0, mx = 0, nonempty = 0;
     for (int s0 = 0; s0 < S; s0++) { base[s0] = acc; acc += (tot[s0] + 63) & ~63; mx = mx > tot[s0] ? mx : tot[s0]; nonempty += tot[s0] > 0 ? 1 : 0; }
     // chunk capacity of a team: the single list's edge buffer shared out, cap (cap - 1) / 2 <= ecap / teams
-    const long long e = nonempty > 0 ? a.ecap / nonempty : 0;
-    int c = (int)((1.0 + sqrt(1.0 + 8.0 * (double)e)) * 0.5);
-    while (c > 0 && (long long)c * (c - 1) / 2 > e) c--;
-    c &= ~63;
-    if (c > a.capmax) c = a.capmax;
+    int c = 0;                                                 // largest multiple of 64 with c (c - 1) / 2 * teams <= ecap, at most capmax
+    while (c + 64 <= a.capmax && (long long)(c + 64) * (c + 63) / 2 * (nonempty > 0 ? nonempty : 1) <= a.ecap) c += 64;
     if (a.slab_cap > 0 && c > a.slab_cap) c = a.slab_cap;      // (OBB_NMS_SLAB_CAP: measurements)
     misc[1] = (mx <= kSlabMaxSeg && nonempty >= 2 && nonempty <= NB && c >= 512) ? 1 : 0;
     misc[2] = nonempty; misc[3] = c;
     SL.cap = c; SL.ecap = (long long)c * (c - 1) / 2;
   }
   __syncthreads();
+  slap(45);
   if (!misc[1]) return 0;                                      // (uniform: every workgroup read the same table)
   // ---- 4: stable scatter, tile by tile
+  u64 seen = 0ull;
   for (int pb = p0; pb < p1; pb += kNmsThreads) {
     const int p = pb + tid;
     int sl = -1;
@@ -1376,8 +1415,7 @@ __device__ __forceinline__ int slab_setup(const NmsArgs& a, const GridPlan& gp, 
       }
       stg_agent(a.order2 + qn, a.order[p]);
       stg_agent(a.pos_old + qn, (uint32_t)p);
-      const u64 old = atomicOr(a.alive2 + (qn >> 6), 1ull << (qn & 63));      // (returning: covered by the wave's vmcnt)
-      asm volatile("; alive bit set %0" ::"v"((unsigned)(old >> 32) ^ (unsigned)old));
+      seen ^= atomicOr(a.alive2 + (qn >> 6), 1ull << (qn & 63));             // (returning, consumed below: covered by the wave's vmcnt)
     }
     __syncthreads();
     if (tid < kMaxSlabs) {
@@ -1386,6 +1424,7 @@ __device__ __forceinline__ int slab_setup(const NmsArgs& a, const GridPlan& gp, 
       run[tid] += add;
     }
   }
+  asm volatile("; alive bits set %0" ::"v"((unsigned)(seen >> 32) ^ (unsigned)seen));
   // ---- the plan: one team per non-empty slab, the spare workgroups in proportion to the sizes
   __syncthreads();
   if (tid < kMaxSlabs) { SL.segb[tid] = tid < S ? base[tid] : 0; SL.sege[tid] = tid < S ? base[tid] + tot[tid] : 0; }
@@ -1403,8 +1442,10 @@ __device__ __forceinline__ int slab_setup(const NmsArgs& a, const GridPlan& gp, 
     }
     SL.nslab = S;
   }
+  slap(46);
   if (!team_barrier(gbar, s_flag)) return -1;                  // (its __syncthreads also publish SL to the workgroup)
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  slap(47);
   return 1;
 }
 
@@ -1491,8 +1532,8 @@ __global__ __launch_bounds__(kNmsThreads) __attribute__((amdgpu_waves_per_eu(1, 
     // (slab_flag[2] != 0: the prep kernel found the data wide enough to look for slabs and marked the x bins: one word decides)
     if (a.slab_cover != nullptr && a.nseg == 1 && a.max_keep <= 0 && a.cull != 0 && a.plan == nullptr && a.bbpart != nullptr && a.slab_flag[2] != 0) {
       const u64 t_su = (a.prof && blockIdx.x == 0 && tid == 0) ? wall_clock64() : 0ull;
-      const GridPlan sp = data_extent();
-      const int st = sp.ok ? slab_setup<G>(a, sp, smem, gbar, &s_flag, s_slab) : 0;
+      // (the bins' origin and scale as the prep kernel derived them: slab_flag[4], [5])
+      const int st = slab_setup<G>(a, __int_as_float(a.slab_flag[4]), __int_as_float(a.slab_flag[5]), smem, gbar, &s_flag, s_slab);
       if (st < 0) return;
       if (a.prof && blockIdx.x == 0 && tid == 0) a.prof[41] += wall_clock64() - t_su;
       if (st > 0) {
@@ -1550,6 +1591,7 @@ __global__ __launch_bounds__(kNmsThreads) __attribute__((amdgpu_waves_per_eu(1, 
       if (grid_on && nr >= kGridMinRows) {           // (a few hundred kept rows: the exhaustive form is the cheaper one)
         if (!grid_built) {                           // first use: sort what is still alive behind the chunk into its cells
           gp = data_extent();
+          gp.fine = a.gfine;
           const int st = gp.ok ? grid_build<G>(a, gp, c0, wg, T, bar, &s_flag, s_i, glevels, n_brute) : 2;
           if (st == 1) { aborted = true; return; }
           grid_built = true;
@@ -1557,7 +1599,7 @@ __global__ __launch_bounds__(kNmsThreads) __attribute__((amdgpu_waves_per_eu(1, 
         }
       }
       if (grid_on && nr >= kGridMinRows) {
-        nms_cross_grid<G>(a, gp, glevels, rows, nr, c0, c1, tw, ntw, L);
+        nms_cross_grid<G>(a, gp, glevels, rows, nr, c0, c1, tw, ntw, L, &s_i[12]);
         if (n_brute > 0) {
           // the boxes the index leaves out: brute kept rows against every column, every kept row against the brute columns
           // (the chunk list in LDS is free between resolve and the next select: it takes the brute rows, capmax at a time)
@@ -1635,7 +1677,7 @@ __global__ __launch_bounds__(kNmsThreads) __attribute__((amdgpu_waves_per_eu(1, 
       lap(1);
       if (cn == 0) continue;                               // nothing alive in the rest of the window (cur == wend now)
       const u64 tpz = (a.prof && tid == 0) ? wall_clock64() : 0ull;
-      nms_pairs<G, GRID>(a, team, cn, cidx, tw, ntw, L);
+      nms_pairs<G, GRID>(a, team, cn, cidx, tw, ntw, L, &s_i[12]);
       if (a.prof && tid == 0) { const u64 d = wall_clock64() - tpz; atomicMax(a.prof + 29, d); atomicAdd(a.prof + 30, d); }
       lap(2);
       // ---- all edges are out: the last arriver resolves the chunk, the others wait for its rows
