@@ -112,18 +112,38 @@ class StandinV5s(nn.Module):
     def calibrate(self, im, conf_thres=0.25, fg_frac=0.03):
         """Shift the head's objectness bias so that about fg_frac of the anchors have obj > conf_thres on `im`, and the class
         biases so that a passing anchor carries one or two confident classes (random weights; timing only)."""
+        # random weights + BatchNorm in eval mode (running mean 0 / var 1) let the signal fade layer by layer until every anchor
+        # carries the same logits: first give the BN layers the statistics of real passes (cumulative average, two batches)
+        bns = [m for m in self.modules() if isinstance(m, nn.BatchNorm2d)]
+        for m in bns:
+            m.reset_running_stats()
+            m.momentum = None
+        self.train()
+        for k in range(2):
+            self.features(im.roll(k, 0).flip(3) if k else im)
+        self.eval()
         feats = self.features(im)
         na, no, nc = self.detect.na, self.detect.no, self.nc
         lg = torch.logit(torch.tensor(conf_thres)).item()
         for i, f in enumerate(feats):
-            raw = self.detect.m[i](f).float().view(f.shape[0], na, no, -1)
+            conv = self.detect.m[i]
+            w = conv.weight.view(na, no, -1)
+            b = conv.bias.view(na, no)
+            raw = conv(f).float().view(f.shape[0], na, no, -1)
+            # spread of the logits like a trained head's (S-pred draws them from N(0, 1.5)): scale the objectness / class rows
+            for sl, target in ((slice(4, 5), 1.5), (slice(5, 5 + nc), 1.0)):
+                sd = raw[:, :, sl].std().item()
+                g = target / max(sd, 1e-6)
+                mu = raw[:, :, sl].mean().item()
+                w.data[:, sl] *= g
+                b.data[:, sl] = (b.data[:, sl].float() - mu) * g      # centred; the quantile shifts below place the thresholds
+            raw = conv(f).float().view(f.shape[0], na, no, -1)
             obj = raw[:, :, 4].flatten()
             q = torch.quantile(obj[: 1 << 20], 1.0 - fg_frac).item()
+            b.data[:, 4] += lg - q                                     # fg_frac of the anchors pass obj > conf_thres
             cls = raw[:, :, 5:5 + nc].flatten()
-            qc = torch.quantile(cls[: 1 << 20], 1.0 - 1.5 / nc).item()
-            b = self.detect.m[i].bias.view(na, -1)
-            b.data[:, 4] += (lg + 1.0) - q
-            b.data[:, 5:5 + nc] += 2.0 - qc
+            qc = torch.quantile(cls[: 1 << 20], 1.0 - 1.2 / nc).item()
+            b.data[:, 5:5 + nc] += 0.0 - qc                            # ~1.2 classes per anchor above sigmoid 0.5: one or two labels per passing anchor
 
 
 class SyntheticVal:
@@ -166,6 +186,7 @@ class SyntheticVal:
 def val_buckets(device, n_images=160, batch=16, nc=16, conf_thres=0.25, iou_thres=0.45, half=True, seed=0):
     """Run the product's val_sharded.run over this rank's synthetic shard; returns the reference's buckets in ms/img."""
     from yolov5_obb_amd import val_sharded
+    torch.backends.cudnn.benchmark = True          # let MIOpen search: its immediate-mode pick for the 6x6 / stride-2 stem is a naive kernel (7.8 ms)
     torch.manual_seed(seed)
     model = StandinV5s(nc).to(device).eval()
     if half:
@@ -174,7 +195,7 @@ def val_buckets(device, n_images=160, batch=16, nc=16, conf_thres=0.25, iou_thre
     im0 = (next(iter(loader))[0].to(device).half() if half else next(iter(loader))[0].to(device).float()) / 255
     model.calibrate(im0, conf_thres)
     with torch.no_grad():
-        for _ in range(2):                                        # MIOpen picks its kernels on the first passes
+        for _ in range(3):                                        # MIOpen picks its kernels on the first passes
             model(im0)
     torch.cuda.synchronize(device)
     # one untimed pass over two batches: the NMS driver sizes its candidate slots / workspace on its first calls

@@ -167,6 +167,7 @@ struct GridDev {
   int* start;                  // [M + 4] exclusive prefix, start[M] = total
   int* wsum;                   // [kMaxTeams] per-workgroup totals of the in-kernel scan
   float4* sorted;              // [n] {x, y, r, position}
+  uint32_t* slot_of;           // [n] position -> entry of `sorted`
   uint32_t* ulist;             // [n] positions kept out of the index
   uint32_t mask;               // M - 1
   // independent slabs (grid.h; nms_core.h slab_setup): coverage bitmap + flag live in the zeroed block behind GridMeta
@@ -480,6 +481,7 @@ static int carve(void* base, int64_t n, int64_t nseg, int recq, int C, Carve* cv
     cv->grid.nparts = (int)((nn + 255) / 256);
     cv->grid.bbpart = (int*)take((size_t)cv->grid.nparts * kBbInts * 4);
     cv->grid.sorted = (float4*)take(nn * 16);
+    cv->grid.slot_of = (uint32_t*)take(nn * 4);
     cv->grid.ulist = (uint32_t*)take(nn * 4);
     const size_t n2 = nn + 64 * (size_t)kMaxSlabs;            // every slab starts on a 64-position boundary
     cv->grid.slab_cnt = (int*)take((size_t)kMaxTeams * kMaxSlabs * 4);
@@ -675,7 +677,7 @@ static int run_nms(int kind, const float* boxes, int stride, const float* scores
   NmsArgs a{};
   if (use_grid) {
     a.gmeta = cv.grid.meta; a.bbpart = cv.grid.bbpart; a.nparts = cv.grid.nparts; a.gcnt = cv.grid.cnt; a.gstart = cv.grid.start;
-    a.gsorted = cv.grid.sorted; a.gwsum = cv.grid.wsum; a.ulist = cv.grid.ulist; a.gmask = cv.grid.mask; a.gfine = grid_fine();
+    a.gsorted = cv.grid.sorted; a.gslot = cv.grid.slot_of; a.gwsum = cv.grid.wsum; a.ulist = cv.grid.ulist; a.gmask = cv.grid.mask; a.gfine = grid_fine();
   }
   if (use_slabs) {
     a.slab_cover = cv.grid.slab_cover; a.slab_flag = cv.grid.slab_flag; a.slab_cnt = cv.grid.slab_cnt; a.slab_keep = cv.grid.slab_keep;

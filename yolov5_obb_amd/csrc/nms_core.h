@@ -72,7 +72,8 @@ struct NmsArgs {
   int nparts;
   int* gcnt;                 // [gmask + 1] zero before the launch and after every build
   int* gstart;               // [gmask + 2] first entry of every table slot in gsorted (exclusive prefix; [gmask + 1] = total)
-  float4* gsorted;           // {x, y, r, sorted position as bits} in slot order
+  float4* gsorted;           // {x, y, r, sorted position as bits | dead flag in bit 31} in slot order
+  uint32_t* gslot;           // [n] sorted position -> its entry of gsorted (boxes in the index)
   int* gwsum;                // [grid size] per-workgroup totals of the distributed scan
   uint32_t* ulist;           // [gmeta->n_brute] sorted positions of the boxes kept out of the index (filled by grid_build)
   uint32_t gmask;            // table size - 1 (power of two)
@@ -919,7 +920,13 @@ __device__ __forceinline__ void nms_cross_grid(const NmsArgs& a, const GridPlan&
   // completed read-modify-writes, and no drain waits for its own
   u64 seen = 0ull;
   auto kill = [&](bool hit, uint32_t cp) {
-    if (hit) seen ^= atomicAnd(a.alive + (cp >> 6), ~(1ull << (cp & 63)));
+    if (hit) {
+      seen ^= atomicAnd(a.alive + (cp >> 6), ~(1ull << (cp & 63)));
+      // ... and the box's entry of the cell-order array gets its "dead" bit (top bit of the position word): later scans drop
+      // it with the circle test instead of fetching its alive word.  Write-through; a reader that still sees the old entry
+      // queues a dead box, which the first decision stage then finds dead: the flag is a filter, the bitmap is the truth
+      stg_agent(reinterpret_cast<uint32_t*>(a.gsorted + a.gslot[cp]) + 3, cp | 0x80000000u);
+    }
   };
   auto drain2 = [&](int cnt) {                     // stage 2: exact clip
     wave_sync();
@@ -991,8 +998,8 @@ __device__ __forceinline__ void nms_cross_grid(const NmsArgs& a, const GridPlan&
       int res = 0;
       uint32_t cp = 0;
       if (lane < cnt) {
-        cp = L.qbuf[(Q.head + lane) & 127];              // (alive when it was queued: checked in the scan)
-        res = G::classify_quick(a.rec + (size_t)rp * G::RECQ, a.rec + (size_t)cp * G::RECQ, G::thr_of(a), true);
+        cp = L.qbuf[(Q.head + lane) & 127];              // (queued without a look at the bitmap: the scan only saw the dead flag)
+        if (col_alive(cp)) res = G::classify_quick(a.rec + (size_t)rp * G::RECQ, a.rec + (size_t)cp * G::RECQ, G::thr_of(a), true);
       }
       kill(res == 1, cp);
       Q.head = (Q.head + cnt) & 127;
@@ -1108,23 +1115,14 @@ __device__ __forceinline__ void nms_cross_grid(const NmsArgs& a, const GridPlan&
 #endif
               }
             }
-            // circle test, then the alive bits of what passed (four independent gathers in flight): most candidates
-            // of a later step are dead already and never reach a queue
-            bool pass[kScanBatch];
-            u64 aw[kScanBatch];
+            // circle test + the entry's dead flag (set by whoever killed the box, see `kill`): most candidates of a later
+            // step are dead already and never reach a queue; what passes is queued without a look at the alive bitmap (that
+            // was a second, dependent round trip per batch) -- the first decision stage checks it
 #pragma unroll
             for (int u = 0; u < kScanBatch; u++) {
-              const uint32_t cp = __float_as_uint(cq[u].w);
+              const uint32_t cw = __float_as_uint(cq[u].w), cp = cw & 0x7fffffffu;
               const float dx = cq[u].x - rq.x, dy = cq[u].y - rq.y, rs = rq.z + cq[u].z;
-              pass[u] = val[u] && (int)cp >= c0 && (int)cp < se && !(dx * dx + dy * dy > rs * rs);
-              // (a plain, cacheable load: a stale word can only show a dead box as alive -- bits go 1 -> 0 -- which costs a
-              //  redundant test, never a missed one; the coherent load takes about twice as long)
-              aw[u] = pass[u] ? a.alive[cp >> 6] : 0ull;
-            }
-#pragma unroll
-            for (int u = 0; u < kScanBatch; u++) {
-              const uint32_t cp = __float_as_uint(cq[u].w);
-              const bool go = pass[u] && ((aw[u] >> (cp & 63)) & 1ull);
+              const bool go = val[u] && !(cw >> 31) && (int)cp >= c0 && (int)cp < se && !(dx * dx + dy * dy > rs * rs);
               if (__ballot(go)) {
                 c_pass += (u64)__popcll(__ballot(go));
                 Q.push(go, cp);
@@ -1237,9 +1235,11 @@ __device__ __forceinline__ int grid_build(const NmsArgs& a, const GridPlan& gp, 
     int lv = 0;
     if (classify(p, slot, q0, lv) == 1) {
       const int k = __hip_atomic_fetch_sub(a.gcnt + slot, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - 1;   // the order inside a slot does not matter
-      u64* o = reinterpret_cast<u64*>(a.gsorted + (size_t)ldg_agent(a.gstart + slot) + k);
+      const int at = ldg_agent(a.gstart + slot) + k;
+      u64* o = reinterpret_cast<u64*>(a.gsorted + (size_t)at);
       stg_agent(o, ((u64)__float_as_uint(q0.y) << 32) | (u64)__float_as_uint(q0.x));
       stg_agent(o + 1, ((u64)(uint32_t)p << 32) | (u64)__float_as_uint(q0.z));
+      stg_agent(a.gslot + p, (uint32_t)at);                    // position -> entry (the killers flag the entry)
     }
   }
   if (!team_barrier(bar, s_flag)) return 1;
