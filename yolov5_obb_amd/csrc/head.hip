@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
 #include <stdint.h>
+#include <type_traits>
 #include "obb_hip.h"
 #include "dtype_device.h"
 #include "loss_math.h"
@@ -64,8 +65,8 @@ template <> struct Pack16<__half> { static constexpr int V = 8; };
 
 // VEC: the input rows are 4-element aligned (HW % 4 == 0) and both outputs are 16-byte aligned at every tile start,
 // so the tile is read with 8/16-byte loads and written with 16-byte stores; otherwise element-wise accesses.
-template <typename T, bool VEC, int kTileHW>
-__global__ __launch_bounds__(256) void k_detect_decode(DetectArgs d) {
+template <typename T, bool VEC, int kTileHW, int NT, int SK>
+__global__ __launch_bounds__(NT) void k_detect_decode(DetectArgs d) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   T* tile = reinterpret_cast<T*>(smem_raw);            // [no] rows of 64 positions, skewed (tix)
   const int tid = threadIdx.x;
@@ -79,28 +80,59 @@ __global__ __launch_bounds__(256) void k_detect_decode(DetectArgs d) {
   // LDS layout: channel row c starts at c*64 + 2*(c>>3) elements.  The store phase reads 8 consecutive channels of one
   // position per lane, i.e. lane stride = 8 rows = 512 + 2 elements: one 32-bit bank further per lane (fp16; two for fp32)
   // instead of the same eight banks again (8-way conflict with a plain 64 / 65 pitch).
-  auto tix = [](int c, int hw) -> int { return c * kTileHW + ((c >> 3) << 1) + hw; };
+  auto tix = [](int c, int hw) -> int { return c * kTileHW + (c >> 3) * SK + hw; };   // SK = 2: one bank per lane in the store phase; 4: two banks, and 4-position groups stay 8-byte aligned (one LDS store per load)
 
   // ---- load (coalesced along hw)
   if constexpr (VEC) {
     // kTileHW/4 threads x 4 positions cover the positions of one channel row; 256/(kTileHW/4) channel rows per step
-    constexpr int TPR = kTileHW / 4, RPS = 256 / TPR;
+    constexpr int TPR = kTileHW / 4, RPS = NT / TPR;
     const int q = tid % TPR, c16 = tid / TPR;
     const int hw = q * 4;
+    if (nhw == kTileHW) {
+      // full tile (all but the last of a plane): kLoadBatch channel rows in flight per thread before the first LDS store --
+      // the loop over 200 rows otherwise waits for every load (one HBM round trip per row and thread)
+      constexpr int kLoadBatch = 8;
+      using Vec = typename std::conditional<sizeof(T) == 2, uint2, float4>::type;
+      for (int c0 = c16; c0 < no; c0 += RPS * kLoadBatch) {
+        Vec v[kLoadBatch];
+#pragma unroll
+        for (int u = 0; u < kLoadBatch; u++) {
+          const int c = c0 + u * RPS;
+          if (c < no) v[u] = *reinterpret_cast<const Vec*>(in + (size_t)c * HW + hw);
+        }
+#pragma unroll
+        for (int u = 0; u < kLoadBatch; u++) {
+          const int c = c0 + u * RPS;
+          if (c < no) {
+            if constexpr (SK == 4) *reinterpret_cast<Vec*>(&tile[tix(c, hw)]) = v[u];
+            else {
+              const T* e = reinterpret_cast<const T*>(&v[u]);
+#pragma unroll
+              for (int j = 0; j < 4; j++) tile[tix(c, hw + j)] = e[j];
+            }
+          }
+        }
+      }
+    } else
     for (int c = c16; c < no; c += RPS) {
       if (hw + 3 < nhw) {
         T v[4];
         if constexpr (sizeof(T) == 2) *reinterpret_cast<uint2*>(v) = *reinterpret_cast<const uint2*>(in + (size_t)c * HW + hw);
         else *reinterpret_cast<float4*>(v) = *reinterpret_cast<const float4*>(in + (size_t)c * HW + hw);
+        if constexpr (SK == 4) {                              // aligned group: one 8- / 16-byte LDS store
+          if constexpr (sizeof(T) == 2) *reinterpret_cast<uint2*>(&tile[tix(c, hw)]) = *reinterpret_cast<const uint2*>(v);
+          else *reinterpret_cast<float4*>(&tile[tix(c, hw)]) = *reinterpret_cast<const float4*>(v);
+        } else {
 #pragma unroll
-        for (int j = 0; j < 4; j++) tile[tix(c, hw + j)] = v[j];
+          for (int j = 0; j < 4; j++) tile[tix(c, hw + j)] = v[j];
+        }
       } else {
         for (int j = 0; j < 4; j++) if (hw + j < nhw) tile[tix(c, hw + j)] = in[(size_t)c * HW + hw + j];
       }
     }
   } else {
     const int hw = tid % kTileHW, c4 = tid / kTileHW;
-    for (int c = c4; c < no; c += 256 / kTileHW)
+    for (int c = c4; c < no; c += NT / kTileHW)
       if (hw < nhw) tile[tix(c, hw)] = in[(size_t)c * HW + hw];
   }
   __syncthreads();
@@ -123,7 +155,7 @@ __global__ __launch_bounds__(256) void k_detect_decode(DetectArgs d) {
   if constexpr (VEC) {
     constexpr int V = Pack16<T>::V;
     const int nvec = nel / V;                           // full 16-byte groups; the tail (< V elements) goes element-wise
-    for (int g = tid; g < nvec; g += 256) {
+    for (int g = tid; g < nvec; g += NT) {
       const int e0 = g * V;
       int hw = e0 / no, c = e0 - hw * no;
       alignas(16) T rawv[V];
@@ -138,7 +170,7 @@ __global__ __launch_bounds__(256) void k_detect_decode(DetectArgs d) {
       if (xo) *reinterpret_cast<uint4*>(xo + e0) = *reinterpret_cast<const uint4*>(rawv);
       if (zo) *reinterpret_cast<uint4*>(zo + e0) = *reinterpret_cast<const uint4*>(decv);
     }
-    for (int e = nvec * V + tid; e < nel; e += 256) {
+    for (int e = nvec * V + tid; e < nel; e += NT) {
       const int hw = e / no, c = e - hw * no;
       const T raw = tile[tix(c, hw)];
       if (xo) xo[e] = raw;
@@ -146,8 +178,8 @@ __global__ __launch_bounds__(256) void k_detect_decode(DetectArgs d) {
     }
   } else {
     int c = tid % no, hw = tid / no;
-    const int dc = 256 % no, dh = 256 / no;
-    for (int e = tid; e < nel; e += 256) {
+    const int dc = NT % no, dh = NT / no;
+    for (int e = tid; e < nel; e += NT) {
       const T raw = tile[tix(c, hw)];
       if (xo) xo[e] = raw;
       if (zo) st_from_float<T>(zo + e, decode_at(raw, c, hw));
@@ -235,11 +267,17 @@ int obb_detect_decode_col(const void* conv_out, int dtype, int64_t bs, int64_t n
   }
   const int HW = (int)(ny * nx);
   const size_t esz = dtype == 0 ? 4 : 2;
-  auto lds_of = [&](int tile) { return ((size_t)no * tile + 2 * (size_t)(no / 8 + 2)) * esz; };   // skewed rows (tix in the kernel)
-  // measured on (16, 3*200, 128..32, ..) fp16: 128-position tiles (256-byte read runs, 3 workgroups per CU) 0.419 ms,
-  // 64-position tiles (6 workgroups per CU) 0.308 ms -- occupancy beats the longer runs
-  const int tile_hw = 64;
-  const size_t lds = lds_of(tile_hw);
+  // variants (OBB_DETECT_VARIANT, measurements on (16, 3*200, 128..32, ..), round 3 -- all with eight channel rows in flight
+  // per thread in the load phase, which is what moved the kernel: fp16 0.310 -> 0.281 ms, fp32 0.590 -> 0.488 ms):
+  // 0 = 64-position tiles, 256 threads, 2-element skew, element-wise LDS stores (default: fp16 0.281, fp32 0.488 ms);
+  // 1 = 4-element skew and one LDS store per 4-position group (fp16 0.282, fp32 0.798: the 16-byte LDS stores conflict);
+  // 2 = 128-position tiles with 512 threads, i.e. 256-byte read runs at the same number of waves per CU (fp16 0.277, fp32 0.954)
+  static int variant = -1;
+  if (variant < 0) { const char* e = getenv("OBB_DETECT_VARIANT"); variant = e ? atoi(e) : 0; if (variant < 0 || variant > 2) variant = 0; }
+  const int tile_hw = variant == 2 ? 128 : 64;
+  const int nthreads = variant == 2 ? 512 : 256;
+  const int skew = variant == 0 ? 2 : 4;
+  const size_t lds = ((size_t)no * tile_hw + (size_t)skew * (size_t)(no / 8 + 2)) * esz;   // skewed rows (tix in the kernel)
   dim3 grid((unsigned)((HW + tile_hw - 1) / tile_hw), (unsigned)(bs * na));
   hipStream_t st = (hipStream_t)stream;
   // vector path: input rows 4-element aligned, every tile of both outputs 16-byte aligned
@@ -247,18 +285,20 @@ int obb_detect_decode_col(const void* conv_out, int dtype, int64_t bs, int64_t n
   bool vec = (HW % 4 == 0) && al16(conv_out) && al16(x_perm_out) && al16(z_out);
   vec = vec && ((size_t)HW * no * esz) % 16 == 0 && ((size_t)a_total * no * esz) % 16 == 0 && ((size_t)a_offset * no * esz) % 16 == 0;
   if (lds > 150 * 1024) return OBB_ERR_BAD_ARG;
-#define OBB_LAUNCH_DETECT(T, VEC, TILE)                                                                                            \
+#define OBB_LAUNCH_DETECT(T, VEC, TILE, NTH, SKW)                                                                                  \
   do {                                                                                                                              \
     if (lds > 48 * 1024 &&                                                                                                          \
-        hipFuncSetAttribute((const void*)k_detect_decode<T, VEC, TILE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) \
+        hipFuncSetAttribute((const void*)k_detect_decode<T, VEC, TILE, NTH, SKW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) \
       return OBB_ERR_LAUNCH;                                                                                                        \
-    k_detect_decode<T, VEC, TILE><<<grid, 256, lds, st>>>(d);                                                                       \
+    k_detect_decode<T, VEC, TILE, NTH, SKW><<<grid, NTH, lds, st>>>(d);                                                             \
   } while (0)
 #define OBB_LAUNCH_DETECT_T(T)                                                                                                      \
   do {                                                                                                                              \
-    if (tile_hw == 128) { if (vec) OBB_LAUNCH_DETECT(T, true, 128); else OBB_LAUNCH_DETECT(T, false, 128); }                        \
-    else { if (vec) OBB_LAUNCH_DETECT(T, true, 64); else OBB_LAUNCH_DETECT(T, false, 64); }                                         \
+    if (variant == 2) { if (vec) OBB_LAUNCH_DETECT(T, true, 128, 512, 4); else OBB_LAUNCH_DETECT(T, false, 128, 512, 4); }          \
+    else if (variant == 1) { if (vec) OBB_LAUNCH_DETECT(T, true, 64, 256, 4); else OBB_LAUNCH_DETECT(T, false, 64, 256, 4); }      \
+    else { if (vec) OBB_LAUNCH_DETECT(T, true, 64, 256, 2); else OBB_LAUNCH_DETECT(T, false, 64, 256, 2); }                         \
   } while (0)
+  (void)nthreads;
   if (dtype == 0) OBB_LAUNCH_DETECT_T(float); else OBB_LAUNCH_DETECT_T(__half);
 #undef OBB_LAUNCH_DETECT_T
 #undef OBB_LAUNCH_DETECT

@@ -999,7 +999,13 @@ __device__ __forceinline__ void nms_cross_grid(const NmsArgs& a, const GridPlan&
       uint32_t cp = 0;
       if (lane < cnt) {
         cp = L.qbuf[(Q.head + lane) & 127];              // (queued without a look at the bitmap: the scan only saw the dead flag)
-        if (col_alive(cp)) res = G::classify_quick(a.rec + (size_t)rp * G::RECQ, a.rec + (size_t)cp * G::RECQ, G::thr_of(a), true);
+        // the bitmap word travels together with the two records (no branch around the test: a dependent round trip less);
+        // a box that died in the meantime just loses its result
+        // (a plain, cacheable load: a stale word can only show a dead box as alive -- bits go 1 -> 0 -- which costs a redundant
+        //  test and an idempotent kill, never a missed one; the coherent load is a round trip to memory)
+        const bool live = (a.alive[cp >> 6] >> (cp & 63)) & 1ull;
+        res = G::classify_quick(a.rec + (size_t)rp * G::RECQ, a.rec + (size_t)cp * G::RECQ, G::thr_of(a), true);
+        if (!live) res = 0;
       }
       kill(res == 1, cp);
       Q.head = (Q.head + cnt) & 127;
