@@ -500,14 +500,29 @@ def main():
     # backbone) + the product's Detect + val_sharded.run.  EVERY rank runs its shard (the final gather is a collective).
     val_obj = None
     if not args.no_extras:
+        local = None
         try:
             from tools import conv_standin
-            val_obj = conv_standin.val_buckets(dev, n_images=160, batch=16, nc=nc, conf_thres=0.25, iou_thres=0.45, half=True, seed=rank)
-            val_obj["n_gpus"] = world
-            val_obj["note"] = ("dt buckets are the slowest rank's, img/s = images of ALL ranks / sum(dt) (val.py:286-291); secondary to `value`: "
-                               "the convolutions are PyTorch-ROCm's, not this repository's")
+            local = conv_standin.val_buckets(dev, n_images=160, batch=16, nc=nc, conf_thres=0.25, iou_thres=0.45, half=True, seed=rank)
         except Exception as e:
-            val_obj = {"error": str(e)}
+            val_obj = {"error": f"rank {rank}: {e}"}
+        # the reduction is outside the try block: every rank takes part, whatever happened to its own run
+        ldt = local["dt_seconds"] if local else [0.0, 0.0, 0.0]
+        slow = [shard.max_over_ranks(x, device=dev) for x in ldt]                 # the job is as slow as its slowest rank
+        ok_all = shard.max_over_ranks(0.0 if local else 1.0, device=dev) == 0.0
+        if local and ok_all:
+            per_rank = local["images_per_rank"]
+            val_obj = {"images": per_rank * world, "images_per_rank": per_rank, "batch": local["batch"], "n_gpus": world,
+                       "anchors_passing_obj_per_image": local["anchors_passing_obj_per_image"], "model": local["model"],
+                       "ms_per_img": {"pre": round(slow[0] / per_rank * 1e3, 4), "inference": round(slow[1] / per_rank * 1e3, 4),
+                                      "nms": round(slow[2] / per_rank * 1e3, 4)},
+                       "img_per_s_seen_over_sum_dt": round(per_rank * world / max(sum(slow), 1e-12), 1),
+                       "nms_share_of_step": round(slow[2] / max(sum(slow), 1e-12), 4),
+                       "note": "dt buckets are the slowest rank's, img/s = images of ALL ranks / sum(dt) (val.py:286-291); secondary to `value`: "
+                               "the convolutions are PyTorch-ROCm's (MIOpen), not this repository's; random-init heads place their candidates "
+                               "at random, so few suppress each other -- the NMS bucket's worst case"}
+        elif val_obj is None:
+            val_obj = {"error": "another rank failed"}
         torch.cuda.empty_cache()
 
     # ---------------- secondary rows of the hot path (rank 0 reports; not part of `value`)

@@ -40,7 +40,7 @@ def _sync(device):
 
 
 def run(model, loader, n_total=None, conf_thres=0.001, iou_thres=0.4, half=True, single_cls=False, augment=False, device=None,
-        ap_per_class=None, names=None, nms=None, postprocess=None, match=None, niou=10):
+        ap_per_class=None, names=None, nms=None, postprocess=None, match=None, niou=10, collect=True):
     """The loop of val.py:180-250 over ``loader`` (this rank's shard, see shard_loader), then the gather.
 
     model(im) -> (out (b, A, no), train_out), like the reference's Model in eval mode.  ``loader`` yields
@@ -49,7 +49,8 @@ def run(model, loader, n_total=None, conf_thres=0.001, iou_thres=0.4, half=True,
     (utils.general.non_max_suppression_obb, val.val_postprocess, val.process_batch); the CPU tests inject stand-ins.
     Returns a dict: rank, world, seen (all ranks), dt (pre-process, inference, NMS seconds of the slowest rank), img_per_s
     (whole job), stats (rank 0: the four concatenated arrays in original image order), metrics (rank 0: what
-    ap_per_class returned, or None)."""
+    ap_per_class returned, or None).  collect=False: no exchange at all -- the rank's own seen / dt (a caller that only wants
+    the time buckets and does its own reduction, bench.py)."""
     if nms is None or postprocess is None or match is None:
         from . import val as V
         from .utils.general import non_max_suppression_obb
@@ -108,6 +109,9 @@ def run(model, loader, n_total=None, conf_thres=0.001, iou_thres=0.4, half=True,
                 else:
                     correct = torch.zeros(pred.shape[0], niou, dtype=torch.bool)
                 per_image.append((correct.cpu(), poly[:, 8].cpu(), poly[:, 9].cpu(), tcls))     # val.py:250
+    if not collect:
+        return {"rank": rank, "world": world, "seen": seen, "dt": list(dt), "img_per_s": seen / max(sum(dt), 1e-12), "stats": None,
+                "metrics": None}
     # ---- the one exchange: per-image tuples to rank 0, in the original order of the image list
     if gidx is None:
         gidx = list(range(rank, rank + world * len(per_image), world)) if world > 1 else list(range(len(per_image)))
