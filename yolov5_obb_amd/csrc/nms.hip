@@ -456,7 +456,7 @@ static int carve(void* base, int64_t n, int64_t nseg, int recq, int C, Carve* cv
   cv->abort_flag = cv->bar + (size_t)kMaxTeams * 128;
   cv->nrows = cv->abort_flag + 64;
   cv->nedges = cv->nrows + kMaxTeams;
-  cv->prof = (u64*)take(48 * 8);
+  cv->prof = (u64*)take(56 * 8);
   cv->plan = (int4*)take((size_t)kMaxTeams * 16);
   cv->seg_begin = (int*)take(ns * 4); cv->seg_end = (int*)take(ns * 4);
   cv->keep_cnt = (int*)take(ns * 4);
@@ -563,7 +563,7 @@ static int nms_steps(int kind, NmsArgs& a, const Carve& cv, int64_t nseg, int64_
   if (phase_prof < 0) { const char* e = getenv("OBB_NMS_PHASE_PROF"); phase_prof = (e && atoi(e)) ? 1 : 0; }
   a.prof = nullptr;
   if (phase_prof) {   // development aid: print the previous call's phase times (synchronises!)
-    u64 h[48];
+    u64 h[56];
     if (hipMemcpy(h, cv.prof, sizeof h, hipMemcpyDeviceToHost) == hipSuccess && h[6] > 0 && h[6] < (1ull << 40)) {
       fprintf(stderr, "[nms phases, wg0, us] select %.1f pairs %.1f wait-resolve %.1f cross %.1f barrier %.1f steps %llu | resolve (any wg) %.1f rounds %llu [first round %.1f other rounds %.1f output %.1f]\n",
               h[1] * 0.01, h[2] * 0.01, h[3] * 0.01, h[5] * 0.01, h[0] * 0.01, h[6], h[9] * 0.01, h[11], h[12] * 0.01, h[13] * 0.01, h[14] * 0.01);
@@ -574,10 +574,11 @@ static int nms_steps(int kind, NmsArgs& a, const Carve& cv, int64_t nseg, int64_
               h[21], h[16] * 0.01, h[19], h[17] * 0.01, h[20], h[18] * 0.01, h[18] * 0.01, h[20], h[15], h[10]);
       fprintf(stderr, "    pairs, wg0 wave 0: items %llu = %.1f us (loads %.1f), stage-1a drains %llu = %.1f us, stage-1b drains %llu = %.1f us, exact drains %llu = %.1f us | slab set-up %.1f us, merge %.1f us (wg0)\n",
               h[32], h[33] * 0.01, h[40] * 0.01, h[34], h[35] * 0.01, h[36], h[37] * 0.01, h[38], h[39] * 0.01, h[41] * 0.01, h[8] * 0.01);
-      if (h[41]) fprintf(stderr, "    slab set-up (wg0): runs %.1f, count %.1f, barrier %.1f, table %.1f, scatter+plan %.1f, barrier %.1f us\n", h[42] * 0.01, h[43] * 0.01,
-                         h[44] * 0.01, h[45] * 0.01, h[46] * 0.01, h[47] * 0.01);
+      if (h[41]) fprintf(stderr, "    slab set-up (wg0): runs %.1f, count %.1f, barrier %.1f, table %.1f (copy %.1f, sums %.1f, decision %.1f), scatter %.1f + plan %.1f, barrier %.1f us\n",
+                         h[42] * 0.01, h[43] * 0.01, h[44] * 0.01, (h[48] + h[49] + h[45]) * 0.01, h[48] * 0.01, h[49] * 0.01, h[45] * 0.01, h[50] * 0.01,
+                         h[46] * 0.01, h[47] * 0.01);
     }
-    if (hipMemsetAsync(cv.prof, 0, 48 * 8, st) != hipSuccess) return OBB_ERR_LAUNCH;
+    if (hipMemsetAsync(cv.prof, 0, 56 * 8, st) != hipSuccess) return OBB_ERR_LAUNCH;
     a.prof = cv.prof;
   }
   const int nb = nms_grid(nseg, n_slots, a.cap_first);

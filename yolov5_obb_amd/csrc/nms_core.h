@@ -53,7 +53,7 @@ struct NmsArgs {
   int* nedges;               // [nteams]   (a team works on one segment at a time: scratch is per team)
   int* bar;                  // [nteams][2][64] arrive / go counters, one 256-byte line each
   int* abort_flag;           // [1] set when a spin gave up
-  u64* prof;                 // optional [48]: wall-clock ticks (10 ns) per phase (development aid)
+  u64* prof;                 // optional [56]: wall-clock ticks (10 ns) per phase (development aid)
   const int4* plan;          // optional [gridDim.x] {segment, team, index in team, team size} per workgroup (k_plan_teams):
                              // workgroups in proportion to the segment sizes; NULL or plan[0].w == 0: static teams
   long long ecap;
@@ -468,8 +468,51 @@ __device__ __forceinline__ void nms_pairs(const NmsArgs& a, int tm, int cn, cons
   }
   ptick();
   if (Q.count > 0) { drain(Q.count); ptock(p_t1a); p_n1a++; }
+  // Leftovers.  A drain costs its latency whatever it holds (LDS look-ups, record fetches, a call into ~1500 instructions:
+  // 10-18 us for the interval stage on a wave that shares its SIMD): a handful of undecided pairs skip the interval and
+  // go straight to the exact clip, which decides them anyway -- one drain instead of two at the end of every step.
+  if (Q1.count > 0 && Q1.count + Q2.count <= 64) {
+    wave_sync();
+    const bool mv = lane < Q1.count;
+    const uint32_t e = mv ? L.qbuf1b[(Q1.head + lane) & 127] : 0u;
+    Q1.head = (Q1.head + Q1.count) & 127;
+    Q1.count = 0;
+    Q2.push(mv, e);
+    wave_sync();
+  }
   if (Q1.count > 0) { drain1b(Q1.count); ptock(p_t1b); p_n1b++; }
-  if (Q2.count > 0) { drain2(Q2.count); ptock(p_t2); p_n2++; }
+  // The exact-clip leftovers of the workgroup's eight waves are pooled (LDS: the row / column position arrays of the wave
+  // blocks, unused in this phase) and drained 64 at a time by as few waves as it takes -- waves 0..3 sit on different
+  // SIMDs: eight waves each clipping a dozen pairs share the four SIMDs and take about twice as long as one full wave alone.
+  {
+    WaveLds<G>* Lw = &L - (threadIdx.x >> 6);                 // the workgroup's wave blocks
+    auto pool_at = [&](int idx) -> uint32_t& { return reinterpret_cast<uint32_t*>(&Lw[idx >> 7])[idx & 127]; };   // rowpos[64] | colpos[64], the first 512 bytes of wave block idx / 128
+    int* s_pool = s_next + 1;
+    __syncthreads();                                           // every wave is out of its item loop (s_next is free: see the reset above)
+    if (threadIdx.x == 0) *s_pool = 0;
+    __syncthreads();
+    int off = 0;
+    if (lane == 0 && Q2.count > 0) off = atomicAdd(s_pool, Q2.count);
+    off = __builtin_amdgcn_readfirstlane(off);
+    for (int k = lane; k < Q2.count; k += 64) pool_at(off + k) = L.qbuf2[(Q2.head + k) & 127];
+    Q2.head = (Q2.head + Q2.count) & 127;
+    Q2.count = 0;
+    __syncthreads();
+    const int total = *s_pool;
+    for (int c0 = (threadIdx.x >> 6) * 64; c0 < total; c0 += kNmsWaves * 64) {
+      const int cnt = min(64, total - c0);
+      bool hit = false;
+      uint32_t packed = 0;
+      if (lane < cnt) {
+        packed = pool_at(c0 + lane);
+        const uint32_t pi = cidx[packed >> 16], pj = cidx[packed & 0xffff];
+        hit = stage_exact<G, FN>(a.rec + (size_t)pi * G::RECQ, a.rec + (size_t)pj * G::RECQ, G::thr_of(a), L.scr + lane);
+      }
+      emit(hit, packed);
+      p_n2++;
+    }
+    ptock(p_t2);
+  }
   if (pprof) {
     a.prof[32] += p_items; a.prof[33] += p_loop + p_load; a.prof[40] += p_load; a.prof[34] += p_n1a; a.prof[35] += p_t1a; a.prof[36] += p_n1b;
     a.prof[37] += p_t1b; a.prof[38] += p_n2; a.prof[39] += p_t2;
@@ -862,6 +905,17 @@ __device__ __forceinline__ void nms_cross(const NmsArgs& a, const uint32_t* rows
       ctock(c_loop);
       if (Q.count > 0) { ctick(); drain(Q.count); ctock(c_d1); c_n1++; alive = alive && !L.cdead[lane]; }
     }
+    if (Q1.count > 0 && Q1.count + Q2.count <= 64) {     // a few leftovers: straight to the exact clip (see nms_pairs)
+      wave_sync();
+      const bool mv = lane < Q1.count;
+      const int sl = (Q1.head + lane) & 127;
+      const uint32_t rowp = mv ? L.qbuf1b[sl] : 0u;
+      const uint32_t cc = mv ? (uint32_t)L.q1bcol[sl] : 0u;
+      Q1.head = (Q1.head + Q1.count) & 127;
+      Q1.count = 0;
+      push2(mv, rowp, cc);
+      wave_sync();
+    }
     if (Q1.count > 0) { ctick(); drain1b(Q1.count); ctock(c_d1); c_n1++; alive = alive && !L.cdead[lane]; }
     if (Q2.count > 0) { ctick(); drain2(Q2.count); ctock(c_d2); c_n2++; alive = alive && !L.cdead[lane]; }
     // RETURNING atomics whose result is consumed: the wave's vmcnt then covers the completed read-modify-write
@@ -980,18 +1034,28 @@ __device__ __forceinline__ void nms_cross_grid(const NmsArgs& a, const GridPlan&
   __syncthreads();
   if (threadIdx.x == 0) *s_next = 0;
   __syncthreads();
-  for (;;) {
+  // A wave holds its current item and the next one: the next item's row position and record (two dependent round trips)
+  // travel while the current item is scanned -- the set-up of an item was ~7 us of latency, a third of a wave's time in
+  // the phase when rows have a few dozen blocks each.
+  auto take = [&]() -> int {
     int k = 0;
     if (lane == 0) k = atomicAdd(s_next, 1);
     k = __builtin_amdgcn_readfirstlane(k);
-    const long long item_ll = (long long)wgi + (long long)k * Tw;
-    if (item_ll >= n_items) break;
-    const int item = (int)item_ll;
+    const long long it = (long long)wgi + (long long)k * Tw;
+    return it < n_items ? (int)it : -1;
+  };
+  uint32_t rp_nx = 0u;
+  float4 rq_nx = make_float4(0.f, 0.f, 0.f, 0.f);
+  int item_nx = take();
+  if (item_nx >= 0) { rp_nx = rows[item_nx / kw]; rq_nx = a.rec[(size_t)rp_nx * G::RECQ]; }
+  for (int item = item_nx; item >= 0; item = item_nx) {
     const int row = item / kw, part = item - row * kw;
     c_items++;
     ctick();
-    const uint32_t rp = rows[row];
-    const float4 rq = a.rec[(size_t)rp * G::RECQ];
+    const uint32_t rp = rp_nx;
+    const float4 rq = rq_nx;
+    item_nx = take();
+    if (item_nx >= 0) { rp_nx = rows[item_nx / kw]; rq_nx = a.rec[(size_t)rp_nx * G::RECQ]; }
     if (grid_is_brute(gp, rq.x, rq.y, rq.z, rq.w)) continue;     // brute row: the caller runs the exhaustive form for it
     auto drain = [&](int cnt) {                    // stage 1a: the cheap register-only tests (entries: column positions)
       wave_sync();
@@ -1149,6 +1213,16 @@ __device__ __forceinline__ void nms_cross_grid(const NmsArgs& a, const GridPlan&
   if (cprof) {
     a.prof[16] += c_scan; a.prof[17] += c_drain; a.prof[18] += c_pro; a.prof[19] += c_nd; a.prof[20] += c_blocks; a.prof[21] += c_items;
     a.prof[15] += c_pass; a.prof[10] += (u64)kw;
+  }
+  if (Q1.count > 0 && Q1.count + Q2.count <= 64) {       // a few leftovers: straight to the exact clip (see nms_pairs)
+    wave_sync();
+    const bool mv = lane < Q1.count;
+    const int sl = (Q1.head + lane) & 127;
+    const uint32_t rowp = mv ? L.qbuf1b[sl] : 0u, cp = mv ? L.qcol1b[sl] : 0u;
+    Q1.head = (Q1.head + Q1.count) & 127;
+    Q1.count = 0;
+    push2(mv, rowp, cp);
+    wave_sync();
   }
   if (Q1.count > 0) drain1b(Q1.count);
   if (Q2.count > 0) drain2(Q2.count);
@@ -1360,6 +1434,7 @@ __device__ __forceinline__ int slab_setup(const NmsArgs& a, float bin_x0, float 
       }
     }
     __syncthreads();
+    slap(48);
     const int s0 = tid & (kMaxSlabs - 1), part = tid >> 6;     // kNmsThreads / kMaxSlabs = 8 parts
     if (s0 < S) {
       const int per = (NB + kNmsWaves - 1) / kNmsWaves;
@@ -1370,6 +1445,7 @@ __device__ __forceinline__ int slab_setup(const NmsArgs& a, float bin_x0, float 
     }
   }
   __syncthreads();
+  slap(49);
   if (tid == 0) {
     int acc = 0, mx = 0, nonempty = 0;
     for (int s0 = 0; s0 < S; s0++) { base[s0] = acc; acc += (tot[s0] + 63) & ~63; mx = mx > tot[s0] ? mx : tot[s0]; nonempty += tot[s0] > 0 ? 1 : 0; }
@@ -1431,6 +1507,7 @@ __device__ __forceinline__ int slab_setup(const NmsArgs& a, float bin_x0, float 
     }
   }
   asm volatile("; alive bits set %0" ::"v"((unsigned)(seen >> 32) ^ (unsigned)seen));
+  slap(50);
   // ---- the plan: one team per non-empty slab, the spare workgroups in proportion to the sizes
   __syncthreads();
   if (tid < kMaxSlabs) { SL.segb[tid] = tid < S ? base[tid] : 0; SL.sege[tid] = tid < S ? base[tid] + tot[tid] : 0; }
