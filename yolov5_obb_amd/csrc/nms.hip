@@ -559,6 +559,7 @@ static int nms_steps(int kind, NmsArgs& a, const Carve& cv, int64_t nseg, int64_
   if (!(pre & kNmsBarZeroed) && hipMemsetAsync(cv.bar, 0, cv.bar_bytes, st) != hipSuccess) return OBB_ERR_LAUNCH;
   a.bar = cv.bar; a.abort_flag = cv.abort_flag; a.nseg = (int)nseg;
   a.cap_first = cap_first();
+  { static int grow = -1; if (grow < 0) { const char* e = getenv("OBB_NMS_GROW"); grow = e ? atoi(e) : 2; if (grow < 2 || grow > 8) grow = 2; } a.grow_sparse = grow; }
   static int phase_prof = -1;
   if (phase_prof < 0) { const char* e = getenv("OBB_NMS_PHASE_PROF"); phase_prof = (e && atoi(e)) ? 1 : 0; }
   a.prof = nullptr;

@@ -90,6 +90,7 @@ struct NmsArgs {
   float4* rec2; uint32_t* order2; uint32_t* pos_old; u64* alive2; u64* kept_bits;
   int alive2_words, kept_words;
   int slab_cap;               // > 0: upper limit of a slab team's chunk capacity
+  int grow_sparse;            // chunk growth factor after a sparse chunk (<= 2: always double)
 };
 
 // ---- cost model shared by the planner (k_plan_teams) and the workgroups that follow its plan
@@ -467,7 +468,33 @@ __device__ __forceinline__ void nms_pairs(const NmsArgs& a, int tm, int cn, cons
     ptock(p_loop);
   }
   ptick();
-  if (Q.count > 0) { drain(Q.count); ptock(p_t1a); p_n1a++; }
+  // The stage-1a leftovers of the workgroup's waves are pooled like the exact-clip leftovers below: full drains on a few
+  // waves instead of eight partial ones that share the SIMDs.
+  {
+    WaveLds<G>* Lw = &L - (threadIdx.x >> 6);
+    auto pool_at = [&](int idx) -> uint32_t& { return reinterpret_cast<uint32_t*>(&Lw[idx >> 7])[idx & 127]; };
+    int* s_pool = s_next + 1;
+    __syncthreads();                                           // every wave is out of its item loop
+    if (threadIdx.x == 0) *s_pool = 0;
+    __syncthreads();
+    int off = 0;
+    if (lane == 0 && Q.count > 0) off = atomicAdd(s_pool, Q.count);
+    off = __builtin_amdgcn_readfirstlane(off);
+    for (int k = lane; k < Q.count; k += 64) pool_at(off + k) = L.qbuf[(Q.head + k) & 127];
+    Q.head = 0; Q.count = 0;
+    __syncthreads();
+    const int total = *s_pool;
+    for (int c0 = (threadIdx.x >> 6) * 64; c0 < total; c0 += kNmsWaves * 64) {
+      const int cnt = min(64, total - c0);
+      wave_sync();
+      if (lane < cnt) L.qbuf[lane] = pool_at(c0 + lane);       // back into this wave's (empty) queue: the ordinary drain takes it from there
+      Q.head = 0; Q.count = cnt;
+      drain(cnt);
+      p_n1a++;
+    }
+    ptock(p_t1a);
+    __syncthreads();                                           // the pool is free again (the exact-clip leftovers use it next)
+  }
   // Leftovers.  A drain costs its latency whatever it holds (LDS look-ups, record fetches, a call into ~1500 instructions:
   // 10-18 us for the interval stage on a wave that shares its SIMD): a handful of undecided pairs skip the interval and
   // go straight to the exact clip, which decides them anyway -- one drain instead of two at the end of every step.
@@ -1034,28 +1061,20 @@ __device__ __forceinline__ void nms_cross_grid(const NmsArgs& a, const GridPlan&
   __syncthreads();
   if (threadIdx.x == 0) *s_next = 0;
   __syncthreads();
-  // A wave holds its current item and the next one: the next item's row position and record (two dependent round trips)
-  // travel while the current item is scanned -- the set-up of an item was ~7 us of latency, a third of a wave's time in
-  // the phase when rows have a few dozen blocks each.
-  auto take = [&]() -> int {
+  // (holding the NEXT item too, so that its row position and record travel while the current item is scanned, was measured:
+  //  no gain -- K=3000 597 against 582 us, uniform 1723 against 1654)
+  for (;;) {
     int k = 0;
     if (lane == 0) k = atomicAdd(s_next, 1);
     k = __builtin_amdgcn_readfirstlane(k);
-    const long long it = (long long)wgi + (long long)k * Tw;
-    return it < n_items ? (int)it : -1;
-  };
-  uint32_t rp_nx = 0u;
-  float4 rq_nx = make_float4(0.f, 0.f, 0.f, 0.f);
-  int item_nx = take();
-  if (item_nx >= 0) { rp_nx = rows[item_nx / kw]; rq_nx = a.rec[(size_t)rp_nx * G::RECQ]; }
-  for (int item = item_nx; item >= 0; item = item_nx) {
+    const long long item_ll = (long long)wgi + (long long)k * Tw;
+    if (item_ll >= n_items) break;
+    const int item = (int)item_ll;
     const int row = item / kw, part = item - row * kw;
     c_items++;
     ctick();
-    const uint32_t rp = rp_nx;
-    const float4 rq = rq_nx;
-    item_nx = take();
-    if (item_nx >= 0) { rp_nx = rows[item_nx / kw]; rq_nx = a.rec[(size_t)rp_nx * G::RECQ]; }
+    const uint32_t rp = rows[row];
+    const float4 rq = a.rec[(size_t)rp * G::RECQ];
     if (grid_is_brute(gp, rq.x, rq.y, rq.z, rq.w)) continue;     // brute row: the caller runs the exhaustive form for it
     auto drain = [&](int cnt) {                    // stage 1a: the cheap register-only tests (entries: column positions)
       wave_sync();
@@ -1423,8 +1442,9 @@ __device__ __forceinline__ int slab_setup(const NmsArgs& a, float bin_x0, float 
     int* tab = misc + 4;                                       // [NB][kMaxSlabs]
     const int nq = (S + 3) >> 2;
     if (tid < NB) {
-      const int4* row = reinterpret_cast<const int4*>(a.slab_cnt + (size_t)tid * kMaxSlabs);
-      int4* dst = reinterpret_cast<int4*>(tab + tid * kMaxSlabs);
+      const int r = (tid + wg) % NB;                           // (every workgroup starts at another row; the copy takes ~15 us either way, and an early touch of the pages did not change that)
+      const int4* row = reinterpret_cast<const int4*>(a.slab_cnt + (size_t)r * kMaxSlabs);
+      int4* dst = reinterpret_cast<int4*>(tab + r * kMaxSlabs);
       for (int j0 = 0; j0 < nq; j0 += 8) {                     // eight loads in flight, then their LDS stores
         int4 v[8];
 #pragma unroll
@@ -1782,7 +1802,9 @@ __global__ __launch_bounds__(kNmsThreads) __attribute__((amdgpu_waves_per_eu(1, 
       if (prof) a.prof[6] += 1;
       // (measured: jumping to the largest chunk when most of a chunk is kept -- sparse data -- is slower, 0.78 -> 0.96 ms at
       //  100k with 18 class offsets: the pair phase grows with the square of the chunk)
-      if (cap < a.capmax) { cap *= 2; if (cap > a.capmax) cap = a.capmax; }
+      // (a.grow_sparse > 2: a chunk that kept more than half of its boxes -- sparse data -- is followed by one that many times
+      //  larger instead of twice; OBB_NMS_GROW, measurements)
+      if (cap < a.capmax) { cap *= (a.grow_sparse > 2 && 2 * nr > cn) ? a.grow_sparse : 2; if (cap > a.capmax) cap = a.capmax; }
     }
   }
   if constexpr (G::HAS_GRID && GRID) {
