@@ -173,6 +173,7 @@ struct GridDev {
   // independent slabs (grid.h; nms_core.h slab_setup): coverage bitmap + flag live in the zeroed block behind GridMeta
   uint32_t* slab_cover; int* slab_flag;
   int* slab_cnt;               // [kMaxTeams][kMaxSlabs] boxes per (workgroup, slab)
+  int* slab_tot;               // [1 + kMaxTeams / 16][kMaxSlabs] totals (in the zeroed block)
   int* slab_keep;              // [kMaxSlabs] kept boxes per slab
   float4* rec2; uint32_t* order2; uint32_t* pos_old; u64* alive2; u64* kept_bits;   // the slab-major copy of the list
   size_t alive2_words, kept_words;
@@ -469,12 +470,14 @@ static int carve(void* base, int64_t n, int64_t nseg, int recq, int C, Carve* cv
   if (recq == RotGeom::RECQ && nseg == 1 && n >= kGridMinN) {
     const uint32_t M = grid_slots(n);
     cv->grid.mask = M - 1;
-    const size_t slab_zero = align_up((size_t)kSlabCopies * kSlabWords * 4 + 64);
+    const size_t slab_tot_bytes = (size_t)(1 + kMaxTeams / 16) * kMaxSlabs * 4;   // slab totals + group totals (slab_setup)
+    const size_t slab_zero = align_up((size_t)kSlabCopies * kSlabWords * 4 + 64) + align_up(slab_tot_bytes);
     cv->grid_zero_bytes = align_up(sizeof(GridMeta)) + slab_zero + ((size_t)M + 4) * 4;
     char* z = take(cv->grid_zero_bytes);
     cv->grid.meta = (GridMeta*)z;
     cv->grid.slab_cover = (uint32_t*)(z ? z + align_up(sizeof(GridMeta)) : nullptr);
     cv->grid.slab_flag = (int*)(z ? z + align_up(sizeof(GridMeta)) + (size_t)kSlabCopies * kSlabWords * 4 : nullptr);
+    cv->grid.slab_tot = (int*)(z ? z + align_up(sizeof(GridMeta)) + align_up((size_t)kSlabCopies * kSlabWords * 4 + 64) : nullptr);
     cv->grid.cnt = (int*)(z ? z + align_up(sizeof(GridMeta)) + slab_zero : nullptr);
     cv->grid.start = (int*)take(((size_t)M + 4) * 4);
     cv->grid.wsum = (int*)take((size_t)1024 * 4);
@@ -682,7 +685,7 @@ static int run_nms(int kind, const float* boxes, int stride, const float* scores
     a.gsorted = cv.grid.sorted; a.gslot = cv.grid.slot_of; a.gwsum = cv.grid.wsum; a.ulist = cv.grid.ulist; a.gmask = cv.grid.mask; a.gfine = grid_fine();
   }
   if (use_slabs) {
-    a.slab_cover = cv.grid.slab_cover; a.slab_flag = cv.grid.slab_flag; a.slab_cnt = cv.grid.slab_cnt; a.slab_keep = cv.grid.slab_keep;
+    a.slab_cover = cv.grid.slab_cover; a.slab_flag = cv.grid.slab_flag; a.slab_cnt = cv.grid.slab_cnt; a.slab_tot = cv.grid.slab_tot; a.slab_keep = cv.grid.slab_keep;
     a.rec2 = cv.grid.rec2; a.order2 = cv.grid.order2; a.pos_old = cv.grid.pos_old; a.alive2 = cv.grid.alive2; a.kept_bits = cv.grid.kept_bits;
     a.alive2_words = (int)cv.grid.alive2_words; a.kept_words = (int)cv.grid.kept_words;
     static int slab_cap = -1;

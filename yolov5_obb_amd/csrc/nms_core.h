@@ -86,6 +86,7 @@ struct NmsArgs {
   const int* slab_flag;       // [0] != 0: a box that cannot be placed (not finite / ill conditioned): no decomposition;
                               // [2] != 0: the data is wide enough to look for slabs (slab_gate) and the bins are marked
   int* slab_cnt;              // [gridDim.x][kMaxSlabs]
+  int* slab_tot;              // [1 + ceil(gridDim.x / 16)][kMaxSlabs] slab totals, then the totals of every group of 16 workgroups (zero before the launch)
   int* slab_keep;             // [kMaxSlabs]
   float4* rec2; uint32_t* order2; uint32_t* pos_old; u64* alive2; u64* kept_bits;
   int alive2_words, kept_words;
@@ -1431,38 +1432,35 @@ __device__ __forceinline__ int slab_setup(const NmsArgs& a, float bin_x0, float 
     }
   }
   __syncthreads();
-  if (tid < kMaxSlabs) stg_agent(a.slab_cnt + (size_t)wg * kMaxSlabs + tid, cnt[tid]);
+  // this workgroup's counts: its own row of the table, and -- one returning atomic each -- the slab totals and the totals of
+  // its group of 16 workgroups: afterwards a workgroup needs the totals, the groups below its own and the rows of its own
+  // group, not all 256 rows (that copy took 15 us)
+  if (tid < kMaxSlabs) {
+    const int c = cnt[tid];
+    stg_agent(a.slab_cnt + (size_t)wg * kMaxSlabs + tid, c);
+    if (c) {
+      int seen = __hip_atomic_fetch_add(a.slab_tot + tid, c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      seen ^= __hip_atomic_fetch_add(a.slab_tot + (size_t)(1 + (wg >> 4)) * kMaxSlabs + tid, c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("; counts added %0" ::"v"(seen));
+    }
+  }
   slap(43);
   if (!team_barrier(gbar, s_flag)) return -1;
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   slap(44);
-  // ---- 3: totals and offsets.  The table first travels into LDS with independent 16-byte loads (thread t: the row of
-  // workgroup t), then thread (slab, part) adds up an eighth of a column -- no load waits for a reduction
+  // ---- 3: totals and offsets: thread (slab, part) adds up its share of the group totals below this workgroup's group and
+  // of the rows of its own group below itself
   {
-    int* tab = misc + 4;                                       // [NB][kMaxSlabs]
-    const int nq = (S + 3) >> 2;
-    if (tid < NB) {
-      const int r = (tid + wg) % NB;                           // (every workgroup starts at another row; the copy takes ~15 us either way, and an early touch of the pages did not change that)
-      const int4* row = reinterpret_cast<const int4*>(a.slab_cnt + (size_t)r * kMaxSlabs);
-      int4* dst = reinterpret_cast<int4*>(tab + r * kMaxSlabs);
-      for (int j0 = 0; j0 < nq; j0 += 8) {                     // eight loads in flight, then their LDS stores
-        int4 v[8];
-#pragma unroll
-        for (int u = 0; u < 8; u++) v[u] = (j0 + u < nq) ? row[j0 + u] : make_int4(0, 0, 0, 0);
-#pragma unroll
-        for (int u = 0; u < 8; u++) if (j0 + u < nq) dst[j0 + u] = v[u];
-      }
-    }
-    __syncthreads();
-    slap(48);
     const int s0 = tid & (kMaxSlabs - 1), part = tid >> 6;     // kNmsThreads / kMaxSlabs = 8 parts
+    const int grp = wg >> 4;
     if (s0 < S) {
-      const int per = (NB + kNmsWaves - 1) / kNmsWaves;
-      int v = 0, below = 0;
-      for (int w = part * per; w < (part + 1) * per && w < NB; w++) { const int c = tab[w * kMaxSlabs + s0]; v += c; if (w < wg) below += c; }
-      if (v) atomicAdd(&tot[s0], v);
+      int below = 0;
+      for (int g2 = part; g2 < grp; g2 += kNmsWaves) below += a.slab_tot[(size_t)(1 + g2) * kMaxSlabs + s0];
+      for (int w = (grp << 4) + part; w < wg; w += kNmsWaves) below += a.slab_cnt[(size_t)w * kMaxSlabs + s0];
       if (below) atomicAdd(&pre[s0], below);
+      if (part == 0) tot[s0] = a.slab_tot[s0];
     }
+    slap(48);
   }
   __syncthreads();
   slap(49);
