@@ -50,7 +50,7 @@ int main(int argc, char** argv) {
       if (memcmp(&r64, &g64, 8) != 0 && !(r64 != r64 && g64 != g64)) { if (mism64 < 5) printf("MISMATCH64 mode %d ref %.17g got %.17g\n", mode, r64, g64); mism64++; }
     }
     if (ref > 0) nonzero++;
-    if (obb::quad_certainly_disjoint(P, Q)) { disjoint++; if (fabs(ref) > worst_noise && mode != 7) worst_noise = fabs(ref); }
+    if (P.minx > Q.maxx || Q.minx > P.maxx || P.miny > Q.maxy || Q.miny > P.maxy) { disjoint++; if (fabs(ref) > worst_noise && mode != 7) worst_noise = fabs(ref); }
   }
   printf("mismatches64=%ld\n", mism64);
   printf("mismatches=%ld nonzero=%ld aabb_disjoint=%ld worst_disjoint_iou=%.3g n=%ld\n", mism, nonzero, disjoint, worst_noise, n);

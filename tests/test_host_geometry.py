@@ -36,6 +36,23 @@ def test_quad_iou_device_code_bit_exact(oracle_lib, tmp_path):
     assert "mismatches=0" in out and "mismatches64=0" in out, out
 
 
+def test_quad_skip_rule_noise_bound(tmp_path):
+    """piou_device.h quad_skip_record / quad_skip_pair: the rounding noise of the reference's origin-based quad intersection on
+    bounding-box-disjoint pairs (ten adversarial families, |coord| 8 .. 70000, plus a greedy ascent that looks for inputs
+    whose roundings line up) stays far below the bound the NMS skip rule is built on, no skipped pair is a hit or has
+    overlapping bounding boxes, and the record's fp16 box is rounded outward."""
+    out = tmp_path / "hc_quadcull"
+    subprocess.run(["g++", "-O2", "-std=c++17", "-ffp-contract=off", f"-I{ROOT}/yolov5_obb_amd/csrc",
+                    f"{ROOT}/tests/native/host_check_quadcull.cpp", "-o", str(out), "-lm"], check=True)
+    r = subprocess.run([str(out), "4000000", "21", "20000"], capture_output=True, text=True)
+    assert r.returncode == 0 and " wrong=0" in r.stdout and "fp16_rounding_errors=0" in r.stdout, r.stdout
+    vals = dict(kv.split("=") for line in r.stdout.splitlines() if "=" in line and not line.startswith("family") for kv in line.split())
+    bound = float(vals["bound_units"])
+    assert float(vals["worst_noise_units"]) * 64 <= bound, r.stdout          # random pairs: measured < 8 units
+    assert float(vals["worst_after_climb_units"]) * 32 <= bound, r.stdout    # after the ascent: measured < 20 units
+    assert int(vals["culled"]) > 1000000, r.stdout
+
+
 def test_fast_iou_interval_contains_the_reference_value(oracle_lib, tmp_path):
     """rbox_quick_bounds and rbox_fast_iou_bounds (the register-only filters in front of the exact clip): whenever one vouches for a pair, the
     oracle's IoU lies inside the interval -- detector-like distributions incl. nearly parallel, thin, class-offset,

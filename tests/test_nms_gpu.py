@@ -260,6 +260,32 @@ def test_nms_poly_30k(dev, oracle_lib):
         assert np.array_equal(ref, got)
 
 
+@pytest.mark.parametrize("thr", [0.0, 0.05, 0.4, -0.1])
+def test_nms_poly_skip_rule(dev, oracle_lib, thr):
+    """The quad NMS skips a pair only when both boxes carry a finite bounding box (piou_device.h quad_cull_box: area large
+    enough against the coordinate magnitude that the rounding noise of the reference's origin-based sum cannot reach the
+    threshold).  A set that mixes every case -- tile coordinates, boxes shifted by 5,000 and by 70,000 (class-offset style:
+    their noise is visible, nothing may be skipped), few-pixel boxes, zero-area quads (the reference's union == 0 rule
+    makes two of them suppress each other at any distance), clockwise rings -- against the oracle, which clips every pair."""
+    from yolov5_obb_amd import nms_rotated_ext
+    d0, s0 = synth.s_clustered(1500, 60, seed=5, extent=1024.0)
+    d1, s1 = synth.s_clustered(600, 30, seed=6, extent=900.0)
+    d1[:, :2] += 5000.0
+    d2, s2 = synth.s_clustered(600, 30, seed=7, extent=900.0)
+    d2[:, :2] += 70000.0
+    d3, s3 = synth.s_uniform(300, 8, extent=1024.0)
+    d3[:, 2:4] = d3[:, 2:4].clamp(max=4.0)                                   # few-pixel boxes
+    dets = torch.cat([d0, d1, d2, d3])
+    scores = synth.tie_free(torch.cat([s0, s1, s2, s3]))
+    quads = synth.rbox_to_quad(dets)
+    quads[::40] = quads[::40, :2].repeat(1, 4)                               # zero-area quads (a point)
+    quads[5::9] = quads[5::9].reshape(-1, 4, 2).flip(1).reshape(-1, 8)        # clockwise rings
+    polys = torch.cat([quads, scores[:, None]], 1).contiguous()
+    ref = oracle.nms_poly(polys.numpy(), thr)
+    got = nms_rotated_ext.nms_poly(polys.to(dev), thr).cpu().numpy()
+    assert np.array_equal(ref, got)
+
+
 def test_ops_rbox_overlaps_device_tensors(dev, oracle_lib):
     """ops.rbox_overlaps -> obb_rbox_overlaps_f32 (the device-pointer form of the devkit's overlaps_kernel,
     poly_overlaps_kernel.cu:280-353): same matrix as the host-pointer `_overlaps`, bit for bit, and as the oracle up to the

@@ -110,13 +110,21 @@ struct RotGeom {
 };
 
 struct QuadGeom {
-  static constexpr int RECQ = 2;
+  static constexpr int RECQ = 3;
   static constexpr int SCR = 40;  // 2 x 10 points x (x,y) per lane
-  // q0 = {x0, y0, x1, y1}  q1 = {x2, y2, x3, y3}
-  // The reference's quad IoU sums signed triangle areas taken from the coordinate origin; for
-  // disjoint quads the terms cancel only up to rounding (measured up to 0.06 at |coord| ~ 5000),
-  // so "IoU == 0" cannot be predicted from a bounding-box test.  No reject: every pair is clipped.
-  static __device__ __forceinline__ bool cheap_reject(const float4&, const float4&) { return false; }
+  // q0 = {fp16 minx | miny, fp16 maxx | maxy (rounded outward), budget f, 0}   q1 = {x0, y0, x1, y1}   q2 = {x2, y2, x3, y3}
+  // The reference's quad IoU sums signed triangle areas taken from the coordinate origin; for disjoint quads the terms
+  // cancel only up to rounding noise that grows with the square of the coordinates, so "IoU == 0" cannot be predicted
+  // from a bounding-box test alone.  A pair is skipped when the bounding boxes are disjoint AND the two boxes' areas are
+  // large enough against their coordinate magnitudes that the noise cannot reach the threshold (piou_device.h:
+  // quad_skip_record / quad_skip_pair; k_prep_quad computes the per-box budget, the threshold is known there); every
+  // other pair is clipped, as the reference does.
+  static __device__ __forceinline__ bool cheap_reject(const float4& a, const float4& b) {
+    QuadSkip A, B;
+    A.lo = __builtin_bit_cast(uint32_t, a.x); A.hi = __builtin_bit_cast(uint32_t, a.y); A.f = a.z;
+    B.lo = __builtin_bit_cast(uint32_t, b.x); B.hi = __builtin_bit_cast(uint32_t, b.y); B.f = b.z;
+    return quad_skip_pair(A, B);
+  }
   static constexpr bool PACKED = false;
   static OBB_HD QuadFeat unpack(const float4& q0, const float4& q1) {
     QuadFeat f;
@@ -128,13 +136,13 @@ struct QuadGeom {
   static __device__ __forceinline__ float iou(const QuadFeat& A, const QuadFeat& B, float* scr) {
     return quad_iou<64>(A, B, scr, scr + 10 * 64, scr + 20 * 64, scr + 30 * 64);
   }
-  static constexpr bool HAS_FAST = false;      // every pair is undecided: the reference's value is not predictable (see above)
+  static constexpr bool HAS_FAST = false;      // every pair that is not skipped is clipped: no value bounds for this formulation
   static constexpr bool HAS_GRID = false;
   template <class A> static __device__ __forceinline__ float thr_of(const A& a) { return a.thr; }
   static __device__ __forceinline__ int classify_quick(const float4*, const float4*, float, bool) { return 2; }
   static __device__ __forceinline__ int classify_full(const float4*, const float4*, float) { return 2; }
   static __device__ __forceinline__ bool hit_exact(const float4* ra, const float4* rb, float thr, float* scr) {
-    return iou(unpack(ra[0], ra[1]), unpack(rb[0], rb[1]), scr) > thr;
+    return iou(unpack(ra[1], ra[2]), unpack(rb[1], rb[2]), scr) > thr;
   }
 };
 

@@ -65,7 +65,11 @@ template <> struct Pack16<__half> { static constexpr int V = 8; };
 
 // VEC: the input rows are 4-element aligned (HW % 4 == 0) and both outputs are 16-byte aligned at every tile start,
 // so the tile is read with 8/16-byte loads and written with 16-byte stores; otherwise element-wise accesses.
-template <typename T, bool VEC, int kTileHW, int NT, int SK>
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+
+// NTS: the tile is read and both outputs are written with non-temporal accesses (every byte is touched once)
+template <typename T, bool VEC, int kTileHW, int NT, int SK, bool NTS = false>
 __global__ __launch_bounds__(NT) void k_detect_decode(DetectArgs d) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   T* tile = reinterpret_cast<T*>(smem_raw);            // [no] rows of 64 positions, skewed (tix)
@@ -98,7 +102,13 @@ __global__ __launch_bounds__(NT) void k_detect_decode(DetectArgs d) {
 #pragma unroll
         for (int u = 0; u < kLoadBatch; u++) {
           const int c = c0 + u * RPS;
-          if (c < no) v[u] = *reinterpret_cast<const Vec*>(in + (size_t)c * HW + hw);
+          if (c < no) {
+            if constexpr (NTS) {
+              using NV = typename std::conditional<sizeof(T) == 2, u32x2_t, u32x4_t>::type;
+              const NV t = __builtin_nontemporal_load(reinterpret_cast<const NV*>(in + (size_t)c * HW + hw));
+              v[u] = __builtin_bit_cast(Vec, t);
+            } else v[u] = *reinterpret_cast<const Vec*>(in + (size_t)c * HW + hw);
+          }
         }
 #pragma unroll
         for (int u = 0; u < kLoadBatch; u++) {
@@ -167,8 +177,13 @@ __global__ __launch_bounds__(NT) void k_detect_decode(DetectArgs d) {
         if (zo) { T o; st_from_float<T>(&o, decode_at(raw, c, hw)); decv[j] = o; }
         if (++c == no) { c = 0; hw++; }
       }
-      if (xo) *reinterpret_cast<uint4*>(xo + e0) = *reinterpret_cast<const uint4*>(rawv);
-      if (zo) *reinterpret_cast<uint4*>(zo + e0) = *reinterpret_cast<const uint4*>(decv);
+      if constexpr (NTS) {
+        if (xo) __builtin_nontemporal_store(*reinterpret_cast<const u32x4_t*>(rawv), reinterpret_cast<u32x4_t*>(xo + e0));
+        if (zo) __builtin_nontemporal_store(*reinterpret_cast<const u32x4_t*>(decv), reinterpret_cast<u32x4_t*>(zo + e0));
+      } else {
+        if (xo) *reinterpret_cast<uint4*>(xo + e0) = *reinterpret_cast<const uint4*>(rawv);
+        if (zo) *reinterpret_cast<uint4*>(zo + e0) = *reinterpret_cast<const uint4*>(decv);
+      }
     }
     for (int e = nvec * V + tid; e < nel; e += NT) {
       const int hw = e / no, c = e - hw * no;
@@ -273,10 +288,10 @@ int obb_detect_decode_col(const void* conv_out, int dtype, int64_t bs, int64_t n
   // 1 = 4-element skew and one LDS store per 4-position group (fp16 0.282, fp32 0.798: the 16-byte LDS stores conflict);
   // 2 = 128-position tiles with 512 threads, i.e. 256-byte read runs at the same number of waves per CU (fp16 0.277, fp32 0.954)
   static int variant = -1;
-  if (variant < 0) { const char* e = getenv("OBB_DETECT_VARIANT"); variant = e ? atoi(e) : 0; if (variant < 0 || variant > 2) variant = 0; }
+  if (variant < 0) { const char* e = getenv("OBB_DETECT_VARIANT"); variant = e ? atoi(e) : 0; if (variant < 0 || variant > 4) variant = 0; }
   const int tile_hw = variant == 2 ? 128 : 64;
   const int nthreads = variant == 2 ? 512 : 256;
-  const int skew = variant == 0 ? 2 : 4;
+  const int skew = (variant == 0 || variant >= 3) ? 2 : 4;
   const size_t lds = ((size_t)no * tile_hw + (size_t)skew * (size_t)(no / 8 + 2)) * esz;   // skewed rows (tix in the kernel)
   dim3 grid((unsigned)((HW + tile_hw - 1) / tile_hw), (unsigned)(bs * na));
   hipStream_t st = (hipStream_t)stream;
@@ -285,16 +300,17 @@ int obb_detect_decode_col(const void* conv_out, int dtype, int64_t bs, int64_t n
   bool vec = (HW % 4 == 0) && al16(conv_out) && al16(x_perm_out) && al16(z_out);
   vec = vec && ((size_t)HW * no * esz) % 16 == 0 && ((size_t)a_total * no * esz) % 16 == 0 && ((size_t)a_offset * no * esz) % 16 == 0;
   if (lds > 150 * 1024) return OBB_ERR_BAD_ARG;
-#define OBB_LAUNCH_DETECT(T, VEC, TILE, NTH, SKW)                                                                                  \
+#define OBB_LAUNCH_DETECT(T, VEC, TILE, NTH, SKW, ...)                                                                             \
   do {                                                                                                                              \
     if (lds > 48 * 1024 &&                                                                                                          \
-        hipFuncSetAttribute((const void*)k_detect_decode<T, VEC, TILE, NTH, SKW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) \
+        hipFuncSetAttribute((const void*)k_detect_decode<T, VEC, TILE, NTH, SKW, ##__VA_ARGS__>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) \
       return OBB_ERR_LAUNCH;                                                                                                        \
-    k_detect_decode<T, VEC, TILE, NTH, SKW><<<grid, NTH, lds, st>>>(d);                                                             \
+    k_detect_decode<T, VEC, TILE, NTH, SKW, ##__VA_ARGS__><<<grid, NTH, lds, st>>>(d);                                              \
   } while (0)
 #define OBB_LAUNCH_DETECT_T(T)                                                                                                      \
   do {                                                                                                                              \
-    if (variant == 2) { if (vec) OBB_LAUNCH_DETECT(T, true, 128, 512, 4); else OBB_LAUNCH_DETECT(T, false, 128, 512, 4); }          \
+    if (variant >= 3 && vec) { OBB_LAUNCH_DETECT(T, true, 64, 256, 2, true); }                                                      \
+    else if (variant == 2) { if (vec) OBB_LAUNCH_DETECT(T, true, 128, 512, 4); else OBB_LAUNCH_DETECT(T, false, 128, 512, 4); }          \
     else if (variant == 1) { if (vec) OBB_LAUNCH_DETECT(T, true, 64, 256, 4); else OBB_LAUNCH_DETECT(T, false, 64, 256, 4); }      \
     else { if (vec) OBB_LAUNCH_DETECT(T, true, 64, 256, 2); else OBB_LAUNCH_DETECT(T, false, 64, 256, 2); }                         \
   } while (0)

@@ -302,13 +302,19 @@ __global__ __launch_bounds__(256) void k_prep_rot64(const double* __restrict__ d
   if (p < 8) alive[((n + 63) >> 6) + p] = 0ull;      // guard words behind the last box (the bitmap is not memset)
 }
 
-__global__ void k_prep_quad(const float* __restrict__ polys, int stride, const uint32_t* __restrict__ order, int n,
+__global__ void k_prep_quad(const float* __restrict__ polys, int stride, const uint32_t* __restrict__ order, int n, float thr, int skip,
                             float4* __restrict__ rec, u64* __restrict__ alive) {
   int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p < n) {
     const float* d = polys + (size_t)order[p] * stride;
-    rec[(size_t)p * 2 + 0] = make_float4(d[0], d[1], d[2], d[3]);
-    rec[(size_t)p * 2 + 1] = make_float4(d[4], d[5], d[6], d[7]);
+    float c[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) c[k] = d[k];
+    // thr <= 0 (or skip == 0): budget -inf, nothing is skipped
+    const QuadSkip sk = quad_skip_record(quad_make_feat(c), skip ? thr : 0.f);
+    rec[(size_t)p * 3 + 0] = make_float4(__builtin_bit_cast(float, sk.lo), __builtin_bit_cast(float, sk.hi), sk.f, 0.f);
+    rec[(size_t)p * 3 + 1] = make_float4(c[0], c[1], c[2], c[3]);
+    rec[(size_t)p * 3 + 2] = make_float4(c[4], c[5], c[6], c[7]);
   }
   const u64 m = __ballot(p < n);
   if ((threadIdx.x & 63) == 0 && (p & ~63) < n) alive[p >> 6] = m;
@@ -406,6 +412,8 @@ struct Carve {
 // table slots of the spatial index (power of two, multiple of 4096)
 // cells of side 2 R_L / 2^fine (grid.h): 1 measured best at 100k (K=3000: 716 -> 648 us, uniform 2361 -> 2138; 2: no further gain)
 static int grid_fine() { static int f = -1; if (f < 0) { const char* e = getenv("OBB_GRID_FINE"); f = e ? atoi(e) : 1; if (f < 0 || f > 2) f = 1; } return f; }
+// OBB_NMS_POLY_STRICT=1: the quad NMS clips every pair (no bounding-box skip; piou_device.h quad_cull_box)
+static int quad_skip() { static int f = -1; if (f < 0) { const char* e = getenv("OBB_NMS_POLY_STRICT"); f = (e && atoi(e) != 0) ? 0 : 1; } return f; }
 static uint32_t grid_slots(int64_t n) { return (n >= 262144 || (grid_fine() > 0 && n >= 32768)) ? 65536u : 16384u; }
 constexpr int64_t kGridMinN = 8192;    // below this the exhaustive cross phase is cheaper than building the index
 
@@ -676,7 +684,7 @@ static int run_nms(int kind, const float* boxes, int stride, const float* scores
     ProfScope ps(PROF_NMS_PREP, st);
     if (kind == 0) k_prep_rot<<<gb, T, 0, st>>>(boxes, cv.vals_b, drop_small, (int)n, cv.rec, cv.alive, cv.grid.bbpart, cv.grid.nparts,
                                                 use_slabs ? cv.grid.slab_cover : nullptr, cv.grid.slab_flag);
-    else k_prep_quad<<<gb, T, 0, st>>>(boxes, stride, cv.vals_b, (int)n, cv.rec, cv.alive);
+    else k_prep_quad<<<gb, T, 0, st>>>(boxes, stride, cv.vals_b, (int)n, thr, quad_skip(), cv.rec, cv.alive);
   }
 
   NmsArgs a{};

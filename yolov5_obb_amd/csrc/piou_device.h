@@ -164,14 +164,96 @@ OBB_HD float quad_iou(const QuadFeat& P, const QuadFeat& Q, float* px, float* py
   return quad_iou_t<STRIDE, true, float>(P, Q, px, py, qx, qy);
 }
 
-// AABB reject: disjoint bounding boxes with a margin -> every signed triangle
-// intersection is empty -> inter == 0 exactly -> IoU == 0 (unless both quads are
-// degenerate, where the reference's union==0 rule yields 1: excluded by the
-// caller checking for a positive extent).
-OBB_HD bool quad_certainly_disjoint(const QuadFeat& P, const QuadFeat& Q) {
-  float ex = fmaxf(P.maxx - P.minx, Q.maxx - Q.minx), ey = fmaxf(P.maxy - P.miny, Q.maxy - Q.miny);
-  float mx = 1e-3f * ex + 1e-6f, my = 1e-3f * ey + 1e-6f;
-  return (P.minx > Q.maxx + mx) || (Q.minx > P.maxx + mx) || (P.miny > Q.maxy + my) || (Q.miny > P.maxy + my);
+// ---- skipping pairs in the NMS hot loop ------------------------------------------------------------------------------
+// quad_iou sums 16 signed triangle intersections taken from the coordinate ORIGIN.  For two quads whose bounding boxes are
+// disjoint the exact sum is 0 (the product of the two winding numbers vanishes everywhere); the fp32 sum is rounding noise:
+// every product in a term is O(M^2), M = largest |coordinate| of the pair, so |inter| <= c u M^2 with u = 2^-24 ("units").
+//   * measured: tests/native/host_check_quadcull.cpp, ten adversarial families of bounding-box-disjoint pairs (slivers, bow
+//     ties, edges along rays from the origin, all quadrants, touching boxes, a vertex at the origin, |coord| 8 .. 70000):
+//     the largest noise over 2 x 10^8 pairs is below 8 units (a sum of a few hundred roundings of <= 1 unit each);
+//   * worst case, every rounding aligned: shoelace (<= 6 products + accumulation per term) ~ 25 units per term, clip
+//     vertices (<= 4 per term, each moved by a few ulps of M against edges <= 2.9 M) ~ 25 units per term, 16 terms:
+//     several hundred units.
+// The bound used is c = 1024 units: above the aligned-roundings accounting, > 100x the largest value seen.  It is an
+// engineering bound, not a machine-checked proof; OBB_NMS_POLY_STRICT=1 turns the skip off (every pair clipped).
+// The absolute 1e-8 sign threshold of the reference drops or adds triangles of area <= 1e-8 each: kQuadSlack.
+//
+// A pair is a hit iff inter / (a1 + a2 - inter) > thr.  With |inter| <= E that cannot happen when E <= t (a1 + a2),
+// t = thr / (1 + thr), and E <= c u (M1^2 + M2^2): with the per-box budget
+//     f_i = t a_i - c u M_i^2 - slack
+// a bounding-box-disjoint pair is skipped iff f_i + f_j >= 0 (the sign of a float sum is exact).  A big box near a small
+// one pays for both; two small boxes far from the origin are always clipped, and so are two zero-area quads (both
+// budgets negative), which keeps the reference's union == 0 rule.  thr <= 0 or a non-finite coordinate: f = -inf / NaN,
+// never skipped.
+//
+// Hot-loop record (one 16-byte load per box, QuadGeom::q0): the bounding box as four fp16 values rounded OUTWARD
+// (1 px steps at |coord| ~ 1000, +-inf beyond 65504: conservative) in two words, and f.
+constexpr float kQuadNoiseUnits = 1024.f;
+constexpr float kQuadNoise = kQuadNoiseUnits / 16777216.f;   // c u
+constexpr float kQuadSlack = 1e-6f;
+
+// largest fp16 <= x (up = false) or smallest fp16 >= x (up = true), as bits; NaN -> NaN
+OBB_HD uint32_t f16_bits_toward(float x, bool up) {
+  const uint32_t u = __builtin_bit_cast(uint32_t, x);
+  const uint32_t sign = u >> 31, ax = u & 0x7fffffffu;
+  if (ax > 0x7f800000u) return 0x7e00u;
+  const bool away = up != (sign != 0u);                 // the direction grows the magnitude
+  uint32_t h;
+  const int e = (int)(ax >> 23) - 127;
+  if (e >= 16) h = away ? 0x7c00u : 0x7bffu;            // beyond the largest finite fp16 (65504 < 2^16)
+  else if (e < -14) {                                   // fp16 subnormal range: multiples of 2^-24
+    const float sc = __builtin_bit_cast(float, ax) * 16777216.f;
+    h = (uint32_t)sc;
+    if (away && (float)h != sc) h++;
+  } else {
+    const uint32_t mant = ax & 0x7fffffu;
+    h = ((uint32_t)(e + 15) << 10) | (mant >> 13);
+    if (away && (mant & 0x1fffu)) h++;                  // the carry runs into the exponent, up to 0x7c00 = inf
+  }
+  return (sign << 15) | h;
+}
+OBB_HD float f16_bits_to_float(uint32_t h) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return (float)__builtin_bit_cast(_Float16, (unsigned short)h);
+#else
+  const uint32_t sign = (h >> 15) & 1u, e = (h >> 10) & 31u, m = h & 1023u;
+  float v;
+  if (e == 0) v = (float)m * (1.0f / 16777216.f);
+  else if (e == 31) v = m ? __builtin_nanf("") : __builtin_huge_valf();
+  else v = __builtin_bit_cast(float, ((e + 112u) << 23) | (m << 13));
+  return sign ? -v : v;
+#endif
+}
+
+struct QuadSkip {
+  uint32_t lo;   // fp16 minx | fp16 miny << 16   (rounded down)
+  uint32_t hi;   // fp16 maxx | fp16 maxy << 16   (rounded up)
+  float f;       // budget (see above)
+};
+
+OBB_HD QuadSkip quad_skip_record(const QuadFeat& q, float thr) {
+  float m = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; i++) m = fmaxf(m, fmaxf(fabsf(q.x[i]), fabsf(q.y[i])));
+  bool nan = false;                                      // fmaxf drops NaNs: look for them explicitly
+#pragma unroll
+  for (int i = 0; i < 4; i++) nan = nan || q.x[i] != q.x[i] || q.y[i] != q.y[i];
+  const float area = fabsf(quad_signed_area(q.x, q.y));
+  const float t = thr / (1.f + thr);
+  QuadSkip r;
+  r.lo = f16_bits_toward(q.minx, false) | (f16_bits_toward(q.miny, false) << 16);
+  r.hi = f16_bits_toward(q.maxx, true) | (f16_bits_toward(q.maxy, true) << 16);
+  // the 1e-3 margins cover the roundings of this expression
+  r.f = (thr > 0.f && !nan) ? area * t * 0.999f - kQuadNoise * 1.001f * m * m - kQuadSlack : -__builtin_huge_valf();
+  return r;
+}
+OBB_HD bool quad_skip_pair(const QuadSkip& a, const QuadSkip& b) {
+  const float aminx = f16_bits_to_float(a.lo & 0xffffu), aminy = f16_bits_to_float(a.lo >> 16);
+  const float amaxx = f16_bits_to_float(a.hi & 0xffffu), amaxy = f16_bits_to_float(a.hi >> 16);
+  const float bminx = f16_bits_to_float(b.lo & 0xffffu), bminy = f16_bits_to_float(b.lo >> 16);
+  const float bmaxx = f16_bits_to_float(b.hi & 0xffffu), bmaxy = f16_bits_to_float(b.hi >> 16);
+  const bool apart = (aminx > bmaxx) || (bminx > amaxx) || (aminy > bmaxy) || (bminy > amaxy);
+  return apart && (a.f + b.f >= 0.f);
 }
 
 }  // namespace obb
