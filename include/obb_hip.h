@@ -281,6 +281,15 @@ int obb_detect_decode_col(const void* conv_out, int dtype, int64_t bs, int64_t n
                           const float* anchors_px_host, float stride, void* x_perm_out, void* z_out, int64_t a_total,
                           int64_t a_offset, void* objcol_out, void* stream);
 
+/* The whole inference branch of Detect.forward (models/yolo.py:61-79: the loop over the nl levels and the torch.cat) in ONE
+ * launch: conv_out[l] is level l's conv output (bs, na*no, ny[l], nx[l]); x_perm_out[l] its permuted raw head (the array or
+ * any entry may be NULL); the levels' rows follow each other in z_out / objcol_out (bs, a_total, ...) in level order, like
+ * torch.cat(z, 1).  anchors_px_host HOST [nl][na][2], strides_host HOST [nl].  nl <= 4.  Same bytes as nl calls of
+ * obb_detect_decode_col with a_offset = the rows of the levels before. */
+int obb_detect_decode_levels(int nl, const void* const* conv_out, int dtype, int64_t bs, int64_t na, int64_t no, const int64_t* ny,
+                             const int64_t* nx, const float* anchors_px_host, const float* strides_host, void* const* x_perm_out,
+                             void* z_out, int64_t a_total, void* objcol_out, void* stream);
+
 /* gaussian_label_cpu (utils/rboxs_utils.py:9-26) for n angles at once: out [n][num_class] fp32, evaluated in double. */
 int obb_csl_encode_f32(const float* labels, int64_t n, int num_class, double u, double sig, float* out, void* stream);
 

@@ -88,6 +88,25 @@ def test_detect_inference_fp16(dev):
     assert (d == 0).float().mean() > 0.98
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+@pytest.mark.parametrize("nc,sizes,bs", [(16, (40, 20, 10), 3), (15, (13, 7, 5), 1), (15, (128, 64, 32), 2)])
+def test_detect_all_levels_in_one_launch_same_bytes(dev, dtype, nc, sizes, bs):
+    """obb_detect_decode_levels (the default of Detect.forward) writes the same z, objectness column and permuted heads as one
+    obb_detect_decode_col call per level -- vector and element-wise paths (13 x 14 maps are not 16-byte aligned), both dtypes."""
+    ch = (8, 16, 32)
+    det = make_detect(nc, ch, dev, dtype)
+    feats = [torch.randn(bs, c, s, s + (i % 2)).to(dtype).to(dev) for i, (c, s) in enumerate(zip(ch, sizes))]
+    outs = []
+    with torch.no_grad():
+        for fused in (True, False):
+            det.fused_levels = fused
+            z, xs = det(list(feats))
+            outs.append((z, z._obb_objcol[0], xs))
+    (z1, c1, x1), (z0, c0, x0) = outs
+    assert torch.equal(z1, z0) and torch.equal(c1, c0) and torch.equal(c1, z1[..., 4])
+    assert all(torch.equal(a, b) for a, b in zip(x1, x0))
+
+
 def test_detect_rejects_cpu_inference_but_trains_on_cpu():
     from yolov5_obb_amd.models.yolo import Detect
     det = Detect(nc=3, anchors=synth.DEFAULT_ANCHORS, ch=(4, 4, 4))

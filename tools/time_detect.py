@@ -24,9 +24,26 @@ for dtype, code in ((torch.float16, 1), (torch.float32, 0)):
                                      _lib.ptr(xs[i]), _lib.ptr(z), a_total, off, _lib.stream_ptr(dev))
             assert rc == 0
             off += na * n * n
+    nl = len(sizes)
+    conv_arr = (C.c_void_p * nl)(*[c.data_ptr() for c in convs])
+    xs_arr = (C.c_void_p * nl)(*[t.data_ptr() for t in xs])
+    ny_arr = (C.c_int64 * nl)(*sizes)
+    px_arr = (C.c_float * (nl * 6))(*[v for p in px for v in p])
+    st_arr = (C.c_float * nl)(*synth.DEFAULT_STRIDES[:nl])
+    def run_levels():
+        rc = L.obb_detect_decode_levels(nl, conv_arr, code, bs, na, no, ny_arr, ny_arr, px_arr, st_arr, xs_arr, _lib.ptr(z), a_total, None,
+                                        _lib.stream_ptr(dev))
+        assert rc == 0
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for _ in range(3): run_levels()
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(20): run_levels()
+    e1.record(); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 20
+    print(f"{str(dtype):14s} detect decode (all levels, one launch): {ms:.3f} ms  -> {3 * z.numel() * z.element_size() / ms / 1e6:.0f} GB/s")
     for _ in range(3): run()
     torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(20): run()
     e1.record(); torch.cuda.synchronize()

@@ -53,6 +53,7 @@ SIGNATURES = {
     "obb_loss_backward": (_i32, [_vp, _vp, _i32, _vp, _i64, _i64, _vp, _vp, _vp, _sz, _vp]),
     "obb_detect_decode": (_i32, [_vp, _i32, _i64, _i64, _i64, _i64, _i64, _vp, _f32, _vp, _vp, _i64, _i64, _vp]),
     "obb_detect_decode_col": (_i32, [_vp, _i32, _i64, _i64, _i64, _i64, _i64, _vp, _f32, _vp, _vp, _i64, _i64, _vp, _vp]),
+    "obb_detect_decode_levels": (_i32, [_i32, _vp, _i32, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp]),
     "obb_csl_encode_f32": (_i32, [_vp, _i64, _i32, C.c_double, C.c_double, _vp, _vp]),
     "obb_rbox2poly_f32": (_i32, [_vp, _i64, _i64, _vp, _vp, _vp]),
     "obb_val_postprocess_f32": (_i32, [_vp, _i64, _f32, _f32, _f32, _vp, _vp, _vp, _vp, _vp]),

@@ -69,15 +69,14 @@ typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
 
 // NTS: the tile is read and both outputs are written with non-temporal accesses (every byte is touched once)
-template <typename T, bool VEC, int kTileHW, int NT, int SK, bool NTS = false>
-__global__ __launch_bounds__(NT) void k_detect_decode(DetectArgs d) {
+template <typename T, bool VEC, int kTileHW, int NT, int SK, bool NTS, bool NTL>
+__device__ __forceinline__ void detect_decode_tile(const DetectArgs& d, const int tile_x, const int ba /* b * na + a */) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   T* tile = reinterpret_cast<T*>(smem_raw);            // [no] rows of 64 positions, skewed (tix)
   const int tid = threadIdx.x;
   const int HW = d.ny * d.nx;
-  const int ba = blockIdx.y;                            // b * na + a
   const int a = ba % d.na, b = ba / d.na;
-  const int hw0 = blockIdx.x * kTileHW;
+  const int hw0 = tile_x * kTileHW;
   const int nhw = min(kTileHW, HW - hw0);
   const int no = d.no;
   const T* in = (const T*)d.in + ((size_t)ba * no) * HW + hw0;
@@ -103,7 +102,7 @@ __global__ __launch_bounds__(NT) void k_detect_decode(DetectArgs d) {
         for (int u = 0; u < kLoadBatch; u++) {
           const int c = c0 + u * RPS;
           if (c < no) {
-            if constexpr (NTS) {
+            if constexpr (NTL) {
               using NV = typename std::conditional<sizeof(T) == 2, u32x2_t, u32x4_t>::type;
               const NV t = __builtin_nontemporal_load(reinterpret_cast<const NV*>(in + (size_t)c * HW + hw));
               v[u] = __builtin_bit_cast(Vec, t);
@@ -204,6 +203,28 @@ __global__ __launch_bounds__(NT) void k_detect_decode(DetectArgs d) {
   }
 }
 
+template <typename T, bool VEC, int kTileHW, int NT, int SK, bool NTS = false, bool NTL = NTS>
+__global__ __launch_bounds__(NT) void k_detect_decode(DetectArgs d) {
+  detect_decode_tile<T, VEC, kTileHW, NT, SK, NTS, NTL>(d, (int)blockIdx.x, (int)blockIdx.y);
+}
+
+// All levels of the head in ONE launch: blockIdx.x runs over the tiles of level 0, then level 1, ...; blockIdx.y = b * na + a.
+// Three back-to-back launches leave the chip draining and refilling twice (the 32 x 32 level alone is a 20 us launch for
+// 5 % of the bytes); in one grid the small levels' tiles fill the gaps of the large one.
+constexpr int kDetectMaxLevels = 4;                      // P3 .. P6
+struct DetectLevels {
+  DetectArgs lv[kDetectMaxLevels];
+  int tile_end[kDetectMaxLevels];                        // running sum of the levels' tile counts
+  int nl;
+};
+template <typename T, bool VEC, int kTileHW, int NT, int SK, bool NTS>
+__global__ __launch_bounds__(NT) void k_detect_decode_levels(DetectLevels m) {
+  const int bx = (int)blockIdx.x;
+  int l = 0;
+  while (l + 1 < m.nl && bx >= m.tile_end[l]) l++;
+  detect_decode_tile<T, VEC, kTileHW, NT, SK, NTS, NTS>(m.lv[l], bx - (l ? m.tile_end[l - 1] : 0), (int)blockIdx.y);
+}
+
 // ------------------------------------------------------------------ CSL encode (utils/rboxs_utils.py:9-26)
 // out[i][k] = y_sig[(k + index_i) mod n],  y_sig[j] = exp(-((j - n/2) - u)^2 / (2 sig^2)),  index_i = int(n/2 - label_i)
 // (python slice semantics: |index| > n leaves the window unrolled).  Evaluated in double like numpy, stored as float.
@@ -284,11 +305,14 @@ int obb_detect_decode_col(const void* conv_out, int dtype, int64_t bs, int64_t n
   const size_t esz = dtype == 0 ? 4 : 2;
   // variants (OBB_DETECT_VARIANT, measurements on (16, 3*200, 128..32, ..), round 3 -- all with eight channel rows in flight
   // per thread in the load phase, which is what moved the kernel: fp16 0.310 -> 0.281 ms, fp32 0.590 -> 0.488 ms):
-  // 0 = 64-position tiles, 256 threads, 2-element skew, element-wise LDS stores (default: fp16 0.281, fp32 0.488 ms);
+  // 3 = variant 0 with non-temporal loads and stores (default: fp16 0.266, fp32 0.480 ms; every byte is touched once, and
+  //     a streaming store does not push the lines the other workgroups are about to read out of L2); 4 = stores only
+  //     (0.268-0.280), 5 = loads only (0.281: no gain);
+  // 0 = 64-position tiles, 256 threads, 2-element skew, element-wise LDS stores (fp16 0.282, fp32 0.488-0.512 ms);
   // 1 = 4-element skew and one LDS store per 4-position group (fp16 0.282, fp32 0.798: the 16-byte LDS stores conflict);
   // 2 = 128-position tiles with 512 threads, i.e. 256-byte read runs at the same number of waves per CU (fp16 0.277, fp32 0.954)
   static int variant = -1;
-  if (variant < 0) { const char* e = getenv("OBB_DETECT_VARIANT"); variant = e ? atoi(e) : 0; if (variant < 0 || variant > 4) variant = 0; }
+  if (variant < 0) { const char* e = getenv("OBB_DETECT_VARIANT"); variant = e ? atoi(e) : 3; if (variant < 0 || variant > 5) variant = 3; }
   const int tile_hw = variant == 2 ? 128 : 64;
   const int nthreads = variant == 2 ? 512 : 256;
   const int skew = (variant == 0 || variant >= 3) ? 2 : 4;
@@ -309,7 +333,9 @@ int obb_detect_decode_col(const void* conv_out, int dtype, int64_t bs, int64_t n
   } while (0)
 #define OBB_LAUNCH_DETECT_T(T)                                                                                                      \
   do {                                                                                                                              \
-    if (variant >= 3 && vec) { OBB_LAUNCH_DETECT(T, true, 64, 256, 2, true); }                                                      \
+    if (variant == 3 && vec) { OBB_LAUNCH_DETECT(T, true, 64, 256, 2, true); }                                                      \
+    else if (variant == 4 && vec) { OBB_LAUNCH_DETECT(T, true, 64, 256, 2, true, false); }                                          \
+    else if (variant == 5 && vec) { OBB_LAUNCH_DETECT(T, true, 64, 256, 2, false, true); }                                          \
     else if (variant == 2) { if (vec) OBB_LAUNCH_DETECT(T, true, 128, 512, 4); else OBB_LAUNCH_DETECT(T, false, 128, 512, 4); }          \
     else if (variant == 1) { if (vec) OBB_LAUNCH_DETECT(T, true, 64, 256, 4); else OBB_LAUNCH_DETECT(T, false, 64, 256, 4); }      \
     else { if (vec) OBB_LAUNCH_DETECT(T, true, 64, 256, 2); else OBB_LAUNCH_DETECT(T, false, 64, 256, 2); }                         \
@@ -318,6 +344,60 @@ int obb_detect_decode_col(const void* conv_out, int dtype, int64_t bs, int64_t n
   if (dtype == 0) OBB_LAUNCH_DETECT_T(float); else OBB_LAUNCH_DETECT_T(__half);
 #undef OBB_LAUNCH_DETECT_T
 #undef OBB_LAUNCH_DETECT
+  return hipGetLastError() == hipSuccess ? OBB_OK : OBB_ERR_LAUNCH;
+}
+
+int obb_detect_decode_levels(int nl, const void* const* conv_out, int dtype, int64_t bs, int64_t na, int64_t no, const int64_t* ny,
+                             const int64_t* nx, const float* anchors_px_host, const float* strides_host, void* const* x_perm_out,
+                             void* z_out, int64_t a_total, void* objcol_out, void* stream) {
+  if (nl < 1 || nl > kDetectMaxLevels || !conv_out || !ny || !nx || !anchors_px_host || !strides_host || bs < 1 || na < 1 ||
+      na > OBB_LOSS_MAX_ANCHORS || no < 6 || no > 5 + 256 + 180 || (dtype != 0 && dtype != 1))
+    return OBB_ERR_BAD_ARG;
+  if (bs * na > 65535) return OBB_ERR_BAD_ARG;
+  const size_t esz = dtype == 0 ? 4 : 2;
+  constexpr int tile_hw = 64, skew = 2;
+  auto al16 = [](const void* p) { return p == nullptr || (((uintptr_t)p) & 15) == 0; };
+  DetectLevels m;
+  m.nl = nl;
+  int64_t off = 0, tiles = 0;
+  bool vec = al16(z_out) && ((size_t)a_total * no * esz) % 16 == 0;
+  bool any_out = z_out != nullptr || objcol_out != nullptr;
+  for (int l = 0; l < kDetectMaxLevels; l++) {
+    DetectArgs& d = m.lv[l];
+    if (l >= nl) { d = m.lv[0]; m.tile_end[l] = (int)tiles; continue; }
+    if (!conv_out[l] || ny[l] < 1 || nx[l] < 1 || ny[l] * nx[l] > 0x7fffffffLL) return OBB_ERR_BAD_ARG;
+    void* xp = x_perm_out ? x_perm_out[l] : nullptr;
+    any_out = any_out || xp != nullptr;
+    d.in = conv_out[l]; d.xperm = xp; d.z = z_out; d.objcol = objcol_out;
+    d.bs = (int)bs; d.na = (int)na; d.no = (int)no; d.ny = (int)ny[l]; d.nx = (int)nx[l];
+    d.a_total = a_total; d.a_off = off; d.stride = strides_host[l];
+    for (int a = 0; a < OBB_LOSS_MAX_ANCHORS; a++) {
+      d.anchor_px[a][0] = a < na ? anchors_px_host[((size_t)l * na + a) * 2] : 0.f;
+      d.anchor_px[a][1] = a < na ? anchors_px_host[((size_t)l * na + a) * 2 + 1] : 0.f;
+    }
+    const int64_t HW = ny[l] * nx[l];
+    vec = vec && (HW % 4 == 0) && al16(conv_out[l]) && al16(xp) && ((size_t)HW * no * esz) % 16 == 0 && ((size_t)off * no * esz) % 16 == 0;
+    tiles += (HW + tile_hw - 1) / tile_hw;
+    if (tiles > 0x7fffffffLL) return OBB_ERR_BAD_ARG;
+    m.tile_end[l] = (int)tiles;
+    off += na * HW;
+  }
+  if ((z_out || objcol_out) && off > a_total) return OBB_ERR_BAD_ARG;
+  if (!any_out) return OBB_OK;
+  const size_t lds = ((size_t)no * tile_hw + (size_t)skew * (size_t)(no / 8 + 2)) * esz;
+  if (lds > 150 * 1024) return OBB_ERR_BAD_ARG;
+  dim3 grid((unsigned)tiles, (unsigned)(bs * na));
+  hipStream_t st = (hipStream_t)stream;
+#define OBB_LAUNCH_LEVELS(T, VEC, NTS)                                                                                              \
+  do {                                                                                                                              \
+    if (lds > 48 * 1024 &&                                                                                                          \
+        hipFuncSetAttribute((const void*)k_detect_decode_levels<T, VEC, tile_hw, 256, skew, NTS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) \
+      return OBB_ERR_LAUNCH;                                                                                                        \
+    k_detect_decode_levels<T, VEC, tile_hw, 256, skew, NTS><<<grid, 256, lds, st>>>(m);                                             \
+  } while (0)
+  if (dtype == 0) { if (vec) OBB_LAUNCH_LEVELS(float, true, true); else OBB_LAUNCH_LEVELS(float, false, false); }
+  else { if (vec) OBB_LAUNCH_LEVELS(__half, true, true); else OBB_LAUNCH_LEVELS(__half, false, false); }
+#undef OBB_LAUNCH_LEVELS
   return hipGetLastError() == hipSuccess ? OBB_OK : OBB_ERR_LAUNCH;
 }
 

@@ -32,6 +32,7 @@ class Detect(nn.Module):
     _cpu_forward = None
     # store z[..., 4] densely next to z for the confidence filter of non_max_suppression_obb (module docstring)
     couple_nms = True
+    fused_levels = True      # all levels decoded by one launch (obb_detect_decode_levels); False: one launch per level
 
     def __init__(self, nc=80, anchors=(), ch=(), inplace=True):  # detection layer
         super().__init__()
@@ -109,19 +110,31 @@ class Detect(nn.Module):
         z = torch.empty((bs, a_total, self.no), dtype=c0.dtype, device=c0.device)
         col = torch.empty((bs, a_total), dtype=c0.dtype, device=c0.device) if self.couple_nms else None
         L = _lib.lib()
-        off = 0
+        for i, (ny, nx) in enumerate(shapes):
+            if self.onnx_dynamic or self.grid[i].shape[2:4] != (ny, nx):
+                self.grid[i], self.anchor_grid[i] = self._make_grid(nx, ny, i)      # kept for attribute compatibility
+        xps = [torch.empty((bs, self.na, ny, nx, self.no), dtype=c0.dtype, device=c0.device) for ny, nx in shapes]
         with torch.cuda.device(c0.device):
             st = _lib.stream_ptr(c0.device)
-            for i in range(self.nl):
-                ny, nx = shapes[i]
-                if self.onnx_dynamic or self.grid[i].shape[2:4] != (ny, nx):
-                    self.grid[i], self.anchor_grid[i] = self._make_grid(nx, ny, i)      # kept for attribute compatibility
-                xp = torch.empty((bs, self.na, ny, nx, self.no), dtype=c0.dtype, device=c0.device)
-                rc = L.obb_detect_decode_col(_lib.ptr(convs[i]), code, bs, self.na, self.no, ny, nx, C.cast(anchor_px[i], C.c_void_p),
-                                             strides[i], _lib.ptr(xp), _lib.ptr(z), a_total, off, _lib.ptr(col), st)
-                _lib.check(rc, "obb_detect_decode_col")
-                x[i] = xp
-                off += self.na * ny * nx
+            if self.nl <= 4 and self.fused_levels:
+                # the loop over the levels and the torch.cat of models/yolo.py:61-79 as ONE launch
+                nl = self.nl
+                rc = L.obb_detect_decode_levels(nl, (C.c_void_p * nl)(*[c.data_ptr() for c in convs]), code, bs, self.na, self.no,
+                                                (C.c_int64 * nl)(*[s[0] for s in shapes]), (C.c_int64 * nl)(*[s[1] for s in shapes]),
+                                                (C.c_float * (nl * self.na * 2))(*[v for a in anchor_px for v in a]),
+                                                (C.c_float * nl)(*strides[:nl]), (C.c_void_p * nl)(*[t.data_ptr() for t in xps]),
+                                                _lib.ptr(z), a_total, _lib.ptr(col), st)
+                _lib.check(rc, "obb_detect_decode_levels")
+            else:
+                off = 0
+                for i in range(self.nl):
+                    ny, nx = shapes[i]
+                    rc = L.obb_detect_decode_col(_lib.ptr(convs[i]), code, bs, self.na, self.no, ny, nx, C.cast(anchor_px[i], C.c_void_p),
+                                                 strides[i], _lib.ptr(xps[i]), _lib.ptr(z), a_total, off, _lib.ptr(col), st)
+                    _lib.check(rc, "obb_detect_decode_col")
+                    off += self.na * ny * nx
+        for i in range(self.nl):
+            x[i] = xps[i]
         if col is not None and not torch.is_inference(z):
             # read by utils.general.non_max_suppression_obb (module docstring).  Under torch.inference_mode() tensors carry no
             # version counter, so "unchanged since Detect wrote it" cannot be checked: the column is not attached and the NMS
