@@ -390,7 +390,10 @@ template <typename T> struct Vec16;
 template <> struct Vec16<float> { static constexpr int V = 4; };
 template <> struct Vec16<__half> { static constexpr int V = 8; };
 
-template <typename T>
+typedef unsigned int loss_u32x4 __attribute__((ext_vector_type(4)));
+
+// NTS: the gradient tensor is written once and read much later (the conv's backward): streaming stores
+template <typename T, bool NTS>
 __global__ __launch_bounds__(256) void k_loss_bwd_dense(const LossDev* __restrict__ dp) {
   constexpr int V = Vec16<T>::V;
   const LossDev& d = *dp;
@@ -429,7 +432,8 @@ __global__ __launch_bounds__(256) void k_loss_bwd_dense(const LossDev* __restric
           if constexpr (V == 4) {
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (j == 0) v.x = val; else if (j == 1) v.y = val; else if (j == 2) v.z = val; else if (j == 3) v.w = val;
-            *reinterpret_cast<float4*>(gb + i0) = v;
+            if constexpr (NTS) __builtin_nontemporal_store(__builtin_bit_cast(loss_u32x4, v), reinterpret_cast<loss_u32x4*>(gb + i0));
+            else *reinterpret_cast<float4*>(gb + i0) = v;
           } else {
             uint4 v = make_uint4(0u, 0u, 0u, 0u);
             if (j >= 0) {
@@ -437,7 +441,8 @@ __global__ __launch_bounds__(256) void k_loss_bwd_dense(const LossDev* __restric
               const int q = j >> 1;
               if (q == 0) v.x = h; else if (q == 1) v.y = h; else if (q == 2) v.z = h; else v.w = h;
             }
-            *reinterpret_cast<uint4*>(gb + i0) = v;
+            if constexpr (NTS) __builtin_nontemporal_store(__builtin_bit_cast(loss_u32x4, v), reinterpret_cast<loss_u32x4*>(gb + i0));
+            else *reinterpret_cast<uint4*>(gb + i0) = v;
           }
         } else {
           for (int q = 0; q < V && i0 + q < nel; q++) st_from_float<T>(gb + i0 + q, q == j ? val : 0.f);
@@ -688,8 +693,11 @@ int obb_loss_backward(const obb_loss_config* cfg, const void* const* p_levels_ho
   }
   k_loss_setup<<<1, 256, 0, st>>>(d, cv.dev);
   dim3 gd(2048, cfg->nl);
-  if (dtype == 0) k_loss_bwd_dense<float><<<gd, 256, 0, st>>>(cv.dev);
-  else k_loss_bwd_dense<__half><<<gd, 256, 0, st>>>(cv.dev);
+  // OBB_LOSS_NT=0: plain stores (measurements)
+  static int nts = -1;
+  if (nts < 0) { const char* e = getenv("OBB_LOSS_NT"); nts = (e && atoi(e) == 0) ? 0 : 1; }
+  if (dtype == 0) { if (nts) k_loss_bwd_dense<float, true><<<gd, 256, 0, st>>>(cv.dev); else k_loss_bwd_dense<float, false><<<gd, 256, 0, st>>>(cv.dev); }
+  else { if (nts) k_loss_bwd_dense<__half, true><<<gd, 256, 0, st>>>(cv.dev); else k_loss_bwd_dense<__half, false><<<gd, 256, 0, st>>>(cv.dev); }
   if (d.cap > 0) {
     if (dtype == 0) k_loss_entries_bwd<float><<<entry_grid(d), 256, 0, st>>>(cv.dev);
     else k_loss_entries_bwd<__half><<<entry_grid(d), 256, 0, st>>>(cv.dev);
