@@ -747,7 +747,7 @@ def main():
                     "survey_8d_bytes_not_moved": alg_bytes,
                     "note": "achieved / frac are over the bytes the filter must move (one 128-byte line per row for obj + the rows that pass + "
                             "output), cold; SURVEY 8d's bs*A*no*2 figure is listed but not used: the kernel never reads most of the tensor"},
-                "obb::k_detect_decode<__half> (3 levels)": None if not detect_obj or "ms" not in detect_obj else {
+                "obb::k_detect_decode_levels<__half> (3 levels, one launch)": None if not detect_obj or "ms" not in detect_obj else {
                     "bound": "hbm", "achieved": detect_obj["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": detect_obj["frac_of_peak"], "frac_of_measured_copy": round(detect_obj["achieved_GBs"] / max(copy_gbs, 1e-9), 4),
                     "traffic": pmc.get("k_detect_decode"),

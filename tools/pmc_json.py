@@ -69,11 +69,16 @@ def main():
         out[name] = bytes_(fk, wk)
         out[name + "_raw_kb"] = {"FETCH_SIZE": round(fk, 1), "WRITE_SIZE": round(wk, 1)}
     out["k_nms_persist_100k"] = out["k_nms_persist_100k_clustered_k300_raw"]
-    fd, wd = find(f, "obb::k_detect_decode<"), find(w, "obb::k_detect_decode<")
-    lv_f = [mean(fd[i::3]) for i in range(3)]
-    lv_w = [mean(wd[i::3]) for i in range(3)]
-    out["k_detect_decode"] = sum(bytes_(a, b) for a, b in zip(lv_f, lv_w))
-    out["k_detect_decode_raw_kb"] = {"FETCH_SIZE": [round(v, 1) for v in lv_f], "WRITE_SIZE": [round(v, 1) for v in lv_w]}
+    try:                                               # all levels in one launch (obb_detect_decode_levels, Detect.forward's default)
+        fd, wd = find(f, "obb::k_detect_decode_levels<"), find(w, "obb::k_detect_decode_levels<")
+        out["k_detect_decode"] = bytes_(mean(fd), mean(wd))
+        out["k_detect_decode_raw_kb"] = {"FETCH_SIZE": round(mean(fd), 1), "WRITE_SIZE": round(mean(wd), 1)}
+    except KeyError:                                   # one launch per level
+        fd, wd = find(f, "obb::k_detect_decode<"), find(w, "obb::k_detect_decode<")
+        lv_f = [mean(fd[i::3]) for i in range(3)]
+        lv_w = [mean(wd[i::3]) for i in range(3)]
+        out["k_detect_decode"] = sum(bytes_(a, b) for a, b in zip(lv_f, lv_w))
+        out["k_detect_decode_raw_kb"] = {"FETCH_SIZE": [round(v, 1) for v in lv_f], "WRITE_SIZE": [round(v, 1) for v in lv_w]}
     if len(sys.argv) > 3:                              # kernel-trace summary of the same driver: avg duration of k_loss_bwd_dense
         for line in open(sys.argv[3]):
             if "obb::k_loss_bwd_dense<" in line:
