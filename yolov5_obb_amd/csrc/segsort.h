@@ -4,7 +4,7 @@
 // speed-test regime (16 images x ~2k candidates: 0.04 ms) and the wrong one for val.py's default conf_thres = 0.001,
 // where every image brings ~65k candidates: 16 workgroups grind through 1M pairs in 2.6 ms.  Here every segment is
 // spread over as many workgroups as it has 2048-element tiles (grid = tiles x segments), one 8-bit digit per pass,
-// three small kernels per pass: tile histograms -> per-segment scan -> stable scatter (wave multi-split: lanes with the
+// two small kernels per pass: tile histograms -> stable scatter with the offset scan built in (wave multi-split: lanes with the
 // same digit find each other with 8 ballots, so the order inside a digit is the input order).  Passes over digits that
 // are constant for the whole call (unused tie / class bits) are skipped by the host.
 #pragma once
@@ -18,7 +18,7 @@ struct SrsArgs {
   const unsigned long long* kin; unsigned long long* kout;
   const uint32_t* vin; uint32_t* vout;
   const int* seg_begin; const int* seg_end;     // [nseg]
-  uint32_t* hist;                               // [nseg][tiles][256] tile histograms, then tile offsets
+  uint32_t* hist;                               // [nseg][tiles][256] tile histograms (k_srs_hist)
   int tiles;                                    // tiles per segment (capacity / kSrsTile)
   int shift;
   const float4* cand; long long cap_img;        // cand != NULL: the digit is the class of the candidate the value points to
@@ -44,30 +44,43 @@ __global__ __launch_bounds__(kSrsThreads) void k_srs_hist(SrsArgs a) {
   out[tid] = s_h[tid];
 }
 
-// one workgroup per segment: hist[g][tile][d] <- number of elements of the segment that precede tile `tile`'s digit-d run
-__global__ __launch_bounds__(256) void k_srs_scan(SrsArgs a) {
-  __shared__ uint32_t s_tot[256];
-  const int g = blockIdx.x, d = threadIdx.x;
-  uint32_t* h = a.hist + (size_t)g * a.tiles * 256;
-  const int nt = (a.seg_end[g] - a.seg_begin[g] + kSrsTile - 1) / kSrsTile;
-  uint32_t run = 0;
-  for (int t = 0; t < nt; t++) { const uint32_t c = h[(size_t)t * 256 + d]; h[(size_t)t * 256 + d] = run; run += c; }
-  s_tot[d] = run;
-  __syncthreads();
-  uint32_t base = 0;                                         // exclusive prefix over the digits (256 values: a plain loop)
-  for (int k = 0; k < d; k++) base += s_tot[k];
-  for (int t = 0; t < nt; t++) h[(size_t)t * 256 + d] += base;
-  if (a.digit_base) a.digit_base[(size_t)g * 256 + d] = base;
-}
-
+// The scatter kernel derives its tile's digit offsets itself: thread d sums the counts of digit d over the tiles before its own and
+// over all tiles of the segment (8 independent loads in flight, rows of 1 KB), the 256 totals are scanned in the workgroup.
+// (Round 2 had a third kernel in between, one workgroup per segment walking the tiles serially: 12 us per pass for the 31 tiles
+//  of the TTA tensor, plus a launch -- the TTA call went from 0.430 to 0.323 ms without it.  Counting the NEXT pass's tile
+//  histograms inside the scatter, one global atomic per element into the tile it lands in, was measured too: 0.385 ms -- the
+//  elements of a tile mostly share the next digit, 2048 atomics on one counter -- so the histogram stays a launch of its own.)
 __global__ __launch_bounds__(kSrsThreads) void k_srs_scatter(SrsArgs a) {
   __shared__ uint32_t s_run[4][256];     // per wave: running count of each digit inside the wave's 512-element slice
   const int g = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int sb = a.seg_begin[g], se = a.seg_end[g];
   const int b0 = sb + tile * kSrsTile;
   if (b0 >= se) return;
-  const uint32_t* off = a.hist + ((size_t)g * a.tiles + tile) * 256;
-  for (int k = tid; k < 4 * 256; k += kSrsThreads) (&s_run[0][0])[k] = 0u;
+  __shared__ uint32_t s_off[256];
+  __shared__ uint32_t s_wtot[4];
+  {
+    const uint32_t* h = a.hist + (size_t)g * a.tiles * 256 + tid;      // digit tid's column of the segment's tile counts
+    const int nt = (se - sb + kSrsTile - 1) / kSrsTile;
+    uint32_t before = 0u, tot = 0u;
+    for (int t0 = 0; t0 < nt; t0 += 8) {
+      uint32_t c[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) c[u] = (t0 + u < nt) ? h[(size_t)(t0 + u) * 256] : 0u;
+#pragma unroll
+      for (int u = 0; u < 8; u++) { tot += c[u]; before += (t0 + u < tile) ? c[u] : 0u; }
+    }
+    uint32_t incl = tot;                                                // exclusive prefix of the digit totals
+#pragma unroll
+    for (int dd = 1; dd < 64; dd <<= 1) { const uint32_t v = __shfl_up(incl, dd); if (lane >= dd) incl += v; }
+    if (lane == 63) s_wtot[wv] = incl;
+    for (int k = tid; k < 4 * 256; k += kSrsThreads) (&s_run[0][0])[k] = 0u;
+    __syncthreads();
+    uint32_t base = incl - tot;
+    for (int w = 0; w < wv; w++) base += s_wtot[w];
+    s_off[tid] = base + before;
+    if (a.digit_base && tile == 0) a.digit_base[(size_t)g * 256 + tid] = base;
+  }
+  const uint32_t* off = s_off;
   __syncthreads();
   const int w0 = b0 + wv * 512;
   unsigned long long key[8]; uint32_t val[8]; uint32_t rnk[8]; bool ok[8];
@@ -126,7 +139,6 @@ static int seg_radix_sort_large(unsigned long long* ka, unsigned long long* kb, 
     a.kin = a_to_b ? ka : kb; a.kout = a_to_b ? kb : ka;
     a.vin = a_to_b ? va : vb; a.vout = a_to_b ? vb : va;
     k_srs_hist<<<gt, kSrsThreads, 0, st>>>(a);
-    k_srs_scan<<<(unsigned)nseg, 256, 0, st>>>(a);
     k_srs_scatter<<<gt, kSrsThreads, 0, st>>>(a);
     a_to_b = !a_to_b;
   }
@@ -149,7 +161,6 @@ static int seg_group_by_class(const unsigned long long* kin, unsigned long long*
   a.kin = kin; a.kout = kout; a.vin = vin; a.vout = vout;
   dim3 gt((unsigned)a.tiles, (unsigned)nseg);
   k_srs_hist<<<gt, kSrsThreads, 0, st>>>(a);
-  k_srs_scan<<<(unsigned)nseg, 256, 0, st>>>(a);
   k_srs_scatter<<<gt, kSrsThreads, 0, st>>>(a);
   return hipGetLastError() == hipSuccess ? OBB_OK : OBB_ERR_LAUNCH;
 }
