@@ -15,6 +15,7 @@
 #include <string.h>
 #include <hip/hip_fp16.h>
 #include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_merge_sort.hpp>
 #include <rocprim/device/device_segmented_radix_sort.hpp>
 #include "nms_core.h"
 #include "obb_hip.h"

@@ -453,6 +453,12 @@ __global__ void k_reset_state(int* __restrict__ cnt, int n_cnt, int* __restrict_
   for (long long k = i; k < n_bar16; k += n) bar16[k] = make_uint4(0u, 0u, 0u, 0u);
 }
 
+// the slots behind the image's candidates get the largest key (single image, device-wide sort over the whole capacity)
+__global__ void k_pad_keys(unsigned long long* __restrict__ keys, uint32_t* __restrict__ vals, const int* __restrict__ sort_end, long long cap) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < cap && i >= (long long)sort_end[0]) { keys[i] = ~0ull; vals[i] = 0u; }
+}
+
 // Sort of npad (a power of two, 64 .. 1024*E) (key, value) pairs that sit in LDS, ascending, by 1024 threads holding E
 // consecutive elements each in registers.
 //   1. every wave sorts its run of 64*E elements with a bitonic network that never leaves the wave: compare-exchange
@@ -938,9 +944,32 @@ static int run_nms_obb(const void* pred, const void* objcol, int dtype, int64_t 
       unsigned mask = 0xF0u;                                            // single-list key: score in bytes 4..7
       for (int d = 0; d < 4; d++) if (tb > d * 8) mask |= 1u << d;
       if (class_ok) mask = 0xFFu;                                       // + class-mode key: anchor 0..2, score 3..6, class 7
-      rc = seg_radix_sort_large(cv.keys_a, cv.keys_b, cv.vals_a, cv.vals_b, cv.sort_begin, cv.sort_end, (int)bs, cap_img, bs * cap_img,
-                                mask, cv.srs_hist, st);
-      if (rc) return rc;
+      // ONE large image (the TTA tensor): the library's device-wide sort over the image's whole capacity, the unused slots padded
+      // with the largest key, instead of eight passes of the segmented sort (OBB_SINGLE_IMAGE_SORT: 0 = segmented sort, 1 =
+      // rocprim::radix_sort_pairs, 2 = rocprim::merge_sort; measurements)
+      static int one_sort = -1;
+      if (one_sort < 0) { const char* e = getenv("OBB_SINGLE_IMAGE_SORT"); one_sort = e ? atoi(e) : 1; if (one_sort < 0 || one_sort > 2) one_sort = 1; }
+      bool done = false;
+      if (bs == 1 && one_sort && !group_ok) {
+        size_t need = 0;
+        hipError_t qe = one_sort == 2
+            ? rocprim::merge_sort(nullptr, need, cv.keys_a, cv.keys_b, cv.vals_a, cv.vals_b, (size_t)cap_img, rocprim::less<unsigned long long>(), st, false)
+            : rocprim::radix_sort_pairs(nullptr, need, cv.keys_a, cv.keys_b, cv.vals_a, cv.vals_b, (size_t)cap_img, 0, 64, st, false);
+        if (qe == hipSuccess && need <= nv.sort_tmp_bytes) {
+          k_pad_keys<<<(unsigned)((cap_img + 255) / 256), 256, 0, st>>>(cv.keys_a, cv.vals_a, cv.sort_end, cap_img);
+          size_t tmp = nv.sort_tmp_bytes;
+          hipError_t se = one_sort == 2
+              ? rocprim::merge_sort(nv.sort_tmp, tmp, cv.keys_a, cv.keys_b, cv.vals_a, cv.vals_b, (size_t)cap_img, rocprim::less<unsigned long long>(), st, false)
+              : rocprim::radix_sort_pairs(nv.sort_tmp, tmp, cv.keys_a, cv.keys_b, cv.vals_a, cv.vals_b, (size_t)cap_img, 0, 64, st, false);
+          if (se != hipSuccess) return OBB_ERR_LAUNCH;
+          done = true;
+        }
+      }
+      if (!done) {
+        rc = seg_radix_sort_large(cv.keys_a, cv.keys_b, cv.vals_a, cv.vals_b, cv.sort_begin, cv.sort_end, (int)bs, cap_img, bs * cap_img,
+                                  mask, cv.srs_hist, st);
+        if (rc) return rc;
+      }
     } else {
       size_t tmp = cv.sort_tmp_bytes;
       if (rocprim::segmented_radix_sort_pairs(cv.sort_tmp, tmp, cv.keys_a, cv.keys_b, cv.vals_a, cv.vals_b,
