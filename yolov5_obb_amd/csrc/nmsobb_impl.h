@@ -702,7 +702,7 @@ __global__ __launch_bounds__(1024) void k_sort_prep_lds(const float4* __restrict
 // order; the global rank of an entry = its index in its own list + the number of entries of every other list that
 // precede it -- binary searches on merge keys (score, anchor, class) staged in LDS.
 constexpr int kMergeLds = 4096;
-constexpr int64_t kSortLargeFrom = 12288;   // expected candidates per image above which the multi-workgroup sort is used
+constexpr int64_t kSortLargeFrom = OBB_NMS_SORT_LDS_HINT;   // expected candidates per image above which the multi-workgroup sort is used: whenever the in-LDS path does not apply (16 images x 2-9k candidates: 0.149 ms against 0.418 for rocprim's one-workgroup-per-segment sort; it was 12288 while the sort had a scan launch per pass)
 __global__ __launch_bounds__(256) void k_gather_out(const float4* __restrict__ cand, const uint32_t* __restrict__ vals_sorted,
                                                     const unsigned long long* __restrict__ keys_sorted, const int64_t* __restrict__ keep,
                                                     const int* __restrict__ seg_begin, const int* __restrict__ keep_cnt,
@@ -714,6 +714,9 @@ __global__ __launch_bounds__(256) void k_gather_out(const float4* __restrict__ c
   __shared__ unsigned long long s_key[kMergeLds];
   __shared__ uint32_t s_val[kMergeLds];
   const int g = blockIdx.x, tid = threadIdx.x;
+  // blockIdx.y = part of gridDim.y: the entries of an image with many kept rows are shared out (every part repeats the prologue;
+  // part 0 writes the counters).  One part per image in the small-image regime.
+  const int part = blockIdx.y, nparts = gridDim.y;
   // The kernel is a chain of dependent global reads (counts -> kept positions -> keys / slots -> candidate rows); everything
   // that does not depend on an earlier read is requested up front: seven latencies became four.
   // kept per segment (clipped to max_det: a class contributes at most max_det rows to the first max_det overall)
@@ -743,7 +746,7 @@ __global__ __launch_bounds__(256) void k_gather_out(const float4* __restrict__ c
   if (tid == 0) for (int c = 0; c < ncs; c++) s_pre[c + 1] += s_pre[c];
   __syncthreads();
   const int total = s_pre[ncs];
-  if (tid == 0) {
+  if (tid == 0 && part == 0) {
     long long nk = total;
     if (max_det > 0 && nk > max_det) nk = max_det;
     out_count[g] = *abort_flag ? -1 : nk;                        // -1: the NMS kernel gave up on a barrier (host raises)
@@ -751,7 +754,7 @@ __global__ __launch_bounds__(256) void k_gather_out(const float4* __restrict__ c
   // status[0]: the largest candidate count if an image overflowed its slots (the caller retries), else 0; status[1]: the largest
   // candidate count (feedback for the caller's next call).  Plain stores by one workgroup -- out_count and status may be pinned
   // host memory (the host layer reads them without a device->host copy).
-  if (g == 0 && tid == 0) {
+  if (g == 0 && tid == 0 && part == 0) {
     long long m4 = s_mx[0];
     for (int k = 1; k < 4; k++) if (s_mx[k] > m4) m4 = s_mx[k];
     status[0] = m4 > cap_img ? m4 : 0;
@@ -779,7 +782,7 @@ __global__ __launch_bounds__(256) void k_gather_out(const float4* __restrict__ c
     }
     __syncthreads();
   }
-  for (int e = tid; e < total; e += 256) {
+  for (int e = tid + 256 * part; e < total; e += 256 * nparts) {
     int c = 0;
     while (s_pre[c + 1] <= e) c++;
     const int k = e - s_pre[c];
@@ -937,7 +940,9 @@ static int run_nms_obb(const void* pred, const void* objcol, int dtype, int64_t 
       dim3 gr((unsigned)((cap_img + 255) / 256), (unsigned)bs);
       k_rekey<<<gr, 256, 0, st>>>(cv.cand, cv.keys_a, cv.sort_begin, cv.sort_end, cv.mode, A, nc);
     }
-    if (expected_cand > kSortLargeFrom) {
+    static long long large_from = -1;                              // OBB_SORT_LARGE_FROM: measurements
+    if (large_from < 0) { const char* e = getenv("OBB_SORT_LARGE_FROM"); large_from = e ? atoll(e) : kSortLargeFrom; if (large_from < 0) large_from = kSortLargeFrom; }
+    if (expected_cand > large_from) {
       // large images (val.py's default conf_thres = 0.001): every image spread over many workgroups (segsort.h)
       int tb = 0;
       while ((1ll << tb) < A * nc + n_extra + 1) tb++;                 // significant bits of the tie word
@@ -1010,7 +1015,9 @@ static int run_nms_obb(const void* pred, const void* objcol, int dtype, int64_t 
   }
   {
     ProfScope ps(PROF_GATHER, st);
-    k_gather_out<<<(unsigned)bs, 256, 0, st>>>(cv.cand, cv.vals_b, cv.keys_b, cv.keep, nv.seg_begin, nv.keep_cnt, cv.mode, ncs, max_det,
+    // parts per image: one up to ~2k expected candidates (the kept rows fit the kernel's LDS and 256 threads), then one per 1024
+    const unsigned gparts = expected_cand <= 2048 ? 1u : (unsigned)((expected_cand + 1023) / 1024 > 16 ? 16 : (expected_cand + 1023) / 1024);
+    k_gather_out<<<dim3((unsigned)bs, gparts), 256, 0, st>>>(cv.cand, cv.vals_b, cv.keys_b, cv.keep, nv.seg_begin, nv.keep_cnt, cv.mode, ncs, max_det,
                                               out, out_count, cv.cnt, cap_img, status, nv.abort_flag, out_packed);
   }
   return hipGetLastError() == hipSuccess ? OBB_OK : OBB_ERR_LAUNCH;
