@@ -40,3 +40,22 @@ def test_no_cpu_fallback_in_product():
             if f.endswith((".py", ".hip", ".h")):
                 src = open(os.path.join(dp, f)).read()
                 assert "import oracle" not in src and "from oracle" not in src and "liboracle" not in src, f
+
+
+def test_argument_checks_answer_before_any_device_call():
+    """Entries validate their arguments first (OBB_ERR_BAD_ARG = -1, nothing is launched): callable without a GPU."""
+    import ctypes as C
+    from yolov5_obb_amd import _lib
+    L = _lib.lib()
+    null = C.c_void_p(0)
+    one = (C.c_int64 * 1)(8)
+    ptrs = (C.c_void_p * 1)(16)
+    f2 = (C.c_float * 6)(*([1.0] * 6))
+    # obb_detect_decode_levels: level count out of range, missing tables, too many anchors, unknown dtype
+    for nl, conv, dtype, na in ((0, ptrs, 1, 3), (5, ptrs, 1, 3), (1, null, 1, 3), (1, ptrs, 7, 3), (1, ptrs, 1, 0), (1, ptrs, 1, 1000)):
+        rc = L.obb_detect_decode_levels(nl, conv, dtype, 2, na, 21, one, one, C.cast(f2, C.c_void_p), C.cast(f2, C.c_void_p), null, null, 0, null, null)
+        assert rc == -1, (nl, dtype, na, rc)
+    # obb_detect_decode: no conv output / no anchors
+    assert L.obb_detect_decode(null, 1, 2, 3, 21, 8, 8, C.cast(f2, C.c_void_p), 8.0, null, null, 0, 0, null) == -1
+    # quad NMS: rows shorter than [8 coordinates, score]
+    assert L.obb_nms_poly_f32(null, 8, 0, 0.1, 0, null, null, null, 0, null) == -1
