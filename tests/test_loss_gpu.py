@@ -46,17 +46,28 @@ def run_both(cl, spec, p, t, dev, dtype=torch.float32):
     return (lo, io, pc), (lg, ig, pg)
 
 
-def check(o, g, rtol=1e-5, grtol=1e-4):
+ACHIEVED = {"scalar_rel": 0.0, "grad_rel": 0.0, "tensors": 0}      # reported by test_zz_report_achieved_errors
+
+
+def check(o, g, rtol=1e-5, grtol=1e-5):
     lo, io, pc = o
     lg, ig, pg = g
     assert lg.shape == (1,) and ig.shape == (4,)
     assert np.allclose(lg.detach().cpu().numpy(), lo.detach().numpy(), rtol=rtol, atol=1e-6), (lg, lo)
     assert np.allclose(ig.cpu().numpy(), io.numpy(), rtol=rtol, atol=1e-6), (ig, io)
+    ref = np.concatenate([lo.detach().numpy().ravel(), io.numpy().ravel()])
+    got = np.concatenate([lg.detach().cpu().numpy().ravel(), ig.cpu().numpy().ravel()])
+    ok = np.abs(ref) > 1e-3
+    if ok.any():
+        ACHIEVED["scalar_rel"] = max(ACHIEVED["scalar_rel"], float(np.max(np.abs(got[ok] - ref[ok]) / np.abs(ref[ok]))))
     for a, b in zip(pg, pc):
         ga, gb = a.grad.float().cpu(), b.grad
         scale = gb.abs().max().item() + 1e-12
         err = (ga - gb).abs().max().item()
         assert err <= grtol * scale, (err, scale)
+        if b.dtype == torch.float32 and a.dtype == torch.float32:
+            ACHIEVED["grad_rel"] = max(ACHIEVED["grad_rel"], err / scale)
+            ACHIEVED["tensors"] += 1
 
 
 @pytest.mark.parametrize("nt", [0, 1, 50, 400])
@@ -202,7 +213,7 @@ def test_focal_loss(dev, gamma):
     forward and gradients vs the oracle's restatement."""
     cl, spec, p, t = make(dev, nt=120, seed=51, hyp_over=dict(fl_gamma=gamma, cls_pw=1.3, obj_pw=0.8))
     assert cl.fl_gamma == gamma
-    check(*run_both(cl, spec, p, t, dev), rtol=2e-5, grtol=2e-4)
+    check(*run_both(cl, spec, p, t, dev), rtol=2e-5, grtol=2e-5)
 
 
 def test_anchor_update_after_construction_is_seen(dev):
@@ -243,3 +254,11 @@ def test_targets_without_csl_columns_are_encoded_on_the_device(dev):
     tc2 = cl.build_targets(pg2, t[:, :7].contiguous().to(dev))[4]
     for a, b in zip(tc1, tc2):
         assert torch.allclose(a, b, rtol=1e-6, atol=1e-30)
+
+
+def test_zz_report_achieved_errors(dev):
+    """Not a check of its own: prints what the fp32 comparisons above achieved (pytest shows it in the warnings summary).  The
+    asserted tolerances are 1e-5 relative on the loss scalars (north_star) and 1e-5 of the tensor's largest |gradient| (1e-4 until the achieved figure was printed: 3.3e-7)."""
+    import warnings
+    warnings.warn(UserWarning(f"ComputeLoss vs oracle (fp32 cases of this run): loss scalars max rel. error {ACHIEVED['scalar_rel']:.2e}; "
+                              f"gradients max |err| / max |grad| = {ACHIEVED['grad_rel']:.2e} over {ACHIEVED['tensors']} tensors"))
