@@ -93,7 +93,10 @@ int obb_nms_rotated_f64(const double* dets5, const double* scores, int64_t n, fl
 /*
  * Quadrilateral NMS.  Replaces nms_rotated_ext.nms_poly (nms_rotated_ext.cpp:42-55 -> poly_nms_cuda,
  * utils/nms_rotated/src/poly_nms_cuda.cu:197-261).  Rows are x1 y1 x2 y2 x3 y3 x4 y4 score (+ ignored extra
- * columns): row_stride >= 9 floats.
+ * columns): row_stride >= 9 floats.  Kept set = the reference's greedy scan over devPolyIoU (poly_nms_cuda.cu:26-142).  Pairs whose
+ * bounding boxes are disjoint AND whose areas outweigh the rounding noise of the reference's origin-based sum (a bound of
+ * 1024 * 2^-24 * M^2 per box, M = its largest |coordinate|) are not clipped; the environment variable
+ * OBB_NMS_POLY_STRICT=1 makes the call clip every pair.
  */
 int obb_nms_poly_f32(const float* polys, int64_t row_stride, int64_t n, float iou_thr, int64_t max_keep, int64_t* keep_out,
                      int64_t* num_keep, void* ws, size_t ws_bytes, void* stream);

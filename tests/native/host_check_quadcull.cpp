@@ -9,7 +9,7 @@
 //   * counts pairs the cull would skip whose IoU exceeds the threshold (must be 0),
 //   * with a third argument: hill-climbs from the noisiest random pairs (ulp-sized and larger moves of single coordinates
 //     that keep the boxes disjoint) to look for inputs whose roundings line up.
-//   usage: host_check_quadcull <n_pairs> <seed> [climb_steps]
+//   usage: host_check_quadcull <n_pairs> <seed> [climb_steps [climb_from_units]]
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -77,6 +77,7 @@ static double climb(float* p, float* q, long steps) {
 int main(int argc, char** argv) {
   long n = argc > 1 ? atol(argv[1]) : 2000000;
   const long climb_steps = argc > 3 ? atol(argv[3]) : 0;
+  const double climb_from = argc > 4 ? atof(argv[4]) : 2.5;      // noise (units) from which a random pair starts an ascent
   double climbed = 0;
   g.seed(argc > 2 ? (unsigned)atol(argv[2]) : 0u);
   const int NF = 10;
@@ -111,7 +112,7 @@ int main(int argc, char** argv) {
       if (r > worst[f]) worst[f] = r;
       if (rs > worst_sum[f]) worst_sum[f] = rs;
       used[f]++;
-      if (climb_steps > 0 && r > 2.5) { float p2[8], q2[8]; memcpy(p2, p, 32); memcpy(q2, q, 32); climbed = fmax(climbed, climb(p2, q2, climb_steps)); }
+      if (climb_steps > 0 && r > climb_from) { float p2[8], q2[8]; memcpy(p2, p, 32); memcpy(q2, q, 32); climbed = fmax(climbed, climb(p2, q2, climb_steps)); }
     }
     for (int t = 0; t < 4; t++) {
       const obb::QuadSkip sp = obb::quad_skip_record(P, thrs[t]), sq = obb::quad_skip_record(Q, thrs[t]);
