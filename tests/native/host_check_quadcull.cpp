@@ -47,16 +47,38 @@ static void make(int f, float span, float* q) {
   }
 }
 
+// The 16-term sum of quad_iou_t itself (same calls in the same order: piou_device.h quad_iou_t), so that the noise is read off
+// directly instead of being backed out of the IoU (inter = iou A / (1 + iou) loses everything when the noise dwarfs the areas
+// and the IoU rounds to -1).  `check`: the IoU rebuilt from this sum must have the bits of quad_iou.
+static float inter_of(const obb::QuadFeat& P, const obb::QuadFeat& Q, float* iou_rebuilt) {
+  float s0[10], s1[10], s2[10], s3[10];
+  float ax[4], ay[4], bx[4], by[4];
+  const float a1 = obb::quad_signed_area(P.x, P.y), a2 = obb::quad_signed_area(Q.x, Q.y);
+  for (int i = 0; i < 4; i++) {
+    ax[i] = (a1 < 0) ? P.x[3 - i] : P.x[i]; ay[i] = (a1 < 0) ? P.y[3 - i] : P.y[i];
+    bx[i] = (a2 < 0) ? Q.x[3 - i] : Q.x[i]; by[i] = (a2 < 0) ? Q.y[3 - i] : Q.y[i];
+  }
+  float inter = 0;
+  for (int i = 0; i < 4; i++)
+    for (int j = 0; j < 4; j++)
+      inter += obb::ptri_tri<1>(ax[i], ay[i], ax[(i + 1) & 3], ay[(i + 1) & 3], bx[j], by[j], bx[(j + 1) & 3], by[(j + 1) & 3], s0, s1, s2, s3);
+  const float ua = fabsf(obb::quad_signed_area(ax, ay)) + fabsf(obb::quad_signed_area(bx, by)) - inter;
+  *iou_rebuilt = (ua == 0.f) ? (inter + 1.f) / (ua + 1.f) : inter / ua;
+  return inter;
+}
+static long g_mirror_bad = 0, g_iou_minus_one = 0;
+
 static double noise_units(const float* p, const float* q) {   // < 0: not a bounding-box-disjoint pair
   float s0[10], s1[10], s2[10], s3[10];
   obb::QuadFeat P = obb::quad_make_feat(p), Q = obb::quad_make_feat(q);
   if (!(P.minx > Q.maxx || Q.minx > P.maxx || P.miny > Q.maxy || Q.miny > P.maxy)) return -1.0;
-  const float iou = obb::quad_iou<1>(P, Q, s0, s1, s2, s3);
-  const double A = (double)fabsf(obb::quad_signed_area(P.x, P.y)) + (double)fabsf(obb::quad_signed_area(Q.x, Q.y));
+  (void)s0; (void)s1; (void)s2; (void)s3;
+  float rebuilt;
+  const float inter = inter_of(P, Q, &rebuilt);
   float m = 0.f;
   for (int k = 0; k < 8; k++) m = fmaxf(m, fmaxf(fabsf(p[k]), fabsf(q[k])));
-  if (!(A > 0) || iou != iou || m == 0.f) return -1.0;
-  return fabs((double)iou * A / (1.0 + (double)iou)) / (ldexp(1.0, -24) * (double)m * m);
+  if (inter != inter || m == 0.f) return -1.0;
+  return fabs((double)inter) / (ldexp(1.0, -24) * (double)m * m);
 }
 
 // greedy ascent on the noise: single-coordinate moves of 1..64 ulps or of a random fraction of a pixel
@@ -105,8 +127,12 @@ int main(int argc, char** argv) {
     const double A = (double)fabsf(obb::quad_signed_area(P.x, P.y)) + (double)fabsf(obb::quad_signed_area(Q.x, Q.y));
     float mp = 0.f, mq = 0.f;
     for (int k = 0; k < 8; k++) { mp = fmaxf(mp, fabsf(p[k])); mq = fmaxf(mq, fabsf(q[k])); }
-    if (A > 0 && iou == iou) {
-      const double inter = fabs((double)iou * A / (1.0 + (double)iou));
+    float rebuilt;
+    const float inter_f = inter_of(P, Q, &rebuilt);
+    if (memcmp(&rebuilt, &iou, 4) != 0 && !(rebuilt != rebuilt && iou != iou)) { if (g_mirror_bad < 5) printf("MIRROR family %d iou %.9g rebuilt %.9g\n", f, iou, rebuilt); g_mirror_bad++; }
+    if (iou == -1.0f) g_iou_minus_one++;      // noise far above the two areas: the back-out formula of an earlier version divided by 0 here
+    if (inter_f == inter_f) {
+      const double inter = fabs((double)inter_f);
       const double M = fmax(mp, mq), u = ldexp(1.0, -24);
       const double r = inter / (u * M * M), rs = inter / (u * ((double)mp * mp + (double)mq * mq));
       if (r > worst[f]) worst[f] = r;
@@ -141,7 +167,8 @@ int main(int argc, char** argv) {
     if (!ok) { if (bad16 < 5) printf("FP16 ROUNDING x %.9g down %.9g up %.9g\n", x, fd, fu); bad16++; }
   }
   printf("fp16_rounding_errors=%ld\n", bad16);
-  wrong += bad16;
+  printf("mirror_mismatches=%ld pairs_with_iou_exactly_minus_one=%ld\n", g_mirror_bad, g_iou_minus_one);
+  wrong += bad16 + g_mirror_bad;
   double w = 0, ws = 0;
   for (int f = 0; f < NF; f++) {
     printf("family %d: disjoint pairs %ld  max noise %.1f units (by M_i^2+M_j^2: %.1f)\n", f, used[f], worst[f], worst_sum[f]);
