@@ -170,11 +170,12 @@ OBB_HD float quad_iou(const QuadFeat& P, const QuadFeat& Q, float* px, float* py
 // every product in a term is O(M^2), M = largest |coordinate| of the pair, so |inter| <= c u M^2 with u = 2^-24 ("units").
 //   * measured: tests/native/host_check_quadcull.cpp, ten adversarial families of bounding-box-disjoint pairs (slivers, bow
 //     ties, edges along rays from the origin, all quadrants, touching boxes, a vertex at the origin, |coord| 8 .. 70000):
-//     the largest noise over 2 x 10^8 pairs is below 8 units (a sum of a few hundred roundings of <= 1 unit each);
+//     the largest noise over 1.6 x 10^10 pairs is 10.3 units, 22.9 after greedy ascents (profiles/r3_quad_noise.md; a sum of a
+//     few hundred roundings of <= 1 unit each);
 //   * worst case, every rounding aligned: shoelace (<= 6 products + accumulation per term) ~ 25 units per term, clip
 //     vertices (<= 4 per term, each moved by a few ulps of M against edges <= 2.9 M) ~ 25 units per term, 16 terms:
 //     several hundred units.
-// The bound used is c = 1024 units: above the aligned-roundings accounting, > 100x the largest value seen.  It is an
+// The bound used is c = 1024 units: above the aligned-roundings accounting, > 40x the largest value found by search.  It is an
 // engineering bound, not a machine-checked proof; OBB_NMS_POLY_STRICT=1 turns the skip off (every pair clipped).
 // The absolute 1e-8 sign threshold of the reference drops or adds triangles of area <= 1e-8 each: kQuadSlack.
 //
