@@ -14,11 +14,10 @@
 #include <stdio.h>
 #include <string.h>
 #include <hip/hip_fp16.h>
-#include <rocprim/device/device_radix_sort.hpp>
-#include <rocprim/device/device_merge_sort.hpp>
-#include <rocprim/device/device_segmented_radix_sort.hpp>
 #include "nms_core.h"
 #include "obb_hip.h"
+#include "psrs_sort.h"
+#include "segsort.h"
 
 namespace obb {
 
@@ -60,25 +59,6 @@ __device__ __forceinline__ uint32_t score_desc_key(float s) {
   return ~k;
 }
 
-__global__ void k_make_keys(const float* __restrict__ scores, int score_stride, const int32_t* __restrict__ seg_id,
-                            const uint32_t* __restrict__ tie, int tie_bits, const float* __restrict__ dets5,
-                            int drop_small, int n, uint64_t* __restrict__ keys, uint32_t* __restrict__ vals) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  uint32_t k = score_desc_key(scores[(size_t)i * score_stride]);
-  if (drop_small) {
-    // nms_rotated_wrapper.py:32  too_small = dets[:, [2, 3]].min(1)[0] < 0.001
-    float w = dets5[(size_t)i * 5 + 2], h = dets5[(size_t)i * 5 + 3];
-    float mn = (h < w) ? h : w;           // torch.min propagates NaN; NaN < 0.001 is False either way
-    if (mn < 0.001f) k = 0xFFFFFFFFu;
-  }
-  uint64_t seg = seg_id ? (uint64_t)(uint32_t)seg_id[i] : 0ull;
-  uint64_t key = (seg << (32 + tie_bits)) | ((uint64_t)k << tie_bits);
-  if (tie_bits) key |= (uint64_t)(tie[i] & ((1u << tie_bits) - 1u));
-  keys[i] = key;
-  vals[i] = (uint32_t)i;
-}
-
 // min / max of four ordered ints over the workgroup (<= 1024 threads); every thread returns the result
 __device__ __forceinline__ void block_minmax4(int& a0, int& a1, int& b0, int& b1, int (*s_red)[4]) {
 #pragma unroll
@@ -93,70 +73,76 @@ __device__ __forceinline__ void block_minmax4(int& a0, int& a1, int& b0, int& b1
   for (int k = 0; k < nw; k++) { a0 = min(a0, s_red[k][0]); a1 = min(a1, s_red[k][1]); b0 = max(b0, s_red[k][2]); b1 = max(b1, s_red[k][3]); }
 }
 
-// single list, no explicit tie word: 32-bit keys (half the sort traffic, half the radix passes)
-// (also: the single segment's table and the zeroing of the team-barrier block -- two launches fewer)
-__global__ void k_make_keys32(const float* __restrict__ scores, int score_stride, const float* __restrict__ dets5, int drop_small,
-                              int n, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, int* seg_begin, int* seg_end,
-                              int* keep_cnt, uint4* __restrict__ bar16, long long n_bar16, uint4* __restrict__ grid16, long long n_grid16,
-                              int* __restrict__ bbpart) {
-  __shared__ int s_red[16][4];
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i == 0) { seg_begin[0] = 0; seg_end[0] = n; keep_cnt[0] = 0; }
-  for (long long k = i; k < n_bar16; k += (long long)gridDim.x * blockDim.x) bar16[k] = make_uint4(0u, 0u, 0u, 0u);
-  for (long long k = i; k < n_grid16; k += (long long)gridDim.x * blockDim.x) grid16[k] = make_uint4(0u, 0u, 0u, 0u);   // GridMeta + slot counters
+// Single list: the runs of the sort (psrs_sort.h) straight from the scores -- key = descending-score bits in the high word,
+// original index in the low word (unique: ties keep ascending index, the documented rule) -- plus everything the old key
+// kernel did on the side: the single segment's table, the zeroing of the team-barrier block and of the index / slab block,
+// and the bounding-box partial of the block's boxes (one per run) for the spatial index.
+struct LocalExtras {
+  int *seg_begin, *seg_end, *keep_cnt;
+  uint4* bar16; long long n_bar16;
+  uint4* grid16; long long n_grid16;
+  int* bbpart;                 // [runs][kBbInts] or NULL
+};
+__device__ __forceinline__ void local_extras(const LocalExtras& x, const float* __restrict__ dets5, int drop_small, int n, int i, bool in_range,
+                                             int (*s_red)[4], uint32_t* key_out) {
+  if (i == 0) { x.seg_begin[0] = 0; x.seg_end[0] = n; x.keep_cnt[0] = 0; }
+  for (long long k = i; k < x.n_bar16; k += (long long)gridDim.x * blockDim.x) x.bar16[k] = make_uint4(0u, 0u, 0u, 0u);
+  for (long long k = i; k < x.n_grid16; k += (long long)gridDim.x * blockDim.x) x.grid16[k] = make_uint4(0u, 0u, 0u, 0u);   // GridMeta + slot counters
   int bx0 = 0x7fffffff, by0 = 0x7fffffff, bx1 = (int)0x80000000, by1 = (int)0x80000000;
   int d2 = 0;                                          // largest w^2 + h^2 of the block, as float bits (>= 0: ordered like ints)
-  if (i < n) {
-    uint32_t k = score_desc_key(scores[(size_t)i * score_stride]);
+  if (in_range) {
     bool ok = true;
     float w = 0.f, h = 0.f;
-    if (drop_small || bbpart != nullptr) { w = dets5[(size_t)i * 5 + 2]; h = dets5[(size_t)i * 5 + 3]; }
+    if (drop_small || x.bbpart != nullptr) { w = dets5[(size_t)i * 5 + 2]; h = dets5[(size_t)i * 5 + 3]; }
     if (drop_small) {
+      // nms_rotated_wrapper.py:32  too_small = dets[:, [2, 3]].min(1)[0] < 0.001   (torch.min propagates NaN; NaN < 0.001 is False)
       float mn = (h < w) ? h : w;
-      if (mn < 0.001f) { k = 0xFFFFFFFFu; ok = false; }
+      if (mn < 0.001f) { *key_out = 0xFFFFFFFFu; ok = false; }
     }
-    keys[i] = k;
-    vals[i] = (uint32_t)i;
-    if (bbpart != nullptr && ok) {
+    if (x.bbpart != nullptr && ok) {
       // bounding box of the finite centres of the boxes that take part: the extent of the data for the spatial index
       // (grid.h), one partial per block, reduced by the blocks of the prep kernel (no atomics)
-      const float x = dets5[(size_t)i * 5], y = dets5[(size_t)i * 5 + 1];
-      if ((x - x == 0.f) && (y - y == 0.f)) { bx0 = bx1 = grid_f2o(x); by0 = by1 = grid_f2o(y); }
+      const float cx = dets5[(size_t)i * 5], cy = dets5[(size_t)i * 5 + 1];
+      if ((cx - cx == 0.f) && (cy - cy == 0.f)) { bx0 = bx1 = grid_f2o(cx); by0 = by1 = grid_f2o(cy); }
       const float q = w * w + h * h;
       if (q - q == 0.f) d2 = __float_as_int(q);
     }
   }
-  if (bbpart != nullptr) {
+  if (x.bbpart != nullptr) {
     int d2b = d2, dummy = d2;
     block_minmax4(bx0, by0, bx1, by1, s_red);
     { int lo0 = 0x7fffffff, lo1 = 0x7fffffff; block_minmax4(lo0, lo1, d2b, dummy, s_red); }
     if (threadIdx.x == 0) {
-      int* o = bbpart + (size_t)blockIdx.x * kBbInts;
+      int* o = x.bbpart + (size_t)blockIdx.x * kBbInts;
       o[0] = bx0; o[1] = by0; o[2] = bx1; o[3] = by1; o[4] = d2b; o[5] = o[6] = o[7] = 0;
     }
   }
 }
-
-__device__ __forceinline__ int key_lower_bound(const uint64_t* keys, int n, uint64_t target) {
-  int lo = 0, hi = n;
-  while (lo < hi) {
-    int mid = (lo + hi) >> 1;
-    if (keys[mid] < target) lo = mid + 1; else hi = mid;
-  }
-  return lo;
+__global__ __launch_bounds__(kPsRun) void k_ps_local_scores(PsBuf b, const float* __restrict__ scores, int score_stride,
+                                                            const float* __restrict__ dets5, int drop_small, LocalExtras x) {
+  __shared__ unsigned long long s_k[kPsRun];
+  __shared__ uint32_t s_v[kPsRun];
+  __shared__ int s_red[16][4];
+  const int n = b.n, tid = threadIdx.x;
+  const int i = blockIdx.x * kPsRun + tid;
+  uint32_t k32 = 0xFFFFFFFFu;
+  if (i < n) k32 = score_desc_key(scores[(size_t)i * score_stride]);
+  local_extras(x, dets5, drop_small, n, i, i < n, s_red, &k32);
+  s_k[tid] = ((unsigned long long)k32 << 32) | (unsigned long long)(uint32_t)i;      // (a pad: 0xFFFFFFFF | position >= n)
+  s_v[tid] = (uint32_t)i;
+  ps_local_tail(b, n, s_k, s_v);
 }
-
-// segment g = sorted positions [seg_begin[g], seg_begin[g+1]); only the first `topk` of them take part
-// (utils/general.py:845-846: x = x[x[:, 5].argsort(descending=True)[:max_nms]])
-__global__ void k_seg_bounds(const uint64_t* __restrict__ keys, int n, int nseg, int shift, long long topk,
-                             int* __restrict__ seg_begin, int* __restrict__ seg_end, int* keep_cnt) {
-  int g = blockIdx.x * blockDim.x + threadIdx.x;
-  if (g >= nseg) return;
-  int lo = key_lower_bound(keys, n, (uint64_t)g << shift);
-  int hi = (g + 1 == nseg) ? n : key_lower_bound(keys, n, (uint64_t)(g + 1) << shift);
-  if (topk > 0 && hi - lo > topk) hi = lo + (int)topk;
-  seg_begin[g] = lo; seg_end[g] = hi;
-  keep_cnt[g] = 0;
+// ... and the plain key kernel for lists the three-launch sort does not take (n > kPsMaxN): 64-bit keys (score bits << 32 |
+// index) for segsort.h's LSD radix sort over the four score bytes (stable: ties keep ascending index)
+__global__ __launch_bounds__(kPsRun) void k_make_keys_wide(const float* __restrict__ scores, int score_stride, const float* __restrict__ dets5,
+                                                           int drop_small, int n, unsigned long long* __restrict__ keys, uint32_t* __restrict__ vals,
+                                                           LocalExtras x) {
+  __shared__ int s_red[16][4];
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t k32 = 0xFFFFFFFFu;
+  if (i < n) k32 = score_desc_key(scores[(size_t)i * score_stride]);
+  local_extras(x, dets5, drop_small, n, i, i < n, s_red, &k32);
+  if (i < n) { keys[i] = ((unsigned long long)k32 << 32) | (unsigned long long)(uint32_t)i; vals[i] = (uint32_t)i; }
 }
 
 // ---------------------------------------------------------------- spatial index (grid.h): counting sort by cell
@@ -271,7 +257,7 @@ __device__ __forceinline__ uint64_t score_desc_key64(double s) {
   return ~k;
 }
 __global__ void k_make_keys_f64(const double* __restrict__ scores, const double* __restrict__ dets5, int drop_small, int n,
-                                uint64_t* __restrict__ keys, uint32_t* __restrict__ vals, int* seg_begin, int* seg_end, int* keep_cnt) {
+                                unsigned long long* __restrict__ keys, uint32_t* __restrict__ vals, int* seg_begin, int* seg_end, int* keep_cnt) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i == 0) { seg_begin[0] = 0; seg_end[0] = n; keep_cnt[0] = 0; }
   if (i >= n) return;
@@ -394,7 +380,7 @@ static int cap_max(int64_t nseg) {
 constexpr int kMaxTeams = 1024;     // >= number of CUs of any gfx950 part
 
 struct Carve {
-  uint64_t *keys_a, *keys_b;
+  unsigned long long *keys_a, *keys_b;
   uint32_t *vals_a, *vals_b;
   void* sort_tmp; size_t sort_tmp_bytes;
   float4* rec; u64* alive; size_t alive_bytes;
@@ -438,26 +424,19 @@ static int hw_cu_count() {
   return cus;
 }
 
-static hipError_t sort_tmp_query(size_t n, size_t* bytes) {
-  *bytes = 0;
-  size_t b64 = 0, b32 = 0;
-  hipError_t e = rocprim::radix_sort_pairs(nullptr, b64, (uint64_t*)nullptr, (uint64_t*)nullptr, (uint32_t*)nullptr,
-                                           (uint32_t*)nullptr, n, 0, 64, (hipStream_t)0, false);
-  if (e != hipSuccess) return e;
-  e = rocprim::radix_sort_pairs(nullptr, b32, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, n, 0,
-                                32, (hipStream_t)0, false);
-  *bytes = (b64 > b32 ? b64 : b32) + 65536;      // (+ slack for the alternative merge-sort configurations of OBB_SORT_CFG)
-  return e;
+// scratch of the sorts: samples + cut table of the three-launch sort (psrs_sort.h), tile histograms of the radix sort (segsort.h)
+static size_t sort_tmp_bytes_for(size_t n) {
+  return align_up(ps_scratch_bytes()) + (((n + kSrsTile - 1) / kSrsTile) + 1) * 256 * 4;
 }
 
 static int carve(void* base, int64_t n, int64_t nseg, int recq, int C, Carve* cv) {
   size_t off = 0;
   auto take = [&](size_t bytes) { size_t o = off; off += align_up(bytes); return base ? (char*)base + o : (char*)nullptr; };
   size_t nn = (size_t)(n > 0 ? n : 1), ns = (size_t)(nseg > 0 ? nseg : 1);
-  cv->keys_a = (uint64_t*)take(nn * 8); cv->keys_b = (uint64_t*)take(nn * 8);
+  cv->keys_a = (unsigned long long*)take(nn * 8); cv->keys_b = (unsigned long long*)take(nn * 8);
   cv->vals_a = (uint32_t*)take(nn * 4); cv->vals_b = (uint32_t*)take(nn * 4);
-  if (sort_tmp_query(nn, &cv->sort_tmp_bytes) != hipSuccess) return OBB_ERR_INTERNAL;
-  cv->sort_tmp = take(cv->sort_tmp_bytes ? cv->sort_tmp_bytes : 16);
+  cv->sort_tmp_bytes = sort_tmp_bytes_for(nn);
+  cv->sort_tmp = take(cv->sort_tmp_bytes);
   cv->rec = (float4*)take(nn * recq * 16);
   cv->alive_bytes = (nn / 64 + 10) * 8;      // + guard words (zeroed by the prep kernels)
   cv->alive = (u64*)take(cv->alive_bytes);
@@ -607,12 +586,32 @@ static int nms_steps(int kind, NmsArgs& a, const Carve& cv, int64_t nseg, int64_
   return a.gmeta != nullptr ? launch_persist<RotGeom, true>(a, (unsigned)nb, st) : launch_persist<RotGeom, false>(a, (unsigned)nb, st);
 }
 
+// One list sorted by descending score, ties by ascending index (nms_rotated_cuda.cu:81-82 leaves the tie order to an
+// unstable sort; this is the documented rule here): sorted keys in cv.keys_b, order in cv.vals_b.  Up to kPsMaxN elements:
+// three launches (psrs_sort.h); longer lists: key kernel + LSD radix sort over the four score bytes (segsort.h).
+static int sort_single_list(const float* scores, int score_stride, const float* dets5, int drop_small, int64_t n, const Carve& cv,
+                            const LocalExtras& x, int* nparts_out, hipStream_t st) {
+  if (n <= kPsMaxN) {
+    PsBuf b{};
+    b.run_k = cv.keys_a; b.run_v = cv.vals_a; b.out_k = cv.keys_b; b.out_v = cv.vals_b; b.n = (int)n; b.n_dev = nullptr; b.err = nullptr;
+    ps_carve_scratch(cv.sort_tmp, &b);
+    const int runs = (int)((n + kPsRun - 1) / kPsRun);
+    k_ps_local_scores<<<(unsigned)runs, kPsRun, 0, st>>>(b, scores, score_stride, dets5, drop_small, x);
+    *nparts_out = runs;
+    return ps_finish(b, runs, st);
+  }
+  const unsigned gb = (unsigned)((n + kPsRun - 1) / kPsRun);
+  k_make_keys_wide<<<gb, kPsRun, 0, st>>>(scores, score_stride, dets5, drop_small, (int)n, cv.keys_a, cv.vals_a, x);
+  *nparts_out = (int)gb;
+  uint32_t* hist = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(cv.sort_tmp) + align_up(ps_scratch_bytes()));
+  return seg_radix_sort_large(cv.keys_a, cv.keys_b, cv.vals_a, cv.vals_b, cv.seg_begin, cv.seg_end, 1, n, n, 0xF0u, hist, st);
+}
+
 // kind: 0 rotated (5 floats + score array), 1 quad (rows of `stride` floats, score in column 8)
-static int run_nms(int kind, const float* boxes, int stride, const float* scores, int score_stride, const int32_t* seg_id,
-                   const uint32_t* tie, int tie_bits, int64_t n, int64_t nseg, int64_t max_seg, float thr, int flags,
-                   int64_t max_keep, int64_t* keep_out, int64_t* num_keep, int64_t* seg_begin_out, void* ws, size_t ws_bytes,
-                   hipStream_t st) {
-  if (n < 0 || nseg < 1 || n > 0x7fffffffLL) return OBB_ERR_BAD_ARG;
+static int run_nms(int kind, const float* boxes, int stride, const float* scores, int score_stride, int64_t n, float thr, int flags,
+                   int64_t max_keep, int64_t* keep_out, int64_t* num_keep, void* ws, size_t ws_bytes, hipStream_t st) {
+  const int64_t nseg = 1;
+  if (n < 0 || n > 0x7fffffffLL) return OBB_ERR_BAD_ARG;
   if (!num_keep || (n > 0 && (!boxes || !scores || !keep_out))) return OBB_ERR_BAD_ARG;
   const int C = cap_max(nseg);
   const int recq = kind == 0 ? RotGeom::RECQ : QuadGeom::RECQ;
@@ -620,17 +619,14 @@ static int run_nms(int kind, const float* boxes, int stride, const float* scores
   int rc = carve(ws, n, nseg, recq, C, &cv);
   if (rc) return rc;
   if (!ws || ws_bytes < cv.total) return OBB_ERR_WORKSPACE;
-  int seg_bits = 0;
-  while ((1ll << seg_bits) < nseg) seg_bits++;
-  if (32 + tie_bits + seg_bits > 64) return OBB_ERR_BAD_ARG;
   const int T = 256;
   const int drop_small = (flags & OBB_NMS_DROP_SMALL) ? 1 : 0;
-  const unsigned gseg = (unsigned)((nseg + T - 1) / T);
+  const unsigned gseg = 1;
 
   if (n == 0) {
     if (hipMemsetAsync(cv.keep_cnt, 0, nseg * 4, st) != hipSuccess) return OBB_ERR_LAUNCH;
     if (hipMemsetAsync(cv.seg_begin, 0, nseg * 4, st) != hipSuccess) return OBB_ERR_LAUNCH;
-    k_finalize<<<gseg, T, 0, st>>>(cv.keep_cnt, cv.seg_begin, (int)nseg, max_keep, nullptr, num_keep, seg_begin_out);
+    k_finalize<<<gseg, T, 0, st>>>(cv.keep_cnt, cv.seg_begin, (int)nseg, max_keep, nullptr, num_keep, nullptr);
     return hipGetLastError() == hipSuccess ? OBB_OK : OBB_ERR_LAUNCH;
   }
 
@@ -639,47 +635,20 @@ static int run_nms(int kind, const float* boxes, int stride, const float* scores
   // spatial index for the cross phases (grid.h): rotated boxes, one list, conservative rejects allowed (thr >= 0)
   static int no_grid = -1;                                         // OBB_NMS_NO_GRID=1: A/B switch for measurements
   if (no_grid < 0) { const char* e = getenv("OBB_NMS_NO_GRID"); no_grid = (e && atoi(e)) ? 1 : 0; }
-  const bool use_grid = !no_grid && kind == 0 && nseg == 1 && tie_bits == 0 && cv.grid.meta != nullptr && thr >= 0.f && n < (1ll << 24);
+  const bool use_grid = !no_grid && kind == 0 && cv.grid.meta != nullptr && thr >= 0.f && n < (1ll << 24);
   static int no_slabs = -1;                                        // OBB_NMS_NO_SLABS=1: A/B switch for measurements
   if (no_slabs < 0) { const char* e = getenv("OBB_NMS_NO_SLABS"); no_slabs = (e && atoi(e)) ? 1 : 0; }
   const bool use_slabs = use_grid && !no_slabs && max_keep <= 0;   // (a limit on the kept boxes keeps the call one list: the windows are per list)
   {
     ProfScope ps(PROF_NMS_SORT, st);
-    size_t tmp = cv.sort_tmp_bytes;
-    if (nseg == 1 && tie_bits == 0) {
-      uint32_t* k32a = reinterpret_cast<uint32_t*>(cv.keys_a);
-      uint32_t* k32b = reinterpret_cast<uint32_t*>(cv.keys_b);
-      k_make_keys32<<<gb, T, 0, st>>>(scores, score_stride, kind == 0 ? boxes : nullptr, kind == 0 ? drop_small : 0, (int)n, k32a,
-                                      cv.vals_a, cv.seg_begin, cv.seg_end, cv.keep_cnt, reinterpret_cast<uint4*>(cv.bar),
-                                      (long long)(cv.bar_bytes / 16), reinterpret_cast<uint4*>(cv.grid.meta),
-                                      use_grid ? (long long)(cv.grid_zero_bytes / 16) : 0ll, (use_grid && kind == 0) ? cv.grid.bbpart : nullptr);
-      pre = kNmsBarZeroed;
-      // OBB_SORT_CFG: rocPRIM merge-sort configurations (measurements): 0 = the library's default (58 us at 100k: block
-      // sort + 7 odd-even merge passes), 1..4 = larger sorted blocks / merge-path merges
-      static int scfg = -1;
-      if (scfg < 0) { const char* e = getenv("OBB_SORT_CFG"); scfg = e ? atoi(e) : 0; if (scfg < 0 || scfg > 4) scfg = 0; }
-      hipError_t se;
-      using rocprim::default_config;
-      using rocprim::merge_sort_config;
-      using rocprim::radix_sort_config;
-      if (scfg == 1) se = rocprim::radix_sort_pairs<radix_sort_config<default_config, merge_sort_config<512, 512, 8, 128, 128, 4, 0>>>(
-                         cv.sort_tmp, tmp, k32a, k32b, cv.vals_a, cv.vals_b, (size_t)n, 0, 32, st, false);
-      else if (scfg == 2) se = rocprim::radix_sort_pairs<radix_sort_config<default_config, merge_sort_config<512, 512, 8, 128, 128, 4, (1u << 30)>>>(
-                              cv.sort_tmp, tmp, k32a, k32b, cv.vals_a, cv.vals_b, (size_t)n, 0, 32, st, false);
-      else if (scfg == 3) se = rocprim::radix_sort_pairs<radix_sort_config<default_config, merge_sort_config<256, 256, 8, 128, 128, 4, (1u << 30)>>>(
-                              cv.sort_tmp, tmp, k32a, k32b, cv.vals_a, cv.vals_b, (size_t)n, 0, 32, st, false);
-      else if (scfg == 4) se = rocprim::radix_sort_pairs<radix_sort_config<default_config, merge_sort_config<1024, 1024, 4, 128, 256, 8, 0>>>(
-                              cv.sort_tmp, tmp, k32a, k32b, cv.vals_a, cv.vals_b, (size_t)n, 0, 32, st, false);
-      else se = rocprim::radix_sort_pairs(cv.sort_tmp, tmp, k32a, k32b, cv.vals_a, cv.vals_b, (size_t)n, 0, 32, st, false);
-      if (se != hipSuccess) return OBB_ERR_LAUNCH;
-    } else {
-      k_make_keys<<<gb, T, 0, st>>>(scores, score_stride, seg_id, tie, tie_bits, kind == 0 ? boxes : nullptr,
-                                    kind == 0 ? drop_small : 0, (int)n, cv.keys_a, cv.vals_a);
-      if (rocprim::radix_sort_pairs(cv.sort_tmp, tmp, cv.keys_a, cv.keys_b, cv.vals_a, cv.vals_b, (size_t)n, 0,
-                                    (unsigned)(32 + tie_bits + seg_bits), st, false) != hipSuccess)
-        return OBB_ERR_LAUNCH;
-      k_seg_bounds<<<gseg, T, 0, st>>>(cv.keys_b, (int)n, (int)nseg, 32 + tie_bits, 0, cv.seg_begin, cv.seg_end, cv.keep_cnt);
-    }
+    LocalExtras x{};
+    x.seg_begin = cv.seg_begin; x.seg_end = cv.seg_end; x.keep_cnt = cv.keep_cnt;
+    x.bar16 = reinterpret_cast<uint4*>(cv.bar); x.n_bar16 = (long long)(cv.bar_bytes / 16);
+    x.grid16 = reinterpret_cast<uint4*>(cv.grid.meta); x.n_grid16 = use_grid ? (long long)(cv.grid_zero_bytes / 16) : 0ll;
+    x.bbpart = (use_grid && kind == 0) ? cv.grid.bbpart : nullptr;
+    rc = sort_single_list(scores, score_stride, kind == 0 ? boxes : nullptr, kind == 0 ? drop_small : 0, n, cv, x, &cv.grid.nparts, st);
+    if (rc) return rc;
+    pre = kNmsBarZeroed;
   }
   {
     ProfScope ps(PROF_NMS_PREP, st);
@@ -712,13 +681,12 @@ static int run_nms(int kind, const float* boxes, int stride, const float* scores
   a.thr = thr; a.thr64 = thr;
   a.cull = (thr >= 0.f) ? 1 : 0;      // rejects predict IoU <= 0 or IoU <= thr; with thr < 0 even IoU == 0 suppresses
 
-  (void)max_seg;   // the step loop is device-driven now: no host-side bound on the segment size is needed
   {
     ProfScope ps(PROF_NMS_STEPS, st);
     rc = nms_steps(kind, a, cv, nseg, n, st, pre);
     if (rc) return rc;
   }
-  k_finalize<<<gseg, T, 0, st>>>(cv.keep_cnt, cv.seg_begin, (int)nseg, max_keep, cv.abort_flag, num_keep, seg_begin_out);
+  k_finalize<<<gseg, T, 0, st>>>(cv.keep_cnt, cv.seg_begin, (int)nseg, max_keep, cv.abort_flag, num_keep, nullptr);
   return hipGetLastError() == hipSuccess ? OBB_OK : OBB_ERR_LAUNCH;
 }
 
@@ -774,9 +742,13 @@ static int run_nms_rot64(const double* dets5, const double* scores, int64_t n, f
   const unsigned gb = (unsigned)((n + T - 1) / T);
   const int drop_small = (flags & OBB_NMS_DROP_SMALL) ? 1 : 0;
   k_make_keys_f64<<<gb, T, 0, st>>>(scores, dets5, drop_small, (int)n, cv.keys_a, cv.vals_a, cv.seg_begin, cv.seg_end, cv.keep_cnt);
-  size_t tmp = cv.sort_tmp_bytes;
-  if (rocprim::radix_sort_pairs(cv.sort_tmp, tmp, cv.keys_a, cv.keys_b, cv.vals_a, cv.vals_b, (size_t)n, 0, 64, st, false) != hipSuccess)
-    return OBB_ERR_LAUNCH;
+  // 64-bit score keys are not unique: the stable LSD radix sort of segsort.h keeps ties in ascending index (eight passes; this
+  // entry serves float64 callers, the double clip behind it costs orders of magnitude more than its sort)
+  {
+    uint32_t* hist = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(cv.sort_tmp) + align_up(ps_scratch_bytes()));
+    rc = seg_radix_sort_large(cv.keys_a, cv.keys_b, cv.vals_a, cv.vals_b, cv.seg_begin, cv.seg_end, 1, n, n, 0xFFu, hist, st);
+    if (rc) return rc;
+  }
   k_prep_rot64<<<gb, T, 0, st>>>(dets5, cv.vals_b, drop_small, (int)n, cv.rec, cv.alive);
   NmsArgs a{};
   a.rec = cv.rec; a.order = cv.vals_b; a.alive = cv.alive; a.seg_begin = cv.seg_begin; a.seg_end = cv.seg_end;
@@ -811,8 +783,7 @@ size_t obb_nms_workspace_bytes(int64_t n, int64_t nseg, int kind) {
 
 int obb_nms_rotated_f32(const float* dets5, const float* scores, int64_t n, float iou_thr, int flags, int64_t max_keep,
                         int64_t* keep_out, int64_t* num_keep, void* ws, size_t ws_bytes, void* stream) {
-  return run_nms(0, dets5, 5, scores, 1, nullptr, nullptr, 0, n, 1, n, iou_thr, flags, max_keep, keep_out, num_keep, nullptr,
-                 ws, ws_bytes, (hipStream_t)stream);
+  return run_nms(0, dets5, 5, scores, 1, n, iou_thr, flags, max_keep, keep_out, num_keep, ws, ws_bytes, (hipStream_t)stream);
 }
 
 int obb_nms_rotated_f64(const double* dets5, const double* scores, int64_t n, float iou_thr, int flags, int64_t max_keep,
@@ -823,8 +794,8 @@ int obb_nms_rotated_f64(const double* dets5, const double* scores, int64_t n, fl
 int obb_nms_poly_f32(const float* polys, int64_t row_stride, int64_t n, float iou_thr, int64_t max_keep, int64_t* keep_out,
                      int64_t* num_keep, void* ws, size_t ws_bytes, void* stream) {
   if (row_stride < 9) return OBB_ERR_BAD_ARG;
-  return run_nms(1, polys, (int)row_stride, polys ? polys + 8 : nullptr, (int)row_stride, nullptr, nullptr, 0, n, 1, n, iou_thr,
-                 0, max_keep, keep_out, num_keep, nullptr, ws, ws_bytes, (hipStream_t)stream);
+  return run_nms(1, polys, (int)row_stride, polys ? polys + 8 : nullptr, (int)row_stride, n, iou_thr, 0, max_keep, keep_out, num_keep,
+                 ws, ws_bytes, (hipStream_t)stream);
 }
 
 
@@ -857,8 +828,7 @@ void _poly_nms(int* keep_out_host, int* num_out_host, const float* polys_host, i
   if (e == hipSuccess) e = hipMemcpy(dp, polys_host, n * polys_dim * 4, hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMemcpy(ds, hs, n * 4, hipMemcpyHostToDevice);
   if (e == hipSuccess) {
-    int rc = run_nms(1, dp, polys_dim, ds, 1, nullptr, nullptr, 0, polys_num, 1, polys_num, nms_overlap_thresh, 0, 0, dk, dn,
-                     nullptr, ws, wsb, (hipStream_t)0);
+    int rc = run_nms(1, dp, polys_dim, ds, 1, polys_num, nms_overlap_thresh, 0, 0, dk, dn, ws, wsb, (hipStream_t)0);
     if (rc) fprintf(stderr, "_poly_nms: launch failed (%d)\n", rc);
     int64_t cnt = 0;
     e = hipMemcpy(&cnt, dn, 8, hipMemcpyDeviceToHost);

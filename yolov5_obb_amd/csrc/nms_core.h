@@ -210,6 +210,20 @@ struct WaveLds {
   float4 align16[0];
 };
 
+// Phases that run once per call or once per step: forceinline by default; a build may turn any of them into a real
+// function (-DOBB_COLD_x="__device__ __attribute__((noinline))") to shorten the live ranges of the persistent kernel.
+#ifndef OBB_COLD_RESOLVE
+#define OBB_COLD_RESOLVE __device__ __forceinline__
+#endif
+#ifndef OBB_COLD_GRID
+#define OBB_COLD_GRID __device__ __forceinline__
+#endif
+#ifndef OBB_COLD_SLAB
+#define OBB_COLD_SLAB __device__ __forceinline__
+#endif
+#ifndef OBB_COLD_SELECT
+#define OBB_COLD_SELECT __device__ __forceinline__
+#endif
 #ifndef OBB_STAGE_ATTR
 #define OBB_STAGE_ATTR __attribute__((noinline))
 #endif
@@ -253,7 +267,7 @@ struct PairQueue {
 // chunk = the first `cap` alive positions in [cur, se); their positions go to this workgroup's LDS list; returns the
 // chunk size and moves `cur` behind the last member.  Members keep their alive bit: nothing reads positions below
 // the cursor again.
-__device__ __forceinline__ int nms_select(const NmsArgs& a, int se, int& cur, int cap, uint32_t* cidx, int* s_i) {
+OBB_COLD_SELECT int nms_select(const NmsArgs& a, int se, int& cur, int cap, uint32_t* cidx, int* s_i) {
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int w_first = cur >> 6, w_last = (se - 1) >> 6;
   int off = 0;
@@ -556,7 +570,7 @@ __device__ __forceinline__ void nms_pairs(const NmsArgs& a, int tm, int cn, cons
 // for the first rounds, until what is left of it fits.
 // LDS (aliasing the wave scratch): state[capmax] | blocked[capmax] | edges[...]
 // returns the number of kept boxes of the chunk (also published in nrows[g])
-__device__ __forceinline__ int nms_resolve(const NmsArgs& a, int g, int sb, int tm, int cn, int kept_before, const uint32_t* cidx, uint8_t* smem,
+OBB_COLD_RESOLVE int nms_resolve(const NmsArgs& a, int g, int sb, int tm, int cn, int kept_before, const uint32_t* cidx, uint8_t* smem,
                            size_t smem_bytes, int* s_i) {
   const int tid = threadIdx.x;
   uint8_t* state = smem;              // 0 undecided, 1 kept, 2 dead
@@ -1259,7 +1273,7 @@ constexpr int kGridMinRows = 512;
 // (guideline 16).  The slot counters are back to zero when the scatter is done.
 // Returns 0: built; 1: barrier abort; 2: not worth using (no usable extent, or more than 1/16 of the boxes are brute).
 template <class G>
-__device__ __forceinline__ int grid_build(const NmsArgs& a, const GridPlan& gp, int c0, int wg, int T, TeamBar& bar, int* s_flag, int* s_i,
+OBB_COLD_GRID int grid_build(const NmsArgs& a, const GridPlan& gp, int c0, int wg, int T, TeamBar& bar, int* s_flag, int* s_i,
                                           uint32_t& level_mask, int& n_brute) {
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int M = (int)a.gmask + 1;
@@ -1366,7 +1380,7 @@ struct SlabLds {
 //   4. STABLE scatter of records / original indices / original positions / alive bits: the order inside a slab is the
 //      score order of the list                                                                      -> team barrier
 template <class G>
-__device__ __forceinline__ int slab_setup(const NmsArgs& a, float bin_x0, float inv, unsigned char* smem, TeamBar& gbar, int* s_flag, SlabLds& SL) {
+OBB_COLD_SLAB int slab_setup(const NmsArgs& a, float bin_x0, float inv, unsigned char* smem, TeamBar& gbar, int* s_flag, SlabLds& SL) {
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int NB = gridDim.x, wg = blockIdx.x;
   uint32_t* starts = reinterpret_cast<uint32_t*>(smem);       // [kSlabWords] bins where a run starts
@@ -1553,7 +1567,7 @@ __device__ __forceinline__ int slab_setup(const NmsArgs& a, float bin_x0, float 
 // After every team has finished its slab (and one more barrier of the whole grid): the kept boxes are the set bits of a
 // bitmap over the ORIGINAL sorted positions; position order is score order, so the output is an ordered compaction of
 // that bitmap.  Every workgroup scans all words for the ranks (n / 64 words: 1563 at N = 100k) and emits its share.
-__device__ __forceinline__ void slab_merge(const u64* kept_bits, int n, const uint32_t* order, int64_t* keep_out, int* keep_cnt, int* s_i) {
+OBB_COLD_SLAB void slab_merge(const u64* kept_bits, int n, const uint32_t* order, int64_t* keep_out, int* keep_cnt, int* s_i) {
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int NB = gridDim.x, wg = blockIdx.x;
   const int W = (n + 63) >> 6;

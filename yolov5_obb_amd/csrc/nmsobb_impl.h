@@ -9,7 +9,7 @@
 //                 multi-label expansion by ballot, CSL decode = wave arg-max over the 180 angle bins (first maximum),
 //                 theta = (idx-90)/180*3.141592, class filter -- and appended to the image's candidate region together
 //                 with a 64-bit sort key (descending conf, then ascending anchor*nc+class: a deterministic tie rule).
-//   segmented radix sort (rocPRIM) per image, top max_nms (30000) kept           (:845-846)
+//   sort per image (in LDS, k_sort_prep_lds; larger images: segsort.h / psrs_sort.h), top max_nms (30000) kept   (:845-846)
 //   k_prep_cand   class offset xy += cls*max_wh (:849-851), rotated-box records, too-small filter of obb_nms
 //   LC-NMS        (nms_core.h) with max_keep = max_det                           (:853-855)
 //   k_gather_out  rows [x y l s theta conf cls] of the kept candidates, [bs][max_det][7] + counts
@@ -459,112 +459,9 @@ __global__ void k_pad_keys(unsigned long long* __restrict__ keys, uint32_t* __re
   if (i < cap && i >= (long long)sort_end[0]) { keys[i] = ~0ull; vals[i] = 0u; }
 }
 
-// Sort of npad (a power of two, 64 .. 1024*E) (key, value) pairs that sit in LDS, ascending, by 1024 threads holding E
-// consecutive elements each in registers.
-//   1. every wave sorts its run of 64*E elements with a bitonic network that never leaves the wave: compare-exchange
-//      distances below E stay inside a thread, the others are lane shuffles;
-//   2. the runs are merged pairwise, log2(npad / (64*E)) levels: every element finds its rank in the sibling run with a
-//      binary search in LDS (strict on one side, non-strict on the other: equal keys -- the padding -- keep distinct
-//      ranks) and is written to its place; in place, two workgroup barriers per level.
-// (The first version ran the whole bitonic network, 10 of its 66 stages at 2048 elements through LDS with a barrier each:
-// 21.7 us on the configs[1] batch, 19.3 us now.  Replacing the lane shuffles of step 1 by DPP modifiers and the gfx950
-// permlane swaps -- no LDS crossbar at all -- was measured SLOWER, 22.6 us: the phase is bound by VALU issue with 16 waves
-// per CU, not by ds_bpermute.)
-template <int E>
-__device__ __forceinline__ void sort_lds_regs(unsigned long long* s_keys, uint32_t* s_vals, int npad, int tid) {
-  constexpr int R = 64 * E;                        // run length of a wave
-  const bool active = tid * E < npad;              // wave-uniform: npad is a multiple of 64
-  unsigned long long k[E];
-  uint32_t v[E];
-#pragma unroll
-  for (int e = 0; e < E; e++) { k[e] = active ? s_keys[tid * E + e] : ~0ull; v[e] = active ? s_vals[tid * E + e] : 0u; }
-  const int kk_top = npad < R ? npad : R;
-  if (active) {
-    for (int kk = 2; kk <= kk_top; kk <<= 1) {
-      const bool last = kk == R;                   // the run's final phase: every run ascending
-      int j = kk >> 1;
-      for (; j >= E; j >>= 1) {                    // partner element i ^ j lives in lane ^ (j / E), same slot e
-        const int lx = j / E;
-#pragma unroll
-        for (int e = 0; e < E; e++) {
-          const int i = tid * E + e;
-          const unsigned long long ok = __shfl_xor(k[e], lx);
-          const uint32_t ov = __shfl_xor(v[e], lx);
-          const bool take_min = ((i & j) == 0) == (last || (i & kk) == 0);
-          if (take_min ? (ok < k[e]) : (ok > k[e])) { k[e] = ok; v[e] = ov; }
-        }
-      }
-#pragma unroll
-      for (int jj = E >> 1; jj >= 1; jj >>= 1) {   // distances inside the thread (compile-time slots)
-        if (jj <= (kk >> 1)) {
-#pragma unroll
-          for (int e = 0; e < E; e++) {
-            if ((e & jj) == 0) {
-              const int e2 = e | jj;
-              const bool up = last || (((tid * E + e) & kk) == 0);
-              if ((k[e] > k[e2]) == up) {
-                const unsigned long long tk = k[e]; k[e] = k[e2]; k[e2] = tk;
-                const uint32_t tv = v[e]; v[e] = v[e2]; v[e2] = tv;
-              }
-            }
-          }
-        }
-      }
-    }
-  }
-  __syncthreads();
-  if (active) {
-#pragma unroll
-    for (int e = 0; e < E; e++) { s_keys[tid * E + e] = k[e]; s_vals[tid * E + e] = v[e]; }
-  }
-  __syncthreads();
-  for (int len = R; len < npad; len <<= 1) {       // (workgroup-uniform)
-    int dst[E];
-    if (active) {
-      int lo[E], hi[E];
-#pragma unroll
-      for (int e = 0; e < E; e++) {
-        const int idx = tid * E + e;
-        const int sib = ((idx / len) ^ 1) * len;   // first element of the sibling run
-        lo[e] = sib; hi[e] = sib + len;
-      }
-      const bool right = ((tid * E) / len) & 1;    // (all E elements of a thread sit in the same run: E divides len)
-      for (int step = len; step > 0; step >>= 1) { // len is a power of two: log2(len) + 1 probes close every interval
-#pragma unroll
-        for (int e = 0; e < E; e++) {
-          if (lo[e] < hi[e]) {
-            const int mid = (lo[e] + hi[e]) >> 1;
-            const unsigned long long km = s_keys[mid];
-            const bool below = right ? (km <= k[e]) : (km < k[e]);     // sibling entries that precede mine
-            if (below) lo[e] = mid + 1; else hi[e] = mid;
-          }
-        }
-      }
-#pragma unroll
-      for (int e = 0; e < E; e++) {
-        const int idx = tid * E + e;
-        const int run = idx / len, pos = idx - run * len;
-        const int sib = (run ^ 1) * len;
-        dst[e] = (run >> 1) * 2 * len + pos + (lo[e] - sib);
-      }
-    }
-    __syncthreads();                               // every search has read the old arrangement
-    if (active) {
-#pragma unroll
-      for (int e = 0; e < E; e++) { s_keys[dst[e]] = k[e]; s_vals[dst[e]] = v[e]; }
-    }
-    __syncthreads();
-    if (active && (len << 1) < npad) {
-#pragma unroll
-      for (int e = 0; e < E; e++) { k[e] = s_keys[tid * E + e]; v[e] = s_vals[tid * E + e]; }
-    }
-  }
-}
-
 // Small and medium images (at most kSortLdsMax candidates each, the regime of the reference's default thresholds): ONE
 // workgroup per image does everything between the decode kernel and the NMS kernel -- segment bookkeeping
-// (k_cand_segments), class keys (k_rekey), the sort (a bitonic network on (key, slot) pairs in LDS instead of rocPRIM's
-// one-small-workgroup-per-segment radix sort), the class segment table (k_class_bounds), the NMS records and the alive
+// (k_cand_segments), class keys (k_rekey), the sort (a bitonic network on (key, slot) pairs in LDS), the class segment table (k_class_bounds), the NMS records and the alive
 // bitmap including its zero words (k_prep_cand + memset): six launches become one.  An image with more candidates than
 // the network takes is left empty; the caller sees its count in status[1] and calls again with that hint.
 constexpr int kSortLdsMax = OBB_NMS_SORT_LDS_MAX;
@@ -702,7 +599,6 @@ __global__ __launch_bounds__(1024) void k_sort_prep_lds(const float4* __restrict
 // order; the global rank of an entry = its index in its own list + the number of entries of every other list that
 // precede it -- binary searches on merge keys (score, anchor, class) staged in LDS.
 constexpr int kMergeLds = 4096;
-constexpr int64_t kSortLargeFrom = OBB_NMS_SORT_LDS_HINT;   // expected candidates per image above which the multi-workgroup sort is used: whenever the in-LDS path does not apply (16 images x 2-9k candidates: 0.149 ms against 0.418 for rocprim's one-workgroup-per-segment sort; it was 12288 while the sort had a scan launch per pass)
 __global__ __launch_bounds__(256) void k_gather_out(const float4* __restrict__ cand, const uint32_t* __restrict__ vals_sorted,
                                                     const unsigned long long* __restrict__ keys_sorted, const int64_t* __restrict__ keep,
                                                     const int* __restrict__ seg_begin, const int* __restrict__ keep_cnt,
@@ -814,19 +710,11 @@ struct ObbCarve {
   float4* cand; unsigned long long *keys_a, *keys_b; uint32_t *vals_a, *vals_b; int* cnt; int *sort_begin, *sort_end;
   int *img_end, *mode, *tiny, *grp_begin, *grp_end, *ticket;
   uint32_t *srs_hist, *digit_base;
-  void* sort_tmp; size_t sort_tmp_bytes;
   int64_t* keep;
   Carve nms;          // rec/dead/segment state reuse the NMS carve (keys/vals/sort_tmp of it unused)
   void* nms_base;
   size_t total;
 };
-
-static hipError_t seg_sort_tmp_query(size_t n, int nseg, size_t* bytes) {
-  *bytes = 0;
-  return rocprim::segmented_radix_sort_pairs(nullptr, *bytes, (unsigned long long*)nullptr, (unsigned long long*)nullptr,
-                                             (uint32_t*)nullptr, (uint32_t*)nullptr, (unsigned int)n, (unsigned int)nseg,
-                                             (int*)nullptr, (int*)nullptr, 0, 64, (hipStream_t)0, false);
-}
 
 static inline int64_t round_cap(int64_t cap_img) { return (cap_img + 63) / 64 * 64; }   // image regions start on alive-bitmap words
 
@@ -844,8 +732,6 @@ static int obb_carve(void* base, int64_t bs, int64_t cap_img, int64_t ncs, ObbCa
   cv->ticket = (int*)take(64);
   cv->digit_base = (uint32_t*)take((size_t)bs * 256 * 4);
   cv->srs_hist = (uint32_t*)take((size_t)bs * ((size_t)(cap_img + kSrsTile - 1) / kSrsTile) * 256 * 4);
-  if (seg_sort_tmp_query(n, (int)bs, &cv->sort_tmp_bytes) != hipSuccess) return OBB_ERR_INTERNAL;
-  cv->sort_tmp = take(cv->sort_tmp_bytes ? cv->sort_tmp_bytes : 16);
   cv->keep = (int64_t*)take(n * 8);
   // NMS state sized for bs * cap_img positions
   cv->nms_base = base ? (char*)base + off : nullptr;
@@ -940,47 +826,30 @@ static int run_nms_obb(const void* pred, const void* objcol, int dtype, int64_t 
       dim3 gr((unsigned)((cap_img + 255) / 256), (unsigned)bs);
       k_rekey<<<gr, 256, 0, st>>>(cv.cand, cv.keys_a, cv.sort_begin, cv.sort_end, cv.mode, A, nc);
     }
-    static long long large_from = -1;                              // OBB_SORT_LARGE_FROM: measurements
-    if (large_from < 0) { const char* e = getenv("OBB_SORT_LARGE_FROM"); large_from = e ? atoll(e) : kSortLargeFrom; if (large_from < 0) large_from = kSortLargeFrom; }
-    if (expected_cand > large_from) {
-      // large images (val.py's default conf_thres = 0.001): every image spread over many workgroups (segsort.h)
+    {
+      // Several images, or one: every image spread over many workgroups (segsort.h's LSD radix sort, two launches per key byte) --
+      // or, ONE large image (the TTA tensor) of up to kPsMaxN slots: the three-launch sort of psrs_sort.h over the image's
+      // candidates (keys are unique: the tie word; the count lives on the device).  This branch is what an un-hinted first call of a
+      // shape takes as well (the fused in-LDS path needs the previous call's largest candidate count).
       int tb = 0;
       while ((1ll << tb) < A * nc + n_extra + 1) tb++;                 // significant bits of the tie word
       unsigned mask = 0xF0u;                                            // single-list key: score in bytes 4..7
       for (int d = 0; d < 4; d++) if (tb > d * 8) mask |= 1u << d;
       if (class_ok) mask = 0xFFu;                                       // + class-mode key: anchor 0..2, score 3..6, class 7
-      // ONE large image (the TTA tensor): the library's device-wide sort over the image's whole capacity, the unused slots padded
-      // with the largest key, instead of eight passes of the segmented sort (OBB_SINGLE_IMAGE_SORT: 0 = segmented sort, 1 =
-      // rocprim::radix_sort_pairs, 2 = rocprim::merge_sort; measurements)
-      static int one_sort = -1;
-      if (one_sort < 0) { const char* e = getenv("OBB_SINGLE_IMAGE_SORT"); one_sort = e ? atoi(e) : 1; if (one_sort < 0 || one_sort > 2) one_sort = 1; }
-      bool done = false;
-      if (bs == 1 && one_sort && !group_ok) {
-        size_t need = 0;
-        hipError_t qe = one_sort == 2
-            ? rocprim::merge_sort(nullptr, need, cv.keys_a, cv.keys_b, cv.vals_a, cv.vals_b, (size_t)cap_img, rocprim::less<unsigned long long>(), st, false)
-            : rocprim::radix_sort_pairs(nullptr, need, cv.keys_a, cv.keys_b, cv.vals_a, cv.vals_b, (size_t)cap_img, 0, 64, st, false);
-        if (qe == hipSuccess && need <= nv.sort_tmp_bytes) {
-          k_pad_keys<<<(unsigned)((cap_img + 255) / 256), 256, 0, st>>>(cv.keys_a, cv.vals_a, cv.sort_end, cap_img);
-          size_t tmp = nv.sort_tmp_bytes;
-          hipError_t se = one_sort == 2
-              ? rocprim::merge_sort(nv.sort_tmp, tmp, cv.keys_a, cv.keys_b, cv.vals_a, cv.vals_b, (size_t)cap_img, rocprim::less<unsigned long long>(), st, false)
-              : rocprim::radix_sort_pairs(nv.sort_tmp, tmp, cv.keys_a, cv.keys_b, cv.vals_a, cv.vals_b, (size_t)cap_img, 0, 64, st, false);
-          if (se != hipSuccess) return OBB_ERR_LAUNCH;
-          done = true;
-        }
-      }
-      if (!done) {
+      if (bs == 1 && !group_ok && cap_img <= kPsMaxN && nv.sort_tmp_bytes >= ps_scratch_bytes()) {
+        PsBuf b{};
+        b.run_k = cv.keys_a; b.run_v = cv.vals_a; b.out_k = cv.keys_b; b.out_v = cv.vals_b;      // (the runs are sorted in place)
+        b.n = (int)cap_img; b.n_dev = cv.sort_end; b.err = nullptr;
+        ps_carve_scratch(nv.sort_tmp, &b);
+        const int runs = (int)((cap_img + kPsRun - 1) / kPsRun);
+        k_ps_local_pairs<<<(unsigned)runs, kPsRun, 0, st>>>(b, cv.keys_a, cv.vals_a);
+        rc = ps_finish(b, runs, st);
+        if (rc) return rc;
+      } else {
         rc = seg_radix_sort_large(cv.keys_a, cv.keys_b, cv.vals_a, cv.vals_b, cv.sort_begin, cv.sort_end, (int)bs, cap_img, bs * cap_img,
                                   mask, cv.srs_hist, st);
         if (rc) return rc;
       }
-    } else {
-      size_t tmp = cv.sort_tmp_bytes;
-      if (rocprim::segmented_radix_sort_pairs(cv.sort_tmp, tmp, cv.keys_a, cv.keys_b, cv.vals_a, cv.vals_b,
-                                              (unsigned int)(bs * cap_img), (unsigned int)bs, cv.sort_begin, cv.sort_end, 0, 64,
-                                              st, false) != hipSuccess)
-        return OBB_ERR_LAUNCH;
     }
     if (group_ok) {
       // images with more than max_nms candidates: group the top max_nms (now in score order) by class, one stable pass

@@ -1,8 +1,9 @@
 // Segmented LSD radix sort of (u64 key, u32 value) pairs for LARGE segments -- gfx950 (included by nms.hip, namespace obb).
 //
-// Why: rocprim::segmented_radix_sort_pairs gives every segment to ONE workgroup.  That is the right shape for the
-// speed-test regime (16 images x ~2k candidates: 0.04 ms) and the wrong one for val.py's default conf_thres = 0.001,
-// where every image brings ~65k candidates: 16 workgroups grind through 1M pairs in 2.6 ms.  Here every segment is
+// Why: a sort that gives every segment to ONE workgroup (the library's segmented sort, used in round 1; the in-LDS path of
+// the fused driver) is the right shape for the speed-test regime (16 images x ~2k candidates: 0.04 ms) and the wrong one for
+// val.py's default conf_thres = 0.001, where every image brings ~65k candidates: 16 workgroups ground through 1M pairs in
+// 2.6 ms.  Here every segment is
 // spread over as many workgroups as it has 2048-element tiles (grid = tiles x segments), one 8-bit digit per pass,
 // two small kernels per pass: tile histograms -> stable scatter with the offset scan built in (wave multi-split: lanes with the
 // same digit find each other with 8 ballots, so the order inside a digit is the input order).  Passes over digits that
