@@ -4,6 +4,8 @@ Bar: kept-index sequences bit-exact (same indices, same order); IoU values bit-e
 for the rotated/quad kernels (same IEEE fp32 operations as the oracle), except the
 devkit overlaps where fp32 cosf/sinf differ between ocml and glibc (<= 1e-5 abs).
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -286,6 +288,26 @@ def test_nms_poly_skip_rule(dev, oracle_lib, thr):
     assert np.array_equal(ref, got)
 
 
+def test_nms_poly_strict_equals_skip_100k(dev, tmp_path):
+    """The skip rule of the quad NMS (csrc/piou_device.h) against the same library with the rule switched off
+    (OBB_NMS_POLY_STRICT=1: every pair is clipped, as the reference does) at N = 100,000 quads in three layouts -- a 1024 px
+    tile, the same shifted by 5,000 px, and 18 class offsets of 4096 px (utils/general.py:849-851) -- at two thresholds: the kept
+    lists must be identical.  (The switch is read once per process: two child processes.)"""
+    import subprocess
+    import sys
+    helper = os.path.join(os.path.dirname(os.path.abspath(__file__)), "helpers", "poly_strict_vs_skip.py")
+    res = {}
+    for strict in ("0", "1"):
+        out = str(tmp_path / f"kept_{strict}.npz")
+        env = dict(os.environ, OBB_NMS_POLY_STRICT=strict)
+        subprocess.run([sys.executable, helper, out], check=True, env=env, timeout=900)
+        res[strict] = np.load(out)
+    assert sorted(res["0"].files) == sorted(res["1"].files) and len(res["0"].files) == 6
+    for k in res["0"].files:
+        assert np.array_equal(res["0"][k], res["1"][k]), k
+        assert len(res["0"][k]) > 300
+
+
 def test_ops_rbox_overlaps_device_tensors(dev, oracle_lib):
     """ops.rbox_overlaps -> obb_rbox_overlaps_f32 (the device-pointer form of the devkit's overlaps_kernel,
     poly_overlaps_kernel.cu:280-353): same matrix as the host-pointer `_overlaps`, bit for bit, and as the oracle up to the
@@ -500,3 +522,52 @@ def test_independent_slabs_same_result(dev, oracle_lib, variant):
         got = nms_rotated_ext._run_rotated(d, s, thr, flags=flags).cpu().numpy()
         assert len(got) == len(ref), (variant, rep, len(got), len(ref))
         assert np.array_equal(ref, got), (variant, rep)
+
+
+def _desc_order(scores):
+    """The documented order of the sort in front of the NMS: descending score, NaN first (torch's order), -0 == +0, ties by
+    ascending original index -- restated with numpy on the score bits."""
+    s = np.asarray(scores, dtype=np.float32)
+    u = s.view(np.uint32).copy()
+    u[s == 0] = 0
+    k = np.where(u & 0x80000000, ~u, u | np.uint32(0x80000000)).astype(np.uint32)
+    k[np.isnan(s)] = 0xFFFFFFFF
+    return np.lexsort((np.arange(len(s)), ~k))
+
+
+def _lattice(n):
+    """n small boxes that cannot touch each other: the NMS keeps every one, its output IS the sort order."""
+    i = torch.arange(n)
+    return torch.stack([(i % 512).float() * 8, (i // 512).float() * 8, torch.full((n,), 2.0), torch.full((n,), 2.0), torch.zeros(n)], 1)
+
+
+@pytest.mark.parametrize("case", ["random", "equal", "ascending", "descending", "interleaved", "ties", "specials"])
+@pytest.mark.parametrize("n", [1, 2, 511, 512, 513, 1000, 70001, 131072, 131073])
+def test_own_sort_order(dev, n, case):
+    """The three-launch sort (csrc/psrs_sort.h; n > 131072: the radix sort of csrc/segsort.h) through the NMS entry point, on
+    boxes that do not interact.  `interleaved`: every run of 512 consecutive elements holds 31 top scores -- the input that
+    drives one bucket of the regular-sampling partition to its bound (the rank-counting merge instead of the in-LDS network)."""
+    if n > 1000 and case in ("equal", "ascending", "ties") and n != 131072:
+        pytest.skip("covered at the other sizes")
+    g = torch.Generator().manual_seed(n)
+    s = torch.rand(n, generator=g)
+    if case == "equal":
+        s = torch.full((n,), 0.5)
+    elif case == "ascending":
+        s = torch.sort(s)[0]
+    elif case == "descending":
+        s = torch.sort(s, descending=True)[0]
+    elif case == "interleaved":
+        s = s * 0.5
+        top = (torch.arange(n) % 512) < 31
+        s[top] = 0.9 + 0.1 * torch.rand(int(top.sum()), generator=g)
+    elif case == "ties":
+        s = (s * 50).round() / 50
+    elif case == "specials":
+        s = s - 0.5
+        idx = torch.randperm(n, generator=g)[: max(1, n // 7)]
+        vals = torch.tensor([float("nan"), 0.0, -0.0, float("inf"), float("-inf"), 1e-45, -1e-45])
+        s[idx] = vals[torch.arange(len(idx)) % len(vals)]
+    dets = _lattice(n)
+    got = _gpu_keep(dets, s, 0.5, dev)
+    assert np.array_equal(got, _desc_order(s.numpy()))

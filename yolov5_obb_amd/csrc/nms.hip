@@ -390,6 +390,7 @@ struct Carve {
   u64* prof;                           // in-kernel phase timing (OBB_NMS_PHASE_PROF=1)
   int4* plan;                          // per-workgroup team plan (k_plan_teams)
   uint32_t *rows, *edges;
+  uint32_t* rows_el; int* nrows_el; long long rows_el_stride;   // early / late rows of overlapped steps (single list with the index: nms_core.h)
   long long ecap;
   GridDev grid;                        // spatial index (rotated boxes, single list); grid.meta == NULL: not carved
   size_t grid_zero_bytes;              // GridMeta + slot counters: one contiguous block, zeroed before every build
@@ -440,7 +441,7 @@ static int carve(void* base, int64_t n, int64_t nseg, int recq, int C, Carve* cv
   cv->rec = (float4*)take(nn * recq * 16);
   cv->alive_bytes = (nn / 64 + 10) * 8;      // + guard words (zeroed by the prep kernels)
   cv->alive = (u64*)take(cv->alive_bytes);
-  cv->bar_bytes = ((size_t)kMaxTeams * 128 + 64 + 2 * (size_t)kMaxTeams) * 4;
+  cv->bar_bytes = ((size_t)kMaxTeams * 128 + 64 + 2 * (size_t)kMaxTeams + (size_t)kBarGroups * 64) * 4;
   cv->bar = (int*)take(cv->bar_bytes);
   cv->abort_flag = cv->bar + (size_t)kMaxTeams * 128;
   cv->nrows = cv->abort_flag + 64;
@@ -455,9 +456,13 @@ static int carve(void* base, int64_t n, int64_t nseg, int recq, int C, Carve* cv
   cv->ecap = (long long)C * (C - 1) / 2; if (cv->ecap < 1) cv->ecap = 1;
   cv->edges = (uint32_t*)take(nteams * (size_t)cv->ecap * 4);
   cv->grid = GridDev{}; cv->grid_zero_bytes = 0;
+  cv->rows_el = nullptr; cv->nrows_el = nullptr; cv->rows_el_stride = 0;
   if (recq == RotGeom::RECQ && nseg == 1 && n >= kGridMinN) {
     const uint32_t M = grid_slots(n);
     cv->grid.mask = M - 1;
+    cv->rows_el_stride = 2LL * C;                              // the one list's team, or one team per slab
+    cv->rows_el = (uint32_t*)take((size_t)(kMaxSlabs + 1) * (size_t)cv->rows_el_stride * 4);
+    cv->nrows_el = (int*)take((size_t)(kMaxSlabs + 1) * 2 * 4);
     const size_t slab_tot_bytes = (size_t)(1 + kMaxTeams / 16) * kMaxSlabs * 4;   // slab totals + group totals (slab_setup)
     const size_t slab_zero = align_up((size_t)kSlabCopies * kSlabWords * 4 + 64) + align_up(slab_tot_bytes);
     cv->grid_zero_bytes = align_up(sizeof(GridMeta)) + slab_zero + ((size_t)M + 4) * 4;
@@ -549,6 +554,7 @@ constexpr int kNmsPlanned = 2;      // the team plan for this launch has been wr
 static int nms_steps(int kind, NmsArgs& a, const Carve& cv, int64_t nseg, int64_t n_slots, hipStream_t st, int pre = 0) {
   if (!(pre & kNmsBarZeroed) && hipMemsetAsync(cv.bar, 0, cv.bar_bytes, st) != hipSuccess) return OBB_ERR_LAUNCH;
   a.bar = cv.bar; a.abort_flag = cv.abort_flag; a.nseg = (int)nseg;
+  a.bar_sub = cv.nedges + kMaxTeams;                 // group counters of the grid-wide barrier, behind the per-team words
   a.cap_first = cap_first();
   { static int grow = -1; if (grow < 0) { const char* e = getenv("OBB_NMS_GROW"); grow = e ? atoi(e) : 2; if (grow < 2 || grow > 8) grow = 2; } a.grow_sparse = grow; }
   static int phase_prof = -1;
@@ -675,6 +681,7 @@ static int run_nms(int kind, const float* boxes, int stride, const float* scores
   a.rec = cv.rec; a.order = cv.vals_b; a.alive = cv.alive; a.seg_begin = cv.seg_begin; a.seg_end = cv.seg_end;
   a.keep_cnt = cv.keep_cnt; a.keep_out = keep_out;
   a.rows = cv.rows; a.nrows = cv.nrows; a.edges = cv.edges; a.nedges = cv.nedges;
+  a.rows_el = cv.rows_el; a.nrows_el = cv.nrows_el; a.rows_el_stride = cv.rows_el_stride;
   a.ecap = cv.ecap; a.n = (int)n; a.capmax = C;
   a.max_keep = (int)(max_keep > 0x7fffffffLL ? 0x7fffffffLL : (max_keep < 0 ? 0 : max_keep));
   a.window = nms_window(a.max_keep);

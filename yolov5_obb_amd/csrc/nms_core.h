@@ -49,9 +49,14 @@ struct NmsArgs {
   int64_t* keep_out;         // segment g writes at keep_out[seg_begin[g] + k]
   uint32_t* rows;            // [n] kept rows (sorted positions) of segment g at rows[seg_begin[g] + k], k = kept index
   int* nrows;                // [nteams] rows kept in the team's current chunk
+  uint32_t* rows_el;         // [nteams][2][capmax] overlapped steps (k_nms_persist, OVL): the chunk's EARLY rows (no conflict edge points at
+                             // them: certainly kept, known after the resolver's first pass) and its LATE rows (kept in a later round)
+  int* nrows_el;             // [nteams][2]
+  long long rows_el_stride;  // uint32 entries per team (2 * the launch's capmax)
   uint32_t* edges;           // [nteams][ecap] (i << 16 | j), chunk-local indices, i < j
   int* nedges;               // [nteams]   (a team works on one segment at a time: scratch is per team)
   int* bar;                  // [nteams][2][64] arrive / go counters, one 256-byte line each
+  int* bar_sub;              // [kBarGroups][64] group counters of the whole grid's two-level barrier (zero before the launch)
   int* abort_flag;           // [1] set when a spin gave up
   u64* prof;                 // optional [56]: wall-clock ticks (10 ns) per phase (development aid)
   const int4* plan;          // optional [gridDim.x] {segment, team, index in team, team size} per workgroup (k_plan_teams):
@@ -128,13 +133,20 @@ __device__ __forceinline__ void rows_reject2(const float4& myrow, int r, const C
   G::cheap_reject2(ax, ay, az, aw, c, r0, r1);
 }
 
+constexpr int kBarGroups = 64;             // groups of 16 workgroups: grids of up to 1024
 constexpr int kNmsThreads = 512;
 constexpr int kNmsWaves = kNmsThreads / 64;
 constexpr unsigned kSpinLimit = 1u << 22;
 
-// Team barriers on one monotonic arrive counter (every barrier of either kind adds T arrivals) and one go word.
+// Team barriers on monotonic counters (every barrier of either kind adds one arrival per workgroup) and one go word on a line
+// of its own, written by whoever completes the barrier: the waiting workgroups poll THAT word, the arrivals do not share a
+// channel with 255 pollers.  Wide teams (the whole grid of a single-list call) arrive in two levels: same-address device
+// atomics retire at ~11 ns apiece (MI355X_MICROARCH.md), 256 arrivals on one counter are 2.8 us of every barrier; with groups
+// of 16 on counters 256 bytes apart and one arrival per group on the top counter it is 16 + 16.
 struct TeamBar {
   int* arrive; int* go; int T; int epoch; int* abort_flag;
+  int* sub;      // group counters (one 256-byte line each) or NULL: one level
+  int wg;        // this workgroup's index in the team
 };
 // spin until *word >= target; false when the spin gave up or another workgroup raised the abort flag
 __device__ __forceinline__ bool spin_until(int* word, int target, int* abort_flag) {
@@ -145,13 +157,26 @@ __device__ __forceinline__ bool spin_until(int* word, int target, int* abort_fla
   }
   return true;
 }
+// one arrival (thread 0 of the workgroup); true in the workgroup whose arrival completes the barrier
+__device__ __forceinline__ bool bar_arrive(const TeamBar& b) {
+  if (b.sub == nullptr) {
+    const int t = __hip_atomic_fetch_add(b.arrive, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return t == b.T * (b.epoch + 1) - 1;
+  }
+  const int g = b.wg >> 4, G = (b.T + 15) >> 4;
+  const int sz = (b.T - (g << 4)) < 16 ? (b.T - (g << 4)) : 16;
+  const int t = __hip_atomic_fetch_add(b.sub + g * 64, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (t != sz * (b.epoch + 1) - 1) return false;
+  const int u = __hip_atomic_fetch_add(b.arrive, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return u == G * (b.epoch + 1) - 1;
+}
 // plain barrier: returns false on abort
 __device__ __forceinline__ bool team_barrier(TeamBar& b, int* s_flag) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // every wave drains its write-through stores / atomics
   __syncthreads();
   if (threadIdx.x == 0) {
-    __hip_atomic_fetch_add(b.arrive, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    *s_flag = spin_until(b.arrive, b.T * (b.epoch + 1), b.abort_flag) ? 0 : 1;
+    if (bar_arrive(b)) { stg_agent(b.go, b.epoch + 1); *s_flag = 0; }
+    else *s_flag = spin_until(b.go, b.epoch + 1, b.abort_flag) ? 0 : 1;
   }
   __syncthreads();
   b.epoch++;
@@ -162,8 +187,7 @@ __device__ __forceinline__ bool serial_begin(TeamBar& b, int* s_flag) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (threadIdx.x == 0) {
-    const int t = __hip_atomic_fetch_add(b.arrive, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const int last = (t == b.T * (b.epoch + 1) - 1) ? 1 : 0;
+    const int last = bar_arrive(b) ? 1 : 0;
     // the last arriver reads what the others published in bulk: ONE agent acquire, then plain loads (guideline 16, R1)
     if (last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     *s_flag = last;
@@ -273,11 +297,17 @@ OBB_COLD_SELECT int nms_select(const NmsArgs& a, int se, int& cur, int cap, uint
   int off = 0;
   __syncthreads();
   if (tid == 0) s_i[8] = se;
-  for (int wbase = w_first; wbase <= w_last && off < cap; wbase += kNmsThreads) {
+  // the first four trips' words are requested together: a late step scans the whole bitmap (1563 words at N = 100k) and paid a
+  // coherent round trip to memory per trip (a dense early chunk ends after the first trip and wastes three loads)
+  u64 pre[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) { const int w = w_first + k * kNmsThreads + tid; pre[k] = (w <= w_last) ? ldg_agent(a.alive + w) : 0ull; }
+  int trip = 0;
+  for (int wbase = w_first; wbase <= w_last && off < cap; wbase += kNmsThreads, trip++) {
     const int w = wbase + tid;
     u64 m = 0ull;
     if (w <= w_last) {
-      m = ldg_agent(a.alive + w);
+      m = trip == 0 ? pre[0] : trip == 1 ? pre[1] : trip == 2 ? pre[2] : trip == 3 ? pre[3] : ldg_agent(a.alive + w);
       const long long lo = (long long)w * 64;
       if (lo < cur) m &= ~((1ull << (cur - lo)) - 1ull);              // positions below the cursor / of the previous segment
       if (lo + 64 > se) m &= (1ull << (se - lo)) - 1ull;
@@ -570,10 +600,13 @@ __device__ __forceinline__ void nms_pairs(const NmsArgs& a, int tm, int cn, cons
 // for the first rounds, until what is left of it fits.
 // LDS (aliasing the wave scratch): state[capmax] | blocked[capmax] | edges[...]
 // returns the number of kept boxes of the chunk (also published in nrows[g])
+// early_ev != 0 (overlapped step): as soon as the first pass over the edges is done, the boxes no edge points at -- kept whatever
+// the rounds decide -- are published as the team's EARLY rows (rows_el, count, then *ev_word = early_ev: the other workgroups start
+// their cross phase on them while the rounds run); the boxes kept in later rounds go to the LATE list.
 OBB_COLD_RESOLVE int nms_resolve(const NmsArgs& a, int g, int sb, int tm, int cn, int kept_before, const uint32_t* cidx, uint8_t* smem,
-                           size_t smem_bytes, int* s_i) {
+                           size_t smem_bytes, int* s_i, int early_ev = 0, int* ev_word = nullptr) {
   const int tid = threadIdx.x;
-  uint8_t* state = smem;              // 0 undecided, 1 kept, 2 dead
+  uint8_t* state = smem;              // 0 undecided, 1 kept, 2 dead, 3 kept in round 0 (an early row)
   uint8_t* blocked = smem + a.capmax;
   uint32_t* ledges = reinterpret_cast<uint32_t*>(smem + 2 * (size_t)a.capmax);
   const long long lcap = ((long long)smem_bytes - 2LL * a.capmax) / 4;
@@ -583,23 +616,23 @@ OBB_COLD_RESOLVE int nms_resolve(const NmsArgs& a, int g, int sb, int tm, int cn
   const uint32_t* edges = a.edges + (size_t)tm * a.ecap;   // plain loads: acquired in serial_begin
   // The list fits in LDS when every thread's share does (one contiguous block per thread, odd length: conflict-free banks).
   const int percap = (int)(((lcap / kNmsThreads) - 1) | 1);
-  int per = (int)((E + kNmsThreads - 1) / kNmsThreads) + 5;   // (+ the slack of dealing the list out four edges at a time)
+  int per = (int)((E + kNmsThreads - 1) / kNmsThreads) + 5;   // (+ the slack of dealing the list out four edges at a time: a thread holds at most 4 * ceil(E / 2048) <= E / 512 + 4 edges)
   per |= 1;
   bool lds_mode = per <= percap;
   if (!lds_mode) per = percap;
   int mycnt = 0;
   uint32_t* mine_e = ledges + (size_t)tid * per;
   if (lds_mode) {
-    // thread t takes the 16-byte groups t, t+512, ... (coalesced global reads, four groups = 16 edges in flight) into its
+    // thread t takes the 16-byte groups t, t+512, ... (coalesced global reads, eight groups = 32 edges in flight) into its
     // own LDS block; the list was written by every workgroup of the team and sits in L2 / memory: this is a latency chain
     const uint4* e4 = reinterpret_cast<const uint4*>(edges);      // (every team's list starts on a 16-byte boundary)
     const long long nvec = E >> 2;
-    for (long long v0 = tid; v0 < nvec; v0 += 4 * kNmsThreads) {
-      uint4 v[4];
+    for (long long v0 = tid; v0 < nvec; v0 += 8 * kNmsThreads) {
+      uint4 v[8];
 #pragma unroll
-      for (int u = 0; u < 4; u++) { const long long k = v0 + (long long)u * kNmsThreads; v[u] = k < nvec ? e4[k] : make_uint4(0u, 0u, 0u, 0u); }
+      for (int u = 0; u < 8; u++) { const long long k = v0 + (long long)u * kNmsThreads; v[u] = k < nvec ? e4[k] : make_uint4(0u, 0u, 0u, 0u); }
 #pragma unroll
-      for (int u = 0; u < 4; u++)
+      for (int u = 0; u < 8; u++)
         if (v0 + (long long)u * kNmsThreads < nvec) {
           mine_e[mycnt] = v[u].x; mine_e[mycnt + 1] = v[u].y; mine_e[mycnt + 2] = v[u].z; mine_e[mycnt + 3] = v[u].w;
           mycnt += 4;
@@ -621,7 +654,7 @@ OBB_COLD_RESOLVE int nms_resolve(const NmsArgs& a, int g, int sb, int tm, int cn
   // one edge (i < j) against the states read for it: true = both ends undecided, the edge stays and j waits for i
   auto decide = [&](uint32_t ed, uint8_t sj, uint8_t si) -> bool {
     if (sj != 0) return false;                       // target decided: the edge is done
-    if (si == 1) { state[ed & 0xffff] = 2; return false; }   // kept source kills the target
+    if (si & 1) { state[ed & 0xffff] = 2; return false; }    // kept source kills the target
     if (si == 2) return false;                       // dead source never matters again
     blocked[ed & 0xffff] = 1;
     return true;
@@ -679,13 +712,38 @@ OBB_COLD_RESOLVE int nms_resolve(const NmsArgs& a, int g, int sb, int tm, int cn
     }
     __syncthreads();
     bool rem = false;
+    const uint8_t kept_mark = (early_ev != 0 && round == 0) ? 3 : 1;
     for (int j = tid; j < cn; j += kNmsThreads) {
       if (state[j] == 0) {
         if (blocked[j]) { rem = true; blocked[j] = 0; }
-        else state[j] = 1;
+        else state[j] = kept_mark;
       }
     }
     const int any = __syncthreads_or(rem ? 1 : 0);     // barrier + "somebody is still undecided" in one
+    if (early_ev != 0 && round == 0) {
+      // the early rows (any order: the cross phases do not care), count, event -- all write-through, the event last
+      uint32_t* er = a.rows_el + (size_t)tm * a.rows_el_stride;
+      if (tid == 0) s_i[9] = 0;
+      __syncthreads();
+      for (int j0 = 0; j0 < cn; j0 += kNmsThreads) {
+        const int j = j0 + tid;
+        const bool f = j < cn && state[j] == 3;
+        const u64 fm = __ballot(f);
+        if (fm) {
+          int base = 0;
+          if ((tid & 63) == 0) base = atomicAdd(&s_i[9], __popcll(fm));
+          base = __shfl(base, 0);
+          if (f) stg_agent(er + base + __popcll(fm & lanemask_lt()), cidx[j]);
+        }
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 0) {
+        stg_agent(a.nrows_el + 2 * tm, s_i[9]);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        stg_agent(ev_word, early_ev);
+      }
+    }
     if (!any) { if (a.prof && tid == 0) atomicAdd(a.prof + 11, (u64)(round + 1)); break; }
     if (!lds_mode) {
       if (compact) lds_mode = true;                                        // the survivors are in LDS now
@@ -700,7 +758,7 @@ OBB_COLD_RESOLVE int nms_resolve(const NmsArgs& a, int g, int sb, int tm, int cn
   int mine = 0;
   for (int q = 0; q < per_n; q++) {
     const int j = tid * per_n + q;
-    if (j < cn && state[j] == 1) mine++;
+    if (j < cn && (state[j] & 1)) mine++;
   }
   int incl = mine;
 #pragma unroll
@@ -715,11 +773,15 @@ OBB_COLD_RESOLVE int nms_resolve(const NmsArgs& a, int g, int sb, int tm, int cn
   for (int k = 0; k < kNmsWaves; k++) { const int t = s_i[k]; if (k < (tid >> 6)) wpre += t; total += t; }
   int rank = wpre + incl - mine;
   uint32_t* rows = a.rows + (size_t)sb + kept_before;         // appended to the segment's kept-row list
+  uint32_t* lr = early_ev != 0 ? a.rows_el + (size_t)tm * a.rows_el_stride + a.rows_el_stride / 2 : nullptr;
+  if (early_ev != 0 && tid == 0) s_i[10] = 0;
+  __syncthreads();
   for (int q = 0; q < per_n; q++) {
     const int j = tid * per_n + q;
-    if (j < cn && state[j] == 1) {
+    if (j < cn && (state[j] & 1)) {
       const uint32_t pos = cidx[j];
       stg_agent(rows + rank, pos);
+      if (early_ev != 0 && state[j] == 1) stg_agent(lr + atomicAdd(&s_i[10], 1), pos);      // (a late row: few per chunk)
       const long long o = (long long)kept_before + rank;
       if (a.keep_out != nullptr) {
         if (a.max_keep <= 0 || o < a.max_keep) a.keep_out[(size_t)sb + o] = a.order ? (int64_t)a.order[pos] : (int64_t)pos;
@@ -733,10 +795,12 @@ OBB_COLD_RESOLVE int nms_resolve(const NmsArgs& a, int g, int sb, int tm, int cn
       rank++;
     }
   }
+  __syncthreads();
   if (tid == 0) {
     stg_agent(a.nrows + tm, total);
     stg_agent(a.nedges + tm, 0);
     stg_agent(a.keep_cnt + g, kept_before + total);   // write-through: resolvers of different steps sit on different XCDs
+    if (early_ev != 0) stg_agent(a.nrows_el + 2 * tm + 1, s_i[10]);
   }
   __syncthreads();
   plap(14);
@@ -1264,6 +1328,7 @@ __device__ __forceinline__ void nms_cross_grid(const NmsArgs& a, const GridPlan&
 }
 
 constexpr int kGridMinRows = 512;
+constexpr int kOvlMinTeam = 8;               // overlapped steps need a team in which one workgroup less does not matter
 
 // Counting sort of the still-alive positions [c0, n) by table slot, by the whole team (= the whole grid: one segment):
 // classify + count -> barrier -> distributed scan (every workgroup a slice of the table, then the prefix of the workgroup
@@ -1609,6 +1674,7 @@ OBB_COLD_SLAB void slab_merge(const u64* kept_bits, int n, const uint32_t* order
 template <class G, bool GRID>
 __global__ __launch_bounds__(kNmsThreads) __attribute__((amdgpu_waves_per_eu(1, 2))) void k_nms_persist(NmsArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr bool OVL = GRID;               // overlapped steps: the single-list instantiation (wide teams); see the step loop
   __shared__ int s_i[16];
   __shared__ int s_flag;
   __shared__ int s_bb[kNmsWaves][4];
@@ -1637,7 +1703,7 @@ __global__ __launch_bounds__(kNmsThreads) __attribute__((amdgpu_waves_per_eu(1, 
     return grid_plan(bb);
   };
   // ---- independent slabs (grid.h): a single list that falls apart into groups that cannot overlap runs as that many segments
-  TeamBar gbar{a.bar, a.bar + 64, NB, 0, a.abort_flag};      // the whole grid (the barrier line of team 0)
+  TeamBar gbar{a.bar, a.bar + 64, NB, 0, a.abort_flag, NB > 32 ? a.bar_sub : nullptr, (int)blockIdx.x};      // the whole grid (the barrier line of team 0)
   bool slab_mode = false;
   const uint32_t* order0 = a.order;
   int64_t* keep_out0 = a.keep_out;
@@ -1682,7 +1748,9 @@ __global__ __launch_bounds__(kNmsThreads) __attribute__((amdgpu_waves_per_eu(1, 
   WaveLds<G>& L = reinterpret_cast<WaveLds<G>*>(smem)[wv];
   uint32_t* cidx = reinterpret_cast<uint32_t*>(smem + sizeof(WaveLds<G>) * kNmsWaves);
   const int tw = wg * kNmsWaves + wv, ntw = T * kNmsWaves;
-  TeamBar bar{a.bar + (size_t)bar_line * 128, a.bar + (size_t)bar_line * 128 + 64, T, 0, a.abort_flag};
+  int tw_c = tw, ntw_c = ntw;                          // the cross phase's share (the early rows of an overlapped step: T - 1 workgroups)
+  TeamBar bar{a.bar + (size_t)bar_line * 128, a.bar + (size_t)bar_line * 128 + 64, T, 0, a.abort_flag,
+              (bar_line == 0 && T == NB && NB > 32) ? a.bar_sub : nullptr, wg};       // (the one team of a single list shares the grid's counters)
   if (!slab_mode && bar_line == 0) bar.epoch = gbar.epoch;   // (a set-up that decided against slabs has used the grid's line already)
 
   const bool prof = a.prof != nullptr && blockIdx.x == 0 && tid == 0;
@@ -1714,7 +1782,7 @@ __global__ __launch_bounds__(kNmsThreads) __attribute__((amdgpu_waves_per_eu(1, 
         }
       }
       if (grid_on && nr >= kGridMinRows) {
-        nms_cross_grid<G>(a, gp, glevels, rows, nr, c0, c1, tw, ntw, L, &s_i[12]);
+        nms_cross_grid<G>(a, gp, glevels, rows, nr, c0, c1, tw_c, ntw_c, L, &s_i[12]);
         if (n_brute > 0) {
           // the boxes the index leaves out: brute kept rows against every column, every kept row against the brute columns
           // (the chunk list in LDS is free between resolve and the next select: it takes the brute rows, capmax at a time)
@@ -1743,15 +1811,15 @@ __global__ __launch_bounds__(kNmsThreads) __attribute__((amdgpu_waves_per_eu(1, 
               nbr += tot;
             }
             __syncthreads();
-            if (nbr > 0) nms_cross<G, GRID>(a, cidx, nbr, c0, c1, nullptr, 0, tw, ntw, L);
+            if (nbr > 0) nms_cross<G, GRID>(a, cidx, nbr, c0, c1, nullptr, 0, tw_c, ntw_c, L);
             __syncthreads();                                     // the list is read until here
           }
-          nms_cross<G, GRID>(a, rows, nr, c0, c1, a.ulist, n_brute, tw, ntw, L);
+          nms_cross<G, GRID>(a, rows, nr, c0, c1, a.ulist, n_brute, tw_c, ntw_c, L);
         }
         return;
       }
     }
-    nms_cross<G, GRID>(a, rows, nr, c0, c1, nullptr, 0, tw, ntw, L);
+    nms_cross<G, GRID>(a, rows, nr, c0, c1, nullptr, 0, tw_c, ntw_c, L);
   };
 
   const int plan_chunk = a.cap_first < a.capmax ? a.cap_first : a.capmax;
@@ -1771,6 +1839,18 @@ __global__ __launch_bounds__(kNmsThreads) __attribute__((amdgpu_waves_per_eu(1, 
     // whose callers spill around the call): whoever needs one leaves a job, the head of the loop runs it.
     const uint32_t* jrows = nullptr;
     int jnr = 0, jc0 = 0, jc1 = 0;
+    // Overlapped steps (OVL kernels, teams of kOvlMinTeam workgroups and more).  The resolver of a step is a FIXED workgroup
+    // (rotating from step to step); everybody else does not wait for its result but for its first pass: the chunk's EARLY
+    // rows -- boxes no conflict edge points at, kept whatever the rounds decide -- are crossed against the later positions by
+    // the other T - 1 workgroups WHILE the rounds run (jmode 1); when the resolver is done the whole team crosses the few
+    // LATE rows (kept in a later round), then the step-end barrier.  A step that would have to build the spatial index (a
+    // team-wide affair) keeps the classic order: wait, then one cross phase over all rows.
+    int jmode = 0;               // 1: the job at hand is the early rows of an overlapped step
+    bool pend_bar = false;       // kills were applied since the last step-end barrier
+    bool crossed0 = false;       // the early rows of the current overlapped step were crossed
+    int ostep = 0;               // overlapped steps so far (the resolver's event word counts 2 per step)
+    int o_cn = 0;
+    int* const ev_word = bar.arrive + 32;
     for (;;) {
       if (jnr > 0) {
         const u64 tcz = (a.prof && tid == 0) ? wall_clock64() : 0ull;
@@ -1778,9 +1858,36 @@ __global__ __launch_bounds__(kNmsThreads) __attribute__((amdgpu_waves_per_eu(1, 
         if (aborted) return;
         if (a.prof && tid == 0) { atomicMax(a.prof + 31, wall_clock64() - tcz); }
         lap(5);
+        jnr = 0;
+        pend_bar = true;
+      }
+      if constexpr (OVL) {
+        if (jmode == 1) {                                  // second half of an overlapped step: the resolver's result
+          jmode = 0; tw_c = tw; ntw_c = ntw;
+          if (tid == 0) {
+            s_flag = spin_until(ev_word, 2 * ostep, a.abort_flag) ? 0 : 1;
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+          }
+          __syncthreads();
+          if (s_flag != 0) return;
+          lap(3);
+          const int nr = ldg_agent(a.nrows + team), nr1 = ldg_agent(a.nrows_el + 2 * team + 1);
+          const bool more = cur < wend && !(a.max_keep > 0 && kept + nr >= a.max_keep);
+          const int kept_before = kept;
+          kept += nr;
+          if (prof) a.prof[6] += 1;
+          if (cap < a.capmax) { cap *= (a.grow_sparse > 2 && 2 * nr > o_cn) ? a.grow_sparse : 2; if (cap > a.capmax) cap = a.capmax; }
+          if (more) {
+            if (crossed0) { if (nr1 > 0) { jrows = a.rows_el + (size_t)team * a.rows_el_stride + a.rows_el_stride / 2; jnr = nr1; } }
+            else if (nr > 0) { jrows = a.rows + sb + kept_before; jnr = nr; }
+            if (jnr > 0) { jc0 = cur; jc1 = wend; continue; }
+          }
+        }
+      }
+      if (pend_bar) {
         if (!team_barrier(bar, &s_flag)) return;           // the kills are visible before anybody selects again
         lap(0);
-        jnr = 0;
+        pend_bar = false;
       }
       if (!(cur < se && !(a.max_keep > 0 && kept >= a.max_keep))) break;
       if (cur >= wend) {                                   // open the next window: every row kept so far against it
@@ -1795,6 +1902,56 @@ __global__ __launch_bounds__(kNmsThreads) __attribute__((amdgpu_waves_per_eu(1, 
       nms_pairs<G, GRID>(a, team, cn, cidx, tw, ntw, L, &s_i[12]);
       if (a.prof && tid == 0) { const u64 d = wall_clock64() - tpz; atomicMax(a.prof + 29, d); atomicAdd(a.prof + 30, d); }
       lap(2);
+      if constexpr (OVL) {
+        if (T >= kOvlMinTeam && a.rows_el != nullptr) {
+          ostep++;
+          o_cn = cn;
+          const int rz = ostep % T;                        // this step's resolver
+          // arrival: everybody; only the resolver waits until all edges are out
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          __syncthreads();
+          if (tid == 0) {
+            int fl = 0;
+            const bool last = bar_arrive(bar);
+            if (last) stg_agent(bar.go, bar.epoch + 1);
+            if (wg == rz) {
+              if (!last) fl = spin_until(bar.go, bar.epoch + 1, a.abort_flag) ? 0 : 1;
+              __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            } else {
+              fl = spin_until(ev_word, 2 * ostep - 1, a.abort_flag) ? 0 : 1;      // the early rows are out
+              __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            }
+            s_flag = fl;
+          }
+          __syncthreads();
+          bar.epoch++;
+          if (s_flag != 0) return;
+          int nr0;
+          if (wg == rz) {
+            lap(3);
+            const u64 ts = (a.prof && tid == 0) ? wall_clock64() : 0ull;
+            nms_resolve(a, g, sb, team, cn, kept, cidx, smem, sizeof(WaveLds<G>) * kNmsWaves, s_i, 2 * ostep - 1, ev_word);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) stg_agent(ev_word, 2 * ostep);     // rows, late rows and counts are out
+            if (a.prof && tid == 0) { atomicAdd(a.prof + 9, wall_clock64() - ts); }
+            lap(4);
+            nr0 = ldg_agent(a.nrows_el + 2 * team);
+          } else {
+            nr0 = ldg_agent(a.nrows_el + 2 * team);
+          }
+          // (uniform over the team: every workgroup evaluates the same numbers)
+          crossed0 = nr0 > 0 && cur < wend && !(a.max_keep > 0 && kept + nr0 >= a.max_keep) &&
+                     !(grid_on && !grid_built && nr0 >= kGridMinRows);
+          jmode = 1;
+          if (crossed0 && wg != rz) {
+            jrows = a.rows_el + (size_t)team * a.rows_el_stride; jnr = nr0; jc0 = cur; jc1 = wend;
+            tw_c = (wg - (wg > rz ? 1 : 0)) * kNmsWaves + wv; ntw_c = (T - 1) * kNmsWaves;
+          }
+          if (crossed0) pend_bar = true;                   // (the resolver applies no kill of its own but meets the others at the barrier)
+          continue;
+        }
+      }
       // ---- all edges are out: the last arriver resolves the chunk, the others wait for its rows
       if (serial_begin(bar, &s_flag)) {
         lap(3);
