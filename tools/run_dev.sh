@@ -1,13 +1,21 @@
 #!/bin/bash
 # Development run on the GPU box: bash tools/run_dev.sh <tag> [pytest args...]  -> gpurun_out/<tag>/
+#   PYTEST=0 skips the test run, PROF=1 adds a rocprofv3 kernel trace of tools/prof_regimes.py
 TAG=${1:-dev}; shift
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/$TAG
 mkdir -p $O
 cd $R
 export TMPDIR=/tmp
-timeout 1500 python -m pytest tests -m gpu -q -x --durations=15 "$@" > $O/pytest.log 2>&1
-echo "pytest rc=$?" >> $O/pytest.log
+if [ "${PYTEST:-1}" != "0" ]; then
+  timeout 1500 python -m pytest -m gpu -q -x --durations=10 "$@" > $O/pytest.log 2>&1
+  echo "pytest rc=$?" >> $O/pytest.log
+fi
 timeout 300 python tools/prof_regimes.py > $O/regimes.txt 2>&1
 OBB_NMS_PHASE_PROF=1 timeout 300 python tools/prof_regimes.py > $O/phases.txt 2>&1
-tail -25 $O/pytest.log; grep -E "^clustered|^uniform" $O/regimes.txt
+if [ "${PROF:-0}" = "1" ]; then
+  rm -rf /tmp/p_kt
+  timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/p_kt -o kt -- python tools/prof_regimes.py > $O/kt.log 2>&1
+  python tools/rocpd_summary.py "$(find /tmp/p_kt -name '*.db' | head -1)" "rocprofv3 --kernel-trace --stats -- python tools/prof_regimes.py" > $O/kernel_stats.md 2>&1
+fi
+[ -f $O/pytest.log ] && tail -12 $O/pytest.log; grep -E "^clustered|^uniform" $O/regimes.txt; [ -f $O/kernel_stats.md ] && head -30 $O/kernel_stats.md

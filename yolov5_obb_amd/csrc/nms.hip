@@ -851,6 +851,15 @@ void _poly_nms(int* keep_out_host, int* num_out_host, const float* polys_host, i
   if (device_id >= 0 && device_id != cur) hipSetDevice(cur);
 }
 
+// The reference declares this function with C++ linkage (poly_nms.hpp:9-10: no extern "C"), so a build of its Cython source
+// (poly_nms.pyx, `cdef extern from "poly_nms.hpp"`) binds the MANGLED name: the same entry point under that name.
+void obb_cxx_poly_nms(int* keep_out_host, int* num_out_host, const float* polys_host, int polys_num, int polys_dim,
+                      float nms_overlap_thresh, int device_id) __asm__("_Z9_poly_nmsPiS_PKfiifi");
+void obb_cxx_poly_nms(int* keep_out_host, int* num_out_host, const float* polys_host, int polys_num, int polys_dim,
+                      float nms_overlap_thresh, int device_id) {
+  _poly_nms(keep_out_host, num_out_host, polys_host, polys_num, polys_dim, nms_overlap_thresh, device_id);
+}
+
 size_t obb_nms_obb_workspace_bytes(int64_t bs, int64_t cap_img, int64_t nc, int agnostic) {
   ObbCarve cv;
   if (bs < 1 || cap_img < 1 || nc < 1 || nc > 256 || obb_carve(nullptr, bs, cap_img, agnostic ? 1 : nc, &cv)) return 0;

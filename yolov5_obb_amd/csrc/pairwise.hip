@@ -268,4 +268,12 @@ void _overlaps(float* overlaps_host, const float* boxes_host, const float* query
   if (device_id >= 0 && device_id != cur) hipSetDevice(cur);
 }
 
+// (the reference declares it with C++ linkage, poly_overlaps.hpp:1: the same entry point under the mangled name its Cython
+// source binds)
+void obb_cxx_overlaps(float* overlaps_host, const float* boxes_host, const float* query_boxes_host, int n, int k, int device_id)
+    __asm__("_Z9_overlapsPfPKfS1_iii");
+void obb_cxx_overlaps(float* overlaps_host, const float* boxes_host, const float* query_boxes_host, int n, int k, int device_id) {
+  _overlaps(overlaps_host, boxes_host, query_boxes_host, n, k, device_id);
+}
+
 }  // extern "C"
