@@ -12,10 +12,11 @@ if [ "${PYTEST:-1}" != "0" ]; then
   echo "pytest rc=$?" >> $O/pytest.log
 fi
 timeout 300 python tools/prof_regimes.py > $O/regimes.txt 2>&1
+OBB_NMS_NO_OVL=1 timeout 300 python tools/prof_regimes.py > $O/regimes_no_ovl.txt 2>&1
 OBB_NMS_PHASE_PROF=1 timeout 300 python tools/prof_regimes.py > $O/phases.txt 2>&1
 if [ "${PROF:-0}" = "1" ]; then
   rm -rf /tmp/p_kt
   timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/p_kt -o kt -- python tools/prof_regimes.py > $O/kt.log 2>&1
   python tools/rocpd_summary.py "$(find /tmp/p_kt -name '*.db' | head -1)" "rocprofv3 --kernel-trace --stats -- python tools/prof_regimes.py" > $O/kernel_stats.md 2>&1
 fi
-[ -f $O/pytest.log ] && tail -12 $O/pytest.log; grep -E "^clustered|^uniform" $O/regimes.txt; [ -f $O/kernel_stats.md ] && head -30 $O/kernel_stats.md
+[ -f $O/pytest.log ] && tail -12 $O/pytest.log; grep -E "^clustered|^uniform" $O/regimes.txt $O/regimes_no_ovl.txt; [ -f $O/kernel_stats.md ] && head -16 $O/kernel_stats.md

@@ -460,7 +460,7 @@ static int carve(void* base, int64_t n, int64_t nseg, int recq, int C, Carve* cv
   if (recq == RotGeom::RECQ && nseg == 1 && n >= kGridMinN) {
     const uint32_t M = grid_slots(n);
     cv->grid.mask = M - 1;
-    cv->rows_el_stride = 2LL * C;                              // the one list's team, or one team per slab
+    cv->rows_el_stride = 2LL * (C + 16);                       // the one list's team, or one team per slab; early half: count + rows
     cv->rows_el = (uint32_t*)take((size_t)(kMaxSlabs + 1) * (size_t)cv->rows_el_stride * 4);
     cv->nrows_el = (int*)take((size_t)(kMaxSlabs + 1) * 2 * 4);
     const size_t slab_tot_bytes = (size_t)(1 + kMaxTeams / 16) * kMaxSlabs * 4;   // slab totals + group totals (slab_setup)
@@ -514,7 +514,7 @@ static int launch_persist(const NmsArgs& a, unsigned nb, hipStream_t st) {
     attr_set = true;
   }
   size_t lds = sizeof(WaveLds<G>) * kNmsWaves;                // pair phases: one scratch block per wave
-  if (lds < (size_t)2 * a.capmax) return OBB_ERR_INTERNAL;    // (aliased by resolve: state + blocked bytes of one chunk)
+  if (lds < (size_t)6 * a.capmax) return OBB_ERR_INTERNAL;    // (aliased by resolve: state + blocked bytes of one chunk + its ordered output list)
   lds += (size_t)a.capmax * 4;                                // + this workgroup's copy of the chunk list
   if (lds > kPersistLdsMax) return OBB_ERR_INTERNAL;
   // OBB_NMS_COOP=1: cooperative launch -- the runtime guarantees that all workgroups are resident together (what the
@@ -681,7 +681,9 @@ static int run_nms(int kind, const float* boxes, int stride, const float* scores
   a.rec = cv.rec; a.order = cv.vals_b; a.alive = cv.alive; a.seg_begin = cv.seg_begin; a.seg_end = cv.seg_end;
   a.keep_cnt = cv.keep_cnt; a.keep_out = keep_out;
   a.rows = cv.rows; a.nrows = cv.nrows; a.edges = cv.edges; a.nedges = cv.nedges;
-  a.rows_el = cv.rows_el; a.nrows_el = cv.nrows_el; a.rows_el_stride = cv.rows_el_stride;
+  static int no_ovl = -1;                                          // OBB_NMS_NO_OVL=1: A/B switch for measurements (classic steps only)
+  if (no_ovl < 0) { const char* e = getenv("OBB_NMS_NO_OVL"); no_ovl = (e && atoi(e)) ? 1 : 0; }
+  a.rows_el = no_ovl ? nullptr : cv.rows_el; a.nrows_el = cv.nrows_el; a.rows_el_stride = cv.rows_el_stride;
   a.ecap = cv.ecap; a.n = (int)n; a.capmax = C;
   a.max_keep = (int)(max_keep > 0x7fffffffLL ? 0x7fffffffLL : (max_keep < 0 ? 0 : max_keep));
   a.window = nms_window(a.max_keep);

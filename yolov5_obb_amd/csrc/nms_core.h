@@ -133,6 +133,7 @@ __device__ __forceinline__ void rows_reject2(const float4& myrow, int r, const C
   G::cheap_reject2(ax, ay, az, aw, c, r0, r1);
 }
 
+constexpr int kOvlMinEdges = 8192;         // overlapped steps (k_nms_persist) only pay for a chunk whose resolve outlasts a second pass of the cross phase
 constexpr int kBarGroups = 64;             // groups of 16 workgroups: grids of up to 1024
 constexpr int kNmsThreads = 512;
 constexpr int kNmsWaves = kNmsThreads / 64;
@@ -620,6 +621,16 @@ OBB_COLD_RESOLVE int nms_resolve(const NmsArgs& a, int g, int sb, int tm, int cn
   per |= 1;
   bool lds_mode = per <= percap;
   if (!lds_mode) per = percap;
+  if (early_ev != 0 && E < kOvlMinEdges) {
+    // few edges: the rounds are over before a separate pass over the late rows would have paid for itself -- no early rows
+    // (count 0, event at once: the others wait for the complete result and cross all rows in one pass)
+    if (tid == 0) {
+      stg_agent(a.rows_el + (size_t)tm * a.rows_el_stride, 0u);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      stg_agent(ev_word, early_ev);
+    }
+    early_ev = 0;
+  }
   int mycnt = 0;
   uint32_t* mine_e = ledges + (size_t)tid * per;
   if (lds_mode) {
@@ -721,7 +732,8 @@ OBB_COLD_RESOLVE int nms_resolve(const NmsArgs& a, int g, int sb, int tm, int cn
     }
     const int any = __syncthreads_or(rem ? 1 : 0);     // barrier + "somebody is still undecided" in one
     if (early_ev != 0 && round == 0) {
-      // the early rows (any order: the cross phases do not care), count, event -- all write-through, the event last
+      // the early rows (any order: the cross phases do not care) behind their count in entry 0, then the event -- all
+      // write-through, ONE drain in between
       uint32_t* er = a.rows_el + (size_t)tm * a.rows_el_stride;
       if (tid == 0) s_i[9] = 0;
       __syncthreads();
@@ -733,16 +745,14 @@ OBB_COLD_RESOLVE int nms_resolve(const NmsArgs& a, int g, int sb, int tm, int cn
           int base = 0;
           if ((tid & 63) == 0) base = atomicAdd(&s_i[9], __popcll(fm));
           base = __shfl(base, 0);
-          if (f) stg_agent(er + base + __popcll(fm & lanemask_lt()), cidx[j]);
+          if (f) stg_agent(er + 1 + base + __popcll(fm & lanemask_lt()), cidx[j]);
         }
       }
+      __syncthreads();
+      if (tid == 0) stg_agent(er, (uint32_t)s_i[9]);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
-      if (tid == 0) {
-        stg_agent(a.nrows_el + 2 * tm, s_i[9]);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        stg_agent(ev_word, early_ev);
-      }
+      if (tid == 0) stg_agent(ev_word, early_ev);
     }
     if (!any) { if (a.prof && tid == 0) atomicAdd(a.prof + 11, (u64)(round + 1)); break; }
     if (!lds_mode) {
@@ -775,24 +785,48 @@ OBB_COLD_RESOLVE int nms_resolve(const NmsArgs& a, int g, int sb, int tm, int cn
   uint32_t* rows = a.rows + (size_t)sb + kept_before;         // appended to the segment's kept-row list
   uint32_t* lr = early_ev != 0 ? a.rows_el + (size_t)tm * a.rows_el_stride + a.rows_el_stride / 2 : nullptr;
   if (early_ev != 0 && tid == 0) s_i[10] = 0;
+  // Two passes: the kept positions first go to an ordered list in LDS (the edge blocks are free now; top bit = a late row),
+  // then thread t emits entries t, t + 512, ... four at a time -- the gather of the original indices (or of the slab copy's
+  // old positions) is four independent loads per thread instead of a chain of up to 16 dependent ones (measured: 22 us of
+  // every 8192-box chunk of the uniform regime sat in this loop).
+  uint32_t* olist = ledges;                                   // cn <= capmax entries fit (lcap >= capmax, checked by the launcher's LDS bound)
   __syncthreads();
   for (int q = 0; q < per_n; q++) {
     const int j = tid * per_n + q;
-    if (j < cn && (state[j] & 1)) {
-      const uint32_t pos = cidx[j];
-      stg_agent(rows + rank, pos);
-      if (early_ev != 0 && state[j] == 1) stg_agent(lr + atomicAdd(&s_i[10], 1), pos);      // (a late row: few per chunk)
-      const long long o = (long long)kept_before + rank;
+    if (j < cn && (state[j] & 1)) { olist[rank] = cidx[j] | (state[j] == 1 && early_ev != 0 ? 0x80000000u : 0u); rank++; }
+  }
+  __syncthreads();
+  for (int k0 = tid; k0 < total; k0 += 4 * kNmsThreads) {
+    uint32_t pv[4], ov[4];
+    bool ok[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int k = k0 + u * kNmsThreads;
+      ok[u] = k < total;
+      pv[u] = ok[u] ? olist[k] : 0u;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const uint32_t pos = pv[u] & 0x7fffffffu;
+      ov[u] = 0u;
+      if (ok[u]) ov[u] = a.keep_out != nullptr ? (a.order ? a.order[pos] : pos) : a.pos_old[pos];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      if (!ok[u]) continue;
+      const int k = k0 + u * kNmsThreads;
+      const uint32_t pos = pv[u] & 0x7fffffffu;
+      stg_agent(rows + k, pos);
+      if (pv[u] >> 31) stg_agent(lr + atomicAdd(&s_i[10], 1), pos);            // (a late row: few per chunk)
+      const long long o = (long long)kept_before + k;
       if (a.keep_out != nullptr) {
-        if (a.max_keep <= 0 || o < a.max_keep) a.keep_out[(size_t)sb + o] = a.order ? (int64_t)a.order[pos] : (int64_t)pos;
+        if (a.max_keep <= 0 || o < a.max_keep) a.keep_out[(size_t)sb + o] = (int64_t)ov[u];
       } else {
         // slab mode: the kept boxes of all slabs meet again in score order through a bitmap over the ORIGINAL sorted
         // positions (slab_merge); a returning atomic whose result is consumed: the wave's vmcnt covers the completed update
-        const uint32_t po = a.pos_old[pos];
-        const u64 old = atomicOr(a.kept_bits + (po >> 6), 1ull << (po & 63));
+        const u64 old = atomicOr(a.kept_bits + (ov[u] >> 6), 1ull << (ov[u] & 63));
         asm volatile("; kept bit set %0" ::"v"((unsigned)(old >> 32) ^ (unsigned)old));
       }
-      rank++;
     }
   }
   __syncthreads();
@@ -1533,11 +1567,18 @@ OBB_COLD_SLAB int slab_setup(const NmsArgs& a, float bin_x0, float inv, unsigned
     const int s0 = tid & (kMaxSlabs - 1), part = tid >> 6;     // kNmsThreads / kMaxSlabs = 8 parts
     const int grp = wg >> 4;
     if (s0 < S) {
-      int below = 0;
-      for (int g2 = part; g2 < grp; g2 += kNmsWaves) below += a.slab_tot[(size_t)(1 + g2) * kMaxSlabs + s0];
-      for (int w = (grp << 4) + part; w < wg; w += kNmsWaves) below += a.slab_cnt[(size_t)w * kMaxSlabs + s0];
+      // (at most two group totals and two rows per thread: all requested before the first is used -- the loop form waited
+      //  for every load in turn, four round trips to lines other workgroups had just written: 14.5 us of the set-up)
+      const int g2a = part, g2b = part + kNmsWaves, wa = (grp << 4) + part, wb = wa + kNmsWaves;
+      const int v0 = g2a < grp ? a.slab_tot[(size_t)(1 + g2a) * kMaxSlabs + s0] : 0;
+      const int v1 = g2b < grp ? a.slab_tot[(size_t)(1 + g2b) * kMaxSlabs + s0] : 0;
+      const int v2 = wa < wg ? a.slab_cnt[(size_t)wa * kMaxSlabs + s0] : 0;
+      const int v3 = wb < wg ? a.slab_cnt[(size_t)wb * kMaxSlabs + s0] : 0;
+      const int vt = part == 0 ? a.slab_tot[s0] : 0;
+      int below = v0 + v1 + v2 + v3;
+      for (int g2 = part + 2 * kNmsWaves; g2 < grp; g2 += kNmsWaves) below += a.slab_tot[(size_t)(1 + g2) * kMaxSlabs + s0];   // (grids beyond 256 workgroups)
       if (below) atomicAdd(&pre[s0], below);
-      if (part == 0) tot[s0] = a.slab_tot[s0];
+      if (part == 0) tot[s0] = vt;
     }
     slap(48);
   }
@@ -1936,16 +1977,14 @@ __global__ __launch_bounds__(kNmsThreads) __attribute__((amdgpu_waves_per_eu(1, 
             if (tid == 0) stg_agent(ev_word, 2 * ostep);     // rows, late rows and counts are out
             if (a.prof && tid == 0) { atomicAdd(a.prof + 9, wall_clock64() - ts); }
             lap(4);
-            nr0 = ldg_agent(a.nrows_el + 2 * team);
-          } else {
-            nr0 = ldg_agent(a.nrows_el + 2 * team);
           }
+          nr0 = (int)ldg_agent(a.rows_el + (size_t)team * a.rows_el_stride);
           // (uniform over the team: every workgroup evaluates the same numbers)
           crossed0 = nr0 > 0 && cur < wend && !(a.max_keep > 0 && kept + nr0 >= a.max_keep) &&
                      !(grid_on && !grid_built && nr0 >= kGridMinRows);
           jmode = 1;
           if (crossed0 && wg != rz) {
-            jrows = a.rows_el + (size_t)team * a.rows_el_stride; jnr = nr0; jc0 = cur; jc1 = wend;
+            jrows = a.rows_el + (size_t)team * a.rows_el_stride + 1; jnr = nr0; jc0 = cur; jc1 = wend;
             tw_c = (wg - (wg > rz ? 1 : 0)) * kNmsWaves + wv; ntw_c = (T - 1) * kNmsWaves;
           }
           if (crossed0) pend_bar = true;                   // (the resolver applies no kill of its own but meets the others at the barrier)

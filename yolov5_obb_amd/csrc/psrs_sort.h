@@ -4,7 +4,8 @@
 // lists of up to kPsMaxN elements.  Parallel sorting by regular sampling in three launches, no workgroup ever waits for
 // another one (no co-residency assumption, nothing spins):
 //   k_ps_local_*   workgroup r makes / reads the keys of run r (kPsRun consecutive elements), sorts them in registers + LDS
-//                  (sort_lds_regs below), stores the sorted run and kPsSamp REGULAR samples of it (every kPsStride-th element);
+//                  (sort_lds_regs below), stores the sorted run and kPsSamp REGULAR samples of it (one per stride of kPsStride elements, at a
+//                  phase that differs from run to run);
 //   k_ps_split     workgroup r ranks its own samples among all samples (all R x 16 of them sit in LDS: <= 32 KB); a sample
 //                  whose rank is a multiple of 16 is a splitter; for every splitter it owns, the workgroup finds the cut of
 //                  EVERY run (the run's samples narrow it to a window of 31 elements, five probes in global memory);
@@ -141,6 +142,7 @@ struct PsBuf {
   int n;
   int* err;                                         // optional: set when a bucket exceeds its bound (cannot happen)
 };
+__host__ __device__ __forceinline__ int ps_phase(int r) { return (r * 13 + 5) & (kPsStride - 1); }
 __device__ __forceinline__ int ps_count(const PsBuf& b) {
   int n = b.n;
   if (b.n_dev) { const int d = *b.n_dev; n = d < n ? d : n; if (n < 0) n = 0; }
@@ -154,7 +156,11 @@ __device__ __forceinline__ void ps_local_tail(const PsBuf& b, int n, unsigned lo
   sort_lds_regs<1>(s_k, s_v, kPsRun, tid);
   const int len = (n - base) < kPsRun ? (n - base) : kPsRun;
   if (tid < len) { b.run_k[base + tid] = s_k[tid]; b.run_v[base + tid] = s_v[tid]; }
-  if (tid < kPsSamp) b.samp[r * kPsSamp + tid] = s_k[(tid + 1) * kPsStride - 1];
+  // sample k = element 32k + phase(r).  The phase differs from run to run: equal-sized runs of similar data put their k-th
+  // samples at nearly the same global rank, so with one phase for all the sorted samples come in 16 tight clusters and the
+  // buckets that straddle a gap between clusters get several thousand elements (measured: 4807); with dithered phases the
+  // samples spread evenly and a bucket holds 512 +- 300.
+  if (tid < kPsSamp) b.samp[r * kPsSamp + tid] = s_k[tid * kPsStride + ps_phase(r)];
 }
 
 // runs from explicit (key, value) pairs (the fused driver's candidates of ONE large image; the count lives on the device)
@@ -206,10 +212,30 @@ __global__ __launch_bounds__(kPsRun) void k_ps_split(PsBuf b) {
     int c;                                           // samples of run r2 that are <= sp (pads are above every splitter)
     { int lo = 0, hi = kPsSamp; while (lo < hi) { const int mid = (lo + hi) >> 1; if (s_samp[r2 * kPsSamp + mid] <= sp) lo = mid + 1; else hi = mid; } c = lo; }
     const int len = (n - r2 * kPsRun) < kPsRun ? (n - r2 * kPsRun) : kPsRun;
-    // element 32c - 1 is <= sp, element 32c + 31 (the next sample) is above it: the cut lies in [32c, 32c + 31]
-    int lo = c * kPsStride < len ? c * kPsStride : len, hi = c * kPsStride + kPsStride - 1 < len ? c * kPsStride + kPsStride - 1 : len;
+    // sample c - 1 (element 32 (c - 1) + phase) is <= sp, sample c (element 32c + phase) is above it: the cut lies in
+    // [32c + phase - 31, 32c + phase] (c = 0: [0, phase]; c = 16: up to the run's end); found in two rounds of independent probes
+    // (3, then 8) instead of five dependent ones
+    const int ph = ps_phase(r2);
+    int lo = c * kPsStride + ph - (kPsStride - 1), hi = c * kPsStride + ph;
+    lo = lo < 0 ? 0 : lo; lo = lo < len ? lo : len; hi = hi < len ? hi : len;
     const unsigned long long* run = b.run_k + (size_t)r2 * kPsRun;
-    while (lo < hi) { const int mid = (lo + hi) >> 1; if (run[mid] <= sp) lo = mid + 1; else hi = mid; }
+    {
+      // elements lo + 8, + 16, + 24 (where they exist below hi): the cut is behind the last one that is <= sp
+      unsigned long long pr[3];
+#pragma unroll
+      for (int t = 0; t < 3; t++) pr[t] = (lo + 8 * (t + 1) - 1 < hi) ? run[lo + 8 * (t + 1) - 1] : ~0ull;
+      int adv = 0;
+#pragma unroll
+      for (int t = 0; t < 3; t++) if (pr[t] <= sp) adv = 8 * (t + 1);
+      lo += adv;
+      unsigned long long pf[8];
+#pragma unroll
+      for (int t = 0; t < 8; t++) pf[t] = (lo + t < hi) ? run[lo + t] : ~0ull;
+      int cntle = 0;
+#pragma unroll
+      for (int t = 0; t < 8; t++) cntle += (pf[t] <= sp) ? 1 : 0;
+      lo += cntle;
+    }
     b.cut[(size_t)s_spj[k] * kPsMaxRuns + r2] = lo;
   }
 }
