@@ -308,6 +308,18 @@ int obb_rbox2poly_f32(const float* rboxes, int64_t n, int64_t row_stride, float*
 int obb_val_postprocess_f32(const float* det7, int64_t n, float pad_x, float pad_y, float gain, float* poly10, float* hbb6,
                             float* polyn10, float* hbbn6, void* stream);
 
+/* The same tail for ALL images of a batch in three launches (val.py:209-250 is a per-image loop): det7 = the packed (N,7)
+ * detections of the batch, image b's rows at [det_off_host[b], det_off_host[b+1]) (bs + 1 host integers, det_off_host[0] = 0,
+ * bs <= 64); targets = the batch's labels on the device, (nt, tcols >= 7) rows [img cls cx cy l s theta ...] in pixels of the
+ * letterboxed frame (the collate format); img5_host = bs x {pad_x, pad_y, gain, native width, native height} (shapes[si] of
+ * val.py).  Label boxes go through rbox2poly -> poly2hbb -> xywh2xyxy -> scale_coords in the reference's order (val.py:238-241).
+ * Outputs (device): the four packed arrays of obb_val_postprocess_f32 (any may be NULL) and stats (N, niou + 2) floats: the
+ * correct row of process_batch as 0 / 1, then conf, then cls -- val.py:250's tuple in one array, one copy per batch. */
+size_t obb_val_tail_batch_workspace_bytes(int64_t n_det, int64_t nt);
+int obb_val_tail_batch_f32(const float* det7, const int64_t* det_off_host, int64_t bs, const float* targets, int64_t nt, int64_t tcols,
+                           const float* img5_host, const float* iouv, int niou, float* poly10, float* hbb6, float* polyn10,
+                           float* hbbn6, float* stats, void* ws, size_t ws_bytes, void* stream);
+
 /* process_batch (val.py:69-90): detections (n,6) [x1 y1 x2 y2 conf cls], labels (m,5) [cls x1 y1 x2 y2], iouv (niou) on the
  * device -> correct (n, niou) bytes (0/1).  No device->host round trip (the reference sorts the matches with numpy). */
 size_t obb_process_batch_workspace_bytes(int64_t n, int64_t m);

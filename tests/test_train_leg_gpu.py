@@ -58,17 +58,18 @@ def test_ddp_amp_gradscaler_step_with_the_hip_loss(dev, oracle_lib, nccl_world1)
     torch.manual_seed(7)
     model = TinyObb(nc, hyp).to(dev).train()
     ddp = DDP(model, device_ids=[dev.index], output_device=dev.index)
+    ddp.hyp = hyp                                                     # train.py:254 hangs the hyper-parameters on the wrapped model
     compute_loss = ComputeLoss(ddp)                                   # (train.py:269 passes the wrapped model as well)
     spec = pyref.LossSpec(hyp, synth.grid_anchors(), torch.tensor(synth.DEFAULT_STRIDES), nc)
     _, targets = synth.s_loss(bs, nc, nt, 11, imgsz=imgsz, sizes=[32, 16, 8])
     g = torch.Generator().manual_seed(3)
     im = torch.rand(bs, 3, imgsz, imgsz, generator=g).to(dev)
     opt = torch.optim.SGD(ddp.parameters(), lr=0.01, momentum=0.9)
-    scaler = torch.cuda.amp.GradScaler(init_scale=1024.0)
+    scaler = torch.amp.GradScaler("cuda", init_scale=1024.0)
     params = [p for p in ddp.parameters()]
     before = [p.detach().clone() for p in params]
 
-    with torch.cuda.amp.autocast():
+    with torch.autocast("cuda", dtype=torch.float16):
         pred = ddp(im)                                                # list of (bs, na, ny, nx, no), fp16 under autocast
         for p in pred:
             assert p.dtype == torch.float16
@@ -92,7 +93,7 @@ def test_ddp_amp_gradscaler_step_with_the_hip_loss(dev, oracle_lib, nccl_world1)
     # (2) the parameter gradients behind DDP's hooks = torch autograd of the same graph fed with the ORACLE's head gradient
     got = [p.grad.detach().clone() for p in params]
     assert all(x is not None and torch.isfinite(x).all() for x in got)
-    with torch.cuda.amp.autocast():
+    with torch.autocast("cuda", dtype=torch.float16):
         pred2 = model(im)                                             # same weights, no DDP wrapper, no loss kernels
     want = torch.autograd.grad(pred2, [p for p in model.parameters()],
                                grad_outputs=[(b.grad * scale).to(device=dev, dtype=torch.float16) for b in pc], allow_unused=True)
@@ -111,7 +112,7 @@ def test_ddp_amp_gradscaler_step_with_the_hip_loss(dev, oracle_lib, nccl_world1)
     assert scaler.get_scale() == scale                                # no inf / nan found: the step was not skipped
     assert sum(float((p.detach() - b).abs().sum()) for p, b in zip(params, before)) > 0
     opt.zero_grad()
-    with torch.cuda.amp.autocast():
+    with torch.autocast("cuda", dtype=torch.float16):
         loss2, _ = compute_loss(ddp(im), targets.to(dev))
     scaler.scale(loss2).backward()
     scaler.step(opt)

@@ -115,3 +115,66 @@ def test_sharded_val_loop_hip_vs_oracle(dev):
     assert np.array_equal(hip["stats"][0], ora["stats"][0])                       # correct (n, 10) bool
     assert np.allclose(hip["stats"][1], ora["stats"][1], rtol=0, atol=0)          # conf: copied through
     assert np.array_equal(hip["stats"][2], ora["stats"][2]) and np.array_equal(hip["stats"][3], ora["stats"][3])
+
+
+@pytest.mark.parametrize("bs", [1, 5, 70])
+def test_batched_tail_equals_the_per_image_tail(dev, bs):
+    """val.val_tail_batch (three launches + one copy per batch) against the per-image val_postprocess / process_batch pair it
+    replaces in the loop: the same four box arrays bit for bit, the same correct rows, conf, cls -- with images without
+    detections, images without labels, and more images than one call takes (64)."""
+    from yolov5_obb_amd.val import process_batch, val_postprocess, val_tail_batch
+    g = torch.Generator().manual_seed(100 + bs)
+    iouv = torch.linspace(0.5, 0.95, 10)
+    preds, tgs, shapes = [], [], []
+    for b in range(bs):
+        n = 0 if b % 7 == 3 else int(torch.randint(1, 60, (1,), generator=g))
+        d = torch.zeros(n, 7)
+        d[:, :2] = torch.rand(n, 2, generator=g) * 900 + 50
+        d[:, 2] = torch.rand(n, generator=g) * 100 + 10
+        d[:, 3] = torch.rand(n, generator=g) * 30 + 5
+        d[:, 4] = (torch.rand(n, generator=g) - 0.5) * 3.1
+        d[:, 5] = torch.sort(torch.rand(n, generator=g), descending=True)[0]
+        d[:, 6] = torch.randint(0, 4, (n,), generator=g).float()
+        preds.append(d)
+        nl = 0 if b % 5 == 1 else int(torch.randint(1, 30, (1,), generator=g))
+        t = torch.zeros(nl, 9)                                   # two extra columns like a collate row with more fields
+        t[:, 0] = b
+        src = torch.randint(0, max(n, 1), (nl,), generator=g)
+        if n:
+            t[:, 1] = d[src, 6]
+            t[:, 2:7] = d[src, :5] + torch.randn(nl, 5, generator=g) * torch.tensor([3., 3., 4., 2., 0.02])
+        else:
+            t[:, 2:4] = torch.rand(nl, 2, generator=g) * 900
+            t[:, 4:6] = 20.0
+        tgs.append(t)
+        gain = 0.5 + 0.5 * float(torch.rand(1, generator=g))
+        shapes.append(((1100 + b, 1300 - b), ((gain, gain), (4.0 + b % 3, 9.5))))
+    targets = torch.cat(tgs, 0)
+    packed = torch.cat(preds, 0).to(dev)
+    views = list(packed.split([p.shape[0] for p in preds]))     # consecutive views of one buffer, as the NMS returns them
+    stats, (boxes, offs) = val_tail_batch(views, targets.to(dev), shapes, iouv.to(dev), want_boxes=True)
+    loose = val_tail_batch([p.to(dev).clone() for p in preds], targets.to(dev), shapes, iouv.to(dev))     # not consecutive: concatenated
+    for b in range(bs):
+        p = preds[b].to(dev)
+        sl = slice(offs[b], offs[b + 1])
+        correct, conf, cls = stats[b]
+        assert correct.shape == (p.shape[0], 10) and torch.equal(conf, preds[b][:, 5]) and torch.equal(cls, preds[b][:, 6])
+        assert all(torch.equal(x, y) for x, y in zip(stats[b], loose[b]))
+        if p.shape[0] == 0:
+            continue
+        ratio_pad = shapes[b][1]
+        ref = val_postprocess(p, ratio_pad=ratio_pad)
+        for got, want in zip(boxes, ref):
+            assert torch.equal(got[sl], want)
+        lab = tgs[b]
+        if len(lab):
+            lab7 = torch.cat((lab[:, 2:7], torch.zeros_like(lab[:, :1]), lab[:, 1:2]), 1).to(dev)
+            tb = val_postprocess(lab7, ratio_pad=ratio_pad)[1][:, :4].clone()
+            tb[:, [0, 2]] -= ratio_pad[1][0]; tb[:, [1, 3]] -= ratio_pad[1][1]
+            tb[:, :4] /= ratio_pad[0][0]
+            tb[:, [0, 2]] = tb[:, [0, 2]].clamp(0, float(shapes[b][0][1])); tb[:, [1, 3]] = tb[:, [1, 3]].clamp(0, float(shapes[b][0][0]))
+            want = process_batch(ref[3], torch.cat((lab[:, 1:2].to(dev), tb), 1), iouv.to(dev)).cpu()
+        else:
+            want = torch.zeros(p.shape[0], 10, dtype=torch.bool)
+        assert torch.equal(correct, want), b
+    assert sum(int(s[0].any()) for s in stats) >= max(1, bs // 3)

@@ -57,6 +57,8 @@ SIGNATURES = {
     "obb_csl_encode_f32": (_i32, [_vp, _i64, _i32, C.c_double, C.c_double, _vp, _vp]),
     "obb_rbox2poly_f32": (_i32, [_vp, _i64, _i64, _vp, _vp, _vp]),
     "obb_val_postprocess_f32": (_i32, [_vp, _i64, _f32, _f32, _f32, _vp, _vp, _vp, _vp, _vp]),
+    "obb_val_tail_batch_workspace_bytes": (_sz, [_i64, _i64]),
+    "obb_val_tail_batch_f32": (_i32, [_vp, _vp, _i64, _vp, _i64, _i64, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "obb_process_batch_workspace_bytes": (_sz, [_i64, _i64]),
     "obb_process_batch_f32": (_i32, [_vp, _i64, _vp, _i64, _vp, _i32, _vp, _vp, _sz, _vp]),
     "obb_rotated_iou_pairs_f32": (_i32, [_vp, _vp, _i64, _vp, _vp]),
@@ -163,6 +165,40 @@ def require_cuda(t, name):
         # the reference dispatches CPU tensors to nms_rotated_cpu (nms_rotated_ext.cpp:38); this build is GPU-only
         raise RuntimeError(f"{name} must be a CUDA/HIP tensor: yolov5_obb_amd is compiled for MI355X only "
                            f"(no CPU path, by design)")
+
+
+# ---- kept-count read-back through polled pinned memory (single-list NMS entry points)
+# The last kernel of a call writes the count with one aligned 8-byte store; the device reaches pinned host memory through the
+# same pointer, so the calling thread can poll it: no copy kernel behind the NMS, no wake-up of a blocked stream wait
+# (utils/general.py does the same for the fused driver's bs + 2 counters).
+_PENDING = -(1 << 62)
+_count_memo = {}
+
+
+def pinned_count(device):
+    """(tensor, numpy view) of one pinned int64 per (device, thread), armed with the PENDING marker."""
+    import threading
+    key = (device.index, threading.get_ident())
+    ent = _count_memo.get(key)
+    if ent is None:
+        t = torch.empty(1, dtype=torch.int64).pin_memory()
+        ent = _count_memo[key] = (t, t.numpy())
+    ent[1][0] = _PENDING
+    return ent
+
+
+def wait_count(view, device, give_up=1.0):
+    """Poll the armed counter; after `give_up` seconds fall back to a stream synchronise (a very long call)."""
+    import time
+    t0 = time.perf_counter()
+    while view[0] == _PENDING:
+        waited = time.perf_counter() - t0
+        if waited > give_up:
+            stream_sync(device)
+            break
+        if waited > 2e-3:
+            time.sleep(0)                                    # let other Python threads run between polls
+    return int(view[0])
 
 
 _ws_cache = {}

@@ -429,32 +429,42 @@ namespace obb {
 //   pred_polyn (n,10) = scale_polys(pred_poly): (x - pad_x) / gain, (y - pad_y) / gain     native image space
 //   pred_hbbn  (n,6)  = [xywh2xyxy(poly2hbb(polyn)), conf, cls]
 // (utils/rboxs_utils.py:106-181, utils/general.py:590-597 xywh2xyxy, :636-650 scale_polys)
+// corners of one rbox (utils/rboxs_utils.py:106-145) and the horizontal box around 8 coordinates (poly2hbb + xywh2xyxy)
+__device__ __forceinline__ void vt_rbox2poly(float x, float y, float w, float h, float th, float* p) {
+  const float Cos = cosf(th), Sin = sinf(th);
+  const float v1x = w / 2 * Cos, v1y = -w / 2 * Sin, v2x = -h / 2 * Sin, v2y = -h / 2 * Cos;
+  p[0] = x + v1x + v2x; p[1] = y + v1y + v2y; p[2] = x + v1x - v2x; p[3] = y + v1y - v2y;
+  p[4] = x - v1x - v2x; p[5] = y - v1y - v2y; p[6] = x - v1x + v2x; p[7] = y - v1y + v2y;
+}
+__device__ __forceinline__ void vt_hbb_xyxy(const float* q, float* o) {
+  const float xmax = fmaxf(fmaxf(q[0], q[2]), fmaxf(q[4], q[6])), xmin = fminf(fminf(q[0], q[2]), fminf(q[4], q[6]));
+  const float ymax = fmaxf(fmaxf(q[1], q[3]), fmaxf(q[5], q[7])), ymin = fminf(fminf(q[1], q[3]), fminf(q[5], q[7]));
+  const float xc = (xmax + xmin) / 2.0f, yc = (ymax + ymin) / 2.0f, bw = xmax - xmin, bh = ymax - ymin;   // poly2hbb
+  o[0] = xc - bw / 2; o[1] = yc - bh / 2; o[2] = xc + bw / 2; o[3] = yc + bh / 2;                          // xywh2xyxy
+}
+// the four outputs of val.py:226-236 for detection row i (any output pointer may be NULL); returns pred_hbbn's box in o4n
+__device__ __forceinline__ void vt_post_one(const float* __restrict__ r, long long i, float pad_x, float pad_y, float gain,
+                                            float* __restrict__ poly10, float* __restrict__ hbb6, float* __restrict__ polyn10,
+                                            float* __restrict__ hbbn6, float* o4n) {
+  const float conf = r[5], cls = r[6];
+  float p[8], o4[4];
+  vt_rbox2poly(r[0], r[1], r[2], r[3], r[4], p);
+  if (poly10) { for (int k = 0; k < 8; k++) poly10[i * 10 + k] = p[k]; poly10[i * 10 + 8] = conf; poly10[i * 10 + 9] = cls; }
+  if (hbb6) { vt_hbb_xyxy(p, o4); for (int k = 0; k < 4; k++) hbb6[i * 6 + k] = o4[k]; hbb6[i * 6 + 4] = conf; hbb6[i * 6 + 5] = cls; }
+  float pn[8];
+#pragma unroll
+  for (int k = 0; k < 8; k++) pn[k] = (p[k] - ((k & 1) ? pad_y : pad_x)) / gain;
+  if (polyn10) { for (int k = 0; k < 8; k++) polyn10[i * 10 + k] = pn[k]; polyn10[i * 10 + 8] = conf; polyn10[i * 10 + 9] = cls; }
+  vt_hbb_xyxy(pn, o4n);
+  if (hbbn6) { for (int k = 0; k < 4; k++) hbbn6[i * 6 + k] = o4n[k]; hbbn6[i * 6 + 4] = conf; hbbn6[i * 6 + 5] = cls; }
+}
 __global__ void k_val_post(const float* __restrict__ det7, long long n, float pad_x, float pad_y, float gain,
                            float* __restrict__ poly10, float* __restrict__ hbb6, float* __restrict__ polyn10,
                            float* __restrict__ hbbn6) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const float* r = det7 + i * 7;
-  const float x = r[0], y = r[1], w = r[2], h = r[3], th = r[4], conf = r[5], cls = r[6];
-  const float Cos = cosf(th), Sin = sinf(th);
-  const float v1x = w / 2 * Cos, v1y = -w / 2 * Sin, v2x = -h / 2 * Sin, v2y = -h / 2 * Cos;
-  float p[8];
-  p[0] = x + v1x + v2x; p[1] = y + v1y + v2y; p[2] = x + v1x - v2x; p[3] = y + v1y - v2y;
-  p[4] = x - v1x - v2x; p[5] = y - v1y - v2y; p[6] = x - v1x + v2x; p[7] = y - v1y + v2y;
-  auto hbb_xyxy = [](const float* q, float* o) {
-    const float xmax = fmaxf(fmaxf(q[0], q[2]), fmaxf(q[4], q[6])), xmin = fminf(fminf(q[0], q[2]), fminf(q[4], q[6]));
-    const float ymax = fmaxf(fmaxf(q[1], q[3]), fmaxf(q[5], q[7])), ymin = fminf(fminf(q[1], q[3]), fminf(q[5], q[7]));
-    const float xc = (xmax + xmin) / 2.0f, yc = (ymax + ymin) / 2.0f, bw = xmax - xmin, bh = ymax - ymin;   // poly2hbb
-    o[0] = xc - bw / 2; o[1] = yc - bh / 2; o[2] = xc + bw / 2; o[3] = yc + bh / 2;                          // xywh2xyxy
-  };
-  float o4[4];
-  if (poly10) { for (int k = 0; k < 8; k++) poly10[i * 10 + k] = p[k]; poly10[i * 10 + 8] = conf; poly10[i * 10 + 9] = cls; }
-  if (hbb6) { hbb_xyxy(p, o4); for (int k = 0; k < 4; k++) hbb6[i * 6 + k] = o4[k]; hbb6[i * 6 + 4] = conf; hbb6[i * 6 + 5] = cls; }
-  float pn[8];
-#pragma unroll
-  for (int k = 0; k < 8; k++) pn[k] = (p[k] - ((k & 1) ? pad_y : pad_x)) / gain;
-  if (polyn10) { for (int k = 0; k < 8; k++) polyn10[i * 10 + k] = pn[k]; polyn10[i * 10 + 8] = conf; polyn10[i * 10 + 9] = cls; }
-  if (hbbn6) { hbb_xyxy(pn, o4); for (int k = 0; k < 4; k++) hbbn6[i * 6 + k] = o4[k]; hbbn6[i * 6 + 4] = conf; hbbn6[i * 6 + 5] = cls; }
+  float o4n[4];
+  vt_post_one(det7 + i * 7, i, pad_x, pad_y, gain, poly10, hbb6, polyn10, hbbn6, o4n);
 }
 
 // val.py:69-90 process_batch.  The reference keeps, per detection, its highest-IoU label among those with the same class and
@@ -490,6 +500,78 @@ __global__ void k_pb_correct(const int* __restrict__ best_label, const float* __
   for (int k = 0; k < niou; k++) correct[(size_t)d * niou + k] = (win && best_iou[d] >= iouv[k]) ? 1 : 0;
 }
 
+
+// ---- the tail for ALL images of a batch (val.py:209-250): three launches and one device -> host copy per batch instead of
+// two launches + a memset + three copies per image.
+constexpr int kValTailMaxBs = 64;
+struct ValTailImgs {                       // by value in the kernel arguments (bs <= kValTailMaxBs)
+  int det_off[kValTailMaxBs + 1];          // detections of image b: rows [det_off[b], det_off[b + 1]) of the packed list
+  float pad_x[kValTailMaxBs], pad_y[kValTailMaxBs], gain[kValTailMaxBs], shape_w[kValTailMaxBs], shape_h[kValTailMaxBs];
+  int bs;
+};
+// labels (val.py:238-241, in the reference's operation order): rbox2poly -> poly2hbb -> xywh2xyxy in the letterboxed frame,
+// THEN scale_coords: subtract the pad, divide by the gain, clip to the native shape (utils/general.py:621-633) -> [x1 y1 x2 y2]
+__global__ void k_vt_labels(const float* __restrict__ targets, int nt, int tcols, ValTailImgs im, float* __restrict__ lab4,
+                            int* __restrict__ winner) {
+  const int l = blockIdx.x * blockDim.x + threadIdx.x;
+  if (l >= nt) return;
+  const float* t = targets + (size_t)l * tcols;               // [img cls cx cy l s theta ...]
+  const int b = (int)t[0];
+  float p[8], o[4] = {0.f, 0.f, 0.f, 0.f};
+  if (b >= 0 && b < im.bs) {
+    vt_rbox2poly(t[2], t[3], t[4], t[5], t[6], p);
+    vt_hbb_xyxy(p, o);
+    o[0] -= im.pad_x[b]; o[2] -= im.pad_x[b]; o[1] -= im.pad_y[b]; o[3] -= im.pad_y[b];
+#pragma unroll
+    for (int k = 0; k < 4; k++) o[k] /= im.gain[b];
+    o[0] = fminf(fmaxf(o[0], 0.f), im.shape_w[b]); o[2] = fminf(fmaxf(o[2], 0.f), im.shape_w[b]);
+    o[1] = fminf(fmaxf(o[1], 0.f), im.shape_h[b]); o[3] = fminf(fmaxf(o[3], 0.f), im.shape_h[b]);
+  }
+#pragma unroll
+  for (int k = 0; k < 4; k++) lab4[(size_t)l * 4 + k] = o[k];
+  winner[l] = 0x7fffffff;
+}
+// per detection: the four outputs of val.py:226-236 and its best label (process_batch, see k_pb_best) among the labels of ITS image
+__global__ void k_vt_dets(const float* __restrict__ det7, int n, ValTailImgs im, const float* __restrict__ targets, int nt, int tcols,
+                          const float* __restrict__ lab4, const float* __restrict__ iouv, float* __restrict__ poly10,
+                          float* __restrict__ hbb6, float* __restrict__ polyn10, float* __restrict__ hbbn6,
+                          int* __restrict__ best_label, float* __restrict__ best_iou, int* __restrict__ winner) {
+  const int d = blockIdx.x * blockDim.x + threadIdx.x;
+  if (d >= n) return;
+  int b = 0;
+  while (b + 1 < im.bs && d >= im.det_off[b + 1]) b++;           // (bs <= 64: a short scan of kernel-argument registers)
+  float b2[4];
+  vt_post_one(det7 + (size_t)d * 7, d, im.pad_x[b], im.pad_y[b], im.gain[b], poly10, hbb6, polyn10, hbbn6, b2);
+  const float cls = det7[(size_t)d * 7 + 6];
+  const float thr0 = iouv[0];                                            // val.py:81  iou >= iouv[0]
+  const float area2 = (b2[2] - b2[0]) * (b2[3] - b2[1]);
+  int bl = -1; float bi = -1.f;
+  for (int l = 0; l < nt; l++) {
+    const float* t = targets + (size_t)l * tcols;
+    if ((int)t[0] != b || t[1] != cls) continue;
+    const float* b1 = lab4 + (size_t)l * 4;
+    const float area1 = (b1[2] - b1[0]) * (b1[3] - b1[1]);
+    const float iw = fmaxf(fminf(b1[2], b2[2]) - fmaxf(b1[0], b2[0]), 0.f);
+    const float ih = fmaxf(fminf(b1[3], b2[3]) - fmaxf(b1[1], b2[1]), 0.f);
+    const float inter = iw * ih;
+    const float iou = inter / (area1 + area2 - inter);                 // utils/metrics.py:265-268
+    if (iou >= thr0 && iou > bi) { bi = iou; bl = l; }
+  }
+  best_label[d] = bl; best_iou[d] = bi;
+  if (bl >= 0) atomicMin(&winner[bl], d);       // (detection indices grow with the image and inside it: the lowest index of the image wins)
+}
+// stats row of detection d: correct[0 .. niou) as 0 / 1, then conf, then cls (val.py:250's tuple, one copy for the batch)
+__global__ void k_vt_stats(const float* __restrict__ det7, const int* __restrict__ best_label, const float* __restrict__ best_iou,
+                           const int* __restrict__ winner, const float* __restrict__ iouv, int n, int niou, float* __restrict__ stats) {
+  const int d = blockIdx.x * blockDim.x + threadIdx.x;
+  if (d >= n) return;
+  const int bl = best_label[d];
+  const bool win = bl >= 0 && winner[bl] == d;
+  float* o = stats + (size_t)d * (niou + 2);
+  for (int k = 0; k < niou; k++) o[k] = (win && best_iou[d] >= iouv[k]) ? 1.f : 0.f;
+  o[niou] = det7[(size_t)d * 7 + 5]; o[niou + 1] = det7[(size_t)d * 7 + 6];
+}
+
 }  // namespace obb
 
 extern "C" {
@@ -500,6 +582,43 @@ int obb_val_postprocess_f32(const float* det7, int64_t n, float pad_x, float pad
   if (n == 0) return OBB_OK;
   if (!det7) return OBB_ERR_BAD_ARG;
   obb::k_val_post<<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(det7, n, pad_x, pad_y, gain, poly10, hbb6, polyn10, hbbn6);
+  return hipGetLastError() == hipSuccess ? OBB_OK : OBB_ERR_LAUNCH;
+}
+
+size_t obb_val_tail_batch_workspace_bytes(int64_t n_det, int64_t nt) {
+  return (size_t)(n_det > 0 ? n_det : 1) * 8 + (size_t)(nt > 0 ? nt : 1) * 20 + 512;
+}
+
+int obb_val_tail_batch_f32(const float* det7, const int64_t* det_off_host, int64_t bs, const float* targets, int64_t nt, int64_t tcols,
+                           const float* img5_host, const float* iouv, int niou, float* poly10, float* hbb6, float* polyn10,
+                           float* hbbn6, float* stats, void* ws, size_t ws_bytes, void* stream) {
+  if (bs < 1 || bs > obb::kValTailMaxBs || nt < 0 || niou < 1 || !det_off_host || !img5_host || !iouv) return OBB_ERR_BAD_ARG;
+  if (nt > 0 && (!targets || tcols < 7)) return OBB_ERR_BAD_ARG;
+  const int64_t n = det_off_host[bs];
+  if (n < 0 || n > 0x7fffffff || nt > 0x7fffffff || det_off_host[0] != 0) return OBB_ERR_BAD_ARG;
+  obb::ValTailImgs im;
+  im.bs = (int)bs;
+  for (int b = 0; b <= (int)bs; b++) {
+    if (b > 0 && det_off_host[b] < det_off_host[b - 1]) return OBB_ERR_BAD_ARG;
+    im.det_off[b] = (int)det_off_host[b];
+  }
+  for (int b = 0; b < (int)bs; b++) {
+    const float* q = img5_host + (size_t)b * 5;                 // pad_x, pad_y, gain, native width, native height
+    if (!(q[2] > 0.f)) return OBB_ERR_BAD_ARG;
+    im.pad_x[b] = q[0]; im.pad_y[b] = q[1]; im.gain[b] = q[2]; im.shape_w[b] = q[3]; im.shape_h[b] = q[4];
+  }
+  if (n == 0) return OBB_OK;
+  if (!det7 || !stats) return OBB_ERR_BAD_ARG;
+  if (!ws || ws_bytes < obb_val_tail_batch_workspace_bytes(n, nt)) return OBB_ERR_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  int* best_label = (int*)ws;
+  float* best_iou = (float*)(best_label + n);
+  float* lab4 = (float*)(((uintptr_t)(best_iou + n) + 255) & ~(uintptr_t)255);
+  int* winner = (int*)(lab4 + (size_t)(nt > 0 ? nt : 1) * 4);
+  if (nt > 0) obb::k_vt_labels<<<(unsigned)((nt + 255) / 256), 256, 0, st>>>(targets, (int)nt, (int)tcols, im, lab4, winner);
+  obb::k_vt_dets<<<(unsigned)((n + 127) / 128), 128, 0, st>>>(det7, (int)n, im, targets, (int)nt, (int)tcols, lab4, iouv, poly10, hbb6, polyn10, hbbn6,
+                                                            best_label, best_iou, winner);
+  obb::k_vt_stats<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(det7, best_label, best_iou, winner, iouv, (int)n, niou, stats);
   return hipGetLastError() == hipSuccess ? OBB_OK : OBB_ERR_LAUNCH;
 }
 

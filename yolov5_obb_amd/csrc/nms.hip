@@ -390,7 +390,6 @@ struct Carve {
   u64* prof;                           // in-kernel phase timing (OBB_NMS_PHASE_PROF=1)
   int4* plan;                          // per-workgroup team plan (k_plan_teams)
   uint32_t *rows, *edges;
-  uint32_t* rows_el; int* nrows_el; long long rows_el_stride;   // early / late rows of overlapped steps (single list with the index: nms_core.h)
   long long ecap;
   GridDev grid;                        // spatial index (rotated boxes, single list); grid.meta == NULL: not carved
   size_t grid_zero_bytes;              // GridMeta + slot counters: one contiguous block, zeroed before every build
@@ -456,13 +455,9 @@ static int carve(void* base, int64_t n, int64_t nseg, int recq, int C, Carve* cv
   cv->ecap = (long long)C * (C - 1) / 2; if (cv->ecap < 1) cv->ecap = 1;
   cv->edges = (uint32_t*)take(nteams * (size_t)cv->ecap * 4);
   cv->grid = GridDev{}; cv->grid_zero_bytes = 0;
-  cv->rows_el = nullptr; cv->nrows_el = nullptr; cv->rows_el_stride = 0;
   if (recq == RotGeom::RECQ && nseg == 1 && n >= kGridMinN) {
     const uint32_t M = grid_slots(n);
     cv->grid.mask = M - 1;
-    cv->rows_el_stride = 2LL * (C + 16);                       // the one list's team, or one team per slab; early half: count + rows
-    cv->rows_el = (uint32_t*)take((size_t)(kMaxSlabs + 1) * (size_t)cv->rows_el_stride * 4);
-    cv->nrows_el = (int*)take((size_t)(kMaxSlabs + 1) * 2 * 4);
     const size_t slab_tot_bytes = (size_t)(1 + kMaxTeams / 16) * kMaxSlabs * 4;   // slab totals + group totals (slab_setup)
     const size_t slab_zero = align_up((size_t)kSlabCopies * kSlabWords * 4 + 64) + align_up(slab_tot_bytes);
     cv->grid_zero_bytes = align_up(sizeof(GridMeta)) + slab_zero + ((size_t)M + 4) * 4;
@@ -506,13 +501,23 @@ static int nms_window(long long max_keep) {
 constexpr size_t kPersistLdsMax = 159 * 1024;   // of the 160 KB per CU: exactly one workgroup per CU
 
 template <class G, bool GRID>
-static int launch_persist(const NmsArgs& a, unsigned nb, hipStream_t st) {
+static int launch_persist(const NmsArgs& a, unsigned nb, hipStream_t st) {   // nb <= number of CUs (nms_grid); static teams and plans are made for that grid
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute((const void*)k_nms_persist<G, GRID>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPersistLdsMax) != hipSuccess)
       return OBB_ERR_LAUNCH;
     attr_set = true;
   }
+  // every workgroup of the launch must be resident at once (team barriers): the grid is bounded by what the occupancy
+  // calculation gives for this instantiation with its largest LDS footprint -- asked once, not assumed
+  static int wg_per_cu = -1;
+  if (wg_per_cu < 0) {
+    int nblk = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nblk, (const void*)k_nms_persist<G, GRID>, kNmsThreads, kPersistLdsMax) != hipSuccess) return OBB_ERR_LAUNCH;
+    wg_per_cu = nblk;
+  }
+  if (wg_per_cu < 1) return OBB_ERR_LAUNCH;
+  { const long long resident = (long long)wg_per_cu * hw_cu_count(); if ((long long)nb > resident) nb = (unsigned)resident; }
   size_t lds = sizeof(WaveLds<G>) * kNmsWaves;                // pair phases: one scratch block per wave
   if (lds < (size_t)6 * a.capmax) return OBB_ERR_INTERNAL;    // (aliased by resolve: state + blocked bytes of one chunk + its ordered output list)
   lds += (size_t)a.capmax * 4;                                // + this workgroup's copy of the chunk list
@@ -681,9 +686,6 @@ static int run_nms(int kind, const float* boxes, int stride, const float* scores
   a.rec = cv.rec; a.order = cv.vals_b; a.alive = cv.alive; a.seg_begin = cv.seg_begin; a.seg_end = cv.seg_end;
   a.keep_cnt = cv.keep_cnt; a.keep_out = keep_out;
   a.rows = cv.rows; a.nrows = cv.nrows; a.edges = cv.edges; a.nedges = cv.nedges;
-  static int no_ovl = -1;                                          // OBB_NMS_NO_OVL=1: A/B switch for measurements (classic steps only)
-  if (no_ovl < 0) { const char* e = getenv("OBB_NMS_NO_OVL"); no_ovl = (e && atoi(e)) ? 1 : 0; }
-  a.rows_el = no_ovl ? nullptr : cv.rows_el; a.nrows_el = cv.nrows_el; a.rows_el_stride = cv.rows_el_stride;
   a.ecap = cv.ecap; a.n = (int)n; a.capmax = C;
   a.max_keep = (int)(max_keep > 0x7fffffffLL ? 0x7fffffffLL : (max_keep < 0 ? 0 : max_keep));
   a.window = nms_window(a.max_keep);

@@ -49,10 +49,6 @@ struct NmsArgs {
   int64_t* keep_out;         // segment g writes at keep_out[seg_begin[g] + k]
   uint32_t* rows;            // [n] kept rows (sorted positions) of segment g at rows[seg_begin[g] + k], k = kept index
   int* nrows;                // [nteams] rows kept in the team's current chunk
-  uint32_t* rows_el;         // [nteams][2][capmax] overlapped steps (k_nms_persist, OVL): the chunk's EARLY rows (no conflict edge points at
-                             // them: certainly kept, known after the resolver's first pass) and its LATE rows (kept in a later round)
-  int* nrows_el;             // [nteams][2]
-  long long rows_el_stride;  // uint32 entries per team (2 * the launch's capmax)
   uint32_t* edges;           // [nteams][ecap] (i << 16 | j), chunk-local indices, i < j
   int* nedges;               // [nteams]   (a team works on one segment at a time: scratch is per team)
   int* bar;                  // [nteams][2][64] arrive / go counters, one 256-byte line each
@@ -133,7 +129,6 @@ __device__ __forceinline__ void rows_reject2(const float4& myrow, int r, const C
   G::cheap_reject2(ax, ay, az, aw, c, r0, r1);
 }
 
-constexpr int kOvlMinEdges = 8192;         // overlapped steps (k_nms_persist) only pay for a chunk whose resolve outlasts a second pass of the cross phase
 constexpr int kBarGroups = 64;             // groups of 16 workgroups: grids of up to 1024
 constexpr int kNmsThreads = 512;
 constexpr int kNmsWaves = kNmsThreads / 64;
@@ -601,13 +596,10 @@ __device__ __forceinline__ void nms_pairs(const NmsArgs& a, int tm, int cn, cons
 // for the first rounds, until what is left of it fits.
 // LDS (aliasing the wave scratch): state[capmax] | blocked[capmax] | edges[...]
 // returns the number of kept boxes of the chunk (also published in nrows[g])
-// early_ev != 0 (overlapped step): as soon as the first pass over the edges is done, the boxes no edge points at -- kept whatever
-// the rounds decide -- are published as the team's EARLY rows (rows_el, count, then *ev_word = early_ev: the other workgroups start
-// their cross phase on them while the rounds run); the boxes kept in later rounds go to the LATE list.
 OBB_COLD_RESOLVE int nms_resolve(const NmsArgs& a, int g, int sb, int tm, int cn, int kept_before, const uint32_t* cidx, uint8_t* smem,
-                           size_t smem_bytes, int* s_i, int early_ev = 0, int* ev_word = nullptr) {
+                           size_t smem_bytes, int* s_i) {
   const int tid = threadIdx.x;
-  uint8_t* state = smem;              // 0 undecided, 1 kept, 2 dead, 3 kept in round 0 (an early row)
+  uint8_t* state = smem;              // 0 undecided, 1 kept, 2 dead
   uint8_t* blocked = smem + a.capmax;
   uint32_t* ledges = reinterpret_cast<uint32_t*>(smem + 2 * (size_t)a.capmax);
   const long long lcap = ((long long)smem_bytes - 2LL * a.capmax) / 4;
@@ -621,16 +613,6 @@ OBB_COLD_RESOLVE int nms_resolve(const NmsArgs& a, int g, int sb, int tm, int cn
   per |= 1;
   bool lds_mode = per <= percap;
   if (!lds_mode) per = percap;
-  if (early_ev != 0 && E < kOvlMinEdges) {
-    // few edges: the rounds are over before a separate pass over the late rows would have paid for itself -- no early rows
-    // (count 0, event at once: the others wait for the complete result and cross all rows in one pass)
-    if (tid == 0) {
-      stg_agent(a.rows_el + (size_t)tm * a.rows_el_stride, 0u);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      stg_agent(ev_word, early_ev);
-    }
-    early_ev = 0;
-  }
   int mycnt = 0;
   uint32_t* mine_e = ledges + (size_t)tid * per;
   if (lds_mode) {
@@ -665,7 +647,7 @@ OBB_COLD_RESOLVE int nms_resolve(const NmsArgs& a, int g, int sb, int tm, int cn
   // one edge (i < j) against the states read for it: true = both ends undecided, the edge stays and j waits for i
   auto decide = [&](uint32_t ed, uint8_t sj, uint8_t si) -> bool {
     if (sj != 0) return false;                       // target decided: the edge is done
-    if (si & 1) { state[ed & 0xffff] = 2; return false; }    // kept source kills the target
+    if (si == 1) { state[ed & 0xffff] = 2; return false; }   // kept source kills the target
     if (si == 2) return false;                       // dead source never matters again
     blocked[ed & 0xffff] = 1;
     return true;
@@ -723,37 +705,13 @@ OBB_COLD_RESOLVE int nms_resolve(const NmsArgs& a, int g, int sb, int tm, int cn
     }
     __syncthreads();
     bool rem = false;
-    const uint8_t kept_mark = (early_ev != 0 && round == 0) ? 3 : 1;
     for (int j = tid; j < cn; j += kNmsThreads) {
       if (state[j] == 0) {
         if (blocked[j]) { rem = true; blocked[j] = 0; }
-        else state[j] = kept_mark;
+        else state[j] = 1;
       }
     }
     const int any = __syncthreads_or(rem ? 1 : 0);     // barrier + "somebody is still undecided" in one
-    if (early_ev != 0 && round == 0) {
-      // the early rows (any order: the cross phases do not care) behind their count in entry 0, then the event -- all
-      // write-through, ONE drain in between
-      uint32_t* er = a.rows_el + (size_t)tm * a.rows_el_stride;
-      if (tid == 0) s_i[9] = 0;
-      __syncthreads();
-      for (int j0 = 0; j0 < cn; j0 += kNmsThreads) {
-        const int j = j0 + tid;
-        const bool f = j < cn && state[j] == 3;
-        const u64 fm = __ballot(f);
-        if (fm) {
-          int base = 0;
-          if ((tid & 63) == 0) base = atomicAdd(&s_i[9], __popcll(fm));
-          base = __shfl(base, 0);
-          if (f) stg_agent(er + 1 + base + __popcll(fm & lanemask_lt()), cidx[j]);
-        }
-      }
-      __syncthreads();
-      if (tid == 0) stg_agent(er, (uint32_t)s_i[9]);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-      if (tid == 0) stg_agent(ev_word, early_ev);
-    }
     if (!any) { if (a.prof && tid == 0) atomicAdd(a.prof + 11, (u64)(round + 1)); break; }
     if (!lds_mode) {
       if (compact) lds_mode = true;                                        // the survivors are in LDS now
@@ -768,7 +726,7 @@ OBB_COLD_RESOLVE int nms_resolve(const NmsArgs& a, int g, int sb, int tm, int cn
   int mine = 0;
   for (int q = 0; q < per_n; q++) {
     const int j = tid * per_n + q;
-    if (j < cn && (state[j] & 1)) mine++;
+    if (j < cn && state[j] == 1) mine++;
   }
   int incl = mine;
 #pragma unroll
@@ -783,9 +741,7 @@ OBB_COLD_RESOLVE int nms_resolve(const NmsArgs& a, int g, int sb, int tm, int cn
   for (int k = 0; k < kNmsWaves; k++) { const int t = s_i[k]; if (k < (tid >> 6)) wpre += t; total += t; }
   int rank = wpre + incl - mine;
   uint32_t* rows = a.rows + (size_t)sb + kept_before;         // appended to the segment's kept-row list
-  uint32_t* lr = early_ev != 0 ? a.rows_el + (size_t)tm * a.rows_el_stride + a.rows_el_stride / 2 : nullptr;
-  if (early_ev != 0 && tid == 0) s_i[10] = 0;
-  // Two passes: the kept positions first go to an ordered list in LDS (the edge blocks are free now; top bit = a late row),
+  // Two passes: the kept positions first go to an ordered list in LDS (the edge blocks are free now),
   // then thread t emits entries t, t + 512, ... four at a time -- the gather of the original indices (or of the slab copy's
   // old positions) is four independent loads per thread instead of a chain of up to 16 dependent ones (measured: 22 us of
   // every 8192-box chunk of the uniform regime sat in this loop).
@@ -793,7 +749,7 @@ OBB_COLD_RESOLVE int nms_resolve(const NmsArgs& a, int g, int sb, int tm, int cn
   __syncthreads();
   for (int q = 0; q < per_n; q++) {
     const int j = tid * per_n + q;
-    if (j < cn && (state[j] & 1)) { olist[rank] = cidx[j] | (state[j] == 1 && early_ev != 0 ? 0x80000000u : 0u); rank++; }
+    if (j < cn && state[j] == 1) { olist[rank] = cidx[j]; rank++; }
   }
   __syncthreads();
   for (int k0 = tid; k0 < total; k0 += 4 * kNmsThreads) {
@@ -807,7 +763,7 @@ OBB_COLD_RESOLVE int nms_resolve(const NmsArgs& a, int g, int sb, int tm, int cn
     }
 #pragma unroll
     for (int u = 0; u < 4; u++) {
-      const uint32_t pos = pv[u] & 0x7fffffffu;
+      const uint32_t pos = pv[u];
       ov[u] = 0u;
       if (ok[u]) ov[u] = a.keep_out != nullptr ? (a.order ? a.order[pos] : pos) : a.pos_old[pos];
     }
@@ -815,9 +771,8 @@ OBB_COLD_RESOLVE int nms_resolve(const NmsArgs& a, int g, int sb, int tm, int cn
     for (int u = 0; u < 4; u++) {
       if (!ok[u]) continue;
       const int k = k0 + u * kNmsThreads;
-      const uint32_t pos = pv[u] & 0x7fffffffu;
+      const uint32_t pos = pv[u];
       stg_agent(rows + k, pos);
-      if (pv[u] >> 31) stg_agent(lr + atomicAdd(&s_i[10], 1), pos);            // (a late row: few per chunk)
       const long long o = (long long)kept_before + k;
       if (a.keep_out != nullptr) {
         if (a.max_keep <= 0 || o < a.max_keep) a.keep_out[(size_t)sb + o] = (int64_t)ov[u];
@@ -834,7 +789,6 @@ OBB_COLD_RESOLVE int nms_resolve(const NmsArgs& a, int g, int sb, int tm, int cn
     stg_agent(a.nrows + tm, total);
     stg_agent(a.nedges + tm, 0);
     stg_agent(a.keep_cnt + g, kept_before + total);   // write-through: resolvers of different steps sit on different XCDs
-    if (early_ev != 0) stg_agent(a.nrows_el + 2 * tm + 1, s_i[10]);
   }
   __syncthreads();
   plap(14);
@@ -1362,7 +1316,6 @@ __device__ __forceinline__ void nms_cross_grid(const NmsArgs& a, const GridPlan&
 }
 
 constexpr int kGridMinRows = 512;
-constexpr int kOvlMinTeam = 8;               // overlapped steps need a team in which one workgroup less does not matter
 
 // Counting sort of the still-alive positions [c0, n) by table slot, by the whole team (= the whole grid: one segment):
 // classify + count -> barrier -> distributed scan (every workgroup a slice of the table, then the prefix of the workgroup
@@ -1715,7 +1668,6 @@ OBB_COLD_SLAB void slab_merge(const u64* kept_bits, int n, const uint32_t* order
 template <class G, bool GRID>
 __global__ __launch_bounds__(kNmsThreads) __attribute__((amdgpu_waves_per_eu(1, 2))) void k_nms_persist(NmsArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  constexpr bool OVL = GRID;               // overlapped steps: the single-list instantiation (wide teams); see the step loop
   __shared__ int s_i[16];
   __shared__ int s_flag;
   __shared__ int s_bb[kNmsWaves][4];
@@ -1789,7 +1741,6 @@ __global__ __launch_bounds__(kNmsThreads) __attribute__((amdgpu_waves_per_eu(1, 
   WaveLds<G>& L = reinterpret_cast<WaveLds<G>*>(smem)[wv];
   uint32_t* cidx = reinterpret_cast<uint32_t*>(smem + sizeof(WaveLds<G>) * kNmsWaves);
   const int tw = wg * kNmsWaves + wv, ntw = T * kNmsWaves;
-  int tw_c = tw, ntw_c = ntw;                          // the cross phase's share (the early rows of an overlapped step: T - 1 workgroups)
   TeamBar bar{a.bar + (size_t)bar_line * 128, a.bar + (size_t)bar_line * 128 + 64, T, 0, a.abort_flag,
               (bar_line == 0 && T == NB && NB > 32) ? a.bar_sub : nullptr, wg};       // (the one team of a single list shares the grid's counters)
   if (!slab_mode && bar_line == 0) bar.epoch = gbar.epoch;   // (a set-up that decided against slabs has used the grid's line already)
@@ -1823,7 +1774,7 @@ __global__ __launch_bounds__(kNmsThreads) __attribute__((amdgpu_waves_per_eu(1, 
         }
       }
       if (grid_on && nr >= kGridMinRows) {
-        nms_cross_grid<G>(a, gp, glevels, rows, nr, c0, c1, tw_c, ntw_c, L, &s_i[12]);
+        nms_cross_grid<G>(a, gp, glevels, rows, nr, c0, c1, tw, ntw, L, &s_i[12]);
         if (n_brute > 0) {
           // the boxes the index leaves out: brute kept rows against every column, every kept row against the brute columns
           // (the chunk list in LDS is free between resolve and the next select: it takes the brute rows, capmax at a time)
@@ -1852,15 +1803,15 @@ __global__ __launch_bounds__(kNmsThreads) __attribute__((amdgpu_waves_per_eu(1, 
               nbr += tot;
             }
             __syncthreads();
-            if (nbr > 0) nms_cross<G, GRID>(a, cidx, nbr, c0, c1, nullptr, 0, tw_c, ntw_c, L);
+            if (nbr > 0) nms_cross<G, GRID>(a, cidx, nbr, c0, c1, nullptr, 0, tw, ntw, L);
             __syncthreads();                                     // the list is read until here
           }
-          nms_cross<G, GRID>(a, rows, nr, c0, c1, a.ulist, n_brute, tw_c, ntw_c, L);
+          nms_cross<G, GRID>(a, rows, nr, c0, c1, a.ulist, n_brute, tw, ntw, L);
         }
         return;
       }
     }
-    nms_cross<G, GRID>(a, rows, nr, c0, c1, nullptr, 0, tw_c, ntw_c, L);
+    nms_cross<G, GRID>(a, rows, nr, c0, c1, nullptr, 0, tw, ntw, L);
   };
 
   const int plan_chunk = a.cap_first < a.capmax ? a.cap_first : a.capmax;
@@ -1880,18 +1831,6 @@ __global__ __launch_bounds__(kNmsThreads) __attribute__((amdgpu_waves_per_eu(1, 
     // whose callers spill around the call): whoever needs one leaves a job, the head of the loop runs it.
     const uint32_t* jrows = nullptr;
     int jnr = 0, jc0 = 0, jc1 = 0;
-    // Overlapped steps (OVL kernels, teams of kOvlMinTeam workgroups and more).  The resolver of a step is a FIXED workgroup
-    // (rotating from step to step); everybody else does not wait for its result but for its first pass: the chunk's EARLY
-    // rows -- boxes no conflict edge points at, kept whatever the rounds decide -- are crossed against the later positions by
-    // the other T - 1 workgroups WHILE the rounds run (jmode 1); when the resolver is done the whole team crosses the few
-    // LATE rows (kept in a later round), then the step-end barrier.  A step that would have to build the spatial index (a
-    // team-wide affair) keeps the classic order: wait, then one cross phase over all rows.
-    int jmode = 0;               // 1: the job at hand is the early rows of an overlapped step
-    bool pend_bar = false;       // kills were applied since the last step-end barrier
-    bool crossed0 = false;       // the early rows of the current overlapped step were crossed
-    int ostep = 0;               // overlapped steps so far (the resolver's event word counts 2 per step)
-    int o_cn = 0;
-    int* const ev_word = bar.arrive + 32;
     for (;;) {
       if (jnr > 0) {
         const u64 tcz = (a.prof && tid == 0) ? wall_clock64() : 0ull;
@@ -1899,36 +1838,9 @@ __global__ __launch_bounds__(kNmsThreads) __attribute__((amdgpu_waves_per_eu(1, 
         if (aborted) return;
         if (a.prof && tid == 0) { atomicMax(a.prof + 31, wall_clock64() - tcz); }
         lap(5);
-        jnr = 0;
-        pend_bar = true;
-      }
-      if constexpr (OVL) {
-        if (jmode == 1) {                                  // second half of an overlapped step: the resolver's result
-          jmode = 0; tw_c = tw; ntw_c = ntw;
-          if (tid == 0) {
-            s_flag = spin_until(ev_word, 2 * ostep, a.abort_flag) ? 0 : 1;
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-          }
-          __syncthreads();
-          if (s_flag != 0) return;
-          lap(3);
-          const int nr = ldg_agent(a.nrows + team), nr1 = ldg_agent(a.nrows_el + 2 * team + 1);
-          const bool more = cur < wend && !(a.max_keep > 0 && kept + nr >= a.max_keep);
-          const int kept_before = kept;
-          kept += nr;
-          if (prof) a.prof[6] += 1;
-          if (cap < a.capmax) { cap *= (a.grow_sparse > 2 && 2 * nr > o_cn) ? a.grow_sparse : 2; if (cap > a.capmax) cap = a.capmax; }
-          if (more) {
-            if (crossed0) { if (nr1 > 0) { jrows = a.rows_el + (size_t)team * a.rows_el_stride + a.rows_el_stride / 2; jnr = nr1; } }
-            else if (nr > 0) { jrows = a.rows + sb + kept_before; jnr = nr; }
-            if (jnr > 0) { jc0 = cur; jc1 = wend; continue; }
-          }
-        }
-      }
-      if (pend_bar) {
         if (!team_barrier(bar, &s_flag)) return;           // the kills are visible before anybody selects again
         lap(0);
-        pend_bar = false;
+        jnr = 0;
       }
       if (!(cur < se && !(a.max_keep > 0 && kept >= a.max_keep))) break;
       if (cur >= wend) {                                   // open the next window: every row kept so far against it
@@ -1943,55 +1855,11 @@ __global__ __launch_bounds__(kNmsThreads) __attribute__((amdgpu_waves_per_eu(1, 
       nms_pairs<G, GRID>(a, team, cn, cidx, tw, ntw, L, &s_i[12]);
       if (a.prof && tid == 0) { const u64 d = wall_clock64() - tpz; atomicMax(a.prof + 29, d); atomicAdd(a.prof + 30, d); }
       lap(2);
-      if constexpr (OVL) {
-        if (T >= kOvlMinTeam && a.rows_el != nullptr) {
-          ostep++;
-          o_cn = cn;
-          const int rz = ostep % T;                        // this step's resolver
-          // arrival: everybody; only the resolver waits until all edges are out
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          __syncthreads();
-          if (tid == 0) {
-            int fl = 0;
-            const bool last = bar_arrive(bar);
-            if (last) stg_agent(bar.go, bar.epoch + 1);
-            if (wg == rz) {
-              if (!last) fl = spin_until(bar.go, bar.epoch + 1, a.abort_flag) ? 0 : 1;
-              __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            } else {
-              fl = spin_until(ev_word, 2 * ostep - 1, a.abort_flag) ? 0 : 1;      // the early rows are out
-              __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            }
-            s_flag = fl;
-          }
-          __syncthreads();
-          bar.epoch++;
-          if (s_flag != 0) return;
-          int nr0;
-          if (wg == rz) {
-            lap(3);
-            const u64 ts = (a.prof && tid == 0) ? wall_clock64() : 0ull;
-            nms_resolve(a, g, sb, team, cn, kept, cidx, smem, sizeof(WaveLds<G>) * kNmsWaves, s_i, 2 * ostep - 1, ev_word);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (tid == 0) stg_agent(ev_word, 2 * ostep);     // rows, late rows and counts are out
-            if (a.prof && tid == 0) { atomicAdd(a.prof + 9, wall_clock64() - ts); }
-            lap(4);
-          }
-          nr0 = (int)ldg_agent(a.rows_el + (size_t)team * a.rows_el_stride);
-          // (uniform over the team: every workgroup evaluates the same numbers)
-          crossed0 = nr0 > 0 && cur < wend && !(a.max_keep > 0 && kept + nr0 >= a.max_keep) &&
-                     !(grid_on && !grid_built && nr0 >= kGridMinRows);
-          jmode = 1;
-          if (crossed0 && wg != rz) {
-            jrows = a.rows_el + (size_t)team * a.rows_el_stride + 1; jnr = nr0; jc0 = cur; jc1 = wend;
-            tw_c = (wg - (wg > rz ? 1 : 0)) * kNmsWaves + wv; ntw_c = (T - 1) * kNmsWaves;
-          }
-          if (crossed0) pend_bar = true;                   // (the resolver applies no kill of its own but meets the others at the barrier)
-          continue;
-        }
-      }
       // ---- all edges are out: the last arriver resolves the chunk, the others wait for its rows
+      // (Round 4 measured the alternative -- a fixed resolver publishes the rows no conflict edge points at after its first
+      //  pass, the other workgroups cross those while the rounds run, the few rows kept in later rounds get a second pass:
+      //  K=300 230 against 221 us, 18 classes 283 / 280, K=3000 550 / 543, uniform 1600 / 1597 -- the second pass costs what
+      //  the overlap saves, a chunk's resolve is only long when there is no cross phase behind it.  Not kept.)
       if (serial_begin(bar, &s_flag)) {
         lap(3);
         const u64 ts = (a.prof && tid == 0) ? wall_clock64() : 0ull;

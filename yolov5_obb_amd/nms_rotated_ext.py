@@ -21,7 +21,7 @@ def _run_rotated_once(dets, scores, iou_threshold, flags, max_keep):
     n = dets.shape[0]
     dev = dets.device
     keep = torch.empty(n, dtype=torch.int64, device=dev)
-    cnt = torch.empty(1, dtype=torch.int64, device=dev)
+    cnt, cnt_view = _lib.pinned_count(dev)
     with _lib.guard(dev):
         st = _lib.stream_handle(dev)
         nbytes = _ws_bytes.get(n)
@@ -33,7 +33,7 @@ def _run_rotated_once(dets, scores, iou_threshold, flags, max_keep):
         rc = L.obb_nms_rotated_f32(_lib.ptr(dets), _lib.ptr(scores), n, float(iou_threshold), int(flags), int(max_keep),
                                    _lib.ptr(keep), _lib.ptr(cnt), _lib.ptr(ws), ws.numel(), _lib.C.c_void_p(st))
     _lib.check(rc, "obb_nms_rotated_f32")
-    return keep[: _lib.checked_count(int(cnt.item()), "obb_nms_rotated_f32")]
+    return keep[: _lib.checked_count(_lib.wait_count(cnt_view, dev), "obb_nms_rotated_f32")]
 
 
 def nms_rotated(dets, scores, iou_threshold):
@@ -71,14 +71,14 @@ def _run_rotated_f64_once(dets, scores, iou_threshold, flags, max_keep):
     n = dets.shape[0]
     dev = dets.device
     keep = torch.empty(n, dtype=torch.int64, device=dev)
-    cnt = torch.empty(1, dtype=torch.int64, device=dev)
+    cnt, cnt_view = _lib.pinned_count(dev)
     with _lib.guard(dev):
         st = _lib.stream_handle(dev)
         ws = _lib.workspace(L.obb_nms_workspace_bytes(n, 1, 3), dev, st)
         rc = L.obb_nms_rotated_f64(_lib.ptr(dets), _lib.ptr(scores), n, float(iou_threshold), int(flags), int(max_keep),
                                    _lib.ptr(keep), _lib.ptr(cnt), _lib.ptr(ws), ws.numel(), _lib.C.c_void_p(st))
     _lib.check(rc, "obb_nms_rotated_f64")
-    return keep[: _lib.checked_count(int(cnt.item()), "obb_nms_rotated_f64")]
+    return keep[: _lib.checked_count(_lib.wait_count(cnt_view, dev), "obb_nms_rotated_f64")]
 
 
 def nms_poly(dets, iou_threshold):
@@ -100,10 +100,10 @@ def nms_poly(dets, iou_threshold):
     n, stride = dets.shape[0], dets.shape[1]
     dev = dets.device
     keep = torch.empty(n, dtype=torch.int64, device=dev)
-    cnt = torch.empty(1, dtype=torch.int64, device=dev)
+    cnt, cnt_view = _lib.pinned_count(dev)
     with _lib.guard(dev):
         ws = _lib.workspace(L.obb_nms_workspace_bytes(n, 1, 1), dev)
         rc = L.obb_nms_poly_f32(_lib.ptr(dets), stride, n, float(iou_threshold), 0, _lib.ptr(keep), _lib.ptr(cnt),
                                 _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev))
     _lib.check(rc, "obb_nms_poly_f32")
-    return keep[: _lib.checked_count(int(cnt.item()), "obb_nms_poly_f32")]
+    return keep[: _lib.checked_count(_lib.wait_count(cnt_view, dev), "obb_nms_poly_f32")]

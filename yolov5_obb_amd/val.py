@@ -58,3 +58,86 @@ def process_batch(detections, labels, iouv):
                                      ws.numel(), _lib.stream_ptr(dev))
     _lib.check(rc, "obb_process_batch_f32")
     return correct
+
+
+_TAIL_MAX_BS = 64      # csrc/head.hip kValTailMaxBs: images per obb_val_tail_batch_f32 call
+
+
+def val_tail_batch(preds, targets, shapes, iouv, want_boxes=False):
+    """The tail of val.py:209-250 for ALL images of a batch: three launches and ONE device -> host copy.
+
+    preds    list of (n_i, 7) CUDA tensors [x y l s theta conf cls], the output of non_max_suppression_obb (consecutive views
+             of its packed buffer are used in place; anything else is concatenated)
+    targets  (nt, >= 7) labels of the batch [img cls cx cy l s theta ...] in pixels of the letterboxed frame
+    shapes   per image (shape (h, w), ratio_pad ((gain, gain), (pad_x, pad_y))) as LoadImagesAndLabels yields them
+    Returns  stats: per image (correct bool (n_i, niou), conf (n_i), cls (n_i)) on the HOST -- what val.py:250 appends -- and,
+             with want_boxes, the packed device arrays (pred_poly, pred_hbb, pred_polyn, pred_hbbn) + the offsets."""
+    import ctypes as C
+    bs = len(preds)
+    if bs == 0:
+        return ([], None) if want_boxes else []
+    for p in preds:
+        _lib.require_cuda(p, "pred")
+    dev = preds[0].device
+    counts = [int(p.shape[0]) for p in preds]
+    n = sum(counts)
+    niou = int(iouv.shape[0])
+    packed = None
+    nz = [p for p in preds if p.shape[0]]
+    if nz and all(p.dtype == torch.float32 and p.is_contiguous() and p.shape[1] == 7 for p in nz):
+        base = nz[0].data_ptr()
+        ok = True
+        for p in nz:
+            ok = ok and p.data_ptr() == base
+            base += p.numel() * 4
+        if ok:                                                   # the split views of one packed buffer, in order
+            packed = torch.as_strided(nz[0], (n, 7), (7, 1))
+    if packed is None:
+        packed = torch.cat([p.to(torch.float32) for p in preds], 0).contiguous() if n else torch.zeros((0, 7), device=dev)
+    tg = targets.to(device=dev, dtype=torch.float32).contiguous()
+    nt, tcols = (int(tg.shape[0]), int(tg.shape[1])) if tg.dim() == 2 else (0, 0)
+    iv = iouv.to(device=dev, dtype=torch.float32).contiguous()
+    stats = torch.empty((n, niou + 2), dtype=torch.float32, device=dev)
+    boxes = None
+    if want_boxes:
+        boxes = (torch.empty((n, 10), dtype=torch.float32, device=dev), torch.empty((n, 6), dtype=torch.float32, device=dev),
+                 torch.empty((n, 10), dtype=torch.float32, device=dev), torch.empty((n, 6), dtype=torch.float32, device=dev))
+    L = _lib.lib()
+    offs = [0]
+    for c in counts:
+        offs.append(offs[-1] + c)
+    if n:
+        with _lib.guard(dev):
+            ws = _lib.workspace(L.obb_val_tail_batch_workspace_bytes(n, nt), dev)
+            for b0 in range(0, bs, _TAIL_MAX_BS):                # (one call for any batch size val.py uses)
+                b1 = min(bs, b0 + _TAIL_MAX_BS)
+                k = b1 - b0
+                doff = (C.c_int64 * (k + 1))(*[o - offs[b0] for o in offs[b0:b1 + 1]])
+                img5 = (C.c_float * (5 * k))()
+                for j in range(k):
+                    shape, ratio_pad = shapes[b0 + j][0], shapes[b0 + j][1]
+                    img5[5 * j + 0], img5[5 * j + 1] = float(ratio_pad[1][0]), float(ratio_pad[1][1])
+                    img5[5 * j + 2] = float(ratio_pad[0][0])
+                    img5[5 * j + 3], img5[5 * j + 4] = float(shape[1]), float(shape[0])
+                tgk = tg
+                if b0 or b1 < bs:                                # a chunk of a very large batch: its labels, re-based
+                    sel = (tg[:, 0] >= b0) & (tg[:, 0] < b1)
+                    tgk = tg[sel].clone()
+                    tgk[:, 0] -= b0
+                ntk = int(tgk.shape[0]) if tgk.dim() == 2 else 0
+                sl = slice(offs[b0], offs[b1])
+
+                def part(t):
+                    return _lib.ptr(t[sl]) if t is not None and offs[b1] > offs[b0] else C.c_void_p(0)
+                rc = L.obb_val_tail_batch_f32(part(packed), C.cast(doff, C.c_void_p), k, _lib.ptr(tgk) if ntk else C.c_void_p(0), ntk,
+                                              tcols, C.cast(img5, C.c_void_p), _lib.ptr(iv), niou,
+                                              part(boxes[0]) if boxes else C.c_void_p(0), part(boxes[1]) if boxes else C.c_void_p(0),
+                                              part(boxes[2]) if boxes else C.c_void_p(0), part(boxes[3]) if boxes else C.c_void_p(0),
+                                              part(stats), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev))
+                _lib.check(rc, "obb_val_tail_batch_f32")
+    host = stats.cpu()                                           # the one copy (and sync) of the batch
+    out = []
+    for b in range(bs):
+        h = host[offs[b]:offs[b + 1]]
+        out.append((h[:, :niou] > 0.5, h[:, niou].clone(), h[:, niou + 1].clone()))
+    return (out, (boxes, offs)) if want_boxes else out

@@ -51,6 +51,12 @@ def run(model, loader, n_total=None, conf_thres=0.001, iou_thres=0.4, half=True,
     (whole job), stats (rank 0: the four concatenated arrays in original image order), metrics (rank 0: what
     ap_per_class returned, or None).  collect=False: no exchange at all -- the rank's own seen / dt (a caller that only wants
     the time buckets and does its own reduction, bench.py)."""
+    # the HIP path's tail runs once per BATCH (val.val_tail_batch: three launches, one copy); injected stand-ins keep the
+    # reference's per-image loop
+    batch_tail = None
+    if postprocess is None and match is None:
+        from . import val as V
+        batch_tail = V.val_tail_batch
     if nms is None or postprocess is None or match is None:
         from . import val as V
         from .utils.general import non_max_suppression_obb
@@ -80,6 +86,21 @@ def run(model, loader, n_total=None, conf_thres=0.001, iou_thres=0.4, half=True,
             dt[1] += t3 - t2
             out = nms(out, conf_thres, iou_thres, multi_label=True, agnostic=single_cls)      # val.py:206
             dt[2] += _sync(device) - t3
+            if batch_tail is not None and device.type == "cuda":
+                if single_cls:
+                    for pred in out:
+                        pred[:, 6] = 0
+                tail = batch_tail(out, targets, shapes, iouv)                    # val.py:209-250 for the whole batch
+                tc = targets[:, :2].cpu() if len(targets) else torch.zeros((0, 2))     # (image, class) of every label: one copy
+                for si, pred in enumerate(out):
+                    tcls = tc[tc[:, 0] == si, 1].tolist()
+                    seen += 1
+                    if len(pred) == 0:
+                        per_image.append((torch.zeros(0, niou, dtype=torch.bool), torch.Tensor(), torch.Tensor(), tcls) if len(tcls) else None)
+                        continue
+                    correct, conf, pcls = tail[si]
+                    per_image.append((correct, conf, pcls, tcls))                # val.py:250
+                continue
             for si, pred in enumerate(out):
                 labels = targets[targets[:, 0] == si, 1:7]           # (n_gt, [cls cx cy l s theta])
                 nl = len(labels)
