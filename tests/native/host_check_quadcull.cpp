@@ -105,6 +105,7 @@ int main(int argc, char** argv) {
   const int NF = 10;
   double worst[NF] = {0}, worst_sum[NF] = {0};
   long used[NF] = {0}, culled = 0, wrong = 0;
+  long cone_skipped = 0, cone_wrong = 0, cone_overlapping_boxes = 0;
   float s0[10], s1[10], s2[10], s3[10];
   for (long i = 0; i < n; i++) {
     const int f = (int)(i % NF);
@@ -118,6 +119,20 @@ int main(int argc, char** argv) {
     }
     obb::QuadFeat P = obb::quad_make_feat(p), Q = obb::quad_make_feat(q);
     const bool disjoint = P.minx > Q.maxx || Q.minx > P.maxx || P.miny > Q.maxy || Q.miny > P.maxy;
+    // The exact rule (piou_device.h quad_cone_skip): whenever it fires -- in either role -- the 16-term sum must be EXACTLY +0
+    // and the IoU +0 (a property a single counter-example would falsify; the bounding boxes need not even be disjoint).
+    for (int role = 0; role < 2; role++) {
+      const obb::QuadFeat& A = role ? Q : P; const obb::QuadFeat& B = role ? P : Q;
+      if (obb::quad_cone_skip(obb::quad_cone_bits(A), obb::quad_cone_bits(B))) {
+        cone_skipped++;
+        if (!disjoint) cone_overlapping_boxes++;
+        float rebuilt;
+        const float it = inter_of(A, B, &rebuilt);
+        const float v = obb::quad_iou<1>(A, B, s0, s1, s2, s3);
+        uint32_t ib, vb; memcpy(&ib, &it, 4); memcpy(&vb, &v, 4);
+        if (ib != 0u || vb != 0u) cone_wrong++;
+      }
+    }
     if (!disjoint) {   // the skip works on outward-rounded fp16 boxes: it must never fire for overlapping bounding boxes
       for (int t = 0; t < 4; t++)
         if (obb::quad_skip_pair(obb::quad_skip_record(P, thrs[t]), obb::quad_skip_record(Q, thrs[t]))) { if (wrong < 5) printf("WRONG: skipped an overlapping pair\n"); wrong++; }
@@ -175,6 +190,7 @@ int main(int argc, char** argv) {
     w = fmax(w, worst[f]); ws = fmax(ws, worst_sum[f]);
   }
   if (climb_steps > 0) printf("worst_after_climb_units=%.1f\n", climbed);
+  printf("cone_skipped=%ld cone_wrong=%ld cone_with_overlapping_boxes=%ld\n", cone_skipped, cone_wrong, cone_overlapping_boxes);
   printf("worst_noise_units=%.1f bound_units=%.0f culled=%ld wrong=%ld\n", w, (double)obb::kQuadNoiseUnits, culled, wrong);
   return wrong ? 1 : 0;
 }

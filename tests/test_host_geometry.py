@@ -46,11 +46,29 @@ def test_quad_skip_rule_noise_bound(tmp_path):
                     f"{ROOT}/tests/native/host_check_quadcull.cpp", "-o", str(out), "-lm"], check=True)
     r = subprocess.run([str(out), "4000000", "21", "20000"], capture_output=True, text=True)
     assert r.returncode == 0 and " wrong=0" in r.stdout and "fp16_rounding_errors=0" in r.stdout, r.stdout
+    assert "cone_wrong=0" in r.stdout and "cone_skipped=0 " not in r.stdout, r.stdout      # the exact rule fired and never on a non-zero sum
     vals = dict(kv.split("=") for line in r.stdout.splitlines() if "=" in line and not line.startswith("family") for kv in line.split())
     bound = float(vals["bound_units"])
     assert float(vals["worst_noise_units"]) * 64 <= bound, r.stdout          # random pairs: measured < 8 units
     assert float(vals["worst_after_climb_units"]) * 32 <= bound, r.stdout    # after the ascent: measured < 20 units
     assert int(vals["culled"]) > 1000000, r.stdout
+
+
+@pytest.mark.parametrize("fma", [False, True])
+def test_quad_cone_rule_gives_exactly_zero(tmp_path, fma):
+    """The PROVED skip rule of the quad IoU (piou_device.h quad_cone_skip): whenever the second quad's cone
+    lies counter-clockwise of the first's, every one of the 16 terms of the reference's sum is exactly zero and the IoU is
+    +0 -- checked on pairs generated to sit on the rule's edges (smallest resolvable gaps, spans up to pi, vertices at the minimum
+    distance, coordinates 2 .. 1e7, bow ties, clockwise rings), in a build without and in a build WITH FMA contraction
+    (nvcc's default for the reference's .cu files)."""
+    out = tmp_path / ("hc_cone_fma" if fma else "hc_cone")
+    flags = ["-march=native", "-ffp-contract=fast"] if fma else ["-ffp-contract=off"]
+    subprocess.run(["g++", "-O2", "-std=c++17", *flags, f"-I{ROOT}/yolov5_obb_amd/csrc",
+                    f"{ROOT}/tests/native/host_check_quadcone.cpp", "-o", str(out), "-lm"], check=True)
+    r = subprocess.run([str(out), "3000000", "5"], capture_output=True, text=True)
+    assert r.returncode == 0 and " wrong=0" in r.stdout, r.stdout + r.stderr
+    vals = dict(kv.split("=") for kv in r.stdout.split())
+    assert int(vals["fired"]) > 1500000 and int(vals["near_edge"]) > 500000, r.stdout
 
 
 def test_fast_iou_interval_contains_the_reference_value(oracle_lib, tmp_path):

@@ -112,18 +112,20 @@ struct RotGeom {
 struct QuadGeom {
   static constexpr int RECQ = 3;
   static constexpr int SCR = 40;  // 2 x 10 points x (x,y) per lane
-  // q0 = {fp16 minx | miny, fp16 maxx | maxy (rounded outward), budget f, 0}   q1 = {x0, y0, x1, y1}   q2 = {x2, y2, x3, y3}
+  // q0 = {fp16 minx | miny, fp16 maxx | maxy (rounded outward), budget f, cone (piou_device.h: quad_cone_bits)}   q1 = {x0, y0, x1, y1}   q2 = {x2, y2, x3, y3}
   // The reference's quad IoU sums signed triangle areas taken from the coordinate origin; for disjoint quads the terms
   // cancel only up to rounding noise that grows with the square of the coordinates, so "IoU == 0" cannot be predicted
-  // from a bounding-box test alone.  A pair is skipped when the bounding boxes are disjoint AND the two boxes' areas are
+  // from a bounding-box test alone.  Two rules (piou_device.h): a pair is skipped when the column box's cone lies
+  // counter-clockwise of the row box's (all 16 terms are then EXACTLY zero: proved), or when the bounding boxes are disjoint AND the two boxes' areas are
   // large enough against their coordinate magnitudes that the noise cannot reach the threshold (piou_device.h:
   // quad_skip_record / quad_skip_pair; k_prep_quad computes the per-box budget, the threshold is known there); every
   // other pair is clipped, as the reference does.
+  // (a = the row box = the first argument of the IoU, b = the column box: the cone rule is not symmetric)
   static __device__ __forceinline__ bool cheap_reject(const float4& a, const float4& b) {
     QuadSkip A, B;
     A.lo = __builtin_bit_cast(uint32_t, a.x); A.hi = __builtin_bit_cast(uint32_t, a.y); A.f = a.z;
     B.lo = __builtin_bit_cast(uint32_t, b.x); B.hi = __builtin_bit_cast(uint32_t, b.y); B.f = b.z;
-    return quad_skip_pair(A, B);
+    return quad_cone_skip(__builtin_bit_cast(uint32_t, a.w), __builtin_bit_cast(uint32_t, b.w)) || quad_skip_pair(A, B);
   }
   static constexpr bool PACKED = false;
   static OBB_HD QuadFeat unpack(const float4& q0, const float4& q1) {

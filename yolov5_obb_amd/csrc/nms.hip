@@ -297,9 +297,11 @@ __global__ void k_prep_quad(const float* __restrict__ polys, int stride, const u
     float c[8];
 #pragma unroll
     for (int k = 0; k < 8; k++) c[k] = d[k];
-    // thr <= 0 (or skip == 0): budget -inf, nothing is skipped
-    const QuadSkip sk = quad_skip_record(quad_make_feat(c), skip ? thr : 0.f);
-    rec[(size_t)p * 3 + 0] = make_float4(__builtin_bit_cast(float, sk.lo), __builtin_bit_cast(float, sk.hi), sk.f, 0.f);
+    // skip bit 1: the bounding-box rule (thr <= 0 or bit clear: budget -inf); bit 0: the exact cone rule
+    const QuadFeat qf = quad_make_feat(c);
+    const QuadSkip sk = quad_skip_record(qf, (skip & 2) ? thr : 0.f);
+    const uint32_t cone = (skip & 1) ? quad_cone_bits(qf) : kConeNone;
+    rec[(size_t)p * 3 + 0] = make_float4(__builtin_bit_cast(float, sk.lo), __builtin_bit_cast(float, sk.hi), sk.f, __builtin_bit_cast(float, cone));
     rec[(size_t)p * 3 + 1] = make_float4(c[0], c[1], c[2], c[3]);
     rec[(size_t)p * 3 + 2] = make_float4(c[4], c[5], c[6], c[7]);
   }
@@ -399,8 +401,13 @@ struct Carve {
 // table slots of the spatial index (power of two, multiple of 4096)
 // cells of side 2 R_L / 2^fine (grid.h): 1 measured best at 100k (K=3000: 716 -> 648 us, uniform 2361 -> 2138; 2: no further gain)
 static int grid_fine() { static int f = -1; if (f < 0) { const char* e = getenv("OBB_GRID_FINE"); f = e ? atoi(e) : 1; if (f < 0 || f > 2) f = 1; } return f; }
-// OBB_NMS_POLY_STRICT=1: the quad NMS clips every pair (no bounding-box skip; piou_device.h quad_cull_box)
-static int quad_skip() { static int f = -1; if (f < 0) { const char* e = getenv("OBB_NMS_POLY_STRICT"); f = (e && atoi(e) != 0) ? 0 : 1; } return f; }
+// Skip rules of the quad NMS (piou_device.h): bit 0 = the exact cone rule (proved), bit 1 = the bounding-box rule (measured noise
+// bound).  OBB_NMS_POLY_STRICT=1: cone rule only (every other pair is clipped); =2: no rule at all, every pair is clipped.
+static int quad_skip() {
+  static int f = -1;
+  if (f < 0) { const char* e = getenv("OBB_NMS_POLY_STRICT"); const int v = e ? atoi(e) : 0; f = v == 1 ? 1 : (v >= 2 ? 0 : 3); }
+  return f;
+}
 static uint32_t grid_slots(int64_t n) { return (n >= 262144 || (grid_fine() > 0 && n >= 32768)) ? 65536u : 16384u; }
 constexpr int64_t kGridMinN = 8192;    // below this the exhaustive cross phase is cheaper than building the index
 

@@ -54,6 +54,7 @@ __global__ __launch_bounds__(64) void k_quad_matrix(const float* __restrict__ a,
                                                     const float* __restrict__ b, long long sb, long long k,
                                                     float* __restrict__ out) {
   __shared__ float4 rowrec[64 * 2];
+  __shared__ uint32_t rowcone[64];
   __shared__ float scr[QuadGeom::SCR * 64];
   const int lane = threadIdx.x;
   const long long i0 = (long long)blockIdx.y * 64, j = (long long)blockIdx.x * 64 + lane;
@@ -64,17 +65,20 @@ __global__ __launch_bounds__(64) void k_quad_matrix(const float* __restrict__ a,
     for (int c = 0; c < 8; c++) v[c] = (i < n) ? a[i * sa + c] : 0.f;
     rowrec[lane * 2] = make_float4(v[0], v[1], v[2], v[3]);
     rowrec[lane * 2 + 1] = make_float4(v[4], v[5], v[6], v[7]);
+    rowcone[lane] = quad_cone_bits(quad_make_feat(v));
   }
   QuadFeat B = {};
   if (j < k) {
 #pragma unroll
     for (int c = 0; c < 4; c++) { B.x[c] = b[j * sb + 2 * c]; B.y[c] = b[j * sb + 2 * c + 1]; }
   }
+  const uint32_t cone_b = j < k ? quad_cone_bits(B) : kConeNone;
   __syncthreads();
   const int nr = (int)((n - i0) < 64 ? (n - i0) : 64);
   for (int r = 0; r < nr; r++) {
     QuadFeat A = QuadGeom::unpack(rowrec[r * 2], rowrec[r * 2 + 1]);
-    if (j < k) out[(i0 + r) * k + j] = QuadGeom::iou(A, B, scr + lane);
+    // the exact cone rule (piou_device.h): all 16 terms of the reference's sum are exactly zero -> IoU = +0, no clip needed
+    if (j < k) out[(i0 + r) * k + j] = quad_cone_skip(rowcone[r], cone_b) ? 0.f : QuadGeom::iou(A, B, scr + lane);
   }
 }
 
@@ -96,23 +100,27 @@ __device__ __forceinline__ void rbox_to_quad_devkit(const float* d, float* qx, f
 __global__ __launch_bounds__(64) void k_rbox_overlaps(const float* __restrict__ boxes, long long n,
                                                       const float* __restrict__ query, long long k, float* __restrict__ out) {
   __shared__ float4 rowrec[64 * 2];
+  __shared__ uint32_t rowcone[64];
   __shared__ float scr[QuadGeom::SCR * 64];
   const int lane = threadIdx.x;
   const long long i0 = (long long)blockIdx.y * 64, j = (long long)blockIdx.x * 64 + lane;
   {
     long long i = i0 + lane;
-    float qx[4] = {0, 0, 0, 0}, qy[4] = {0, 0, 0, 0};
-    if (i < n) rbox_to_quad_devkit(boxes + i * 5, qx, qy);
-    rowrec[lane * 2] = make_float4(qx[0], qy[0], qx[1], qy[1]);
-    rowrec[lane * 2 + 1] = make_float4(qx[2], qy[2], qx[3], qy[3]);
+    QuadFeat A = {};
+    if (i < n) rbox_to_quad_devkit(boxes + i * 5, A.x, A.y);
+    rowrec[lane * 2] = make_float4(A.x[0], A.y[0], A.x[1], A.y[1]);
+    rowrec[lane * 2 + 1] = make_float4(A.x[2], A.y[2], A.x[3], A.y[3]);
+    rowcone[lane] = i < n ? quad_cone_bits(A) : kConeNone;
   }
   QuadFeat B = {};
   if (j < k) rbox_to_quad_devkit(query + j * 5, B.x, B.y);
+  const uint32_t cone_b = j < k ? quad_cone_bits(B) : kConeNone;
   __syncthreads();
   const int nr = (int)((n - i0) < 64 ? (n - i0) : 64);
   for (int r = 0; r < nr; r++) {
     QuadFeat A = QuadGeom::unpack(rowrec[r * 2], rowrec[r * 2 + 1]);
-    if (j < k) out[(i0 + r) * k + j] = QuadGeom::iou(A, B, scr + lane);
+    // the exact cone rule (piou_device.h): all 16 terms of the reference's sum are exactly zero -> IoU = +0, no clip needed
+    if (j < k) out[(i0 + r) * k + j] = quad_cone_skip(rowcone[r], cone_b) ? 0.f : QuadGeom::iou(A, B, scr + lane);
   }
 }
 

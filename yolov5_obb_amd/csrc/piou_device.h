@@ -226,6 +226,44 @@ OBB_HD float f16_bits_to_float(uint32_t h) {
 #endif
 }
 
+// ---- the exact rule: the second quad's cone lies counter-clockwise of the first's ------------------------------------
+// PROVED, at any coordinate magnitude (DESIGN.md section 4.1 spells the argument out).  quad_iou(P, Q) clips every triangle
+// (o, a, b) of P -- o the coordinate origin, (a, b) an edge of P -- first against the line o -> c, c a vertex of Q, with
+//     s(v) = fl(fl(cx * vy) - fl(vx * cy))          (ptri with the origin as the line's first point: no subtraction rounds)
+// and keeps what lies to its LEFT (s > 1e-8).  If every vertex of P lies CLOCKWISE of every vertex of Q as seen from the
+// origin, by an angle in [2e-4, pi - 4e-4], and no vertex is closer than 1 to the origin, then s(a) and s(b) are below -1e-8
+// (exact cross product <= -2e-4 |c||v| <= -2.2e-4, rounding <= 2^-23 |c||v|: the sign is safe with or without FMA
+// contraction), s(o) = 0 exactly, the two crossings are computed as (0 * s2 - v * 0) / s2 = 0 exactly, the clipped polygon is
+// the single point (0, 0), every later clip keeps or drops that point, the shoelace sum over <= 1 point is 0: ALL 16 terms are
+// exactly 0, inter = +0, and with a non-zero area on either side IoU = +0 -- never above a threshold >= 0.  (With P
+// counter-clockwise of Q the last clip line runs d -> o and the intermediate polygon is not a point: no such statement, and
+// none is used.)  The cone of a quad = the polar angles of its four vertices, as 16-bit fixed point (2 pi / 65536 per unit)
+// widened by two units on either side, which also covers atan2f's error on any libm; a quad around the origin, across the
+// negative x axis, with a vertex within 1.5 (L1) of the origin, with a non-finite coordinate or with zero computed area has no
+// cone and is never skipped by this rule.
+constexpr uint32_t kConeNone = 0x0000FFFFu;            // lo = 0xFFFF > hi = 0
+OBB_HD uint32_t quad_cone_bits(const QuadFeat& q) {
+  float lo = 4.f, hi = -4.f;
+  bool ok = quad_signed_area(q.x, q.y) != 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const float x = q.x[i], y = q.y[i];
+    ok = ok && (x - x == 0.f) && (y - y == 0.f) && (fabsf(x) + fabsf(y) >= 1.5f);
+    const float t = atan2f(y, x);
+    lo = fminf(lo, t); hi = fmaxf(hi, t);
+  }
+  if (!ok || !(hi - lo < 3.1f)) return kConeNone;
+  const float sc = 65536.f / 6.2831855f;
+  float ulo = floorf((lo + 3.1415927f) * sc) - 2.f, uhi = ceilf((hi + 3.1415927f) * sc) + 2.f;
+  ulo = ulo < 0.f ? 0.f : ulo; uhi = uhi > 65535.f ? 65535.f : uhi;
+  return (uint32_t)ulo | ((uint32_t)uhi << 16);
+}
+// P = the FIRST argument of quad_iou (the NMS's row box), Q = the second (the column box)
+OBB_HD bool quad_cone_skip(uint32_t p, uint32_t q) {
+  const int plo = (int)(p & 0xffffu), phi = (int)(p >> 16), qlo = (int)(q & 0xffffu), qhi = (int)(q >> 16);
+  return plo <= phi && qlo <= qhi && phi < qlo && (qhi - plo) < 32768 - 4;
+}
+
 struct QuadSkip {
   uint32_t lo;   // fp16 minx | fp16 miny << 16   (rounded down)
   uint32_t hi;   // fp16 maxx | fp16 maxy << 16   (rounded up)
