@@ -39,6 +39,8 @@ namespace obb {
 
 typedef unsigned long long u64;
 
+struct SlabPlan;
+
 struct NmsArgs {
   const float4* rec;         // [n][RECQ] AoS records in sorted order (read-only in this kernel)
   const uint32_t* order;     // sorted position -> original index (NULL: keep_out receives the sorted position itself)
@@ -91,6 +93,7 @@ struct NmsArgs {
   int* slab_keep;             // [kMaxSlabs]
   float4* rec2; uint32_t* order2; uint32_t* pos_old; u64* alive2; u64* kept_bits;
   int alive2_words, kept_words;
+  const SlabPlan* slab_plan;  // written by k_slab_split in front of this launch (NULL: no decomposition was looked for)
   int slab_cap;               // > 0: upper limit of a slab team's chunk capacity
   int grow_sparse;            // chunk growth factor after a sparse chunk (<= 2: always double)
 };
@@ -1415,16 +1418,21 @@ OBB_COLD_GRID int grid_build(const NmsArgs& a, const GridPlan& gp, int c0, int w
 
 
 // ------------------------------------------------------------------ independent slabs (grid.h): set-up and merge
-// What the set-up leaves behind for the rest of the kernel (static LDS, a few hundred bytes)
-struct SlabLds {
+// What the set-up kernel (k_slab_split) leaves behind for the persistent kernel, in global memory
+struct SlabPlan {
+  int mode;                               // 0: the call stays one list; 1: slab mode
+  int nslab;
+  int cap; int pad0;                      // chunk capacity of one team
+  long long ecap;                         // edge-list capacity of one team (the single list's buffer is shared out)
   int segb[kMaxSlabs], sege[kMaxSlabs];   // positions [segb, sege) of slab s in the slab-major layout
-  int nslab;                              // 0: the call stays one list
-  int my_seg, my_team, my_idx, my_T;      // this workgroup's slab (-1: none), team id, index in the team, team size
-  int cap; long long ecap;                // chunk capacity / edge-list capacity of one team (the single list's buffer is shared out)
+  int4 wg[1024];                          // per workgroup of the persistent launch: {slab or -1, team id, index in the team, team size}
 };
 
-// Runs at the very start of the single-list kernel, by all workgroups.  Returns 0: one list (nothing changed); 1: slab mode
-// (SL filled in, the slab-major copy of the list is complete and visible); -1: barrier abort.
+// A launch of its own in front of the persistent kernel, same grid (round 4; rounds 2-3 ran it at the start of the
+// persistent kernel: 65 us, of which the timers explained 50 -- code that runs once per call inside a 230 KB kernel is fetched
+// cold, instruction line by instruction line; as a kernel of a few KB it is not, and a list that does not decompose pays
+// an empty launch instead of nothing).  Leaves mode 0 (one list, nothing changed) or 1 (slab mode: the plan is filled in and the
+// slab-major copy of the list is complete); a barrier abort leaves mode 0 and the abort flag.
 //   1. runs of marked x bins -> slab of a bin (every workgroup from the same bitmap: same result);
 //   2. every workgroup counts the alive boxes of its contiguous block of positions per slab          -> team barrier
 //   3. totals, this workgroup's offsets, the 64-aligned start of every slab; uniform decision (>= 2 non-empty slabs, none
@@ -1432,7 +1440,7 @@ struct SlabLds {
 //   4. STABLE scatter of records / original indices / original positions / alive bits: the order inside a slab is the
 //      score order of the list                                                                      -> team barrier
 template <class G>
-OBB_COLD_SLAB int slab_setup(const NmsArgs& a, float bin_x0, float inv, unsigned char* smem, TeamBar& gbar, int* s_flag, SlabLds& SL) {
+__device__ __forceinline__ int slab_setup(const NmsArgs& a, float bin_x0, float inv, unsigned char* smem, TeamBar& gbar, int* s_flag, SlabPlan& SL) {
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int NB = gridDim.x, wg = blockIdx.x;
   uint32_t* starts = reinterpret_cast<uint32_t*>(smem);       // [kSlabWords] bins where a run starts
@@ -1444,7 +1452,6 @@ OBB_COLD_SLAB int slab_setup(const NmsArgs& a, float bin_x0, float inv, unsigned
   int* run = base + kMaxSlabs;                                // [kMaxSlabs] ... placed by earlier tiles of this workgroup
   int* wcnt = run + kMaxSlabs;                                // [kNmsWaves][kMaxSlabs] per wave of the current tile
   int* misc = wcnt + kNmsWaves * kMaxSlabs;                   // [4]
-  if (tid == 0) SL.nslab = 0;
   if (*a.slab_flag != 0 || NB > kNmsThreads) return 0;        // (written by the prep kernel: uniform)
   const bool sprof = a.prof != nullptr && blockIdx.x == 0 && tid == 0;
   u64 st0 = sprof ? wall_clock64() : 0ull;
@@ -1546,7 +1553,7 @@ OBB_COLD_SLAB int slab_setup(const NmsArgs& a, float bin_x0, float inv, unsigned
     if (a.slab_cap > 0 && c > a.slab_cap) c = a.slab_cap;      // (OBB_NMS_SLAB_CAP: measurements)
     misc[1] = (mx <= kSlabMaxSeg && nonempty >= 2 && nonempty <= NB && c >= 512) ? 1 : 0;
     misc[2] = nonempty; misc[3] = c;
-    SL.cap = c; SL.ecap = (long long)c * (c - 1) / 2;
+    if (wg == 0) { SL.cap = c; SL.ecap = (long long)c * (c - 1) / 2; }
   }
   __syncthreads();
   slap(45);
@@ -1599,28 +1606,42 @@ OBB_COLD_SLAB int slab_setup(const NmsArgs& a, float bin_x0, float inv, unsigned
   }
   asm volatile("; alive bits set %0" ::"v"((unsigned)(seen >> 32) ^ (unsigned)seen));
   slap(50);
-  // ---- the plan: one team per non-empty slab, the spare workgroups in proportion to the sizes
+  // ---- the plan: one team per non-empty slab, the spare workgroups in proportion to the sizes (written by workgroup 0)
   __syncthreads();
-  if (tid < kMaxSlabs) { SL.segb[tid] = tid < S ? base[tid] : 0; SL.sege[tid] = tid < S ? base[tid] + tot[tid] : 0; }
-  if (tid == 0) {
-    long long total = 0;
-    for (int s0 = 0; s0 < S; s0++) total += tot[s0];
-    const int spare = NB - misc[2];
-    int w = 0, team = 0;
-    SL.my_seg = -1; SL.my_team = 0; SL.my_idx = 0; SL.my_T = 1;
-    for (int s0 = 0; s0 < S; s0++) {
-      if (tot[s0] <= 0) continue;
-      const int T = 1 + (int)((long long)spare * tot[s0] / total);
-      if (wg >= w && wg < w + T) { SL.my_seg = s0; SL.my_team = team; SL.my_idx = wg - w; SL.my_T = T; }
-      w += T; team++;
+  if (wg == 0) {
+    if (tid < kMaxSlabs) { SL.segb[tid] = tid < S ? base[tid] : 0; SL.sege[tid] = tid < S ? base[tid] + tot[tid] : 0; }
+    if (tid == 0) {
+      long long total = 0;
+      for (int s0 = 0; s0 < S; s0++) total += tot[s0];
+      const int spare = NB - misc[2];
+      int w = 0, team = 0;
+      for (int s0 = 0; s0 < S; s0++) {
+        if (tot[s0] <= 0) continue;
+        const int T = 1 + (int)((long long)spare * tot[s0] / total);
+        for (int i = 0; i < T; i++) SL.wg[w + i] = make_int4(s0, team, i, T);
+        w += T; team++;
+      }
+      for (; w < NB; w++) SL.wg[w] = make_int4(-1, 0, 0, 1);
+      SL.nslab = S;
     }
-    SL.nslab = S;
   }
   slap(46);
-  if (!team_barrier(gbar, s_flag)) return -1;                  // (its __syncthreads also publish SL to the workgroup)
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  if (!team_barrier(gbar, s_flag)) return -1;                  // every workgroup's share of the slab-major copy is out
   slap(47);
   return 1;
+}
+
+// the set-up as a kernel: grid = the persistent launch's grid (its per-workgroup count table), one two-level grid barrier of its own
+template <class G>
+__global__ __launch_bounds__(kNmsThreads) void k_slab_split(NmsArgs a, SlabPlan* sp) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[(2 * kSlabWords + 6 * kMaxSlabs + kNmsWaves * kMaxSlabs + 8) * 4];
+  __shared__ int s_flag;
+  if (blockIdx.x == 0 && threadIdx.x == 0) sp->mode = 0;
+  if (a.slab_flag[2] == 0) return;                             // the data is not wide enough to look for slabs (k_prep_rot / the sort's record tail)
+  // the barrier line of team 1 (unused by a single-list call) and the second group-counter block
+  TeamBar gbar{a.bar + 128, a.bar + 128 + 64, (int)gridDim.x, 0, a.abort_flag, gridDim.x > 32 ? a.bar_sub + kBarGroups * 64 : nullptr, (int)blockIdx.x};
+  const int st = slab_setup<G>(a, __int_as_float(a.slab_flag[4]), __int_as_float(a.slab_flag[5]), smem, gbar, &s_flag, *sp);
+  if (st == 1 && blockIdx.x == 0 && threadIdx.x == 0) sp->mode = 1;
 }
 
 // After every team has finished its slab (and one more barrier of the whole grid): the kept boxes are the set bits of a
@@ -1671,7 +1692,6 @@ __global__ __launch_bounds__(kNmsThreads) __attribute__((amdgpu_waves_per_eu(1, 
   __shared__ int s_i[16];
   __shared__ int s_flag;
   __shared__ int s_bb[kNmsWaves][4];
-  __shared__ SlabLds s_slab;
   const int tid = threadIdx.x, wv = tid >> 6;
   const int NB = gridDim.x;
   // the extent of the data from the key kernel's per-workgroup partials (every workgroup reduces them itself)
@@ -1702,20 +1722,14 @@ __global__ __launch_bounds__(kNmsThreads) __attribute__((amdgpu_waves_per_eu(1, 
   int64_t* keep_out0 = a.keep_out;
   int* keep_cnt0 = a.keep_cnt;
   const int n0 = a.n;
+  const SlabPlan* sp = nullptr;
   if constexpr (G::HAS_GRID && GRID) {
-    // (slab_flag[2] != 0: the prep kernel found the data wide enough to look for slabs and marked the x bins: one word decides)
-    if (a.slab_cover != nullptr && a.nseg == 1 && a.max_keep <= 0 && a.cull != 0 && a.plan == nullptr && a.bbpart != nullptr && a.slab_flag[2] != 0) {
-      const u64 t_su = (a.prof && blockIdx.x == 0 && tid == 0) ? wall_clock64() : 0ull;
-      // (the bins' origin and scale as the prep kernel derived them: slab_flag[4], [5])
-      const int st = slab_setup<G>(a, __int_as_float(a.slab_flag[4]), __int_as_float(a.slab_flag[5]), smem, gbar, &s_flag, s_slab);
-      if (st < 0) return;
-      if (a.prof && blockIdx.x == 0 && tid == 0) a.prof[41] += wall_clock64() - t_su;
-      if (st > 0) {
-        slab_mode = true;
-        a.rec = a.rec2; a.order = a.order2; a.alive = a.alive2; a.keep_out = nullptr; a.keep_cnt = a.slab_keep;
-        a.nseg = s_slab.nslab; a.capmax = s_slab.cap; a.ecap = s_slab.ecap;
-      }
-      __syncthreads();                                       // the set-up's LDS scratch is free from here on
+    // (k_slab_split ran in front of this launch and decided: one word of its plan)
+    if (a.slab_plan != nullptr && a.nseg == 1 && a.slab_plan->mode == 1) {
+      sp = a.slab_plan;
+      slab_mode = true;
+      a.rec = a.rec2; a.order = a.order2; a.alive = a.alive2; a.keep_out = nullptr; a.keep_cnt = a.slab_keep;
+      a.nseg = sp->nslab; a.capmax = sp->cap; a.ecap = sp->ecap;
     }
   }
   int nteams = a.nseg < NB ? a.nseg : NB;
@@ -1725,9 +1739,10 @@ __global__ __launch_bounds__(kNmsThreads) __attribute__((amdgpu_waves_per_eu(1, 
   int bar_line = team;
   long long skip_cost = -1;                            // >= 0: segments at least this expensive belong to a team of their own
   bool idle = false;
-  if (slab_mode) {                                     // one team per slab (slab_setup); barrier lines 64.. (line 0 is the grid's)
-    g_step = 1; team = s_slab.my_team; wg = s_slab.my_idx; T = s_slab.my_T; bar_line = 64 + team;
-    if (s_slab.my_seg < 0) { idle = true; g_first = 0; g_last = -1; } else { g_first = g_last = s_slab.my_seg; }
+  if (slab_mode) {                                     // one team per slab (k_slab_split's plan); barrier lines 64.. (line 0 is the grid's)
+    const int4 pl = sp->wg[blockIdx.x];
+    g_step = 1; team = pl.y; wg = pl.z; T = pl.w; bar_line = 64 + team;
+    if (pl.x < 0) { idle = true; g_first = 0; g_last = -1; } else { g_first = g_last = pl.x; }
   } else if (a.plan != nullptr && a.plan[0].w > 0) {   // planned (k_plan_teams): a team on one segment, or one workgroup on a run of small ones
     const int4 pl = a.plan[blockIdx.x];
     if (pl.x < 0) return;
@@ -1743,7 +1758,6 @@ __global__ __launch_bounds__(kNmsThreads) __attribute__((amdgpu_waves_per_eu(1, 
   const int tw = wg * kNmsWaves + wv, ntw = T * kNmsWaves;
   TeamBar bar{a.bar + (size_t)bar_line * 128, a.bar + (size_t)bar_line * 128 + 64, T, 0, a.abort_flag,
               (bar_line == 0 && T == NB && NB > 32) ? a.bar_sub : nullptr, wg};       // (the one team of a single list shares the grid's counters)
-  if (!slab_mode && bar_line == 0) bar.epoch = gbar.epoch;   // (a set-up that decided against slabs has used the grid's line already)
 
   const bool prof = a.prof != nullptr && blockIdx.x == 0 && tid == 0;
   u64 t0 = prof ? wall_clock64() : 0ull;
@@ -1816,7 +1830,7 @@ __global__ __launch_bounds__(kNmsThreads) __attribute__((amdgpu_waves_per_eu(1, 
 
   const int plan_chunk = a.cap_first < a.capmax ? a.cap_first : a.capmax;
   for (int g = g_first; g <= g_last; g += g_step) {
-    const int sb = slab_mode ? s_slab.segb[g] : a.seg_begin[g], se = slab_mode ? s_slab.sege[g] : a.seg_end[g];
+    const int sb = slab_mode ? sp->segb[g] : a.seg_begin[g], se = slab_mode ? sp->sege[g] : a.seg_end[g];
     // (the first segment of a plan entry is always the workgroup's own: a run starts with a small segment, and a big
     //  segment whose team has one member is an entry of its own)
     if (skip_cost >= 0 && g != g_first && plan_cost(se - sb, plan_chunk) >= skip_cost) continue;
