@@ -19,9 +19,10 @@ collective on the data path; RCCL = backend "nccl" is only used for the timing b
 images/s; `n_gpus` = dist.get_world_size(), `rccl_ranks` = the ranks that met at the RCCL barrier.
 --dry-run: the launcher / rank plumbing alone on the CPU (gloo), no GPU work -- what the CPU test exercises.
 
-The timed K steps run with the library's stage events on (`obb_profile_enable`: ten HIP event records per step on the
-kernels' stream, what `roofline` / `kernels` / `stages_ms` are computed from); `ms_per_step_without_stage_events` is the same
-K steps once more without them.
+The timed K steps run with HIP events around the step's dominant kernel (the persistent NMS kernel; `obb_profile_enable(2)`: two
+event records per step on the kernels' stream); `ms_per_step_with_all_stage_events` is the same K steps with events around all
+five stages (ten records, ~30 us per step: what `stages_ms` / `kernels` list for the other stages), and
+`ms_per_step_without_stage_events` the same K steps without any.
 
 The JSON line also carries
   roofline      BASELINE.json's target figure: rotated NMS at N = 100k candidates, SURVEY.md section 8d's algorithmic bytes
@@ -108,6 +109,15 @@ def bench_next_rows(dev, dets_per_image):
             poly, hbb, polyn, hbbn = V.val_postprocess(d, ratio_pad=((0.7314, 0.7314), (12.0, 3.5)))
             V.process_batch(hbbn, lb, iouv)
     ms = wall(tail, 20)
+    # ... and the whole batch in one call (val.val_tail_batch: three launches + one copy; what val_sharded.run uses)
+    tg = torch.cat([torch.cat((torch.full((lb.shape[0], 1), float(i), device=dev), lb[:, :1], torch.zeros((lb.shape[0], 5), device=dev)), 1)
+                    for i, lb in enumerate(labels)], 0)
+    for i, (d, lb) in enumerate(zip(dets_per_image, labels)):          # label rows [img cls cx cy l s theta]: boxes around the detections' own
+        sel = tg[:, 0] == i
+        k = int(sel.sum())
+        tg[sel, 2:7] = d[:k, :5]
+    shapes_b = [((1400, 1400), ((0.7314, 0.7314), (12.0, 3.5)))] * len(dets_per_image)
+    ms_batch = wall(lambda: V.val_tail_batch(dets_per_image, tg, shapes_b, iouv), 20)
     d0, l0 = dets_per_image[0].cpu(), labels[0].cpu()
     t0 = time.perf_counter()
     for _ in range(5):
@@ -115,7 +125,10 @@ def bench_next_rows(dev, dets_per_image):
         pyref.process_batch(pp[3], l0, iouv.cpu())
     cms = (time.perf_counter() - t0) / 5 * 1e3
     res["val_tail"] = {"workload": f"{len(dets_per_image)} images x ~{int(dets_per_image[0].shape[0])} detections: val_postprocess + process_batch",
-                       "ms_per_batch": round(ms, 3), "ms_per_image": round(ms / len(dets_per_image), 4),
+                       "ms_per_batch": round(ms_batch, 3), "ms_per_image": round(ms_batch / len(dets_per_image), 4),
+                       "ms_per_batch_per_image_calls": round(ms, 3),
+                       "note": "ms_per_batch: val.val_tail_batch (three launches + one device->host copy for the batch, incl. that copy and "
+                               "its sync); ms_per_batch_per_image_calls: round 3's loop of val_postprocess + process_batch per image",
                        "cpu_port_ms_per_image": round(cms, 3)}
     # ---- ResultMerge: one class file of 300 source images (tiles 1024/824, two rates)
     lines = gg.merge_input_lines(300, 40, 7, False)
@@ -284,15 +297,29 @@ def main():
     for i in range(max(args.warmup, ROTATE)):
         out = non_max_suppression_obb(preds[i % ROTATE], **kw)
     barrier()
-    L.obb_profile_enable(1)
+    # THE timed region: K steps with HIP events around the step's dominant kernel only (the persistent NMS kernel: two records per
+    # step on the kernels' own stream; recording all five stages costs ten records = ~30 us of a 0.2 ms step)
+    L.obb_profile_enable(2)
     t0 = time.perf_counter()
     for i in range(args.steps):
         out = non_max_suppression_obb(preds[i % ROTATE], **kw)
     barrier()
     dt = time.perf_counter() - t0
+    ms_sum_t, cnts_t = collect_profile(L)
+    L.obb_profile_enable(0)
+    # the same K steps with events around every stage: the per-stage figures of `stages_ms` / `kernels` (the NMS kernel's own figure
+    # stays the one measured inside the timed region above)
+    barrier()
+    L.obb_profile_enable(1)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        out = non_max_suppression_obb(preds[i % ROTATE], **kw)
+    barrier()
+    ms_all_events = shard.max_over_ranks(time.perf_counter() - t0, device=dev) / args.steps * 1e3
     ms_sum, cnts = collect_profile(L)
     L.obb_profile_enable(0)
-    # the same K steps once more without the library's stage events (10 event records per step): informational
+    ms_sum[3], cnts[3] = ms_sum_t[3], cnts_t[3]
+    # ... and once more without any event: informational
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -524,6 +551,7 @@ def main():
                                       "nms": round(slow[2] / per_rank * 1e3, 4)},
                        "img_per_s_seen_over_sum_dt": round(per_rank * world / max(sum(slow), 1e-12), 1),
                        "nms_share_of_step": round(slow[2] / max(sum(slow), 1e-12), 4),
+                       "nms_stages_ms_per_batch": local.get("nms_stages_ms_per_batch"),
                        "note": "dt buckets are the slowest rank's, img/s = images of ALL ranks / sum(dt) (val.py:286-291); secondary to `value`: "
                                "the convolutions are PyTorch-ROCm's (MIOpen), not this repository's; random-init heads place their candidates "
                                "at random, so few suppress each other -- the NMS bucket's worst case"}
@@ -726,7 +754,7 @@ def main():
             "metric": METRIC,
             "value": round(value, 2), "unit": "img/s", "n_gpus": dist.get_world_size() if dist is not None else 1, "rccl_ranks": rccl_ranks,
             "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 4), "ms_per_step_without_stage_events": round(ms_plain, 4),
+            "ms_per_step": round(ms_per_step, 4), "ms_per_step_with_all_stage_events": round(ms_all_events, 4), "ms_per_step_without_stage_events": round(ms_plain, 4),
             "ms_per_step_one_tensor_warm": round(ms_warm, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f16", "data": "synthetic",
             "config": {"workload": f"DOTAv1.5 1024^2 bs16 (BASELINE metric; configs[1] thresholds): yolov5 OBB head output (16,64512,201) fp16, "

@@ -209,10 +209,22 @@ def val_buckets(device, n_images=160, batch=16, nc=16, conf_thres=0.25, iou_thre
     val_sharded.run(model, SyntheticVal(2 * batch, batch, nc=nc, seed=seed), conf_thres=conf_thres, iou_thres=iou_thres, half=half, device=device)
     # collect=False: no collective in here -- a rank that fails returns an error while the others would wait in the gather;
     # bench.py reduces the buckets itself, outside any try block
+    # the library's stage events around the timed loop: what the NMS bucket of this (random-init) workload is made of
+    import ctypes as C
+    from yolov5_obb_amd import _lib
+    L = _lib.lib()
+    L.obb_profile_enable(1)
     res = val_sharded.run(model, loader, conf_thres=conf_thres, iou_thres=iou_thres, half=half, device=device, collect=False)
+    torch.cuda.synchronize(device)
+    ms = (C.c_double * 8)(); cnt = (C.c_int64 * 8)()
+    L.obb_profile_collect(C.cast(ms, C.c_void_p), C.cast(cnt, C.c_void_p), 8)
+    L.obb_profile_enable(0)
+    names = ("decode", "sort", "prep", "nms_kernel", "gather")
+    stages = {names[i]: round(ms[i] / max(1, cnt[i]), 4) for i in range(5)}
+    stages["calls"] = int(cnt[0])
     with torch.no_grad():
         z = model(im0)[0]
         n_pass = int((z[..., 4] > conf_thres).sum()) // max(1, im0.shape[0])
     return {"images_per_rank": int(res["seen"]), "batch": batch, "anchors_passing_obj_per_image": n_pass,
             "model": "yolov5s-shaped conv stand-in (tools/conv_standin.py, random init, fp16) + product Detect",
-            "dt_seconds": [float(x) for x in res["dt"]]}
+            "dt_seconds": [float(x) for x in res["dt"]], "nms_stages_ms_per_batch": stages}

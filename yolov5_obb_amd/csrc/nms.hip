@@ -25,7 +25,7 @@ namespace obb {
 // bench.py switches this on to time the dominant kernels on the stream they are launched on.
 enum { PROF_DECODE = 0, PROF_SEGSORT, PROF_PREP, PROF_STEPS, PROF_GATHER, PROF_NMS_SORT, PROF_NMS_PREP, PROF_NMS_STEPS, PROF_N };
 struct ProfState {
-  bool on = false;
+  int on = 0;          // 0 off, 1 every stage, 2 only the NMS kernels (PROF_STEPS / PROF_NMS_STEPS: the dominant kernel of a call)
   static constexpr int kMax = 8192;
   hipEvent_t ev0[kMax], ev1[kMax];
   int id[kMax];
@@ -36,6 +36,7 @@ struct ProfScope {
   int slot = -1; hipStream_t st;
   ProfScope(int stage, hipStream_t s) : st(s) {
     if (!g_prof.on || g_prof.used >= ProfState::kMax) return;
+    if (g_prof.on == 2 && stage != PROF_STEPS && stage != PROF_NMS_STEPS) return;
     slot = g_prof.used++;
     if (slot >= g_prof.created) { hipEventCreate(&g_prof.ev0[slot]); hipEventCreate(&g_prof.ev1[slot]); g_prof.created = slot + 1; }
     g_prof.id[slot] = stage;
@@ -82,14 +83,12 @@ struct LocalExtras {
   uint4* bar16; long long n_bar16;
   uint4* grid16; long long n_grid16;
   int* bbpart;                 // [runs][kBbInts] or NULL
-  u64* alive; long long n_alive;   // alive bitmap words to zero (the fused record tail ORs its bits in), or NULL
 };
 __device__ __forceinline__ void local_extras(const LocalExtras& x, const float* __restrict__ dets5, int drop_small, int n, int i, bool in_range,
                                              int (*s_red)[4], uint32_t* key_out) {
   if (i == 0) { x.seg_begin[0] = 0; x.seg_end[0] = n; x.keep_cnt[0] = 0; }
   for (long long k = i; k < x.n_bar16; k += (long long)gridDim.x * blockDim.x) x.bar16[k] = make_uint4(0u, 0u, 0u, 0u);
   for (long long k = i; k < x.n_grid16; k += (long long)gridDim.x * blockDim.x) x.grid16[k] = make_uint4(0u, 0u, 0u, 0u);   // GridMeta + slot counters
-  if (x.alive != nullptr) for (long long k = i; k < x.n_alive; k += (long long)gridDim.x * blockDim.x) x.alive[k] = 0ull;
   int bx0 = 0x7fffffff, by0 = 0x7fffffff, bx1 = (int)0x80000000, by1 = (int)0x80000000;
   int d2 = 0;                                          // largest w^2 + h^2 of the block, as float bits (>= 0: ordered like ints)
   if (in_range) {
@@ -247,75 +246,6 @@ __global__ __launch_bounds__(256) void k_prep_rot(const float* __restrict__ dets
     if (v && (__hip_atomic_load(dst + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & v) != v) atomicOr(dst + k, v);
   }
 }
-
-// The same work as the tail of the sort's last kernel (psrs_sort.h: k_ps_bucket<Tail>): every sorted element arrives with its
-// final position, so the records, the order array, the alive bits (OR-ed into the bitmap the run kernel zeroed) and the slab
-// marks are written there and the k_prep_rot launch (8 us + a launch gap at 100k) disappears from the single-list path.
-struct RotPrepTail {
-  const float* dets5; int drop_small, n;
-  float4* rec; u64* alive; uint32_t* order;
-  const int* bbpart; int nparts;
-  uint32_t* slab_cover; int* slab_flag;
-  GridPlan gp; float inv; int gate; int bad;
-  static __device__ __forceinline__ uint32_t* cover_lds() { __shared__ uint32_t s_cover[kSlabWords]; return s_cover; }
-  __device__ __forceinline__ void begin(const PsBuf&) {
-    __shared__ int s_red[16][4];
-    gate = 0; bad = 0; inv = 0.f;
-    if (blockIdx.x == 0 && threadIdx.x < 8) alive[((n + 63) >> 6) + threadIdx.x] = 0ull;      // guard words behind the last box
-    if (slab_cover == nullptr) return;
-    float max_w2h2 = 0.f;
-    gp = plan_from_partials(bbpart, nparts, s_red, &max_w2h2);
-    gate = slab_gate(gp, max_w2h2) ? 1 : 0;
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-      slab_flag[2] = gate;
-      slab_flag[4] = __float_as_int(gp.x0);
-      slab_flag[5] = __float_as_int(slab_inv_bin(gp));
-    }
-    if (!gate) return;
-    uint32_t* s_cover = cover_lds();
-    for (int k = threadIdx.x; k < kSlabWords; k += blockDim.x) s_cover[k] = 0u;
-    inv = slab_inv_bin(gp);
-    __syncthreads();
-  }
-  __device__ __forceinline__ void element(const PsBuf&, int pos, unsigned long long, uint32_t val) {
-    const float* d = dets5 + (size_t)val * 5;
-    const float x = d[0], y = d[1], w = d[2], h = d[3], a = d[4];
-    RBoxFeat f = rbox_make_feat(x, y, w, h, a);
-    float4 q[4];
-    RotGeom::pack(f, q);
-#pragma unroll
-    for (int k = 0; k < 4; k++) rec[(size_t)pos * 4 + k] = q[k];
-    order[pos] = val;
-    const float mn = (h < w) ? h : w;
-    const bool ok = !(drop_small && mn < 0.001f);
-    if (ok) atomicOr(alive + (pos >> 6), 1ull << (pos & 63));
-    if (gate && ok) {
-      const float r = q[0].z, ms2 = q[0].w;
-      if (!slab_box_ok(gp, x, y, r, ms2)) bad = 1;
-      else {
-        uint32_t* s_cover = cover_lds();
-        const float hw = slab_halfwidth(gp, x, r);
-        const int b0 = slab_bin(x - hw, gp.x0, inv), b1 = slab_bin(x + hw, gp.x0, inv);
-        for (int wd = b0 >> 5; wd <= (b1 >> 5); wd++) {
-          const int lo = max(b0, wd * 32) & 31, hi = min(b1, wd * 32 + 31) & 31;
-          const uint32_t mk = (hi == 31 ? 0xffffffffu : ((1u << (hi + 1)) - 1u)) & ~((1u << lo) - 1u);
-          if ((s_cover[wd] & mk) != mk) atomicOr(&s_cover[wd], mk);
-        }
-      }
-    }
-  }
-  __device__ __forceinline__ void end(const PsBuf&) {
-    if (!gate) return;                                   // (uniform: every thread derived the same gate)
-    const int anybad = __syncthreads_or(bad);
-    if (anybad && threadIdx.x == 0) atomicOr(slab_flag, 1);
-    uint32_t* s_cover = cover_lds();
-    uint32_t* dst = slab_cover + (size_t)(blockIdx.x % kSlabCopies) * kSlabWords;
-    for (int k = threadIdx.x; k < kSlabWords; k += blockDim.x) {
-      const uint32_t v = s_cover[k];
-      if (v && (__hip_atomic_load(dst + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & v) != v) atomicOr(dst + k, v);
-    }
-  }
-};
 
 // ---- float64 rotated boxes (RotGeom64): 64-bit keys from the double scores, records from the double boxes
 __device__ __forceinline__ uint64_t score_desc_key64(double s) {
@@ -687,19 +617,18 @@ static int nms_steps(int kind, NmsArgs& a, const Carve& cv, int64_t nseg, int64_
 // One list sorted by descending score, ties by ascending index (nms_rotated_cuda.cu:81-82 leaves the tie order to an
 // unstable sort; this is the documented rule here): sorted keys in cv.keys_b, order in cv.vals_b.  Up to kPsMaxN elements:
 // three launches (psrs_sort.h); longer lists: key kernel + LSD radix sort over the four score bytes (segsort.h).
-// prep != NULL: the rotated single list -- the records are written by the sort's last kernel when the three-launch sort runs
-// (*prep_done = 1), else the caller launches k_prep_rot
+// (Writing the NMS records in the tail of the sort's last kernel instead of a launch of their own was built and measured in
+//  round 4: the bucket kernel went from 16.6 to 34 us -- one workgroup per CU because of its 104 KB of LDS, the double-precision
+//  sin / cos and the gathers of the boxes at that occupancy -- against 8 us for k_prep_rot: 9 us slower per call.  Not kept.)
 static int sort_single_list(const float* scores, int score_stride, const float* dets5, int drop_small, int64_t n, const Carve& cv,
-                            LocalExtras x, int* nparts_out, hipStream_t st, RotPrepTail* prep = nullptr, int* prep_done = nullptr) {
+                            const LocalExtras& x, int* nparts_out, hipStream_t st) {
   if (n <= kPsMaxN) {
     PsBuf b{};
     b.run_k = cv.keys_a; b.run_v = cv.vals_a; b.out_k = cv.keys_b; b.out_v = cv.vals_b; b.n = (int)n; b.n_dev = nullptr; b.err = nullptr;
     ps_carve_scratch(cv.sort_tmp, &b);
     const int runs = (int)((n + kPsRun - 1) / kPsRun);
-    if (prep != nullptr) { x.alive = cv.alive; x.n_alive = (long long)(cv.alive_bytes / 8); }
     k_ps_local_scores<<<(unsigned)runs, kPsRun, 0, st>>>(b, scores, score_stride, dets5, drop_small, x);
     *nparts_out = runs;
-    if (prep != nullptr) { prep->nparts = runs; *prep_done = 1; return ps_finish(b, runs, st, *prep); }
     return ps_finish(b, runs, st);
   }
   const unsigned gb = (unsigned)((n + kPsRun - 1) / kPsRun);
@@ -733,7 +662,7 @@ static int run_nms(int kind, const float* boxes, int stride, const float* scores
   }
 
   const unsigned gb = (unsigned)((n + T - 1) / T);
-  int pre = 0, prep_fused = 0;
+  int pre = 0;
   // spatial index for the cross phases (grid.h): rotated boxes, one list, conservative rejects allowed (thr >= 0)
   static int no_grid = -1;                                         // OBB_NMS_NO_GRID=1: A/B switch for measurements
   if (no_grid < 0) { const char* e = getenv("OBB_NMS_NO_GRID"); no_grid = (e && atoi(e)) ? 1 : 0; }
@@ -748,18 +677,11 @@ static int run_nms(int kind, const float* boxes, int stride, const float* scores
     x.bar16 = reinterpret_cast<uint4*>(cv.bar); x.n_bar16 = (long long)(cv.bar_bytes / 16);
     x.grid16 = reinterpret_cast<uint4*>(cv.grid.meta); x.n_grid16 = use_grid ? (long long)(cv.grid_zero_bytes / 16) : 0ll;
     x.bbpart = (use_grid && kind == 0) ? cv.grid.bbpart : nullptr;
-    x.alive = nullptr; x.n_alive = 0;
-    RotPrepTail prep{};
-    prep.dets5 = boxes; prep.drop_small = drop_small; prep.n = (int)n; prep.rec = cv.rec; prep.alive = cv.alive; prep.order = cv.vals_b;
-    prep.bbpart = cv.grid.bbpart; prep.nparts = 0; prep.slab_cover = use_slabs ? cv.grid.slab_cover : nullptr; prep.slab_flag = cv.grid.slab_flag;
-    static int no_fuse = -1;                                       // OBB_NMS_NO_PREP_FUSION=1: A/B switch for measurements
-    if (no_fuse < 0) { const char* e = getenv("OBB_NMS_NO_PREP_FUSION"); no_fuse = (e && atoi(e)) ? 1 : 0; }
-    rc = sort_single_list(scores, score_stride, kind == 0 ? boxes : nullptr, kind == 0 ? drop_small : 0, n, cv, x, &cv.grid.nparts, st,
-                          (kind == 0 && !no_fuse) ? &prep : nullptr, &prep_fused);
+    rc = sort_single_list(scores, score_stride, kind == 0 ? boxes : nullptr, kind == 0 ? drop_small : 0, n, cv, x, &cv.grid.nparts, st);
     if (rc) return rc;
     pre = kNmsBarZeroed;
   }
-  if (!prep_fused) {
+  {
     ProfScope ps(PROF_NMS_PREP, st);
     if (kind == 0) k_prep_rot<<<gb, T, 0, st>>>(boxes, cv.vals_b, drop_small, (int)n, cv.rec, cv.alive, cv.grid.bbpart, cv.grid.nparts,
                                                 use_slabs ? cv.grid.slab_cover : nullptr, cv.grid.slab_flag);
@@ -990,7 +912,7 @@ int obb_non_max_suppression_obb_col(const void* pred, const void* objcol, int dt
 }
 
 int obb_profile_enable(int on) {
-  g_prof.on = on != 0;
+  g_prof.on = on == 2 ? 2 : (on != 0 ? 1 : 0);
   g_prof.used = 0;
   return OBB_OK;
 }

@@ -1,9 +1,9 @@
 // Pairwise IoU entry points: element-wise pairs, dense matrices, and the devkit's
 // rbox overlaps (DOTA_devkit/poly_nms_gpu/poly_overlaps_kernel.cu:280-353).
 //
-// Layout: one wave-sized workgroup per 64 x 64 output tile.  Lanes own COLUMNS
-// (so each store instruction writes 64 consecutive floats of one output row),
-// the row box is wave-uniform and read from LDS as a broadcast.  The <=24/20
+// Layout: a 64 x 64 output tile per workgroup.  Rotated IoU: one wave, lanes own COLUMNS (each store instruction writes 64
+// consecutive floats of one output row), the row box is wave-uniform and read from LDS as a broadcast.  Quad IoU: four
+// waves, 16 rows each, exact zeros written at once and the clips run from a compacted queue (k_quad_tile).  The <= 24 / 20
 // clip points of each lane live in an LDS column (bank == lane).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -50,38 +50,6 @@ __global__ __launch_bounds__(64) void k_riou_matrix(const float* __restrict__ a5
   }
 }
 
-__global__ __launch_bounds__(64) void k_quad_matrix(const float* __restrict__ a, long long sa, long long n,
-                                                    const float* __restrict__ b, long long sb, long long k,
-                                                    float* __restrict__ out) {
-  __shared__ float4 rowrec[64 * 2];
-  __shared__ uint32_t rowcone[64];
-  __shared__ float scr[QuadGeom::SCR * 64];
-  const int lane = threadIdx.x;
-  const long long i0 = (long long)blockIdx.y * 64, j = (long long)blockIdx.x * 64 + lane;
-  {
-    long long i = i0 + lane;
-    float v[8];
-#pragma unroll
-    for (int c = 0; c < 8; c++) v[c] = (i < n) ? a[i * sa + c] : 0.f;
-    rowrec[lane * 2] = make_float4(v[0], v[1], v[2], v[3]);
-    rowrec[lane * 2 + 1] = make_float4(v[4], v[5], v[6], v[7]);
-    rowcone[lane] = quad_cone_bits(quad_make_feat(v));
-  }
-  QuadFeat B = {};
-  if (j < k) {
-#pragma unroll
-    for (int c = 0; c < 4; c++) { B.x[c] = b[j * sb + 2 * c]; B.y[c] = b[j * sb + 2 * c + 1]; }
-  }
-  const uint32_t cone_b = j < k ? quad_cone_bits(B) : kConeNone;
-  __syncthreads();
-  const int nr = (int)((n - i0) < 64 ? (n - i0) : 64);
-  for (int r = 0; r < nr; r++) {
-    QuadFeat A = QuadGeom::unpack(rowrec[r * 2], rowrec[r * 2 + 1]);
-    // the exact cone rule (piou_device.h): all 16 terms of the reference's sum are exactly zero -> IoU = +0, no clip needed
-    if (j < k) out[(i0 + r) * k + j] = quad_cone_skip(rowcone[r], cone_b) ? 0.f : QuadGeom::iou(A, B, scr + lane);
-  }
-}
-
 // RotBox2Poly (poly_overlaps_kernel.cu:280-297): fp32 cos/sin, corner arithmetic in double
 // (the "/ 2.0" literals promote), one rounding to float per coordinate.
 __device__ __forceinline__ void rbox_to_quad_devkit(const float* d, float* qx, float* qy) {
@@ -97,33 +65,69 @@ __device__ __forceinline__ void rbox_to_quad_devkit(const float* d, float* qx, f
   qy[3] = (float)(y + ss * (-w / 2.0) + cs * (-h / 2.0));
 }
 
-__global__ __launch_bounds__(64) void k_rbox_overlaps(const float* __restrict__ boxes, long long n,
-                                                      const float* __restrict__ query, long long k, float* __restrict__ out) {
-  __shared__ float4 rowrec[64 * 2];
-  __shared__ uint32_t rowcone[64];
-  __shared__ float scr[QuadGeom::SCR * 64];
-  const int lane = threadIdx.x;
-  const long long i0 = (long long)blockIdx.y * 64, j = (long long)blockIdx.x * 64 + lane;
-  {
-    long long i = i0 + lane;
-    QuadFeat A = {};
-    if (i < n) rbox_to_quad_devkit(boxes + i * 5, A.x, A.y);
-    rowrec[lane * 2] = make_float4(A.x[0], A.y[0], A.x[1], A.y[1]);
-    rowrec[lane * 2 + 1] = make_float4(A.x[2], A.y[2], A.x[3], A.y[3]);
-    rowcone[lane] = i < n ? quad_cone_bits(A) : kConeNone;
+// Dense quad IoU tile: 64 rows x 64 columns per workgroup of four waves (devPolyIoU, utils/nms_rotated/src/poly_nms_cuda.cu:122-142;
+// DEVKIT: the rows / columns are rboxes turned into quads by RotBox2Poly, DOTA_devkit/poly_nms_gpu/poly_overlaps_kernel.cu:280-353).
+// Round 3 ran one wave per tile, every lane clipping its own column against the row of the trip: a pair the exact cone rule
+// (piou_device.h) could skip still cost a full clip whenever ONE of the 64 lanes needed one.  Now a wave walks its 16 rows, writes
+// the exact zeros of the skipped pairs straight away and pushes the others into a ring queue in LDS; the clip (48 half-plane
+// cuts, ~10^4 instructions) only ever runs on 64 queued pairs at a time, whatever tile they come from.
+constexpr int kQtWaves = 4;
+template <bool DEVKIT>
+__global__ __launch_bounds__(64 * kQtWaves) void k_quad_tile(const float* __restrict__ a, long long sa, long long n, const float* __restrict__ b,
+                                                             long long sb, long long k, float* __restrict__ out) {
+  __shared__ float4 rowq[64 * 2], colq[64 * 2];
+  __shared__ uint32_t rowcone[64], colcone[64];
+  __shared__ uint32_t queue[kQtWaves][128];
+  __shared__ float scr[kQtWaves][QuadGeom::SCR * 64];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const long long i0 = (long long)blockIdx.y * 64, j0 = (long long)blockIdx.x * 64;
+  if (tid < 128) {                                       // threads 0..63 stage the rows, 64..127 the columns
+    const bool is_col = tid >= 64;
+    const long long idx = (is_col ? j0 : i0) + lane, lim = is_col ? k : n;
+    const float* src = is_col ? b : a;
+    const long long st = is_col ? sb : sa;
+    QuadFeat q = {};
+    if (idx < lim) {
+      if (DEVKIT) rbox_to_quad_devkit(src + idx * 5, q.x, q.y);
+      else {
+#pragma unroll
+        for (int c = 0; c < 4; c++) { q.x[c] = src[idx * st + 2 * c]; q.y[c] = src[idx * st + 2 * c + 1]; }
+      }
+    }
+    float4* dq = is_col ? colq : rowq;
+    dq[lane * 2] = make_float4(q.x[0], q.y[0], q.x[1], q.y[1]);
+    dq[lane * 2 + 1] = make_float4(q.x[2], q.y[2], q.x[3], q.y[3]);
+    (is_col ? colcone : rowcone)[lane] = idx < lim ? quad_cone_bits(q) : kConeNone;
   }
-  QuadFeat B = {};
-  if (j < k) rbox_to_quad_devkit(query + j * 5, B.x, B.y);
-  const uint32_t cone_b = j < k ? quad_cone_bits(B) : kConeNone;
   __syncthreads();
+  uint32_t* q = queue[wv];
+  int head = 0, count = 0;                               // wave-uniform
+  auto drain = [&](int cnt) {
+    __builtin_amdgcn_wave_barrier();
+    if (lane < cnt) {
+      const uint32_t e = q[(head + lane) & 127];
+      const int r = (int)(e >> 8), c = (int)(e & 255u);
+      const QuadFeat A = QuadGeom::unpack(rowq[r * 2], rowq[r * 2 + 1]), B = QuadGeom::unpack(colq[c * 2], colq[c * 2 + 1]);
+      out[(i0 + r) * k + j0 + c] = QuadGeom::iou(A, B, scr[wv] + lane);
+    }
+    head = (head + cnt) & 127; count -= cnt;
+    __builtin_amdgcn_wave_barrier();
+  };
   const int nr = (int)((n - i0) < 64 ? (n - i0) : 64);
-  for (int r = 0; r < nr; r++) {
-    QuadFeat A = QuadGeom::unpack(rowrec[r * 2], rowrec[r * 2 + 1]);
-    // the exact cone rule (piou_device.h): all 16 terms of the reference's sum are exactly zero -> IoU = +0, no clip needed
-    if (j < k) out[(i0 + r) * k + j] = quad_cone_skip(rowcone[r], cone_b) ? 0.f : QuadGeom::iou(A, B, scr + lane);
+  const bool cvalid = j0 + lane < k;
+  const uint32_t cone_b = colcone[lane];
+  for (int r = wv * 16; r < wv * 16 + 16 && r < nr; r++) {
+    // the exact cone rule: all 16 terms of the reference's sum are exactly zero -> IoU = +0, no clip
+    const bool skip = quad_cone_skip(rowcone[r], cone_b);
+    if (cvalid && skip) out[(i0 + r) * k + j0 + lane] = 0.f;
+    const bool work = cvalid && !skip;
+    const unsigned long long m = __ballot(work);
+    if (work) q[(head + count + __popcll(m & ((1ull << lane) - 1ull))) & 127] = ((uint32_t)r << 8) | (uint32_t)lane;
+    count += __popcll(m);
+    if (count >= 64) drain(64);
   }
+  if (count > 0) drain(count);
 }
-
 
 // DOTA Task-1 evaluation, the det x GT part of voc_eval (DOTA_devkit/dota_evaluation_task1.py:168-223): for every
 // detection, over the ground-truth quads of ITS image, the horizontal-box gate with the +1 convention (:181-204,
@@ -227,7 +231,7 @@ int obb_quad_iou_matrix_f32(const float* a, int64_t a_stride, int64_t n, const f
   if (n == 0 || k == 0) return OBB_OK;
   dim3 g((unsigned)((k + 63) / 64), (unsigned)((n + 63) / 64));
   if (g.y > 65535) return OBB_ERR_BAD_ARG;
-  k_quad_matrix<<<g, 64, 0, (hipStream_t)stream>>>(a, a_stride, n, b, b_stride, k, out);
+  k_quad_tile<false><<<g, 64 * kQtWaves, 0, (hipStream_t)stream>>>(a, a_stride, n, b, b_stride, k, out);
   return OBB_CHECK_LAUNCH();
 }
 
@@ -236,7 +240,7 @@ int obb_rbox_overlaps_f32(const float* boxes5, int64_t n, const float* query5, i
   if (n == 0 || k == 0) return OBB_OK;
   dim3 g((unsigned)((k + 63) / 64), (unsigned)((n + 63) / 64));
   if (g.y > 65535) return OBB_ERR_BAD_ARG;
-  k_rbox_overlaps<<<g, 64, 0, (hipStream_t)stream>>>(boxes5, n, query5, k, out);
+  k_quad_tile<true><<<g, 64 * kQtWaves, 0, (hipStream_t)stream>>>(boxes5, 5, n, query5, 5, k, out);
   return OBB_CHECK_LAUNCH();
 }
 

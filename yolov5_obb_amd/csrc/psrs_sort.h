@@ -240,24 +240,13 @@ __global__ __launch_bounds__(kPsRun) void k_ps_split(PsBuf b) {
   }
 }
 
-// What a bucket's workgroup does with its sorted elements: the default tail stores the sorted (key, value) list; a caller's tail may
-// do the work of the kernel that would read the list next (nms.hip: the NMS records of the single-list path) and save that
-// launch.  begin() / end() run once per workgroup (all threads), element() once per element with its final position.
-struct PsStoreTail {
-  __device__ __forceinline__ void begin(const PsBuf&) {}
-  __device__ __forceinline__ void element(const PsBuf& b, int pos, unsigned long long k, uint32_t v) { b.out_k[pos] = k; b.out_v[pos] = v; }
-  __device__ __forceinline__ void end(const PsBuf&) {}
-};
-
-template <class Tail>
-__global__ __launch_bounds__(kPsRun) void k_ps_bucket(PsBuf b, Tail tail) {
+__global__ __launch_bounds__(kPsRun) void k_ps_bucket(PsBuf b) {
   extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];   // keys [kPsBucketCap] | values [kPsBucketCap]
   __shared__ int s_off[kPsMaxRuns + 1], s_lo[kPsMaxRuns], s_w[8][2];
   unsigned long long* s_k = reinterpret_cast<unsigned long long*>(s_raw);
   uint32_t* s_v = reinterpret_cast<uint32_t*>(s_k + kPsBucketCap);
   const int n = ps_count(b), R = (n + kPsRun - 1) / kPsRun, j = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   if (j >= R) return;
-  tail.begin(b);
   // piece of run `tid` that belongs to bucket j: (splitter j-1, splitter j]
   int lo = 0, hi = 0;
   if (tid < R) {
@@ -296,7 +285,7 @@ __global__ __launch_bounds__(kPsRun) void k_ps_bucket(PsBuf b, Tail tail) {
     if (npad <= 512) sort_lds_regs<1>(s_k, s_v, npad, tid);
     else if (npad <= 1024) sort_lds_regs<2>(s_k, s_v, npad, tid);
     else sort_lds_regs<4>(s_k, s_v, npad, tid);
-    for (int q = tid; q < m; q += kPsRun) tail.element(b, base + q, s_k[q], s_v[q]);
+    for (int q = tid; q < m; q += kPsRun) { b.out_k[(size_t)base + q] = s_k[q]; b.out_v[(size_t)base + q] = s_v[q]; }
   } else {
     // large bucket: rank of an element = its index in its own piece + the elements of every other piece below it
     __syncthreads();
@@ -312,10 +301,9 @@ __global__ __launch_bounds__(kPsRun) void k_ps_bucket(PsBuf b, Tail tail) {
         while (l2 < h2) { const int mid = (l2 + h2) >> 1; if (s_k[mid] < e) l2 = mid + 1; else h2 = mid; }
         rank += l2 - l0;
       }
-      tail.element(b, base + rank, e, s_v[q]);
+      b.out_k[(size_t)base + rank] = e; b.out_v[(size_t)base + rank] = s_v[q];
     }
   }
-  tail.end(b);
 }
 
 constexpr size_t kPsBucketLds = (size_t)kPsBucketCap * 12;
@@ -327,17 +315,15 @@ static inline void ps_carve_scratch(void* scratch, PsBuf* b) {
   b->cut = reinterpret_cast<int*>(reinterpret_cast<char*>(scratch) + (size_t)kPsMaxRuns * kPsSamp * 8);
 }
 // launches 2 and 3 (the caller has launched its k_ps_local_* flavour over `runs` workgroups)
-template <class Tail>
-static int ps_finish(const PsBuf& b, int runs, hipStream_t st, const Tail& tail) {
+static int ps_finish(const PsBuf& b, int runs, hipStream_t st) {
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)k_ps_bucket<Tail>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPsBucketLds) != hipSuccess) return OBB_ERR_LAUNCH;
+    if (hipFuncSetAttribute((const void*)k_ps_bucket, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPsBucketLds) != hipSuccess) return OBB_ERR_LAUNCH;
     attr_set = true;
   }
   if (runs > 1) k_ps_split<<<(unsigned)runs, kPsRun, 0, st>>>(b);
-  k_ps_bucket<Tail><<<(unsigned)runs, kPsRun, kPsBucketLds, st>>>(b, tail);
+  k_ps_bucket<<<(unsigned)runs, kPsRun, kPsBucketLds, st>>>(b);
   return hipGetLastError() == hipSuccess ? OBB_OK : OBB_ERR_LAUNCH;
 }
-static int ps_finish(const PsBuf& b, int runs, hipStream_t st) { return ps_finish(b, runs, st, PsStoreTail{}); }
 
 }  // namespace obb
