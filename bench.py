@@ -590,6 +590,61 @@ def main():
                         "ms_fwd_bwd": round(lms, 4), "grad_bytes": gbytes,
                         "note": "gradient tensors written exactly once (k_loss_bwd_dense, HBM-write bound)"}
             del pg
+            # the dtype train.py runs it in: fp16 head outputs (amp.autocast, train.py:324-326) and a GradScaler's scaled incoming
+            # gradient (:332) -- same shapes
+            ph = [x.to(dev).half().requires_grad_(True) for x in p_l]
+
+            def loss_step_h():
+                for x in ph:
+                    x.grad = None
+                ls, _ = cl(ph, tg)
+                (ls * 1024.0).backward()
+            for _ in range(3):
+                loss_step_h()
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(10):
+                loss_step_h()
+            e1.record()
+            torch.cuda.synchronize()
+            loss_obj["loss_fp16"] = {"workload": "the same shapes with fp16 head outputs and a x1024 incoming gradient (amp.autocast + GradScaler, train.py:324-332)",
+                                     "ms_fwd_bwd": round(e0.elapsed_time(e1) / 10, 4), "grad_bytes": sum(x.numel() * 2 for x in ph)}
+            del ph
+            # one training step of a small model around the HIP loss the way train.py drives it (:245,320-345): DDP on RCCL when the job
+            # is a process group, autocast, GradScaler, SGD -- a plumbing figure (three conv stems + this package's Detect at 1024^2,
+            # bs 16: the convolutions are PyTorch-ROCm's), next to the loss's own share of it
+            try:
+                from tests.test_train_leg_gpu import TinyObb
+                hyp_t = synth.scaled_hyp(lnc, 1024)
+                torch.manual_seed(0)
+                net = TinyObb(lnc, hyp_t).to(dev).train()
+                step_model = net                                  # (rank 0 alone runs the extras: no DDP wrapper here -- its hooks and buckets with
+                cl_t = ComputeLoss(step_model)                    #  this loss are exercised by tests/test_train_leg_gpu.py on an RCCL group)
+                opt = torch.optim.SGD(step_model.parameters(), lr=0.01, momentum=0.9)
+                scaler = torch.amp.GradScaler("cuda")
+                im_t = torch.rand(16, 3, 1024, 1024, device=dev)
+
+                def train_step():
+                    opt.zero_grad(set_to_none=True)
+                    with torch.autocast("cuda", dtype=torch.float16):
+                        ls, _ = cl_t(step_model(im_t), tg)
+                    scaler.scale(ls).backward()
+                    scaler.step(opt)
+                    scaler.update()
+                for _ in range(3):
+                    train_step()
+                torch.cuda.synchronize()
+                e0.record()
+                for _ in range(10):
+                    train_step()
+                e1.record()
+                torch.cuda.synchronize()
+                loss_obj["train_step"] = {"workload": "TinyObb (3 conv stems + Detect, tests/test_train_leg_gpu.py) at (16,3,1024,1024): forward under autocast(fp16), "
+                                                      "HIP ComputeLoss (nt = 1500), GradScaler backward, SGD step; one process, no DDP wrapper (that leg: tests/test_train_leg_gpu.py)",
+                                          "ms_per_step": round(e0.elapsed_time(e1) / 10, 4), "scale": float(scaler.get_scale())}
+                del net, step_model, im_t
+            except Exception as e:
+                loss_obj["train_step"] = {"error": str(e)}
             # Detect decode of the batch: 3 conv outputs (16, 3*no, n, n) fp16 -> z (16,64512,no) + permuted heads
             na_d, sizes_d = 3, (128, 64, 32)
             convs = [torch.randn(bs, na_d * no, n, n, device=dev, dtype=torch.float16) for n in sizes_d]

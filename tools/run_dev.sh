@@ -12,7 +12,7 @@ if [ "${PYTEST:-1}" != "0" ]; then
   echo "pytest rc=$?" >> $O/pytest.log
 fi
 timeout 300 python tools/prof_regimes.py > $O/regimes.txt 2>&1
-OBB_NMS_NO_PREP_FUSION=1 timeout 300 python tools/prof_regimes.py > $O/regimes_nofuse.txt 2>&1
+
 OBB_NMS_PHASE_PROF=1 timeout 300 python tools/prof_regimes.py > $O/phases.txt 2>&1
 if [ "${PROF:-0}" = "1" ]; then
   rm -rf /tmp/p_kt
@@ -22,5 +22,5 @@ fi
 if [ "${BENCH:-0}" = "1" ]; then
   timeout 900 python bench.py > $O/bench.json 2> $O/bench.err
 fi
-[ -f $O/pytest.log ] && tail -14 $O/pytest.log; grep -E "^clustered|^uniform" $O/regimes.txt $O/regimes_nofuse.txt; [ -f $O/kernel_stats.md ] && head -14 $O/kernel_stats.md
+[ -f $O/pytest.log ] && tail -14 $O/pytest.log; grep -E "^clustered|^uniform" $O/regimes.txt; [ -f $O/kernel_stats.md ] && head -14 $O/kernel_stats.md
 [ -f $O/bench.json ] && cut -c1-300 $O/bench.json

@@ -132,6 +132,7 @@ __device__ __forceinline__ void rows_reject2(const float4& myrow, int r, const C
   G::cheap_reject2(ax, ay, az, aw, c, r0, r1);
 }
 
+constexpr int kResolveTail = 256;           // live edges from which ONE wave finishes a chunk's resolve (nms_resolve)
 constexpr int kBarGroups = 64;             // groups of 16 workgroups: grids of up to 1024
 constexpr int kNmsThreads = 512;
 constexpr int kNmsWaves = kNmsThreads / 64;
@@ -636,6 +637,7 @@ OBB_COLD_RESOLVE int nms_resolve(const NmsArgs& a, int g, int sb, int tm, int cn
     }
     if (tid < (int)(E & 3)) mine_e[mycnt++] = edges[(nvec << 2) + tid];
   }
+  if (tid == 0) { s_i[9] = 0; s_i[10] = 0; }                  // live-edge counters of the rounds (by round parity)
   __syncthreads();
   u64 tp = 0;
   if (a.prof && tid == 0) { tp = wall_clock64(); atomicAdd(a.prof + 25, (u64)E); atomicMax(a.prof + 27, (u64)E); atomicAdd(a.prof + 28, (u64)cn); atomicAdd(a.prof + 26, (u64)(lds_mode ? 1 : 0)); }
@@ -706,7 +708,11 @@ OBB_COLD_RESOLVE int nms_resolve(const NmsArgs& a, int g, int sb, int tm, int cn
       }
       if (compact) mycnt = w;
     }
+    // live edges of the whole list (LDS mode): two counters by round parity, the idle one is cleared for the next round
+    int* live_cnt = &s_i[9 + (round & 1)];
+    if (lds_mode && mycnt > 0) atomicAdd(live_cnt, mycnt);
     __syncthreads();
+    if (tid == 0) s_i[9 + ((round + 1) & 1)] = 0;
     bool rem = false;
     for (int j = tid; j < cn; j += kNmsThreads) {
       if (state[j] == 0) {
@@ -719,6 +725,57 @@ OBB_COLD_RESOLVE int nms_resolve(const NmsArgs& a, int g, int sb, int tm, int cn
     if (!lds_mode) {
       if (compact) lds_mode = true;                                        // the survivors are in LDS now
       else compact = __syncthreads_or(remaining > per ? 1 : 0) == 0;       // block-uniform: next round copies them
+    } else if (*live_cnt <= kResolveTail && (long long)kNmsThreads * per + kResolveTail <= lcap) {
+      // The tail: a few hundred live edges, a few dozen undecided boxes, and a dependency chain that still needs several
+      // rounds (a round here decides one level of the chain: 9-10 rounds for the 1873-box chunk of S-clustered K=300, of
+      // which the first leaves 29 846 -> ~100 edges).  A block-wide round costs ~3 us whatever it holds (three workgroup
+      // barriers, a pass over all cn states); ONE wave with the edges in registers runs a round in a few hundred cycles:
+      // kills by the sources kept so far; blocks by undecided sources; targets nobody blocks are kept; edges whose target is
+      // decided or whose source is dead are dropped.  Same fixed point: a box is kept once every higher-scored neighbour is
+      // dead, dropped as soon as one is kept.
+      uint32_t* tail_e = ledges + lcap - kResolveTail;   // (behind the per-thread blocks: checked above)
+      if (tid == 0) s_i[14] = 0;
+      __syncthreads();
+      if (mycnt > 0) {
+        const int tb = atomicAdd(&s_i[14], mycnt);
+        for (int k = 0; k < mycnt; k++) tail_e[tb + k] = mine_e[k];
+      }
+      __syncthreads();
+      if (tid < 64) {
+        const int et = s_i[14];
+        uint32_t ed[kResolveTail / 64];
+        bool lv[kResolveTail / 64];
+#pragma unroll
+        for (int c = 0; c < kResolveTail / 64; c++) { const int k = tid + 64 * c; lv[c] = k < et; ed[c] = lv[c] ? tail_e[k] : 0u; }
+        auto wsync = [&]() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); };
+        for (int guard = 0; guard < 70000; guard++) {
+#pragma unroll
+          for (int c = 0; c < kResolveTail / 64; c++)
+            if (lv[c] && state[ed[c] >> 16] == 1) state[ed[c] & 0xffff] = 2;                          // kills
+          wsync();
+#pragma unroll
+          for (int c = 0; c < kResolveTail / 64; c++)
+            if (lv[c] && state[ed[c] & 0xffff] == 0 && state[ed[c] >> 16] == 0) blocked[ed[c] & 0xffff] = 1;   // blocks
+          wsync();
+#pragma unroll
+          for (int c = 0; c < kResolveTail / 64; c++)
+            if (lv[c] && state[ed[c] & 0xffff] == 0 && !blocked[ed[c] & 0xffff]) state[ed[c] & 0xffff] = 1;      // nobody blocks it: kept
+          wsync();
+          bool any_live = false;
+#pragma unroll
+          for (int c = 0; c < kResolveTail / 64; c++)
+            if (lv[c]) {
+              const uint8_t sj = state[ed[c] & 0xffff], si = state[ed[c] >> 16];
+              blocked[ed[c] & 0xffff] = 0;
+              if (sj != 0 || si == 2) lv[c] = false; else any_live = true;
+            }
+          wsync();
+          if (__ballot(any_live) == 0ull) break;
+        }
+      }
+      __syncthreads();
+      if (a.prof && tid == 0) atomicAdd(a.prof + 11, (u64)(round + 2));
+      break;
     }
     if (round == 0) plap(12);
   }
