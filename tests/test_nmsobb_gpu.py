@@ -147,8 +147,11 @@ def test_in_lds_sort_path_and_an_undersold_hint(dev, oracle_lib):
         kw = dict(conf_thres=0.2, iou_thres=0.45, multi_label=True, max_det=1500, agnostic=agn)
         ref = pyref.non_max_suppression_obb(pred.clone(), **kw)
         general._cand_memo.clear()
-        _cmp(general.non_max_suppression_obb(pred.to(dev), **kw), ref)          # hint 0: library sort
+        general._cand_memo[key] = 0
+        _cmp(general.non_max_suppression_obb(pred.to(dev), **kw), ref)          # hint 0: the generic multi-workgroup sort
         assert 0 < general._cand_memo[key] <= 6144
+        general._cand_memo.clear()
+        _cmp(general.non_max_suppression_obb(pred.to(dev), **kw), ref)          # no history: the in-LDS path at once
         for rep in range(2):
             _cmp(general.non_max_suppression_obb(pred.to(dev), **kw), ref)      # hinted: in-LDS path
     kw = dict(conf_thres=0.001, iou_thres=0.45, multi_label=True, max_det=1500)
@@ -168,6 +171,7 @@ def test_the_bench_workload_itself_matches_the_oracle(dev, oracle_lib):
     ref = pyref.non_max_suppression_obb(pred.clone(), **kw)
     general._cand_memo.clear()
     p = pred.to(dev)
+    general._cand_memo[(64512, 15, True)] = 0                   # first the generic sort (hint 0), then the hinted in-LDS sort
     for rep in range(2):
         _cmp(general.non_max_suppression_obb(p, **kw), ref, ties=True)
     assert sum(r.shape[0] for r in ref) > 3000
@@ -183,7 +187,8 @@ def test_headline_tensors_of_bench_py(dev, oracle_lib, r):
     kw = dict(conf_thres=0.25, iou_thres=0.45, multi_label=True, max_det=1500)
     ref = pyref.non_max_suppression_obb(p.cpu().clone(), **kw)
     assert sum(x.shape[0] for x in ref) > 3000
-    for rep in range(2):                                   # first call of the shape (no hint), then the hinted in-LDS sort
+    general._cand_memo[(64512, 16, True)] = 0              # the generic sort first (hint 0), then the hinted in-LDS sort
+    for rep in range(2):
         _cmp(general.non_max_suppression_obb(p, **kw), ref, ties=True)
 
 

@@ -48,11 +48,11 @@ class Detect(nn.Module):
 
     @staticmethod
     def _tensor_key(t):
-        """(version, storage address) of a tensor; inference tensors track no version counter: their address alone."""
+        """(version, storage address) of a tensor; inference tensors track no version counter: None = "cannot be cached"."""
         try:
             return (t._version, t.data_ptr())
         except RuntimeError:
-            return (None, t.data_ptr())
+            return None
 
     def _host_tables(self):
         # The reference reads anchors / stride on every call (models/yolo.py:90-91), so an in-place update after the first
@@ -60,7 +60,9 @@ class Detect(nn.Module):
         # on the tensors' version counters and storage, like ComputeLoss._refresh_host_tables.
         stride_t = torch.as_tensor(self.stride)
         key = (self._tensor_key(self.anchors), self._tensor_key(stride_t))
-        if self._anchor_px is None or self._anchor_px[2] != key:
+        # (a tensor without a version counter -- created under torch.inference_mode() -- can change unnoticed: the small host table
+        #  is then rebuilt on every call, as the reference re-reads the anchors on every call)
+        if self._anchor_px is None or None in key or self._anchor_px[2] != key:
             st = [float(s) for s in stride_t.float().cpu().tolist()]
             an = self.anchors.detach().float().cpu()
             px = [(an[i] * st[i]).reshape(-1).tolist() for i in range(self.nl)]      # anchor_grid values (:90-91)

@@ -22,9 +22,9 @@ _POLL_GIVE_UP = 1.0   # ... after this many seconds: fall back to a stream synch
 _MAX_NMS = 30000    # utils/general.py:794
 _CSL = 180          # utils/general.py:784
 _cap_memo = {}      # (A, nc, multi_label) -> candidate slots per image that sufficed last time
-_ws_memo = {}       # (bs, cap, nc, agnostic) -> workspace bytes (a ctypes call saved per batch)
+_ws_memo = {}       # (bs, cap, nc, agnostic, grid capped) -> workspace bytes (a ctypes call saved per batch)
 _meta_memo = {}     # (device index, bs, thread) -> the int64 buffer the counters are read back from
-_cand_memo = {}     # same key -> largest candidate count of an image in the previous call (sort-algorithm hint)
+_cand_memo = {}     # same key -> largest candidate count of an image in the previous call (sort-algorithm hint; 0 forces the generic sort)
 _SORT_LDS_HINT = 6144   # include/obb_hip.h OBB_NMS_SORT_LDS_HINT: hints up to this select the one-workgroup-per-image sort ...
 _SORT_LDS_MAX = 8192    # ... OBB_NMS_SORT_LDS_MAX: which takes at most this many candidates of an image
 
@@ -132,12 +132,16 @@ def non_max_suppression_obb(prediction, conf_thres=0.25, iou_thres=0.45, classes
     capped = False                # obb_nms_set_max_grid is per calling thread (thread_local in the library): no other thread sees it
     try:
         while True:
-            hint = int(_cand_memo.get(key, 0))
+            # no history for this shape: assume the regime of the reference's default thresholds (at most a few thousand
+            # candidates per image: the one-workgroup-per-image sort); a batch that turns out larger reports it (status[1]) and is
+            # run once more on the multi-workgroup sort, which the memo then selects directly -- the first call of a shape is the fast
+            # path, not the slow one (round 3 started from hint 0 = the generic sort)
+            hint = int(_cand_memo.get(key, _SORT_LDS_HINT))
             if meta_np is not None:
                 meta_np.fill(_PENDING)
             with _lib.guard(dev):
                 st = _lib.stream_handle(dev)
-                wkey = (bs, cap, nc, agn)
+                wkey = (bs, cap, nc, agn, capped)          # (the library sizes the workspace from the calling thread's grid cap)
                 nbytes = _ws_memo.get(wkey)
                 if nbytes is None:
                     nbytes = _ws_memo[wkey] = L.obb_nms_obb_workspace_bytes(bs, cap, nc, agn)

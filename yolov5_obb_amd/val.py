@@ -61,6 +61,18 @@ def process_batch(detections, labels, iouv):
 
 
 _TAIL_MAX_BS = 64      # csrc/head.hip kValTailMaxBs: images per obb_val_tail_batch_f32 call
+_pin_cache = {}
+
+
+def _pinned_rows(n, cols):
+    """A pinned (n, cols) float32 view of a cached host buffer (per thread; grown geometrically)."""
+    import threading
+    key = (threading.get_ident(), cols)
+    buf = _pin_cache.get(key)
+    if buf is None or buf.shape[0] < n:
+        buf = torch.empty((max(1024, 2 * n), cols), dtype=torch.float32).pin_memory()
+        _pin_cache[key] = buf
+    return buf[:n]
 
 
 def val_tail_batch(preds, targets, shapes, iouv, want_boxes=False):
@@ -135,9 +147,15 @@ def val_tail_batch(preds, targets, shapes, iouv, want_boxes=False):
                                               part(boxes[2]) if boxes else C.c_void_p(0), part(boxes[3]) if boxes else C.c_void_p(0),
                                               part(stats), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev))
                 _lib.check(rc, "obb_val_tail_batch_f32")
-    host = stats.cpu()                                           # the one copy (and sync) of the batch
-    out = []
-    for b in range(bs):
-        h = host[offs[b]:offs[b + 1]]
-        out.append((h[:, :niou] > 0.5, h[:, niou].clone(), h[:, niou + 1].clone()))
+    # the one copy (and sync) of the batch: into a cached pinned buffer, then three splits (a per-image slicing loop of small
+    # host tensor ops cost more than the three launches)
+    host = _pinned_rows(n, niou + 2)
+    if n:
+        host.copy_(stats, non_blocking=True)
+        torch.cuda.current_stream(dev).synchronize()
+    host = host.clone()                                          # (the pinned buffer is reused by the next batch)
+    correct = (host[:, :niou] > 0.5).split(counts)
+    conf = host[:, niou].contiguous().split(counts)
+    pcls = host[:, niou + 1].contiguous().split(counts)
+    out = list(zip(correct, conf, pcls))
     return (out, (boxes, offs)) if want_boxes else out
