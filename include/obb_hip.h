@@ -60,6 +60,13 @@ int obb_nms_set_max_grid(int max_workgroups);
 int obb_profile_enable(int on);
 int obb_profile_collect(double* ms_sum_host, int64_t* count_host, int n_stages);
 
+/* Environment variables read by the library (once per process).  Every build:
+ *   OBB_NMS_POLY_STRICT=1   quad NMS: only the proved skip rule (csrc/piou_device.h: the cone rule); =2: no rule at all, every pair
+ *                           is clipped like the reference does (tests/test_nms_gpu.py::test_nms_poly_strict_equals_skip_100k)
+ *   OBB_NMS_PHASE_PROF=1    in-kernel phase timers of the persistent NMS kernel, printed to stderr (synchronises; development aid)
+ * Development builds only (make DEV=1; ignored otherwise): the A/B switches OBB_NMS_NO_GRID, OBB_NMS_NO_SLABS, OBB_NO_CLASS_SEG,
+ * OBB_NO_LDS_SORT, OBB_NMS_GROUP_AFTER_CUT, OBB_NMS_CHUNK*, OBB_NMS_GROW, OBB_NMS_SLAB_CAP, OBB_GRID_FINE, OBB_LOSS_NT. */
+
 /* ------------------------------------------------------------------ NMS ------------------------------ */
 
 /* Scratch bytes for n boxes in nseg segments.  kind: 0 = rotated boxes, 1 = quads, 2 = double-precision quads (merge NMS),

@@ -303,19 +303,13 @@ int obb_detect_decode_col(const void* conv_out, int dtype, int64_t bs, int64_t n
   }
   const int HW = (int)(ny * nx);
   const size_t esz = dtype == 0 ? 4 : 2;
-  // variants (OBB_DETECT_VARIANT, measurements on (16, 3*200, 128..32, ..), round 3 -- all with eight channel rows in flight
-  // per thread in the load phase, which is what moved the kernel: fp16 0.310 -> 0.281 ms, fp32 0.590 -> 0.488 ms):
-  // 3 = variant 0 with non-temporal loads and stores (default: fp16 0.266, fp32 0.480 ms; every byte is touched once, and
-  //     a streaming store does not push the lines the other workgroups are about to read out of L2); 4 = stores only
-  //     (0.268-0.280), 5 = loads only (0.281: no gain);
-  // 0 = 64-position tiles, 256 threads, 2-element skew, element-wise LDS stores (fp16 0.282, fp32 0.488-0.512 ms);
-  // 1 = 4-element skew and one LDS store per 4-position group (fp16 0.282, fp32 0.798: the 16-byte LDS stores conflict);
-  // 2 = 128-position tiles with 512 threads, i.e. 256-byte read runs at the same number of waves per CU (fp16 0.277, fp32 0.954)
-  static int variant = -1;
-  if (variant < 0) { const char* e = getenv("OBB_DETECT_VARIANT"); variant = e ? atoi(e) : 3; if (variant < 0 || variant > 5) variant = 3; }
-  const int tile_hw = variant == 2 ? 128 : 64;
-  const int nthreads = variant == 2 ? 512 : 256;
-  const int skew = (variant == 0 || variant >= 3) ? 2 : 4;
+  // 64-position tiles, 256 threads, 2-element skew, eight channel rows in flight per thread, non-temporal loads and stores
+  // (every byte is touched once; a streaming store does not push the lines other workgroups are about to read out of L2).
+  // Measured against it in round 3 on (16, 3*200, 128..32, ..) and removed: a 4-element skew with one LDS store per 4-position
+  // group (fp32 0.80 against 0.48 ms: the 16-byte LDS stores conflict), 128-position tiles with 512 threads (fp16 0.277
+  // against 0.266, fp32 0.95), non-temporal stores only (0.268-0.280) / loads only (0.281).
+  const int tile_hw = 64;
+  const int skew = 2;
   const size_t lds = ((size_t)no * tile_hw + (size_t)skew * (size_t)(no / 8 + 2)) * esz;   // skewed rows (tix in the kernel)
   dim3 grid((unsigned)((HW + tile_hw - 1) / tile_hw), (unsigned)(bs * na));
   hipStream_t st = (hipStream_t)stream;
@@ -333,14 +327,8 @@ int obb_detect_decode_col(const void* conv_out, int dtype, int64_t bs, int64_t n
   } while (0)
 #define OBB_LAUNCH_DETECT_T(T)                                                                                                      \
   do {                                                                                                                              \
-    if (variant == 3 && vec) { OBB_LAUNCH_DETECT(T, true, 64, 256, 2, true); }                                                      \
-    else if (variant == 4 && vec) { OBB_LAUNCH_DETECT(T, true, 64, 256, 2, true, false); }                                          \
-    else if (variant == 5 && vec) { OBB_LAUNCH_DETECT(T, true, 64, 256, 2, false, true); }                                          \
-    else if (variant == 2) { if (vec) OBB_LAUNCH_DETECT(T, true, 128, 512, 4); else OBB_LAUNCH_DETECT(T, false, 128, 512, 4); }          \
-    else if (variant == 1) { if (vec) OBB_LAUNCH_DETECT(T, true, 64, 256, 4); else OBB_LAUNCH_DETECT(T, false, 64, 256, 4); }      \
-    else { if (vec) OBB_LAUNCH_DETECT(T, true, 64, 256, 2); else OBB_LAUNCH_DETECT(T, false, 64, 256, 2); }                         \
+    if (vec) { OBB_LAUNCH_DETECT(T, true, 64, 256, 2, true); } else { OBB_LAUNCH_DETECT(T, false, 64, 256, 2); }                    \
   } while (0)
-  (void)nthreads;
   if (dtype == 0) OBB_LAUNCH_DETECT_T(float); else OBB_LAUNCH_DETECT_T(__half);
 #undef OBB_LAUNCH_DETECT_T
 #undef OBB_LAUNCH_DETECT

@@ -693,9 +693,7 @@ int obb_loss_backward(const obb_loss_config* cfg, const void* const* p_levels_ho
   }
   k_loss_setup<<<1, 256, 0, st>>>(d, cv.dev);
   dim3 gd(2048, cfg->nl);
-  // OBB_LOSS_NT=0: plain stores (measurements)
-  static int nts = -1;
-  if (nts < 0) { const char* e = getenv("OBB_LOSS_NT"); nts = (e && atoi(e) == 0) ? 0 : 1; }
+  static const int nts = obb_dev_switch("OBB_LOSS_NT", 1) != 0 ? 1 : 0;      // 0: plain stores (development builds: measurements)
   if (dtype == 0) { if (nts) k_loss_bwd_dense<float, true><<<gd, 256, 0, st>>>(cv.dev); else k_loss_bwd_dense<float, false><<<gd, 256, 0, st>>>(cv.dev); }
   else { if (nts) k_loss_bwd_dense<__half, true><<<gd, 256, 0, st>>>(cv.dev); else k_loss_bwd_dense<__half, false><<<gd, 256, 0, st>>>(cv.dev); }
   if (d.cap > 0) {

@@ -362,22 +362,18 @@ static inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a
 // OBB_NMS_CHUNK_MAX (default 8192 for a single list, 2048 per segment for batches: the edge list is sized for
 // the worst case cap*(cap-1)/2 per segment).
 static int env_int(const char* name, int dflt, int lo, int hi) {
-  const char* e = getenv(name);
-  int v = e ? atoi(e) : dflt;
+  int v = obb_dev_switch(name, dflt);
   if (v < lo) v = lo;
   if (v > hi) v = hi;
   return (v + 63) / 64 * 64;
 }
-static int cap_first() { static int c = 0; if (!c) c = env_int("OBB_NMS_CHUNK", 2048, 64, 8192); return c; }   // clipped to cap_max in the kernel
+static int cap_first() { static const int c = env_int("OBB_NMS_CHUNK", 2048, 64, 8192); return c; }   // clipped to cap_max in the kernel
 // (the edge list of a team is sized for the worst case cap*(cap-1)/2 of one chunk: 134 MB at 8192, 8.4 MB at 2048,
 //  2 MB at 1024 -- times the number of teams)
 static int cap_max(int64_t nseg) {
-  static int c1 = 0, cb = 0, cm = 0;
-  if (!c1) {
-    c1 = env_int("OBB_NMS_CHUNK_MAX", 8192, 64, 16384);
-    cb = env_int("OBB_NMS_CHUNK_MAX_BATCHED", 2048, 64, 16384);
-    cm = env_int("OBB_NMS_CHUNK_MAX_MANY", 1024, 64, 16384);
-  }
+  static const int c1 = env_int("OBB_NMS_CHUNK_MAX", 8192, 64, 16384);
+  static const int cb = env_int("OBB_NMS_CHUNK_MAX_BATCHED", 2048, 64, 16384);
+  static const int cm = env_int("OBB_NMS_CHUNK_MAX_MANY", 1024, 64, 16384);
   return nseg == 1 ? c1 : (nseg <= 64 ? cb : cm);
 }
 
@@ -402,12 +398,11 @@ struct Carve {
 
 // table slots of the spatial index (power of two, multiple of 4096)
 // cells of side 2 R_L / 2^fine (grid.h): 1 measured best at 100k (K=3000: 716 -> 648 us, uniform 2361 -> 2138; 2: no further gain)
-static int grid_fine() { static int f = -1; if (f < 0) { const char* e = getenv("OBB_GRID_FINE"); f = e ? atoi(e) : 1; if (f < 0 || f > 2) f = 1; } return f; }
+static int grid_fine() { static const int f = [] { const int v = obb_dev_switch("OBB_GRID_FINE", 1); return (v < 0 || v > 2) ? 1 : v; }(); return f; }
 // Skip rules of the quad NMS (piou_device.h): bit 0 = the exact cone rule (proved), bit 1 = the bounding-box rule (measured noise
 // bound).  OBB_NMS_POLY_STRICT=1: cone rule only (every other pair is clipped); =2: no rule at all, every pair is clipped.
 static int quad_skip() {
-  static int f = -1;
-  if (f < 0) { const char* e = getenv("OBB_NMS_POLY_STRICT"); const int v = e ? atoi(e) : 0; f = v == 1 ? 1 : (v >= 2 ? 0 : 3); }
+  static const int f = [] { const char* e = getenv("OBB_NMS_POLY_STRICT"); const int v = e ? atoi(e) : 0; return v == 1 ? 1 : (v >= 2 ? 0 : 3); }();
   return f;
 }
 static uint32_t grid_slots(int64_t n) { return (n >= 262144 || (grid_fine() > 0 && n >= 32768)) ? 65536u : 16384u; }
@@ -532,17 +527,8 @@ static int launch_persist(const NmsArgs& a, unsigned nb, hipStream_t st) {   // 
   if (lds < (size_t)6 * a.capmax) return OBB_ERR_INTERNAL;    // (aliased by resolve: state + blocked bytes of one chunk + its ordered output list)
   lds += (size_t)a.capmax * 4;                                // + this workgroup's copy of the chunk list
   if (lds > kPersistLdsMax) return OBB_ERR_INTERNAL;
-  // OBB_NMS_COOP=1: cooperative launch -- the runtime guarantees that all workgroups are resident together (what the
-  // kernel's spin barriers need) instead of the kernel finding out by a barrier time-out; measured switch
-  static int coop = -1;
-  if (coop < 0) { const char* e = getenv("OBB_NMS_COOP"); coop = (e && atoi(e)) ? 1 : 0; }
-  if (coop) {
-    NmsArgs tmp = a;
-    void* params[] = {(void*)&tmp};
-    if (hipLaunchCooperativeKernel((const void*)k_nms_persist<G, GRID>, dim3(nb), dim3(kNmsThreads), params, (unsigned)lds, st) != hipSuccess)
-      return OBB_ERR_LAUNCH;
-    return OBB_OK;
-  }
+  // (a cooperative launch -- the runtime guarantees residency instead of the kernel finding out by a barrier time-out -- was
+  //  measured in round 3: +18 us per call; the abort + retry with 8 workgroups stays the answer to a grid that is not resident)
   k_nms_persist<G, GRID><<<nb, kNmsThreads, lds, st>>>(a);
   return OBB_OK;
 }
@@ -571,9 +557,8 @@ static int nms_steps(int kind, NmsArgs& a, const Carve& cv, int64_t nseg, int64_
   a.bar = cv.bar; a.abort_flag = cv.abort_flag; a.nseg = (int)nseg;
   a.bar_sub = cv.nedges + kMaxTeams;                 // group counters of the grid-wide barrier, behind the per-team words
   a.cap_first = cap_first();
-  { static int grow = -1; if (grow < 0) { const char* e = getenv("OBB_NMS_GROW"); grow = e ? atoi(e) : 2; if (grow < 2 || grow > 8) grow = 2; } a.grow_sparse = grow; }
-  static int phase_prof = -1;
-  if (phase_prof < 0) { const char* e = getenv("OBB_NMS_PHASE_PROF"); phase_prof = (e && atoi(e)) ? 1 : 0; }
+  { static const int grow = [] { const int v = obb_dev_switch("OBB_NMS_GROW", 2); return (v < 2 || v > 8) ? 2 : v; }(); a.grow_sparse = grow; }
+  static const int phase_prof = [] { const char* e = getenv("OBB_NMS_PHASE_PROF"); return (e && atoi(e)) ? 1 : 0; }();
   a.prof = nullptr;
   if (phase_prof) {   // development aid: print the previous call's phase times (synchronises!)
     u64 h[56];
@@ -664,11 +649,9 @@ static int run_nms(int kind, const float* boxes, int stride, const float* scores
   const unsigned gb = (unsigned)((n + T - 1) / T);
   int pre = 0;
   // spatial index for the cross phases (grid.h): rotated boxes, one list, conservative rejects allowed (thr >= 0)
-  static int no_grid = -1;                                         // OBB_NMS_NO_GRID=1: A/B switch for measurements
-  if (no_grid < 0) { const char* e = getenv("OBB_NMS_NO_GRID"); no_grid = (e && atoi(e)) ? 1 : 0; }
+  static const int no_grid = obb_dev_switch("OBB_NMS_NO_GRID", 0) != 0;          // A/B switch (development builds)
   const bool use_grid = !no_grid && kind == 0 && cv.grid.meta != nullptr && thr >= 0.f && n < (1ll << 24);
-  static int no_slabs = -1;                                        // OBB_NMS_NO_SLABS=1: A/B switch for measurements
-  if (no_slabs < 0) { const char* e = getenv("OBB_NMS_NO_SLABS"); no_slabs = (e && atoi(e)) ? 1 : 0; }
+  static const int no_slabs = obb_dev_switch("OBB_NMS_NO_SLABS", 0) != 0;        // A/B switch (development builds)
   const bool use_slabs = use_grid && !no_slabs && max_keep <= 0;   // (a limit on the kept boxes keeps the call one list: the windows are per list)
   {
     ProfScope ps(PROF_NMS_SORT, st);
@@ -698,10 +681,10 @@ static int run_nms(int kind, const float* boxes, int stride, const float* scores
     a.rec2 = cv.grid.rec2; a.order2 = cv.grid.order2; a.pos_old = cv.grid.pos_old; a.alive2 = cv.grid.alive2; a.kept_bits = cv.grid.kept_bits;
     a.alive2_words = (int)cv.grid.alive2_words; a.kept_words = (int)cv.grid.kept_words;
     a.slab_plan = cv.grid.slab_plan;
-    static int slab_cap = -1;
+
     // chunk capacity of a slab team: 1024 measured best at 100k / 18 slabs (512: 363 us, 1024: 330, 1536: 362, 1920: 383 --
     // a team has ~14 workgroups: the pair phase grows with the square of the chunk, smaller chunks add steps)
-    if (slab_cap < 0) { const char* e = getenv("OBB_NMS_SLAB_CAP"); slab_cap = e ? atoi(e) : 1024; if (slab_cap < 0) slab_cap = 0; }
+    static const int slab_cap = [] { const int v = obb_dev_switch("OBB_NMS_SLAB_CAP", 1024); return v < 0 ? 0 : v; }();
     a.slab_cap = slab_cap ? (slab_cap + 63) / 64 * 64 : 0;
   }
   a.rec = cv.rec; a.order = cv.vals_b; a.alive = cv.alive; a.seg_begin = cv.seg_begin; a.seg_end = cv.seg_end;

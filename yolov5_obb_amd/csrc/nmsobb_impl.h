@@ -754,14 +754,12 @@ static int run_nms_obb(const void* pred, const void* objcol, int dtype, int64_t 
   cap_img = round_cap(cap_img);
   const int ncs = agnostic ? 1 : nc;                               // NMS segments per image
   // class segmentation needs the class in 8 and the anchor index in 24 key bits
-  static int no_class_seg = -1;                                    // OBB_NO_CLASS_SEG=1: A/B switch for measurements
-  if (no_class_seg < 0) { const char* e = getenv("OBB_NO_CLASS_SEG"); no_class_seg = (e && atoi(e)) ? 1 : 0; }
+  static const int no_class_seg = obb_dev_switch("OBB_NO_CLASS_SEG", 0) != 0;    // A/B switch (development builds)
   const int class_ok = (!no_class_seg && !agnostic && nc > 1 && A + n_extra < (1ll << 24)) ? 1 : 0;
   // the class-grouping pass for images with more than max_nms candidates is only worth launching when such images are expected
   // (off by default: per-class segments cannot share the max_det early stop of the single list, which usually ends the
   //  NMS of such images after the first ~2000 of 30000 candidates; OBB_NMS_GROUP_AFTER_CUT=1 enables it)
-  static int group_cut = -1;
-  if (group_cut < 0) { const char* e = getenv("OBB_NMS_GROUP_AFTER_CUT"); group_cut = (e && atoi(e)) ? 1 : 0; }
+  static const int group_cut = obb_dev_switch("OBB_NMS_GROUP_AFTER_CUT", 0) != 0;
   const int group_ok = (group_cut && class_ok && max_nms > 0 && expected_cand > max_nms) ? 1 : 0;
   ObbCarve cv;
   int rc = obb_carve(ws, bs, cap_img, ncs, &cv);
@@ -796,8 +794,7 @@ static int run_nms_obb(const void* pred, const void* objcol, int dtype, int64_t 
   const unsigned gs = (unsigned)((bs + 255) / 256);
   Carve& nv = cv.nms;
   const int64_t max_seg = (max_nms > 0 && max_nms < cap_img) ? max_nms : cap_img;
-  static int no_lds_sort = -1;                                     // OBB_NO_LDS_SORT=1: A/B switch for measurements
-  if (no_lds_sort < 0) { const char* e = getenv("OBB_NO_LDS_SORT"); no_lds_sort = (e && atoi(e)) ? 1 : 0; }
+  static const int no_lds_sort = obb_dev_switch("OBB_NO_LDS_SORT", 0) != 0;      // A/B switch (development builds)
   const bool lds_sort = !no_lds_sort && expected_cand > 0 && expected_cand <= kSortLdsHint && !group_ok;
   // grid of the NMS launch (needed by the planner inside the fused kernel)
   const int nms_capmax = cap_max(bs * ncs);

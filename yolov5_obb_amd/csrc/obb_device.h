@@ -17,9 +17,25 @@
 #define OBB_HD inline
 #endif
 
+#include <stdlib.h>
+
 namespace obb {
 
 constexpr int kWave = 64;  // gfx950 wavefront width (hard-coded on purpose)
+
+// Measurement switches: environment variables that select an A/B code path exist only in a development build
+// (`make DEV=1` = -DOBB_DEV_SWITCHES); the production library ignores them, so a stray variable cannot change what runs.
+// Callers keep the value in a function-local `static const` (initialised once, thread-safe).  The two switches that stay
+// in every build are documented in include/obb_hip.h: OBB_NMS_POLY_STRICT (tests) and OBB_NMS_PHASE_PROF (in-kernel timers).
+inline int obb_dev_switch(const char* name, int dflt) {
+#ifdef OBB_DEV_SWITCHES
+  const char* e = getenv(name);
+  return e ? atoi(e) : dflt;
+#else
+  (void)name;
+  return dflt;
+#endif
+}
 
 // ---- float thresholds equivalent to the reference's double-literal compares ----
 // The reference compares float values with double literals (1e-14, 1e-6, 1e-8):
