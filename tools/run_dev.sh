@@ -1,6 +1,7 @@
 #!/bin/bash
 # Development run on the GPU box: bash tools/run_dev.sh <tag> [pytest args...]  -> gpurun_out/<tag>/
-#   PYTEST=0 skips the test run, PROF=1 adds a rocprofv3 kernel trace of tools/prof_regimes.py, BENCH=1 runs bench.py
+#   PYTEST=0 skips the test run, PROF=1 adds a rocprofv3 kernel trace of tools/prof_regimes.py, BENCH=1 runs bench.py,
+#   VARIANTS="v1 sb8": also times yolov5_obb_amd/libobb_hip_<variant>.so (compile-time A/B builds)
 TAG=${1:-dev}; shift
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/$TAG
@@ -12,7 +13,9 @@ if [ "${PYTEST:-1}" != "0" ]; then
   echo "pytest rc=$?" >> $O/pytest.log
 fi
 timeout 300 python tools/prof_regimes.py > $O/regimes.txt 2>&1
-
+for v in $VARIANTS; do
+  OBB_HIP_LIB=$R/yolov5_obb_amd/libobb_hip_$v.so timeout 300 python tools/prof_regimes.py > $O/regimes_$v.txt 2>&1
+done
 OBB_NMS_PHASE_PROF=1 timeout 300 python tools/prof_regimes.py > $O/phases.txt 2>&1
 if [ "${PROF:-0}" = "1" ]; then
   rm -rf /tmp/p_kt
@@ -22,5 +25,5 @@ fi
 if [ "${BENCH:-0}" = "1" ]; then
   timeout 900 python bench.py > $O/bench.json 2> $O/bench.err
 fi
-[ -f $O/pytest.log ] && tail -14 $O/pytest.log; grep -E "^clustered|^uniform" $O/regimes.txt; [ -f $O/kernel_stats.md ] && head -14 $O/kernel_stats.md
+[ -f $O/pytest.log ] && tail -14 $O/pytest.log; grep -E "^clustered|^uniform" $O/regimes*.txt; [ -f $O/kernel_stats.md ] && head -14 $O/kernel_stats.md
 [ -f $O/bench.json ] && cut -c1-300 $O/bench.json

@@ -12,7 +12,8 @@ import threading
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libobb_hip.so")
+# OBB_HIP_LIB: another build of the same library (A/B measurements of compile-time variants); default: the in-tree build
+LIB_PATH = os.environ.get("OBB_HIP_LIB") or os.path.join(_HERE, "libobb_hip.so")
 
 OBB_OK = 0
 OBB_NMS_DROP_SMALL = 1
