@@ -41,8 +41,7 @@ struct GridMeta {
   int bb[4];               // ordered-int encodings of min x, min y, max x, max y over the finite boxes that take part
   int n_brute;             // boxes kept out of the index
   uint32_t level_mask;     // levels that hold at least one box
-  int ticket;              // row-batch tickets of the indexed cross phases (monotonic over the call; zero before the launch)
-  int pad[9];
+  int pad[10];
 };
 
 // float <-> int with the same ordering (finite values and infinities; NaN must be filtered by the caller)

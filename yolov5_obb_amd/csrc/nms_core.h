@@ -230,7 +230,7 @@ struct WaveLds {
   uint8_t q1bcol[128];     // cross phase: column lane of a stage-1b entry
   uint8_t q2col[128];      // cross phase: column lane of a stage-2 entry
   uint8_t cdead[64];
-  uint32_t qrow[128];      // grid cross: row position of a stage-1a entry (entries of several rows share a queue)
+  uint8_t pad[64];
   float4 align16[0];
 };
 
@@ -1104,24 +1104,22 @@ constexpr int kScanBatch = OBB_SCAN_BATCH;          // blocks of candidates in f
 // box is usually dead by the time the second of two overlapping kept rows gets to it), kills are one atomicAnd per box.
 // Brute rows (flag in quad 3) are skipped here: the caller runs the exhaustive form for them.
 //
-// Work distribution (round 4).  Rounds 2-3 dealt items (row, part) to the waves: part j of kw took every kw-th block of the
-// row's ranges -- every part repeated the row's set-up (windows of all levels, two dependent table look-ups per cell row:
-// 4-7 us), and a phase ended when the slowest wave had finished its last item (30-80 us).  Now a workgroup takes BATCHES of
-// eight rows (tickets from one agent-scope counter: a few hundred per phase): each wave sets ONE row up and leaves its
-// ranges in LDS (the chunk list's 32 KB are free during the cross phase), then all eight waves draw blocks of ALL eight
-// rows from one LDS counter, four at a time.  The queues carry (row, column) pairs and live across batches.
-constexpr int kCgPasses = 3;                         // passes of 64 cell rows per row; a row with more scans the whole array
-constexpr int kCgLists = kNmsWaves * kCgPasses;      // 1 KB each in the chunk-list region
-struct CgHead {                                      // static LDS of the kernel
-  float4 rq[kNmsWaves];                              // quad 0 of the batch's rows
-  uint32_t rp[kNmsWaves];                            // their sorted positions
-  int cnt[kCgLists];                                 // blocks per list
-  int tot[kCgLists + 1];                             // exclusive prefix
-  int next;                                          // next block ordinal of the batch
-  int ticket[2];                                     // this batch / the next one (drawn ahead)
-};
-
-#ifdef OBB_CROSS_GRID_V1
+// Work distribution: an item is (row, part): part j of kw takes every kw-th block of the row's candidate ranges, so that
+// a step with few kept rows still occupies every wave of the team; items go round-robin over the team's waves.  Per item
+// the blocks are first listed in LDS (lanes = cell rows of a window, in parallel), then read four at a time -- four
+// independent 16-byte loads per lane in flight: the phase is bound by memory latency, not by arithmetic.
+//
+// Measured and not kept (round 4, steps of the 100k call, us; this form = 547 at K=3000 / 1553 uniform on the same box):
+//  * workgroup batches of eight rows, ONE set-up per row (the parts above repeat it: 4-7 us each), its 64-lane range lists
+//    left in LDS, all eight waves drawing blocks of all eight rows from one LDS counter, batches handed out by an agent-scope
+//    ticket: correct, 633 / 1612.  The set-up did shrink (52 -> 3 us per wave at K=3000), but every drawn block paid a
+//    two-level search of the lists (ballot + four read-lanes + four LDS reads) and a batch cost three workgroup barriers;
+//  * the same with explicit block descriptors (first entry | count) written by the producer waves into fixed 512-entry
+//    parts of an LDS queue, rows per batch adapted to the phase (nr / 2T, at most eight): 572 / 1624;
+//  * eight blocks in flight instead of four: 605 / 1516 on the first variant, 604 / 1912 on the second (registers).
+// The counters say why none of it pays: the blocks are 72 % full (46 of 64 lanes), a wave gets through one in 0.43 us
+// whichever way it is handed out -- the time is the round trip of the loads at two waves per SIMD (250 VGPRs), not the
+// hand-out.  What would pay is fewer blocks per row (now ~50: a tighter index), not a cheaper way to reach them.
 template <class G>
 __device__ __forceinline__ void nms_cross_grid(const NmsArgs& a, const GridPlan& gp, uint32_t level_mask, const uint32_t* rows, int nr,
                                                int c0, int se, int tw, int ntw, WaveLds<G>& L, int* s_next) {
@@ -1388,292 +1386,6 @@ __device__ __forceinline__ void nms_cross_grid(const NmsArgs& a, const GridPlan&
   if (Q2.count > 0) drain2(Q2.count);
   asm volatile("; kills applied %0" ::"v"((unsigned)(seen >> 32) ^ (unsigned)seen));
 }
-#else
-template <class G>
-__device__ __forceinline__ void nms_cross_grid(const NmsArgs& a, const GridPlan& gp, uint32_t level_mask, const uint32_t* rows, int nr,
-                                               int c0, int se, int wgi, int Tw, WaveLds<G>& L, uint32_t* lists, CgHead& H, int& tbase) {
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const uint32_t mmask = a.gmask;
-  const int M = (int)mmask + 1;
-  const int nbatch = (nr + kNmsWaves - 1) / kNmsWaves;
-  const bool cprof = a.prof != nullptr && blockIdx.x == 0 && threadIdx.x == 0;
-  u64 ct0 = 0, c_pro = 0, c_scan = 0, c_drain = 0, c_nd = 0, c_items = 0, c_blocks = 0, c_pass = 0;
-  auto ctick = [&]() { if (cprof) ct0 = wall_clock64(); };
-  auto ctock = [&](u64& acc) { if (cprof) acc += wall_clock64() - ct0; };
-  PairQueue Q{L.qbuf, 0, 0}, Q1{L.qbuf1b, 0, 0}, Q2{L.qbuf2, 0, 0};
-  auto col_alive = [&](uint32_t cp) -> bool { return (ldg_agent(a.alive + (cp >> 6)) >> (cp & 63)) & 1ull; };
-  // kills: RETURNING atomics whose results are consumed at the end of the phase -- the wave's vmcnt then covers the
-  // completed read-modify-writes, and no drain waits for its own
-  u64 seen = 0ull;
-  auto kill = [&](bool hit, uint32_t cp) {
-    if (hit) {
-      seen ^= atomicAnd(a.alive + (cp >> 6), ~(1ull << (cp & 63)));
-      // ... and the box's entry of the cell-order array gets its "dead" bit (top bit of the position word): later scans drop
-      // it with the circle test instead of fetching its alive word.  Write-through; a reader that still sees the old entry
-      // queues a dead box, which the first decision stage then finds dead: the flag is a filter, the bitmap is the truth
-      stg_agent(reinterpret_cast<uint32_t*>(a.gsorted + a.gslot[cp]) + 3, cp | 0x80000000u);
-    }
-  };
-  auto drain2 = [&](int cnt) {                     // stage 2: exact clip
-    wave_sync();
-    bool hit = false;
-    uint32_t cp = 0;
-    if (lane < cnt) {
-      const int slot = (Q2.head + lane) & 127;
-      const uint32_t rowp = L.qbuf2[slot];
-      cp = L.qcol2[slot];
-      if (col_alive(cp)) hit = nms_stage_exact<G>(a.rec + (size_t)rowp * G::RECQ, a.rec + (size_t)cp * G::RECQ, G::thr_of(a), L.scr + lane);
-    }
-    kill(hit, cp);
-    Q2.head = (Q2.head + cnt) & 127;
-    Q2.count -= cnt;
-    wave_sync();
-  };
-  auto push2 = [&](bool undecided, uint32_t rowp, uint32_t cp) {
-    const u64 m2 = __ballot(undecided);
-    if (undecided) {
-      const int slot = (Q2.head + Q2.count + __popcll(m2 & lanemask_lt())) & 127;
-      L.qbuf2[slot] = rowp;
-      L.qcol2[slot] = cp;
-    }
-    Q2.count += __popcll(m2);
-  };
-  auto drain1b = [&](int cnt) {                    // stage 1b: the IoU interval
-    wave_sync();
-    int res = 0;
-    uint32_t rowp = 0, cp = 0;
-    if (lane < cnt) {
-      const int slot = (Q1.head + lane) & 127;
-      rowp = L.qbuf1b[slot];
-      cp = L.qcol1b[slot];
-      if (col_alive(cp)) res = nms_stage_full<G>(a.rec + (size_t)rowp * G::RECQ, a.rec + (size_t)cp * G::RECQ, G::thr_of(a));
-    }
-    kill(res == 1, cp);
-    Q1.head = (Q1.head + cnt) & 127;
-    Q1.count -= cnt;
-    push2(res == 2, rowp, cp);
-    wave_sync();
-    if (Q2.count >= 64) drain2(64);
-  };
-  auto drain = [&](int cnt) {                      // stage 1a: the cheap register-only tests; entries (row position, column position)
-    wave_sync();
-    int res = 0;
-    uint32_t rowp = 0, cp = 0;
-    if (lane < cnt) {
-      const int slot = (Q.head + lane) & 127;
-      cp = L.qbuf[slot];                           // (queued without a look at the bitmap: the scan only saw the dead flag)
-      rowp = L.qrow[slot];
-      // the bitmap word travels together with the two records (no branch around the test: a dependent round trip less);
-      // a box that died in the meantime just loses its result
-      // (a plain, cacheable load: a stale word can only show a dead box as alive -- bits go 1 -> 0 -- which costs a redundant
-      //  test and an idempotent kill, never a missed one; the coherent load is a round trip to memory)
-      const bool live = (a.alive[cp >> 6] >> (cp & 63)) & 1ull;
-      res = G::classify_quick(a.rec + (size_t)rowp * G::RECQ, a.rec + (size_t)cp * G::RECQ, G::thr_of(a), true);
-      if (!live) res = 0;
-    }
-    kill(res == 1, cp);
-    Q.head = (Q.head + cnt) & 127;
-    Q.count -= cnt;
-    {
-      const u64 m1 = __ballot(res == 3);
-      if (res == 3) {
-        const int slot = (Q1.head + Q1.count + __popcll(m1 & lanemask_lt())) & 127;
-        L.qbuf1b[slot] = rowp;
-        L.qcol1b[slot] = cp;
-      }
-      Q1.count += __popcll(m1);
-    }
-    push2(res == 2, rowp, cp);
-    wave_sync();
-    if (Q1.count >= 64) drain1b(64);
-    if (Q2.count >= 64) drain2(64);
-  };
-  auto push1 = [&](bool go, uint32_t rowp, uint32_t cp) {
-    const u64 m = __ballot(go);
-    if (go) {
-      const int slot = (Q.head + Q.count + __popcll(m & lanemask_lt())) & 127;
-      L.qbuf[slot] = cp;
-      L.qrow[slot] = rowp;
-    }
-    Q.count += __popcll(m);
-  };
-  // list `li` of the batch: four arrays of 64 words (first entry, end, end of the wrapped piece, inclusive block prefix)
-  auto list_s = [&](int li) -> uint32_t* { return lists + (size_t)li * 256; };
-
-  // ---- the tickets: batch numbers tbase + wgi-independent counter values; one is always drawn ahead
-  __syncthreads();
-  if (tid == 0) H.ticket[0] = __hip_atomic_fetch_add(&a.gmeta->ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - tbase;
-  __syncthreads();
-  for (int it = 0;; it++) {
-    const int batch = H.ticket[it & 1];
-    if (batch >= nbatch) break;
-    int nxt = 0;
-    if (tid == 0) nxt = __hip_atomic_fetch_add(&a.gmeta->ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - tbase;   // used at the end of the batch
-    c_items++;
-    ctick();
-    // ---- set-up: wave wv lists the blocks of row batch * 8 + wv
-    {
-      const int row = batch * kNmsWaves + wv;
-      int nlist_blocks[kCgPasses];
-#pragma unroll
-      for (int p = 0; p < kCgPasses; p++) nlist_blocks[p] = 0;
-      if (row < nr) {
-        const uint32_t rp = rows[row];
-        const float4 rq = a.rec[(size_t)rp * G::RECQ];
-        if (lane == 0) { H.rq[wv] = rq; H.rp[wv] = rp; }
-        if (!grid_is_brute(gp, rq.x, rq.y, rq.z, rq.w)) {        // (brute row: the caller runs the exhaustive form for it)
-          // the window of every level first: a window with more cells than half the table has slots would visit every entry
-          // several times -- then the whole array is scanned once instead (every indexed box is a candidate)
-          bool whole = false;
-          int ncomb = 0;
-          for (uint32_t lm = level_mask; lm; lm &= lm - 1) {
-            const int lv = __builtin_ctz(lm);
-            const float inv = grid_level_inv_cell(gp, lv);
-            const float d = grid_query_halfwidth(gp, lv, rq.x, rq.y, rq.z);
-            const float nc = floorf(2.f * d * inv) + 2.f;
-            if (!(nc * nc < 0.5f * (float)M)) whole = true;
-            const int lasty = grid_last_cell(gp.yr, inv);
-            ncomb += grid_cell(rq.y + d, gp.y0, inv, lasty) - grid_cell(rq.y - d, gp.y0, inv, lasty) + 1;
-          }
-          if (ncomb > 64 * kCgPasses) whole = true;
-          const int npass = whole ? 1 : (ncomb + 63) >> 6;
-          for (int p = 0; p < npass; p++) {
-            // this lane's cell row: its slots [i0, i0 + len) (possibly wrapping) -> up to two pieces [s, e), [0, e2)
-            int s = 0, e = 0, e2 = 0;
-            if (whole) {
-              if (lane == 0) e = a.gstart[M];
-            } else {
-              const int my = p * 64 + lane;
-              int before = 0, my_lv = -1, my_cx0 = 0, my_cy = 0, my_len = 0;
-              for (uint32_t lm = level_mask; lm; lm &= lm - 1) {
-                const int lv = __builtin_ctz(lm);
-                const float inv = grid_level_inv_cell(gp, lv);
-                const float d = grid_query_halfwidth(gp, lv, rq.x, rq.y, rq.z);
-                const int lastx = grid_last_cell(gp.xr, inv), lasty = grid_last_cell(gp.yr, inv);
-                const int cx0 = grid_cell(rq.x - d, gp.x0, inv, lastx), cy0 = grid_cell(rq.y - d, gp.y0, inv, lasty);
-                const int len = grid_cell(rq.x + d, gp.x0, inv, lastx) - cx0 + 1;
-                const int nyr = grid_cell(rq.y + d, gp.y0, inv, lasty) - cy0 + 1;
-                if (my >= before && my < before + nyr) { my_lv = lv; my_cx0 = cx0; my_cy = cy0 + (my - before); my_len = len; }
-                before += nyr;
-              }
-              if (my_lv >= 0) {
-                const uint32_t i0 = grid_slot(my_lv, my_cx0, my_cy, mmask);
-                const int e1 = (int)i0 + my_len;
-                s = a.gstart[i0];
-                e = a.gstart[e1 <= M ? e1 : M];
-                if (e1 > M) e2 = a.gstart[e1 - M];
-              }
-            }
-            const int nb1 = e > s ? (e - s + 63) >> 6 : 0, nb2 = (e2 + 63) >> 6;
-            int incl = nb1 + nb2;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) { const int u = __shfl_up(incl, d); if (lane >= d) incl += u; }
-            uint32_t* ls = list_s(wv * kCgPasses + p);
-            ls[lane] = (uint32_t)s; ls[64 + lane] = (uint32_t)e; ls[128 + lane] = (uint32_t)e2; ls[192 + lane] = (uint32_t)incl;
-            nlist_blocks[p] = __builtin_amdgcn_readlane(incl, 63);
-          }
-        }
-      }
-      if (lane == 0) {
-#pragma unroll
-        for (int p = 0; p < kCgPasses; p++) H.cnt[wv * kCgPasses + p] = nlist_blocks[p];
-      }
-    }
-    __syncthreads();
-    if (tid < 64) {                                  // prefix of the lists' block counts (24 values), the batch's block counter
-      int v = tid < kCgLists ? H.cnt[tid] : 0;
-      int incl = v;
-#pragma unroll
-      for (int d = 1; d < 32; d <<= 1) { const int u = __shfl_up(incl, d); if (lane >= d) incl += u; }
-      if (tid < kCgLists) H.tot[tid] = incl - v;
-      if (tid == kCgLists - 1) H.tot[kCgLists] = incl;
-      if (tid == 0) H.next = 0;
-    }
-    __syncthreads();
-    ctock(c_pro);
-    ctick();
-    // ---- all waves draw blocks of all rows of the batch, kScanBatch at a time
-    const int total = H.tot[kCgLists];
-    const int tl = lane <= kCgLists ? H.tot[lane] : 0x7fffffff;       // lane l holds the first block ordinal of list l
-    c_blocks += (u64)total;
-    for (;;) {
-      int o0 = 0;
-      if (lane == 0) o0 = atomicAdd(&H.next, kScanBatch);
-      o0 = __builtin_amdgcn_readfirstlane(o0);
-      if (o0 >= total) break;
-      uint32_t k0[kScanBatch], rowp[kScanBatch];
-      int bn[kScanBatch];
-      float rx[kScanBatch], ry[kScanBatch], rr[kScanBatch];
-      float4 cq[kScanBatch];
-      bool val[kScanBatch];
-#pragma unroll
-      for (int u = 0; u < kScanBatch; u++) {
-        const int o = o0 + u;
-        bn[u] = 0; k0[u] = 0u; rowp[u] = 0u; rx[u] = ry[u] = rr[u] = 0.f;
-        if (o < total) {                             // (wave-uniform)
-          const int li = __popcll(__ballot(tl <= o)) - 1;             // the last list that starts at or before o
-          const int ol = o - __builtin_amdgcn_readlane(tl, li);
-          const uint32_t* ls = list_s(li);
-          const int pfx = (int)ls[192 + lane];
-          const int sel = __builtin_ctzll(__ballot(pfx > ol));          // the cell row that holds block ol of the list
-          const int s = __builtin_amdgcn_readlane((int)ls[lane], sel), e = __builtin_amdgcn_readlane((int)ls[64 + lane], sel);
-          const int e2 = __builtin_amdgcn_readlane((int)ls[128 + lane], sel), pf = __builtin_amdgcn_readlane(pfx, sel);
-          const int nb1 = e > s ? (e - s + 63) >> 6 : 0, nb2 = (e2 + 63) >> 6;
-          const int bidx = ol - (pf - (nb1 + nb2));
-          const int kk = bidx < nb1 ? s + bidx * 64 : (bidx - nb1) * 64, kend = bidx < nb1 ? e : e2;
-          k0[u] = (uint32_t)kk; bn[u] = min(64, kend - kk);
-          const int w = li / kCgPasses;
-          const float4 rq = H.rq[w];
-          rx[u] = rq.x; ry[u] = rq.y; rr[u] = rq.z; rowp[u] = H.rp[w];
-        }
-        val[u] = lane < bn[u];
-        cq[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (val[u]) cq[u] = a.gsorted[(size_t)k0[u] + lane];
-      }
-      // circle test + the entry's dead flag (set by whoever killed the box, see `kill`): most candidates of a later
-      // step are dead already and never reach a queue; what passes is queued without a look at the alive bitmap (that
-      // was a second, dependent round trip per batch) -- the first decision stage checks it
-#pragma unroll
-      for (int u = 0; u < kScanBatch; u++) {
-        const uint32_t cw = __float_as_uint(cq[u].w), cp = cw & 0x7fffffffu;
-        const float dx = cq[u].x - rx[u], dy = cq[u].y - ry[u], rs = rr[u] + cq[u].z;
-        const bool go = val[u] && !(cw >> 31) && (int)cp >= c0 && (int)cp < se && !(dx * dx + dy * dy > rs * rs);
-        if (__ballot(go)) {
-          c_pass += (u64)__popcll(__ballot(go));
-          push1(go, rowp[u], cp);
-          if (Q.count >= 64) { ctock(c_scan); ctick(); drain(64); ctock(c_drain); c_nd++; ctick(); }
-        }
-      }
-    }
-    ctock(c_scan);
-    __syncthreads();                                 // every wave is out of the batch's lists
-    if (tid == 0) H.ticket[(it + 1) & 1] = nxt;
-    __syncthreads();
-  }
-  tbase += nbatch + Tw;                              // (every workgroup of the team drew exactly one ticket past the last batch)
-  (void)wgi;
-  ctick();
-  if (Q.count > 0) { drain(Q.count); c_nd++; }
-  ctock(c_drain);
-  if (cprof) {
-    a.prof[16] += c_scan; a.prof[17] += c_drain; a.prof[18] += c_pro; a.prof[19] += c_nd; a.prof[20] += c_blocks; a.prof[21] += c_items;
-    a.prof[15] += c_pass; a.prof[10] += 1;
-  }
-  if (Q1.count > 0 && Q1.count + Q2.count <= 64) {       // a few leftovers: straight to the exact clip (see nms_pairs)
-    wave_sync();
-    const bool mv = lane < Q1.count;
-    const int sl = (Q1.head + lane) & 127;
-    const uint32_t rowp = mv ? L.qbuf1b[sl] : 0u, cp = mv ? L.qcol1b[sl] : 0u;
-    Q1.head = (Q1.head + Q1.count) & 127;
-    Q1.count = 0;
-    push2(mv, rowp, cp);
-    wave_sync();
-  }
-  if (Q1.count > 0) drain1b(Q1.count);
-  if (Q2.count > 0) drain2(Q2.count);
-  asm volatile("; kills applied %0" ::"v"((unsigned)(seen >> 32) ^ (unsigned)seen));
-}
-#endif
 
 constexpr int kGridMinRows = 512;
 
@@ -2049,8 +1761,6 @@ __global__ __launch_bounds__(kNmsThreads) __attribute__((amdgpu_waves_per_eu(1, 
   __shared__ int s_i[16];
   __shared__ int s_flag;
   __shared__ int s_bb[kNmsWaves][4];
-  __shared__ CgHead s_cg;                  // indexed cross phase: the batch's rows and block lists (the lists themselves: chunk-list region)
-  int cg_tbase = 0;                        // tickets drawn by the indexed cross phases so far (uniform over the grid)
   const int tid = threadIdx.x, wv = tid >> 6;
   const int NB = gridDim.x;
   // the extent of the data from the key kernel's per-workgroup partials (every workgroup reduces them itself)
@@ -2131,8 +1841,7 @@ __global__ __launch_bounds__(kNmsThreads) __attribute__((amdgpu_waves_per_eu(1, 
   uint32_t glevels = 0;
   int n_brute = 0;
   if constexpr (G::HAS_GRID && GRID) {
-    grid_on = a.gmeta != nullptr && a.nseg == 1 && T == NB && ((int)a.gmask + T) / T <= kNmsThreads && T <= kNmsThreads && a.cull != 0 &&
-              a.capmax >= kCgLists * 256;            // (the block lists of the indexed cross phase live in the chunk-list region)
+    grid_on = a.gmeta != nullptr && a.nseg == 1 && T == NB && ((int)a.gmask + T) / T <= kNmsThreads && T <= kNmsThreads && a.cull != 0;
   }
   // kept rows x alive positions of [c0, c1)
   auto cross = [&](const uint32_t* rows, int nr, int c0, int c1) {
@@ -2148,11 +1857,7 @@ __global__ __launch_bounds__(kNmsThreads) __attribute__((amdgpu_waves_per_eu(1, 
         }
       }
       if (grid_on && nr >= kGridMinRows) {
-#ifdef OBB_CROSS_GRID_V1
         nms_cross_grid<G>(a, gp, glevels, rows, nr, c0, c1, tw, ntw, L, &s_i[12]);
-#else
-        nms_cross_grid<G>(a, gp, glevels, rows, nr, c0, c1, wg, T, L, cidx, s_cg, cg_tbase);
-#endif
         if (n_brute > 0) {
           // the boxes the index leaves out: brute kept rows against every column, every kept row against the brute columns
           // (the chunk list in LDS is free between resolve and the next select: it takes the brute rows, capmax at a time)
