@@ -366,7 +366,7 @@ def main():
     nms_alg = int(sum(bytes_nms(int(c)) for c in cand))
     nms_ach = nms_alg / (nms_ms_step * 1e-3) / 1e9
     pmc = {}
-    for name in ("r3_pmc.json", "r2_pmc.json", "r1_pmc.json"):
+    for name in ("r4_pmc.json", "r3_pmc.json", "r2_pmc.json", "r1_pmc.json"):
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", name)))
             pmc["_file"] = "profiles/" + name
@@ -863,7 +863,7 @@ def main():
             "nms_100k": nms_obj, "nmsobb_nc15": nc15_obj, "nmsobb_nc2": nc2_obj, "nmsobb_tta": tta_obj, "polygon_paths": poly_obj,
             "loss": loss_obj, "detect": detect_obj, "detect_nms_chain": coupled_obj, "next_rows": next_rows,
             "cpu_baseline": cpu,
-            "parity_unpinned": ["poly2rbox (utils/rboxs_utils.py:39-81: needs cv2.minAreaRect, OpenCV is not in this image)",
+            "parity_unpinned": ["poly2rbox against cv2.minAreaRect (utils/rboxs_utils.py:39-81: OpenCV is not in this image; without it the minimum-area rectangle is computed natively and the function is property-tested, tests/test_poly2rbox_props.py)",
                                 "OBB mAP@0.5 within 0.1 of the reference (DOTA_devkit/dota_evaluation_task1.py:320: no weights / dataset offline)"],
         }
         print(json.dumps(line), flush=True)

@@ -1,10 +1,10 @@
 #!/bin/bash
 # Full measurement set of a round on the GPU box (run through gpurun from the repo root):
 #   bash tools/final_run.sh <tag> [round]   -> gpurun_out/<tag>/{pytest_gpu.log, smoke.log, bench.json, *_kernel_stats.md, pmc_*.md}
-# and, on the box, profiles/<round>_pmc.json (default round: r3) so that the bench line of the same call reads this run's counters.
+# and, on the box, profiles/<round>_pmc.json (default round: r4) so that the bench line of the same call reads this run's counters.
 # rocprofv3 writes rocpd SQLite databases (tens of MB): they stay in /tmp, only the markdown summaries come back.
 TAG=${1:-run}
-RND=${2:-r3}
+RND=${2:-r4}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/$TAG
 mkdir -p $O

@@ -3,8 +3,10 @@
 ``gaussian_label_cpu``, ``regular_theta``, ``rbox2poly``, ``poly2hbb`` and ``poly_filter`` keep the reference's
 signatures and numpy/torch behaviour (they are small host/elementwise helpers used by the dataloader, val.py and
 detect.py); the device-side CSL encode used by the loss path lives in ``csl_encode`` (libobb_hip.so).
-``poly2rbox`` needs OpenCV's minAreaRect exactly like the reference (utils/rboxs_utils.py:61) and raises a clear
-ImportError when cv2 is not installed.
+``poly2rbox`` calls OpenCV's minAreaRect like the reference (utils/rboxs_utils.py:61) when cv2 is installed; without it
+(this image) the minimum-area rectangle comes from ``_min_area_rect`` below -- the same definition, rotating calipers over the
+hull's edges in double precision; the long-edge normalisation that follows does not depend on which of the equivalent
+(w, h, angle) descriptions of a rectangle it is handed.
 """
 import numpy as np
 import torch
@@ -63,17 +65,59 @@ def regular_theta(theta, mode='180', start=-pi / 2):
     return theta + start
 
 
+def _min_area_rect(pts):
+    """Minimum-area enclosing rectangle of a few points, ((cx, cy), (w, h), angle in degrees) in the convention of
+    cv2.minAreaRect since OpenCV 4.5.1: w is the extent along the direction `angle`, measured from the x axis towards the
+    y axis of the image frame, angle in (0, 90].  One of the rectangle's sides lies on an edge of the convex hull."""
+    p = np.asarray(pts, dtype=np.float64).reshape(-1, 2)
+    q = sorted(set(map(tuple, p.tolist())))
+    if len(q) == 1:
+        return (q[0][0], q[0][1]), (0.0, 0.0), 90.0
+
+    def half(seq):
+        h = []
+        for v in seq:
+            while len(h) >= 2 and (h[-1][0] - h[-2][0]) * (v[1] - h[-2][1]) - (h[-1][1] - h[-2][1]) * (v[0] - h[-2][0]) <= 0:
+                h.pop()
+            h.append(v)
+        return h[:-1]
+    hull = np.array(half(q) + half(q[::-1]))                     # monotone chain; two points for a degenerate set
+    best = None
+    for i in range(len(hull)):
+        d = hull[(i + 1) % len(hull)] - hull[i]
+        n = float(np.hypot(d[0], d[1]))
+        if n == 0.0:
+            continue
+        u = d / n
+        v = np.array([-u[1], u[0]])
+        a, b = hull @ u, hull @ v
+        w, h = float(a.max() - a.min()), float(b.max() - b.min())
+        if best is None or w * h < best[0]:
+            c = u * (a.max() + a.min()) / 2 + v * (b.max() + b.min()) / 2
+            best = (w * h, c, w, h, float(np.degrees(np.arctan2(u[1], u[0]))))
+    _, c, w, h, ang = best
+    k = int(np.floor(ang / 90.0))
+    ang -= 90.0 * k
+    if k % 2:
+        w, h = h, w
+    if ang <= 0.0:                                              # (0, 90]: an axis-aligned rectangle reports 90
+        ang += 90.0
+        w, h = h, w
+    return (float(c[0]), float(c[1])), (w, h), ang
+
+
 def poly2rbox(polys, num_cls_thata=180, radius=6.0, use_pi=False, use_gaussian=False):
     """poly (n,8) -> long-edge rbox (n,[cx cy l s θ]) [+ CSL labels] (utils/rboxs_utils.py:39-81)."""
     try:
         import cv2
-    except ImportError as e:  # the reference imports cv2 at module import time (utils/rboxs_utils.py:6)
-        raise ImportError("poly2rbox needs OpenCV (cv2.minAreaRect), as in the reference") from e
+        min_area_rect = cv2.minAreaRect
+    except ImportError:       # (the reference imports cv2 at module import time, utils/rboxs_utils.py:6)
+        min_area_rect = _min_area_rect
     assert polys.shape[-1] == 8
     csl_labels, rboxes = [], []
     for poly in polys:
         poly = np.float32(poly.reshape(4, 2))
-        (x, y), (w, h), angle = cv2.minAreaRect(poly)
+        (x, y), (w, h), angle = min_area_rect(poly)
         theta = -angle / 180 * pi
         if w != max(w, h):
             w, h = h, w
