@@ -2007,7 +2007,7 @@ __device__ __forceinline__ void block_scan2(long long va, long long vb, long lon
   pa = wa + ia - va; pb = wb + ib - vb;
 }
 
-struct PlanLds { long long a[16], b[16]; int first[1024], last[1024]; };
+struct PlanLds { long long a[16], b[16]; int first[1024], last[1024], size[1024]; };
 
 // the planner proper: called by all 1024 threads of one workgroup (k_plan_teams, or the planner block of the fused
 // sort/prep kernel); seg_begin / seg_end -- or the segment sizes, when seg_size is given -- must be visible to the caller
@@ -2018,7 +2018,15 @@ __device__ __forceinline__ void plan_teams_block(const int* seg_begin, const int
   const int tid = threadIdx.x;
   const int per = (nseg + 1023) / 1024;
   const int g0 = tid * per, g1 = (g0 + per < nseg) ? g0 + per : nseg;
-  auto cost_of = [&](int g) -> long long { return plan_cost((long long)(seg_size ? seg_size[g] : seg_end[g] - seg_begin[g]), chunk); };
+  // (the sizes are read from global memory ONCE: the five passes below each cost a dependent round trip otherwise)
+  const bool staged = nseg <= 1024;
+  if (staged) {
+    if (tid < nseg) S.size[tid] = seg_size ? seg_size[tid] : seg_end[tid] - seg_begin[tid];
+    __syncthreads();
+  }
+  auto cost_of = [&](int g) -> long long {
+    return plan_cost((long long)(staged ? S.size[g] : (seg_size ? seg_size[g] : seg_end[g] - seg_begin[g])), chunk);
+  };
   // ---- totals
   long long myc = 0, myn = 0, pa, pb, total, nne;
   for (int g = g0; g < g1; g++) { const long long c = cost_of(g); myc += c; myn += c > 0 ? 1 : 0; }

@@ -444,13 +444,16 @@ __global__ void k_prep_cand(const float4* __restrict__ cand, const uint32_t* __r
 // One launch instead of four memsets: candidate counters, tiny-box flags, the caller's status words, the fused kernel's
 // ticket and the team-barrier block of the NMS kernel.
 __global__ void k_reset_state(int* __restrict__ cnt, int n_cnt, int* __restrict__ tiny, int bs, int64_t* __restrict__ status,
-                              int* __restrict__ ticket, uint4* __restrict__ bar16, long long n_bar16) {
+                              int* __restrict__ ticket, uint4* __restrict__ bar16, long long n_bar16, uint4* __restrict__ alive16,
+                              long long n_alive16) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x, n = (long long)gridDim.x * blockDim.x;
   for (long long k = i; k < n_cnt; k += n) cnt[k] = 0;
   for (long long k = i; k < bs; k += n) tiny[k] = 0;
   (void)status;                                                 // (both status words are written by k_gather_out)
   if (i == 2) *ticket = 0;
   for (long long k = i; k < n_bar16; k += n) bar16[k] = make_uint4(0u, 0u, 0u, 0u);
+  // (the in-LDS sort path ORs its alive bits into zeroed words: several workgroups share the words of an image)
+  for (long long k = i; k < n_alive16; k += n) alive16[k] = make_uint4(0u, 0u, 0u, 0u);
 }
 
 // the slots behind the image's candidates get the largest key (single image, device-wide sort over the whole capacity)
@@ -474,23 +477,36 @@ __global__ __launch_bounds__(1024) void k_sort_prep_lds(const float4* __restrict
                                                         int* sort_end, int* img_end, int* mode, int* grp_begin, int* grp_end,
                                                         int* __restrict__ seg_begin, int* __restrict__ seg_end, int* __restrict__ keep_cnt,
                                                         float4* __restrict__ rec, u64* __restrict__ alive, int* __restrict__ ticket,
-                                                        int plan_nb, int plan_chunk, int4* __restrict__ plan, int* __restrict__ seg_size) {
+                                                        int plan_nb, int plan_chunk, int4* __restrict__ plan, int* __restrict__ seg_size, int P) {
   extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
   __shared__ PlanLds s_plan;
-  __shared__ int s_hist[256];
+  __shared__ int s_hist[256], s_cls_off[256], s_cls_cur[256], s_cls_task[257], s_cls_max, s_cls_ntask;
+  __shared__ u64 s_abits[kSortLdsMax / 2 / 64];
   unsigned long long* s_keys = reinterpret_cast<unsigned long long*>(s_raw);
   uint32_t* s_vals = reinterpret_cast<uint32_t*>(s_keys + kSortLdsMax);
-  const int g = blockIdx.x, tid = threadIdx.x, T = 1024;
+  // blockIdx.x = image * P + part (class-segment images: part q orders and prepares the classes c with c % P == q; every
+  // part reads the image's keys and builds the whole histogram itself), the last block is the planner
+  const int g = blockIdx.x / P, q = blockIdx.x - g * P, tid = threadIdx.x, T = 1024;
   if (g == bs) {
     // The planner block (launched only when there is a plan to make): the NMS launch is planned from the segment SIZES,
     // which every image's workgroup knows after its first pass over the keys -- long before its sort is done.  This block
     // waits for the bs size tables (the other workgroups never wait for anything, so it cannot hang however the blocks
     // are scheduled) and plans while they sort: the 16 us of plan_teams_block used to be the tail of the last workgroup.
+#ifdef OBB_SORT_TRACE
+    const unsigned long long tp0 = wall_clock64();
+#endif
     if (tid == 0) {
       while (__hip_atomic_load(ticket, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < bs) __builtin_amdgcn_s_sleep(4);
     }
     __syncthreads();
+#ifdef OBB_SORT_TRACE
+    const unsigned long long tp1 = wall_clock64();
+#endif
     plan_teams_block(nullptr, nullptr, seg_size, bs * ncs, plan_nb, plan_chunk, plan, s_plan);
+#ifdef OBB_SORT_TRACE
+    __syncthreads();
+    if (tid == 0) printf("planner: waited %llu planned %llu (x10 ns)\n", tp1 - tp0, wall_clock64() - tp1);
+#endif
     return;
   }
   long long c = cnt[g * kCntPad];
@@ -502,15 +518,16 @@ __global__ __launch_bounds__(1024) void k_sort_prep_lds(const float4* __restrict
   const int e = (int)(over_nms ? max_nms : c);                 // :845-846 top max_nms by confidence
   const int m = (class_ok && !over_cap && !tiny[g] && !over_nms) ? 1 : 0;
   const int n = (int)c;
-  if (tid == 0) {
+  if (q > 0 && m != 1) return;                                 // one list per image: part 0 does it all
+  if (tid == 0 && q == 0) {
     sort_begin[g] = b0; sort_end[g] = b0 + n; img_end[g] = b0 + e; mode[g] = m;
     grp_begin[g] = b0; grp_end[g] = b0;
   }
-  for (int sgm = tid; sgm < ncs; sgm += T) { seg_begin[g * ncs + sgm] = b0; seg_end[g * ncs + sgm] = b0; keep_cnt[g * ncs + sgm] = 0; }
   if (tid < 256) s_hist[tid] = 0;
+  if (tid < kSortLdsMax / 2 / 64) s_abits[tid] = 0ull;
   __syncthreads();
 #ifdef OBB_SORT_TRACE
-  unsigned long long tt[8]; int ti_ = 0;
+  unsigned long long tt[12]; int ti_ = 0;
 #define TSTAMP() do { __syncthreads(); tt[ti_++] = wall_clock64(); } while (0)
 #else
 #define TSTAMP() do {} while (0)
@@ -529,27 +546,166 @@ __global__ __launch_bounds__(1024) void k_sort_prep_lds(const float4* __restrict
         const unsigned long long cls = (unsigned long long)(int)cand[(size_t)(b0 + i) * 2 + 1].z;
         const unsigned long long anchor = tie < lim ? tie / nc : (unsigned long long)A + (tie - lim);
         k = (cls << 56) | (score << 24) | (anchor & 0xffffffull);
-        if (plan != nullptr) atomicAdd(&s_hist[(int)cls & 255], 1);
+        atomicAdd(&s_hist[(int)cls & 255], 1);
       }
     }
     s_keys[i] = k; s_vals[i] = v;
   }
   __syncthreads();
-  if (plan != nullptr) {                                       // the size table of this image, for the planner block
-    for (int sgm = tid; sgm < ncs; sgm += T) seg_size[g * ncs + sgm] = (m == 1) ? s_hist[sgm] : (sgm == 0 ? e : 0);
-    __threadfence();
+  if (plan != nullptr && q == 0) {                             // the size table of this image, for the planner block
+    // write-through stores, drained, then a RELAXED arrival: a release fence here writes back every dirty line of this XCD's
+    // L2 -- the records the other parts are storing at this very moment (measured: this handshake 4.8 -> 10.4 us)
+    for (int sgm = tid; sgm < ncs; sgm += T) stg_agent(seg_size + g * ncs + sgm, (m == 1) ? s_hist[sgm] : (sgm == 0 ? e : 0));
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (tid == 0) __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0) __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   TSTAMP();
   // ascending; keys are unique (the tie word), so the result is the one total order
   // elements per thread: as few as the 1024 threads allow (measured: 8 per thread with 256 busy threads moves four more
   // levels into registers but is 16 us slower at 2048 candidates -- the lane shuffles become the bottleneck)
-  switch (npad >> 10) {
-    case 0: case 1: sort_lds_regs<1>(s_keys, s_vals, npad, tid); break;
-    case 2: sort_lds_regs<2>(s_keys, s_vals, npad, tid); break;
-    case 4: sort_lds_regs<4>(s_keys, s_vals, npad, tid); break;
-    default: sort_lds_regs<8>(s_keys, s_vals, npad, tid); break;
+  // Class-segment images of up to 4096 candidates (the reference's default thresholds: ~1.7k per image in 15-18 classes): the
+  // order wanted is class-major, so the candidates are first dealt into their class buckets (the histogram exists already;
+  // scan, one LDS atomic per element) and every bucket is then ordered on its own, without a workgroup barrier inside --
+  // instead of the 66 stages + 5 rank-merge levels of the 2048-element network (19.3 us).
+  bool by_class = false;
+  if (m == 1 && n <= kSortLdsMax / 2) {              // (workgroup-uniform)
+    if (tid < 64) {
+      int c4[4], sum = 0, mx = 0;
+#pragma unroll
+      for (int u = 0; u < 4; u++) { c4[u] = s_hist[tid * 4 + u]; sum += c4[u]; mx = c4[u] > mx ? c4[u] : mx; }
+      int incl = sum;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) { const int up = __shfl_up(incl, d); if (tid >= d) incl += up; }
+#pragma unroll
+      for (int d = 32; d >= 1; d >>= 1) { const int o = __shfl_xor(mx, d); mx = o > mx ? o : mx; }
+      int run = incl - sum;
+#pragma unroll
+      for (int u = 0; u < 4; u++) { s_cls_off[tid * 4 + u] = run; s_cls_cur[tid * 4 + u] = run; run += c4[u]; }
+      // tasks of the rank-counting pass below: one per 64 elements of a class
+      int t4[4], tsum = 0;
+#pragma unroll
+      for (int u = 0; u < 4; u++) { t4[u] = ((tid * 4 + u) % P == q) ? (c4[u] + 63) >> 6 : 0; tsum += t4[u]; }
+      int tincl = tsum;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) { const int up = __shfl_up(tincl, d); if (tid >= d) tincl += up; }
+      int trun = tincl - tsum;
+#pragma unroll
+      for (int u = 0; u < 4; u++) { s_cls_task[tid * 4 + u] = trun; trun += t4[u]; }
+      if (tid == 63) { s_cls_task[256] = tincl; s_cls_ntask = tincl; }
+      if (tid == 0) s_cls_max = mx;
+    }
+    __syncthreads();
+    // (the rank counting is quadratic in the bucket: beyond 512 elements -- two classes, one dominant class -- the 16-wave network takes over)
+    by_class = s_cls_max <= 512;
+  }
+  TSTAMP();
+  if (!by_class) {
+    if (q > 0) return;                               // (workgroup-uniform) the network orders the whole image in part 0
+    for (int sgm = tid; sgm < ncs; sgm += T) { seg_begin[g * ncs + sgm] = b0; seg_end[g * ncs + sgm] = b0; keep_cnt[g * ncs + sgm] = 0; }
+    __syncthreads();
+  }
+  if (by_class) {
+    // segment table of this part's classes: straight from the histogram
+    for (int c = q + P * tid; c < ncs; c += P * T) {
+      const int cc = s_hist[c], sb = cc ? b0 + s_cls_off[c] : b0;
+      seg_begin[g * ncs + c] = sb; seg_end[g * ncs + c] = sb + cc; keep_cnt[g * ncs + c] = 0;
+    }
+    unsigned long long* s_keys2 = s_keys + kSortLdsMax / 2;
+    uint32_t* s_vals2 = s_vals + kSortLdsMax / 2;
+    unsigned long long kr[4];
+    uint32_t vr[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) { const int i = tid + u * T; if (i < n) { kr[u] = s_keys[i]; vr[u] = s_vals[i]; } }
+    __syncthreads();                                 // (the scatter's target overlaps nothing that is still being read: n <= 4096)
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int i = tid + u * T;
+      if (i < n && (int)(kr[u] >> 56) % P == q) {
+        const int pos = atomicAdd(&s_cls_cur[(int)(kr[u] >> 56)], 1);
+        s_keys2[pos] = kr[u]; s_vals2[pos] = vr[u];
+      }
+    }
+    __syncthreads();
+    TSTAMP();
+    // Every bucket is ordered by RANK COUNTING: a task is (class, 64 of its elements); each lane holds one of them and counts
+    // the bucket's keys below its own -- the bucket is read 64 keys at a time (one LDS read per lane) and handed round with
+    // v_readlane, so a comparison is two scalar broadcasts, one 64-bit compare and one add-with-carry, no LDS traffic.  Keys
+    // are unique, so the rank is the element's place.  (The in-wave bitonic network on the same buckets: 11.3 us -- three
+    // ds_bpermute per element and stage, 16 waves on one LDS; this: see DESIGN 4.2b.)
+    const int wv = tid >> 6, lane = tid & 63;
+    const int ntask = s_cls_ntask;
+    for (int t = wv; t < ntask; t += T / 64) {
+      int c = 0;
+      {                                              // the class whose task range holds t (<= 256 classes: four per lane)
+        u64 found = 0ull;
+        int base_c = 0;
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const int cc = u * 64 + lane;
+          const bool in = t >= s_cls_task[cc] && t < s_cls_task[cc + 1];
+          const u64 b = __ballot(in);
+          if (b) { found = b; base_c = u * 64; }
+        }
+        c = base_c + __builtin_ctzll(found);
+      }
+      const int off = s_cls_off[c], cnt = s_hist[c], mine_i = (t - s_cls_task[c]) * 64 + lane;
+      const bool have = mine_i < cnt;
+      const unsigned long long mine = have ? s_keys2[off + mine_i] : 0ull;
+      const uint32_t myv = have ? s_vals2[off + mine_i] : 0u;
+      int rank = 0;
+      for (int cb = 0; cb < cnt; cb += 64) {
+        const unsigned long long ck = (cb + lane < cnt) ? s_keys2[off + cb + lane] : ~0ull;   // pads above every key: never counted
+        const uint32_t clo = (uint32_t)ck, chi = (uint32_t)(ck >> 32);
+        const int mm = min(64, cnt - cb);
+        int j = 0;
+        for (; j + 4 <= mm; j += 4) {
+#pragma unroll
+          for (int z = 0; z < 4; z++) {
+            const unsigned long long kj = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)chi, j + z) << 32) |
+                                          (uint32_t)__builtin_amdgcn_readlane((int)clo, j + z);
+            rank += (kj < mine) ? 1 : 0;
+          }
+        }
+        for (; j < mm; j++) {
+          const unsigned long long kj = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)chi, j) << 32) |
+                                        (uint32_t)__builtin_amdgcn_readlane((int)clo, j);
+          rank += (kj < mine) ? 1 : 0;
+        }
+      }
+      // the element's place is known: its sorted (key, slot) pair, its NMS record and its alive bit go out from here (the
+      // generic tail below is the network's)
+      if (have) {
+        const int p = off + rank;
+        keys_out[b0 + p] = mine; vals_out[b0 + p] = myv;
+        const size_t ci = (size_t)b0 + myv;
+        const float4 c0 = cand[ci * 2], c1 = cand[ci * 2 + 1];
+        const float coff = c1.z * class_offset;                  // :849
+        RBoxFeat f = rbox_make_feat(c0.x + coff, c0.y + coff, c0.z, c0.w, c1.x);
+        float4 rq[4];
+        RotGeom::pack(f, rq);
+#pragma unroll
+        for (int u = 0; u < 4; u++) rec[(size_t)(b0 + p) * 4 + u] = rq[u];
+        const float mn = (c0.w < c0.z) ? c0.w : c0.z;
+        if (!(mn < 0.001f)) atomicOr(&s_abits[p >> 6], 1ull << (p & 63));   // nms_rotated_wrapper.py:32
+      }
+    }
+    __syncthreads();
+    // the image's bitmap words were zeroed by k_reset_state; a word can hold positions of classes of several parts
+    if (tid < kSortLdsMax / 2 / 64) { const u64 w = s_abits[tid]; if (w) atomicOr(alive + ((size_t)b0 >> 6) + tid, w); }
+    if (g == bs - 1 && q == 0 && tid < 8) alive[(((size_t)bs * cap_img) >> 6) + tid] = 0ull;   // the bitmap's guard words
+    TSTAMP();
+#ifdef OBB_SORT_TRACE
+    if (tid == 0 && g == 0) { printf("sortprep g %d part %d n %d by class, max %d:", g, q, n, s_cls_max); for (int z = 1; z < ti_; z++) printf(" %llu", tt[z] - tt[z - 1]); printf(" (x10 ns)\n"); }
+#endif
+    return;
+  } else {
+    switch (npad >> 10) {
+      case 0: case 1: sort_lds_regs<1>(s_keys, s_vals, npad, tid); break;
+      case 2: sort_lds_regs<2>(s_keys, s_vals, npad, tid); break;
+      case 4: sort_lds_regs<4>(s_keys, s_vals, npad, tid); break;
+      default: sort_lds_regs<8>(s_keys, s_vals, npad, tid); break;
+    }
   }
   TSTAMP();
   for (int i = tid; i < n; i += T) { keys_out[b0 + i] = s_keys[i]; vals_out[b0 + i] = s_vals[i]; }
@@ -589,7 +745,7 @@ __global__ __launch_bounds__(1024) void k_sort_prep_lds(const float4* __restrict
   if (g == bs - 1 && tid < 8) alive[(((size_t)bs * cap_img) >> 6) + tid] = 0ull;   // the bitmap's guard words
 #ifdef OBB_SORT_TRACE
   TSTAMP();
-  if (tid == 0 && g == 0) printf("sortprep g %d n %d: load %llu sort %llu write+seg %llu rec %llu (x10 ns)\n", g, n, tt[1]-tt[0], tt[2]-tt[1], tt[3]-tt[2], tt[4]-tt[3]);
+  if (tid == 0 && g == 0) { printf("sortprep g %d n %d by_class %d max %d:", g, n, (int)by_class, s_cls_max); for (int q = 1; q < ti_; q++) printf(" %llu", tt[q] - tt[q - 1]); printf(" (x10 ns)\n"); }
 #endif
 #undef TSTAMP
 }
@@ -777,10 +933,15 @@ static int run_nms_obb(const void* pred, const void* objcol, int dtype, int64_t 
   }
   d.cap_img = cap_img; d.cand = cv.cand; d.keys = cv.keys_a; d.vals = cv.vals_a; d.cnt = cv.cnt; d.tiny = cv.tiny;
 
+  static const int no_lds_sort = obb_dev_switch("OBB_NO_LDS_SORT", 0) != 0;      // A/B switch (development builds)
+  const bool lds_sort = !no_lds_sort && expected_cand > 0 && expected_cand <= kSortLdsHint && !group_ok;
   {
     Carve& nv0 = cv.nms;
+    // (cap_img is a multiple of 64 -> bs * cap_img / 64 words; + the guard words, rounded up to 16 bytes)
+    const long long alive16 = lds_sort ? (long long)((((size_t)bs * cap_img) >> 6) + 8 + 1) / 2 : 0ll;
     k_reset_state<<<256, 256, 0, st>>>(cv.cnt, (int)(bs * kCntPad), cv.tiny, (int)bs, status, cv.ticket,
-                                       reinterpret_cast<uint4*>(nv0.bar), (long long)(nv0.bar_bytes / 16));
+                                       reinterpret_cast<uint4*>(nv0.bar), (long long)(nv0.bar_bytes / 16),
+                                       reinterpret_cast<uint4*>(nv0.alive), alive16);
   }
   // rows per workgroup: 2048 when that still gives two workgroups per CU, else 1024 / 512 (small batches, the TTA tensor)
   d.rows_per_thread = (bs * A >= 4LL * kDecThreads * 480) ? 4 : (bs * A >= 2LL * kDecThreads * 480) ? 2 : 1;
@@ -794,8 +955,6 @@ static int run_nms_obb(const void* pred, const void* objcol, int dtype, int64_t 
   const unsigned gs = (unsigned)((bs + 255) / 256);
   Carve& nv = cv.nms;
   const int64_t max_seg = (max_nms > 0 && max_nms < cap_img) ? max_nms : cap_img;
-  static const int no_lds_sort = obb_dev_switch("OBB_NO_LDS_SORT", 0) != 0;      // A/B switch (development builds)
-  const bool lds_sort = !no_lds_sort && expected_cand > 0 && expected_cand <= kSortLdsHint && !group_ok;
   // grid of the NMS launch (needed by the planner inside the fused kernel)
   const int nms_capmax = cap_max(bs * ncs);
   const int plan_chunk = cap_first() < nms_capmax ? cap_first() : nms_capmax;
@@ -809,11 +968,12 @@ static int run_nms_obb(const void* pred, const void* objcol, int dtype, int64_t 
         return OBB_ERR_LAUNCH;
       attr_set = true;
     }
-    k_sort_prep_lds<<<(unsigned)bs + (plan_nb > 0 ? 1u : 0u), 1024, lds, st>>>(cv.cand, cv.keys_a, cv.vals_a, cv.keys_b, cv.vals_b, cv.cnt, cv.tiny, (int)bs, cap_img,
+    const int parts = (class_ok && ncs >= 8) ? 4 : 1;           // class-segment images: four workgroups each take every fourth class
+    k_sort_prep_lds<<<(unsigned)(bs * parts) + (plan_nb > 0 ? 1u : 0u), 1024, lds, st>>>(cv.cand, cv.keys_a, cv.vals_a, cv.keys_b, cv.vals_b, cv.cnt, cv.tiny, (int)bs, cap_img,
                                                    max_nms, class_ok, A, nc, ncs, agnostic ? 0.f : max_wh, cv.sort_begin, cv.sort_end,
                                                    cv.img_end, cv.mode, cv.grp_begin, cv.grp_end, nv.seg_begin, nv.seg_end, nv.keep_cnt,
                                                    nv.rec, nv.alive, cv.ticket, plan_nb, plan_chunk, plan_nb > 0 ? nv.plan : nullptr,
-                                                   reinterpret_cast<int*>(cv.digit_base));   // (the class-bounds table of the other sort paths: free here)
+                                                   reinterpret_cast<int*>(cv.digit_base), parts);   // (digit_base: the class-bounds table of the other sort paths, free here)
   } else {
    {
     ProfScope ps(PROF_SEGSORT, st);
