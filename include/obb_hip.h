@@ -181,22 +181,28 @@ int64_t obb_task1_format_rows(const char* text_host, const int32_t* name_off_hos
  *               `labels` of autolabelling (:807-813), prepared by the host layer; n_extra rows
  *   cap_img     candidate slots reserved per image.  If an image produces more, status[0] receives that count
  *               (> cap_img) and the caller must retry with a larger cap_img (A*nc can never overflow).
- *   expected_cand  candidates per image the caller expects (status[1] of its previous call; 0 = unknown: always valid).
- *               Selects the sort: 1 .. OBB_NMS_SORT_LDS_HINT -> one workgroup per image sorts in LDS and also builds the
- *               NMS records (six launches fewer); above ~12k the per-image sort runs on many workgroups per image
- *               (csrc/segsort.h); otherwise rocPRIM's one-workgroup-per-segment sort.  The in-LDS sort takes at most
- *               OBB_NMS_SORT_LDS_MAX candidates of an image: with a hint in 1 .. OBB_NMS_SORT_LDS_HINT and
- *               status[1] > OBB_NMS_SORT_LDS_MAX after the call, such images were left EMPTY -- call again with
- *               expected_cand = status[1] (the Python layer does).  Otherwise the result does not depend on the hint.
+ *   expected_cand  what the caller expects, from status[1] of its previous call of this shape (0 = unknown: always valid):
+ *               bits 0..31  candidates per image.  Selects the sort: 1 .. OBB_NMS_SORT_LDS_HINT -> the images are sorted in LDS
+ *               by a kernel that also builds the NMS records (six launches fewer); larger -> the multi-workgroup sorts of
+ *               csrc/segsort.h / csrc/psrs_sort.h.  The in-LDS sort takes at most OBB_NMS_SORT_LDS_MAX candidates of an image:
+ *               with a hint in 1 .. OBB_NMS_SORT_LDS_HINT and status[1] (low word) > OBB_NMS_SORT_LDS_MAX after the call, such
+ *               images were left EMPTY -- call again with that count as the hint (the Python layer does).
+ *               bits 32..62 the largest NMS segment (boxes of one class of one image).  1 .. OBB_NMS_SMALL_SEG together with the
+ *               in-LDS sort and iou_thres >= 0 selects the one-workgroup-per-segment NMS kernel (csrc/nms_small.h); a call that
+ *               meets a larger segment there sets status[0] = -1: NOTHING of its output is valid, call again with the
+ *               segment size status[1] reports (the Python layer does).  0 or larger: the persistent kernel.
+ *               Apart from these two retry cases the result does not depend on the hint.
  *   out         [bs][max_det][7] fp32 rows [x y l s theta conf cls];  out_count [bs] int64 (-1: device-side abort);
  *               out_packed != 0: the rows of image b start right behind those of image b-1 (row sum(out_count[0..b-1]))
  *               instead of at row b*max_det -- the same buffer size is required, one split instead of bs slices on the host
- *               status [2] int64: [0] overflow count (see cap_img), [1] largest candidate count of any image
+ *               status [2] int64: [0] overflow count (see cap_img), or -1 (see expected_cand); [1] largest candidate count of any
+ *               image in bits 0..31, largest NMS segment in bits 32..62 (0 where the sort path does not know it)
  *               out_count and status are written with plain 8-byte stores by the last kernel of the call: they may live in
  *               device memory or in pinned host memory (hipHostMalloc) that the caller polls instead of copying back
  * Score ties are ordered by ascending (anchor*nc + class): deterministic, where the reference inherits the order
  * of torch's unstable sort.
  */
+#define OBB_NMS_SMALL_SEG 384
 #define OBB_NMS_SORT_LDS_HINT 6144
 #define OBB_NMS_SORT_LDS_MAX 8192
 size_t obb_nms_obb_workspace_bytes(int64_t bs, int64_t cap_img, int64_t nc, int agnostic);

@@ -17,6 +17,7 @@
 #include "nms_core.h"
 #include "obb_hip.h"
 #include "psrs_sort.h"
+#include "nms_small.h"
 #include "segsort.h"
 
 namespace obb {

@@ -1,0 +1,296 @@
+// Greedy NMS of MANY SMALL segments, one workgroup per segment, nothing shared between workgroups -- gfx950 (included by
+// nms.hip behind nms_core.h, namespace obb).
+//
+// The regime: the fused driver at the reference's default thresholds (utils/general.py:772-862 with conf 0.25): 16 images x
+// 16 classes = 256 segments of ~100 boxes (a few above 200).  The persistent kernel of nms_core.h is built for lists of 10^5
+// boxes -- chunks, a replicated state machine on a shared bitmap, edge lists in global memory, rounds of a maximal independent
+// set, team barriers, a planner in front: for a 100-box segment its workgroup spends 7 us selecting, 12 us resolving and every
+// record it touches is a global round trip (busiest workgroup 69 us, mean 47).  Here a segment lives in LDS from its first
+// load to its last store:
+//   1. records (64 bytes per box) and the segment's slice of the alive bitmap -> LDS;
+//   2. pairs: 64 x 16 slices of the upper triangle, drawn by the eight waves from an LDS counter; the circle test of
+//      RotGeom::cheap_reject on quad 0, then the same three decision stages as everywhere else (classify_quick, classify_full,
+//      hit_exact -- the decisions ARE the reference's), each with its own LDS queue so that a stage always runs on a full wave;
+//      "IoU > thr" sets bit j of row i of a bit matrix in LDS;
+//   3. the reference's scan itself, by one wave: the lowest alive position is kept and clears its row's bits -- one
+//      iteration per KEPT box;
+//   4. the kept positions and their count.
+// No barrier between workgroups, no co-residency assumption, no planner.  A segment with more than kSmallMax boxes raises a
+// flag and is left alone: the host layer repeats the call on the persistent kernel (it chooses this kernel from the
+// previous call's largest segment, include/obb_hip.h: expected_cand).
+#pragma once
+
+namespace obb {
+
+constexpr int kSmallMax = OBB_NMS_SMALL_SEG;        // boxes per segment (include/obb_hip.h)
+constexpr int kSmallWords = kSmallMax / 64;         // bit-matrix words per row
+constexpr int kSmallThreads = 512;
+constexpr int kSmallWaves = kSmallThreads / 64;
+
+struct SmallArgs {
+  const float4* rec;         // [n][RECQ] records in sorted order
+  const u64* alive;          // bit p: position p takes part (the small-box filter clears bits)
+  const int* seg_begin;      // [nseg]
+  const int* seg_end;        // [nseg]
+  int* keep_cnt;             // [nseg] (output)
+  int64_t* keep_out;         // segment g writes sorted positions at keep_out[seg_begin[g] + k]
+  int* too_big;              // set to the size of a segment this kernel does not take
+  float thr;
+  int max_keep;              // 0 = unlimited
+};
+
+// The three decision stages are real functions here (one body each, called from the full drains and from the pooled
+// leftovers): a workgroup runs most of this kernel's code exactly once, so its time is instruction FETCH as much as
+// execution -- with the stages inlined at both call sites the kernel was 17.5k instructions, and a wave that found no work
+// took 2 us to get through it.
+template <class G>
+__device__ __attribute__((noinline)) int small_quick(const float4* ra, const float4* rb, float thr) {
+  return G::classify_quick(ra, rb, thr, true);
+}
+
+template <class G>
+struct SmallWave {                                  // per wave
+  float scr[G::SCR * 64];                           // exact-clip scratch, one column per lane
+  uint32_t q0[128], q1[128], q2[128];               // pending (i << 16 | j) pairs of the three stages
+};
+
+template <class G>
+__global__ __launch_bounds__(kSmallThreads) void k_nms_small(SmallArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+  __shared__ int s_next, s_nkept, s_qcnt[kSmallWaves], s_qhead[kSmallWaves], s_qcnt2[kSmallWaves];
+  __shared__ uint32_t s_kept[kSmallMax];
+  float4* s_rec = reinterpret_cast<float4*>(s_raw);                                  // [kSmallMax][RECQ]
+  u64* s_mask = reinterpret_cast<u64*>(s_rec + (size_t)kSmallMax * G::RECQ);         // [kSmallMax][kSmallWords]
+  u64* s_alive = s_mask + (size_t)kSmallMax * kSmallWords;                           // [kSmallWords] + pad
+  SmallWave<G>* s_wave = reinterpret_cast<SmallWave<G>*>(s_alive + 8);
+  const int seg = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int sb = a.seg_begin[seg], n = a.seg_end[seg] - sb;
+  if (n <= 0) return;                                            // (keep_cnt is zero already)
+  if (n > kSmallMax) { if (tid == 0) atomicMax(a.too_big, n); return; }
+#ifdef OBB_SMALL_TRACE
+  unsigned long long tt[8]; int ti_ = 0, nd0 = 0, nd1 = 0, nd2 = 0, nit = 0;
+#define SSTAMP() do { tt[ti_++] = wall_clock64(); } while (0)
+#else
+#define SSTAMP() do {} while (0)
+#endif
+  SSTAMP();
+  // ---- 1. the segment -> LDS
+  for (int t = tid; t < n * G::RECQ; t += kSmallThreads) s_rec[t] = a.rec[(size_t)sb * G::RECQ + t];
+  for (int t = tid; t < n * kSmallWords; t += kSmallThreads) s_mask[t] = 0ull;
+  if (tid < kSmallWords) {
+    const int w0 = (sb >> 6) + tid, sh = sb & 63;
+    u64 v = a.alive[w0] >> sh;
+    if (sh) v |= a.alive[w0 + 1] << (64 - sh);
+    const int left = n - tid * 64;                               // positions of this word that belong to the segment
+    if (left <= 0) v = 0ull; else if (left < 64) v &= (1ull << left) - 1ull;
+    s_alive[tid] = v;
+  }
+  if (tid == 0) s_next = 0;
+  __syncthreads();
+  SSTAMP();
+  // ---- 2. pairs
+  const float thr = a.thr;
+  SmallWave<G>& W = s_wave[wv];
+  PairQueue Q0{W.q0, 0, 0}, Q1{W.q1, 0, 0}, Q2{W.q2, 0, 0};
+  auto hit = [&](bool h, int i, int j) { if (h) atomicOr(&s_mask[i * kSmallWords + (j >> 6)], 1ull << (j & 63)); };
+  auto drain2 = [&](int cnt) {                                   // the exact clip
+#ifdef OBB_SMALL_TRACE
+    nd2++;
+#endif
+    wave_sync();
+    bool h = false;
+    int i = 0, j = 0;
+    if (lane < cnt) {
+      const uint32_t e = W.q2[(Q2.head + lane) & 127];
+      i = (int)(e >> 16); j = (int)(e & 0xffffu);
+      h = nms_stage_exact<G>(s_rec + i * G::RECQ, s_rec + j * G::RECQ, thr, W.scr + lane);
+    }
+    hit(h, i, j);
+    Q2.head = (Q2.head + cnt) & 127; Q2.count -= cnt;
+    wave_sync();
+  };
+  auto drain1 = [&](int cnt) {                                   // the IoU interval
+#ifdef OBB_SMALL_TRACE
+    nd1++;
+#endif
+    wave_sync();
+    int res = 0, i = 0, j = 0;
+    uint32_t e = 0;
+    if (lane < cnt) {
+      e = W.q1[(Q1.head + lane) & 127];
+      i = (int)(e >> 16); j = (int)(e & 0xffffu);
+      res = nms_stage_full<G>(s_rec + i * G::RECQ, s_rec + j * G::RECQ, thr);
+    }
+    hit(res == 1, i, j);
+    Q1.head = (Q1.head + cnt) & 127; Q1.count -= cnt;
+    Q2.push(res == 2, e);
+    wave_sync();
+    if (Q2.count >= 64) drain2(64);
+  };
+  auto drain0 = [&](int cnt) {                                   // the register-only bounds
+#ifdef OBB_SMALL_TRACE
+    nd0++;
+#endif
+    wave_sync();
+    int res = 0, i = 0, j = 0;
+    uint32_t e = 0;
+    if (lane < cnt) {
+      e = W.q0[(Q0.head + lane) & 127];
+      i = (int)(e >> 16); j = (int)(e & 0xffffu);
+      res = small_quick<G>(s_rec + i * G::RECQ, s_rec + j * G::RECQ, thr);
+    }
+    hit(res == 1, i, j);
+    Q0.head = (Q0.head + cnt) & 127; Q0.count -= cnt;
+    Q1.push(res == 3, e);
+    Q2.push(res == 2, e);
+    wave_sync();
+    if (Q2.count >= 64) drain2(64);                              // (first: drain1 may add up to 64 more)
+    if (Q1.count >= 64) drain1(64);
+  };
+  {
+    const int nb = (n + 63) >> 6;
+    const int nitems = nb * (nb + 1) / 2 * 4;                    // upper-triangle tiles x four 16-row slices
+    for (;;) {
+      int it = 0;
+      if (lane == 0) it = atomicAdd(&s_next, 1);
+      it = __builtin_amdgcn_readfirstlane(it);
+      if (it >= nitems) break;
+#ifdef OBB_SMALL_TRACE
+      nit++;
+#endif
+      const int tile = it >> 2, quarter = it & 3;
+      int ti = 0, rem = tile;                                    // tile -> (ti, tj), ti <= tj: row ti holds nb - ti tiles
+      while (rem >= nb - ti) { rem -= nb - ti; ti++; }
+      const int tj = ti + rem;
+      const int j = tj * 64 + lane;
+      const bool jv = j < n && ((s_alive[tj] >> lane) & 1ull);
+      const float4 cq = s_rec[(j < n ? j : 0) * G::RECQ];
+      const int i0 = ti * 64 + quarter * 16;
+      const u64 arow = s_alive[ti] >> (quarter * 16);
+#pragma unroll 4
+      for (int r = 0; r < 16; r++) {
+        const int i = i0 + r;
+        if (i >= n) break;                                       // (wave-uniform)
+        if (!((arow >> r) & 1ull)) continue;
+        const float4 rq = s_rec[i * G::RECQ];                    // (all lanes the same address: a broadcast)
+        const bool pass = jv && i < j && !G::cheap_reject(rq, cq);
+        if (__ballot(pass)) {
+          Q0.push(pass, ((uint32_t)i << 16) | (uint32_t)j);
+          if (Q0.count >= 64) drain0(64);
+        }
+      }
+    }
+    SSTAMP();
+    // Leftovers: every wave holds a few pairs per stage.  A drain costs its instructions whatever it holds (150 / 1500 / ~4000
+    // per stage), and eight nearly empty ones share four SIMDs -- so the leftovers of a stage are POOLED: the eight rings are
+    // read as one list, 64 entries per wave, by as few waves as it takes (what a wave decides goes to its own next ring).
+    for (int stage = 0; stage < 3; stage++) {
+      PairQueue& Q = stage == 0 ? Q0 : (stage == 1 ? Q1 : Q2);
+      for (;;) {                                                 // (one pass unless the rings hold more than 8 x 64 pairs)
+        if (lane == 0) { s_qcnt[wv] = Q.count; s_qhead[wv] = Q.head; if (stage == 1) s_qcnt2[wv] = Q2.count; }
+        __syncthreads();
+        if (stage == 1) {
+          // what is left for the interval stage and the exact clip together fits one wave: the interval stage (1700
+          // instructions to spare some pairs the clip) would only stand in front of a clip that runs anyway -- its pairs join
+          // the clip's ring and the stage is skipped
+          int t12 = 0;
+#pragma unroll
+          for (int w = 0; w < kSmallWaves; w++) t12 += s_qcnt[w] + s_qcnt2[w];
+          if (t12 <= 64) {                                       // (workgroup-uniform)
+            if (Q1.count > 0) {
+              wave_sync();
+              const bool mv = lane < Q1.count;
+              const uint32_t e1 = mv ? W.q1[(Q1.head + lane) & 127] : 0u;
+              Q1.head = (Q1.head + Q1.count) & 127; Q1.count = 0;
+              Q2.push(mv, e1);
+              wave_sync();
+            }
+            __syncthreads();
+            break;
+          }
+        }
+        int pre[kSmallWaves + 1];
+        pre[0] = 0;
+#pragma unroll
+        for (int w = 0; w < kSmallWaves; w++) pre[w + 1] = pre[w] + s_qcnt[w];
+        const int total = pre[kSmallWaves];
+        if (total == 0) { __syncthreads(); break; }              // (workgroup-uniform; the barrier: s_qcnt is rewritten by the next stage)
+        const int g = wv * 64 + lane;                            // wave wv takes pooled entries [64 wv, 64 wv + 64)
+        int res = 0, i = 0, j = 0;
+        uint32_t e = 0;
+        const bool busy = wv * 64 < total;                       // (wave-uniform)
+        if (busy && g < total) {
+          int w = 0;
+#pragma unroll
+          for (int u = 1; u < kSmallWaves; u++) w += (g >= pre[u]) ? 1 : 0;
+          const uint32_t* ring = stage == 0 ? s_wave[w].q0 : (stage == 1 ? s_wave[w].q1 : s_wave[w].q2);
+          e = ring[(s_qhead[w] + (g - pre[w])) & 127];
+          i = (int)(e >> 16); j = (int)(e & 0xffffu);
+          const float4* ra = s_rec + i * G::RECQ;
+          const float4* rb = s_rec + j * G::RECQ;
+          if (stage == 0) res = small_quick<G>(ra, rb, thr);
+          else if (stage == 1) res = nms_stage_full<G>(ra, rb, thr);
+          else res = nms_stage_exact<G>(ra, rb, thr, W.scr + lane) ? 1 : 0;
+        }
+        hit(res == 1, i, j);
+#ifdef OBB_SMALL_TRACE
+        if (busy) { if (stage == 0) nd0++; else if (stage == 1) nd1++; else nd2++; }
+#endif
+        __syncthreads();                                         // every reader is done with the rings of this stage ...
+        {                                                        // this wave's ring lost what the pass took of it
+          const int room = kSmallWaves * 64 - pre[wv];
+          const int took = room <= 0 ? 0 : (room < s_qcnt[wv] ? room : s_qcnt[wv]);
+          Q.head = (Q.head + took) & 127; Q.count -= took;
+        }
+        if (busy) {                                              // ... before anybody's next ring grows
+          if (stage == 0) { Q1.push(res == 3, e); Q2.push(res == 2, e); }
+          else if (stage == 1) Q2.push(res == 2, e);
+          wave_sync();
+          if (Q2.count >= 64) drain2(64);                        // (a ring holds 128: full drains stay with the wave)
+          if (stage == 0 && Q1.count >= 64) drain1(64);
+        }
+        __syncthreads();                                         // (s_qcnt is rewritten by the next pass)
+      }
+    }
+  }
+  SSTAMP();
+  __syncthreads();
+  SSTAMP();
+  // ---- 3. the scan (nms_rotated_cuda.cu:109-128): the lowest alive position is kept and removes what it overlaps
+  if (wv == 0) {
+    u64 cur = lane < kSmallWords ? s_alive[lane] : 0ull;
+    int k = 0;
+    const int limit = a.max_keep > 0 ? a.max_keep : 0x7fffffff;
+    const int nw = (n + 63) >> 6;
+    for (int w = 0; w < nw && k < limit; w++) {
+      u64 pending = ((u64)(uint32_t)__builtin_amdgcn_readlane((int)(cur >> 32), w) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)cur, w);
+      while (pending && k < limit) {
+        const int b = __builtin_ctzll(pending), i = w * 64 + b;
+        if (lane == 0) s_kept[k] = (uint32_t)i;
+        k++;
+        if (lane < kSmallWords) cur &= ~s_mask[i * kSmallWords + lane];
+        pending = ((u64)(uint32_t)__builtin_amdgcn_readlane((int)(cur >> 32), w) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)cur, w);
+        pending = b < 63 ? (pending & (~0ull << (b + 1))) : 0ull;
+      }
+    }
+    if (lane == 0) s_nkept = k;
+  }
+  __syncthreads();
+  SSTAMP();
+  // ---- 4. out
+  const int nk = s_nkept;
+  for (int k = tid; k < nk; k += kSmallThreads) a.keep_out[(size_t)sb + k] = (int64_t)(sb + (int)s_kept[k]);
+  if (tid == 0) a.keep_cnt[seg] = nk;
+#ifdef OBB_SMALL_TRACE
+  SSTAMP();
+  if (lane == 0 && (seg % 41 == 0) && (wv == 0 || wv == 5)) printf("small seg %d n %d kept %d wave %d: load %llu items %llu leftovers %llu wait %llu scan %llu out %llu | items %d drains %d %d %d (x10 ns)\n", seg, n, nk, wv, tt[1]-tt[0], tt[2]-tt[1], tt[3]-tt[2], tt[4]-tt[3], tt[5]-tt[4], tt[6]-tt[5], nit, nd0, nd1, nd2);
+#endif
+#undef SSTAMP
+}
+
+template <class G>
+static size_t small_lds_bytes() {
+  return (size_t)kSmallMax * G::RECQ * 16 + (size_t)kSmallMax * kSmallWords * 8 + 8 * 8 + sizeof(SmallWave<G>) * kSmallWaves;
+}
+
+}  // namespace obb

@@ -450,7 +450,7 @@ __global__ void k_reset_state(int* __restrict__ cnt, int n_cnt, int* __restrict_
   for (long long k = i; k < n_cnt; k += n) cnt[k] = 0;
   for (long long k = i; k < bs; k += n) tiny[k] = 0;
   (void)status;                                                 // (both status words are written by k_gather_out)
-  if (i == 2) *ticket = 0;
+  if (i < 16) ticket[i] = 0;                                    // [0] the planner's ticket, [4] largest NMS segment, [8] a segment k_nms_small left out
   for (long long k = i; k < n_bar16; k += n) bar16[k] = make_uint4(0u, 0u, 0u, 0u);
   // (the in-LDS sort path ORs its alive bits into zeroed words: several workgroups share the words of an image)
   for (long long k = i; k < n_alive16; k += n) alive16[k] = make_uint4(0u, 0u, 0u, 0u);
@@ -599,6 +599,8 @@ __global__ __launch_bounds__(1024) void k_sort_prep_lds(const float4* __restrict
     // (the rank counting is quadratic in the bucket: beyond 512 elements -- two classes, one dominant class -- the 16-wave network takes over)
     by_class = s_cls_max <= 512;
   }
+  // the call's largest NMS segment (feedback for the caller's choice of the NMS kernel, include/obb_hip.h: status[1])
+  if (q == 0 && tid == 0) atomicMax(ticket + 4, (m == 1 && n <= kSortLdsMax / 2) ? s_cls_max : e);
   TSTAMP();
   if (!by_class) {
     if (q > 0) return;                               // (workgroup-uniform) the network orders the whole image in part 0
@@ -760,7 +762,8 @@ __global__ __launch_bounds__(256) void k_gather_out(const float4* __restrict__ c
                                                     const int* __restrict__ seg_begin, const int* __restrict__ keep_cnt,
                                                     const int* __restrict__ mode, int ncs, long long max_det, float* __restrict__ out,
                                                     int64_t* __restrict__ out_count, const int* __restrict__ cnt, long long cap_img,
-                                                    int64_t* __restrict__ status, const int* __restrict__ abort_flag, int packed) {
+                                                    int64_t* __restrict__ status, const int* __restrict__ abort_flag, int packed,
+                                                    const int* __restrict__ info) {
   __shared__ int s_pre[257], s_seg[256];
   __shared__ long long s_rows[4], s_mx[4];
   __shared__ unsigned long long s_key[kMergeLds];
@@ -809,8 +812,10 @@ __global__ __launch_bounds__(256) void k_gather_out(const float4* __restrict__ c
   if (g == 0 && tid == 0 && part == 0) {
     long long m4 = s_mx[0];
     for (int k = 1; k < 4; k++) if (s_mx[k] > m4) m4 = s_mx[k];
-    status[0] = m4 > cap_img ? m4 : 0;
-    status[1] = m4;
+    // info[8] != 0: k_nms_small met a segment above its limit -- nothing of this call is valid, the caller repeats it with
+    // the persistent kernel (status[0] = -1); info[4]: the largest NMS segment where the sort kernel knew it (else 0)
+    status[0] = info[8] ? -1 : (m4 > cap_img ? m4 : 0);
+    status[1] = m4 | ((long long)(info[8] > info[4] ? info[8] : info[4]) << 32);
   }
   // first output row of the image: g * max_det, or (packed) the number of rows of the images before it
   const long long row0 = packed ? s_rows[0] + s_rows[1] + s_rows[2] + s_rows[3] : (long long)g * max_det;
@@ -907,6 +912,10 @@ static int run_nms_obb(const void* pred, const void* objcol, int dtype, int64_t 
     return OBB_ERR_BAD_ARG;
   if (A * nc + n_extra > 0xffffffffLL || bs * cap_img > 0x7fffffffLL) return OBB_ERR_BAD_ARG;
   if (dtype != 0 && dtype != 1) return OBB_ERR_BAD_ARG;
+  // expected_cand: low 32 bits = the previous call's largest candidate count of an image (0: unknown), high 32 bits = its
+  // largest NMS segment (0: unknown) -- both as status[1] reported them
+  const int64_t seg_hint = (expected_cand >> 32) & 0x7fffffff;
+  expected_cand &= 0xffffffffll;
   cap_img = round_cap(cap_img);
   const int ncs = agnostic ? 1 : nc;                               // NMS segments per image
   // class segmentation needs the class in 8 and the anchor index in 24 key bits
@@ -958,7 +967,10 @@ static int run_nms_obb(const void* pred, const void* objcol, int dtype, int64_t 
   // grid of the NMS launch (needed by the planner inside the fused kernel)
   const int nms_capmax = cap_max(bs * ncs);
   const int plan_chunk = cap_first() < nms_capmax ? cap_first() : nms_capmax;
-  const int plan_nb = (bs * ncs > 1) ? nms_grid(bs * ncs, bs * max_seg, cap_first()) : 0;
+  // Which NMS kernel: one workgroup per segment, everything in LDS (nms_small.h), when the previous call's largest segment fits it
+  // (class segments, the in-LDS sort, thr >= 0: its first decision stage uses the conservative bounds); else the persistent kernel.
+  const bool small_nms = lds_sort && class_ok && seg_hint > 0 && seg_hint <= kSmallMax && iou_thres >= 0.f && bs * ncs <= 65535;
+  const int plan_nb = (bs * ncs > 1 && !small_nms) ? nms_grid(bs * ncs, bs * max_seg, cap_first()) : 0;
   if (lds_sort) {
     ProfScope ps(PROF_SEGSORT, st);
     static bool attr_set = false;
@@ -1034,7 +1046,20 @@ static int run_nms_obb(const void* pred, const void* objcol, int dtype, int64_t 
   a.rows = nv.rows; a.nrows = nv.nrows; a.edges = nv.edges; a.nedges = nv.nedges;
   a.ecap = nv.ecap; a.n = (int)(bs * cap_img); a.capmax = cap_max(bs * ncs);
   a.max_keep = (int)max_det; a.window = nms_window(max_det); a.thr = iou_thres; a.cull = (iou_thres >= 0.f) ? 1 : 0;
-  {
+  if (small_nms) {
+    ProfScope ps(PROF_STEPS, st);
+    static bool attr_set = false;
+    const size_t lds = small_lds_bytes<RotGeom>();
+    if (!attr_set) {
+      if (hipFuncSetAttribute((const void*)k_nms_small<RotGeom>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return OBB_ERR_LAUNCH;
+      attr_set = true;
+    }
+    SmallArgs sa{};
+    sa.rec = nv.rec; sa.alive = nv.alive; sa.seg_begin = nv.seg_begin; sa.seg_end = nv.seg_end; sa.keep_cnt = nv.keep_cnt;
+    sa.keep_out = cv.keep; sa.too_big = cv.ticket + 8; sa.thr = iou_thres; sa.max_keep = (int)max_det;
+    k_nms_small<RotGeom><<<(unsigned)(bs * ncs), kSmallThreads, lds, st>>>(sa);
+  } else {
     ProfScope ps(PROF_STEPS, st);
     rc = nms_steps(0, a, nv, bs * ncs, bs * max_seg, st, kNmsBarZeroed | ((lds_sort && plan_nb > 0) ? kNmsPlanned : 0));
     if (rc) return rc;
@@ -1044,7 +1069,7 @@ static int run_nms_obb(const void* pred, const void* objcol, int dtype, int64_t 
     // parts per image: one up to ~2k expected candidates (the kept rows fit the kernel's LDS and 256 threads), then one per 1024
     const unsigned gparts = expected_cand <= 2048 ? 1u : (unsigned)((expected_cand + 1023) / 1024 > 16 ? 16 : (expected_cand + 1023) / 1024);
     k_gather_out<<<dim3((unsigned)bs, gparts), 256, 0, st>>>(cv.cand, cv.vals_b, cv.keys_b, cv.keep, nv.seg_begin, nv.keep_cnt, cv.mode, ncs, max_det,
-                                              out, out_count, cv.cnt, cap_img, status, nv.abort_flag, out_packed);
+                                              out, out_count, cv.cnt, cap_img, status, nv.abort_flag, out_packed, cv.ticket);
   }
   return hipGetLastError() == hipSuccess ? OBB_OK : OBB_ERR_LAUNCH;
 }

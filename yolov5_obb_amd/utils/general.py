@@ -27,6 +27,8 @@ _meta_memo = {}     # (device index, bs, thread) -> the int64 buffer the counter
 _cand_memo = {}     # same key -> largest candidate count of an image in the previous call (sort-algorithm hint; 0 forces the generic sort)
 _SORT_LDS_HINT = 6144   # include/obb_hip.h OBB_NMS_SORT_LDS_HINT: hints up to this select the one-workgroup-per-image sort ...
 _SORT_LDS_MAX = 8192    # ... OBB_NMS_SORT_LDS_MAX: which takes at most this many candidates of an image
+_seg_memo = {}          # same key -> largest NMS segment (an image's class) of the previous call: chooses the NMS kernel (the one-
+_SEG_SMALL = 384        # workgroup-per-segment kernel of csrc/nms_small.h takes segments up to this size; 0 = unknown: the persistent one)
 
 
 def _label_rows(labels, bs, nc, device):
@@ -137,6 +139,9 @@ def non_max_suppression_obb(prediction, conf_thres=0.25, iou_thres=0.45, classes
             # run once more on the multi-workgroup sort, which the memo then selects directly -- the first call of a shape is the fast
             # path, not the slow one (round 3 started from hint 0 = the generic sort)
             hint = int(_cand_memo.get(key, _SORT_LDS_HINT))
+            # the same for the NMS kernel: assume the small segments of that regime (a few hundred boxes per image and class);
+            # a call that meets a larger one reports it (status[0] = -1) and is repeated on the persistent kernel
+            seg_hint = int(_seg_memo.get(key, 1))
             if meta_np is not None:
                 meta_np.fill(_PENDING)
             with _lib.guard(dev):
@@ -149,7 +154,7 @@ def non_max_suppression_obb(prediction, conf_thres=0.25, iou_thres=0.45, classes
                 rc = L.obb_non_max_suppression_obb_col(
                     _lib.ptr(pred), _lib.ptr(col), dtype, bs, A, no, float(conf_thres), float(iou_thres),
                     C.cast(cls_arr, C.c_void_p) if cls_arr is not None else C.c_void_p(0), n_cls, agn, int(multi),
-                    max_det, _MAX_NMS, float(_MAX_WH), _lib.ptr(extra), n_extra, cap, hint, _lib.ptr(out), 1, _lib.ptr(meta),
+                    max_det, _MAX_NMS, float(_MAX_WH), _lib.ptr(extra), n_extra, cap, hint | (seg_hint << 32), _lib.ptr(out), 1, _lib.ptr(meta),
                     C.c_void_p(meta.data_ptr() + 8 * bs), _lib.ptr(ws), ws.numel(), C.c_void_p(st))
             _lib.check(rc, "obb_non_max_suppression_obb")
             if meta_np is not None:                                   # every entry is one aligned 8-byte store of the last kernel
@@ -164,6 +169,10 @@ def non_max_suppression_obb(prediction, conf_thres=0.25, iou_thres=0.45, classes
                 m = meta_np.tolist()
             else:
                 m = meta.tolist()                                     # the single device->host sync of the call
+            seg_max, m[bs + 1] = m[bs + 1] >> 32, m[bs + 1] & 0xffffffff       # status[1]: largest segment | largest candidate count
+            if m[bs] == -1:                                           # a segment above the small kernel's limit: nothing is valid
+                _seg_memo[key] = max(int(seg_max), _SEG_SMALL + 1)
+                continue
             if min(m[:bs]) < 0:                                       # a team barrier of the NMS kernel timed out
                 if capped:
                     _lib.checked_count(min(m[:bs]), "obb_non_max_suppression_obb")
@@ -182,5 +191,6 @@ def non_max_suppression_obb(prediction, conf_thres=0.25, iou_thres=0.45, classes
             L.obb_nms_set_max_grid(0)
     _cap_memo[key] = cap
     _cand_memo[key] = int(m[bs + 1])
+    _seg_memo[key] = int(seg_max)                                     # (0: the sort path of this call does not report it)
     counts = m[:bs]
     return list(out.narrow(0, 0, sum(counts)).split_with_sizes(counts))     # one call instead of bs slicing ops
