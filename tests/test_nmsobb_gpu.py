@@ -203,3 +203,80 @@ def test_tta_tensor_of_bench_py(dev, oracle_lib):
     general._cand_memo.clear()
     for rep in range(3):                                   # un-hinted, then hinted with the large count
         _cmp(general.non_max_suppression_obb(p, **kw), ref, ties=True)
+
+
+def _set_class(pred, b, rows, c, nc, conf=0.97):
+    """rows of image b become confident members of class c only."""
+    pred[b, rows, 4] = conf
+    pred[b, rows, 5:5 + nc] = 0.01
+    pred[b, rows, 5 + c] = 0.99
+
+
+def test_small_segment_kernel_and_its_limits(dev, oracle_lib):
+    """csrc/nms_small.h (one workgroup per class segment, chosen from the previous call's largest segment):
+    (1) the regime it is made for, repeated calls;  (2) a DENSE segment near its size limit -- 330 near-duplicates of one object in
+    one class: every pair passes the circle test, the rings overflow into full drains and the pooled leftovers take several
+    passes -- at three thresholds;  (3) a segment ABOVE the limit: the call reports it, the host layer repeats it on the
+    persistent kernel and remembers; a following small batch goes back to the small kernel;  (4) max_det below the kept count."""
+    from yolov5_obb_amd.utils import general
+    nc, A = 15, 20000
+    key = (A, nc, True)
+    base = synth.s_pred(3, A, nc, seed=51, n_obj=60, fg_frac=0.03)
+    kw = dict(conf_thres=0.25, iou_thres=0.45, multi_label=True, max_det=1500)
+    # (1)
+    general._seg_memo.clear(); general._cand_memo.clear()
+    ref = pyref.non_max_suppression_obb(base.clone(), **kw)
+    for rep in range(3):
+        _cmp(general.non_max_suppression_obb(base.to(dev), **kw), ref)
+    assert 0 < general._seg_memo[key] <= general._SEG_SMALL                  # the small kernel ran and reported its largest segment
+    # (2) 330 jittered copies of one box, all class 3, image 1 (+ the ~40 candidates the class has anyway: below the limit of 384)
+    dense = base.clone()
+    g = torch.Generator().manual_seed(9)
+    rows = torch.arange(100, 430)
+    dense[1, rows, 0:2] = torch.tensor([400.0, 300.0]) + torch.randn(330, 2, generator=g) * 4
+    dense[1, rows, 2:4] = torch.tensor([90.0, 30.0]) * (1 + 0.08 * torch.randn(330, 2, generator=g))
+    _set_class(dense, 1, rows, 3, nc)
+    dense[1, rows, 4] = 0.5 + 0.45 * torch.rand(330, generator=g)            # distinct scores
+    dense[1, rows, 5 + nc:] = 0.02
+    dense[1, rows, 5 + nc + 40] = 0.9                                        # one angle bin for all
+    for thr in (0.1, 0.45, 0.8):
+        kw2 = dict(kw, iou_thres=thr)
+        ref = pyref.non_max_suppression_obb(dense.clone(), **kw2)
+        general._seg_memo[key] = 1
+        _cmp(general.non_max_suppression_obb(dense.to(dev), **kw2), ref)
+        assert 300 < general._seg_memo[key] <= general._SEG_SMALL            # still the small kernel
+    # (3) 500 confident boxes of one class in image 2: above the limit
+    big = base.clone()
+    rows = torch.arange(1000, 1500)
+    _set_class(big, 2, rows, 7, nc)
+    ref = pyref.non_max_suppression_obb(big.clone(), **kw)
+    general._seg_memo[key] = 1                                               # the optimistic assumption of a first call
+    _cmp(general.non_max_suppression_obb(big.to(dev), **kw), ref)            # repeated on the persistent kernel behind the scenes
+    assert general._seg_memo[key] > general._SEG_SMALL
+    _cmp(general.non_max_suppression_obb(big.to(dev), **kw), ref)            # persistent kernel directly
+    ref = pyref.non_max_suppression_obb(base.clone(), **kw)
+    _cmp(general.non_max_suppression_obb(base.to(dev), **kw), ref)           # persistent kernel (hint still large) ...
+    assert general._seg_memo[key] <= general._SEG_SMALL
+    _cmp(general.non_max_suppression_obb(base.to(dev), **kw), ref)           # ... and back on the small one
+    # (4)
+    for md in (5, 37):
+        kw4 = dict(kw, max_det=md)
+        _cmp(general.non_max_suppression_obb(base.to(dev), **kw4), pyref.non_max_suppression_obb(base.clone(), **kw4))
+
+
+def test_sort_prep_class_buckets_and_the_network_fallback(dev, oracle_lib):
+    """The in-LDS sort kernel orders class buckets by rank counting on four workgroups per image; a bucket above 512 candidates
+    (a dominant class) sends the image to the 16-wave network in one workgroup.  Both inside one batch, fp16 ties included."""
+    from yolov5_obb_amd.utils import general
+    nc, A = 16, 30000
+    pred = synth.s_pred(4, A, nc, seed=61, n_obj=70, fg_frac=0.04)
+    rows = torch.arange(2000, 2700)
+    _set_class(pred, 2, rows, 5, nc, conf=0.9)                               # image 2: 700 candidates of class 5
+    pred[3, :, 4] = 0.0                                                      # image 3: empty
+    for half in (False, True):
+        p = pred.to(torch.float16) if half else pred
+        kw = dict(conf_thres=0.25, iou_thres=0.45, multi_label=True, max_det=1500)
+        ref = pyref.non_max_suppression_obb(p.clone(), **kw)
+        general._seg_memo.clear(); general._cand_memo.clear()
+        for rep in range(3):
+            _cmp(general.non_max_suppression_obb(p.to(dev), **kw), ref, ties=half)
