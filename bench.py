@@ -832,11 +832,11 @@ def main():
             "hbm_copy": hbm_copy,
             "val_buckets": val_obj,
             "kernels": {
-                "obb::k_nms_persist<obb::RotGeom> (bs16 step)": {
+                "obb::k_nms_small<obb::RotGeom> (bs16 step)": {
                     "bound": "hbm", "achieved": round(nms_ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(nms_ach / HBM_PEAK_GBS, 5), "traffic": pmc.get("k_nms_persist_bs16"), "algorithmic_bytes": nms_alg,
                     "avg_kernel_ms": round(nms_ms_step, 5), "candidates_per_image": [int(c) for c in cand],
-                    "note": "largest share of the step; latency / VALU bound at ~1.7k candidates per image, not HBM bound"},
+                    "note": "largest share of the step; one workgroup per (image, class) segment of ~100 boxes held in LDS (csrc/nms_small.h; round 3: the persistent kernel, 0.073 ms): VALU bound by the decision stages, not HBM bound"},
                 "obb::k_decode<__half>": {
                     "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "avg_kernel_ms": round(dec_ms, 5), "avg_kernel_ms_one_tensor_warm": round(dec_ms_warm, 5),
