@@ -294,9 +294,9 @@ def main():
         torch.cuda.synchronize()
 
     out = None
-    # device spin-up, outside the W warmup steps: the first ~50 ms of calls after an idle period run 20-25 % slower than the
-    # steady state (measured in round 4: the FIRST timed loop of 200 steps took 0.248 ms per step whatever events it carried,
-    # the second and third loops 0.220 / 0.195), so the clocks get ~0.4 s of the same calls before anything is counted
+    # device spin-up, outside the W warmup steps: ~0.4 s of the same calls before anything is counted.  (Round 4 saw the FIRST
+    # timed loop run 9-30 us per step slower than the later ones and first blamed the clocks; the cause was the library creating
+    # its HIP events lazily inside that loop -- obb_profile_enable creates them up front now.  The spin-up stays: it is cheap.)
     t_spin = time.perf_counter()
     i = 0
     while time.perf_counter() - t_spin < 0.4:

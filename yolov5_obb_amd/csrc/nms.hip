@@ -898,6 +898,16 @@ int obb_non_max_suppression_obb_col(const void* pred, const void* objcol, int dt
 int obb_profile_enable(int on) {
   g_prof.on = on == 2 ? 2 : (on != 0 ? 1 : 0);
   g_prof.used = 0;
+  // the events exist before the first call that records one: creating them lazily put 2 x hipEventCreate per stage into the
+  // caller's timed loop (bench.py's first loop ran 9-30 us per step slower than its later ones, depending on the host)
+  if (g_prof.on) {
+    const int want = 2048 < ProfState::kMax ? 2048 : ProfState::kMax;
+    while (g_prof.created < want) {
+      if (hipEventCreate(&g_prof.ev0[g_prof.created]) != hipSuccess) return OBB_ERR_INTERNAL;
+      if (hipEventCreate(&g_prof.ev1[g_prof.created]) != hipSuccess) { hipEventDestroy(g_prof.ev0[g_prof.created]); return OBB_ERR_INTERNAL; }
+      g_prof.created++;
+    }
+  }
   return OBB_OK;
 }
 
