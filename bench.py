@@ -127,8 +127,8 @@ def bench_next_rows(dev, dets_per_image):
     res["val_tail"] = {"workload": f"{len(dets_per_image)} images x ~{int(dets_per_image[0].shape[0])} detections: val_postprocess + process_batch",
                        "ms_per_batch": round(ms_batch, 3), "ms_per_image": round(ms_batch / len(dets_per_image), 4),
                        "ms_per_batch_per_image_calls": round(ms, 3),
-                       "note": "ms_per_batch: val.val_tail_batch (three launches + one device->host copy for the batch, incl. that copy and "
-                               "its sync); ms_per_batch_per_image_calls: round 3's loop of val_postprocess + process_batch per image",
+                       "note": "ms_per_batch: val.val_tail_batch (three launches, the statistics written straight into polled pinned host memory); "
+                               "ms_per_batch_per_image_calls: round 3's loop of val_postprocess + process_batch per image",
                        "cpu_port_ms_per_image": round(cms, 3)}
     # ---- ResultMerge: one class file of 300 source images (tiles 1024/824, two rates)
     lines = gg.merge_input_lines(300, 40, 7, False)

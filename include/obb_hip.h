@@ -334,6 +334,12 @@ size_t obb_val_tail_batch_workspace_bytes(int64_t n_det, int64_t nt);
 int obb_val_tail_batch_f32(const float* det7, const int64_t* det_off_host, int64_t bs, const float* targets, int64_t nt, int64_t tcols,
                            const float* img5_host, const float* iouv, int niou, float* poly10, float* hbb6, float* polyn10,
                            float* hbbn6, float* stats, void* ws, size_t ws_bytes, void* stream);
+/* The same, for a caller that does not want to copy `stats` back and wait for the stream: `stats` and `done` point into PINNED
+ * HOST memory (hipHostMalloc: the device writes through the same pointers); `done` receives n (the number of detections) once
+ * every row of `stats` is visible to the host -- the caller sets it to a negative value before the call and polls it. */
+int obb_val_tail_batch_polled_f32(const float* det7, const int64_t* det_off_host, int64_t bs, const float* targets, int64_t nt,
+                                  int64_t tcols, const float* img5_host, const float* iouv, int niou, float* poly10, float* hbb6,
+                                  float* polyn10, float* hbbn6, float* stats, void* ws, size_t ws_bytes, void* stream, int64_t* done);
 
 /* process_batch (val.py:69-90): detections (n,6) [x1 y1 x2 y2 conf cls], labels (m,5) [cls x1 y1 x2 y2], iouv (niou) on the
  * device -> correct (n, niou) bytes (0/1).  No device->host round trip (the reference sorts the matches with numpy). */

@@ -523,7 +523,8 @@ __global__ void k_vt_labels(const float* __restrict__ targets, int nt, int tcols
 __global__ void k_vt_dets(const float* __restrict__ det7, int n, ValTailImgs im, const float* __restrict__ targets, int nt, int tcols,
                           const float* __restrict__ lab4, const float* __restrict__ iouv, float* __restrict__ poly10,
                           float* __restrict__ hbb6, float* __restrict__ polyn10, float* __restrict__ hbbn6,
-                          int* __restrict__ best_label, float* __restrict__ best_iou, int* __restrict__ winner) {
+                          int* __restrict__ best_label, float* __restrict__ best_iou, int* __restrict__ winner, int* __restrict__ counter) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) *counter = 0;       // k_vt_stats' arrival counter (that kernel runs behind this one)
   const int d = blockIdx.x * blockDim.x + threadIdx.x;
   if (d >= n) return;
   int b = 0;
@@ -549,15 +550,26 @@ __global__ void k_vt_dets(const float* __restrict__ det7, int n, ValTailImgs im,
   if (bl >= 0) atomicMin(&winner[bl], d);       // (detection indices grow with the image and inside it: the lowest index of the image wins)
 }
 // stats row of detection d: correct[0 .. niou) as 0 / 1, then conf, then cls (val.py:250's tuple, one copy for the batch)
+// `done` (optional, pinned host memory like `stats` may be): receives n once EVERY row has landed -- each workgroup makes its
+// rows visible system-wide (fence), then arrives on a device counter; the last one stores the flag.  The host polls it instead of
+// copying the rows back and waiting for the stream.
 __global__ void k_vt_stats(const float* __restrict__ det7, const int* __restrict__ best_label, const float* __restrict__ best_iou,
-                           const int* __restrict__ winner, const float* __restrict__ iouv, int n, int niou, float* __restrict__ stats) {
+                           const int* __restrict__ winner, const float* __restrict__ iouv, int n, int niou, float* __restrict__ stats,
+                           int* __restrict__ counter, long long* __restrict__ done) {
   const int d = blockIdx.x * blockDim.x + threadIdx.x;
-  if (d >= n) return;
-  const int bl = best_label[d];
-  const bool win = bl >= 0 && winner[bl] == d;
-  float* o = stats + (size_t)d * (niou + 2);
-  for (int k = 0; k < niou; k++) o[k] = (win && best_iou[d] >= iouv[k]) ? 1.f : 0.f;
-  o[niou] = det7[(size_t)d * 7 + 5]; o[niou + 1] = det7[(size_t)d * 7 + 6];
+  if (d < n) {
+    const int bl = best_label[d];
+    const bool win = bl >= 0 && winner[bl] == d;
+    float* o = stats + (size_t)d * (niou + 2);
+    for (int k = 0; k < niou; k++) o[k] = (win && best_iou[d] >= iouv[k]) ? 1.f : 0.f;
+    o[niou] = det7[(size_t)d * 7 + 5]; o[niou + 1] = det7[(size_t)d * 7 + 6];
+  }
+  if (done != nullptr) {                                          // (kernel-uniform)
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0 && atomicAdd(counter, 1) == (int)gridDim.x - 1)
+      __hip_atomic_store(done, (long long)n, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
 }
 
 }  // namespace obb
@@ -577,9 +589,9 @@ size_t obb_val_tail_batch_workspace_bytes(int64_t n_det, int64_t nt) {
   return (size_t)(n_det > 0 ? n_det : 1) * 8 + (size_t)(nt > 0 ? nt : 1) * 20 + 512;
 }
 
-int obb_val_tail_batch_f32(const float* det7, const int64_t* det_off_host, int64_t bs, const float* targets, int64_t nt, int64_t tcols,
-                           const float* img5_host, const float* iouv, int niou, float* poly10, float* hbb6, float* polyn10,
-                           float* hbbn6, float* stats, void* ws, size_t ws_bytes, void* stream) {
+static int val_tail_batch_impl(const float* det7, const int64_t* det_off_host, int64_t bs, const float* targets, int64_t nt, int64_t tcols,
+                               const float* img5_host, const float* iouv, int niou, float* poly10, float* hbb6, float* polyn10,
+                               float* hbbn6, float* stats, void* ws, size_t ws_bytes, void* stream, int64_t* done) {
   if (bs < 1 || bs > obb::kValTailMaxBs || nt < 0 || niou < 1 || !det_off_host || !img5_host || !iouv) return OBB_ERR_BAD_ARG;
   if (nt > 0 && (!targets || tcols < 7)) return OBB_ERR_BAD_ARG;
   const int64_t n = det_off_host[bs];
@@ -595,7 +607,7 @@ int obb_val_tail_batch_f32(const float* det7, const int64_t* det_off_host, int64
     if (!(q[2] > 0.f)) return OBB_ERR_BAD_ARG;
     im.pad_x[b] = q[0]; im.pad_y[b] = q[1]; im.gain[b] = q[2]; im.shape_w[b] = q[3]; im.shape_h[b] = q[4];
   }
-  if (n == 0) return OBB_OK;
+  if (n == 0) { if (done) *done = 0; return OBB_OK; }            // (host-visible memory: nothing to wait for)
   if (!det7 || !stats) return OBB_ERR_BAD_ARG;
   if (!ws || ws_bytes < obb_val_tail_batch_workspace_bytes(n, nt)) return OBB_ERR_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
@@ -603,11 +615,28 @@ int obb_val_tail_batch_f32(const float* det7, const int64_t* det_off_host, int64
   float* best_iou = (float*)(best_label + n);
   float* lab4 = (float*)(((uintptr_t)(best_iou + n) + 255) & ~(uintptr_t)255);
   int* winner = (int*)(lab4 + (size_t)(nt > 0 ? nt : 1) * 4);
+  int* counter = (int*)(((uintptr_t)(winner + (nt > 0 ? nt : 1)) + 63) & ~(uintptr_t)63);   // (inside the 512 spare bytes)
   if (nt > 0) obb::k_vt_labels<<<(unsigned)((nt + 255) / 256), 256, 0, st>>>(targets, (int)nt, (int)tcols, im, lab4, winner);
   obb::k_vt_dets<<<(unsigned)((n + 127) / 128), 128, 0, st>>>(det7, (int)n, im, targets, (int)nt, (int)tcols, lab4, iouv, poly10, hbb6, polyn10, hbbn6,
-                                                            best_label, best_iou, winner);
-  obb::k_vt_stats<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(det7, best_label, best_iou, winner, iouv, (int)n, niou, stats);
+                                                            best_label, best_iou, winner, counter);
+  obb::k_vt_stats<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(det7, best_label, best_iou, winner, iouv, (int)n, niou, stats, counter,
+                                                              reinterpret_cast<long long*>(done));
   return hipGetLastError() == hipSuccess ? OBB_OK : OBB_ERR_LAUNCH;
+}
+
+int obb_val_tail_batch_f32(const float* det7, const int64_t* det_off_host, int64_t bs, const float* targets, int64_t nt, int64_t tcols,
+                           const float* img5_host, const float* iouv, int niou, float* poly10, float* hbb6, float* polyn10,
+                           float* hbbn6, float* stats, void* ws, size_t ws_bytes, void* stream) {
+  return val_tail_batch_impl(det7, det_off_host, bs, targets, nt, tcols, img5_host, iouv, niou, poly10, hbb6, polyn10, hbbn6, stats, ws,
+                             ws_bytes, stream, nullptr);
+}
+
+int obb_val_tail_batch_polled_f32(const float* det7, const int64_t* det_off_host, int64_t bs, const float* targets, int64_t nt,
+                                  int64_t tcols, const float* img5_host, const float* iouv, int niou, float* poly10, float* hbb6,
+                                  float* polyn10, float* hbbn6, float* stats, void* ws, size_t ws_bytes, void* stream, int64_t* done) {
+  if (!done) return OBB_ERR_BAD_ARG;
+  return val_tail_batch_impl(det7, det_off_host, bs, targets, nt, tcols, img5_host, iouv, niou, poly10, hbb6, polyn10, hbbn6, stats, ws,
+                             ws_bytes, stream, done);
 }
 
 size_t obb_process_batch_workspace_bytes(int64_t n, int64_t m) { return (size_t)(n > 0 ? n : 1) * 8 + (size_t)(m > 0 ? m : 1) * 4 + 256; }

@@ -62,6 +62,7 @@ def process_batch(detections, labels, iouv):
 
 _TAIL_MAX_BS = 64      # csrc/head.hip kValTailMaxBs: images per obb_val_tail_batch_f32 call
 _pin_cache = {}
+_arr_cache = {}
 
 
 def _pinned_rows(n, cols):
@@ -75,8 +76,17 @@ def _pinned_rows(n, cols):
     return buf[:n]
 
 
+def _as_f32_cuda(t, dev):
+    """t as a contiguous float32 tensor on dev -- without a torch call when it already is one (the common case)."""
+    if t.dtype == torch.float32 and t.device == dev and t.is_contiguous():
+        return t
+    return t.to(device=dev, dtype=torch.float32).contiguous()
+
+
 def val_tail_batch(preds, targets, shapes, iouv, want_boxes=False):
-    """The tail of val.py:209-250 for ALL images of a batch: three launches and ONE device -> host copy.
+    """The tail of val.py:209-250 for ALL images of a batch: three launches, and the statistics land in pinned host memory
+    that this thread polls (no copy kernel, no blocked stream wait; the host side of this function is most of its time, so it
+    avoids every torch call it can).
 
     preds    list of (n_i, 7) CUDA tensors [x y l s theta conf cls], the output of non_max_suppression_obb (consecutive views
              of its packed buffer are used in place; anything else is concatenated)
@@ -88,74 +98,91 @@ def val_tail_batch(preds, targets, shapes, iouv, want_boxes=False):
     bs = len(preds)
     if bs == 0:
         return ([], None) if want_boxes else []
-    for p in preds:
-        _lib.require_cuda(p, "pred")
     dev = preds[0].device
-    counts = [int(p.shape[0]) for p in preds]
-    n = sum(counts)
-    niou = int(iouv.shape[0])
-    packed = None
-    nz = [p for p in preds if p.shape[0]]
-    if nz and all(p.dtype == torch.float32 and p.is_contiguous() and p.shape[1] == 7 for p in nz):
-        base = nz[0].data_ptr()
-        ok = True
-        for p in nz:
-            ok = ok and p.data_ptr() == base
-            base += p.numel() * 4
-        if ok:                                                   # the split views of one packed buffer, in order
-            packed = torch.as_strided(nz[0], (n, 7), (7, 1))
-    if packed is None:
-        packed = torch.cat([p.to(torch.float32) for p in preds], 0).contiguous() if n else torch.zeros((0, 7), device=dev)
-    tg = targets.to(device=dev, dtype=torch.float32).contiguous()
-    nt, tcols = (int(tg.shape[0]), int(tg.shape[1])) if tg.dim() == 2 else (0, 0)
-    iv = iouv.to(device=dev, dtype=torch.float32).contiguous()
-    stats = torch.empty((n, niou + 2), dtype=torch.float32, device=dev)
+    if dev.type != "cuda":
+        _lib.require_cuda(preds[0], "pred")
+    counts = [p.shape[0] for p in preds]
+    offs = [0] * (bs + 1)
+    for b in range(bs):
+        offs[b + 1] = offs[b] + counts[b]
+    n = offs[bs]
+    niou = iouv.shape[0]
+    # the detections as ONE (n, 7) array: the split views of non_max_suppression_obb's packed buffer in order, else a copy
+    packed, first = None, None
+    ok = True
+    for p in preds:
+        if p.shape[0] == 0:
+            continue
+        if p.device != dev or p.dtype != torch.float32 or p.dim() != 2 or p.shape[1] != 7 or not p.is_contiguous():
+            if p.device.type != "cuda":
+                _lib.require_cuda(p, "pred")
+            ok = False
+            break
+        if first is None:
+            first, nxt = p, p.data_ptr()
+        if p.data_ptr() != nxt:
+            ok = False
+            break
+        nxt += p.shape[0] * 28
+    if n:
+        if ok and first is not None:
+            packed = first if first.shape[0] == n else torch.as_strided(first, (n, 7), (7, 1))
+        else:
+            packed = torch.cat([p.to(torch.float32) for p in preds], 0).contiguous()
+    tg = _as_f32_cuda(targets, dev) if targets.dim() == 2 and targets.shape[0] else None
+    nt, tcols = (tg.shape[0], tg.shape[1]) if tg is not None else (0, 0)
+    iv = _as_f32_cuda(iouv, dev)
+    host = _pinned_rows(n, niou + 2)                             # the kernels write the rows straight into it
     boxes = None
     if want_boxes:
         boxes = (torch.empty((n, 10), dtype=torch.float32, device=dev), torch.empty((n, 6), dtype=torch.float32, device=dev),
                  torch.empty((n, 10), dtype=torch.float32, device=dev), torch.empty((n, 6), dtype=torch.float32, device=dev))
-    L = _lib.lib()
-    offs = [0]
-    for c in counts:
-        offs.append(offs[-1] + c)
     if n:
+        L = _lib.lib()
+        null = C.c_void_p(0)
         with _lib.guard(dev):
-            ws = _lib.workspace(L.obb_val_tail_batch_workspace_bytes(n, nt), dev)
+            st = _lib.stream_handle(dev)
+            ws = _lib.workspace(L.obb_val_tail_batch_workspace_bytes(n, nt), dev, st)
+            flag, flag_np = _lib.pinned_count(dev)
             for b0 in range(0, bs, _TAIL_MAX_BS):                # (one call for any batch size val.py uses)
                 b1 = min(bs, b0 + _TAIL_MAX_BS)
                 k = b1 - b0
-                doff = (C.c_int64 * (k + 1))(*[o - offs[b0] for o in offs[b0:b1 + 1]])
-                img5 = (C.c_float * (5 * k))()
-                for j in range(k):
-                    shape, ratio_pad = shapes[b0 + j][0], shapes[b0 + j][1]
-                    img5[5 * j + 0], img5[5 * j + 1] = float(ratio_pad[1][0]), float(ratio_pad[1][1])
-                    img5[5 * j + 2] = float(ratio_pad[0][0])
-                    img5[5 * j + 3], img5[5 * j + 4] = float(shape[1]), float(shape[0])
-                tgk = tg
-                if b0 or b1 < bs:                                # a chunk of a very large batch: its labels, re-based
+                arrs = _arr_cache.get(k)
+                if arrs is None:
+                    arrs = _arr_cache[k] = ((C.c_int64 * (k + 1))(), (C.c_float * (5 * k))())
+                doff, img5 = arrs
+                base = offs[b0]
+                doff[:] = [o - base for o in offs[b0:b1 + 1]] if base else offs[b0:b1 + 1]
+                flat = []
+                for j in range(b0, b1):
+                    shape, ratio_pad = shapes[j][0], shapes[j][1]
+                    flat += (ratio_pad[1][0], ratio_pad[1][1], ratio_pad[0][0], shape[1], shape[0])
+                img5[:] = flat
+                tgk, ntk = tg, nt
+                if nt and (b0 or b1 < bs):                       # a chunk of a very large batch: its labels, re-based
                     sel = (tg[:, 0] >= b0) & (tg[:, 0] < b1)
                     tgk = tg[sel].clone()
                     tgk[:, 0] -= b0
-                ntk = int(tgk.shape[0]) if tgk.dim() == 2 else 0
-                sl = slice(offs[b0], offs[b1])
+                    ntk = int(tgk.shape[0])
+                lo, hi = offs[b0], offs[b1]
+                if hi == lo:
+                    continue
 
-                def part(t):
-                    return _lib.ptr(t[sl]) if t is not None and offs[b1] > offs[b0] else C.c_void_p(0)
-                rc = L.obb_val_tail_batch_f32(part(packed), C.cast(doff, C.c_void_p), k, _lib.ptr(tgk) if ntk else C.c_void_p(0), ntk,
-                                              tcols, C.cast(img5, C.c_void_p), _lib.ptr(iv), niou,
-                                              part(boxes[0]) if boxes else C.c_void_p(0), part(boxes[1]) if boxes else C.c_void_p(0),
-                                              part(boxes[2]) if boxes else C.c_void_p(0), part(boxes[3]) if boxes else C.c_void_p(0),
-                                              part(stats), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev))
+                def part(t, cols):
+                    return C.c_void_p(t.data_ptr() + lo * cols * 4)
+                if b1 < bs or b0:                                # not the last chunk of several: the rows are waited for at the end
+                    flag_np[0] = _lib._PENDING
+                rc = L.obb_val_tail_batch_polled_f32(
+                    part(packed, 7), C.cast(doff, C.c_void_p), k, C.c_void_p(tgk.data_ptr()) if ntk else null, ntk, tcols,
+                    C.cast(img5, C.c_void_p), C.c_void_p(iv.data_ptr()), niou,
+                    part(boxes[0], 10) if boxes else null, part(boxes[1], 6) if boxes else null,
+                    part(boxes[2], 10) if boxes else null, part(boxes[3], 6) if boxes else null,
+                    part(host, niou + 2), C.c_void_p(ws.data_ptr()), ws.numel(), C.c_void_p(st), C.c_void_p(flag.data_ptr()))
                 _lib.check(rc, "obb_val_tail_batch_f32")
-    # the one copy (and sync) of the batch: into a cached pinned buffer, then three splits (a per-image slicing loop of small
-    # host tensor ops cost more than the three launches)
-    host = _pinned_rows(n, niou + 2)
-    if n:
-        host.copy_(stats, non_blocking=True)
-        torch.cuda.current_stream(dev).synchronize()
+                _lib.wait_count(flag_np, dev)                    # every row of this chunk is in `host`
     host = host.clone()                                          # (the pinned buffer is reused by the next batch)
     correct = (host[:, :niou] > 0.5).split(counts)
-    conf = host[:, niou].contiguous().split(counts)
-    pcls = host[:, niou + 1].contiguous().split(counts)
+    conf = host[:, niou].split(counts)
+    pcls = host[:, niou + 1].split(counts)
     out = list(zip(correct, conf, pcls))
     return (out, (boxes, offs)) if want_boxes else out
