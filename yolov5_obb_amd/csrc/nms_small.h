@@ -288,6 +288,12 @@ __global__ __launch_bounds__(kSmallThreads) void k_nms_small(SmallArgs a) {
 #undef SSTAMP
 }
 
+// (the whole segment state of one workgroup must fit the CU's 160 KB: records + bit matrix + alive words + eight wave blocks,
+//  + the kernel's few static words)
+static_assert((size_t)kSmallMax * RotGeom::RECQ * 16 + (size_t)kSmallMax * kSmallWords * 8 + 64 + sizeof(SmallWave<RotGeom>) * kSmallWaves +
+              kSmallMax * 4 + 256 <= 160 * 1024, "k_nms_small: LDS budget");
+static_assert(kSmallMax % 64 == 0 && kSmallMax <= 65535, "k_nms_small: pair entries are (i << 16 | j)");
+
 template <class G>
 static size_t small_lds_bytes() {
   return (size_t)kSmallMax * G::RECQ * 16 + (size_t)kSmallMax * kSmallWords * 8 + 8 * 8 + sizeof(SmallWave<G>) * kSmallWaves;
