@@ -70,7 +70,7 @@ int obb_profile_collect(double* ms_sum_host, int64_t* count_host, int n_stages);
 /* ------------------------------------------------------------------ NMS ------------------------------ */
 
 /* Scratch bytes for n boxes in nseg segments.  kind: 0 = rotated boxes, 1 = quads, 2 = double-precision quads (merge NMS),
- * 3 = double-precision rotated boxes (obb_nms_rotated_f64). */
+ * 3 = double-precision rotated boxes (obb_nms_rotated_f64), 4 = obb_merge_nms_poly_all_f64, 5 = obb_merge_nms_hbb_f64. */
 size_t obb_nms_workspace_bytes(int64_t n, int64_t nseg, int kind);
 
 /*
@@ -126,6 +126,20 @@ int obb_nms_poly_f32(const float* polys, int64_t row_stride, int64_t n, float io
  */
 int obb_merge_nms_poly_f64(const double* dets9, int64_t n, const int32_t* order, const int32_t* seg_off, int64_t nseg,
                            double thresh, int64_t* keep_out, int64_t* num_keep, void* ws, size_t ws_bytes, void* stream);
+
+/*
+ * The other two merge variants of the same file, same conventions (order / seg_off / keep_out / num_keep as above):
+ *   obb_merge_nms_poly_all_f64   py_cpu_nms_poly (ResultMerge_multi_process.py:24-60): no horizontal-box gate -- iou_poly of the
+ *                                kept box and EVERY remaining candidate.  Workspace: obb_nms_workspace_bytes(n, nseg, 4).
+ *   obb_merge_nms_hbb_f64        py_cpu_nms (:125-157; what mergebyrec hands to mergebase): horizontal boxes [x1 y1 x2 y2] in
+ *                                columns 0..3 of rows of row_stride doubles, "+ 1" in areas and intersections, numpy double
+ *                                arithmetic incl. its NaN rules (np.maximum hands a NaN through; 0 / 0 removes the box).
+ *                                Workspace: obb_nms_workspace_bytes(n, nseg, 5).
+ */
+int obb_merge_nms_poly_all_f64(const double* dets9, int64_t n, const int32_t* order, const int32_t* seg_off, int64_t nseg,
+                               double thresh, int64_t* keep_out, int64_t* num_keep, void* ws, size_t ws_bytes, void* stream);
+int obb_merge_nms_hbb_f64(const double* dets, int64_t row_stride, int64_t n, const int32_t* order, const int32_t* seg_off,
+                          int64_t nseg, double thresh, int64_t* keep_out, int64_t* num_keep, void* ws, size_t ws_bytes, void* stream);
 
 /*
  * DOTA Task-1 evaluation: the detection x ground-truth part of voc_eval (DOTA_devkit/dota_evaluation_task1.py:168-223)

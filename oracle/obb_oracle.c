@@ -195,10 +195,12 @@ void oracle_piou_matrix_f64(const double *a8, int64_t n, const double *b8, int64
 }
 
 /* rbox [cx,cy,w,h,theta] -> quad, as DOTA_devkit/poly_nms_gpu/poly_overlaps_kernel.cu:280-297:
- * float cos/sin, corner arithmetic in double (the "/ 2.0" literals), one rounding to float. */
+ * float cos/sin, corner arithmetic in double (the "/ 2.0" literals), one rounding to float.
+ * The reference's cos(float) is CUDA's device cosf (<= 2 ulp, not correctly rounded, not reproducible elsewhere); the
+ * restatement takes the correctly rounded float (double cos / sin rounded once), as the product's kernel does. */
 void oracle_rbox2quad_devkit(const float *b, float *q8)
 {
-    float cs = cosf(b[4]), ss = sinf(b[4]);
+    float cs = (float)cos((double)b[4]), ss = (float)sin((double)b[4]);
     double w = b[2], h = b[3], x = b[0], y = b[1];
     q8[0] = (float)(x + cs * (w / 2.0) - ss * (-h / 2.0));
     q8[2] = (float)(x + cs * (w / 2.0) - ss * (h / 2.0));

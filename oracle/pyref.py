@@ -353,7 +353,46 @@ def merge_nms_poly_fast(dets, thresh):
     return keep
 
 
-def merge_result_lines(lines, thresh=0.2):
+def merge_nms_poly_all(dets, thresh):
+    """DOTA_devkit/ResultMerge_multi_process.py:24-60 (py_cpu_nms_poly): like the fast variant WITHOUT the horizontal-box gate --
+    iou_poly(kept, candidate) for every remaining candidate."""
+    import oracle
+    dets = np.asarray(dets, dtype=np.float64).reshape(-1, 9)
+    order = dets[:, 8].argsort()[::-1]
+    keep = []
+    while order.size > 0:
+        i = order[0]
+        keep.append(int(i))
+        rest = order[1:]
+        if rest.size == 0:
+            break
+        ovr = oracle.piou_matrix(dets[i:i + 1, :8].copy(), dets[rest, :8].copy())[0]
+        order = rest[np.where(ovr <= thresh)[0]]
+    return keep
+
+
+def merge_nms_hbb(dets, thresh):
+    """DOTA_devkit/ResultMerge_multi_process.py:125-157 (py_cpu_nms, what mergebyrec hands to mergebase): horizontal boxes in
+    columns 0..3, the score in column 4, the "+ 1" pixel convention in areas AND intersections, numpy double arithmetic."""
+    dets = np.asarray(dets, dtype=np.float64)
+    x1, y1, x2, y2 = dets[:, 0], dets[:, 1], dets[:, 2], dets[:, 3]
+    areas = (x2 - x1 + 1) * (y2 - y1 + 1)
+    order = dets[:, 4].argsort()[::-1]
+    keep = []
+    while order.size > 0:
+        i = order[0]
+        keep.append(int(i))
+        rest = order[1:]
+        w = np.maximum(0.0, np.minimum(x2[i], x2[rest]) - np.maximum(x1[i], x1[rest]) + 1)
+        h = np.maximum(0.0, np.minimum(y2[i], y2[rest]) - np.maximum(y1[i], y1[rest]) + 1)
+        inter = w * h
+        with np.errstate(invalid='ignore', divide='ignore'):
+            ovr = inter / (areas[i] + areas[rest] - inter)
+        order = rest[np.where(ovr <= thresh)[0]]
+    return keep
+
+
+def merge_result_lines(lines, thresh=0.2, nms=None):
     """mergesingle of ResultMerge_multi_process.py:183-234 on the lines of one Task1_<class>.txt: returns the output lines."""
     import re
     boxes = {}
@@ -373,7 +412,7 @@ def merge_result_lines(lines, thresh=0.2):
         boxes.setdefault(oriname, []).append(det)
     out = []
     for name, dets in boxes.items():
-        for k in merge_nms_poly_fast(np.array(dets), thresh):
+        for k in (nms or merge_nms_poly_fast)(np.array(dets), thresh):
             det = dets[k]
             out.append(name + ' ' + str(round(det[-1], 2)) + ' ' + ' '.join(str(round(v, 1)) for v in det[:8]))
     return out

@@ -79,3 +79,42 @@ def test_many_small_segments_in_one_call(dev, oracle_lib):
     for k, rows in boxes.items():
         ref = [rows[i] for i in pyref.merge_nms_poly_fast(np.array(rows), 0.2)]
         assert got[k] == ref, k
+
+
+@pytest.mark.parametrize("n,extent,seed", [(1, 100, 0), (2, 10, 1), (65, 60, 2), (700, 300, 3), (2500, 400, 4)])
+def test_the_other_merge_variants_vs_oracle(dev, oracle_lib, n, extent, seed):
+    """py_cpu_nms_poly (no horizontal-box gate: every pair through iou_poly) and py_cpu_nms (horizontal boxes, the "+ 1"
+    convention, numpy's NaN rules) -- ResultMerge_multi_process.py:24-60, :125-157.  The oracle restatements were checked against
+    the reference's own two functions in the build container (frozen in tests/golden/merge_variants.npz, tests/test_oracle_golden.py::test_merge_variants_vs_reference_devkit)."""
+    from yolov5_obb_amd.DOTA_devkit.ResultMerge_multi_process import py_cpu_nms, py_cpu_nms_poly
+    d = _dets(n, seed, extent)
+    for thr in (0.0, 0.2, 0.5):
+        assert [int(k) for k in py_cpu_nms_poly(d, thr)] == pyref.merge_nms_poly_all(d, thr), (n, thr)
+        # nine-column rows as mergebyrec passes them: box = the first two vertices, "score" = x3
+        assert [int(k) for k in py_cpu_nms(d, thr)] == pyref.merge_nms_hbb(d, thr), (n, thr)
+    rng = np.random.RandomState(seed + 50)
+    h = np.stack([d[:, 0], d[:, 1], d[:, 0] + rng.rand(n) * 60, d[:, 1] + rng.rand(n) * 40, np.round(rng.rand(n), 2)], 1)
+    h[::7, 2] = h[::7, 0] - 1                              # zero areas: 0 / 0 = NaN against each other -> removed
+    h[3::11, 3] = h[3::11, 1] - 5                          # negative heights: negative areas
+    if n > 20:
+        h[5, 0] = np.nan; h[9, 3] = np.inf
+    for thr in (-0.1, 0.0, 0.3, 1.0):
+        with np.errstate(all='ignore'):
+            ref = pyref.merge_nms_hbb(h, thr)
+        assert [int(k) for k in py_cpu_nms(h, thr)] == ref, (n, thr)
+    assert py_cpu_nms(np.zeros((0, 5)), 0.2) == [] and py_cpu_nms_poly(np.zeros((0, 9)), 0.2) == []
+    with pytest.raises(IndexError):
+        py_cpu_nms(np.zeros((3, 4)), 0.2)
+
+
+def test_mergebyrec_files(dev, oracle_lib, tmp_path):
+    """mergebyrec = mergebase with py_cpu_nms on the nine-column rows of a class file: the output file equals the oracle's chain
+    (same parser / writer as mergesingle, the horizontal-box scan in place of the polygon one)."""
+    from yolov5_obb_amd.DOTA_devkit import ResultMerge_multi_process as RM
+    lines = merge_input_lines(12, 30, 3, True)
+    src, dst = tmp_path / "src", tmp_path / "dst"
+    src.mkdir()
+    (src / "Task1_ship.txt").write_text('\n'.join(lines) + '\n')
+    RM.mergebyrec(str(src), str(dst))
+    want = '\n'.join(pyref.merge_result_lines(lines, nms=pyref.merge_nms_hbb)) + '\n'
+    assert (dst / "Task1_ship.txt").read_text() == want and want.count('\n') > 10

@@ -1,6 +1,7 @@
 """Tile -> full-image merge of DOTA Task-1 result files on the GPU: the interface of the reference's
-DOTA_devkit/ResultMerge_multi_process.py (`py_cpu_nms_poly_fast`, `nmsbynamedict`, `poly2origpoly`, `mergesingle`,
-`mergebase`, `mergebase_parallel`, `mergebypoly`, `nms_thresh`), same on-disk formats in and out.
+DOTA_devkit/ResultMerge_multi_process.py (`py_cpu_nms_poly_fast`, `py_cpu_nms_poly`, `py_cpu_nms`, `nmsbynamedict`,
+`poly2origpoly`, `mergesingle`, `mergebase`, `mergebase_parallel`, `mergebypoly`, `mergebyrec`, `nms_thresh`), same on-disk
+formats in and out.
 
 The reference runs one Python process per class file (`Pool(16)`, :238-244) and, inside each, a Python double loop over
 SWIG `polyiou.iou_poly` calls per source image (:62-123).  Here a class file is ONE device call
@@ -34,11 +35,13 @@ def _device():
     return torch.device("cuda", torch.cuda.current_device())
 
 
-def merge_nms_segments(dets, orders, thresh):
-    """dets (n,9) float64 host array; orders: list of int arrays (row indices in processing order, one per segment).
-    Returns a list of kept row-index arrays (processing order).  One device call for all segments."""
+def merge_nms_segments(dets, orders, thresh, variant="poly_fast"):
+    """dets (n,9) float64 host array ((n, >= 4) for variant "hbb"); orders: list of int arrays (row indices in processing order, one
+    per segment).  Returns a list of kept row-index arrays (processing order).  One device call for all segments.
+    variant: "poly_fast" (py_cpu_nms_poly_fast), "poly_all" (py_cpu_nms_poly: no horizontal-box gate), "hbb" (py_cpu_nms)."""
     dev = _device()
-    dets = np.ascontiguousarray(dets, dtype=np.float64).reshape(-1, 9)
+    dets = np.ascontiguousarray(dets, dtype=np.float64)
+    dets = dets.reshape(-1, 9) if variant != "hbb" else dets.reshape(len(dets), -1)
     nseg = len(orders)
     if nseg == 0:
         return []
@@ -55,10 +58,16 @@ def merge_nms_segments(dets, orders, thresh):
     d_off = torch.from_numpy(off).to(dev)
     keep = torch.empty(n, dtype=torch.int64, device=dev)
     cnt = torch.empty(nseg, dtype=torch.int64, device=dev)
-    ws = _lib.workspace(L.obb_nms_workspace_bytes(n, nseg, 2), dev)
-    _lib.check(L.obb_merge_nms_poly_f64(_lib.ptr(d_dets), dets.shape[0], _lib.ptr(d_order), _lib.ptr(d_off), nseg, float(thresh),
-                                        _lib.ptr(keep), _lib.ptr(cnt), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev)),
-               "obb_merge_nms_poly_f64")
+    if variant == "hbb":
+        ws = _lib.workspace(L.obb_nms_workspace_bytes(n, nseg, 5), dev)
+        rc = L.obb_merge_nms_hbb_f64(_lib.ptr(d_dets), dets.shape[1], dets.shape[0], _lib.ptr(d_order), _lib.ptr(d_off), nseg, float(thresh),
+                                     _lib.ptr(keep), _lib.ptr(cnt), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev))
+    else:
+        fn, kind = (L.obb_merge_nms_poly_all_f64, 4) if variant == "poly_all" else (L.obb_merge_nms_poly_f64, 2)
+        ws = _lib.workspace(L.obb_nms_workspace_bytes(n, nseg, kind), dev)
+        rc = fn(_lib.ptr(d_dets), dets.shape[0], _lib.ptr(d_order), _lib.ptr(d_off), nseg, float(thresh),
+                _lib.ptr(keep), _lib.ptr(cnt), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev))
+    _lib.check(rc, "obb_merge_nms_*_f64")
     cnt_h = cnt.cpu().numpy()
     if (cnt_h < 0).any():
         raise RuntimeError("obb_merge_nms_poly_f64: device-side abort")
@@ -74,6 +83,28 @@ def py_cpu_nms_poly_fast(dets, thresh):
         return []
     order = dets[:, 8].argsort()[::-1]             # :79
     return list(merge_nms_segments(dets, [order], thresh)[0])
+
+
+def py_cpu_nms_poly(dets, thresh):
+    """Signature of ResultMerge_multi_process.py:24 -- the variant without the horizontal-box gate: iou_poly of the kept box
+    and every remaining candidate.  On the GPU like the fast one."""
+    dets = np.asarray(dets, dtype=np.float64).reshape(-1, 9)
+    if len(dets) == 0:
+        return []
+    order = dets[:, 8].argsort()[::-1]             # :35
+    return list(merge_nms_segments(dets, [order], thresh, variant="poly_all")[0])
+
+
+def py_cpu_nms(dets, thresh):
+    """Signature of ResultMerge_multi_process.py:125 ("Pure Python NMS baseline"): horizontal boxes in columns 0..3, the score
+    in column 4 of `dets`, whatever else the rows hold -- mergebyrec passes the nine-column rows of a class file."""
+    dets = np.asarray(dets, dtype=np.float64)
+    if dets.ndim != 2 or dets.shape[1] < 5:
+        raise IndexError("py_cpu_nms: rows [x1 y1 x2 y2 score ...] expected")      # (the reference fails on dets[:, 4])
+    if len(dets) == 0:
+        return []
+    order = dets[:, 4].argsort()[::-1]             # :136
+    return list(merge_nms_segments(dets, [order], thresh, variant="hbb")[0])
 
 
 def nmsbynamedict(nameboxdict, nms, thresh):
@@ -222,6 +253,14 @@ def mergebase_parallel(srcpath, dstpath, nms):
     files = sorted(_files(srcpath))
     for i in shard.shard_indices(len(files)):
         mergesingle(dstpath, nms, files[i])
+
+
+def mergebyrec(srcpath, dstpath):
+    """:251-263: mergebase with py_cpu_nms."""
+    if os.path.exists(dstpath):
+        shutil.rmtree(dstpath)
+    os.makedirs(dstpath)
+    mergebase(srcpath, dstpath, py_cpu_nms)
 
 
 def mergebypoly(srcpath, dstpath):

@@ -37,6 +37,8 @@ SIGNATURES = {
     "obb_nms_rotated_f64": (_i32, [_vp, _vp, _i64, _f32, _i32, _i64, _vp, _vp, _vp, _sz, _vp]),
     "obb_nms_poly_f32": (_i32, [_vp, _i64, _i64, _f32, _i64, _vp, _vp, _vp, _sz, _vp]),
     "obb_merge_nms_poly_f64": (_i32, [_vp, _i64, _vp, _vp, _i64, C.c_double, _vp, _vp, _vp, _sz, _vp]),
+    "obb_merge_nms_poly_all_f64": (_i32, [_vp, _i64, _vp, _vp, _i64, C.c_double, _vp, _vp, _vp, _sz, _vp]),
+    "obb_merge_nms_hbb_f64": (_i32, [_vp, _i64, _i64, _vp, _vp, _i64, C.c_double, _vp, _vp, _vp, _sz, _vp]),
     "obb_task1_parse_tiles": (_i64, [_vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "obb_task1_format_rows": (_i64, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64]),
     "obb_task1_parse_dets": (_i64, [_vp, _i64, _i64, _vp, _vp, _vp, _vp]),

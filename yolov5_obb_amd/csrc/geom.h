@@ -181,16 +181,24 @@ struct QuadGeom64 {
   // scr = this lane's column of the wave's scratch (column index = lane); the double flavour shares the 10 KB block
   // between the two half-waves, one after the other
   static __device__ __forceinline__ bool hit_exact(const float4* ra, const float4* rb, double thr, float* scr) {
+    return hit_exact_t<true>(ra, rb, thr, scr);
+  }
+  // GATE: the horizontal-box gate of py_cpu_nms_poly_fast; without it every pair goes through iou_poly (py_cpu_nms_poly)
+  template <bool GATE>
+  static __device__ __forceinline__ bool hit_exact_t(const float4* ra, const float4* rb, double thr, float* scr) {
     const int lane = threadIdx.x & 63;
     double* base = reinterpret_cast<double*>(scr - lane) + (lane & 31);
     const QuadFeatT<double> A = unpack(ra), B = unpack(rb);
-    double ax1, ay1, ax2, ay2, bx1, by1, bx2, by2;
-    hbb(A, &ax1, &ay1, &ax2, &ay2); hbb(B, &bx1, &by1, &bx2, &by2);
-    // :70,87-96  areas with the +1 convention, intersection without it
-    const double area_a = (ax2 - ax1 + 1) * (ay2 - ay1 + 1), area_b = (bx2 - bx1 + 1) * (by2 - by1 + 1);
-    const double w = fmax(0.0, fmin(ax2, bx2) - fmax(ax1, bx1)), h = fmax(0.0, fmin(ay2, by2) - fmax(ay1, by1));
-    const double hi = w * h;
-    const bool look = hi / (area_a + area_b - hi) > 0;
+    bool look = true;
+    if constexpr (GATE) {
+      double ax1, ay1, ax2, ay2, bx1, by1, bx2, by2;
+      hbb(A, &ax1, &ay1, &ax2, &ay2); hbb(B, &bx1, &by1, &bx2, &by2);
+      // :70,87-96  areas with the +1 convention, intersection without it
+      const double area_a = (ax2 - ax1 + 1) * (ay2 - ay1 + 1), area_b = (bx2 - bx1 + 1) * (by2 - by1 + 1);
+      const double w = fmax(0.0, fmin(ax2, bx2) - fmax(ax1, bx1)), h = fmax(0.0, fmin(ay2, by2) - fmax(ay1, by1));
+      const double hi = w * h;
+      look = hi / (area_a + area_b - hi) > 0;
+    }
     bool hit = false;
     int nhalf = 2;
     asm volatile("" : "+s"(nhalf));   // opaque trip count: the two passes must stay two passes (lanes l and l + 32 share a column)
@@ -201,6 +209,52 @@ struct QuadGeom64 {
       }
     }
     return hit;
+  }
+};
+
+// py_cpu_nms_poly (DOTA_devkit/ResultMerge_multi_process.py:24-60): the merge NMS WITHOUT the horizontal-box gate -- every
+// pair of a kept row and a remaining candidate goes through polyiou.cpp's iou_poly.  Nothing may be skipped: iou_poly of two
+// quads whose horizontal boxes are apart is not 0 by construction (rounding noise, NaN for degenerate quads).
+struct QuadGeom64All : QuadGeom64 {
+  static __device__ __forceinline__ bool cheap_reject(const float4&, const float4&) { return false; }
+  static __device__ __forceinline__ bool hit_exact(const float4* ra, const float4* rb, double thr, float* scr) {
+    return QuadGeom64::hit_exact_t<false>(ra, rb, thr, scr);
+  }
+};
+
+// py_cpu_nms (DOTA_devkit/ResultMerge_multi_process.py:125-157; what mergebyrec hands to mergebase): horizontal boxes
+// [x1 y1 x2 y2] with the "+ 1" pixel convention in areas and intersections, numpy double arithmetic.
+//   q0 = {x1 rounded down, y1 rounded down, x2 + 1 rounded up, y2 + 1 rounded up} in fp32 for the hot loop -- or
+//        {-inf, -inf, +inf, +inf} for a box that must meet every partner: a coordinate that is not finite, an area <= 0
+//        (0 / 0 and negative unions give NaN or a negative ratio: np.where(ovr <= thresh) decides those), or a threshold < 0 /
+//        NaN (then even an overlap of 0 removes a box; the prep kernel knows the threshold);
+//   q1 = {x1, y1}, q2 = {x2, y2} as doubles.
+// A pair the hot loop rejects has x2a + 1 < x1b (or the like) in exact arithmetic, so numpy's w = max(0, xx2 - xx1 + 1) is
+// exactly 0, inter = 0 and, both areas being positive, ovr = 0 <= thresh: never removed.
+struct HbbGeom64 {
+  static constexpr int RECQ = 3;
+  static constexpr int SCR = 40;   // (unused by the clip-free test; the wave blocks double as the resolve phase's LDS: same footprint as QuadGeom64)
+  static constexpr bool HAS_FAST = false;
+  static constexpr bool HAS_GRID = false;
+  static constexpr bool PACKED = false;
+  template <class A> static __device__ __forceinline__ double thr_of(const A& a) { return a.thr64; }
+  static __device__ __forceinline__ bool cheap_reject(const float4& a, const float4& b) {
+    return (a.z < b.x) || (b.z < a.x) || (a.w < b.y) || (b.w < a.y);
+  }
+  static __device__ __forceinline__ int classify_quick(const float4*, const float4*, double, bool) { return 2; }
+  static __device__ __forceinline__ int classify_full(const float4*, const float4*, double) { return 2; }
+  // np.maximum / np.minimum hand a NaN operand through (fmax / fmin would drop it)
+  static __device__ __forceinline__ double npmax(double a, double b) { return (a != a) ? a : ((b != b) ? b : (a > b ? a : b)); }
+  static __device__ __forceinline__ double npmin(double a, double b) { return (a != a) ? a : ((b != b) ? b : (a < b ? a : b)); }
+  static __device__ __forceinline__ bool hit_exact(const float4* ra, const float4* rb, double thr, float*) {
+    const double2 a1 = *reinterpret_cast<const double2*>(ra + 1), a2 = *reinterpret_cast<const double2*>(ra + 2);
+    const double2 b1 = *reinterpret_cast<const double2*>(rb + 1), b2 = *reinterpret_cast<const double2*>(rb + 2);
+    const double area_a = (a2.x - a1.x + 1) * (a2.y - a1.y + 1), area_b = (b2.x - b1.x + 1) * (b2.y - b1.y + 1);   // :133
+    const double w = npmax(0.0, npmin(a2.x, b2.x) - npmax(a1.x, b1.x) + 1);                                      // :143-149
+    const double h = npmax(0.0, npmin(a2.y, b2.y) - npmax(a1.y, b1.y) + 1);
+    const double inter = w * h;
+    const double ovr = inter / (area_a + area_b - inter);                                                        // :151
+    return !(ovr <= thr);                                                                                        // :153
   }
 };
 

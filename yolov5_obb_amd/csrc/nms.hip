@@ -338,6 +338,27 @@ __global__ void k_prep_quad64(const double* __restrict__ dets9, const int32_t* _
   if (p < 8) alive[((n + 63) >> 6) + p] = 0ull;      // guard words behind the last box (the bitmap is not memset)
 }
 
+// records of the horizontal-box merge NMS (HbbGeom64): columns 0..3 of rows of `stride` doubles, in processing order
+__global__ void k_prep_hbb64(const double* __restrict__ dets, int stride, const int32_t* __restrict__ order, int n, int allow_reject,
+                             float4* __restrict__ rec, u64* __restrict__ alive) {
+  int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p < n) {
+    const double* d = dets + (size_t)order[p] * stride;
+    const double x1 = d[0], y1 = d[1], x2 = d[2], y2 = d[3];
+    const double area = (x2 - x1 + 1) * (y2 - y1 + 1);
+    const bool fin = (x1 - x1 == 0.0) && (y1 - y1 == 0.0) && (x2 - x2 == 0.0) && (y2 - y2 == 0.0);
+    float4* r = rec + (size_t)p * HbbGeom64::RECQ;
+    const float inf = __builtin_huge_valf();
+    r[0] = (allow_reject && fin && area > 0.0 && area - area == 0.0) ? make_float4(f32_down(x1), f32_down(y1), f32_up(x2 + 1), f32_up(y2 + 1))
+                                                                    : make_float4(-inf, -inf, inf, inf);
+    double2* q = reinterpret_cast<double2*>(r + 1);
+    q[0] = make_double2(x1, y1); q[1] = make_double2(x2, y2);
+  }
+  const u64 m = __ballot(p < n);
+  if ((threadIdx.x & 63) == 0 && (p & ~63) < n) alive[p >> 6] = m;
+  if (p < 8) alive[((n + 63) >> 6) + p] = 0ull;      // guard words behind the last box (the bitmap is not memset)
+}
+
 __global__ void k_seg_from_offsets(const int32_t* __restrict__ seg_off, int nseg, int* seg_begin, int* seg_end, int* keep_cnt) {
   int g = blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= nseg) return;
@@ -594,6 +615,8 @@ static int nms_steps(int kind, NmsArgs& a, const Carve& cv, int64_t nseg, int64_
   } else {
     a.slab_plan = nullptr;
   }
+  if (kind == 5) return launch_persist<HbbGeom64, false>(a, (unsigned)nb, st);
+  if (kind == 4) return launch_persist<QuadGeom64All, false>(a, (unsigned)nb, st);
   if (kind == 3) return launch_persist<RotGeom64, false>(a, (unsigned)nb, st);
   if (kind == 2) return launch_persist<QuadGeom64, false>(a, (unsigned)nb, st);
   if (kind == 1) return launch_persist<QuadGeom, false>(a, (unsigned)nb, st);
@@ -706,18 +729,23 @@ static int run_nms(int kind, const float* boxes, int stride, const float* scores
   return hipGetLastError() == hipSuccess ? OBB_OK : OBB_ERR_LAUNCH;
 }
 
-static int kind_recq(int kind) { return kind == 0 ? RotGeom::RECQ : (kind == 1 ? QuadGeom::RECQ : (kind == 2 ? QuadGeom64::RECQ : RotGeom64::RECQ)); }
+static int kind_recq(int kind) {
+  return kind == 0 ? RotGeom::RECQ : (kind == 1 ? QuadGeom::RECQ : (kind == 2 || kind == 4 ? QuadGeom64::RECQ : (kind == 5 ? HbbGeom64::RECQ : RotGeom64::RECQ)));
+}
 
 // Tile -> full-image merge NMS: nseg independent lists, the caller fixes the processing order (numpy's argsort()[::-1] of
 // the reference is not a stable sort: its tie order is the host's business).  keep_out receives ROW indices, the kept rows of
 // segment g at keep_out[seg_off[g] ...], in processing order.
-static int run_merge_nms(const double* dets9, int64_t n, const int32_t* order, const int32_t* seg_off, int64_t nseg, double thr,
-                         int64_t* keep_out, int64_t* num_keep, void* ws, size_t ws_bytes, hipStream_t st) {
+// kind 2: py_cpu_nms_poly_fast (rows of 9 doubles), 4: py_cpu_nms_poly (the same rows, no horizontal-box gate), 5: py_cpu_nms
+// (horizontal boxes in columns 0..3 of rows of `stride` doubles).
+static int run_merge_nms(int kind, const double* dets9, int stride, int64_t n, const int32_t* order, const int32_t* seg_off, int64_t nseg,
+                         double thr, int64_t* keep_out, int64_t* num_keep, void* ws, size_t ws_bytes, hipStream_t st) {
   if (n < 0 || nseg < 1 || n > 0x7fffffffLL || !num_keep || !seg_off) return OBB_ERR_BAD_ARG;
   if (n > 0 && (!dets9 || !order || !keep_out)) return OBB_ERR_BAD_ARG;
+  if (kind == 5 && stride < 4) return OBB_ERR_BAD_ARG;
   const int C = cap_max(nseg);
   Carve cv;
-  int rc = carve(ws, n, nseg, QuadGeom64::RECQ, C, &cv);
+  int rc = carve(ws, n, nseg, kind_recq(kind), C, &cv);
   if (rc) return rc;
   if (!ws || ws_bytes < cv.total) return OBB_ERR_WORKSPACE;
   const int T = 256;
@@ -727,14 +755,15 @@ static int run_merge_nms(const double* dets9, int64_t n, const int32_t* order, c
     k_finalize<<<gseg, T, 0, st>>>(cv.keep_cnt, cv.seg_begin, (int)nseg, 0, nullptr, num_keep, nullptr);
     return hipGetLastError() == hipSuccess ? OBB_OK : OBB_ERR_LAUNCH;
   }
-  k_prep_quad64<<<(unsigned)((n + T - 1) / T), T, 0, st>>>(dets9, order, (int)n, cv.rec, cv.alive);
+  if (kind == 5) k_prep_hbb64<<<(unsigned)((n + T - 1) / T), T, 0, st>>>(dets9, stride, order, (int)n, (thr >= 0.0) ? 1 : 0, cv.rec, cv.alive);
+  else k_prep_quad64<<<(unsigned)((n + T - 1) / T), T, 0, st>>>(dets9, order, (int)n, cv.rec, cv.alive);
   NmsArgs a{};
   a.rec = cv.rec; a.order = reinterpret_cast<const uint32_t*>(order); a.alive = cv.alive;
   a.seg_begin = cv.seg_begin; a.seg_end = cv.seg_end; a.keep_cnt = cv.keep_cnt; a.keep_out = keep_out;
   a.rows = cv.rows; a.nrows = cv.nrows; a.edges = cv.edges; a.nedges = cv.nedges;
   a.ecap = cv.ecap; a.n = (int)n; a.capmax = C; a.max_keep = 0; a.window = 0;
   a.thr = (float)thr; a.thr64 = thr; a.cull = 1;
-  rc = nms_steps(2, a, cv, nseg, n, st);
+  rc = nms_steps(kind, a, cv, nseg, n, st);
   if (rc) return rc;
   k_finalize<<<gseg, T, 0, st>>>(cv.keep_cnt, cv.seg_begin, (int)nseg, 0, cv.abort_flag, num_keep, nullptr);
   return hipGetLastError() == hipSuccess ? OBB_OK : OBB_ERR_LAUNCH;
@@ -792,7 +821,7 @@ extern "C" {
 size_t obb_nms_workspace_bytes(int64_t n, int64_t nseg, int kind) {
   Carve cv;
   if (n < 0 || nseg < 1) return 0;
-  if (kind < 0 || kind > 3) return 0;
+  if (kind < 0 || kind > 5) return 0;
   if (carve(nullptr, n, nseg, kind_recq(kind), cap_max(nseg), &cv)) return 0;
   return cv.total;
 }
@@ -817,7 +846,18 @@ int obb_nms_poly_f32(const float* polys, int64_t row_stride, int64_t n, float io
 
 int obb_merge_nms_poly_f64(const double* dets9, int64_t n, const int32_t* order, const int32_t* seg_off, int64_t nseg, double thresh,
                            int64_t* keep_out, int64_t* num_keep, void* ws, size_t ws_bytes, void* stream) {
-  return run_merge_nms(dets9, n, order, seg_off, nseg, thresh, keep_out, num_keep, ws, ws_bytes, (hipStream_t)stream);
+  return run_merge_nms(2, dets9, 9, n, order, seg_off, nseg, thresh, keep_out, num_keep, ws, ws_bytes, (hipStream_t)stream);
+}
+
+int obb_merge_nms_poly_all_f64(const double* dets9, int64_t n, const int32_t* order, const int32_t* seg_off, int64_t nseg, double thresh,
+                               int64_t* keep_out, int64_t* num_keep, void* ws, size_t ws_bytes, void* stream) {
+  return run_merge_nms(4, dets9, 9, n, order, seg_off, nseg, thresh, keep_out, num_keep, ws, ws_bytes, (hipStream_t)stream);
+}
+
+int obb_merge_nms_hbb_f64(const double* dets, int64_t row_stride, int64_t n, const int32_t* order, const int32_t* seg_off, int64_t nseg,
+                          double thresh, int64_t* keep_out, int64_t* num_keep, void* ws, size_t ws_bytes, void* stream) {
+  if (row_stride < 4 || row_stride > 0x7fffffff) return OBB_ERR_BAD_ARG;
+  return run_merge_nms(5, dets, (int)row_stride, n, order, seg_off, nseg, thresh, keep_out, num_keep, ws, ws_bytes, (hipStream_t)stream);
 }
 
 // Devkit host-pointer API (DOTA_devkit/poly_nms_gpu/poly_nms.hpp:9-10, poly_nms_kernel.cu:277-329): the rows

@@ -52,8 +52,13 @@ __global__ __launch_bounds__(64) void k_riou_matrix(const float* __restrict__ a5
 
 // RotBox2Poly (poly_overlaps_kernel.cu:280-297): fp32 cos/sin, corner arithmetic in double
 // (the "/ 2.0" literals promote), one rounding to float per coordinate.
+// The reference's `float cs = cos(dbox[4])` is CUDA's device cosf: within 2 ulp of the true value, not correctly rounded, and
+// not reproducible by any other libm (ocml's cosf and glibc's differ from it and from each other in the last bit for some
+// angles: up to 5e-5 of IoU on a 4-pixel box).  Both this kernel and the oracle take the CORRECTLY ROUNDED float -- the
+// double-precision cos / sin rounded once -- which lies inside the reference's own error band and makes the two sides agree
+// bit for bit (round 3 used each side's cosf: 1e-4 max between them).
 __device__ __forceinline__ void rbox_to_quad_devkit(const float* d, float* qx, float* qy) {
-  float cs = cosf(d[4]), ss = sinf(d[4]);
+  float cs = (float)cos((double)d[4]), ss = (float)sin((double)d[4]);
   double w = d[2], h = d[3], x = d[0], y = d[1];
   qx[0] = (float)(x + cs * (w / 2.0) - ss * (-h / 2.0));
   qx[1] = (float)(x + cs * (w / 2.0) - ss * (h / 2.0));
