@@ -1,8 +1,8 @@
 """GPU parity: rotated / quad NMS and pairwise IoU through the C ABI vs the CPU oracle.
 
 Bar: kept-index sequences bit-exact (same indices, same order); IoU values bit-exact
-for the rotated/quad kernels (same IEEE fp32 operations as the oracle), except the
-devkit overlaps where fp32 cosf/sinf differ between ocml and glibc (<= 1e-5 abs).
+for the rotated/quad kernels (same IEEE fp32 operations as the oracle); the devkit overlaps
+too, up to a last-bit difference of the two double libms' cos / sin (<= 1e-5 abs).
 """
 import os
 
