@@ -118,3 +118,21 @@ def test_mergebyrec_files(dev, oracle_lib, tmp_path):
     RM.mergebyrec(str(src), str(dst))
     want = '\n'.join(pyref.merge_result_lines(lines, nms=pyref.merge_nms_hbb)) + '\n'
     assert (dst / "Task1_ship.txt").read_text() == want and want.count('\n') > 10
+
+
+def test_gated_out_pairs_follow_numpy(dev, oracle_lib):
+    """py_cpu_nms_poly_fast judges a pair its horizontal-box gate keeps out of iou_poly by the horizontal ratio itself
+    (ResultMerge_multi_process.py:99-115): 0 <= thresh keeps the candidate -- unless the threshold is negative -- and a NaN
+    ratio (a non-finite coordinate; np.min / np.maximum hand NaN through) removes it."""
+    from yolov5_obb_amd.DOTA_devkit.ResultMerge_multi_process import py_cpu_nms_poly_fast
+    d = _dets(300, 11, 400, ties=False)
+    for thr in (-0.05, -1.0):
+        with np.errstate(all='ignore'):
+            ref = pyref.merge_nms_poly_fast(d, thr)
+        assert [int(k) for k in py_cpu_nms_poly_fast(d, thr)] == ref and len(ref) == 1      # everything behind the first box goes
+    e = d.copy()
+    e[17, 2] = np.nan; e[40, 5] = np.inf; e[77, :8] = 3.0                                  # NaN / inf coordinates, a point
+    for thr in (0.0, 0.2):
+        with np.errstate(all='ignore'):
+            ref = pyref.merge_nms_poly_fast(e, thr)
+        assert [int(k) for k in py_cpu_nms_poly_fast(e, thr)] == ref, thr

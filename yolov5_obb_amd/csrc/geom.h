@@ -161,14 +161,19 @@ struct QuadGeom64 {
   static constexpr bool HAS_GRID = false;
   template <class A> static __device__ __forceinline__ double thr_of(const A& a) { return a.thr64; }
   static __device__ __forceinline__ bool cheap_reject(const float4& a, const float4& b) {
-    return !(fminf(a.z, b.z) > fmaxf(a.x, b.x) && fminf(a.w, b.w) > fmaxf(a.y, b.y));
+    // (a box of {-inf, -inf, +inf, +inf} meets every partner: non-finite coordinates, negative thresholds -- k_prep_quad64)
+    const bool always = (a.x == -__builtin_huge_valf()) || (b.x == -__builtin_huge_valf());
+    return !always && !(fminf(a.z, b.z) > fmaxf(a.x, b.x) && fminf(a.w, b.w) > fmaxf(a.y, b.y));
   }
   static constexpr bool PACKED = false;
   static __device__ __forceinline__ int classify_quick(const float4*, const float4*, double, bool) { return 2; }
   static __device__ __forceinline__ int classify_full(const float4*, const float4*, double) { return 2; }
+  // np.maximum / np.minimum hand a NaN operand through (fmax / fmin would drop it)
+  static __device__ __forceinline__ double npmax(double a, double b) { return (a != a) ? a : ((b != b) ? b : (a > b ? a : b)); }
+  static __device__ __forceinline__ double npmin(double a, double b) { return (a != a) ? a : ((b != b) ? b : (a < b ? a : b)); }
   static __device__ __forceinline__ void hbb(const QuadFeatT<double>& f, double* x1, double* y1, double* x2, double* y2) {
-    *x1 = fmin(fmin(f.x[0], f.x[1]), fmin(f.x[2], f.x[3])); *x2 = fmax(fmax(f.x[0], f.x[1]), fmax(f.x[2], f.x[3]));
-    *y1 = fmin(fmin(f.y[0], f.y[1]), fmin(f.y[2], f.y[3])); *y2 = fmax(fmax(f.y[0], f.y[1]), fmax(f.y[2], f.y[3]));
+    *x1 = npmin(npmin(f.x[0], f.x[1]), npmin(f.x[2], f.x[3])); *x2 = npmax(npmax(f.x[0], f.x[1]), npmax(f.x[2], f.x[3]));   // np.min / np.max: NaN wins
+    *y1 = npmin(npmin(f.y[0], f.y[1]), npmin(f.y[2], f.y[3])); *y2 = npmax(npmax(f.y[0], f.y[1]), npmax(f.y[2], f.y[3]));
   }
   static __device__ __forceinline__ QuadFeatT<double> unpack(const float4* r) {
     const double2* d = reinterpret_cast<const double2*>(r + 1);
@@ -189,17 +194,20 @@ struct QuadGeom64 {
     const int lane = threadIdx.x & 63;
     double* base = reinterpret_cast<double*>(scr - lane) + (lane & 31);
     const QuadFeatT<double> A = unpack(ra), B = unpack(rb);
-    bool look = true;
+    bool look = true, hit = false;
     if constexpr (GATE) {
       double ax1, ay1, ax2, ay2, bx1, by1, bx2, by2;
       hbb(A, &ax1, &ay1, &ax2, &ay2); hbb(B, &bx1, &by1, &bx2, &by2);
       // :70,87-96  areas with the +1 convention, intersection without it
       const double area_a = (ax2 - ax1 + 1) * (ay2 - ay1 + 1), area_b = (bx2 - bx1 + 1) * (by2 - by1 + 1);
-      const double w = fmax(0.0, fmin(ax2, bx2) - fmax(ax1, bx1)), h = fmax(0.0, fmin(ay2, by2) - fmax(ay1, by1));
+      const double w = npmax(0.0, npmin(ax2, bx2) - npmax(ax1, bx1)), h = npmax(0.0, npmin(ay2, by2) - npmax(ay1, by1));
       const double hi = w * h;
-      look = hi / (area_a + area_b - hi) > 0;
+      const double hv = hi / (area_a + area_b - hi);
+      look = hv > 0;
+      // a pair the gate keeps out of iou_poly is judged on the horizontal ratio itself (:115: np.where(hbb_ovr <= thresh)):
+      // 0 <= thresh keeps it for thresh >= 0; a NaN ratio (non-finite coordinates) or a negative threshold removes it
+      hit = !look && !(hv <= thr);
     }
-    bool hit = false;
     int nhalf = 2;
     asm volatile("" : "+s"(nhalf));   // opaque trip count: the two passes must stay two passes (lanes l and l + 32 share a column)
     for (int half = 0; half < nhalf; half++) {

@@ -317,8 +317,10 @@ __global__ void k_prep_quad(const float* __restrict__ polys, int stride, const u
 // segment.  Record = fp32 AABB rounded outward + the 8 doubles.
 __device__ __forceinline__ float f32_down(double v) { float f = (float)v; return ((double)f > v) ? nextafterf(f, -INFINITY) : f; }
 __device__ __forceinline__ float f32_up(double v) { float f = (float)v; return ((double)f < v) ? nextafterf(f, INFINITY) : f; }
-__global__ void k_prep_quad64(const double* __restrict__ dets9, const int32_t* __restrict__ order, int n, float4* __restrict__ rec,
-                              u64* __restrict__ alive) {
+// allow_reject = 0 (a negative or NaN threshold: even a ratio of 0 removes a box) or a coordinate that is not finite: the hot
+// loop's box is the whole plane, i.e. the pair always reaches hit_exact, which applies numpy's rules to it
+__global__ void k_prep_quad64(const double* __restrict__ dets9, const int32_t* __restrict__ order, int n, int allow_reject,
+                              float4* __restrict__ rec, u64* __restrict__ alive) {
   int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p < n) {
     const double* d = dets9 + (size_t)order[p] * 9;
@@ -328,7 +330,11 @@ __global__ void k_prep_quad64(const double* __restrict__ dets9, const int32_t* _
     const double x1 = fmin(fmin(v[0], v[2]), fmin(v[4], v[6])), x2 = fmax(fmax(v[0], v[2]), fmax(v[4], v[6]));
     const double y1 = fmin(fmin(v[1], v[3]), fmin(v[5], v[7])), y2 = fmax(fmax(v[1], v[3]), fmax(v[5], v[7]));
     float4* r = rec + (size_t)p * QuadGeom64::RECQ;
-    r[0] = make_float4(f32_down(x1), f32_down(y1), f32_up(x2), f32_up(y2));
+    bool fin = true;
+#pragma unroll
+    for (int k = 0; k < 8; k++) fin = fin && (v[k] - v[k] == 0.0);
+    const float inf = __builtin_huge_valf();
+    r[0] = (allow_reject && fin) ? make_float4(f32_down(x1), f32_down(y1), f32_up(x2), f32_up(y2)) : make_float4(-inf, -inf, inf, inf);
     double2* q = reinterpret_cast<double2*>(r + 1);
 #pragma unroll
     for (int k = 0; k < 4; k++) q[k] = make_double2(v[2 * k], v[2 * k + 1]);
@@ -756,7 +762,7 @@ static int run_merge_nms(int kind, const double* dets9, int stride, int64_t n, c
     return hipGetLastError() == hipSuccess ? OBB_OK : OBB_ERR_LAUNCH;
   }
   if (kind == 5) k_prep_hbb64<<<(unsigned)((n + T - 1) / T), T, 0, st>>>(dets9, stride, order, (int)n, (thr >= 0.0) ? 1 : 0, cv.rec, cv.alive);
-  else k_prep_quad64<<<(unsigned)((n + T - 1) / T), T, 0, st>>>(dets9, order, (int)n, cv.rec, cv.alive);
+  else k_prep_quad64<<<(unsigned)((n + T - 1) / T), T, 0, st>>>(dets9, order, (int)n, (thr >= 0.0) ? 1 : 0, cv.rec, cv.alive);
   NmsArgs a{};
   a.rec = cv.rec; a.order = reinterpret_cast<const uint32_t*>(order); a.alive = cv.alive;
   a.seg_begin = cv.seg_begin; a.seg_end = cv.seg_end; a.keep_cnt = cv.keep_cnt; a.keep_out = keep_out;
