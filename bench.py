@@ -425,8 +425,11 @@ def main():
                 "kernel": "obb::k_nms_persist<obb::RotGeom> (+ sort, prep) @ N = 100k", "regime": wr["distribution"],
                 "avg_call_ms": wr["ms_per_call"], "avg_kernel_ms": wr["stages_ms"]["steps"], "pair_tests_per_s": wr["pair_tests_per_s"],
                 "frac_by_regime": {r: regimes[r]["frac"] for r in regimes},
-                "note": "whole NMS call (sort + prep + persistent kernel) over the dense-mask algorithmic bytes; the kernel never "
-                        "builds the mask (traffic << algorithmic bytes): a time target, see pair_tests_per_s"}
+                "note": "frac = SURVEY 8d bytes over avg_call_ms, the whole NMS call: three sort launches (k_ps_*), the record kernel, "
+                        "k_slab_split (52 us when the list falls apart into class slabs, 4 us otherwise) and k_nms_persist<RotGeom, true>; "
+                        "avg_kernel_ms = the HIP-event time of the last two together (the stage 'steps'); compare "
+                        "profiles/r4_hotpath_kernel_stats.md.  The kernel never builds the mask (traffic << algorithmic bytes): a time "
+                        "target, see pair_tests_per_s"}
 
     # ---------------- measured copy ceiling next to the spec peak (256 MiB device-to-device, read + write)
     cbuf = torch.empty(256 << 20, dtype=torch.uint8, device=dev)
