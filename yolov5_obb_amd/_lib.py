@@ -21,7 +21,7 @@ _ERR = {-1: "bad argument", -2: "workspace missing or too small", -3: "kernel la
         -4: "internal error", -5: "no usable HIP device"}
 
 _lib = None
-_lock = threading.Lock()
+_lock = threading.RLock()
 
 _vp, _i64, _i32, _f32, _sz = C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_size_t
 
@@ -93,6 +93,44 @@ def lib():
             fn.argtypes = args
         _lib = L
     return _lib
+
+
+# ---- the compiled binding (csrc/torch_ext/nms_rotated_ext.cpp -> nms_rotated_ext_c.so, built by __graft_entry__.build())
+# OBB_BINDING=ctypes keeps every call on the ctypes binding of this file (the fallback binding); default: the compiled
+# module when it has been built, which binds the very library `lib()` loaded (dlopen of the same path: one copy of its state).
+EXT_PATH = os.path.join(_HERE, "nms_rotated_ext_c.so")
+_ext = None
+_ext_tried = False
+
+
+def compiled():
+    """The compiled torch binding (module nms_rotated_ext_c) or None."""
+    global _ext, _ext_tried
+    if _ext_tried:
+        return _ext
+    with _lock:
+        if _ext_tried:
+            return _ext
+        mod = None
+        if os.environ.get("OBB_BINDING", "auto").lower() != "ctypes":
+            if os.path.exists(EXT_PATH):
+                import importlib.machinery
+                import importlib.util
+                loader = importlib.machinery.ExtensionFileLoader("nms_rotated_ext_c", EXT_PATH)
+                spec = importlib.util.spec_from_file_location("nms_rotated_ext_c", EXT_PATH, loader=loader)
+                mod = importlib.util.module_from_spec(spec)
+                loader.exec_module(mod)
+            elif os.environ.get("OBB_BINDING", "auto").lower() == "compiled":
+                raise ImportError(f"{EXT_PATH} not found: run `python -c 'import __graft_entry__ as g; g.build()'`")
+            else:
+                import warnings
+                warnings.warn(f"{EXT_PATH} is not built: yolov5_obb_amd falls back to its ctypes binding of libobb_hip.so "
+                              "(same kernels, slower host side); run __graft_entry__.build()")
+        if mod is not None:
+            lib()                              # the library must load (ImportError with build instructions otherwise)
+            mod.init(LIB_PATH)
+        _ext, _ext_tried = mod, True
+    return _ext
 
 
 def check(rc, what):

@@ -2,7 +2,9 @@
 (utils/nms_rotated/src/nms_rotated_ext.cpp:57-60): ``nms_rotated`` and ``nms_poly``.
 
 Same signatures, return conventions and error types; the work is done by
-``obb_nms_rotated_f32`` / ``obb_nms_poly_f32`` of libobb_hip.so.
+``obb_nms_rotated_f32`` / ``obb_nms_poly_f32`` of libobb_hip.so.  Two bindings of that C ABI exist: the compiled torch
+extension ``nms_rotated_ext_c`` (csrc/torch_ext/nms_rotated_ext.cpp, pybind11 like the reference's module; used when built)
+and the ctypes calls below (the fallback binding, ``OBB_BINDING=ctypes``).
 """
 import torch
 
@@ -13,6 +15,9 @@ _ws_bytes = {}      # n -> obb_nms_workspace_bytes(n, 1, 0)
 
 
 def _run_rotated(dets, scores, iou_threshold, flags=0, max_keep=0):
+    ext = _lib.compiled()
+    if ext is not None:          # the compiled binding: same entry point, checks and abort retry (csrc/torch_ext/nms_rotated_ext.cpp)
+        return ext.nms_rotated_opts(dets, scores, float(iou_threshold), int(flags), int(max_keep))
     return _lib.retry_on_abort(lambda: _run_rotated_once(dets, scores, iou_threshold, flags, max_keep))
 
 
@@ -63,6 +68,9 @@ def _run_rotated_f64(dets, scores, iou_threshold, flags=0, max_keep=0):
     (nms_rotated_cuda.cu:96).  ``obb_nms_rotated_f64`` does the same on the device: double scores decide the order (ties:
     ascending index, NaN first), every IoU is evaluated in double (csrc/riou64_device.h, the policy RotGeom64 of the
     persistent NMS kernel) and compared with the float threshold of the kernel's signature (nms_rotated_cuda.cu:14,60)."""
+    ext = _lib.compiled()
+    if ext is not None:
+        return ext.nms_rotated_opts(dets, scores, float(iou_threshold), int(flags), int(max_keep))
     return _lib.retry_on_abort(lambda: _run_rotated_f64_once(dets.contiguous(), scores.contiguous(), iou_threshold, flags, max_keep))
 
 
@@ -95,6 +103,9 @@ def nms_poly(dets, iou_threshold):
         raise RuntimeError(f"nms_poly: float32 expected (the reference wrapper casts with .float()), got {dets.dtype}")
     if dets.dim() != 2 or dets.shape[1] < 9:
         raise RuntimeError(f"nms_poly: expected dets (N,9), got {tuple(dets.shape)}")
+    ext = _lib.compiled()
+    if ext is not None:
+        return ext.nms_poly(dets, float(iou_threshold))
     dets = dets.contiguous()
     L = _lib.lib()
     n, stride = dets.shape[0], dets.shape[1]

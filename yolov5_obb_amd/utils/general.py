@@ -21,12 +21,14 @@ _POLL_SECONDS = 2e-3  # busy-poll this long (a bs16 step is ~0.2 ms), then yield
 _POLL_GIVE_UP = 1.0   # ... after this many seconds: fall back to a stream synchronise
 _MAX_NMS = 30000    # utils/general.py:794
 _CSL = 180          # utils/general.py:784
-_cap_memo = {}      # (A, nc, multi_label) -> candidate slots per image that sufficed last time
+_cap_memo = {}      # (device, thread, A, nc, multi_label, conf_thres) -> candidate slots per image that sufficed last time
 _ws_memo = {}       # (bs, cap, nc, agnostic, grid capped) -> workspace bytes (a ctypes call saved per batch)
 _meta_memo = {}     # (device index, bs, thread) -> the int64 buffer the counters are read back from
 _cand_memo = {}     # same key -> largest candidate count of an image in the previous call (sort-algorithm hint; 0 forces the generic sort)
 _SORT_LDS_HINT = 6144   # include/obb_hip.h OBB_NMS_SORT_LDS_HINT: hints up to this select the one-workgroup-per-image sort ...
 _SORT_LDS_MAX = 8192    # ... OBB_NMS_SORT_LDS_MAX: which takes at most this many candidates of an image
+_hold = {}              # (key, "seg" | "cand") -> calls the larger regime is still held after a repeated call (hysteresis)
+_HOLD = 8
 _seg_memo = {}          # same key -> largest NMS segment (an image's class) of the previous call: chooses the NMS kernel (the one-
 _SEG_SMALL = 384        # workgroup-per-segment kernel of csrc/nms_small.h takes segments up to this size; 0 = unknown: the persistent one)
 
@@ -104,6 +106,13 @@ def non_max_suppression_obb(prediction, conf_thres=0.25, iou_thres=0.45, classes
         return [torch.zeros((0, 7), device=dev)] * bs
 
     extra = _label_rows(labels, bs, nc, dev) if labels else None
+    ext = _lib.compiled()
+    if ext is not None:
+        # the compiled binding (csrc/torch_ext/nms_rotated_ext.cpp): the same call sequence, retries and hint memo as below, in C++
+        cl = None
+        if classes is not None:
+            cl = [int(c) for c in (classes if isinstance(classes, (list, tuple)) else list(classes))]
+        return ext.non_max_suppression_obb(pred, float(conf_thres), float(iou_thres), cl, bool(agnostic), multi, extra, int(max_det), col)
     n_extra = 0 if extra is None else extra.shape[0]
     cls_arr = None
     if classes is not None:
@@ -116,7 +125,8 @@ def non_max_suppression_obb(prediction, conf_thres=0.25, iou_thres=0.45, classes
         n_cls = 0
 
     worst = A * (nc if multi else 1) + n_extra
-    key = (A, nc, multi)
+    # per device, calling thread and confidence threshold: other callers' batches say nothing about this one's
+    key = (dev.index, threading.get_ident(), A, nc, multi, float(conf_thres))
     cap = min(worst, max(_cap_memo.get(key, 0), 65536))
     L = _lib.lib()
     max_det = int(max_det)
@@ -172,6 +182,7 @@ def non_max_suppression_obb(prediction, conf_thres=0.25, iou_thres=0.45, classes
             seg_max, m[bs + 1] = m[bs + 1] >> 32, m[bs + 1] & 0xffffffff       # status[1]: largest segment | largest candidate count
             if m[bs] == -1:                                           # a segment above the small kernel's limit: nothing is valid
                 _seg_memo[key] = max(int(seg_max), _SEG_SMALL + 1)
+                _hold[key, "seg"] = _HOLD
                 continue
             if min(m[:bs]) < 0:                                       # a team barrier of the NMS kernel timed out
                 if capped:
@@ -184,13 +195,27 @@ def non_max_suppression_obb(prediction, conf_thres=0.25, iou_thres=0.45, classes
                 continue
             if 0 < hint <= _SORT_LDS_HINT and m[bs + 1] > _SORT_LDS_MAX:   # the hint undersold this batch: such images were left out
                 _cand_memo[key] = int(m[bs + 1])
+                _hold[key, "cand"] = _HOLD
                 continue
             break
     finally:
         if capped:
             L.obb_nms_set_max_grid(0)
     _cap_memo[key] = cap
-    _cand_memo[key] = int(m[bs + 1])
-    _seg_memo[key] = int(seg_max)                                     # (0: the sort path of this call does not report it)
+    # the hints of the next call.  After a repeated call the larger regime is held for _HOLD calls unless the batch falls clearly
+    # (25 %) below the limit: a stream whose batches hover around a limit does not pay the repeat on every other batch
+    cand, seg = int(m[bs + 1]), int(seg_max)                          # (seg 0: the sort path of this call does not report it)
+    if _hold.get((key, "cand"), 0) > 0 and cand > _SORT_LDS_HINT * 3 // 4:
+        _hold[key, "cand"] -= 1
+        cand = max(cand, _SORT_LDS_HINT + 1)
+    else:
+        _hold[key, "cand"] = 0
+    if _hold.get((key, "seg"), 0) > 0 and (seg == 0 or seg > _SEG_SMALL * 3 // 4):
+        _hold[key, "seg"] -= 1
+        seg = max(seg, _SEG_SMALL + 1)
+    else:
+        _hold[key, "seg"] = 0
+    _cand_memo[key] = cand
+    _seg_memo[key] = seg
     counts = m[:bs]
     return list(out.narrow(0, 0, sum(counts)).split_with_sizes(counts))     # one call instead of bs slicing ops

@@ -95,9 +95,13 @@ def val_tail_batch(preds, targets, shapes, iouv, want_boxes=False):
     Returns  stats: per image (correct bool (n_i, niou), conf (n_i), cls (n_i)) on the HOST -- what val.py:250 appends -- and,
              with want_boxes, the packed device arrays (pred_poly, pred_hbb, pred_polyn, pred_hbbn) + the offsets."""
     import ctypes as C
+    import threading
     bs = len(preds)
     if bs == 0:
         return ([], None) if want_boxes else []
+    ext = _lib.compiled()
+    if ext is not None:          # the compiled binding builds the per-image tuples in C++ (csrc/torch_ext/nms_rotated_ext.cpp)
+        return ext.val_tail_batch(list(preds), targets, shapes, iouv, bool(want_boxes))
     dev = preds[0].device
     if dev.type != "cuda":
         _lib.require_cuda(preds[0], "pred")
@@ -147,9 +151,10 @@ def val_tail_batch(preds, targets, shapes, iouv, want_boxes=False):
             for b0 in range(0, bs, _TAIL_MAX_BS):                # (one call for any batch size val.py uses)
                 b1 = min(bs, b0 + _TAIL_MAX_BS)
                 k = b1 - b0
-                arrs = _arr_cache.get(k)
+                akey = (threading.get_ident(), k)           # ctypes releases the GIL during the call that reads them: per thread
+                arrs = _arr_cache.get(akey)
                 if arrs is None:
-                    arrs = _arr_cache[k] = ((C.c_int64 * (k + 1))(), (C.c_float * (5 * k))())
+                    arrs = _arr_cache[akey] = ((C.c_int64 * (k + 1))(), (C.c_float * (5 * k))())
                 doff, img5 = arrs
                 base = offs[b0]
                 doff[:] = [o - base for o in offs[b0:b1 + 1]] if base else offs[b0:b1 + 1]

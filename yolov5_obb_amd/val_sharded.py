@@ -71,6 +71,7 @@ def run(model, loader, n_total=None, conf_thres=0.001, iou_thres=0.4, half=True,
     iouv = torch.linspace(0.5, 0.95, niou, device=device)           # val.py:172
     gidx = getattr(loader, "global_indices", None)
     per_image, dt, seen = [], [0.0, 0.0, 0.0], 0
+    dt_batches = []                                                  # (pre-process, inference, NMS) seconds of every batch
     with torch.no_grad():
         for im, targets, paths, shapes in loader:
             t1 = _sync(device)
@@ -85,7 +86,9 @@ def run(model, loader, n_total=None, conf_thres=0.001, iou_thres=0.4, half=True,
             t3 = _sync(device)
             dt[1] += t3 - t2
             out = nms(out, conf_thres, iou_thres, multi_label=True, agnostic=single_cls)      # val.py:206
-            dt[2] += _sync(device) - t3
+            t4 = _sync(device)
+            dt[2] += t4 - t3
+            dt_batches.append((t2 - t1, t3 - t2, t4 - t3))
             if batch_tail is not None and device.type == "cuda":
                 if single_cls:
                     for pred in out:
@@ -132,7 +135,7 @@ def run(model, loader, n_total=None, conf_thres=0.001, iou_thres=0.4, half=True,
                 per_image.append((correct.cpu(), poly[:, 8].cpu(), poly[:, 9].cpu(), tcls))     # val.py:250
     if not collect:
         return {"rank": rank, "world": world, "seen": seen, "dt": list(dt), "img_per_s": seen / max(sum(dt), 1e-12), "stats": None,
-                "metrics": None}
+                "metrics": None, "dt_batches": dt_batches}
     # ---- the one exchange: per-image tuples to rank 0, in the original order of the image list
     if gidx is None:
         gidx = list(range(rank, rank + world * len(per_image), world)) if world > 1 else list(range(len(per_image)))
@@ -148,7 +151,7 @@ def run(model, loader, n_total=None, conf_thres=0.001, iou_thres=0.4, half=True,
     seen_all = n_total
     slow = [shard.max_over_ranks(x, device=device if device.type == "cuda" else None) for x in dt]
     res = {"rank": rank, "world": world, "seen": seen_all, "dt": slow, "img_per_s": seen_all / max(sum(slow), 1e-12),
-           "stats": None, "metrics": None}
+           "stats": None, "metrics": None, "dt_batches": dt_batches}
     if rank == 0:
         st = [s for s in full if s is not None]
         if st:
