@@ -172,6 +172,42 @@ def bench_next_rows(dev, dets_per_image):
     return res
 
 
+def provenance(_lib, L):
+    """Which binaries were timed: library version string, size / mtime / sha256 of the shared objects, the binding in use."""
+    import hashlib
+
+    def ident(path):
+        try:
+            h = hashlib.sha256(open(path, "rb").read()).hexdigest()[:16]
+            st = os.stat(path)
+            return {"path": os.path.relpath(path, ROOT), "bytes": st.st_size, "mtime": int(st.st_mtime), "sha256_16": h}
+        except OSError as e:
+            return {"path": path, "error": str(e)}
+    ext = _lib.compiled()
+    return {"obb_version": L.obb_version().decode(), "library": ident(_lib.LIB_PATH),
+            "binding": "compiled (nms_rotated_ext_c, pybind11)" if ext is not None else "ctypes (fallback)",
+            "binding_module": ident(_lib.EXT_PATH) if ext is not None else None,
+            "torch": torch.__version__, "hip": getattr(torch.version, "hip", None)}
+
+
+def host_cpu_budget():
+    """CPUs this process may really use: min(visible cores, the cgroup's CPU quota) -- cpu.max (cgroup v2) or cfs_quota_us / cfs_period_us."""
+    n = os.cpu_count() or 1
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(p))))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // p))
+        except Exception:
+            pass
+    return n
+
+
 def free_port():
     import socket
     with socket.socket() as s:
@@ -287,6 +323,13 @@ def main():
              for r in range(ROTATE)]
     pred = preds[0]
     torch.cuda.synchronize()
+    # Host threads: this container may use 16 CPUs' worth of time per 100 ms (cgroup cpu.max = 1600000 100000 on the GPU boxes) while
+    # torch sizes its intra-op pool from the 256 cores it sees (128 threads).  Every parallel CPU op (a host-side torch.rand of 10^5
+    # rows, a clone of a 44k-element tensor) leaves 128 OpenMP workers spinning for a few ms, the cgroup's quota of the period is gone,
+    # and the kernel's CFS bandwidth control parks EVERY thread of the process until the period ends: the "~70-88 ms stall of any call"
+    # of rounds 2-4 (profiles/r5_host_stall.md: cpu.stat nr_throttled grows with the stalls, OMP_NUM_THREADS=1 removes both).  The
+    # bench keeps torch inside the budget it really has.
+    torch.set_num_threads(host_cpu_budget())
 
     def barrier():
         if dist is not None:
@@ -366,13 +409,19 @@ def main():
     nms_alg = int(sum(bytes_nms(int(c)) for c in cand))
     nms_ach = nms_alg / (nms_ms_step * 1e-3) / 1e9
     pmc = {}
-    for name in ("r4_pmc.json", "r3_pmc.json", "r2_pmc.json", "r1_pmc.json"):
+    for name in ("r5_pmc.json", "r4_pmc.json", "r3_pmc.json", "r2_pmc.json", "r1_pmc.json"):
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", name)))
             pmc["_file"] = "profiles/" + name
             break
         except Exception:
             continue
+    sq = {}
+    try:
+        sq = json.load(open(os.path.join(ROOT, "profiles", "r5_sq.json")))
+        sq["_file"] = "profiles/r5_sq.json"
+    except Exception:
+        pass
     stage_names = ["decode", "segsort", "prep", "nms_steps", "gather"]
     stages = {stage_names[i]: round(ms_sum[i] / max(1, cnts[i]), 4) for i in range(5)}
     stages_warm = {stage_names[i]: round(ms_sum_w[i] / max(1, cnts_w[i]), 4) for i in range(5)}
@@ -389,7 +438,7 @@ def main():
         for _ in range(3):
             k100 = nms_rotated_ext.nms_rotated(d100, s100, 0.4)
         torch.cuda.synchronize()
-        time.sleep(0.3)                          # profiles/r2_stall_env.md: a ~86 ms stall of ANY kernel follows host-side data preparation by up to ~40 ms
+        time.sleep(0.05)                         # (rounds 2-4 waited 0.3 s here for "a ~86 ms stall that follows host-side data preparation": CFS throttling of the container after 128 OpenMP workers had spun, see torch.set_num_threads above)
         k100 = nms_rotated_ext.nms_rotated(d100, s100, 0.4)
         torch.cuda.synchronize()
         per_call = []                            # the call as a user sees it (no stage events inside the timed region)
@@ -425,6 +474,11 @@ def main():
                 "kernel": "obb::k_nms_persist<obb::RotGeom> (+ sort, prep) @ N = 100k", "regime": wr["distribution"],
                 "avg_call_ms": wr["ms_per_call"], "avg_kernel_ms": wr["stages_ms"]["steps"], "pair_tests_per_s": wr["pair_tests_per_s"],
                 "frac_by_regime": {r: regimes[r]["frac"] for r in regimes},
+                # the roofline that binds this kernel is not HBM (traffic << algorithmic bytes): SQ counters of k_nms_persist per regime --
+                # valu_frac = issued VALU cycles / (256 CUs x 4 SIMDs x kernel cycles), wait_frac = share of the waves' resident time spent
+                # parked (s_waitcnt, barrier spins), from profiles/r5_sq.md (rocprofv3 --pmc, separate passes; tools/rocpd_sq.py)
+                "sq": {r: sq.get("k_nms_persist_100k_" + r.replace("_raw", "")) for r in regimes}, "sq_source": sq.get("_file"),
+                "valu_frac": (sq.get("k_nms_persist_100k_" + worst.replace("_raw", "")) or {}).get("valu_frac"),
                 "note": "frac = SURVEY 8d bytes over avg_call_ms, the whole NMS call: three sort launches (k_ps_*), the record kernel, "
                         "k_slab_split (52 us when the list falls apart into class slabs, 4 us otherwise) and k_nms_persist<RotGeom, true>; "
                         "avg_kernel_ms = the HIP-event time of the last two together (the stage 'steps'); compare "
@@ -748,7 +802,7 @@ def main():
             import oracle
             from oracle import pyref, pyref_model
             oracle.build(with_ref=False)
-            ncores = os.cpu_count() or 1
+            ncores = host_cpu_budget()                         # (cores the cgroup lets this process use: 16 of the 256 it sees on the GPU boxes)
             sample = pred[:1].float().cpu()                     # 1 image of the same batch, fp32 like --device cpu
             torch.set_num_threads(ncores)
             t0 = time.perf_counter()
@@ -782,7 +836,7 @@ def main():
             cpu["nms_1thread_note"] = "oracle port of nms_rotated_cpu (>=), iou 0.4, one thread; null = skipped by the time box"
             # (ii) detect.py --device cpu equivalent: model forward + NMS + rbox2poly + scale_polys per image, all host cores
             net = pyref_model.YoloV5nObb(16).eval()
-            torch.set_num_threads(min(ncores, 32))               # (intra-op threads: hundreds of them slow torch's CPU convolutions down)
+            torch.set_num_threads(ncores)                        # (= the cgroup's CPU budget, see host_cpu_budget)
             img = torch.rand(1, 3, 1024, 1024)
             buckets = [0.0, 0.0, 0.0]
             nimg2 = 0
@@ -806,9 +860,10 @@ def main():
                                        "images": nimg2, "input": "1x3x1024x1024 synthetic",
                                        "ms_per_image": {"inference": round(buckets[0] / nimg2 * 1e3, 2), "nms": round(buckets[1] / nimg2 * 1e3, 3),
                                                         "rbox2poly_scale": round(buckets[2] / nimg2 * 1e3, 3)},
-                                       "img_per_s": round(nimg2 / sum(buckets), 3), "threads": int(torch.get_num_threads()), "nproc": int(ncores),
-                                       "threads_note": "SURVEY 8d(ii) asks for all host cores; torch's CPU convolutions get SLOWER beyond a few dozen "
-                                                       "intra-op threads on this host, so the leg runs min(nproc, 32) threads and records both numbers",
+                                       "img_per_s": round(nimg2 / sum(buckets), 3), "threads": int(torch.get_num_threads()), "nproc": int(os.cpu_count() or 1), "cpu_budget": int(ncores),
+                                       "threads_note": "SURVEY 8d(ii) asks for all host cores: the leg runs as many threads as the container's CPU quota allows "
+                                                       "(cpu_budget; more threads than that only trigger CFS throttling -- what rounds 2-4 saw as 'convolutions get slower "
+                                                       "beyond a few dozen threads')",
                                        "note": "random-init logits: the objectness prior passes few anchors, so the NMS bucket is near "
                                                "its floor; the NMS-heavy case is the `value` / `sample` pair above"}
         except Exception as e:                                  # the baseline is informative; never fail the bench on it
@@ -819,7 +874,7 @@ def main():
         line = {
             "metric": METRIC,
             "value": round(value, 2), "unit": "img/s", "n_gpus": dist.get_world_size() if dist is not None else 1, "rccl_ranks": rccl_ranks,
-            "steps": args.steps, "warmup": args.warmup,
+            "steps": args.steps, "warmup": args.warmup, "build": provenance(_lib, L),
             "ms_per_step": round(ms_per_step, 4), "ms_per_step_with_all_stage_events": round(ms_all_events, 4), "ms_per_step_without_stage_events": round(ms_plain, 4),
             "ms_per_step_one_tensor_warm": round(ms_warm, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f16", "data": "synthetic",

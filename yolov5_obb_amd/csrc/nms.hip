@@ -595,7 +595,8 @@ static int nms_steps(int kind, NmsArgs& a, const Carve& cv, int64_t nseg, int64_
               h[1] * 0.01, h[2] * 0.01, h[3] * 0.01, h[5] * 0.01, h[0] * 0.01, h[6], h[9] * 0.01, h[11], h[12] * 0.01, h[13] * 0.01, h[14] * 0.01);
       fprintf(stderr, "    resolve: edges total %llu, max per chunk %llu, chunk sizes total %llu, chunks resolved from LDS %llu\n", h[25], h[27], h[28], h[26]);
       fprintf(stderr, "    pairs phase per workgroup (wave 0): longest %.1f us, sum over steps and workgroups / workgroups %.1f us; cross: longest single %.1f us\n", h[29] * 0.01, h[24] ? h[30] * 0.01 / h[24] : 0.0, h[31] * 0.01);
-      fprintf(stderr, "    workgroups: %llu, busy time max %.1f us, mean %.1f us\n", h[24], h[22] * 0.01, h[24] ? h[23] * 0.01 / h[24] : 0.0);
+      fprintf(stderr, "    workgroups: %llu, busy time max %.1f us, mean %.1f us; cross phases: mean over workgroups %.1f us (sum over steps; wg0: cross + barrier = the slowest workgroup of every step)\n",
+              h[24], h[22] * 0.01, h[24] ? h[23] * 0.01 / h[24] : 0.0, h[24] ? h[51] * 0.01 / h[24] : 0.0);
       fprintf(stderr, "    cross, wave 0: items %llu row-loops / scans %.1f us, stage-1 drains %llu = %.1f us | exhaustive: stage-2 drains %llu = %.1f us | indexed: per-item setup %.1f us, blocks %llu, queued pairs %llu, parts (sum over steps) %llu\n",
               h[21], h[16] * 0.01, h[19], h[17] * 0.01, h[20], h[18] * 0.01, h[18] * 0.01, h[20], h[15], h[10]);
       fprintf(stderr, "    pairs, wg0 wave 0: items %llu = %.1f us (loads %.1f), stage-1a drains %llu = %.1f us, stage-1b drains %llu = %.1f us, exact drains %llu = %.1f us | slab set-up %.1f us, merge %.1f us (wg0)\n",

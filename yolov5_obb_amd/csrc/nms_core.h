@@ -1919,7 +1919,7 @@ __global__ __launch_bounds__(kNmsThreads) __attribute__((amdgpu_waves_per_eu(1, 
         const u64 tcz = (a.prof && tid == 0) ? wall_clock64() : 0ull;
         cross(jrows, jnr, jc0, jc1);
         if (aborted) return;
-        if (a.prof && tid == 0) { atomicMax(a.prof + 31, wall_clock64() - tcz); }
+        if (a.prof && tid == 0) { const u64 dcz = wall_clock64() - tcz; atomicMax(a.prof + 31, dcz); atomicAdd(a.prof + 51, dcz); }
         lap(5);
         if (!team_barrier(bar, &s_flag)) return;           // the kills are visible before anybody selects again
         lap(0);

@@ -99,8 +99,30 @@ struct DecodeArgs {
   unsigned long long* keys;  // [bs*cap_img]
   uint32_t* vals;            // [bs*cap_img] slot index inside the image region
   int* cnt;                  // [bs * kCntPad] candidates produced (may exceed cap_img: overflow), one 256-B line each
-  int* tiny;                 // [bs] set when the image has a candidate with 0.001 <= min(l,s) < 1 (no class segmentation)
+  int* tiny;                 // [bs] flags of the image (kImg*): what decides whether its classes may run as independent NMS segments
+  float win_lo, win_hi;      // every candidate's circle must lie in win_lo < x < win_hi (a window narrower than max_wh), else kImgWide
 };
+
+// Per-image flags (DecodeArgs::tiny).  The reference runs ONE list per image with xy += cls * max_wh (utils/general.py:849-851);
+// one NMS segment per class gives the same kept set exactly when no pair of boxes of DIFFERENT classes can interact:
+//   kImgSmall   a candidate has a short side in [0.001, 1) px: the reference's fp32 corner arithmetic is ill conditioned for such a
+//               box against a partner tens of thousands of pixels away (riou_device.h: rbox_pair_well_conditioned) and can
+//               report an overlap there.  Such an image keeps its class segments only if k_tiny_cross has CHECKED every
+//               ill-conditioned cross-class pair with the exact clip and found no IoU > thr (round 5; rounds 1-4: single list);
+//   kImgWide    a candidate's circle leaves the window [win_lo, win_hi] on x (an oversized or far-out box, NaN / inf): circles
+//               of different classes could really touch -- always the single list;
+//   kImgChecked k_tiny_cross ran for the image and completed its list of small boxes;   kImgCross  it found a cross-class hit.
+constexpr int kImgSmall = 1, kImgWide = 2, kImgChecked = 4, kImgCross = 8;
+__host__ __device__ __forceinline__ bool img_single_list(int t) {
+  return (t & kImgWide) || ((t & kImgSmall) && (!(t & kImgChecked) || (t & kImgCross)));
+}
+__device__ __forceinline__ int cand_flags(float x, float l, float s, float win_lo, float win_hi) {
+  const float mn = (s < l) ? s : l;
+  const float rr = sqrtf(l * l + s * s) * 0.501f + 0.5f;
+  int f = (mn >= 0.001f && mn < 1.0f) ? kImgSmall : 0;
+  if (!(x - rr > win_lo && x + rr < win_hi)) f |= kImgWide;     // (NaN / inf anywhere: the comparisons fail)
+  return f;
+}
 
 __device__ __forceinline__ bool class_allowed(const ClassMask& cm, int c) {
   const int q = (c >> 6) & 3;   // select chain instead of a dynamic index: the mask lives in kernel-argument SGPRs
@@ -188,7 +210,7 @@ __global__ __launch_bounds__(kDecThreads) void k_decode(DecodeArgs a) {
   uint32_t* vals = a.vals + (size_t)b * a.cap_img;
   float4* c0s = s_c0[wv]; float4* c1s = s_c1[wv]; unsigned long long* kys = s_key[wv];
   int staged = 0;   // wave-uniform
-  bool tiny_seen = false;
+  int flags_seen = 0;
   if (tid == 0) s_n = 0;
   __syncthreads();
 
@@ -257,8 +279,7 @@ __global__ __launch_bounds__(kDecThreads) void k_decode(DecodeArgs a) {
     argmax_unkey(row_max_u64(tk), tv, ti);
     const float theta = ((float)(ti - 90) / 180.0f) * 3.141592f;
     const float bx = cur.box[0], by = cur.box[1], bl = cur.box[2], bs_ = cur.box[3];
-    const float mn = (bs_ < bl) ? bs_ : bl;
-    const bool tiny = mn >= 0.001f && mn < 1.0f;
+    const int bflags = cand_flags(bx, bl, bs_, a.win_lo, a.win_hi);
     const long long rw = (long long)cur.row;
     auto stage = [&](bool p, float conf, int c) {        // one candidate per lane with p set
       const unsigned long long pb = __ballot(p);
@@ -270,7 +291,7 @@ __global__ __launch_bounds__(kDecThreads) void k_decode(DecodeArgs a) {
         c0s[i] = make_float4(bx, by, bl, bs_);
         c1s[i] = make_float4(theta, conf, (float)c, 0.f);
         kys[i] = ((unsigned long long)score_desc_key(conf) << 32) | (unsigned long long)(uint32_t)(rw * a.nc + c);
-        if (tiny) tiny_seen = true;
+        flags_seen |= bflags;
       }
       staged += np;
     };
@@ -306,7 +327,10 @@ __global__ __launch_bounds__(kDecThreads) void k_decode(DecodeArgs a) {
     }
   }
 
-  if (__ballot(tiny_seen) && lane == 0) atomicOr(&a.tiny[b], 1);
+  {
+    const int fl = (__ballot(flags_seen & kImgSmall) ? kImgSmall : 0) | (__ballot(flags_seen & kImgWide) ? kImgWide : 0);
+    if (fl && lane == 0) atomicOr(&a.tiny[b], fl);
+  }
   // ---- one atomic per workgroup for whatever is still staged
   if (lane == 0) s_cnt[wv] = staged;
   __syncthreads();
@@ -329,13 +353,68 @@ __global__ void k_append_extra(const float* __restrict__ extra8, int m, long lon
   const int b = (int)e[0];
   if (b < 0 || b >= a.bs) return;
   const int slot = atomicAdd(&a.cnt[b * kCntPad], 1);
-  { const float mn = (e[4] < e[3]) ? e[4] : e[3]; if (mn >= 0.001f && mn < 1.0f) atomicOr(&a.tiny[b], 1); }
+  { const int fl = cand_flags(e[1], e[3], e[4], a.win_lo, a.win_hi); if (fl) atomicOr(&a.tiny[b], fl); }
   if (slot >= a.cap_img) return;
   const size_t g = (size_t)b * a.cap_img + slot;
   a.cand[g * 2] = make_float4(e[1], e[2], e[3], e[4]);
   a.cand[g * 2 + 1] = make_float4(e[5], e[6], e[7], 0.f);
   a.keys[g] = ((unsigned long long)score_desc_key(e[6]) << 32) | (unsigned long long)(uint32_t)(A * nc + i);
   a.vals[g] = (uint32_t)slot;
+}
+
+// Cross-class check of the images that hold short-sided boxes (kImgSmall, see the flag table above): every pair (short-sided
+// box T, box B of ANOTHER class) that rbox_pair_well_conditioned does not vouch for goes through the reference's own clip in
+// the reference's argument order (the higher-scored box first, nms_rotated_cuda.cu:44-60), in the coordinates the reference
+// uses (xy + cls * max_wh).  No IoU > thr among them: the classes of the image cannot interact (well-conditioned cross-class
+// pairs have disjoint circles inside their windows: the reference returns exactly 0), its class segments give the reference's
+// kept set.  Otherwise -- or with more than kTinyMax short-sided boxes -- the image keeps the reference's single list.
+// Launched only when the caller's previous call of the shape met such boxes (expected_cand bit 62): grid (kTinyParts, bs),
+// blocks of images without the flag return at once.  Candidates beyond the top-max_nms cut are tested as well: conservative.
+constexpr int kTinyMax = 1024;
+constexpr int kTinyParts = 32;
+__global__ __launch_bounds__(256) void k_tiny_cross(const float4* __restrict__ cand, const unsigned long long* __restrict__ keys,
+                                                    const int* __restrict__ cnt, long long cap_img, float class_offset, float thr,
+                                                    int* __restrict__ tiny) {
+  __shared__ float scr[RotGeom::SCR * 256];                     // clip scratch: one column per thread inside its wave's block
+  __shared__ int s_list[kTinyMax];
+  __shared__ int s_n;
+  const int b = blockIdx.y, part = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  if ((tiny[b] & (kImgSmall | kImgWide)) != kImgSmall) return;
+  long long n = cnt[b * kCntPad];
+  if (n > cap_img) n = cap_img;                                  // (a call that overflowed its slots is repeated by the caller)
+  const size_t base = (size_t)b * cap_img;
+  if (tid == 0) s_n = 0;
+  __syncthreads();
+  for (long long j = tid; j < n; j += 256) {                     // the image's short-sided candidates: every part builds the same set
+    const float4 c0 = cand[(base + j) * 2];
+    const float mn = c0.w < c0.z ? c0.w : c0.z;
+    if (mn >= 0.001f && mn < 1.0f) { const int k = atomicAdd(&s_n, 1); if (k < kTinyMax) s_list[k] = (int)j; }
+  }
+  __syncthreads();
+  const int nt = s_n;
+  if (nt > kTinyMax) return;                                     // not checked: single list
+  if (part == 0 && tid == 0) atomicOr(&tiny[b], kImgChecked);
+  bool hit = false;
+  float* myscr = scr + wv * (RotGeom::SCR * 64) + lane;
+  for (long long j = (long long)part * 256 + tid; j < n; j += (long long)gridDim.x * 256) {
+    const float4 c0 = cand[(base + j) * 2], c1 = cand[(base + j) * 2 + 1];
+    if (fminf(c0.z, c0.w) < 0.001f) continue;                    // dropped by obb_nms (nms_rotated_wrapper.py:32): never a partner
+    const float offB = c1.z * class_offset;
+    const RBoxFeat B = rbox_make_feat(c0.x + offB, c0.y + offB, c0.z, c0.w, c1.x);
+    const unsigned long long kB = keys[base + j];
+    for (int t = 0; t < nt; t++) {
+      const int jt = s_list[t];
+      const float4 t0 = cand[(base + jt) * 2], t1 = cand[(base + jt) * 2 + 1];
+      if (t1.z == c1.z) continue;                                // same class: decided inside the class segment, as in the single list
+      const float offT = t1.z * class_offset;
+      const RBoxFeat T = rbox_make_feat(t0.x + offT, t0.y + offT, t0.z, t0.w, t1.x);
+      if (rbox_pair_well_conditioned(T, B)) continue;            // circles apart (different windows) and well conditioned: exactly 0
+      const unsigned long long kT = keys[base + jt];             // smaller key = sorts first = the row box of the reference's kernel
+      const float v = kT < kB ? rbox_iou<64>(T, B, myscr, myscr + 24 * 64) : rbox_iou<64>(B, T, myscr, myscr + 24 * 64);
+      if (v > thr) hit = true;
+    }
+  }
+  if (__ballot(hit) && lane == 0) atomicOr(&tiny[b], kImgCross);
 }
 
 // per image: sort range, number of positions that take part, mode:
@@ -356,7 +435,7 @@ __global__ void k_cand_segments(const int* __restrict__ cnt, const int* __restri
   const bool over_nms = max_nms > 0 && c > max_nms;
   if (over_nms) c = max_nms;                                 // :845-846 top max_nms by confidence
   img_end[g] = b0 + (int)c;
-  const int m = (class_ok && !over_cap && !tiny[g]) ? (over_nms ? (group_ok ? 2 : 0) : 1) : 0;   // group_ok: the host launches the pass
+  const int m = (class_ok && !over_cap && !img_single_list(tiny[g])) ? (over_nms ? (group_ok ? 2 : 0) : 1) : 0;   // group_ok: the host launches the pass
   mode[g] = m;
   grp_begin[g] = b0; grp_end[g] = (m == 2) ? b0 + (int)c : b0;      // range of the class-grouping pass (empty unless mode 2)
 }
@@ -516,7 +595,7 @@ __global__ __launch_bounds__(1024) void k_sort_prep_lds(const float4* __restrict
   if (c > kSortLdsMax) c = 0;                                  // not this kernel's regime: reported through status[1]
   const bool over_nms = max_nms > 0 && c > max_nms;
   const int e = (int)(over_nms ? max_nms : c);                 // :845-846 top max_nms by confidence
-  const int m = (class_ok && !over_cap && !tiny[g] && !over_nms) ? 1 : 0;
+  const int m = (class_ok && !over_cap && !img_single_list(tiny[g]) && !over_nms) ? 1 : 0;
   const int n = (int)c;
   if (q > 0 && m != 1) return;                                 // one list per image: part 0 does it all
   if (tid == 0 && q == 0) {
@@ -763,9 +842,10 @@ __global__ __launch_bounds__(256) void k_gather_out(const float4* __restrict__ c
                                                     const int* __restrict__ mode, int ncs, long long max_det, float* __restrict__ out,
                                                     int64_t* __restrict__ out_count, const int* __restrict__ cnt, long long cap_img,
                                                     int64_t* __restrict__ status, const int* __restrict__ abort_flag, int packed,
-                                                    const int* __restrict__ info) {
+                                                    const int* __restrict__ info, const int* __restrict__ tiny) {
   __shared__ int s_pre[257], s_seg[256];
   __shared__ long long s_rows[4], s_mx[4];
+  __shared__ int s_tf[4];
   __shared__ unsigned long long s_key[kMergeLds];
   __shared__ uint32_t s_val[kMergeLds];
   const int g = blockIdx.x, tid = threadIdx.x;
@@ -784,6 +864,7 @@ __global__ __launch_bounds__(256) void k_gather_out(const float4* __restrict__ c
   if (tid == 0) s_pre[0] = 0;
   // (packed) rows of the images before this one; (workgroup 0) the largest candidate count -- same round trip as above
   long long mine = 0, mx = 0;
+  int tf = 0;
   if (packed) {
     for (int b2 = tid; b2 < g; b2 += 256) {
       long long t = 0;
@@ -793,10 +874,10 @@ __global__ __launch_bounds__(256) void k_gather_out(const float4* __restrict__ c
     }
   }
   if (g == 0)
-    for (int b2 = tid; b2 < (int)gridDim.x; b2 += 256) { const long long c = cnt[b2 * kCntPad]; if (c > mx) mx = c; }
+    for (int b2 = tid; b2 < (int)gridDim.x; b2 += 256) { const long long c = cnt[b2 * kCntPad]; if (c > mx) mx = c; tf |= tiny[b2] & kImgSmall; }
 #pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) { mine += __shfl_xor(mine, d); const long long o = __shfl_xor(mx, d); if (o > mx) mx = o; }
-  if ((tid & 63) == 0) { s_rows[tid >> 6] = mine; s_mx[tid >> 6] = mx; }
+  for (int d = 32; d >= 1; d >>= 1) { mine += __shfl_xor(mine, d); const long long o = __shfl_xor(mx, d); if (o > mx) mx = o; tf |= __shfl_xor(tf, d); }
+  if ((tid & 63) == 0) { s_rows[tid >> 6] = mine; s_mx[tid >> 6] = mx; s_tf[tid >> 6] = tf; }
   __syncthreads();
   if (tid == 0) for (int c = 0; c < ncs; c++) s_pre[c + 1] += s_pre[c];
   __syncthreads();
@@ -815,7 +896,9 @@ __global__ __launch_bounds__(256) void k_gather_out(const float4* __restrict__ c
     // info[8] != 0: k_nms_small met a segment above its limit -- nothing of this call is valid, the caller repeats it with
     // the persistent kernel (status[0] = -1); info[4]: the largest NMS segment where the sort kernel knew it (else 0)
     status[0] = info[8] ? -1 : (m4 > cap_img ? m4 : 0);
-    status[1] = m4 | ((long long)(info[8] > info[4] ? info[8] : info[4]) << 32);
+    // bit 62: an image of this call held short-sided boxes (kImgSmall) -- the caller's next call asks for k_tiny_cross
+    const long long small_seen = (s_tf[0] | s_tf[1] | s_tf[2] | s_tf[3]) ? (1ll << 62) : 0ll;
+    status[1] = m4 | (((long long)(info[8] > info[4] ? info[8] : info[4]) & 0x3fffffffll) << 32) | small_seen;
   }
   // first output row of the image: g * max_det, or (packed) the number of rows of the images before it
   const long long row0 = packed ? s_rows[0] + s_rows[1] + s_rows[2] + s_rows[3] : (long long)g * max_det;
@@ -914,13 +997,15 @@ static int run_nms_obb(const void* pred, const void* objcol, int dtype, int64_t 
   if (dtype != 0 && dtype != 1) return OBB_ERR_BAD_ARG;
   // expected_cand: low 32 bits = the previous call's largest candidate count of an image (0: unknown), high 32 bits = its
   // largest NMS segment (0: unknown) -- both as status[1] reported them
-  const int64_t seg_hint = (expected_cand >> 32) & 0x7fffffff;
+  const int64_t seg_hint = (expected_cand >> 32) & 0x3fffffff;
+  const bool small_hint = ((expected_cand >> 62) & 1) != 0;        // the previous call met short-sided boxes: run k_tiny_cross
   expected_cand &= 0xffffffffll;
   cap_img = round_cap(cap_img);
   const int ncs = agnostic ? 1 : nc;                               // NMS segments per image
   // class segmentation needs the class in 8 and the anchor index in 24 key bits
   static const int no_class_seg = obb_dev_switch("OBB_NO_CLASS_SEG", 0) != 0;    // A/B switch (development builds)
-  const int class_ok = (!no_class_seg && !agnostic && nc > 1 && A + n_extra < (1ll << 24)) ? 1 : 0;
+  // (iou_thres < 0: IoU = 0 > thr, boxes of different classes DO suppress each other in the reference's single list)
+  const int class_ok = (!no_class_seg && !agnostic && nc > 1 && A + n_extra < (1ll << 24) && iou_thres >= 0.f && max_wh > 0.f) ? 1 : 0;
   // the class-grouping pass for images with more than max_nms candidates is only worth launching when such images are expected
   // (off by default: per-class segments cannot share the max_det early stop of the single list, which usually ends the
   //  NMS of such images after the first ~2000 of 30000 candidates; OBB_NMS_GROUP_AFTER_CUT=1 enables it)
@@ -941,6 +1026,7 @@ static int run_nms_obb(const void* pred, const void* objcol, int dtype, int64_t 
     if (c >= 0 && c < 256) d.cm.w[c >> 6] |= 1ull << (c & 63);
   }
   d.cap_img = cap_img; d.cand = cv.cand; d.keys = cv.keys_a; d.vals = cv.vals_a; d.cnt = cv.cnt; d.tiny = cv.tiny;
+  d.win_lo = -0.35f * max_wh; d.win_hi = 0.6f * max_wh;            // 0.95 max_wh wide: circles of different classes cannot touch
 
   static const int no_lds_sort = obb_dev_switch("OBB_NO_LDS_SORT", 0) != 0;      // A/B switch (development builds)
   const bool lds_sort = !no_lds_sort && expected_cand > 0 && expected_cand <= kSortLdsHint && !group_ok;
@@ -961,6 +1047,8 @@ static int run_nms_obb(const void* pred, const void* objcol, int dtype, int64_t 
     else k_decode<__half><<<gd, kDecThreads, 0, st>>>(d);
   }
   if (n_extra > 0 && extra8) k_append_extra<<<(unsigned)((n_extra + 255) / 256), 256, 0, st>>>(extra8, (int)n_extra, A, nc, d);
+  if (small_hint && class_ok)
+    k_tiny_cross<<<dim3(kTinyParts, (unsigned)bs), 256, 0, st>>>(cv.cand, cv.keys_a, cv.cnt, cap_img, max_wh, iou_thres, cv.tiny);
   const unsigned gs = (unsigned)((bs + 255) / 256);
   Carve& nv = cv.nms;
   const int64_t max_seg = (max_nms > 0 && max_nms < cap_img) ? max_nms : cap_img;
@@ -1069,7 +1157,7 @@ static int run_nms_obb(const void* pred, const void* objcol, int dtype, int64_t 
     // parts per image: one up to ~2k expected candidates (the kept rows fit the kernel's LDS and 256 threads), then one per 1024
     const unsigned gparts = expected_cand <= 2048 ? 1u : (unsigned)((expected_cand + 1023) / 1024 > 16 ? 16 : (expected_cand + 1023) / 1024);
     k_gather_out<<<dim3((unsigned)bs, gparts), 256, 0, st>>>(cv.cand, cv.vals_b, cv.keys_b, cv.keep, nv.seg_begin, nv.keep_cnt, cv.mode, ncs, max_det,
-                                              out, out_count, cv.cnt, cap_img, status, nv.abort_flag, out_packed, cv.ticket);
+                                              out, out_count, cv.cnt, cap_img, status, nv.abort_flag, out_packed, cv.ticket, cv.tiny);
   }
   return hipGetLastError() == hipSuccess ? OBB_OK : OBB_ERR_LAUNCH;
 }

@@ -202,10 +202,38 @@ struct ShapeMemo {
   int64_t cand = OBB_NMS_SORT_LDS_HINT;        // largest candidate count of an image in the previous call: the sort hint.  No history:
                                                // the regime of the reference's default thresholds (a few thousand candidates per image)
   int64_t seg = 1;                             // largest NMS segment of the previous call: chooses the NMS kernel (no history: small)
+  bool small_boxes = false;                    // the previous call met boxes with a sub-pixel side: the next one runs the cross-class check
   int hold_seg = 0, hold_cand = 0;             // > 0: a call was repeated because its hint undersold it -- keep the larger regime this
                                                // many calls unless the batch falls clearly (25 %) below the limit: a stream whose
                                                // batches hover around a limit does not pay the repeat on every other batch
 };
+
+std::map<ShapeKey, ShapeMemo>& shape_memos() {            // per calling thread: other threads' batches say nothing about this one's
+  static thread_local std::map<ShapeKey, ShapeMemo> memos;
+  return memos;
+}
+uint32_t conf_key(double conf_thres) {
+  const float f = (float)conf_thres;
+  uint32_t b;
+  std::memcpy(&b, &f, 4);
+  return b;
+}
+// Introspection of the hint memo (tests, tools): the state of a shape, forcing a hint, forgetting everything.
+void hints_clear() { shape_memos().clear(); }
+py::object hint_get(int dev, int64_t A, int64_t nc, bool multi, double conf_thres) {
+  auto& m = shape_memos();
+  auto it = m.find(ShapeKey{dev, A, nc, multi, conf_key(conf_thres)});
+  if (it == m.end()) return py::none();
+  py::dict d;
+  d["cap"] = it->second.cap; d["cand"] = it->second.cand; d["seg"] = it->second.seg;
+  d["hold_cand"] = it->second.hold_cand; d["hold_seg"] = it->second.hold_seg; d["small_boxes"] = it->second.small_boxes;
+  return std::move(d);
+}
+void hint_set(int dev, int64_t A, int64_t nc, bool multi, double conf_thres, int64_t cand, int64_t seg) {
+  ShapeMemo& e = shape_memos()[ShapeKey{dev, A, nc, multi, conf_key(conf_thres)}];
+  if (cand >= 0) { e.cand = cand; e.hold_cand = 0; }
+  if (seg >= 0) { e.seg = seg; e.hold_seg = 0; }
+}
 
 std::vector<at::Tensor> non_max_suppression_obb(const at::Tensor& prediction, double conf_thres, double iou_thres,
                                                 const c10::optional<std::vector<int64_t>>& classes, bool agnostic, bool multi_label,
@@ -257,12 +285,9 @@ std::vector<at::Tensor> non_max_suppression_obb(const at::Tensor& prediction, do
       col_p = c.data_ptr();
   }
 
-  static thread_local std::map<ShapeKey, ShapeMemo> memos;
   static thread_local std::map<std::tuple<int64_t, int64_t, int64_t, int, bool>, size_t> ws_memo;
   const float conf_f = (float)conf_thres;
-  uint32_t conf_bits;
-  std::memcpy(&conf_bits, &conf_f, 4);
-  ShapeMemo& memo = memos[ShapeKey{(int)dev.index(), A, nc, multi, conf_bits}];
+  ShapeMemo& memo = shape_memos()[ShapeKey{(int)dev.index(), A, nc, multi, conf_key(conf_thres)}];
   const int64_t worst = A * (multi ? nc : 1) + n_extra;
   int64_t cap = std::min(worst, std::max<int64_t>(memo.cap, 65536));
 
@@ -273,7 +298,7 @@ std::vector<at::Tensor> non_max_suppression_obb(const at::Tensor& prediction, do
   AbortRetry retry;
   int64_t seg_max = 0, cand_max = 0;
   for (;;) {
-    const int64_t hint = memo.cand, seg_hint = memo.seg;
+    const int64_t hint = memo.cand & 0xffffffffll, seg_hint = memo.seg & 0x3fffffffll;
     const auto wkey = std::make_tuple(bs, cap, nc, (int)agnostic, retry.capped);
     auto it = ws_memo.find(wkey);
     if (it == ws_memo.end()) it = ws_memo.emplace(wkey, api.obb_nms_obb_workspace_bytes(bs, cap, nc, agnostic ? 1 : 0)).first;
@@ -281,7 +306,8 @@ std::vector<at::Tensor> non_max_suppression_obb(const at::Tensor& prediction, do
     arm(meta);
     const int rc = api.obb_non_max_suppression_obb_col(pred.data_ptr(), col_p, dtype, bs, A, no, conf_f, (float)iou_thres, cls.empty() ? nullptr : cls.data(),
                                                        (int)cls.size(), agnostic ? 1 : 0, multi ? 1 : 0, max_det, kMaxNms, (float)kMaxWh, extra_p, n_extra, cap,
-                                                       hint | (seg_hint << 32), out.data_ptr<float>(), 1, meta.p, meta.p + bs, ws.data_ptr(), (size_t)ws.numel(),
+                                                       hint | (seg_hint << 32) | (memo.small_boxes ? (int64_t(1) << 62) : 0), out.data_ptr<float>(), 1, meta.p, meta.p + bs,
+                                                       ws.data_ptr(), (size_t)ws.numel(),
                                                        stream.stream());
     check(rc, "obb_non_max_suppression_obb");
     {
@@ -289,8 +315,9 @@ std::vector<at::Tensor> non_max_suppression_obb(const at::Tensor& prediction, do
       wait_words(meta, stream);
     }
     const int64_t st0 = meta.p[bs], st1 = meta.p[bs + 1];
-    seg_max = st1 >> 32;
+    seg_max = (st1 >> 32) & 0x3fffffffll;
     cand_max = st1 & 0xffffffffll;
+    memo.small_boxes = ((st1 >> 62) & 1) != 0;
     if (st0 == -1) {                                                   // a segment above the small kernel's limit: nothing is valid
       memo.seg = std::max<int64_t>(seg_max, OBB_NMS_SMALL_SEG + 1);
       memo.hold_seg = kHold;
@@ -488,5 +515,9 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("non_max_suppression_obb", &non_max_suppression_obb, py::arg("prediction"), py::arg("conf_thres") = 0.25, py::arg("iou_thres") = 0.45,
         py::arg("classes") = py::none(), py::arg("agnostic") = false, py::arg("multi_label") = false, py::arg("extra") = py::none(),
         py::arg("max_det") = 1500, py::arg("objcol") = py::none());
+  m.def("hints_clear", &hints_clear, "forget the hint memo of the calling thread");
+  m.def("hint_get", &hint_get, py::arg("device_index"), py::arg("A"), py::arg("nc"), py::arg("multi_label"), py::arg("conf_thres"));
+  m.def("hint_set", &hint_set, py::arg("device_index"), py::arg("A"), py::arg("nc"), py::arg("multi_label"), py::arg("conf_thres"),
+        py::arg("cand") = -1, py::arg("seg") = -1);
   m.def("val_tail_batch", &val_tail_batch, py::arg("preds"), py::arg("targets"), py::arg("shapes"), py::arg("iouv"), py::arg("want_boxes") = false);
 }

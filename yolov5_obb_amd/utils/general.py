@@ -33,6 +33,52 @@ _seg_memo = {}          # same key -> largest NMS segment (an image's class) of 
 _SEG_SMALL = 384        # workgroup-per-segment kernel of csrc/nms_small.h takes segments up to this size; 0 = unknown: the persistent one)
 
 
+_small_memo = {}        # same key -> the previous call met boxes with a sub-pixel side (status[1] bit 62): the next call runs k_tiny_cross
+
+
+def _key(dev_index, A, nc, multi, conf_thres):
+    # per device, calling thread and confidence threshold: other callers' batches say nothing about this one's
+    return (dev_index, threading.get_ident(), int(A), int(nc), bool(multi), float(conf_thres))
+
+
+def hints_clear():
+    """Forget what earlier calls learned about their shapes (tests, tools)."""
+    for d in (_cap_memo, _cand_memo, _seg_memo, _hold, _small_memo):
+        d.clear()
+    ext = _lib.compiled()
+    if ext is not None:
+        ext.hints_clear()
+
+
+def hint_get(device, A, nc, multi_label, conf_thres):
+    """The hint state of a shape on the active binding: dict(cand=, seg=, cap=, small_boxes=) or None."""
+    idx = torch.device(device).index
+    idx = torch.cuda.current_device() if idx is None else idx
+    ext = _lib.compiled()
+    if ext is not None:
+        return ext.hint_get(idx, int(A), int(nc), bool(multi_label), float(conf_thres))
+    key = _key(idx, A, nc, multi_label, conf_thres)
+    if key not in _cand_memo and key not in _seg_memo:
+        return None
+    return {"cand": _cand_memo.get(key, _SORT_LDS_HINT), "seg": _seg_memo.get(key, 1), "cap": _cap_memo.get(key, 0),
+            "small_boxes": bool(_small_memo.get(key, False))}
+
+
+def hint_set(device, A, nc, multi_label, conf_thres, cand=None, seg=None):
+    """Force the hints of the next call of a shape (cand = 0: the generic sort; seg = 1: the small-segment kernel)."""
+    idx = torch.device(device).index
+    idx = torch.cuda.current_device() if idx is None else idx
+    ext = _lib.compiled()
+    if ext is not None:
+        ext.hint_set(idx, int(A), int(nc), bool(multi_label), float(conf_thres), -1 if cand is None else int(cand), -1 if seg is None else int(seg))
+        return
+    key = _key(idx, A, nc, multi_label, conf_thres)
+    if cand is not None:
+        _cand_memo[key] = int(cand); _hold[key, "cand"] = 0
+    if seg is not None:
+        _seg_memo[key] = int(seg); _hold[key, "seg"] = 0
+
+
 def _label_rows(labels, bs, nc, device):
     """Apriori labels for autolabelling (utils/general.py:807-813) as candidate rows [img, x, y, l, s, theta, conf, cls]:
     obj = 1, one-hot class = 1 -> conf = 1; the CSL part of such a row is all zeros -> arg-max bin 0 -> theta = -90/180*pi."""
@@ -125,8 +171,7 @@ def non_max_suppression_obb(prediction, conf_thres=0.25, iou_thres=0.45, classes
         n_cls = 0
 
     worst = A * (nc if multi else 1) + n_extra
-    # per device, calling thread and confidence threshold: other callers' batches say nothing about this one's
-    key = (dev.index, threading.get_ident(), A, nc, multi, float(conf_thres))
+    key = _key(dev.index, A, nc, multi, conf_thres)
     cap = min(worst, max(_cap_memo.get(key, 0), 65536))
     L = _lib.lib()
     max_det = int(max_det)
@@ -164,7 +209,8 @@ def non_max_suppression_obb(prediction, conf_thres=0.25, iou_thres=0.45, classes
                 rc = L.obb_non_max_suppression_obb_col(
                     _lib.ptr(pred), _lib.ptr(col), dtype, bs, A, no, float(conf_thres), float(iou_thres),
                     C.cast(cls_arr, C.c_void_p) if cls_arr is not None else C.c_void_p(0), n_cls, agn, int(multi),
-                    max_det, _MAX_NMS, float(_MAX_WH), _lib.ptr(extra), n_extra, cap, hint | (seg_hint << 32), _lib.ptr(out), 1, _lib.ptr(meta),
+                    max_det, _MAX_NMS, float(_MAX_WH), _lib.ptr(extra), n_extra, cap,
+                    (hint & 0xffffffff) | ((seg_hint & 0x3fffffff) << 32) | ((1 << 62) if _small_memo.get(key) else 0), _lib.ptr(out), 1, _lib.ptr(meta),
                     C.c_void_p(meta.data_ptr() + 8 * bs), _lib.ptr(ws), ws.numel(), C.c_void_p(st))
             _lib.check(rc, "obb_non_max_suppression_obb")
             if meta_np is not None:                                   # every entry is one aligned 8-byte store of the last kernel
@@ -179,7 +225,8 @@ def non_max_suppression_obb(prediction, conf_thres=0.25, iou_thres=0.45, classes
                 m = meta_np.tolist()
             else:
                 m = meta.tolist()                                     # the single device->host sync of the call
-            seg_max, m[bs + 1] = m[bs + 1] >> 32, m[bs + 1] & 0xffffffff       # status[1]: largest segment | largest candidate count
+            _small_memo[key] = bool((m[bs + 1] >> 62) & 1)                    # status[1]: bit 62 = boxes with a sub-pixel side were met,
+            seg_max, m[bs + 1] = (m[bs + 1] >> 32) & 0x3fffffff, m[bs + 1] & 0xffffffff       # largest segment | largest candidate count
             if m[bs] == -1:                                           # a segment above the small kernel's limit: nothing is valid
                 _seg_memo[key] = max(int(seg_max), _SEG_SMALL + 1)
                 _hold[key, "seg"] = _HOLD

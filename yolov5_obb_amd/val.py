@@ -185,8 +185,12 @@ def val_tail_batch(preds, targets, shapes, iouv, want_boxes=False):
                     part(host, niou + 2), C.c_void_p(ws.data_ptr()), ws.numel(), C.c_void_p(st), C.c_void_p(flag.data_ptr()))
                 _lib.check(rc, "obb_val_tail_batch_f32")
                 _lib.wait_count(flag_np, dev)                    # every row of this chunk is in `host`
-    host = host.clone()                                          # (the pinned buffer is reused by the next batch)
-    correct = (host[:, :niou] > 0.5).split(counts)
+    # (the pinned buffer is reused by the next batch.  Copy and compare through numpy, single-threaded: a torch CPU op on these
+    #  ~44k elements fans out to the whole intra-op pool -- 128 OpenMP workers on the GPU boxes -- whose spinning uses up the
+    #  container's CPU quota: the kernel then parks the process for the rest of the 100 ms period, profiles/r5_host_stall.md)
+    arr = host.numpy().copy()
+    host = torch.from_numpy(arr)
+    correct = torch.from_numpy(arr[:, :niou] > 0.5).split(counts)
     conf = host[:, niou].split(counts)
     pcls = host[:, niou + 1].split(counts)
     out = list(zip(correct, conf, pcls))
