@@ -514,7 +514,7 @@ def main():
     del preds[1:]
     torch.cuda.empty_cache()
     extras = rank == 0 and not args.no_extras
-    nc15_obj = nc2_obj = tta_obj = None
+    nc15_obj = nc2_obj = tta_obj = dense_obj = None
     if extras:
         try:
             p15 = synth.s_pred(bs, A, 15, seed=2000, n_obj=120, fg_frac=0.03, device=dev, dtype=torch.float16)
@@ -527,6 +527,23 @@ def main():
             nc2_obj = {"workload": "BASELINE configs[4] shape: DroneVehicle batch (16, 64512, 187) fp16, nc = 2, speed-task thresholds (one tensor, warm)",
                        "ms_per_batch": round(ms2, 4), "img_per_s": round(bs / (ms2 * 1e-3), 1), "detections": nd2}
             del p2
+            # the regime of the conv stand-in's val loop: thousands of candidates per image of which most are
+            # KEPT, every image at max_det -- 4000 planted objects per image, ~1 passing anchor each (tests/test_nmsobb_gpu.py::
+            # test_dense_mostly_kept_regime_matches_the_oracle is the parity test of this generator)
+            pdk = synth.s_pred(bs, A, nc, seed=2003, n_obj=4000, fg_frac=0.08, device=dev, dtype=torch.float16)
+            for _ in range(3):
+                non_max_suppression_obb(pdk, **kw)
+            L.obb_profile_enable(1)
+            msdk, nddk = time_nmsobb(pdk, kw)
+            pmd, pcd = collect_profile(L)
+            L.obb_profile_enable(0)
+            with torch.no_grad():
+                cdk = int((((pdk[..., 5:5 + nc] * pdk[..., 4:5]) > kw["conf_thres"]) & (pdk[..., 4:5] > kw["conf_thres"])).sum()) // bs
+            dense_obj = {"workload": "(16, 64512, 201) fp16 with 4000 planted objects per image: thousands of candidates per image, most kept, every image at max_det "
+                                     "(the regime of val_buckets' random-init heads), speed-task thresholds (one tensor, warm)",
+                         "ms_per_batch": round(msdk, 4), "img_per_s": round(bs / (msdk * 1e-3), 1), "candidates_per_image": cdk, "detections": nddk,
+                         "stages_ms": {n_: round(pmd[i_] / max(1, pcd[i_]), 4) for i_, n_ in enumerate(("decode", "sort", "prep", "nms_kernel", "gather"))}}
+            del pdk
             ptta = synth.s_pred(1, 114627, 18, seed=2001, n_obj=300, fg_frac=0.05, device=dev, dtype=torch.float16)
             kw_tta = dict(conf_thres=0.01, iou_thres=0.4, multi_label=True, max_det=1500)
             mstta, ndtta = time_nmsobb(ptta, kw_tta)
@@ -918,7 +935,7 @@ def main():
                     "note": "kernel time from the rocprofv3 kernel trace in profiles/ (the bench times ComputeLoss fwd+bwd as a whole)"},
             },
             "pmc_source": pmc.get("_file"),
-            "nms_100k": nms_obj, "nmsobb_nc15": nc15_obj, "nmsobb_nc2": nc2_obj, "nmsobb_tta": tta_obj, "polygon_paths": poly_obj,
+            "nms_100k": nms_obj, "nmsobb_nc15": nc15_obj, "nmsobb_nc2": nc2_obj, "nmsobb_dense_kept": dense_obj, "nmsobb_tta": tta_obj, "polygon_paths": poly_obj,
             "loss": loss_obj, "detect": detect_obj, "detect_nms_chain": coupled_obj, "next_rows": next_rows,
             "cpu_baseline": cpu,
             "parity_unpinned": ["poly2rbox against cv2.minAreaRect (utils/rboxs_utils.py:39-81: OpenCV is not in this image; without it the minimum-area rectangle is computed natively and the function is property-tested, tests/test_poly2rbox_props.py)",

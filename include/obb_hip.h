@@ -104,8 +104,11 @@ int obb_nms_rotated_f64(const double* dets5, const double* scores, int64_t n, fl
  * utils/nms_rotated/src/poly_nms_cuda.cu:197-261).  Rows are x1 y1 x2 y2 x3 y3 x4 y4 score (+ ignored extra
  * columns): row_stride >= 9 floats.  Kept set = the reference's greedy scan over devPolyIoU (poly_nms_cuda.cu:26-142).  Pairs whose
  * bounding boxes are disjoint AND whose areas outweigh the rounding noise of the reference's origin-based sum (a bound of
- * 1024 * 2^-24 * M^2 per box, M = its largest |coordinate|) are not clipped; the environment variable
- * OBB_NMS_POLY_STRICT=1 makes the call clip every pair.
+ * 1024 * 2^-24 * M^2 per box, M = its largest |coordinate|) are not clipped.  That bound is backed by search
+ * (2.8 * 10^10 skip decisions, none wrong), not by proof, and is only applied inside the envelope the search covered: a quad with
+ * every |coordinate| <= 70,000 and a bounding box of at most 600 x 600; any other quad is decided by the proved rule (the second
+ * quad's cone counter-clockwise of the first's: all 16 terms exactly zero) or clipped like the reference does.
+ * OBB_NMS_POLY_STRICT=1 keeps only the proved rule, =2 clips every pair.
  */
 int obb_nms_poly_f32(const float* polys, int64_t row_stride, int64_t n, float iou_thr, int64_t max_keep, int64_t* keep_out,
                      int64_t* num_keep, void* ws, size_t ws_bytes, void* stream);
@@ -201,16 +204,26 @@ int64_t obb_task1_format_rows(const char* text_host, const int32_t* name_off_hos
  *               csrc/segsort.h / csrc/psrs_sort.h.  The in-LDS sort takes at most OBB_NMS_SORT_LDS_MAX candidates of an image:
  *               with a hint in 1 .. OBB_NMS_SORT_LDS_HINT and status[1] (low word) > OBB_NMS_SORT_LDS_MAX after the call, such
  *               images were left EMPTY -- call again with that count as the hint (the Python layer does).
- *               bits 32..62 the largest NMS segment (boxes of one class of one image).  1 .. OBB_NMS_SMALL_SEG together with the
+ *               bits 32..60 the largest NMS segment (boxes of one class of one image).  1 .. OBB_NMS_SMALL_SEG together with the
  *               in-LDS sort and iou_thres >= 0 selects the one-workgroup-per-segment NMS kernel (csrc/nms_small.h); a call that
  *               meets a larger segment there sets status[0] = -1: NOTHING of its output is valid, call again with the
  *               segment size status[1] reports (the Python layer does).  0 or larger: the persistent kernel.
- *               Apart from these two retry cases the result does not depend on the hint.
+ *               bit 62      the previous call met boxes with a short side in [0.001, 1) px (status[1] bit 62).  The reference's fp32
+ *               clip is ill conditioned for such a box against a partner tens of thousands of pixels away, i.e. across its
+ *               cls * max_wh offsets (utils/general.py:849-851), so an image holding one may only keep its per-class NMS segments if
+ *               no such pair has IoU > iou_thres.  With the bit set the call checks exactly that (k_tiny_cross: the reference's own
+ *               clip on every ill-conditioned cross-class pair; images with at most 32 such boxes and 65536 box x candidate
+ *               combinations: the stray sub-pixel box of a trained detector, ~80 us at most) and keeps the class segments of every
+ *               image that passes; without it -- and for an image that fails, is above those bounds, or holds a box whose circle
+ *               leaves a 0.95 max_wh window -- the image runs as the reference's single list.  Either way the rows are the reference's.
+ *               Apart from the two retry cases the result does not depend on the hint.
  *   out         [bs][max_det][7] fp32 rows [x y l s theta conf cls];  out_count [bs] int64 (-1: device-side abort);
  *               out_packed != 0: the rows of image b start right behind those of image b-1 (row sum(out_count[0..b-1]))
  *               instead of at row b*max_det -- the same buffer size is required, one split instead of bs slices on the host
  *               status [2] int64: [0] overflow count (see cap_img), or -1 (see expected_cand); [1] largest candidate count of any
- *               image in bits 0..31, largest NMS segment in bits 32..62 (0 where the sort path does not know it)
+ *               image in bits 0..31, largest NMS segment in bits 32..60 (0 where the sort path does not know it), bit 62: an image
+ *               held boxes with a sub-pixel short side -- hand these back as expected_cand of the next call of the shape; bit 61
+ *               (informational, masked out of the hint): such an image kept its class segments in this call
  *               out_count and status are written with plain 8-byte stores by the last kernel of the call: they may live in
  *               device memory or in pinned host memory (hipHostMalloc) that the caller polls instead of copying back
  * Score ties are ordered by ascending (anchor*nc + class): deterministic, where the reference inherits the order
@@ -337,7 +350,7 @@ int obb_rbox2poly_f32(const float* rboxes, int64_t n, int64_t row_stride, float*
 int obb_val_postprocess_f32(const float* det7, int64_t n, float pad_x, float pad_y, float gain, float* poly10, float* hbb6,
                             float* polyn10, float* hbbn6, void* stream);
 
-/* The same tail for ALL images of a batch in three launches (val.py:209-250 is a per-image loop): det7 = the packed (N,7)
+/* The same tail for ALL images of a batch in two launches (val.py:209-250 is a per-image loop): det7 = the packed (N,7)
  * detections of the batch, image b's rows at [det_off_host[b], det_off_host[b+1]) (bs + 1 host integers, det_off_host[0] = 0,
  * bs <= 64); targets = the batch's labels on the device, (nt, tcols >= 7) rows [img cls cx cy l s theta ...] in pixels of the
  * letterboxed frame (the collate format); img5_host = bs x {pad_x, pad_y, gain, native width, native height} (shapes[si] of

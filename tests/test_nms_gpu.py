@@ -308,6 +308,29 @@ def test_nms_poly_strict_equals_skip_100k(dev, tmp_path):
         assert len(res["0"][k]) > 100
 
 
+def test_nms_poly_fresh_seed_every_rule_against_no_rule(dev, tmp_path):
+    """Rule B of the quad NMS is a searched bound, used only inside the envelope the search covered
+    (csrc/piou_device.h: |coordinate| <= 70,000, bounding box <= 600 x 600).  Every run of the suite extends the search: 30,000
+    quads of six adversarial families ON BOTH SIDES of the envelope, drawn from a FRESH seed (printed; pass OBB_TEST_SEED to
+    repeat one), through the library with both rules (default), with the proved rule only (OBB_NMS_POLY_STRICT=1) and with no
+    rule at all (=2: every pair clipped, as the reference does), at three thresholds: identical kept lists."""
+    import subprocess
+    import sys
+    import time
+    seed = int(os.environ.get("OBB_TEST_SEED", int(time.time()) % 1000000007))
+    print(f"fresh seed of this run: {seed}")
+    helper = os.path.join(os.path.dirname(os.path.abspath(__file__)), "helpers", "poly_strict_vs_skip.py")
+    res = {}
+    for strict in ("0", "1", "2"):
+        out = str(tmp_path / f"fresh_{strict}.npz")
+        subprocess.run([sys.executable, helper, out, "fresh", str(seed)], check=True, env=dict(os.environ, OBB_NMS_POLY_STRICT=strict), timeout=900)
+        res[strict] = np.load(out)
+    for k in res["2"].files:
+        assert len(res["2"][k]) > 1000, (seed, k)
+        assert np.array_equal(res["0"][k], res["2"][k]), f"seed {seed}, {k}: rules A + B differ from the clip of every pair"
+        assert np.array_equal(res["1"][k], res["2"][k]), f"seed {seed}, {k}: rule A differs from the clip of every pair"
+
+
 def test_ops_rbox_overlaps_device_tensors(dev, oracle_lib):
     """ops.rbox_overlaps -> obb_rbox_overlaps_f32 (the device-pointer form of the devkit's overlaps_kernel,
     poly_overlaps_kernel.cu:280-353): same matrix as the host-pointer `_overlaps`, bit for bit, and as the oracle.  The one

@@ -255,21 +255,25 @@ def mergebase_parallel(srcpath, dstpath, nms):
         mergesingle(dstpath, nms, files[i])
 
 
-def mergebyrec(srcpath, dstpath):
-    """:251-263: mergebase with py_cpu_nms."""
-    if os.path.exists(dstpath):
-        shutil.rmtree(dstpath)
-    os.makedirs(dstpath)
-    mergebase(srcpath, dstpath, py_cpu_nms)
-
-
-def mergebypoly(srcpath, dstpath):
-    """:265-281."""
-    rank, _ = shard.world()
+def _fresh_dir_on_rank0(dstpath):
+    """The reference deletes and recreates dstpath (:253-256, :267-270); under a multi-rank launch only rank 0 may, and the others
+    wait until it is done (every rank writes its own class files into it afterwards)."""
+    rank, world = shard.world()
     if rank == 0:
         if os.path.exists(dstpath):
             shutil.rmtree(dstpath)
         os.makedirs(dstpath)
-    if shard.world()[1] > 1:
+    if world > 1:
         torch.distributed.barrier()
+
+
+def mergebyrec(srcpath, dstpath):
+    """:251-263: mergebase with py_cpu_nms.  Class files are split over the ranks like mergebypoly's (one process: all of them)."""
+    _fresh_dir_on_rank0(dstpath)
+    mergebase_parallel(srcpath, dstpath, py_cpu_nms)
+
+
+def mergebypoly(srcpath, dstpath):
+    """:265-281."""
+    _fresh_dir_on_rank0(dstpath)
     mergebase_parallel(srcpath, dstpath, py_cpu_nms_poly_fast)

@@ -489,7 +489,7 @@ __global__ void k_pb_correct(const int* __restrict__ best_label, const float* __
 }
 
 
-// ---- the tail for ALL images of a batch (val.py:209-250): three launches and one device -> host copy per batch instead of
+// ---- the tail for ALL images of a batch (val.py:209-250): two launches (round 4: three) and one device -> host copy per batch instead of
 // two launches + a memset + three copies per image.
 constexpr int kValTailMaxBs = 64;
 struct ValTailImgs {                       // by value in the kernel arguments (bs <= kValTailMaxBs)
@@ -497,33 +497,26 @@ struct ValTailImgs {                       // by value in the kernel arguments (
   float pad_x[kValTailMaxBs], pad_y[kValTailMaxBs], gain[kValTailMaxBs], shape_w[kValTailMaxBs], shape_h[kValTailMaxBs];
   int bs;
 };
-// labels (val.py:238-241, in the reference's operation order): rbox2poly -> poly2hbb -> xywh2xyxy in the letterboxed frame,
+// a label's box (val.py:238-241, in the reference's operation order): rbox2poly -> poly2hbb -> xywh2xyxy in the letterboxed frame,
 // THEN scale_coords: subtract the pad, divide by the gain, clip to the native shape (utils/general.py:621-633) -> [x1 y1 x2 y2]
-__global__ void k_vt_labels(const float* __restrict__ targets, int nt, int tcols, ValTailImgs im, float* __restrict__ lab4,
-                            int* __restrict__ winner) {
-  const int l = blockIdx.x * blockDim.x + threadIdx.x;
-  if (l >= nt) return;
-  const float* t = targets + (size_t)l * tcols;               // [img cls cx cy l s theta ...]
-  const int b = (int)t[0];
-  float p[8], o[4] = {0.f, 0.f, 0.f, 0.f};
-  if (b >= 0 && b < im.bs) {
-    vt_rbox2poly(t[2], t[3], t[4], t[5], t[6], p);
-    vt_hbb_xyxy(p, o);
-    o[0] -= im.pad_x[b]; o[2] -= im.pad_x[b]; o[1] -= im.pad_y[b]; o[3] -= im.pad_y[b];
+__device__ __forceinline__ void vt_label_box(const float* t, const ValTailImgs& im, int b, float* o) {
+  float p[8];
+  vt_rbox2poly(t[2], t[3], t[4], t[5], t[6], p);                // t = [img cls cx cy l s theta ...]
+  vt_hbb_xyxy(p, o);
+  o[0] -= im.pad_x[b]; o[2] -= im.pad_x[b]; o[1] -= im.pad_y[b]; o[3] -= im.pad_y[b];
 #pragma unroll
-    for (int k = 0; k < 4; k++) o[k] /= im.gain[b];
-    o[0] = fminf(fmaxf(o[0], 0.f), im.shape_w[b]); o[2] = fminf(fmaxf(o[2], 0.f), im.shape_w[b]);
-    o[1] = fminf(fmaxf(o[1], 0.f), im.shape_h[b]); o[3] = fminf(fmaxf(o[3], 0.f), im.shape_h[b]);
-  }
-#pragma unroll
-  for (int k = 0; k < 4; k++) lab4[(size_t)l * 4 + k] = o[k];
-  winner[l] = 0x7fffffff;
+  for (int k = 0; k < 4; k++) o[k] /= im.gain[b];
+  o[0] = fminf(fmaxf(o[0], 0.f), im.shape_w[b]); o[2] = fminf(fmaxf(o[2], 0.f), im.shape_w[b]);
+  o[1] = fminf(fmaxf(o[1], 0.f), im.shape_h[b]); o[3] = fminf(fmaxf(o[3], 0.f), im.shape_h[b]);
 }
+// Round 5: two launches (round 4: three -- a label kernel in front, and an atomicMin "winner" table that needed it for its
+// initialisation).  The label boxes are computed where they are used (a detection meets one or two labels of its image and class),
+// and the winner of a label -- the lowest-indexed detection of the image whose best label it is (process_batch's first np.unique
+// pass, val.py:84-86) -- is found by the stats kernel with a scan over the earlier detections of the image.
 // per detection: the four outputs of val.py:226-236 and its best label (process_batch, see k_pb_best) among the labels of ITS image
 __global__ void k_vt_dets(const float* __restrict__ det7, int n, ValTailImgs im, const float* __restrict__ targets, int nt, int tcols,
-                          const float* __restrict__ lab4, const float* __restrict__ iouv, float* __restrict__ poly10,
-                          float* __restrict__ hbb6, float* __restrict__ polyn10, float* __restrict__ hbbn6,
-                          int* __restrict__ best_label, float* __restrict__ best_iou, int* __restrict__ winner, int* __restrict__ counter) {
+                          const float* __restrict__ iouv, float* __restrict__ poly10, float* __restrict__ hbb6, float* __restrict__ polyn10,
+                          float* __restrict__ hbbn6, int* __restrict__ best_label, float* __restrict__ best_iou, int* __restrict__ counter) {
   if (blockIdx.x == 0 && threadIdx.x == 0) *counter = 0;       // k_vt_stats' arrival counter (that kernel runs behind this one)
   const int d = blockIdx.x * blockDim.x + threadIdx.x;
   if (d >= n) return;
@@ -538,7 +531,8 @@ __global__ void k_vt_dets(const float* __restrict__ det7, int n, ValTailImgs im,
   for (int l = 0; l < nt; l++) {
     const float* t = targets + (size_t)l * tcols;
     if ((int)t[0] != b || t[1] != cls) continue;
-    const float* b1 = lab4 + (size_t)l * 4;
+    float b1[4];
+    vt_label_box(t, im, b, b1);
     const float area1 = (b1[2] - b1[0]) * (b1[3] - b1[1]);
     const float iw = fmaxf(fminf(b1[2], b2[2]) - fmaxf(b1[0], b2[0]), 0.f);
     const float ih = fmaxf(fminf(b1[3], b2[3]) - fmaxf(b1[1], b2[1]), 0.f);
@@ -547,19 +541,38 @@ __global__ void k_vt_dets(const float* __restrict__ det7, int n, ValTailImgs im,
     if (iou >= thr0 && iou > bi) { bi = iou; bl = l; }
   }
   best_label[d] = bl; best_iou[d] = bi;
-  if (bl >= 0) atomicMin(&winner[bl], d);       // (detection indices grow with the image and inside it: the lowest index of the image wins)
 }
 // stats row of detection d: correct[0 .. niou) as 0 / 1, then conf, then cls (val.py:250's tuple, one copy for the batch)
 // `done` (optional, pinned host memory like `stats` may be): receives n once EVERY row has landed -- each workgroup makes its
 // rows visible system-wide (fence), then arrives on a device counter; the last one stores the flag.  The host polls it instead of
 // copying the rows back and waiting for the stream.
 __global__ void k_vt_stats(const float* __restrict__ det7, const int* __restrict__ best_label, const float* __restrict__ best_iou,
-                           const int* __restrict__ winner, const float* __restrict__ iouv, int n, int niou, float* __restrict__ stats,
+                           ValTailImgs im, const float* __restrict__ iouv, int n, int niou, float* __restrict__ stats,
                            int* __restrict__ counter, long long* __restrict__ done) {
   const int d = blockIdx.x * blockDim.x + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  // the winner of a label = the lowest-indexed detection of the image that chose it (detection indices grow inside the image).  A
+  // matched detection looks for an earlier one with the same label; the wave scans that prefix TOGETHER, 64 entries per trip (a
+  // lane on its own walked up to a few hundred dependent loads: the first version of this kernel took longer than the launch it saved)
+  int bl = -1, off_b = 0;
   if (d < n) {
-    const int bl = best_label[d];
-    const bool win = bl >= 0 && winner[bl] == d;
+    bl = best_label[d];
+    int b = 0;
+    while (b + 1 < im.bs && d >= im.det_off[b + 1]) b++;
+    off_b = im.det_off[b];
+  }
+  bool win = bl >= 0;
+  for (unsigned long long todo = __ballot(win); todo; todo &= todo - 1) {
+    const int l0 = __builtin_ctzll(todo);
+    const int bl0 = __shfl(bl, l0), d0 = __shfl(d, l0), o0 = __shfl(off_b, l0);
+    bool found = false;
+    for (int e0 = o0; e0 < d0 && !found; e0 += 64) {
+      const int e = e0 + lane;
+      found = __ballot(e < d0 && best_label[e] == bl0) != 0ull;
+    }
+    if (found && lane == l0) win = false;
+  }
+  if (d < n) {
     float* o = stats + (size_t)d * (niou + 2);
     for (int k = 0; k < niou; k++) o[k] = (win && best_iou[d] >= iouv[k]) ? 1.f : 0.f;
     o[niou] = det7[(size_t)d * 7 + 5]; o[niou + 1] = det7[(size_t)d * 7 + 6];
@@ -613,13 +626,10 @@ static int val_tail_batch_impl(const float* det7, const int64_t* det_off_host, i
   hipStream_t st = (hipStream_t)stream;
   int* best_label = (int*)ws;
   float* best_iou = (float*)(best_label + n);
-  float* lab4 = (float*)(((uintptr_t)(best_iou + n) + 255) & ~(uintptr_t)255);
-  int* winner = (int*)(lab4 + (size_t)(nt > 0 ? nt : 1) * 4);
-  int* counter = (int*)(((uintptr_t)(winner + (nt > 0 ? nt : 1)) + 63) & ~(uintptr_t)63);   // (inside the 512 spare bytes)
-  if (nt > 0) obb::k_vt_labels<<<(unsigned)((nt + 255) / 256), 256, 0, st>>>(targets, (int)nt, (int)tcols, im, lab4, winner);
-  obb::k_vt_dets<<<(unsigned)((n + 127) / 128), 128, 0, st>>>(det7, (int)n, im, targets, (int)nt, (int)tcols, lab4, iouv, poly10, hbb6, polyn10, hbbn6,
-                                                            best_label, best_iou, winner, counter);
-  obb::k_vt_stats<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(det7, best_label, best_iou, winner, iouv, (int)n, niou, stats, counter,
+  int* counter = (int*)(((uintptr_t)(best_iou + n) + 255) & ~(uintptr_t)255);              // (inside the 512 spare bytes)
+  obb::k_vt_dets<<<(unsigned)((n + 127) / 128), 128, 0, st>>>(det7, (int)n, im, targets, (int)nt, (int)tcols, iouv, poly10, hbb6, polyn10, hbbn6,
+                                                            best_label, best_iou, counter);
+  obb::k_vt_stats<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(det7, best_label, best_iou, im, iouv, (int)n, niou, stats, counter,
                                                               reinterpret_cast<long long*>(done));
   return hipGetLastError() == hipSuccess ? OBB_OK : OBB_ERR_LAUNCH;
 }

@@ -1695,7 +1695,10 @@ __device__ __forceinline__ int slab_setup(const NmsArgs& a, float bin_x0, float 
     }
   }
   slap(46);
-  if (!team_barrier(gbar, s_flag)) return -1;                  // every workgroup's share of the slab-major copy is out
+  // (No barrier behind the scatter: the set-up is a kernel of its own since round 4 and the persistent launch behind it on the
+  //  stream only starts when every workgroup of this one has finished -- the barrier that used to stand here cost 9 us of a 56 us
+  //  kernel.  The stores are write-through; the persistent kernel's first loads of the copy come after a kernel boundary.)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   slap(47);
   return 1;
 }
@@ -2021,11 +2024,14 @@ __device__ __forceinline__ void plan_teams_block(const int* seg_begin, const int
   // (the sizes are read from global memory ONCE: the five passes below each cost a dependent round trip otherwise)
   const bool staged = nseg <= 1024;
   if (staged) {
-    if (tid < nseg) S.size[tid] = seg_size ? seg_size[tid] : seg_end[tid] - seg_begin[tid];
+    // (seg_size comes from the other workgroups of the SAME launch -- the planner block of the fused sort kernel -- written with
+    //  agent-scope stores behind a relaxed ticket: read it with agent-scope loads, so that no stale line of this CU's cache can
+    //  stand in for a size and leave a segment without a workgroup)
+    if (tid < nseg) S.size[tid] = seg_size ? ldg_agent(seg_size + tid) : seg_end[tid] - seg_begin[tid];
     __syncthreads();
   }
   auto cost_of = [&](int g) -> long long {
-    return plan_cost((long long)(staged ? S.size[g] : (seg_size ? seg_size[g] : seg_end[g] - seg_begin[g])), chunk);
+    return plan_cost((long long)(staged ? S.size[g] : (seg_size ? ldg_agent(seg_size + g) : seg_end[g] - seg_begin[g])), chunk);
   };
   // ---- totals
   long long myc = 0, myn = 0, pa, pb, total, nne;

@@ -367,10 +367,13 @@ __global__ void k_append_extra(const float* __restrict__ extra8, int m, long lon
 // the reference's argument order (the higher-scored box first, nms_rotated_cuda.cu:44-60), in the coordinates the reference
 // uses (xy + cls * max_wh).  No IoU > thr among them: the classes of the image cannot interact (well-conditioned cross-class
 // pairs have disjoint circles inside their windows: the reference returns exactly 0), its class segments give the reference's
-// kept set.  Otherwise -- or with more than kTinyMax short-sided boxes -- the image keeps the reference's single list.
+// kept set.  Otherwise the image keeps the reference's single list -- and so does an image with more than kTinyMax short-sided
+// boxes or more than kTinyPairs (box, candidate) combinations: the clip costs ~8 us per 64 pairs, the check is meant for the stray
+// sub-pixel box of a trained detector (bounded at ~80 us per image), not for the hundreds a random-initialised head produces.
 // Launched only when the caller's previous call of the shape met such boxes (expected_cand bit 62): grid (kTinyParts, bs),
 // blocks of images without the flag return at once.  Candidates beyond the top-max_nms cut are tested as well: conservative.
-constexpr int kTinyMax = 1024;
+constexpr int kTinyMax = 32;             // short-sided boxes of an image the check takes ...
+constexpr long long kTinyPairs = 65536;   // ... and candidates x short-sided boxes: above either the image is not checked (single list)
 constexpr int kTinyParts = 32;
 __global__ __launch_bounds__(256) void k_tiny_cross(const float4* __restrict__ cand, const unsigned long long* __restrict__ keys,
                                                     const int* __restrict__ cnt, long long cap_img, float class_offset, float thr,
@@ -392,7 +395,7 @@ __global__ __launch_bounds__(256) void k_tiny_cross(const float4* __restrict__ c
   }
   __syncthreads();
   const int nt = s_n;
-  if (nt > kTinyMax) return;                                     // not checked: single list
+  if (nt > kTinyMax || (long long)nt * n > kTinyPairs) return;   // not checked: single list
   if (part == 0 && tid == 0) atomicOr(&tiny[b], kImgChecked);
   bool hit = false;
   float* myscr = scr + wv * (RotGeom::SCR * 64) + lane;
@@ -874,7 +877,13 @@ __global__ __launch_bounds__(256) void k_gather_out(const float4* __restrict__ c
     }
   }
   if (g == 0)
-    for (int b2 = tid; b2 < (int)gridDim.x; b2 += 256) { const long long c = cnt[b2 * kCntPad]; if (c > mx) mx = c; tf |= tiny[b2] & kImgSmall; }
+    for (int b2 = tid; b2 < (int)gridDim.x; b2 += 256) {
+      const long long c = cnt[b2 * kCntPad];
+      if (c > mx) mx = c;
+      const int t = tiny[b2];
+      tf |= t & kImgSmall;
+      if ((t & kImgSmall) && !img_single_list(t)) tf |= 16;      // ... and kept its class segments (k_tiny_cross vouched for it)
+    }
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) { mine += __shfl_xor(mine, d); const long long o = __shfl_xor(mx, d); if (o > mx) mx = o; tf |= __shfl_xor(tf, d); }
   if ((tid & 63) == 0) { s_rows[tid >> 6] = mine; s_mx[tid >> 6] = mx; s_tf[tid >> 6] = tf; }
@@ -896,9 +905,11 @@ __global__ __launch_bounds__(256) void k_gather_out(const float4* __restrict__ c
     // info[8] != 0: k_nms_small met a segment above its limit -- nothing of this call is valid, the caller repeats it with
     // the persistent kernel (status[0] = -1); info[4]: the largest NMS segment where the sort kernel knew it (else 0)
     status[0] = info[8] ? -1 : (m4 > cap_img ? m4 : 0);
-    // bit 62: an image of this call held short-sided boxes (kImgSmall) -- the caller's next call asks for k_tiny_cross
-    const long long small_seen = (s_tf[0] | s_tf[1] | s_tf[2] | s_tf[3]) ? (1ll << 62) : 0ll;
-    status[1] = m4 | (((long long)(info[8] > info[4] ? info[8] : info[4]) & 0x3fffffffll) << 32) | small_seen;
+    // bit 62: an image of this call held short-sided boxes (kImgSmall) -- the caller's next call asks for k_tiny_cross;
+    // bit 61: such an image kept its class segments in THIS call (informational)
+    const int tfa = s_tf[0] | s_tf[1] | s_tf[2] | s_tf[3];
+    const long long small_seen = ((tfa & kImgSmall) ? (1ll << 62) : 0ll) | ((tfa & 16) ? (1ll << 61) : 0ll);
+    status[1] = m4 | (((long long)(info[8] > info[4] ? info[8] : info[4]) & 0x1fffffffll) << 32) | small_seen;
   }
   // first output row of the image: g * max_det, or (packed) the number of rows of the images before it
   const long long row0 = packed ? s_rows[0] + s_rows[1] + s_rows[2] + s_rows[3] : (long long)g * max_det;
@@ -997,7 +1008,7 @@ static int run_nms_obb(const void* pred, const void* objcol, int dtype, int64_t 
   if (dtype != 0 && dtype != 1) return OBB_ERR_BAD_ARG;
   // expected_cand: low 32 bits = the previous call's largest candidate count of an image (0: unknown), high 32 bits = its
   // largest NMS segment (0: unknown) -- both as status[1] reported them
-  const int64_t seg_hint = (expected_cand >> 32) & 0x3fffffff;
+  const int64_t seg_hint = (expected_cand >> 32) & 0x1fffffff;
   const bool small_hint = ((expected_cand >> 62) & 1) != 0;        // the previous call met short-sided boxes: run k_tiny_cross
   expected_cand &= 0xffffffffll;
   cap_img = round_cap(cap_img);

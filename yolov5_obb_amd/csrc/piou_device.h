@@ -192,6 +192,12 @@ OBB_HD float quad_iou(const QuadFeat& P, const QuadFeat& Q, float* px, float* py
 constexpr float kQuadNoiseUnits = 1024.f;
 constexpr float kQuadNoise = kQuadNoiseUnits / 16777216.f;   // c u
 constexpr float kQuadSlack = 1e-6f;
+// The bound is a SEARCHED one: it is only used inside the envelope the searches covered (round 5; include/obb_hip.h states it at
+// obb_nms_poly_f32) -- every coordinate |x|, |y| <= kQuadEnvCoord and a bounding box of at most kQuadEnvSize in either direction
+// (the ten families of tests/native/host_check_quadcull.cpp: extents 8 .. 70,000 px, boxes 0.01 .. 600 px).  A quad outside it gets
+// no budget (f = -inf): its pairs are decided by the proved cone rule or clipped.
+constexpr float kQuadEnvCoord = 70000.f;
+constexpr float kQuadEnvSize = 600.f;
 
 // largest fp16 <= x (up = false) or smallest fp16 >= x (up = true), as bits; NaN -> NaN
 OBB_HD uint32_t f16_bits_toward(float x, bool up) {
@@ -283,7 +289,8 @@ OBB_HD QuadSkip quad_skip_record(const QuadFeat& q, float thr) {
   r.lo = f16_bits_toward(q.minx, false) | (f16_bits_toward(q.miny, false) << 16);
   r.hi = f16_bits_toward(q.maxx, true) | (f16_bits_toward(q.maxy, true) << 16);
   // the 1e-3 margins cover the roundings of this expression
-  r.f = (thr > 0.f && !nan) ? area * t * 0.999f - kQuadNoise * 1.001f * m * m - kQuadSlack : -__builtin_huge_valf();
+  const bool in_env = m <= kQuadEnvCoord && (q.maxx - q.minx) <= kQuadEnvSize && (q.maxy - q.miny) <= kQuadEnvSize;   // (false on NaN)
+  r.f = (thr > 0.f && !nan && in_env) ? area * t * 0.999f - kQuadNoise * 1.001f * m * m - kQuadSlack : -__builtin_huge_valf();
   return r;
 }
 OBB_HD bool quad_skip_pair(const QuadSkip& a, const QuadSkip& b) {

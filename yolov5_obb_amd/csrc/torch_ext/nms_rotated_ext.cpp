@@ -202,6 +202,7 @@ struct ShapeMemo {
   int64_t cand = OBB_NMS_SORT_LDS_HINT;        // largest candidate count of an image in the previous call: the sort hint.  No history:
                                                // the regime of the reference's default thresholds (a few thousand candidates per image)
   int64_t seg = 1;                             // largest NMS segment of the previous call: chooses the NMS kernel (no history: small)
+  bool small_resolved = false;                 // ... and (informational) such an image kept its class segments in that call
   bool small_boxes = false;                    // the previous call met boxes with a sub-pixel side: the next one runs the cross-class check
   int hold_seg = 0, hold_cand = 0;             // > 0: a call was repeated because its hint undersold it -- keep the larger regime this
                                                // many calls unless the batch falls clearly (25 %) below the limit: a stream whose
@@ -226,7 +227,7 @@ py::object hint_get(int dev, int64_t A, int64_t nc, bool multi, double conf_thre
   if (it == m.end()) return py::none();
   py::dict d;
   d["cap"] = it->second.cap; d["cand"] = it->second.cand; d["seg"] = it->second.seg;
-  d["hold_cand"] = it->second.hold_cand; d["hold_seg"] = it->second.hold_seg; d["small_boxes"] = it->second.small_boxes;
+  d["hold_cand"] = it->second.hold_cand; d["hold_seg"] = it->second.hold_seg; d["small_boxes"] = it->second.small_boxes; d["small_resolved"] = it->second.small_resolved;
   return std::move(d);
 }
 void hint_set(int dev, int64_t A, int64_t nc, bool multi, double conf_thres, int64_t cand, int64_t seg) {
@@ -298,7 +299,7 @@ std::vector<at::Tensor> non_max_suppression_obb(const at::Tensor& prediction, do
   AbortRetry retry;
   int64_t seg_max = 0, cand_max = 0;
   for (;;) {
-    const int64_t hint = memo.cand & 0xffffffffll, seg_hint = memo.seg & 0x3fffffffll;
+    const int64_t hint = memo.cand & 0xffffffffll, seg_hint = memo.seg & 0x1fffffffll;
     const auto wkey = std::make_tuple(bs, cap, nc, (int)agnostic, retry.capped);
     auto it = ws_memo.find(wkey);
     if (it == ws_memo.end()) it = ws_memo.emplace(wkey, api.obb_nms_obb_workspace_bytes(bs, cap, nc, agnostic ? 1 : 0)).first;
@@ -315,7 +316,8 @@ std::vector<at::Tensor> non_max_suppression_obb(const at::Tensor& prediction, do
       wait_words(meta, stream);
     }
     const int64_t st0 = meta.p[bs], st1 = meta.p[bs + 1];
-    seg_max = (st1 >> 32) & 0x3fffffffll;
+    seg_max = (st1 >> 32) & 0x1fffffffll;
+    memo.small_resolved = ((st1 >> 61) & 1) != 0;
     cand_max = st1 & 0xffffffffll;
     memo.small_boxes = ((st1 >> 62) & 1) != 0;
     if (st0 == -1) {                                                   // a segment above the small kernel's limit: nothing is valid
@@ -462,16 +464,20 @@ py::object val_tail_batch(const std::vector<at::Tensor>& preds, const at::Tensor
   }
   // what val.py:250 appends, per image: (correct bool (n_i, niou), conf (n_i), cls (n_i)) on the host.  Two arrays for the
   // whole batch (the pinned buffer is reused by the next call), per-image views of them
-  at::Tensor rows = at::empty({n, niou + 2}, at::TensorOptions().dtype(at::kFloat));
-  if (n) std::memcpy(rows.data_ptr<float>(), host, (size_t)n * (size_t)(niou + 2) * 4);
+  // (one pass over the pinned rows: the bool matrix and the (conf, cls) pairs; no torch CPU op -- a parallel one would wake the
+  //  whole intra-op pool, see profiles/r5_host_stall.md)
   at::Tensor correct = at::empty({n, niou}, at::TensorOptions().dtype(at::kBool));
+  at::Tensor cc = at::empty({n, 2}, at::TensorOptions().dtype(at::kFloat));
   {
-    const float* r = rows.data_ptr<float>();
+    const float* r = host;
     bool* c = correct.data_ptr<bool>();
-    for (int64_t i = 0; i < n; i++)
-      for (int64_t j = 0; j < niou; j++) c[i * niou + j] = r[i * (niou + 2) + j] > 0.5f;
+    float* q = cc.data_ptr<float>();
+    for (int64_t i = 0; i < n; i++, r += niou + 2, c += niou, q += 2) {
+      for (int64_t j = 0; j < niou; j++) c[j] = r[j] > 0.5f;
+      q[0] = r[niou]; q[1] = r[niou + 1];
+    }
   }
-  const at::Tensor conf = rows.select(1, niou), pcls = rows.select(1, niou + 1);
+  const at::Tensor conf = cc.select(1, 0), pcls = cc.select(1, 1);
   py::list out((size_t)bs);
   for (int64_t b = 0; b < bs; b++) {
     const int64_t c = offs[b + 1] - offs[b];

@@ -61,7 +61,7 @@ def hint_get(device, A, nc, multi_label, conf_thres):
     if key not in _cand_memo and key not in _seg_memo:
         return None
     return {"cand": _cand_memo.get(key, _SORT_LDS_HINT), "seg": _seg_memo.get(key, 1), "cap": _cap_memo.get(key, 0),
-            "small_boxes": bool(_small_memo.get(key, False))}
+            "small_boxes": bool(_small_memo.get(key, False)), "small_resolved": bool(_small_memo.get((key, "resolved"), False))}
 
 
 def hint_set(device, A, nc, multi_label, conf_thres, cand=None, seg=None):
@@ -210,7 +210,7 @@ def non_max_suppression_obb(prediction, conf_thres=0.25, iou_thres=0.45, classes
                     _lib.ptr(pred), _lib.ptr(col), dtype, bs, A, no, float(conf_thres), float(iou_thres),
                     C.cast(cls_arr, C.c_void_p) if cls_arr is not None else C.c_void_p(0), n_cls, agn, int(multi),
                     max_det, _MAX_NMS, float(_MAX_WH), _lib.ptr(extra), n_extra, cap,
-                    (hint & 0xffffffff) | ((seg_hint & 0x3fffffff) << 32) | ((1 << 62) if _small_memo.get(key) else 0), _lib.ptr(out), 1, _lib.ptr(meta),
+                    (hint & 0xffffffff) | ((seg_hint & 0x1fffffff) << 32) | ((1 << 62) if _small_memo.get(key) else 0), _lib.ptr(out), 1, _lib.ptr(meta),
                     C.c_void_p(meta.data_ptr() + 8 * bs), _lib.ptr(ws), ws.numel(), C.c_void_p(st))
             _lib.check(rc, "obb_non_max_suppression_obb")
             if meta_np is not None:                                   # every entry is one aligned 8-byte store of the last kernel
@@ -226,7 +226,8 @@ def non_max_suppression_obb(prediction, conf_thres=0.25, iou_thres=0.45, classes
             else:
                 m = meta.tolist()                                     # the single device->host sync of the call
             _small_memo[key] = bool((m[bs + 1] >> 62) & 1)                    # status[1]: bit 62 = boxes with a sub-pixel side were met,
-            seg_max, m[bs + 1] = (m[bs + 1] >> 32) & 0x3fffffff, m[bs + 1] & 0xffffffff       # largest segment | largest candidate count
+            _small_memo[key, "resolved"] = bool((m[bs + 1] >> 61) & 1)        # bit 61 = ... and such an image kept its class segments
+            seg_max, m[bs + 1] = (m[bs + 1] >> 32) & 0x1fffffff, m[bs + 1] & 0xffffffff       # largest segment | largest candidate count
             if m[bs] == -1:                                           # a segment above the small kernel's limit: nothing is valid
                 _seg_memo[key] = max(int(seg_max), _SEG_SMALL + 1)
                 _hold[key, "seg"] = _HOLD

@@ -65,6 +65,9 @@ def regular_theta(theta, mode='180', start=-pi / 2):
     return theta + start
 
 
+_warned_no_cv2 = False
+
+
 def _min_area_rect(pts):
     """Minimum-area enclosing rectangle of a few points, ((cx, cy), (w, h), angle in degrees) in the convention of
     cv2.minAreaRect since OpenCV 4.5.1: w is the extent along the direction `angle`, measured from the x axis towards the
@@ -82,7 +85,16 @@ def _min_area_rect(pts):
             h.append(v)
         return h[:-1]
     hull = np.array(half(q) + half(q[::-1]))                     # monotone chain; two points for a degenerate set
-    best = None
+    def normalised(w, h, ang):                                   # angle into (0, 90], sides swapped with every quarter turn
+        k = int(np.floor(ang / 90.0))
+        ang -= 90.0 * k
+        if k % 2:
+            w, h = h, w
+        if ang <= 0.0:                                          # (0, 90]: an axis-aligned rectangle reports 90
+            ang += 90.0
+            w, h = h, w
+        return w, h, ang
+    cands = []
     for i in range(len(hull)):
         d = hull[(i + 1) % len(hull)] - hull[i]
         n = float(np.hypot(d[0], d[1]))
@@ -92,17 +104,14 @@ def _min_area_rect(pts):
         v = np.array([-u[1], u[0]])
         a, b = hull @ u, hull @ v
         w, h = float(a.max() - a.min()), float(b.max() - b.min())
-        if best is None or w * h < best[0]:
-            c = u * (a.max() + a.min()) / 2 + v * (b.max() + b.min()) / 2
-            best = (w * h, c, w, h, float(np.degrees(np.arctan2(u[1], u[0]))))
-    _, c, w, h, ang = best
-    k = int(np.floor(ang / 90.0))
-    ang -= 90.0 * k
-    if k % 2:
-        w, h = h, w
-    if ang <= 0.0:                                              # (0, 90]: an axis-aligned rectangle reports 90
-        ang += 90.0
-        w, h = h, w
+        c = u * (a.max() + a.min()) / 2 + v * (b.max() + b.min()) / 2
+        cands.append((w * h, c) + normalised(w, h, float(np.degrees(np.arctan2(u[1], u[0])))))
+    # Tie rule (this function's own; OpenCV's rotating calipers work in float32 and keep whichever edge they meet first): among
+    # the hull edges whose rectangle is within 1e-12 of the smallest area, the one with the smallest normalised angle.  The four
+    # edges of a rectangle give the same normalised (w, h, angle) up to rounding, so the rule only decides genuinely different
+    # rectangles of equal area.
+    amin = min(t[0] for t in cands)
+    _, c, w, h, ang = min((t for t in cands if t[0] <= amin * (1.0 + 1e-12) + 1e-300), key=lambda t: t[4])
     return (float(c[0]), float(c[1])), (w, h), ang
 
 
@@ -113,6 +122,13 @@ def poly2rbox(polys, num_cls_thata=180, radius=6.0, use_pi=False, use_gaussian=F
         min_area_rect = cv2.minAreaRect
     except ImportError:       # (the reference imports cv2 at module import time, utils/rboxs_utils.py:6)
         min_area_rect = _min_area_rect
+        global _warned_no_cv2
+        if not _warned_no_cv2:
+            import warnings
+            warnings.warn("poly2rbox: OpenCV is not installed, the minimum-area rectangle comes from this package's own float64 "
+                          "implementation (same definition; parity with cv2.minAreaRect's float32 calipers is unpinned: equal-area "
+                          "ties and last-bit angles can differ)")
+            _warned_no_cv2 = True
     assert polys.shape[-1] == 8
     csl_labels, rboxes = [], []
     for poly in polys:

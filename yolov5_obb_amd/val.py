@@ -84,7 +84,7 @@ def _as_f32_cuda(t, dev):
 
 
 def val_tail_batch(preds, targets, shapes, iouv, want_boxes=False):
-    """The tail of val.py:209-250 for ALL images of a batch: three launches, and the statistics land in pinned host memory
+    """The tail of val.py:209-250 for ALL images of a batch: two launches, and the statistics land in pinned host memory
     that this thread polls (no copy kernel, no blocked stream wait; the host side of this function is most of its time, so it
     avoids every torch call it can).
 
