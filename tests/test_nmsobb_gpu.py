@@ -133,8 +133,8 @@ def test_sub_pixel_boxes_keep_their_class_segments_unless_classes_really_interac
     pred[1, thin, 3] = torch.rand(12, generator=g) * 0.6 + 0.3
     _set_class(pred, 1, thin[:6], 2, nc, conf=0.95)
     _set_class(pred, 1, thin[6:], 9, nc, conf=0.95)
-    rows = torch.arange(3000, 3024)                                        # (24 of them: within the check's bounds, so that it is the check
-    pred[2, rows, 0:2] = torch.rand(24, 2, generator=g) * 1000 + 10        #  that sends this image to the single list)
+    rows = torch.arange(3000, 3024)                                        # (24 of them: it is the check that
+    pred[2, rows, 0:2] = torch.rand(24, 2, generator=g) * 1000 + 10        #  sends this image to the single list)
     pred[2, rows, 2] = torch.rand(24, generator=g) * 300 + 100
     pred[2, rows, 3] = torch.rand(24, generator=g) * 0.002 + 0.001
     _set_class(pred, 2, rows, 0, nc, conf=0.99)
@@ -152,8 +152,8 @@ def test_sub_pixel_boxes_keep_their_class_segments_unless_classes_really_interac
         _cmp(general.non_max_suppression_obb(p, **kw), ref)
     st = general.hint_get(dev, A, nc, True, 0.25)
     assert st["small_boxes"] and st["small_resolved"]                       # image 1 kept its class segments (image 2 did not: exact either way)
-    many = pred.clone()                                                    # hundreds of sub-pixel boxes (a random-initialised head): above the
-    lots = torch.rand(A, generator=g) < 0.02                               # check's bounds, the image stays on the single list -- same rows
+    many = pred.clone()                                                    # ~800 sub-pixel boxes (a random-initialised head): above the check's
+    lots = torch.rand(A, generator=g) < 0.05                               # bound of 512, the image stays on the single list -- same rows
     many[1, lots, 3] = torch.rand(int(lots.sum()), generator=g) * 0.6 + 0.3
     many[1, lots, 4] = 0.95
     refm = pyref.non_max_suppression_obb(many.clone(), **kw)

@@ -96,6 +96,7 @@ struct NmsArgs {
   const SlabPlan* slab_plan;  // written by k_slab_split in front of this launch (NULL: no decomposition was looked for)
   int slab_cap;               // > 0: upper limit of a slab team's chunk capacity
   int grow_sparse;            // chunk growth factor after a sparse chunk (<= 2: always double)
+  int lpt;                    // 1: the resolver hands the kept rows of a chunk to the indexed cross phase LARGEST FIRST (nms_resolve)
 };
 
 // ---- cost model shared by the planner (k_plan_teams) and the workgroups that follow its plan
@@ -812,6 +813,52 @@ OBB_COLD_RESOLVE int nms_resolve(const NmsArgs& a, int g, int sb, int tm, int cn
     if (j < cn && state[j] == 1) { olist[rank] = cidx[j]; rank++; }
   }
   __syncthreads();
+  // Largest rows first (round 5).  The indexed cross phase deals (row, part) items to the workgroups in row order, and an item's
+  // cost grows with the row's radius (the query windows, and the number of candidates whose circles touch): with the rows in score
+  // order -- i.e. in random size order -- the last item a workgroup started was as likely a heavy one as not, and every step ended
+  // with 255 workgroups waiting for it (S-uniform at 100k, in-kernel timers: the mean workgroup spent 560 us in its cross phases, the
+  // slowest of every step added up to 1010 us).  The order of `rows` is free: the cross phases only need the SET (kills are
+  // idempotent), the output order comes from `olist`.  Four buckets by radius relative to the chunk's largest, in bucket order.
+  uint32_t* lcode = olist + a.capmax;                         // [total] bucket << 16 | slot in the bucket   (lcap >= 2 capmax + 8: checked below)
+  int* lcnt = reinterpret_cast<int*>(olist + 2 * (size_t)a.capmax);   // [0..3] bucket sizes, [4] largest radius (float bits; radii are >= 0)
+  const bool lpt = a.lpt != 0 && a.gmeta != nullptr && a.nseg == 1 && a.keep_out != nullptr && total >= 512 && lcap >= 2LL * a.capmax + 8;
+  if (lpt) {
+    if (tid < 5) lcnt[tid] = 0;
+    __syncthreads();
+    int mx = 0;
+    for (int k0 = tid; k0 < total; k0 += 4 * kNmsThreads) {
+      float rv[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) { const int k = k0 + u * kNmsThreads; rv[u] = k < total ? a.rec[(size_t)olist[k] * 4].z : 0.f; }
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int k = k0 + u * kNmsThreads;
+        if (k < total) { const int rb = __float_as_int(rv[u] >= 0.f ? rv[u] : 0.f); lcode[k] = (uint32_t)rb; mx = rb > mx ? rb : mx; }   // (NaN: 0)
+      }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { const int o = __shfl_xor(mx, d); mx = o > mx ? o : mx; }
+    if ((tid & 63) == 0 && mx > 0) atomicMax(&lcnt[4], mx);
+    __syncthreads();
+    const float rmax = __int_as_float(lcnt[4]);
+    for (int k0 = 0; k0 < total; k0 += kNmsThreads) {          // (wave-uniform trip count: ballots inside)
+      const int k = k0 + tid;
+      int b = -1;
+      if (k < total) { const float r = __int_as_float((int)lcode[k]); b = r >= 0.75f * rmax ? 0 : (r >= 0.5f * rmax ? 1 : (r >= 0.3f * rmax ? 2 : 3)); }
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const u64 m = __ballot(b == q);
+        if (m) {
+          int base = 0;
+          if ((tid & 63) == (int)__builtin_ctzll(m)) base = atomicAdd(&lcnt[q], __popcll(m));
+          base = __shfl(base, (int)__builtin_ctzll(m));
+          if (b == q) lcode[k] = ((uint32_t)q << 16) | (uint32_t)(base + __popcll(m & lanemask_lt()));
+        }
+      }
+    }
+    __syncthreads();
+  }
+  const int lb1 = lpt ? lcnt[0] : 0, lb2 = lpt ? lb1 + lcnt[1] : 0, lb3 = lpt ? lb2 + lcnt[2] : 0;
   for (int k0 = tid; k0 < total; k0 += 4 * kNmsThreads) {
     uint32_t pv[4], ov[4];
     bool ok[4];
@@ -832,7 +879,9 @@ OBB_COLD_RESOLVE int nms_resolve(const NmsArgs& a, int g, int sb, int tm, int cn
       if (!ok[u]) continue;
       const int k = k0 + u * kNmsThreads;
       const uint32_t pos = pv[u];
-      stg_agent(rows + k, pos);
+      int kr = k;                                               // the row's place in the cross phase's list
+      if (lpt) { const uint32_t c = lcode[k]; const int q = (int)(c >> 16); kr = (q == 0 ? 0 : (q == 1 ? lb1 : (q == 2 ? lb2 : lb3))) + (int)(c & 0xffffu); }
+      stg_agent(rows + kr, pos);
       const long long o = (long long)kept_before + k;
       if (a.keep_out != nullptr) {
         if (a.max_keep <= 0 || o < a.max_keep) a.keep_out[(size_t)sb + o] = (int64_t)ov[u];

@@ -363,22 +363,28 @@ __global__ void k_append_extra(const float* __restrict__ extra8, int m, long lon
 }
 
 // Cross-class check of the images that hold short-sided boxes (kImgSmall, see the flag table above): every pair (short-sided
-// box T, box B of ANOTHER class) that rbox_pair_well_conditioned does not vouch for goes through the reference's own clip in
-// the reference's argument order (the higher-scored box first, nms_rotated_cuda.cu:44-60), in the coordinates the reference
-// uses (xy + cls * max_wh).  No IoU > thr among them: the classes of the image cannot interact (well-conditioned cross-class
-// pairs have disjoint circles inside their windows: the reference returns exactly 0), its class segments give the reference's
-// kept set.  Otherwise the image keeps the reference's single list -- and so does an image with more than kTinyMax short-sided
-// boxes or more than kTinyPairs (box, candidate) combinations: the clip costs ~8 us per 64 pairs, the check is meant for the stray
-// sub-pixel box of a trained detector (bounded at ~80 us per image), not for the hundreds a random-initialised head produces.
+// box T, box B of ANOTHER class) that rbox_pair_well_conditioned does not vouch for goes through the reference's own arithmetic
+// in the reference's argument order (the higher-scored box first, nms_rotated_cuda.cu:44-60), in the coordinates the reference
+// uses (xy + cls * max_wh): first the COUNT of the clip's candidate points (rbox_npoints: the 16 edge crossings and the contained
+// corners in the reference's fp32 operations, ~400 flops, no scratch) -- at most two points and the reference returns IoU = 0
+// (box_iou_rotated_utils.h:322-324), which is what happens for all but a few thin boxes that point along the diagonal of the class
+// offsets -- and the whole clip only for the pairs with more.  No IoU > thr among them: the classes of the image cannot interact
+// (well-conditioned cross-class pairs have disjoint circles inside their windows: the reference returns exactly 0), its class
+// segments give the reference's kept set.  Otherwise the image keeps the reference's single list -- and so does an image with more
+// than kTinyMax short-sided boxes or more than kTinyPairs (box, candidate) combinations (bounded cost: ~0.1 ms per image at the
+// bound; a trained detector's stray sub-pixel box costs microseconds).
 // Launched only when the caller's previous call of the shape met such boxes (expected_cand bit 62): grid (kTinyParts, bs),
 // blocks of images without the flag return at once.  Candidates beyond the top-max_nms cut are tested as well: conservative.
-constexpr int kTinyMax = 32;             // short-sided boxes of an image the check takes ...
-constexpr long long kTinyPairs = 65536;   // ... and candidates x short-sided boxes: above either the image is not checked (single list)
+constexpr int kTinyMax = 512;             // short-sided boxes of an image the check takes ...
+constexpr long long kTinyPairs = 2000000; // ... and candidates x short-sided boxes: above either the image is not checked (single list)
 constexpr int kTinyParts = 32;
 __global__ __launch_bounds__(256) void k_tiny_cross(const float4* __restrict__ cand, const unsigned long long* __restrict__ keys,
                                                     const int* __restrict__ cnt, long long cap_img, float class_offset, float thr,
                                                     int* __restrict__ tiny) {
-  __shared__ float scr[RotGeom::SCR * 256];                     // clip scratch: one column per thread inside its wave's block
+  __shared__ float scr[RotGeom::SCR * 256];                     // clip scratch (the rare full clip): one column per thread inside its wave's block
+  __shared__ RBoxFeat s_feat[kTinyMax];                         // the short-sided boxes in the reference's coordinates
+  __shared__ unsigned long long s_key[kTinyMax];
+  __shared__ float s_cls[kTinyMax];
   __shared__ int s_list[kTinyMax];
   __shared__ int s_n;
   const int b = blockIdx.y, part = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -397,6 +403,15 @@ __global__ __launch_bounds__(256) void k_tiny_cross(const float4* __restrict__ c
   const int nt = s_n;
   if (nt > kTinyMax || (long long)nt * n > kTinyPairs) return;   // not checked: single list
   if (part == 0 && tid == 0) atomicOr(&tiny[b], kImgChecked);
+  for (int t = tid; t < nt; t += 256) {
+    const int jt = s_list[t];
+    const float4 t0 = cand[(base + jt) * 2], t1 = cand[(base + jt) * 2 + 1];
+    const float offT = t1.z * class_offset;
+    s_feat[t] = rbox_make_feat(t0.x + offT, t0.y + offT, t0.z, t0.w, t1.x);
+    s_key[t] = keys[base + jt];
+    s_cls[t] = t1.z;
+  }
+  __syncthreads();
   bool hit = false;
   float* myscr = scr + wv * (RotGeom::SCR * 64) + lane;
   for (long long j = (long long)part * 256 + tid; j < n; j += (long long)gridDim.x * 256) {
@@ -406,14 +421,13 @@ __global__ __launch_bounds__(256) void k_tiny_cross(const float4* __restrict__ c
     const RBoxFeat B = rbox_make_feat(c0.x + offB, c0.y + offB, c0.z, c0.w, c1.x);
     const unsigned long long kB = keys[base + j];
     for (int t = 0; t < nt; t++) {
-      const int jt = s_list[t];
-      const float4 t0 = cand[(base + jt) * 2], t1 = cand[(base + jt) * 2 + 1];
-      if (t1.z == c1.z) continue;                                // same class: decided inside the class segment, as in the single list
-      const float offT = t1.z * class_offset;
-      const RBoxFeat T = rbox_make_feat(t0.x + offT, t0.y + offT, t0.z, t0.w, t1.x);
+      if (s_cls[t] == c1.z) continue;                            // same class: decided inside the class segment, as in the single list
+      const RBoxFeat T = s_feat[t];
       if (rbox_pair_well_conditioned(T, B)) continue;            // circles apart (different windows) and well conditioned: exactly 0
-      const unsigned long long kT = keys[base + jt];             // smaller key = sorts first = the row box of the reference's kernel
-      const float v = kT < kB ? rbox_iou<64>(T, B, myscr, myscr + 24 * 64) : rbox_iou<64>(B, T, myscr, myscr + 24 * 64);
+      const bool t_first = s_key[t] < kB;                        // smaller key = sorts first = the row box of the reference's kernel
+      const int np = t_first ? rbox_npoints(T, B) : rbox_npoints(B, T);
+      if (np <= 2) continue;                                     // the reference returns 0 (:322-324 / :353)
+      const float v = t_first ? rbox_iou<64>(T, B, myscr, myscr + 24 * 64) : rbox_iou<64>(B, T, myscr, myscr + 24 * 64);
       if (v > thr) hit = true;
     }
   }

@@ -253,18 +253,14 @@ OBB_HD bool rbox_quick_bounds(const RBoxFeat& A, const RBoxFeat& B, IouBounds* o
   return out->lo == out->lo && out->hi == out->hi;
 }
 
-// Full clip.  A = higher-scored ("row") box, B = lower-scored ("column") box:
-// the argument order is part of the contract (nms_rotated_cuda.cu:60).
-// px/py: scratch for 24 points, element i at [i * STRIDE].
-template <int STRIDE>
-OBB_HD float rbox_iou(const RBoxFeat& A, const RBoxFeat& B, float* px, float* py) {
+// The first half of the clip -- the candidate points of the intersection polygon: the 16 edge / edge crossings and the corners of
+// either box inside the other (box_iou_rotated_utils.h:93-154) -- as a function of its own: STORE = true writes them to the
+// scratch columns (rbox_iou below), STORE = false only COUNTS them, in the same arithmetic.  A count of <= 2 means the reference
+// returns IoU = 0 (:322-324: `if (num <= 2) return 0.0`): the cross-class check of the fused NMS driver (nmsobb_impl.h:
+// k_tiny_cross) screens its far-apart pairs with the count alone, ~400 flops and no scratch instead of the whole clip.
+template <int STRIDE, bool STORE>
+OBB_HD int rbox_points(const RBoxFeat& A, const RBoxFeat& B, float* px, float* py) {
   constexpr float kDetLe = f32_floor(1e-14);   // fabs(det) <= 1e-14
-  constexpr float kAreaLt = f32_ceil(1e-14);   // area < 1e-14
-  constexpr float kCpLtNeg = f32_ceil(-1e-6);  // cp < -1e-6
-  constexpr float kCpLt = f32_ceil(1e-6);      // fabs(cp) < 1e-6
-  constexpr float kD2Gt = f32_floor(1e-8);     // dist > 1e-8
-
-  if (A.area < kAreaLt || B.area < kAreaLt) return 0.f;  // :353
 
   // centre shift, evaluated in double like the reference (:338-346)
   double mx = (double)(A.x + B.x) * 0.5, my = (double)(A.y + B.y) * 0.5;
@@ -300,8 +296,10 @@ OBB_HD float rbox_iou(const RBoxFeat& A, const RBoxFeat& B, float* px, float* py
       float t1 = (e2x[j] * dy - dx * e2y[j]) / det;
       float t2 = (e1x[i] * dy - dx * e1y[i]) / det;
       if (t1 >= 0.0f && t1 <= 1.0f && t2 >= 0.0f && t2 <= 1.0f) {
-        px[n * STRIDE] = v1x[i] + e1x[i] * t1;
-        py[n * STRIDE] = v1y[i] + e1y[i] * t1;
+        if constexpr (STORE) {
+          px[n * STRIDE] = v1x[i] + e1x[i] * t1;
+          py[n * STRIDE] = v1y[i] + e1y[i] * t1;
+        }
         n++;
       }
     }
@@ -316,7 +314,8 @@ OBB_HD float rbox_iou(const RBoxFeat& A, const RBoxFeat& B, float* px, float* py
       float apab = apx * e2x[0] + apy * e2y[0];
       float apad = -(apx * e2x[3] + apy * e2y[3]);
       if (apab >= 0 && apad >= 0 && apab <= abab && apad <= adad) {
-        px[n * STRIDE] = v1x[i]; py[n * STRIDE] = v1y[i]; n++;
+        if constexpr (STORE) { px[n * STRIDE] = v1x[i]; py[n * STRIDE] = v1y[i]; }
+        n++;
       }
     }
   }
@@ -330,10 +329,33 @@ OBB_HD float rbox_iou(const RBoxFeat& A, const RBoxFeat& B, float* px, float* py
       float apab = apx * e1x[0] + apy * e1y[0];
       float apad = -(apx * e1x[3] + apy * e1y[3]);
       if (apab >= 0 && apad >= 0 && apab <= abab && apad <= adad) {
-        px[n * STRIDE] = v2x[i]; py[n * STRIDE] = v2y[i]; n++;
+        if constexpr (STORE) { px[n * STRIDE] = v2x[i]; py[n * STRIDE] = v2y[i]; }
+        n++;
       }
     }
   }
+  return n;
+}
+
+// the count alone; -1: a box of (numerically) no area -- the reference returns 0 before it looks at any point (:353)
+OBB_HD int rbox_npoints(const RBoxFeat& A, const RBoxFeat& B) {
+  constexpr float kAreaLt = f32_ceil(1e-14);   // area < 1e-14
+  if (A.area < kAreaLt || B.area < kAreaLt) return -1;
+  return rbox_points<1, false>(A, B, nullptr, nullptr);
+}
+
+// Full clip.  A = higher-scored ("row") box, B = lower-scored ("column") box:
+// the argument order is part of the contract (nms_rotated_cuda.cu:60).
+// px/py: scratch for 24 points, element i at [i * STRIDE].
+template <int STRIDE>
+OBB_HD float rbox_iou(const RBoxFeat& A, const RBoxFeat& B, float* px, float* py) {
+  constexpr float kAreaLt = f32_ceil(1e-14);   // area < 1e-14
+  constexpr float kCpLtNeg = f32_ceil(-1e-6);  // cp < -1e-6
+  constexpr float kCpLt = f32_ceil(1e-6);      // fabs(cp) < 1e-6
+  constexpr float kD2Gt = f32_floor(1e-8);     // dist > 1e-8
+
+  if (A.area < kAreaLt || B.area < kAreaLt) return 0.f;  // :353
+  const int n = rbox_points<STRIDE, true>(A, B, px, py);
 
   float inter = 0.f;
   if (n > 2) {
