@@ -212,7 +212,7 @@ int64_t obb_task1_format_rows(const char* text_host, const int32_t* name_off_hos
  *               clip is ill conditioned for such a box against a partner tens of thousands of pixels away, i.e. across its
  *               cls * max_wh offsets (utils/general.py:849-851), so an image holding one may only keep its per-class NMS segments if
  *               no such pair has IoU > iou_thres.  With the bit set the call checks exactly that (k_tiny_cross: the reference's own
- *               arithmetic on every ill-conditioned cross-class pair; images with at most 512 such boxes and 2 * 10^6 box x candidate
+ *               arithmetic on every ill-conditioned cross-class pair; images with at most 64 such boxes and 262,144 box x candidate
  *               combinations: microseconds for the stray sub-pixel box of a trained detector) and keeps the class segments of every
  *               image that passes; without it -- and for an image that fails, is above those bounds, or holds a box whose circle
  *               leaves a 0.95 max_wh window -- the image runs as the reference's single list.  Either way the rows are the reference's.

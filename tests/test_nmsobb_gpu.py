@@ -153,7 +153,7 @@ def test_sub_pixel_boxes_keep_their_class_segments_unless_classes_really_interac
     st = general.hint_get(dev, A, nc, True, 0.25)
     assert st["small_boxes"] and st["small_resolved"]                       # image 1 kept its class segments (image 2 did not: exact either way)
     many = pred.clone()                                                    # ~800 sub-pixel boxes (a random-initialised head): above the check's
-    lots = torch.rand(A, generator=g) < 0.05                               # bound of 512, the image stays on the single list -- same rows
+    lots = torch.rand(A, generator=g) < 0.05                               # bound of 64, the image stays on the single list -- same rows
     many[1, lots, 3] = torch.rand(int(lots.sum()), generator=g) * 0.6 + 0.3
     many[1, lots, 4] = 0.95
     refm = pyref.non_max_suppression_obb(many.clone(), **kw)

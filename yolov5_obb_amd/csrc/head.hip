@@ -513,32 +513,66 @@ __device__ __forceinline__ void vt_label_box(const float* t, const ValTailImgs& 
 // initialisation).  The label boxes are computed where they are used (a detection meets one or two labels of its image and class),
 // and the winner of a label -- the lowest-indexed detection of the image whose best label it is (process_batch's first np.unique
 // pass, val.py:84-86) -- is found by the stats kernel with a scan over the earlier detections of the image.
-// per detection: the four outputs of val.py:226-236 and its best label (process_batch, see k_pb_best) among the labels of ITS image
+// per detection: the four outputs of val.py:226-236 and its best label (process_batch, see k_pb_best) among the labels of ITS image.
+// The label boxes of the one or two images a workgroup's 128 detections belong to are computed once into LDS (a detection
+// computing the box of every label it meets -- double-precision sin / cos on divergent lanes -- made the kernel slower than the
+// launch it saved); more than kVtLabLds labels in range: computed where they are met.
+constexpr int kVtLabLds = 512;
 __global__ void k_vt_dets(const float* __restrict__ det7, int n, ValTailImgs im, const float* __restrict__ targets, int nt, int tcols,
                           const float* __restrict__ iouv, float* __restrict__ poly10, float* __restrict__ hbb6, float* __restrict__ polyn10,
                           float* __restrict__ hbbn6, int* __restrict__ best_label, float* __restrict__ best_iou, int* __restrict__ counter) {
+  __shared__ float s_lab[kVtLabLds][4];
+  __shared__ float s_lc[kVtLabLds];
+  __shared__ int s_li[kVtLabLds], s_lb[kVtLabLds];
+  __shared__ int s_nl;
   if (blockIdx.x == 0 && threadIdx.x == 0) *counter = 0;       // k_vt_stats' arrival counter (that kernel runs behind this one)
   const int d = blockIdx.x * blockDim.x + threadIdx.x;
+  const int d_first = blockIdx.x * blockDim.x, d_last = (d_first + (int)blockDim.x < n ? d_first + (int)blockDim.x : n) - 1;
+  int b_lo = 0, b_hi = 0;
+  while (b_lo + 1 < im.bs && d_first >= im.det_off[b_lo + 1]) b_lo++;   // (bs <= 64: short scans of kernel-argument registers)
+  b_hi = b_lo;
+  while (b_hi + 1 < im.bs && d_last >= im.det_off[b_hi + 1]) b_hi++;
+  if (threadIdx.x == 0) s_nl = 0;
+  __syncthreads();
+  for (int l = threadIdx.x; l < nt; l += blockDim.x) {
+    const float* t = targets + (size_t)l * tcols;
+    const int lb = (int)t[0];
+    if (lb >= b_lo && lb <= b_hi) {
+      const int k = atomicAdd(&s_nl, 1);
+      if (k < kVtLabLds) { s_li[k] = l; s_lb[k] = lb; s_lc[k] = t[1]; vt_label_box(t, im, lb, s_lab[k]); }
+    }
+  }
+  __syncthreads();
+  const int nl = s_nl;
   if (d >= n) return;
-  int b = 0;
-  while (b + 1 < im.bs && d >= im.det_off[b + 1]) b++;           // (bs <= 64: a short scan of kernel-argument registers)
+  int b = b_lo;
+  while (b + 1 < im.bs && d >= im.det_off[b + 1]) b++;
   float b2[4];
   vt_post_one(det7 + (size_t)d * 7, d, im.pad_x[b], im.pad_y[b], im.gain[b], poly10, hbb6, polyn10, hbbn6, b2);
   const float cls = det7[(size_t)d * 7 + 6];
   const float thr0 = iouv[0];                                            // val.py:81  iou >= iouv[0]
   const float area2 = (b2[2] - b2[0]) * (b2[3] - b2[1]);
   int bl = -1; float bi = -1.f;
-  for (int l = 0; l < nt; l++) {
-    const float* t = targets + (size_t)l * tcols;
-    if ((int)t[0] != b || t[1] != cls) continue;
-    float b1[4];
-    vt_label_box(t, im, b, b1);
+  auto consider = [&](const float* b1, int l) {
     const float area1 = (b1[2] - b1[0]) * (b1[3] - b1[1]);
     const float iw = fmaxf(fminf(b1[2], b2[2]) - fmaxf(b1[0], b2[0]), 0.f);
     const float ih = fmaxf(fminf(b1[3], b2[3]) - fmaxf(b1[1], b2[1]), 0.f);
     const float inter = iw * ih;
     const float iou = inter / (area1 + area2 - inter);                 // utils/metrics.py:265-268
-    if (iou >= thr0 && iou > bi) { bi = iou; bl = l; }
+    // the best label = the first maximum in label order (the staged list is in arrival order: the tie goes to the lower index)
+    if (iou >= thr0 && (iou > bi || (iou == bi && l < bl))) { bi = iou; bl = l; }
+  };
+  if (nl <= kVtLabLds) {
+    for (int k = 0; k < nl; k++)
+      if (s_lb[k] == b && s_lc[k] == cls) consider(s_lab[k], s_li[k]);
+  } else {
+    for (int l = 0; l < nt; l++) {
+      const float* t = targets + (size_t)l * tcols;
+      if ((int)t[0] != b || t[1] != cls) continue;
+      float b1[4];
+      vt_label_box(t, im, b, b1);
+      consider(b1, l);
+    }
   }
   best_label[d] = bl; best_iou[d] = bi;
 }

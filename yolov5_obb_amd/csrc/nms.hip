@@ -586,7 +586,7 @@ static int nms_steps(int kind, NmsArgs& a, const Carve& cv, int64_t nseg, int64_
   a.bar_sub = cv.nedges + kMaxTeams;                 // group counters of the grid-wide barrier, behind the per-team words
   a.cap_first = cap_first();
   { static const int grow = [] { const int v = obb_dev_switch("OBB_NMS_GROW", 2); return (v < 2 || v > 8) ? 2 : v; }(); a.grow_sparse = grow; }
-  { static const int lpt = obb_dev_switch("OBB_NMS_LPT", 1) != 0; a.lpt = lpt; }      // A/B switch (development builds): rows of a chunk largest first
+  { static const int lpt = obb_dev_switch("OBB_NMS_LPT", 1) & 1; a.lpt = lpt; }      // A/B switch (development builds): rows of a chunk largest first
   static const int phase_prof = [] { const char* e = getenv("OBB_NMS_PHASE_PROF"); return (e && atoi(e)) ? 1 : 0; }();
   a.prof = nullptr;
   if (phase_prof) {   // development aid: print the previous call's phase times (synchronises!)

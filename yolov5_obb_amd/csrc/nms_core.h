@@ -819,21 +819,34 @@ OBB_COLD_RESOLVE int nms_resolve(const NmsArgs& a, int g, int sb, int tm, int cn
   // with 255 workgroups waiting for it (S-uniform at 100k, in-kernel timers: the mean workgroup spent 560 us in its cross phases, the
   // slowest of every step added up to 1010 us).  The order of `rows` is free: the cross phases only need the SET (kills are
   // idempotent), the output order comes from `olist`.  Four buckets by radius relative to the chunk's largest, in bucket order.
-  uint32_t* lcode = olist + a.capmax;                         // [total] bucket << 16 | slot in the bucket   (lcap >= 2 capmax + 8: checked below)
-  int* lcnt = reinterpret_cast<int*>(olist + 2 * (size_t)a.capmax);   // [0..3] bucket sizes, [4] largest radius (float bits; radii are >= 0)
-  const bool lpt = a.lpt != 0 && a.gmeta != nullptr && a.nseg == 1 && a.keep_out != nullptr && total >= 512 && lcap >= 2LL * a.capmax + 8;
+  uint32_t* lcode = olist + a.capmax;                         // [total] bucket << 16 | slot in the bucket   (lcap >= 3 capmax + 8: checked below)
+  int* lcnt = reinterpret_cast<int*>(olist + 3 * (size_t)a.capmax);   // [0..3] bucket sizes, [4] largest radius (float bits; radii are >= 0)
+  const bool lpt = (a.lpt & 1) != 0 && a.gmeta != nullptr && a.nseg == 1 && a.keep_out != nullptr && total >= 512 && lcap >= 3LL * a.capmax + 8;
   if (lpt) {
     if (tid < 5) lcnt[tid] = 0;
     __syncthreads();
     int mx = 0;
+    // (the radius travels together with the original index the output needs: one round trip per four entries, as without the
+    //  ordering -- a first version fetched them in two passes and its resolver ran 12 us per step longer, most of what it saved)
     for (int k0 = tid; k0 < total; k0 += 4 * kNmsThreads) {
       float rv[4];
-#pragma unroll
-      for (int u = 0; u < 4; u++) { const int k = k0 + u * kNmsThreads; rv[u] = k < total ? a.rec[(size_t)olist[k] * 4].z : 0.f; }
+      uint32_t ov[4];
 #pragma unroll
       for (int u = 0; u < 4; u++) {
         const int k = k0 + u * kNmsThreads;
-        if (k < total) { const int rb = __float_as_int(rv[u] >= 0.f ? rv[u] : 0.f); lcode[k] = (uint32_t)rb; mx = rb > mx ? rb : mx; }   // (NaN: 0)
+        const uint32_t pos = k < total ? olist[k] : 0u;
+        rv[u] = k < total ? a.rec[(size_t)pos * 4].z : 0.f;
+        ov[u] = (k < total && a.order) ? a.order[pos] : pos;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int k = k0 + u * kNmsThreads;
+        if (k < total) {
+          const int rb = __float_as_int(rv[u] >= 0.f ? rv[u] : 0.f);                  // (NaN: 0)
+          lcode[k] = (uint32_t)rb; mx = rb > mx ? rb : mx;
+          const long long o = (long long)kept_before + k;
+          if (a.max_keep <= 0 || o < a.max_keep) a.keep_out[(size_t)sb + o] = (int64_t)ov[u];
+        }
       }
     }
 #pragma unroll
@@ -858,8 +871,18 @@ OBB_COLD_RESOLVE int nms_resolve(const NmsArgs& a, int g, int sb, int tm, int cn
     }
     __syncthreads();
   }
-  const int lb1 = lpt ? lcnt[0] : 0, lb2 = lpt ? lb1 + lcnt[1] : 0, lb3 = lpt ? lb2 + lcnt[2] : 0;
-  for (int k0 = tid; k0 < total; k0 += 4 * kNmsThreads) {
+  if (lpt) {                                                    // the rows in bucket order: scattered in LDS, stored coalesced
+    uint32_t* olist2 = lcode + a.capmax;                        // (behind lcode; lcnt moved behind it: 3 capmax + 8 <= lcap)
+    const int lb1 = lcnt[0], lb2 = lb1 + lcnt[1], lb3 = lb2 + lcnt[2];
+    for (int k = tid; k < total; k += kNmsThreads) {
+      const uint32_t c = lcode[k];
+      const int q = (int)(c >> 16);
+      olist2[(q == 0 ? 0 : (q == 1 ? lb1 : (q == 2 ? lb2 : lb3))) + (int)(c & 0xffffu)] = olist[k];
+    }
+    __syncthreads();
+    for (int k = tid; k < total; k += kNmsThreads) stg_agent(rows + k, olist2[k]);
+  }
+  for (int k0 = tid; k0 < total && !lpt; k0 += 4 * kNmsThreads) {
     uint32_t pv[4], ov[4];
     bool ok[4];
 #pragma unroll
@@ -879,9 +902,7 @@ OBB_COLD_RESOLVE int nms_resolve(const NmsArgs& a, int g, int sb, int tm, int cn
       if (!ok[u]) continue;
       const int k = k0 + u * kNmsThreads;
       const uint32_t pos = pv[u];
-      int kr = k;                                               // the row's place in the cross phase's list
-      if (lpt) { const uint32_t c = lcode[k]; const int q = (int)(c >> 16); kr = (q == 0 ? 0 : (q == 1 ? lb1 : (q == 2 ? lb2 : lb3))) + (int)(c & 0xffffu); }
-      stg_agent(rows + kr, pos);
+      stg_agent(rows + k, pos);
       const long long o = (long long)kept_before + k;
       if (a.keep_out != nullptr) {
         if (a.max_keep <= 0 || o < a.max_keep) a.keep_out[(size_t)sb + o] = (int64_t)ov[u];
@@ -1245,6 +1266,10 @@ __device__ __forceinline__ void nms_cross_grid(const NmsArgs& a, const GridPlan&
   // twice the average (uniform, 100k: 2069 -> 1841 us with the pooled deal).  Tickets of four rows drawn by the
   // workgroups from one agent-scope counter were measured as well (1847 us): the tail of a phase is one ITEM long
   // (30-80 us), whoever draws it -- not kept.
+  // (Round 5, with the rows largest first -- nms_resolve -- so that the LAST items are the cheap ones: the last quarter of the items
+  //  drawn by the waves from one agent-scope counter, four items per draw, the rest dealt statically.  Measured on one box: S-uniform
+  //  1.83-1.86 ms against 1.575 with the static deal alone, K=3000 0.66 against 0.63 -- a draw of four items is a coarser tail than
+  //  one item of the static deal, and the waves of all workgroups queue on one address.  Not kept.)
   const int wgi = tw / kNmsWaves, Tw = ntw / kNmsWaves;
   __syncthreads();
   if (threadIdx.x == 0) *s_next = 0;

@@ -371,12 +371,14 @@ __global__ void k_append_extra(const float* __restrict__ extra8, int m, long lon
 // offsets -- and the whole clip only for the pairs with more.  No IoU > thr among them: the classes of the image cannot interact
 // (well-conditioned cross-class pairs have disjoint circles inside their windows: the reference returns exactly 0), its class
 // segments give the reference's kept set.  Otherwise the image keeps the reference's single list -- and so does an image with more
-// than kTinyMax short-sided boxes or more than kTinyPairs (box, candidate) combinations (bounded cost: ~0.1 ms per image at the
-// bound; a trained detector's stray sub-pixel box costs microseconds).
+// than kTinyMax short-sided boxes or more than kTinyPairs (box, candidate) combinations: the check is for the stray sub-pixel box of
+// a trained detector (microseconds), and bounded at a few tens of microseconds per image.  (Measured on the conv stand-in's random-
+// initialised heads, which put hundreds of sub-pixel boxes into some images: with bounds of 512 / 2 x 10^6 the check cost 0.7 ms per
+// batch there and saved 0.4 ms of NMS kernel; such images keep the single list.)
 // Launched only when the caller's previous call of the shape met such boxes (expected_cand bit 62): grid (kTinyParts, bs),
 // blocks of images without the flag return at once.  Candidates beyond the top-max_nms cut are tested as well: conservative.
-constexpr int kTinyMax = 512;             // short-sided boxes of an image the check takes ...
-constexpr long long kTinyPairs = 2000000; // ... and candidates x short-sided boxes: above either the image is not checked (single list)
+constexpr int kTinyMax = 64;              // short-sided boxes of an image the check takes ...
+constexpr long long kTinyPairs = 262144;  // ... and candidates x short-sided boxes: above either the image is not checked (single list)
 constexpr int kTinyParts = 32;
 __global__ __launch_bounds__(256) void k_tiny_cross(const float4* __restrict__ cand, const unsigned long long* __restrict__ keys,
                                                     const int* __restrict__ cnt, long long cap_img, float class_offset, float thr,
