@@ -109,7 +109,7 @@ def bench_next_rows(dev, dets_per_image):
             poly, hbb, polyn, hbbn = V.val_postprocess(d, ratio_pad=((0.7314, 0.7314), (12.0, 3.5)))
             V.process_batch(hbbn, lb, iouv)
     ms = wall(tail, 20)
-    # ... and the whole batch in one call (val.val_tail_batch: three launches + one copy; what val_sharded.run uses)
+    # ... and the whole batch in one call (val.val_tail_batch: two launches, rows into polled pinned memory; what val_sharded.run uses)
     tg = torch.cat([torch.cat((torch.full((lb.shape[0], 1), float(i), device=dev), lb[:, :1], torch.zeros((lb.shape[0], 5), device=dev)), 1)
                     for i, lb in enumerate(labels)], 0)
     for i, (d, lb) in enumerate(zip(dets_per_image, labels)):          # label rows [img cls cx cy l s theta]: boxes around the detections' own
@@ -118,6 +118,9 @@ def bench_next_rows(dev, dets_per_image):
         tg[sel, 2:7] = d[:k, :5]
     shapes_b = [((1400, 1400), ((0.7314, 0.7314), (12.0, 3.5)))] * len(dets_per_image)
     ms_batch = wall(lambda: V.val_tail_batch(dets_per_image, tg, shapes_b, iouv), 20)
+    # (the labels above are half as many as the detections -- ~115 per image; a DOTA tile holds a few dozen: the same call with 23 per image)
+    tg23 = torch.cat([tg[tg[:, 0] == i][:23] for i in range(len(dets_per_image))], 0).contiguous()
+    ms_batch23 = wall(lambda: V.val_tail_batch(dets_per_image, tg23, shapes_b, iouv), 20)
     d0, l0 = dets_per_image[0].cpu(), labels[0].cpu()
     t0 = time.perf_counter()
     for _ in range(5):
@@ -126,9 +129,11 @@ def bench_next_rows(dev, dets_per_image):
     cms = (time.perf_counter() - t0) / 5 * 1e3
     res["val_tail"] = {"workload": f"{len(dets_per_image)} images x ~{int(dets_per_image[0].shape[0])} detections: val_postprocess + process_batch",
                        "ms_per_batch": round(ms_batch, 3), "ms_per_image": round(ms_batch / len(dets_per_image), 4),
+                       "labels_per_image": int(tg.shape[0]) // len(dets_per_image), "ms_per_batch_23_labels_per_image": round(ms_batch23, 3),
                        "ms_per_batch_per_image_calls": round(ms, 3),
-                       "note": "ms_per_batch: val.val_tail_batch (three launches, the statistics written straight into polled pinned host memory); "
-                               "ms_per_batch_per_image_calls: round 3's loop of val_postprocess + process_batch per image",
+                       "note": "ms_per_batch: val.val_tail_batch through the active binding (two launches since round 5, the statistics written straight into "
+                               "polled pinned host memory), with as many labels as half the detections; ms_per_batch_23_labels_per_image: the same with a DOTA "
+                               "tile's label count; ms_per_batch_per_image_calls: round 3's loop of val_postprocess + process_batch per image",
                        "cpu_port_ms_per_image": round(cms, 3)}
     # ---- ResultMerge: one class file of 300 source images (tiles 1024/824, two rates)
     lines = gg.merge_input_lines(300, 40, 7, False)
@@ -228,7 +233,7 @@ def spawn_ranks(args, argv):
             return 2
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")           # dmabuf IPC: RCCL across processes needs it on this driver
-    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // max(1, args.gpus))))
+    env.setdefault("OMP_NUM_THREADS", str(max(1, host_cpu_budget() // max(1, args.gpus))))      # (the container's CPU quota, shared by the ranks)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
            "--master-port", str(free_port()), os.path.abspath(__file__)] + list(argv)
     return subprocess.call(cmd, env=env)
@@ -329,7 +334,7 @@ def main():
     # and the kernel's CFS bandwidth control parks EVERY thread of the process until the period ends: the "~70-88 ms stall of any call"
     # of rounds 2-4 (profiles/r5_host_stall.md: cpu.stat nr_throttled grows with the stalls, OMP_NUM_THREADS=1 removes both).  The
     # bench keeps torch inside the budget it really has.
-    torch.set_num_threads(host_cpu_budget())
+    torch.set_num_threads(max(1, host_cpu_budget() // max(1, world)))      # (the ranks of one node share the container's quota)
 
     def barrier():
         if dist is not None:

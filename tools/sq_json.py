@@ -15,7 +15,7 @@ def main():
     rows = {}
     for line in open(path):
         if line.startswith("## `"):
-            sec = line.split("`")[1]
+            sec = line.split("`")[1].replace("obb::", "")
             hdr = None
             continue
         if sec and line.startswith("| # |"):

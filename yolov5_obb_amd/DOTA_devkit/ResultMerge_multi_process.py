@@ -108,14 +108,20 @@ def py_cpu_nms(dets, thresh):
 
 
 def nmsbynamedict(nameboxdict, nms, thresh):
-    """:159-174.  With nms = py_cpu_nms_poly_fast all images go to the device in one call."""
-    if nms is py_cpu_nms_poly_fast:
+    """:159-174.  With one of this module's three NMS functions all images go to the device in ONE call (every image a segment of
+    the persistent kernel, its own `argsort()[::-1]` as the processing order); any other callable is applied image by image like
+    the reference does."""
+    variant = {py_cpu_nms_poly_fast: ("poly_fast", 8), py_cpu_nms_poly: ("poly_all", 8), py_cpu_nms: ("hbb", 4)}.get(nms)
+    if variant is not None:
         names = list(nameboxdict)
-        arrs = [np.asarray(nameboxdict[k], dtype=np.float64).reshape(-1, 9) for k in names]
-        base = np.cumsum([0] + [len(a) for a in arrs])
-        orders = [a[:, 8].argsort()[::-1] + base[i] for i, a in enumerate(arrs)]
-        keeps = merge_nms_segments(np.concatenate(arrs) if arrs else np.zeros((0, 9)), orders, thresh)
-        return {k: [nameboxdict[k][int(j - base[i])] for j in keeps[i]] for i, k in enumerate(names)}
+        arrs = [np.asarray(nameboxdict[k], dtype=np.float64) for k in names]
+        # (rows of nine numbers, [8 coordinates, score]: what parse_result_file produces; anything else goes image by image, where
+        #  the per-image functions raise what the reference raises)
+        if all(a.ndim == 2 and a.shape[1] == 9 for a in arrs):
+            base = np.cumsum([0] + [len(a) for a in arrs])
+            orders = [a[:, variant[1]].argsort()[::-1] + base[i] for i, a in enumerate(arrs)]          # :79 / :35 / :136
+            keeps = merge_nms_segments(np.concatenate(arrs) if arrs else np.zeros((0, 9)), orders, thresh, variant=variant[0])
+            return {k: [nameboxdict[k][int(j - base[i])] for j in keeps[i]] for i, k in enumerate(names)}
     return {k: [nameboxdict[k][int(j)] for j in nms(np.array(nameboxdict[k]), thresh)] for k in nameboxdict}
 
 
