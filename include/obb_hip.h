@@ -296,7 +296,8 @@ int obb_loss_export_targets(const obb_loss_config* cfg, int64_t nt, int level, i
  * dtype 0 = fp32, 1 = fp16 (arithmetic is fp32 either way).  loss_out (device, 5 + nl floats):
  * [0] (lbox+lobj+lcls+ltheta)*bs, [1..4] lbox, lobj, lcls, ltheta (gains applied), [5+i] the un-balanced objectness
  * BCE of level i (what autobalance reads, :180-181).  [0] is NaN when a target row is out of range.
- * The workspace keeps the matched rows for obb_loss_backward: pass the same buffer, untouched. */
+ * The workspace keeps the matched rows and (round 5) a dense copy of every anchor row's objectness logit for obb_loss_backward
+ * (which then reads 4 contiguous bytes per row instead of one 128-byte line of each 800-byte row): pass the same buffer, untouched. */
 int obb_loss_forward(const obb_loss_config* cfg, const void* const* p_levels_host, int dtype, const float* targets, int64_t nt,
                      int64_t tcols, float* loss_out, void* ws, size_t ws_bytes, void* stream);
 /* Gradient of loss_out[0] with respect to every p[i], times *grad_scale (device scalar: the incoming dL/dloss, e.g.

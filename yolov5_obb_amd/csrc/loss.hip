@@ -60,6 +60,8 @@ struct LossDev {
   float4* e_tbox;
   float *part_box, *part_cls, *part_th, *part_obj;
   double* dense_part;     // [nl][kDenseBlocks]
+  float* objcol;          // [sum rows] the objectness logit of every anchor row, written densely by the forward's dense pass
+                          // (round 5): the backward reads 4 contiguous bytes per row instead of one 128-byte line of an 800-byte row
 };
 
 __global__ void k_loss_setup(LossDev d, LossDev* dst) {
@@ -234,6 +236,7 @@ __global__ __launch_bounds__(256) void k_loss_dense_fwd(const LossDev* __restric
   const T* p = (const T*)d.p[lv];
   const int no = d.no;
   const float pw = d.obj_pw, fg = d.fl_gamma;
+  float* col = d.objcol + d.cell_off[lv];              // the level's slice of the dense logit column (the backward's input)
   float acc = 0.f;
   const long long step = (long long)gridDim.x * 256;
   long long r = (long long)blockIdx.x * 256 + tid;
@@ -242,9 +245,10 @@ __global__ __launch_bounds__(256) void k_loss_dense_fwd(const LossDev* __restric
     const float x1 = ld_as_float<T>(p + (size_t)(r + step) * no + 4);
     const float x2 = ld_as_float<T>(p + (size_t)(r + 2 * step) * no + 4);
     const float x3 = ld_as_float<T>(p + (size_t)(r + 3 * step) * no + 4);
+    col[r] = x0; col[r + step] = x1; col[r + 2 * step] = x2; col[r + 3 * step] = x3;
     acc += bce_focal(x0, 0.f, pw, fg); acc += bce_focal(x1, 0.f, pw, fg); acc += bce_focal(x2, 0.f, pw, fg); acc += bce_focal(x3, 0.f, pw, fg);
   }
-  for (; r < rows; r += step) acc += bce_focal(ld_as_float<T>(p + (size_t)r * no + 4), 0.f, pw, fg);
+  for (; r < rows; r += step) { const float x = ld_as_float<T>(p + (size_t)r * no + 4); col[r] = x; acc += bce_focal(x, 0.f, pw, fg); }
   const double w = wave_sum_d((double)acc);
   if ((tid & 63) == 0) s_part[tid >> 6] = w;
   __syncthreads();
@@ -400,7 +404,7 @@ __global__ __launch_bounds__(256) void k_loss_bwd_dense(const LossDev* __restric
   const int lv = blockIdx.y, lane = threadIdx.x & 63;
   const long long rows = d.rows[lv];
   const int no = d.no;
-  const T* p = (const T*)d.p[lv];
+  const float* col = d.objcol + d.cell_off[lv];
   T* g = (T*)d.grad[lv];
   const float inv_no = 1.0f / (float)no;
   // a target row that named an image or class outside the batch (the reference raises IndexError) made the loss NaN in
@@ -412,7 +416,9 @@ __global__ __launch_bounds__(256) void k_loss_bwd_dense(const LossDev* __restric
     const long long R0 = rg << 6;
     const int nr = (int)((rows - R0) < 64 ? (rows - R0) : 64);
     // d BCE(x, 0)/dx = sigmoid(x) for every pos_weight (FocalLoss: the general form)
-    const float gv = (lane < nr) ? bce_focal_grad(ld_as_float<T>(p + (size_t)(R0 + lane) * no + 4), 0.f, d.obj_pw, d.fl_gamma) * gs : 0.f;
+    // (the logit from the column the forward left: one coalesced 256-byte read per 64 rows -- reading p[row][4] cost a 128-byte line
+    //  per row, 132 MB next to the 830 MB this kernel writes; the value is the same float)
+    const float gv = (lane < nr) ? bce_focal_grad(col[R0 + lane], 0.f, d.obj_pw, d.fl_gamma) * gs : 0.f;
     const int nel = nr * no;
     T* gb = g + (size_t)R0 * no;                      // 64*no*sizeof(T) bytes per region: 16-byte aligned
     const int nch = (nel + V - 1) / V;
@@ -522,7 +528,7 @@ static inline size_t al(size_t v) { return (v + 255) / 256 * 256; }
 struct LossCarve {
   LossDev* dev;
   int* counts; int* head; int *e_cell, *e_t, *e_ao, *prev; float4* e_tbox;
-  float *part_box, *part_cls, *part_th, *part_obj; double* dense_part;
+  float *part_box, *part_cls, *part_th, *part_obj; double* dense_part; float* objcol;
   int* blkcnt; float* lvl_out;
   size_t head_bytes, total;
 };
@@ -555,6 +561,7 @@ static void loss_carve(void* base, const obb_loss_config* c, int64_t nt, LossCar
   cv->e_tbox = (float4*)take(ce * 16);
   cv->part_box = (float*)take(ce * 4); cv->part_cls = (float*)take(ce * 4); cv->part_th = (float*)take(ce * 4); cv->part_obj = (float*)take(ce * 4);
   cv->dense_part = (double*)take((size_t)kLv * kDenseBlocks * 8);
+  cv->objcol = (float*)take((size_t)tot * 4);
   cv->lvl_out = (float*)take(kLv * 4 * 4);
   cv->blkcnt = (int*)take(((size_t)5 * c->na * (size_t)nt / 1024 + 2) * c->nl * 4);
   cv->total = off;
@@ -580,7 +587,7 @@ static void loss_fill(LossDev& d, const obb_loss_config* c, const LossCarve& cv,
   d.targets = targets;
   d.counts = cv.counts; d.head = cv.head; d.e_cell = cv.e_cell; d.e_t = cv.e_t; d.e_ao = cv.e_ao; d.prev = cv.prev;
   d.e_tbox = cv.e_tbox; d.part_box = cv.part_box; d.part_cls = cv.part_cls; d.part_th = cv.part_th; d.part_obj = cv.part_obj;
-  d.dense_part = cv.dense_part;
+  d.dense_part = cv.dense_part; d.objcol = cv.objcol;
 }
 
 static int run_match(const obb_loss_config* c, const LossCarve& cv, const LossDev& d, hipStream_t st) {

@@ -602,7 +602,7 @@ static int nms_steps(int kind, NmsArgs& a, const Carve& cv, int64_t nseg, int64_
               h[21], h[16] * 0.01, h[19], h[17] * 0.01, h[20], h[18] * 0.01, h[18] * 0.01, h[20], h[15], h[10]);
       fprintf(stderr, "    pairs, wg0 wave 0: items %llu = %.1f us (loads %.1f), stage-1a drains %llu = %.1f us, stage-1b drains %llu = %.1f us, exact drains %llu = %.1f us | slab set-up %.1f us, merge %.1f us (wg0)\n",
               h[32], h[33] * 0.01, h[40] * 0.01, h[34], h[35] * 0.01, h[36], h[37] * 0.01, h[38], h[39] * 0.01, h[41] * 0.01, h[8] * 0.01);
-      if (h[41]) fprintf(stderr, "    slab set-up (wg0): runs %.1f, count %.1f, barrier %.1f, table %.1f (copy %.1f, sums %.1f, decision %.1f), scatter %.1f + plan %.1f, barrier %.1f us\n",
+      if (h[43]) fprintf(stderr, "    slab set-up (wg0): runs %.1f, count %.1f, barrier %.1f, table %.1f (copy %.1f, sums %.1f, decision %.1f), scatter %.1f + plan %.1f, barrier %.1f us\n",
                          h[42] * 0.01, h[43] * 0.01, h[44] * 0.01, (h[48] + h[49] + h[45]) * 0.01, h[48] * 0.01, h[49] * 0.01, h[45] * 0.01, h[50] * 0.01,
                          h[46] * 0.01, h[47] * 0.01);
     }

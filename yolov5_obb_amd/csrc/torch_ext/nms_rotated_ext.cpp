@@ -74,15 +74,18 @@ struct Pinned {
   int64_t n = 0;
 };
 // one buffer per (thread, device, purpose, size): never handed out, re-armed before every call
+// (The buffers are never freed: a pinned tensor released from a thread_local destructor at interpreter shutdown would call into a
+//  host allocator that may be gone already; a few dozen bytes per (thread, device, batch size).)
 Pinned& pinned_words(int dev, int purpose, int64_t n) {
-  static thread_local std::map<std::tuple<int, int, int64_t>, Pinned> memo;
-  Pinned& e = memo[std::make_tuple(dev, purpose, n)];
-  if (!e.p) {
-    e.t = at::empty({n}, at::TensorOptions().dtype(at::kLong).pinned_memory(true));
-    e.p = e.t.data_ptr<int64_t>();
-    e.n = n;
+  static thread_local std::map<std::tuple<int, int, int64_t>, Pinned*> memo;
+  Pinned*& e = memo[std::make_tuple(dev, purpose, n)];
+  if (!e) {
+    e = new Pinned();
+    e->t = at::empty({n}, at::TensorOptions().dtype(at::kLong).pinned_memory(true));
+    e->p = e->t.data_ptr<int64_t>();
+    e->n = n;
   }
-  return e;
+  return *e;
 }
 void arm(Pinned& w) {
   for (int64_t i = 0; i < w.n; i++) __atomic_store_n(w.p + i, kPending, __ATOMIC_RELAXED);
@@ -414,8 +417,10 @@ py::object val_tail_batch(const std::vector<at::Tensor>& preds, const at::Tensor
     nt = tg.size(0); tcols = tg.size(1);
   }
   const at::Tensor iv = iouv.to(dev, at::kFloat).contiguous();
-  static thread_local std::map<int64_t, HostRows> pin_rows;            // per thread and row width; grown geometrically
-  HostRows& hr = pin_rows[niou + 2];
+  static thread_local std::map<int64_t, HostRows*> pin_rows;           // per thread and row width; grown geometrically; never freed (see pinned_words)
+  HostRows*& hrp = pin_rows[niou + 2];
+  if (!hrp) hrp = new HostRows();
+  HostRows& hr = *hrp;
   if (!hr.t.defined() || hr.rows < n) {
     hr.rows = std::max<int64_t>(1024, 2 * n); hr.cols = niou + 2;
     hr.t = at::empty({hr.rows, hr.cols}, at::TensorOptions().dtype(at::kFloat).pinned_memory(true));
