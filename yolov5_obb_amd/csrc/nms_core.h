@@ -1673,6 +1673,7 @@ __device__ __forceinline__ int slab_setup(const NmsArgs& a, float bin_x0, float 
       // (at most two group totals and two rows per thread: all requested before the first is used -- the loop form waited
       //  for every load in turn, four round trips to lines other workgroups had just written: 14.5 us of the set-up)
       const int g2a = part, g2b = part + kNmsWaves, wa = (grp << 4) + part, wb = wa + kNmsWaves;
+      // (agent-scope loads instead of plain ones behind the fence were measured: no difference)
       const int v0 = g2a < grp ? a.slab_tot[(size_t)(1 + g2a) * kMaxSlabs + s0] : 0;
       const int v1 = g2b < grp ? a.slab_tot[(size_t)(1 + g2b) * kMaxSlabs + s0] : 0;
       const int v2 = wa < wg ? a.slab_cnt[(size_t)wa * kMaxSlabs + s0] : 0;
@@ -1752,20 +1753,36 @@ __device__ __forceinline__ int slab_setup(const NmsArgs& a, float bin_x0, float 
   // ---- the plan: one team per non-empty slab, the spare workgroups in proportion to the sizes (written by workgroup 0)
   __syncthreads();
   if (wg == 0) {
+    // (all threads: the serial form -- thread 0 writing the NB entries -- took 10 us at the end of the one workgroup every other one
+    //  had already left behind: a fifth of the kernel)
     if (tid < kMaxSlabs) { SL.segb[tid] = tid < S ? base[tid] : 0; SL.sege[tid] = tid < S ? base[tid] + tot[tid] : 0; }
+    int* tsz = cnt;                                            // [kMaxSlabs] team size of a slab (0: empty), then its first workgroup in `run`
+    int* tfirst = run;                                         // (both arrays are free after the scatter)
+    __syncthreads();
     if (tid == 0) {
       long long total = 0;
       for (int s0 = 0; s0 < S; s0++) total += tot[s0];
       const int spare = NB - misc[2];
-      int w = 0, team = 0;
+      int w = 0;
       for (int s0 = 0; s0 < S; s0++) {
-        if (tot[s0] <= 0) continue;
-        const int T = 1 + (int)((long long)spare * tot[s0] / total);
-        for (int i = 0; i < T; i++) SL.wg[w + i] = make_int4(s0, team, i, T);
-        w += T; team++;
+        const int T = tot[s0] > 0 ? 1 + (int)((long long)spare * tot[s0] / total) : 0;
+        tsz[s0] = T; tfirst[s0] = w; w += T;
       }
-      for (; w < NB; w++) SL.wg[w] = make_int4(-1, 0, 0, 1);
+      misc[0] = w;                                             // workgroups with a slab
       SL.nslab = S;
+    }
+    __syncthreads();
+    for (int w = tid; w < NB; w += kNmsThreads) {
+      int4 e = make_int4(-1, 0, 0, 1);
+      if (w < misc[0]) {
+        int team = 0;
+        for (int s0 = 0; s0 < S; s0++) {
+          if (tsz[s0] <= 0) continue;
+          if (w >= tfirst[s0] && w < tfirst[s0] + tsz[s0]) { e = make_int4(s0, team, w - tfirst[s0], tsz[s0]); break; }
+          team++;
+        }
+      }
+      SL.wg[w] = e;
     }
   }
   slap(46);
