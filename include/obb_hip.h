@@ -219,7 +219,10 @@ int64_t obb_task1_format_rows(const char* text_host, const int32_t* name_off_hos
  *               Apart from the two retry cases the result does not depend on the hint.
  *   out         [bs][max_det][7] fp32 rows [x y l s theta conf cls];  out_count [bs] int64 (-1: device-side abort);
  *               out_packed != 0: the rows of image b start right behind those of image b-1 (row sum(out_count[0..b-1]))
- *               instead of at row b*max_det -- the same buffer size is required, one split instead of bs slices on the host
+ *               instead of at row b*max_det -- the same buffer size is required, one split instead of bs slices on the host.
+ *               out_packed = 0 is the faster form where the small-segment NMS kernel runs (expected_cand, bits 32..60): the rows of an
+ *               image do not wait for the counts of the images in front of it, so that kernel writes them itself (csrc/nmsobb_impl.h:
+ *               SmallGather) and the call is one launch shorter; obb_val_tail_batch_rows_f32 consumes that layout in place.
  *               status [2] int64: [0] overflow count (see cap_img), or -1 (see expected_cand); [1] largest candidate count of any
  *               image in bits 0..31, largest NMS segment in bits 32..60 (0 where the sort path does not know it), bit 62: an image
  *               held boxes with a sub-pixel short side -- hand these back as expected_cand of the next call of the shape; bit 61
@@ -368,6 +371,13 @@ int obb_val_tail_batch_f32(const float* det7, const int64_t* det_off_host, int64
 int obb_val_tail_batch_polled_f32(const float* det7, const int64_t* det_off_host, int64_t bs, const float* targets, int64_t nt,
                                   int64_t tcols, const float* img5_host, const float* iouv, int niou, float* poly10, float* hbb6,
                                   float* polyn10, float* hbbn6, float* stats, void* ws, size_t ws_bytes, void* stream, int64_t* done);
+/* The same for detections that are NOT packed: image b's rows are det7[det_row_host[b] .. det_row_host[b] + det_off_host[b+1] -
+ * det_off_host[b]) (bs host integers, rows of 7 floats from det7) -- the layout obb_non_max_suppression_obb writes with
+ * out_packed = 0 (det_row_host[b] = b * max_det), consumed where it lies.  Every OUTPUT stays packed by det_off_host.  done may be
+ * NULL (then the caller waits for the stream), else as above. */
+int obb_val_tail_batch_rows_f32(const float* det7, const int64_t* det_row_host, const int64_t* det_off_host, int64_t bs, const float* targets,
+                                int64_t nt, int64_t tcols, const float* img5_host, const float* iouv, int niou, float* poly10, float* hbb6,
+                                float* polyn10, float* hbbn6, float* stats, void* ws, size_t ws_bytes, void* stream, int64_t* done);
 
 /* process_batch (val.py:69-90): detections (n,6) [x1 y1 x2 y2 conf cls], labels (m,5) [cls x1 y1 x2 y2], iouv (niou) on the
  * device -> correct (n, niou) bytes (0/1).  No device->host round trip (the reference sorts the matches with numpy). */

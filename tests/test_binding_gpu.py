@@ -128,3 +128,42 @@ def test_val_tail_both_bindings_identical(dev, ctypes_binding):
         assert c1.dtype == torch.bool and torch.equal(c1, c2) and torch.equal(f1, f2) and torch.equal(p1, p2)
     for a, b in zip(boxes_c, boxes_p):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("bs,A,nc,max_det,fg,n_obj", [
+    (2, 6000, 80, 50, 0.06, 150),      # many classes, rows beyond max_det dropped by rank
+    (20, 4000, 16, 300, 0.03, 60),     # 320 segments: more workgroups than compute units
+    (4, 2000, 3, 300, 0.004, 30),      # a handful of rows per image (several lanes share one entry's lists), one image without any
+    (1, 12000, 200, 1500, 0.05, 300),  # 200 segments of one image
+    (16, 12000, 16, 1500, 0.03, 120),  # the shape of the headline step, smaller
+])
+def test_output_stage_inside_the_nms_kernel_matches_the_separate_one_and_the_oracle(dev, ctypes_binding, bs, A, nc, max_det, fg, n_obj):
+    """Round 5: with out_packed = 0 (the compiled binding) the small-segment NMS kernel writes the output rows itself
+    (csrc/nmsobb_impl.h: SmallGather); with out_packed = 1 (the ctypes binding) k_gather_out does, in a launch of its own.  Same
+    rows, the oracle's (utils/general.py:772-862), on the first (un-hinted) call and on the hinted ones."""
+    from oracle import pyref
+    from yolov5_obb_amd import _lib
+    from yolov5_obb_amd.utils.general import non_max_suppression_obb
+    pred = synth.s_pred(bs, A, nc, seed=100 + bs + nc, n_obj=n_obj, fg_frac=fg)
+    if bs == 4:
+        pred[1, :, 4] = 0.0
+    kw = dict(conf_thres=0.25, iou_thres=0.45, multi_label=True, max_det=max_det)
+    want = [synth.canon_rows(w) for w in pyref.non_max_suppression_obb(pred.clone(), **kw)]
+    pd = pred.to(dev)
+    rows = {}
+    for binding in ("ctypes", "compiled"):
+        if binding == "compiled":
+            _lib._ext_tried = False
+            assert _lib.compiled() is not None
+        for call in range(3):
+            got = non_max_suppression_obb(pd, **kw)
+            assert len(got) == bs
+            for b, (g, w) in enumerate(zip(got, want)):
+                assert g.shape[0] <= max_det
+                assert np.array_equal(synth.canon_rows(g.cpu()), w), (binding, call, b)
+        rows[binding] = [g.cpu() for g in got]
+    for a, b in zip(rows["ctypes"], rows["compiled"]):       # the ORDER of the rows as well (descending score: the reference's single pass)
+        assert torch.equal(a, b)
+    if bs > 1:
+        d0 = got[0].data_ptr()
+        assert all(g.data_ptr() == d0 + b * max_det * 28 for b, g in enumerate(got) if g.shape[0]), "image b's rows start at row b * max_det"

@@ -63,6 +63,7 @@ SIGNATURES = {
     "obb_val_tail_batch_workspace_bytes": (_sz, [_i64, _i64]),
     "obb_val_tail_batch_f32": (_i32, [_vp, _vp, _i64, _vp, _i64, _i64, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "obb_val_tail_batch_polled_f32": (_i32, [_vp, _vp, _i64, _vp, _i64, _i64, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp]),
+    "obb_val_tail_batch_rows_f32": (_i32, [_vp, _vp, _vp, _i64, _vp, _i64, _i64, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp]),
     "obb_process_batch_workspace_bytes": (_sz, [_i64, _i64]),
     "obb_process_batch_f32": (_i32, [_vp, _i64, _vp, _i64, _vp, _i32, _vp, _vp, _sz, _vp]),
     "obb_rotated_iou_pairs_f32": (_i32, [_vp, _vp, _i64, _vp, _vp]),

@@ -493,7 +493,8 @@ __global__ void k_pb_correct(const int* __restrict__ best_label, const float* __
 // two launches + a memset + three copies per image.
 constexpr int kValTailMaxBs = 64;
 struct ValTailImgs {                       // by value in the kernel arguments (bs <= kValTailMaxBs)
-  int det_off[kValTailMaxBs + 1];          // detections of image b: rows [det_off[b], det_off[b + 1]) of the packed list
+  int det_off[kValTailMaxBs + 1];          // detections of image b: rows [det_off[b], det_off[b + 1]) of the packed list (and of every output)
+  int det_row[kValTailMaxBs];              // row of det7 that holds the FIRST detection of image b (packed input: det_off[b])
   float pad_x[kValTailMaxBs], pad_y[kValTailMaxBs], gain[kValTailMaxBs], shape_w[kValTailMaxBs], shape_h[kValTailMaxBs];
   int bs;
 };
@@ -548,8 +549,9 @@ __global__ void k_vt_dets(const float* __restrict__ det7, int n, ValTailImgs im,
   int b = b_lo;
   while (b + 1 < im.bs && d >= im.det_off[b + 1]) b++;
   float b2[4];
-  vt_post_one(det7 + (size_t)d * 7, d, im.pad_x[b], im.pad_y[b], im.gain[b], poly10, hbb6, polyn10, hbbn6, b2);
-  const float cls = det7[(size_t)d * 7 + 6];
+  const float* row = det7 + ((size_t)im.det_row[b] + (d - im.det_off[b])) * 7;
+  vt_post_one(row, d, im.pad_x[b], im.pad_y[b], im.gain[b], poly10, hbb6, polyn10, hbbn6, b2);
+  const float cls = row[6];
   const float thr0 = iouv[0];                                            // val.py:81  iou >= iouv[0]
   const float area2 = (b2[2] - b2[0]) * (b2[3] - b2[1]);
   int bl = -1; float bi = -1.f;
@@ -588,12 +590,12 @@ __global__ void k_vt_stats(const float* __restrict__ det7, const int* __restrict
   // the winner of a label = the lowest-indexed detection of the image that chose it (detection indices grow inside the image).  A
   // matched detection looks for an earlier one with the same label; the wave scans that prefix TOGETHER, 64 entries per trip (a
   // lane on its own walked up to a few hundred dependent loads: the first version of this kernel took longer than the launch it saved)
-  int bl = -1, off_b = 0;
+  int bl = -1, off_b = 0, row_b = 0;
   if (d < n) {
     bl = best_label[d];
     int b = 0;
     while (b + 1 < im.bs && d >= im.det_off[b + 1]) b++;
-    off_b = im.det_off[b];
+    off_b = im.det_off[b]; row_b = im.det_row[b];
   }
   bool win = bl >= 0;
   for (unsigned long long todo = __ballot(win); todo; todo &= todo - 1) {
@@ -609,7 +611,8 @@ __global__ void k_vt_stats(const float* __restrict__ det7, const int* __restrict
   if (d < n) {
     float* o = stats + (size_t)d * (niou + 2);
     for (int k = 0; k < niou; k++) o[k] = (win && best_iou[d] >= iouv[k]) ? 1.f : 0.f;
-    o[niou] = det7[(size_t)d * 7 + 5]; o[niou + 1] = det7[(size_t)d * 7 + 6];
+    const float* row = det7 + ((size_t)row_b + (d - off_b)) * 7;
+    o[niou] = row[5]; o[niou + 1] = row[6];
   }
   if (done != nullptr) {                                          // (kernel-uniform)
     __threadfence_system();
@@ -636,7 +639,7 @@ size_t obb_val_tail_batch_workspace_bytes(int64_t n_det, int64_t nt) {
   return (size_t)(n_det > 0 ? n_det : 1) * 8 + (size_t)(nt > 0 ? nt : 1) * 20 + 512;
 }
 
-static int val_tail_batch_impl(const float* det7, const int64_t* det_off_host, int64_t bs, const float* targets, int64_t nt, int64_t tcols,
+static int val_tail_batch_impl(const float* det7, const int64_t* det_row_host, const int64_t* det_off_host, int64_t bs, const float* targets, int64_t nt, int64_t tcols,
                                const float* img5_host, const float* iouv, int niou, float* poly10, float* hbb6, float* polyn10,
                                float* hbbn6, float* stats, void* ws, size_t ws_bytes, void* stream, int64_t* done) {
   if (bs < 1 || bs > obb::kValTailMaxBs || nt < 0 || niou < 1 || !det_off_host || !img5_host || !iouv) return OBB_ERR_BAD_ARG;
@@ -648,6 +651,11 @@ static int val_tail_batch_impl(const float* det7, const int64_t* det_off_host, i
   for (int b = 0; b <= (int)bs; b++) {
     if (b > 0 && det_off_host[b] < det_off_host[b - 1]) return OBB_ERR_BAD_ARG;
     im.det_off[b] = (int)det_off_host[b];
+  }
+  for (int b = 0; b < (int)bs; b++) {
+    const int64_t r = det_row_host ? det_row_host[b] : det_off_host[b];
+    if (r < 0 || r > 0x7fffffff - (det_off_host[b + 1] - det_off_host[b])) return OBB_ERR_BAD_ARG;
+    im.det_row[b] = (int)r;
   }
   for (int b = 0; b < (int)bs; b++) {
     const float* q = img5_host + (size_t)b * 5;                 // pad_x, pad_y, gain, native width, native height
@@ -671,7 +679,7 @@ static int val_tail_batch_impl(const float* det7, const int64_t* det_off_host, i
 int obb_val_tail_batch_f32(const float* det7, const int64_t* det_off_host, int64_t bs, const float* targets, int64_t nt, int64_t tcols,
                            const float* img5_host, const float* iouv, int niou, float* poly10, float* hbb6, float* polyn10,
                            float* hbbn6, float* stats, void* ws, size_t ws_bytes, void* stream) {
-  return val_tail_batch_impl(det7, det_off_host, bs, targets, nt, tcols, img5_host, iouv, niou, poly10, hbb6, polyn10, hbbn6, stats, ws,
+  return val_tail_batch_impl(det7, nullptr, det_off_host, bs, targets, nt, tcols, img5_host, iouv, niou, poly10, hbb6, polyn10, hbbn6, stats, ws,
                              ws_bytes, stream, nullptr);
 }
 
@@ -679,8 +687,16 @@ int obb_val_tail_batch_polled_f32(const float* det7, const int64_t* det_off_host
                                   int64_t tcols, const float* img5_host, const float* iouv, int niou, float* poly10, float* hbb6,
                                   float* polyn10, float* hbbn6, float* stats, void* ws, size_t ws_bytes, void* stream, int64_t* done) {
   if (!done) return OBB_ERR_BAD_ARG;
-  return val_tail_batch_impl(det7, det_off_host, bs, targets, nt, tcols, img5_host, iouv, niou, poly10, hbb6, polyn10, hbbn6, stats, ws,
+  return val_tail_batch_impl(det7, nullptr, det_off_host, bs, targets, nt, tcols, img5_host, iouv, niou, poly10, hbb6, polyn10, hbbn6, stats, ws,
                              ws_bytes, stream, done);
+}
+
+int obb_val_tail_batch_rows_f32(const float* det7, const int64_t* det_row_host, const int64_t* det_off_host, int64_t bs, const float* targets,
+                                int64_t nt, int64_t tcols, const float* img5_host, const float* iouv, int niou, float* poly10, float* hbb6,
+                                float* polyn10, float* hbbn6, float* stats, void* ws, size_t ws_bytes, void* stream, int64_t* done) {
+  if (!det_row_host) return OBB_ERR_BAD_ARG;
+  return val_tail_batch_impl(det7, det_row_host, det_off_host, bs, targets, nt, tcols, img5_host, iouv, niou, poly10, hbb6, polyn10, hbbn6, stats,
+                             ws, ws_bytes, stream, done);
 }
 
 size_t obb_process_batch_workspace_bytes(int64_t n, int64_t m) { return (size_t)(n > 0 ? n : 1) * 8 + (size_t)(m > 0 ? m : 1) * 4 + 256; }

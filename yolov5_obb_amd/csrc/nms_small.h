@@ -14,8 +14,10 @@
 //      "IoU > thr" sets bit j of row i of a bit matrix in LDS;
 //   3. the reference's scan itself, by one wave: the lowest alive position is kept and clears its row's bits -- one
 //      iteration per KEPT box;
-//   4. the kept positions and their count.
-// No barrier between workgroups, no co-residency assumption, no planner.  A segment with more than kSmallMax boxes raises a
+//   4. the kept positions and their count -- or, with an output stage behind the segments (the kernel's TAIL: SmallGather of
+//      nmsobb_impl.h, round 5), the merge key and candidate slot of every kept box, written through for the workgroup that
+//      finishes the image.
+// No barrier between workgroups, no co-residency assumption, no planner (the TAIL counts arrivals on a ticket; nobody waits).  A segment with more than kSmallMax boxes raises a
 // flag and is left alone: the host layer repeats the call on the persistent kernel (it chooses this kernel from the
 // previous call's largest segment, include/obb_hip.h: expected_cand).
 #pragma once
@@ -37,6 +39,21 @@ struct SmallArgs {
   int* too_big;              // set to the size of a segment this kernel does not take
   float thr;
   int max_keep;              // 0 = unlimited
+  // With an output stage behind the segments (the kernel's TAIL, nmsobb_impl.h: SmallGather) a segment publishes what that stage
+  // merges -- the merge key and the candidate slot of every kept box, at [seg_begin[g] + k] -- instead of keep_out's positions;
+  // pub_key == nullptr: keep_out.
+  const unsigned long long* keys_sorted;   // [n] sort keys in sorted order
+  const uint32_t* vals_sorted;             // [n] candidate slots in sorted order
+  const int* mode;                         // [images] 1: the class-segment key (rotated into the merge key), else as it is
+  int ncs;                                 // segments per image
+  unsigned long long* pub_key;             // [n_pos]
+  uint32_t* pub_val;
+  long long n_pos;
+};
+// no output stage: the caller's next launch reads keep_out / keep_cnt
+struct SmallNoTail {
+  struct Args {};
+  static __device__ __forceinline__ void run(const SmallArgs&, const Args&, unsigned char*) {}
 };
 
 // The three decision stages are real functions here (one body each, called from the full drains and from the pooled
@@ -55,10 +72,11 @@ struct SmallWave {                                  // per wave
 };
 
 template <class G>
-__global__ __launch_bounds__(kSmallThreads) void k_nms_small(SmallArgs a) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+__device__ __forceinline__ void small_segment(const SmallArgs& a, unsigned char* s_raw) {
   __shared__ int s_next, s_nkept, s_qcnt[kSmallWaves], s_qhead[kSmallWaves], s_qcnt2[kSmallWaves];
   __shared__ uint32_t s_kept[kSmallMax];
+  __shared__ unsigned long long s_pk[kSmallMax];                 // (publishing) sort key and candidate slot of every position
+  __shared__ uint32_t s_pv[kSmallMax];
   float4* s_rec = reinterpret_cast<float4*>(s_raw);                                  // [kSmallMax][RECQ]
   u64* s_mask = reinterpret_cast<u64*>(s_rec + (size_t)kSmallMax * G::RECQ);         // [kSmallMax][kSmallWords]
   u64* s_alive = s_mask + (size_t)kSmallMax * kSmallWords;                           // [kSmallWords] + pad
@@ -77,6 +95,9 @@ __global__ __launch_bounds__(kSmallThreads) void k_nms_small(SmallArgs a) {
   // ---- 1. the segment -> LDS
   for (int t = tid; t < n * G::RECQ; t += kSmallThreads) s_rec[t] = a.rec[(size_t)sb * G::RECQ + t];
   for (int t = tid; t < n * kSmallWords; t += kSmallThreads) s_mask[t] = 0ull;
+  const bool pub = a.pub_key != nullptr;                         // (kernel-uniform)
+  if (pub)                                                       // requested with the records: no latency of its own
+    for (int t = tid; t < n; t += kSmallThreads) { s_pk[t] = a.keys_sorted[(size_t)sb + t]; s_pv[t] = a.vals_sorted[(size_t)sb + t]; }
   if (tid < kSmallWords) {
     const int w0 = (sb >> 6) + tid, sh = sb & 63;
     u64 v = a.alive[w0] >> sh;
@@ -279,8 +300,20 @@ __global__ __launch_bounds__(kSmallThreads) void k_nms_small(SmallArgs a) {
   SSTAMP();
   // ---- 4. out
   const int nk = s_nkept;
-  for (int k = tid; k < nk; k += kSmallThreads) a.keep_out[(size_t)sb + k] = (int64_t)(sb + (int)s_kept[k]);
-  if (tid == 0) a.keep_cnt[seg] = nk;
+  if (pub) {
+    // write-through stores: the output stage of the image runs in whichever workgroup finishes last, on any XCD
+    const int md = a.mode[seg / a.ncs];
+    for (int k = tid; k < nk; k += kSmallThreads) {
+      const int i = (int)s_kept[k];
+      const unsigned long long key = s_pk[i];
+      stg_agent(a.pub_key + (size_t)sb + k, md == 1 ? ((key << 8) | (key >> 56)) : key);
+      stg_agent(a.pub_val + (size_t)sb + k, s_pv[i]);
+    }
+    if (tid == 0) stg_agent(a.keep_cnt + seg, nk);
+  } else {
+    for (int k = tid; k < nk; k += kSmallThreads) a.keep_out[(size_t)sb + k] = (int64_t)(sb + (int)s_kept[k]);
+    if (tid == 0) a.keep_cnt[seg] = nk;
+  }
 #ifdef OBB_SMALL_TRACE
   SSTAMP();
   if (lane == 0 && (seg % 41 == 0) && (wv == 0 || wv == 5)) printf("small seg %d n %d kept %d wave %d: load %llu items %llu leftovers %llu wait %llu scan %llu out %llu | items %d drains %d %d %d (x10 ns)\n", seg, n, nk, wv, tt[1]-tt[0], tt[2]-tt[1], tt[3]-tt[2], tt[4]-tt[3], tt[5]-tt[4], tt[6]-tt[5], nit, nd0, nd1, nd2);
@@ -288,10 +321,19 @@ __global__ __launch_bounds__(kSmallThreads) void k_nms_small(SmallArgs a) {
 #undef SSTAMP
 }
 
+// TAIL::run follows the segment in every workgroup (also those of empty segments): the output stage of the fused driver counts
+// the segments of an image there and runs in the one that arrives last.
+template <class G, class TAIL>
+__global__ __launch_bounds__(kSmallThreads) void k_nms_small(SmallArgs a, typename TAIL::Args ta) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+  small_segment<G>(a, s_raw);
+  TAIL::run(a, ta, s_raw);
+}
+
 // (the whole segment state of one workgroup must fit the CU's 160 KB: records + bit matrix + alive words + eight wave blocks,
 //  + the kernel's few static words)
 static_assert((size_t)kSmallMax * RotGeom::RECQ * 16 + (size_t)kSmallMax * kSmallWords * 8 + 64 + sizeof(SmallWave<RotGeom>) * kSmallWaves +
-              kSmallMax * 4 + 256 <= 160 * 1024, "k_nms_small: LDS budget");
+              kSmallMax * 4 + kSmallMax * 12 + 256 <= 160 * 1024, "k_nms_small: LDS budget");
 static_assert(kSmallMax % 64 == 0 && kSmallMax <= 65535, "k_nms_small: pair entries are (i << 16 | j)");
 
 template <class G>

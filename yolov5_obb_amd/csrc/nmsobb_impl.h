@@ -542,13 +542,14 @@ __global__ void k_prep_cand(const float4* __restrict__ cand, const uint32_t* __r
 // One launch instead of four memsets: candidate counters, tiny-box flags, the caller's status words, the fused kernel's
 // ticket and the team-barrier block of the NMS kernel.
 __global__ void k_reset_state(int* __restrict__ cnt, int n_cnt, int* __restrict__ tiny, int bs, int64_t* __restrict__ status,
-                              int* __restrict__ ticket, uint4* __restrict__ bar16, long long n_bar16, uint4* __restrict__ alive16,
+                              int* __restrict__ ticket, int n_ticket, uint4* __restrict__ bar16, long long n_bar16, uint4* __restrict__ alive16,
                               long long n_alive16) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x, n = (long long)gridDim.x * blockDim.x;
   for (long long k = i; k < n_cnt; k += n) cnt[k] = 0;
   for (long long k = i; k < bs; k += n) tiny[k] = 0;
-  (void)status;                                                 // (both status words are written by k_gather_out)
-  if (i < 16) ticket[i] = 0;                                    // [0] the planner's ticket, [4] largest NMS segment, [8] a segment k_nms_small left out
+  (void)status;                                                 // (both status words are written by the output stage)
+  if (i < n_ticket) ticket[i] = 0;                              // [0] the planner's ticket, [4] largest NMS segment, [8] a segment k_nms_small left out,
+                                                                // [16 .. 16 + bs] the tickets of k_nms_small's output stage
   for (long long k = i; k < n_bar16; k += n) bar16[k] = make_uint4(0u, 0u, 0u, 0u);
   // (the in-LDS sort path ORs its alive bits into zeroed words: several workgroups share the words of an image)
   for (long long k = i; k < n_alive16; k += n) alive16[k] = make_uint4(0u, 0u, 0u, 0u);
@@ -977,6 +978,229 @@ __global__ __launch_bounds__(256) void k_gather_out(const float4* __restrict__ c
   }
 }
 
+// The same output stage INSIDE k_nms_small (its TAIL): the segments of an image count themselves on a ticket and the workgroup
+// that arrives last merges the image's kept lists and writes its rows -- the launch of k_gather_out, its start-up and two of its
+// four dependent round trips (kept positions -> keys / slots: the segments publish merge keys and slots themselves) are gone
+// from the step.  Rows of image g start at g * max_det (a packed output needs the totals of ALL earlier images: that stays with
+// k_gather_out).  The image that finishes last writes the two status words.  No workgroup waits for another one.
+struct SmallGather {
+  struct Args {
+    const float4* cand; const int* cnt; const int* tiny; const int* info;
+    int* ticket;               // [bs] segments of the image that are done, [bs] images that are done (zeroed by k_reset_state)
+    float* out; int64_t* out_count; int64_t* status;
+    long long cap_img, max_det;
+    int bs;
+  };
+  static constexpr int kLds = kSortLdsMax;                       // entries staged in LDS: an image of the in-LDS sort has no more candidates
+  static constexpr size_t kLdsBytes = 2064 + (size_t)kLds * 16;
+  static __device__ __forceinline__ void run(const SmallArgs& a, const Args& ga, unsigned char* s_raw) {
+    __shared__ int s_flag, s_maxc;
+    const int tid = threadIdx.x, lane = tid & 63, ncs = a.ncs, g = (int)blockIdx.x / ncs;
+#ifdef OBB_SMALL_TRACE
+    unsigned long long tt[10]; int ti_ = 0;
+#define GSTAMP() do { tt[ti_++] = wall_clock64(); } while (0)
+#else
+#define GSTAMP() do {} while (0)
+#endif
+    GSTAMP();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // this wave's published entries are written through
+    __syncthreads();
+    // The stage is a chain of dependent round trips (~1 us each), so everything is requested as early as its address is known:
+    // thread (c, k) of the first `spec` threads per segment asks for the k-th published entry of segment c TOGETHER with the
+    // segment's count (most segments keep fewer than `spec` boxes: no second trip); the segment's first position comes from the
+    // sort kernel and is requested while the ticket is under way.
+    int spec = 2;
+    while (spec * 2 * ncs <= kSmallThreads) spec <<= 1;          // (ncs <= 256)
+    const int myc = tid / spec, myk = tid - myc * spec;
+    const bool mine = myc < ncs;
+    const int sb_c = mine ? a.seg_begin[g * ncs + myc] : 0;
+    int t2 = -1;                                                 // (thread 0) images that were done before this one
+    if (tid == 0) {
+      const int last = __hip_atomic_fetch_add(ga.ticket + g, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == ncs - 1 ? 1 : 0;
+      // every segment of this image is done -- the image counts as done for the status words (which do not wait for its rows)
+      if (last) t2 = __hip_atomic_fetch_add(ga.ticket + ga.bs, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      s_flag = last;
+    }
+    __syncthreads();
+    if (!s_flag) return;                                         // (workgroup-uniform)
+    GSTAMP();
+    // ---- the image's output (the segment state in s_raw is dead).  What other workgroups of this launch wrote is read with
+    // agent-scope loads (they wrote it through); the rest comes from earlier launches.
+    int* s_pre = reinterpret_cast<int*>(s_raw);                  // [257]
+    int* s_seg = s_pre + 260;                                    // [256]
+    unsigned long long* s_key = reinterpret_cast<unsigned long long*>(s_raw + 2064);
+    uint32_t* s_val = reinterpret_cast<uint32_t*>(s_key + kLds);
+    uint32_t* s_ck = s_val + kLds;                               // (segment << 16 | index in its list) of a staged entry
+    const long long max_det = ga.max_det;
+    int cnt_c = 0;
+    unsigned long long key = 0ull;
+    uint32_t val = 0u;
+    if (mine) {
+      cnt_c = ldg_agent(a.keep_cnt + g * ncs + myc);
+      size_t p = (size_t)sb_c + myk;
+      if (p >= (size_t)a.n_pos) p = (size_t)a.n_pos - 1;        // (beyond the segment's count the entry is not used)
+      val = ldg_agent(a.pub_val + p);
+      key = ldg_agent(a.pub_key + p);
+    }
+    // (wave 0) the inputs of the status words come from earlier launches: under way during the trips above
+    long long mx = 0;
+    int tf = 0, big = 0;
+    if (tid < 64) {
+      for (int b2 = lane; b2 < ga.bs; b2 += 64) {
+        const long long c = ga.cnt[b2 * kCntPad];
+        if (c > mx) mx = c;
+        const int t = ga.tiny[b2];
+        tf |= t & kImgSmall;
+        if ((t & kImgSmall) && !img_single_list(t)) tf |= 16;
+      }
+      // the image that is done last reads the too-big word now: every segment of every image has arrived
+      if (tid == 0 && t2 == ga.bs - 1) big = ldg_agent(ga.info + 8);
+    }
+    if (max_det > 0 && cnt_c > max_det) cnt_c = (int)max_det;   // a class contributes at most max_det rows to the first max_det overall
+    if (mine && myk == 0) { s_pre[myc + 1] = cnt_c; s_seg[myc] = sb_c; }
+    if (tid == 0) s_pre[0] = 0;
+    const int more = __syncthreads_or(cnt_c > spec ? 1 : 0);
+    if (tid < 64) {                                              // inclusive scan of s_pre[1 .. ncs], four per lane (ncs <= 256), and the largest
+      int v[4], sum = 0, m = 0;
+#pragma unroll
+      for (int j = 0; j < 4; j++) { const int c = lane * 4 + j; v[j] = c < ncs ? s_pre[c + 1] : 0; sum += v[j]; m = v[j] > m ? v[j] : m; }
+      int inc = sum;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(inc, d); if (lane >= d) inc += t; }
+#pragma unroll
+      for (int d = 32; d >= 1; d >>= 1) { const int o = __shfl_xor(m, d); m = o > m ? o : m; }
+      int run = inc - sum;
+#pragma unroll
+      for (int j = 0; j < 4; j++) { const int c = lane * 4 + j; run += v[j]; if (c < ncs) s_pre[c + 1] = run; }
+      if (lane == 0) s_maxc = m;
+    }
+    __syncthreads();
+    const int total = s_pre[ncs], maxc = s_maxc;
+    GSTAMP();
+    if (tid == 0) ga.out_count[g] = (max_det > 0 && total > max_det) ? max_det : (long long)total;
+    const bool single = a.mode[g] == 0;
+    const bool in_lds = total <= kLds;
+    auto seg_of = [&](int e) -> int {                            // the segment c with s_pre[c] <= e < s_pre[c + 1]
+      int lo = 0, hi = ncs - 1;
+      while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (s_pre[mid] <= e) lo = mid; else hi = mid - 1; }
+      return lo;
+    };
+    if (in_lds) {
+      if (mine && myk < cnt_c) { const int e = s_pre[myc] + myk; s_val[e] = val; s_key[e] = key; s_ck[e] = ((uint32_t)myc << 16) | (uint32_t)myk; }
+      if (more)                                                  // (workgroup-uniform) a segment kept more than `spec` boxes: the rest of it
+        for (int e = tid; e < total; e += kSmallThreads) {
+          const int c = seg_of(e), k = e - s_pre[c];
+          if (k < spec) continue;
+          const size_t p = (size_t)s_seg[c] + k;
+          s_val[e] = ldg_agent(a.pub_val + p);
+          s_key[e] = ldg_agent(a.pub_key + p);
+          s_ck[e] = ((uint32_t)c << 16) | (uint32_t)k;
+        }
+      __syncthreads();
+    }
+    GSTAMP();
+    // rank of an entry = its index in its own list + the entries of every other list in front of it (binary searches on the
+    // merge keys); up to 16 lanes share the lists of one entry when the image has few entries.  A lane runs the searches of eight
+    // lists in lock step (same number of halving steps for all: the loads of a step are independent of each other).
+    int tpe = 1;
+    if (!single) while (tpe < 16 && total * tpe * 2 <= kSmallThreads) tpe <<= 1;
+    int top = 1;
+    while (top * 2 <= maxc) top <<= 1;                           // the largest power of two <= the longest list
+    const int sub = tid & (tpe - 1), per_round = kSmallThreads / tpe, nlist = (ncs + tpe - 1) / tpe;
+    for (int e0 = 0; e0 < total; e0 += per_round) {
+      const int e = e0 + tid / tpe;
+      const bool valid = e < total;
+      int c = 0, k = 0, rank = 0;
+      if (valid) {
+        if (in_lds) { const uint32_t ck = s_ck[e]; c = (int)(ck >> 16); k = (int)(ck & 0xffffu); }
+        else { c = seg_of(e); k = e - s_pre[c]; }
+      }
+      const bool writer = valid && sub == 0;
+      float4 c0 = make_float4(0.f, 0.f, 0.f, 0.f), c1 = c0;
+      if (writer) {                                              // the row is under way while the rank is computed
+        const uint32_t slot = in_lds ? s_val[e] : ldg_agent(a.pub_val + (size_t)s_seg[c] + k);
+        const size_t ci = (size_t)g * ga.cap_img + slot;
+        c0 = ga.cand[ci * 2]; c1 = ga.cand[ci * 2 + 1];
+      }
+      GSTAMP();
+      if (valid && !single) {
+        if (in_lds) {
+          const unsigned long long mk = s_key[e];
+          for (int j0 = 0; j0 < nlist; j0 += 8) {
+            int base[8], len[8], pos[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+              const int c2 = sub + (j0 + j) * tpe;
+              const bool ok = c2 < ncs && c2 != c;
+              base[j] = ok ? s_pre[c2] : 0;
+              len[j] = ok ? s_pre[c2 + 1] - base[j] : 0;
+              pos[j] = 0;
+            }
+            for (int st = top; st >= 1; st >>= 1) {
+              unsigned long long k2[8];                          // (all eight loads first: written as one conditional per list the
+#pragma unroll                                                   //  compiler branches around each load and waits for it in turn)
+              for (int j = 0; j < 8; j++) {
+                const int q = pos[j] + st;
+                int at = base[j] + (q <= len[j] ? q : len[j]) - 1;
+                at = at < 0 ? 0 : at;
+                k2[j] = s_key[at];
+              }
+#pragma unroll
+              for (int j = 0; j < 8; j++) {
+                const int q = pos[j] + st;
+                const bool take = (q <= len[j]) & (k2[j] < mk);
+                pos[j] = take ? q : pos[j];
+              }
+            }
+#pragma unroll
+            for (int j = 0; j < 8; j++) rank += pos[j];
+          }
+        } else {
+          const unsigned long long mk = ldg_agent(a.pub_key + (size_t)s_seg[c] + k);
+          for (int c2 = sub; c2 < ncs; c2 += tpe) {
+            if (c2 == c) continue;
+            int lo = 0, hi = s_pre[c2 + 1] - s_pre[c2];
+            while (lo < hi) {
+              const int mid = (lo + hi) >> 1;
+              if (ldg_agent(a.pub_key + (size_t)s_seg[c2] + mid) < mk) lo = mid + 1; else hi = mid;
+            }
+            rank += lo;
+          }
+        }
+      }
+      GSTAMP();
+      for (int d = 1; d < tpe; d <<= 1) rank += __shfl_xor(rank, d);
+      rank += k;
+#ifdef OBB_SMALL_TRACE
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      GSTAMP();
+#endif
+      if (!writer || (max_det > 0 && rank >= max_det)) continue;
+      float* o = ga.out + ((size_t)g * max_det + rank) * 7;
+      o[0] = c0.x; o[1] = c0.y; o[2] = c0.z; o[3] = c0.w; o[4] = c1.x; o[5] = c1.y; o[6] = c1.z;
+    }
+    GSTAMP();
+#ifdef OBB_SMALL_TRACE
+    if (tid == 0) printf("tail img %d total %d done before %d: ticket %llu counts+entries %llu stage %llu segof+issue %llu search %llu row wait %llu stores %llu (x10 ns) end %llu\n", g, total, t2, tt[1]-tt[0], tt[2]-tt[1], tt[3]-tt[2], tt[4]-tt[3], tt[5]-tt[4], tt[6]-tt[5], tt[7]-tt[6], tt[7]);
+#endif
+#undef GSTAMP
+    // ---- the call's status words, by the image that was done last (k_gather_out: workgroup 0; see there for their meaning)
+    if (tid >= 64) return;
+    const int writes = __shfl(t2, 0) == ga.bs - 1;               // (wave-uniform)
+    if (!writes) return;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { const long long o = __shfl_xor(mx, d); if (o > mx) mx = o; tf |= __shfl_xor(tf, d); }
+    if (lane == 0) {
+      const int seg4 = ga.info[4];
+      ga.status[0] = big ? -1 : (mx > ga.cap_img ? mx : 0);
+      const long long small_seen = ((tf & kImgSmall) ? (1ll << 62) : 0ll) | ((tf & 16) ? (1ll << 61) : 0ll);
+      ga.status[1] = mx | (((long long)(big > seg4 ? big : seg4) & 0x1fffffffll) << 32) | small_seen;
+    }
+  }
+};
+static_assert(SmallGather::kLdsBytes <= (size_t)kSmallMax * RotGeom::RECQ * 16 + (size_t)kSmallMax * kSmallWords * 8 + 64 + sizeof(SmallWave<RotGeom>) * kSmallWaves,
+              "SmallGather: the merge lists live where the segment state was");
+
 struct ObbCarve {
   float4* cand; unsigned long long *keys_a, *keys_b; uint32_t *vals_a, *vals_b; int* cnt; int *sort_begin, *sort_end;
   int *img_end, *mode, *tiny, *grp_begin, *grp_end, *ticket;
@@ -1000,7 +1224,7 @@ static int obb_carve(void* base, int64_t bs, int64_t cap_img, int64_t ncs, ObbCa
   cv->cnt = (int*)take(bs * 4 * kCntPad); cv->sort_begin = (int*)take(bs * 4); cv->sort_end = (int*)take(bs * 4);
   cv->img_end = (int*)take(bs * 4); cv->mode = (int*)take(bs * 4); cv->tiny = (int*)take(bs * 4);
   cv->grp_begin = (int*)take(bs * 4); cv->grp_end = (int*)take(bs * 4);
-  cv->ticket = (int*)take(64);
+  cv->ticket = (int*)take(64 + (size_t)(bs + 1) * 4);         // 16 words + k_nms_small's output stage: [bs] + [1]
   cv->digit_base = (uint32_t*)take((size_t)bs * 256 * 4);
   cv->srs_hist = (uint32_t*)take((size_t)bs * ((size_t)(cap_img + kSrsTile - 1) / kSrsTile) * 256 * 4);
   cv->keep = (int64_t*)take(n * 8);
@@ -1061,7 +1285,7 @@ static int run_nms_obb(const void* pred, const void* objcol, int dtype, int64_t 
     Carve& nv0 = cv.nms;
     // (cap_img is a multiple of 64 -> bs * cap_img / 64 words; + the guard words, rounded up to 16 bytes)
     const long long alive16 = lds_sort ? (long long)((((size_t)bs * cap_img) >> 6) + 8 + 1) / 2 : 0ll;
-    k_reset_state<<<256, 256, 0, st>>>(cv.cnt, (int)(bs * kCntPad), cv.tiny, (int)bs, status, cv.ticket,
+    k_reset_state<<<256, 256, 0, st>>>(cv.cnt, (int)(bs * kCntPad), cv.tiny, (int)bs, status, cv.ticket, (int)(16 + bs + 1),
                                        reinterpret_cast<uint4*>(nv0.bar), (long long)(nv0.bar_bytes / 16),
                                        reinterpret_cast<uint4*>(nv0.alive), alive16);
   }
@@ -1161,25 +1385,39 @@ static int run_nms_obb(const void* pred, const void* objcol, int dtype, int64_t 
   a.rows = nv.rows; a.nrows = nv.nrows; a.edges = nv.edges; a.nedges = nv.nedges;
   a.ecap = nv.ecap; a.n = (int)(bs * cap_img); a.capmax = cap_max(bs * ncs);
   a.max_keep = (int)max_det; a.window = nms_window(max_det); a.thr = iou_thres; a.cull = (iou_thres >= 0.f) ? 1 : 0;
+  // the output stage runs inside k_nms_small unless the caller wants packed rows (SmallGather)
+  static const int no_fused_out = obb_dev_switch("OBB_NO_FUSED_OUT", 0) != 0;    // A/B switch (development builds)
+  const bool fused_out = small_nms && !out_packed && !no_fused_out;
   if (small_nms) {
     ProfScope ps(PROF_STEPS, st);
     static bool attr_set = false;
     const size_t lds = small_lds_bytes<RotGeom>();
     if (!attr_set) {
-      if (hipFuncSetAttribute((const void*)k_nms_small<RotGeom>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      if (hipFuncSetAttribute((const void*)k_nms_small<RotGeom, SmallNoTail>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+          hipFuncSetAttribute((const void*)k_nms_small<RotGeom, SmallGather>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return OBB_ERR_LAUNCH;
       attr_set = true;
     }
     SmallArgs sa{};
     sa.rec = nv.rec; sa.alive = nv.alive; sa.seg_begin = nv.seg_begin; sa.seg_end = nv.seg_end; sa.keep_cnt = nv.keep_cnt;
     sa.keep_out = cv.keep; sa.too_big = cv.ticket + 8; sa.thr = iou_thres; sa.max_keep = (int)max_det;
-    k_nms_small<RotGeom><<<(unsigned)(bs * ncs), kSmallThreads, lds, st>>>(sa);
+    sa.ncs = ncs; sa.mode = cv.mode;
+    if (fused_out) {
+      // (keys_a / vals_a, the sort's input, are free: they take what the segments publish)
+      sa.keys_sorted = cv.keys_b; sa.vals_sorted = cv.vals_b; sa.pub_key = cv.keys_a; sa.pub_val = cv.vals_a; sa.n_pos = bs * cap_img;
+      SmallGather::Args ga{};
+      ga.cand = cv.cand; ga.cnt = cv.cnt; ga.tiny = cv.tiny; ga.info = cv.ticket; ga.ticket = cv.ticket + 16;
+      ga.out = out; ga.out_count = out_count; ga.status = status; ga.cap_img = cap_img; ga.max_det = max_det; ga.bs = (int)bs;
+      k_nms_small<RotGeom, SmallGather><<<(unsigned)(bs * ncs), kSmallThreads, lds, st>>>(sa, ga);
+    } else {
+      k_nms_small<RotGeom, SmallNoTail><<<(unsigned)(bs * ncs), kSmallThreads, lds, st>>>(sa, SmallNoTail::Args{});
+    }
   } else {
     ProfScope ps(PROF_STEPS, st);
     rc = nms_steps(0, a, nv, bs * ncs, bs * max_seg, st, kNmsBarZeroed | ((lds_sort && plan_nb > 0) ? kNmsPlanned : 0));
     if (rc) return rc;
   }
-  {
+  if (!fused_out) {
     ProfScope ps(PROF_GATHER, st);
     // parts per image: one up to ~2k expected candidates (the kept rows fit the kernel's LDS and 256 threads), then one per 1024
     const unsigned gparts = expected_cand <= 2048 ? 1u : (unsigned)((expected_cand + 1023) / 1024 > 16 ? 16 : (expected_cand + 1023) / 1024);

@@ -37,7 +37,7 @@ namespace {
 #define OBB_API(X)                                                                                                         \
   X(obb_version) X(obb_nms_set_max_grid) X(obb_nms_workspace_bytes) X(obb_nms_rotated_f32) X(obb_nms_rotated_f64)       \
   X(obb_nms_poly_f32) X(obb_nms_obb_workspace_bytes) X(obb_non_max_suppression_obb_col)                                   \
-  X(obb_val_tail_batch_workspace_bytes) X(obb_val_tail_batch_polled_f32)
+  X(obb_val_tail_batch_workspace_bytes) X(obb_val_tail_batch_rows_f32)
 
 struct Api {
 #define X(name) decltype(&::name) name = nullptr;
@@ -297,7 +297,8 @@ std::vector<at::Tensor> non_max_suppression_obb(const at::Tensor& prediction, do
 
   c10::DeviceGuard guard(dev);
   const auto stream = c10::hip::getCurrentHIPStream(dev.index());
-  at::Tensor out = at::empty({bs * max_det, 7}, at::TensorOptions().dtype(at::kFloat).device(dev));   // packed: image b's rows follow image b-1's
+  at::Tensor out = at::empty({bs * max_det, 7}, at::TensorOptions().dtype(at::kFloat).device(dev));   // image b's rows start at b * max_det (out_packed = 0:
+                                                                                                       // the NMS kernel writes them itself, one launch less)
   Pinned& meta = pinned_words(dev.index(), 1, bs + 2);                                                 // counts[bs] + status[2]
   AbortRetry retry;
   int64_t seg_max = 0, cand_max = 0;
@@ -310,7 +311,7 @@ std::vector<at::Tensor> non_max_suppression_obb(const at::Tensor& prediction, do
     arm(meta);
     const int rc = api.obb_non_max_suppression_obb_col(pred.data_ptr(), col_p, dtype, bs, A, no, conf_f, (float)iou_thres, cls.empty() ? nullptr : cls.data(),
                                                        (int)cls.size(), agnostic ? 1 : 0, multi ? 1 : 0, max_det, kMaxNms, (float)kMaxWh, extra_p, n_extra, cap,
-                                                       hint | (seg_hint << 32) | (memo.small_boxes ? (int64_t(1) << 62) : 0), out.data_ptr<float>(), 1, meta.p, meta.p + bs,
+                                                       hint | (seg_hint << 32) | (memo.small_boxes ? (int64_t(1) << 62) : 0), out.data_ptr<float>(), 0, meta.p, meta.p + bs,
                                                        ws.data_ptr(), (size_t)ws.numel(),
                                                        stream.stream());
     check(rc, "obb_non_max_suppression_obb");
@@ -354,12 +355,7 @@ std::vector<at::Tensor> non_max_suppression_obb(const at::Tensor& prediction, do
   if (memo.hold_seg > 0 && (seg_max == 0 || seg_max > OBB_NMS_SMALL_SEG * 3 / 4)) { memo.hold_seg--; memo.seg = std::max<int64_t>(seg_max, OBB_NMS_SMALL_SEG + 1); }
   else { memo.hold_seg = 0; memo.seg = seg_max; }                      // (0: the sort path of this call does not report it)
   result.reserve((size_t)bs);
-  int64_t off = 0;
-  for (int64_t b = 0; b < bs; b++) {
-    const int64_t c = meta.p[b];
-    result.push_back(out.narrow(0, off, c));
-    off += c;
-  }
+  for (int64_t b = 0; b < bs; b++) result.push_back(out.narrow(0, b * max_det, meta.p[b]));
   return result;
 }
 
@@ -390,24 +386,28 @@ py::object val_tail_batch(const std::vector<at::Tensor>& preds, const at::Tensor
   for (int64_t b = 0; b < bs; b++) offs[b + 1] = offs[b] + preds[b].size(0);
   const int64_t n = offs[bs];
   const int64_t niou = iouv.size(0);
-  // the detections as ONE (n, 7) array: consecutive views of non_max_suppression_obb's packed buffer are used in place
-  at::Tensor packed;
+  // the detections where they lie: views of ONE buffer of 7-float rows (what non_max_suppression_obb returns: image b at row
+  // b * max_det; a packed list as well) are addressed by their first rows; anything else is concatenated
+  at::Tensor base;                                                     // the tensor whose data pointer the rows count from
+  std::vector<int64_t> rows((size_t)bs, 0);
   if (n) {
     bool ok = true;
-    const char* nxt = nullptr;
-    const at::Tensor* first = nullptr;
-    for (const at::Tensor& p : preds) {
+    const char* p0 = nullptr;
+    for (int64_t b = 0; b < bs && ok; b++) {
+      const at::Tensor& p = preds[(size_t)b];
       if (p.size(0) == 0) continue;
       if (p.device() != dev || p.scalar_type() != at::kFloat || p.dim() != 2 || p.size(1) != 7 || !p.is_contiguous()) { require_cuda(p, "pred"); ok = false; break; }
-      if (!first) { first = &p; nxt = (const char*)p.data_ptr(); }
-      if ((const char*)p.data_ptr() != nxt) { ok = false; break; }
-      nxt += p.size(0) * 28;
+      const char* q = (const char*)p.data_ptr();
+      if (!p0) { p0 = q; base = p; }
+      const int64_t diff = q - p0;
+      if (diff < 0 || diff % 28 != 0 || diff / 28 > 0x7fffffff - p.size(0) || !p.is_alias_of(base)) { ok = false; break; }
+      rows[(size_t)b] = diff / 28;
     }
-    if (ok && first) packed = first->size(0) == n ? *first : at::as_strided(*first, {n, 7}, {7, 1});
-    else {
+    if (!ok) {
       std::vector<at::Tensor> f;
       for (const at::Tensor& p : preds) f.push_back(p.to(dev, at::kFloat));
-      packed = at::cat(f, 0).contiguous();
+      base = at::cat(f, 0).contiguous();
+      for (int64_t b = 0; b < bs; b++) rows[(size_t)b] = offs[(size_t)b];
     }
   }
   at::Tensor tg;
@@ -436,7 +436,7 @@ py::object val_tail_batch(const std::vector<at::Tensor>& preds, const at::Tensor
     const auto stream = c10::hip::getCurrentHIPStream(dev.index());
     at::Tensor ws = workspace(api.obb_val_tail_batch_workspace_bytes(n, nt), dev);
     Pinned& flag = pinned_words(dev.index(), 2, 1);
-    std::vector<int64_t> doff;
+    std::vector<int64_t> doff, drow;
     std::vector<float> img5;
     for (int64_t b0 = 0; b0 < bs; b0 += kTailMaxBs) {                  // (one call for any batch size val.py uses)
       const int64_t b1 = std::min(bs, b0 + kTailMaxBs), k = b1 - b0;
@@ -444,6 +444,7 @@ py::object val_tail_batch(const std::vector<at::Tensor>& preds, const at::Tensor
       if (hi == lo) continue;
       doff.assign((size_t)k + 1, 0);
       for (int64_t j = 0; j <= k; j++) doff[j] = offs[b0 + j] - lo;
+      drow.assign(rows.begin() + b0, rows.begin() + b1);
       img5.assign((size_t)(5 * k), 0.f);
       for (int64_t j = 0; j < k; j++) img5_of(shapes[(size_t)(b0 + j)], img5.data() + 5 * j);
       at::Tensor tgk = tg;
@@ -455,8 +456,8 @@ py::object val_tail_batch(const std::vector<at::Tensor>& preds, const at::Tensor
         ntk = tgk.size(0);
       }
       arm(flag);
-      const int rc = api.obb_val_tail_batch_polled_f32(
-          packed.data_ptr<float>() + lo * 7, doff.data(), k, ntk ? tgk.data_ptr<float>() : nullptr, ntk, tcols, img5.data(), iv.data_ptr<float>(), (int)niou,
+      const int rc = api.obb_val_tail_batch_rows_f32(
+          base.data_ptr<float>(), drow.data(), doff.data(), k, ntk ? tgk.data_ptr<float>() : nullptr, ntk, tcols, img5.data(), iv.data_ptr<float>(), (int)niou,
           want_boxes ? boxes[0].data_ptr<float>() + lo * 10 : nullptr, want_boxes ? boxes[1].data_ptr<float>() + lo * 6 : nullptr,
           want_boxes ? boxes[2].data_ptr<float>() + lo * 10 : nullptr, want_boxes ? boxes[3].data_ptr<float>() + lo * 6 : nullptr,
           host + lo * (niou + 2), ws.data_ptr(), (size_t)ws.numel(), stream.stream(), flag.p);
