@@ -252,6 +252,21 @@ int obb_non_max_suppression_obb_col(const void* pred, const void* objcol, int dt
                                     int64_t n_extra, int64_t cap_img, int64_t expected_cand, float* out, int out_packed,
                                     int64_t* out_count, int64_t* status, void* ws, size_t ws_bytes, void* stream);
 
+/* The same call with its candidate counters in a buffer of the CALLER's that outlives the call: `state` = obb_nms_obb_state_bytes(bs)
+ * bytes of device memory (256-byte aligned), zeroed ONCE by the caller (hipMemset) and then handed to every call with this bs
+ * that is ordered on one stream.  Each call finds it zeroed and leaves it zeroed (its last kernel does that), so the call has no
+ * reset launch of its own; the filter kernel zeroes the state of the later launches on its way.  At the reference's default
+ * thresholds with out_packed = 0 the whole of non_max_suppression_obb is then THREE launches (filter + CSL decode, sort, NMS +
+ * output rows).  A call that returns an error may leave the buffer dirty: zero it again.  Two calls that are not ordered on one
+ * stream need a buffer each.  Everything else as obb_non_max_suppression_obb_col (objcol may be NULL). */
+size_t obb_nms_obb_state_bytes(int64_t bs);
+int obb_non_max_suppression_obb_st(const void* pred, const void* objcol, int dtype, int64_t bs, int64_t A, int64_t no,
+                                   float conf_thres, float iou_thres, const int32_t* classes_host, int n_classes, int agnostic,
+                                   int multi_label, int64_t max_det, int64_t max_nms, float max_wh, const float* extra8,
+                                   int64_t n_extra, int64_t cap_img, int64_t expected_cand, float* out, int out_packed,
+                                   int64_t* out_count, int64_t* status, void* ws, size_t ws_bytes, void* state, size_t state_bytes,
+                                   void* stream);
+
 /* ------------------------------------------------------------------ training loss -------------------- */
 
 /*

@@ -167,3 +167,68 @@ def test_output_stage_inside_the_nms_kernel_matches_the_separate_one_and_the_ora
     if bs > 1:
         d0 = got[0].data_ptr()
         assert all(g.data_ptr() == d0 + b * max_det * 28 for b, g in enumerate(got) if g.shape[0]), "image b's rows start at row b * max_det"
+
+
+def test_caller_kept_counters_are_left_zeroed_by_every_path_and_change_no_row(dev):
+    """obb_non_max_suppression_obb_st (include/obb_hip.h): the candidate counters live in a buffer of the caller's, zeroed once;
+    each call leaves them zeroed (no reset launch).  Through the C ABI: the un-hinted call (generic sort + persistent kernel +
+    k_gather_out), the hinted one (in-LDS sort + small-segment kernel with its own output stage, out_packed = 0) and the hinted
+    packed one (small-segment kernel + k_gather_out) give the rows of obb_non_max_suppression_obb_col, and the buffer reads zero
+    after each of them."""
+    import ctypes as C
+    from yolov5_obb_amd import _lib
+    L = _lib.lib()
+    bs, A, nc, max_det = 6, 9000, 15, 300
+    pred = synth.s_pred(bs, A, nc, seed=77, n_obj=60, fg_frac=0.04).to(dev)
+    no = pred.shape[2]
+    cap = A * nc
+    ws = torch.empty(L.obb_nms_obb_workspace_bytes(bs, cap, nc, 0), dtype=torch.uint8, device=dev)
+    state = torch.zeros(L.obb_nms_obb_state_bytes(bs), dtype=torch.uint8, device=dev)
+    assert state.numel() >= bs * 260
+    null = C.c_void_p(0)
+
+    def call(hint, packed, kept):
+        out = torch.zeros((bs * max_det, 7), dtype=torch.float32, device=dev)
+        meta = torch.zeros(bs + 2, dtype=torch.int64, device=dev)
+        args = [_lib.ptr(pred), null, 0, bs, A, no, 0.25, 0.45, null, 0, 0, 1, max_det, 30000, 4096.0, null, 0, cap, hint, _lib.ptr(out), packed,
+                _lib.ptr(meta), C.c_void_p(meta.data_ptr() + 8 * bs), _lib.ptr(ws), ws.numel()]
+        with _lib.guard(dev):
+            st = C.c_void_p(_lib.stream_handle(dev))
+            if kept:
+                rc = L.obb_non_max_suppression_obb_st(*args, _lib.ptr(state), state.numel(), st)
+            else:
+                rc = L.obb_non_max_suppression_obb_col(*args, st)
+        assert rc == 0
+        torch.cuda.synchronize()
+        m = meta.tolist()
+        assert m[bs] == 0 and min(m[:bs]) >= 0, m
+        rows, off = [], 0
+        for b in range(bs):
+            first = off if packed else b * max_det
+            rows.append(out[first:first + m[b]].cpu())
+            off += m[b]
+        return rows, m[bs + 1]
+
+    ref, st1 = call(0, 1, False)
+    assert sum(len(r) for r in ref) > 300
+    hint = (st1 & 0xffffffff) | (((st1 >> 32) & 0x1fffffff) << 32)
+    assert 0 < ((st1 >> 32) & 0x1fffffff) <= 384 or ((st1 >> 32) & 0x1fffffff) == 0
+    ref_h, st2 = call(hint, 1, False)
+    hint = (st2 & 0xffffffff) | (((st2 >> 32) & 0x1fffffff) << 32)
+    assert 0 < (hint >> 32) <= 384, "the hinted call reports the largest class segment: the next one takes the small-segment kernel"
+    for h, packed in ((0, 1), (0, 0), (hint, 0), (hint, 1), (hint, 0)):
+        got, _ = call(h, packed, True)
+        assert int(state.count_nonzero()) == 0, (h, packed)
+        for g, r in zip(got, ref):
+            assert torch.equal(g, r), (h, packed)
+    for g, r in zip(ref_h, ref):
+        assert torch.equal(g, r)
+    # a misaligned or short buffer is refused before anything is launched
+    with _lib.guard(dev):
+        st = C.c_void_p(_lib.stream_handle(dev))
+        out = torch.zeros((bs * max_det, 7), dtype=torch.float32, device=dev)
+        meta = torch.zeros(bs + 2, dtype=torch.int64, device=dev)
+        args = [_lib.ptr(pred), null, 0, bs, A, no, 0.25, 0.45, null, 0, 0, 1, max_det, 30000, 4096.0, null, 0, cap, 0, _lib.ptr(out), 0,
+                _lib.ptr(meta), C.c_void_p(meta.data_ptr() + 8 * bs), _lib.ptr(ws), ws.numel()]
+        assert L.obb_non_max_suppression_obb_st(*args, _lib.ptr(state), 16, st) != 0
+        assert L.obb_non_max_suppression_obb_st(*args, null, state.numel(), st) != 0

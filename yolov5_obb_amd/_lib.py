@@ -49,6 +49,9 @@ SIGNATURES = {
                                            _vp, _i64, _i64, _i64, _vp, _i32, _vp, _vp, _vp, _sz, _vp]),
     "obb_non_max_suppression_obb_col": (_i32, [_vp, _vp, _i32, _i64, _i64, _i64, _f32, _f32, _vp, _i32, _i32, _i32, _i64, _i64, _f32,
                                                _vp, _i64, _i64, _i64, _vp, _i32, _vp, _vp, _vp, _sz, _vp]),
+    "obb_nms_obb_state_bytes": (_sz, [_i64]),
+    "obb_non_max_suppression_obb_st": (_i32, [_vp, _vp, _i32, _i64, _i64, _i64, _f32, _f32, _vp, _i32, _i32, _i32, _i64, _i64, _f32,
+                                              _vp, _i64, _i64, _i64, _vp, _i32, _vp, _vp, _vp, _sz, _vp, _sz, _vp]),
     "obb_loss_workspace_bytes": (_sz, [_vp, _i64]),
     "obb_loss_build_targets": (_i32, [_vp, _vp, _i64, _i64, _vp, _vp, _sz, _vp]),
     "obb_loss_export_targets": (_i32, [_vp, _i64, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),

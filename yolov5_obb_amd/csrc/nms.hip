@@ -943,6 +943,20 @@ int obb_non_max_suppression_obb_col(const void* pred, const void* objcol, int dt
                      (hipStream_t)stream);
 }
 
+size_t obb_nms_obb_state_bytes(int64_t bs) { return bs < 1 ? 0 : obb_state_bytes(bs); }
+
+int obb_non_max_suppression_obb_st(const void* pred, const void* objcol, int dtype, int64_t bs, int64_t A, int64_t no,
+                                   float conf_thres, float iou_thres, const int32_t* classes_host, int n_classes, int agnostic,
+                                   int multi_label, int64_t max_det, int64_t max_nms, float max_wh, const float* extra8,
+                                   int64_t n_extra, int64_t cap_img, int64_t expected_cand, float* out, int out_packed,
+                                   int64_t* out_count, int64_t* status, void* ws, size_t ws_bytes, void* state, size_t state_bytes,
+                                   void* stream) {
+  if (!state) return OBB_ERR_BAD_ARG;
+  return run_nms_obb(pred, objcol, dtype, bs, A, no, conf_thres, iou_thres, classes_host, n_classes, agnostic, multi_label, max_det,
+                     max_nms, max_wh, extra8, n_extra, cap_img, expected_cand, out, out_packed ? 1 : 0, out_count, status, ws, ws_bytes,
+                     (hipStream_t)stream, state, state_bytes);
+}
+
 int obb_profile_enable(int on) {
   g_prof.on = on == 2 ? 2 : (on != 0 ? 1 : 0);
   g_prof.used = 0;

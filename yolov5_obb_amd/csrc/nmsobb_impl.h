@@ -101,6 +101,11 @@ struct DecodeArgs {
   int* cnt;                  // [bs * kCntPad] candidates produced (may exceed cap_img: overflow), one 256-B line each
   int* tiny;                 // [bs] flags of the image (kImg*): what decides whether its classes may run as independent NMS segments
   float win_lo, win_hi;      // every candidate's circle must lie in win_lo < x < win_hi (a window narrower than max_wh), else kImgWide
+  // state of the LATER launches that this kernel zeroes on its way (a call with caller-kept counters has no reset launch:
+  // obb_non_max_suppression_obb_st); all NULL / 0: k_reset_state did it
+  int* z_ticket; int n_ticket;
+  uint4* z_bar16; long long n_bar16;
+  uint4* z_alive16; long long n_alive16;
 };
 
 // Per-image flags (DecodeArgs::tiny).  The reference runs ONE list per image with xy += cls * max_wh (utils/general.py:849-851);
@@ -212,6 +217,12 @@ __global__ __launch_bounds__(kDecThreads) void k_decode(DecodeArgs a) {
   int staged = 0;   // wave-uniform
   int flags_seen = 0;
   if (tid == 0) s_n = 0;
+  if (a.z_ticket != nullptr) {                                   // (kernel-uniform) what k_reset_state zeroes for the sort and NMS launches
+    const long long i = ((long long)blockIdx.y * gridDim.x + blockIdx.x) * kDecThreads + tid, n = (long long)gridDim.x * gridDim.y * kDecThreads;
+    if (i < a.n_ticket) a.z_ticket[i] = 0;
+    for (long long k = i; k < a.n_bar16; k += n) a.z_bar16[k] = make_uint4(0u, 0u, 0u, 0u);
+    for (long long k = i; k < a.n_alive16; k += n) a.z_alive16[k] = make_uint4(0u, 0u, 0u, 0u);
+  }
   __syncthreads();
 
   auto write_out = [&](long long base, int count) {
@@ -862,7 +873,8 @@ __global__ __launch_bounds__(256) void k_gather_out(const float4* __restrict__ c
                                                     const int* __restrict__ mode, int ncs, long long max_det, float* __restrict__ out,
                                                     int64_t* __restrict__ out_count, const int* __restrict__ cnt, long long cap_img,
                                                     int64_t* __restrict__ status, const int* __restrict__ abort_flag, int packed,
-                                                    const int* __restrict__ info, const int* __restrict__ tiny) {
+                                                    const int* __restrict__ info, const int* __restrict__ tiny, int* __restrict__ clean_cnt,
+                                                    int* __restrict__ clean_tiny) {
   __shared__ int s_pre[257], s_seg[256];
   __shared__ long long s_rows[4], s_mx[4];
   __shared__ int s_tf[4];
@@ -928,6 +940,10 @@ __global__ __launch_bounds__(256) void k_gather_out(const float4* __restrict__ c
     const long long small_seen = ((tfa & kImgSmall) ? (1ll << 62) : 0ll) | ((tfa & 16) ? (1ll << 61) : 0ll);
     status[1] = m4 | (((long long)(info[8] > info[4] ? info[8] : info[4]) & 0x1fffffffll) << 32) | small_seen;
   }
+  // caller-kept counters (obb_non_max_suppression_obb_st) are left zeroed for the next call: this workgroup was their last
+  // reader whose reading matters (the other parts of image 0 read them too, but only this one writes the status words)
+  if (clean_cnt != nullptr && g == 0 && part == 0)
+    for (int b2 = tid; b2 < (int)gridDim.x; b2 += 256) { clean_cnt[b2 * kCntPad] = 0; clean_tiny[b2] = 0; }
   // first output row of the image: g * max_det, or (packed) the number of rows of the images before it
   const long long row0 = packed ? s_rows[0] + s_rows[1] + s_rows[2] + s_rows[3] : (long long)g * max_det;
   const int md = mode[g];
@@ -990,6 +1006,7 @@ struct SmallGather {
     float* out; int64_t* out_count; int64_t* status;
     long long cap_img, max_det;
     int bs;
+    int* clean_cnt; int* clean_tiny;   // caller-kept counters to leave zeroed (obb_non_max_suppression_obb_st), or NULL
   };
   static constexpr int kLds = kSortLdsMax;                       // entries staged in LDS: an image of the in-LDS sort has no more candidates
   static constexpr size_t kLdsBytes = 2064 + (size_t)kLds * 16;
@@ -1190,6 +1207,9 @@ struct SmallGather {
     if (!writes) return;
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) { const long long o = __shfl_xor(mx, d); if (o > mx) mx = o; tf |= __shfl_xor(tf, d); }
+    // (the counters were read above; the images still at work on their rows do not use theirs)
+    if (ga.clean_cnt != nullptr)
+      for (int b2 = lane; b2 < ga.bs; b2 += 64) { ga.clean_cnt[b2 * kCntPad] = 0; ga.clean_tiny[b2] = 0; }
     if (lane == 0) {
       const int seg4 = ga.info[4];
       ga.status[0] = big ? -1 : (mx > ga.cap_img ? mx : 0);
@@ -1200,6 +1220,8 @@ struct SmallGather {
 };
 static_assert(SmallGather::kLdsBytes <= (size_t)kSmallMax * RotGeom::RECQ * 16 + (size_t)kSmallMax * kSmallWords * 8 + 64 + sizeof(SmallWave<RotGeom>) * kSmallWaves,
               "SmallGather: the merge lists live where the segment state was");
+
+static inline size_t obb_state_bytes(int64_t bs) { return align_up((size_t)bs * kCntPad * 4 + (size_t)bs * 4); }   // cnt lines + tiny flags
 
 struct ObbCarve {
   float4* cand; unsigned long long *keys_a, *keys_b; uint32_t *vals_a, *vals_b; int* cnt; int *sort_begin, *sort_end;
@@ -1240,7 +1262,8 @@ static int obb_carve(void* base, int64_t bs, int64_t cap_img, int64_t ncs, ObbCa
 static int run_nms_obb(const void* pred, const void* objcol, int dtype, int64_t bs, int64_t A, int64_t no, float conf_thres, float iou_thres,
                        const int32_t* classes_host, int n_classes, int agnostic, int multi_label, int64_t max_det, int64_t max_nms,
                        float max_wh, const float* extra8, int64_t n_extra, int64_t cap_img, int64_t expected_cand, float* out,
-                       int out_packed, int64_t* out_count, int64_t* status, void* ws, size_t ws_bytes, hipStream_t st) {
+                       int out_packed, int64_t* out_count, int64_t* status, void* ws, size_t ws_bytes, hipStream_t st, void* state = nullptr,
+                       size_t state_bytes = 0) {
   const int nc = (int)(no - 5 - 180);                              // :784
   if (bs < 1 || A < 1 || nc < 1 || nc > 256 || max_det < 1 || cap_img < 1 || !pred || !out || !out_count || !status)
     return OBB_ERR_BAD_ARG;
@@ -1266,6 +1289,13 @@ static int run_nms_obb(const void* pred, const void* objcol, int dtype, int64_t 
   int rc = obb_carve(ws, bs, cap_img, ncs, &cv);
   if (rc) return rc;
   if (!ws || ws_bytes < cv.total) return OBB_ERR_WORKSPACE;
+  // caller-kept counters: zero when the call starts (the caller's memset, or the previous call's last kernel) -- no reset launch
+  const bool kept = state != nullptr;
+  if (kept) {
+    if (state_bytes < obb_state_bytes(bs) || ((uintptr_t)state & 255u)) return OBB_ERR_WORKSPACE;
+    cv.cnt = (int*)state;
+    cv.tiny = cv.cnt + bs * kCntPad;
+  }
 
   DecodeArgs d;
   d.pred = pred; d.objcol = objcol; d.A = A; d.no = (int)no; d.nc = nc; d.bs = (int)bs; d.conf_thres = conf_thres;
@@ -1281,13 +1311,20 @@ static int run_nms_obb(const void* pred, const void* objcol, int dtype, int64_t 
 
   static const int no_lds_sort = obb_dev_switch("OBB_NO_LDS_SORT", 0) != 0;      // A/B switch (development builds)
   const bool lds_sort = !no_lds_sort && expected_cand > 0 && expected_cand <= kSortLdsHint && !group_ok;
+  d.z_ticket = nullptr; d.n_ticket = 0; d.z_bar16 = nullptr; d.n_bar16 = 0; d.z_alive16 = nullptr; d.n_alive16 = 0;
   {
     Carve& nv0 = cv.nms;
     // (cap_img is a multiple of 64 -> bs * cap_img / 64 words; + the guard words, rounded up to 16 bytes)
     const long long alive16 = lds_sort ? (long long)((((size_t)bs * cap_img) >> 6) + 8 + 1) / 2 : 0ll;
-    k_reset_state<<<256, 256, 0, st>>>(cv.cnt, (int)(bs * kCntPad), cv.tiny, (int)bs, status, cv.ticket, (int)(16 + bs + 1),
-                                       reinterpret_cast<uint4*>(nv0.bar), (long long)(nv0.bar_bytes / 16),
-                                       reinterpret_cast<uint4*>(nv0.alive), alive16);
+    if (kept) {                                                    // the filter kernel zeroes what the later launches need
+      d.z_ticket = cv.ticket; d.n_ticket = (int)(16 + bs + 1);
+      d.z_bar16 = reinterpret_cast<uint4*>(nv0.bar); d.n_bar16 = (long long)(nv0.bar_bytes / 16);
+      d.z_alive16 = reinterpret_cast<uint4*>(nv0.alive); d.n_alive16 = alive16;
+    } else {
+      k_reset_state<<<256, 256, 0, st>>>(cv.cnt, (int)(bs * kCntPad), cv.tiny, (int)bs, status, cv.ticket, (int)(16 + bs + 1),
+                                         reinterpret_cast<uint4*>(nv0.bar), (long long)(nv0.bar_bytes / 16),
+                                         reinterpret_cast<uint4*>(nv0.alive), alive16);
+    }
   }
   // rows per workgroup: 2048 when that still gives two workgroups per CU, else 1024 / 512 (small batches, the TTA tensor)
   d.rows_per_thread = (bs * A >= 4LL * kDecThreads * 480) ? 4 : (bs * A >= 2LL * kDecThreads * 480) ? 2 : 1;
@@ -1408,6 +1445,7 @@ static int run_nms_obb(const void* pred, const void* objcol, int dtype, int64_t 
       SmallGather::Args ga{};
       ga.cand = cv.cand; ga.cnt = cv.cnt; ga.tiny = cv.tiny; ga.info = cv.ticket; ga.ticket = cv.ticket + 16;
       ga.out = out; ga.out_count = out_count; ga.status = status; ga.cap_img = cap_img; ga.max_det = max_det; ga.bs = (int)bs;
+      ga.clean_cnt = kept ? cv.cnt : nullptr; ga.clean_tiny = kept ? cv.tiny : nullptr;
       k_nms_small<RotGeom, SmallGather><<<(unsigned)(bs * ncs), kSmallThreads, lds, st>>>(sa, ga);
     } else {
       k_nms_small<RotGeom, SmallNoTail><<<(unsigned)(bs * ncs), kSmallThreads, lds, st>>>(sa, SmallNoTail::Args{});
@@ -1422,7 +1460,8 @@ static int run_nms_obb(const void* pred, const void* objcol, int dtype, int64_t 
     // parts per image: one up to ~2k expected candidates (the kept rows fit the kernel's LDS and 256 threads), then one per 1024
     const unsigned gparts = expected_cand <= 2048 ? 1u : (unsigned)((expected_cand + 1023) / 1024 > 16 ? 16 : (expected_cand + 1023) / 1024);
     k_gather_out<<<dim3((unsigned)bs, gparts), 256, 0, st>>>(cv.cand, cv.vals_b, cv.keys_b, cv.keep, nv.seg_begin, nv.keep_cnt, cv.mode, ncs, max_det,
-                                              out, out_count, cv.cnt, cap_img, status, nv.abort_flag, out_packed, cv.ticket, cv.tiny);
+                                              out, out_count, cv.cnt, cap_img, status, nv.abort_flag, out_packed, cv.ticket, cv.tiny,
+                                              kept ? cv.cnt : nullptr, kept ? cv.tiny : nullptr);
   }
   return hipGetLastError() == hipSuccess ? OBB_OK : OBB_ERR_LAUNCH;
 }

@@ -36,7 +36,7 @@ namespace {
 // ---------------------------------------------------------------- the C ABI, bound at run time
 #define OBB_API(X)                                                                                                         \
   X(obb_version) X(obb_nms_set_max_grid) X(obb_nms_workspace_bytes) X(obb_nms_rotated_f32) X(obb_nms_rotated_f64)       \
-  X(obb_nms_poly_f32) X(obb_nms_obb_workspace_bytes) X(obb_non_max_suppression_obb_col)                                   \
+  X(obb_nms_poly_f32) X(obb_nms_obb_workspace_bytes) X(obb_nms_obb_state_bytes) X(obb_non_max_suppression_obb_st)                                   \
   X(obb_val_tail_batch_workspace_bytes) X(obb_val_tail_batch_rows_f32)
 
 struct Api {
@@ -110,6 +110,21 @@ void wait_words(const Pinned& w, const c10::hip::HIPStream& stream) {
 at::Tensor workspace(size_t bytes, const at::Device& dev) {
   // the caching allocator hands the same block back call after call; stream-ordered with the kernels that use it
   return at::empty({(int64_t)(bytes ? bytes : 1)}, at::TensorOptions().dtype(at::kByte).device(dev));
+}
+
+// The candidate counters of obb_non_max_suppression_obb_st: a small device buffer per (thread, device, stream, batch size) that
+// this module keeps -- zeroed when it is made, left zeroed by every call that completes (include/obb_hip.h), zeroed again
+// after one that did not.  Never freed (see pinned_words).
+struct StateBuf { at::Tensor t; bool clean = false; };
+StateBuf& state_buf(const at::Device& dev, const c10::hip::HIPStream& stream, int64_t bs) {
+  static thread_local std::map<std::tuple<int, int64_t, int64_t>, StateBuf*> memo;
+  StateBuf*& e = memo[std::make_tuple((int)dev.index(), (int64_t)stream.id(), bs)];
+  if (!e) {
+    e = new StateBuf();
+    e->t = at::zeros({(int64_t)api.obb_nms_obb_state_bytes(bs)}, at::TensorOptions().dtype(at::kByte).device(dev));
+    e->clean = true;
+  }
+  return *e;
 }
 
 void require_cuda(const at::Tensor& t, const char* name) {      // _lib.require_cuda
@@ -308,17 +323,21 @@ std::vector<at::Tensor> non_max_suppression_obb(const at::Tensor& prediction, do
     auto it = ws_memo.find(wkey);
     if (it == ws_memo.end()) it = ws_memo.emplace(wkey, api.obb_nms_obb_workspace_bytes(bs, cap, nc, agnostic ? 1 : 0)).first;
     at::Tensor ws = workspace(it->second, dev);
+    StateBuf& sb = state_buf(dev, stream, bs);
+    if (!sb.clean) sb.t.zero_();                                       // the previous call on it did not complete
+    sb.clean = false;
     arm(meta);
-    const int rc = api.obb_non_max_suppression_obb_col(pred.data_ptr(), col_p, dtype, bs, A, no, conf_f, (float)iou_thres, cls.empty() ? nullptr : cls.data(),
+    const int rc = api.obb_non_max_suppression_obb_st(pred.data_ptr(), col_p, dtype, bs, A, no, conf_f, (float)iou_thres, cls.empty() ? nullptr : cls.data(),
                                                        (int)cls.size(), agnostic ? 1 : 0, multi ? 1 : 0, max_det, kMaxNms, (float)kMaxWh, extra_p, n_extra, cap,
                                                        hint | (seg_hint << 32) | (memo.small_boxes ? (int64_t(1) << 62) : 0), out.data_ptr<float>(), 0, meta.p, meta.p + bs,
-                                                       ws.data_ptr(), (size_t)ws.numel(),
+                                                       ws.data_ptr(), (size_t)ws.numel(), sb.t.data_ptr(), (size_t)sb.t.numel(),
                                                        stream.stream());
     check(rc, "obb_non_max_suppression_obb");
     {
       py::gil_scoped_release nogil;
       wait_words(meta, stream);
     }
+    sb.clean = true;                                                   // every launch of the call was made: its last kernel zeroes the counters
     const int64_t st0 = meta.p[bs], st1 = meta.p[bs + 1];
     seg_max = (st1 >> 32) & 0x1fffffffll;
     memo.small_resolved = ((st1 >> 61) & 1) != 0;
