@@ -427,6 +427,8 @@ def main():
         sq["_file"] = "profiles/r5_sq.json"
     except Exception:
         pass
+    # (through the compiled binding the step is three launches: "gather" -- k_gather_out -- reads 0, the output rows are written by the
+    #  NMS kernel and counted in "nms_steps"; there is no reset launch either: obb_non_max_suppression_obb_st)
     stage_names = ["decode", "segsort", "prep", "nms_steps", "gather"]
     stages = {stage_names[i]: round(ms_sum[i] / max(1, cnts[i]), 4) for i in range(5)}
     stages_warm = {stage_names[i]: round(ms_sum_w[i] / max(1, cnts_w[i]), 4) for i in range(5)}
@@ -916,7 +918,7 @@ def main():
                     "bound": "hbm", "achieved": round(nms_ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(nms_ach / HBM_PEAK_GBS, 5), "traffic": pmc.get("k_nms_persist_bs16"), "algorithmic_bytes": nms_alg,
                     "avg_kernel_ms": round(nms_ms_step, 5), "candidates_per_image": [int(c) for c in cand],
-                    "note": "largest share of the step; one workgroup per (image, class) segment of ~100 boxes held in LDS (csrc/nms_small.h; round 3: the persistent kernel, 0.073 ms): VALU bound by the decision stages, not HBM bound"},
+                    "note": "largest share of the step; one workgroup per (image, class) segment of ~100 boxes held in LDS (csrc/nms_small.h; round 3: the persistent kernel, 0.073 ms): VALU bound by the decision stages, not HBM bound.  Since round 5 the time includes the output rows: the workgroup that finishes an image merges its kept lists and writes them (csrc/nmsobb_impl.h SmallGather; the stage 'gather' is 0), and the call is three launches (filter, sort, this kernel)"},
                 "obb::k_decode<__half>": {
                     "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "avg_kernel_ms": round(dec_ms, 5), "avg_kernel_ms_one_tensor_warm": round(dec_ms_warm, 5),

@@ -3,6 +3,7 @@
 #   bash tools/final_run.sh <tag> [round]   -> gpurun_out/<tag>/{pytest_gpu.log, smoke.log, bench.json, *_kernel_stats.md, pmc_*.md}
 # and, on the box, profiles/<round>_pmc.json + <round>_sq.{md,json} (default round: r5) so that the bench line of the same call reads this run's counters.
 # rocprofv3 writes rocpd SQLite databases (tens of MB): they stay in /tmp, only the markdown summaries come back.
+# SKIP_SQ=1: without the three SQ counter passes (profiles/<round>_sq.* stay as they are); SKIP_HIPTRACE=1: without the traced validation loop.
 TAG=${1:-run}
 RND=${2:-r5}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -27,23 +28,27 @@ PA="SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_
 PB="SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE"
 PC="SQ_IFETCH SQ_INSTS_SMEM SQ_ACTIVE_INST_SCA SQ_BUSY_CU_CYCLES SQ_WAIT_INST_LDS SQ_INSTS_BRANCH SQ_ACTIVE_INST_MISC SQ_ACTIVE_INST_FLAT GRBM_GUI_ACTIVE"
 i=0; DBS=""
-for P in "$PA" "$PB" "$PC"; do
+[ -n "$SKIP_SQ" ] || for P in "$PA" "$PB" "$PC"; do
   i=$((i+1)); rm -rf /tmp/p_sq$i
   SQ_REPS=3 timeout 420 rocprofv3 --kernel-trace --pmc $P -d /tmp/p_sq$i -o sq$i -- python tools/prof_sq.py > $O/sq_pass$i.log 2>&1
   D=$(db /tmp/p_sq$i); [ -n "$D" ] && DBS="$DBS $D"
 done
+if [ -z "$SKIP_SQ" ]; then
 python tools/rocpd_sq.py "rocprofv3 --kernel-trace --pmc <8 SQ counters + GRBM_GUI_ACTIVE> -- python tools/prof_sq.py (three passes, SQ_REPS=3)" 3 $DBS > $O/sq.md 2> $O/sq.err
 python tools/sq_json.py $O/sq.md > $O/sq.json 2>> $O/sq.err && cp $O/sq.json profiles/${RND}_sq.json && cp $O/sq.md profiles/${RND}_sq.md
+fi
 # the counters feed bench.py's `traffic` fields: refresh the json before the bench line is produced
 python tools/pmc_json.py gpurun_out/$TAG/pmc_fetch.md gpurun_out/$TAG/pmc_write.md gpurun_out/$TAG/kernel_stats.md > $O/pmc.json 2> $O/pmc_json.err && cp $O/pmc.json profiles/${RND}_pmc.json
 # the HIP API timeline of the validation loop on the ctypes binding with torch's default thread count (the configuration that showed the
 # 70-88 ms stalls of rounds 2-4, before its val tail stopped issuing parallel CPU ops) next to the cgroup's throttle counters, and the same
 # loop on the compiled binding: profiles/r5_host_stall.md (the measurement that found the cause is gpurun_out/r5d/cgroup.txt, quoted there)
 { echo "cpu.max $(cat /sys/fs/cgroup/cpu.max 2>/dev/null)"; grep -E "nr_throttled|throttled_usec" /sys/fs/cgroup/cpu.stat 2>/dev/null; } > $O/cgroup_before.txt
+if [ -z "$SKIP_HIPTRACE" ]; then
 rm -rf /tmp/p_hip
 OBB_BINDING=ctypes timeout 600 rocprofv3 --hip-trace --kernel-trace -d /tmp/p_hip -o hip -- python tools/trace_valbuckets.py 2 0 > $O/vb_ctypes_traced.log 2>&1
 python tools/rocpd_hiptrace.py "$(db /tmp/p_hip)" 1000 1000 900 > $O/hiptrace_ctypes.md 2> $O/hiptrace.err
 grep -E "nr_throttled|throttled_usec" /sys/fs/cgroup/cpu.stat > $O/cgroup_after_ctypes.txt 2>/dev/null
+fi
 timeout 400 python tools/trace_valbuckets.py 5 0 > $O/vb_compiled.log 2>&1
 grep -E "nr_throttled|throttled_usec" /sys/fs/cgroup/cpu.stat > $O/cgroup_after_compiled.txt 2>/dev/null
 timeout 300 python tools/time_valtail.py > $O/valtail.txt 2>&1
