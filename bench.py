@@ -914,7 +914,7 @@ def main():
             "hbm_copy": hbm_copy,
             "val_buckets": val_obj,
             "kernels": {
-                "obb::k_nms_small<obb::RotGeom> (bs16 step)": {
+                "obb::k_nms_small<obb::RotGeom, obb::SmallGather> (bs16 step)": {
                     "bound": "hbm", "achieved": round(nms_ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(nms_ach / HBM_PEAK_GBS, 5), "traffic": pmc.get("k_nms_persist_bs16"), "algorithmic_bytes": nms_alg,
                     "avg_kernel_ms": round(nms_ms_step, 5), "candidates_per_image": [int(c) for c in cand],

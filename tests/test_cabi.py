@@ -96,3 +96,27 @@ def test_ctypes_binding_can_be_forced(monkeypatch):
             "assert _lib.compiled() is None; print(_lib.lib().obb_version().decode())")
     out = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "obb_hip" in out.stdout, out.stderr[-400:]
+
+
+def test_compiled_binding_builds_its_output_views_like_as_strided():
+    """The binding makes the per-image views it returns directly (csrc/torch_ext/nms_rotated_ext.cpp: view_of) instead of one
+    dispatcher call per view: same storage, offsets, strides and values as torch.as_strided, writes go through to the base."""
+    import torch
+    from yolov5_obb_amd import _lib
+    ext = _lib.compiled()
+    assert ext is not None
+    t = torch.arange(240 * 7, dtype=torch.float32).view(240, 7)
+    for row0, rows in ((0, 0), (0, 5), (30, 17), (239, 1)):
+        v = ext._view_of(t, row0 * 7, [rows, 7], [7, 1])
+        w = torch.as_strided(t, (rows, 7), (7, 1), row0 * 7)
+        assert v.shape == w.shape and v.stride() == w.stride() and v.storage_offset() == w.storage_offset() and torch.equal(v, w)
+        assert v.dtype == t.dtype and v.device == t.device and not v.requires_grad and v.is_contiguous()
+    b = t[10:]                                               # a base with a storage offset of its own
+    assert torch.equal(ext._view_of(b, 7 * 5, [3, 7], [7, 1]), b[5:8])
+    c = torch.stack((torch.arange(50.), torch.arange(50.) + 100), 1)
+    assert torch.equal(ext._view_of(c, 2 * 10 + 1, [7], [2]), c[10:17, 1])
+    m = torch.zeros(20, 10, dtype=torch.bool)
+    v = ext._view_of(m, 3 * 10, [4, 10], [10, 1])
+    v[1, 2] = True
+    assert m[4, 2] and int(m.sum()) == 1 and v.dtype == torch.bool
+    assert (v + 0).sum() == 1 and torch.cat([v, v]).shape == (8, 10)          # ordinary ops accept the views

@@ -127,6 +127,17 @@ StateBuf& state_buf(const at::Device& dev, const c10::hip::HIPStream& stream, in
   return *e;
 }
 
+// A view of `base`'s storage made directly (what at::as_strided does underneath, ATen/native/TensorShape.cpp: as_strided_tensorimpl)
+// without a trip through the dispatcher and the autograd keys per view: the fused driver hands back one view per image, the val tail
+// three -- 16 to 48 `narrow` calls were 10-30 us of host time behind kernels that had already finished.  `base` never requires grad here.
+at::Tensor view_of(const at::Tensor& base, int64_t offset_elems, c10::IntArrayRef sizes, c10::IntArrayRef strides) {
+  auto impl = c10::make_intrusive<c10::TensorImpl>(c10::TensorImpl::VIEW, c10::Storage(base.storage()), base.key_set(), base.dtype());
+  impl->set_storage_offset(base.storage_offset() + offset_elems);
+  impl->set_sizes_and_strides(sizes, strides);
+  impl->set_version_counter(base.unsafeGetTensorImpl()->version_counter());
+  return at::Tensor(std::move(impl));
+}
+
 void require_cuda(const at::Tensor& t, const char* name) {      // _lib.require_cuda
   if (!t.is_cuda())
     throw std::runtime_error(std::string(name) + " must be a CUDA/HIP tensor: yolov5_obb_amd is compiled for MI355X only (no CPU path, by design)");
@@ -374,7 +385,7 @@ std::vector<at::Tensor> non_max_suppression_obb(const at::Tensor& prediction, do
   if (memo.hold_seg > 0 && (seg_max == 0 || seg_max > OBB_NMS_SMALL_SEG * 3 / 4)) { memo.hold_seg--; memo.seg = std::max<int64_t>(seg_max, OBB_NMS_SMALL_SEG + 1); }
   else { memo.hold_seg = 0; memo.seg = seg_max; }                      // (0: the sort path of this call does not report it)
   result.reserve((size_t)bs);
-  for (int64_t b = 0; b < bs; b++) result.push_back(out.narrow(0, b * max_det, meta.p[b]));
+  for (int64_t b = 0; b < bs; b++) result.push_back(view_of(out, b * max_det * 7, {meta.p[b], 7}, {7, 1}));
   return result;
 }
 
@@ -502,11 +513,10 @@ py::object val_tail_batch(const std::vector<at::Tensor>& preds, const at::Tensor
       q[0] = r[niou]; q[1] = r[niou + 1];
     }
   }
-  const at::Tensor conf = cc.select(1, 0), pcls = cc.select(1, 1);
   py::list out((size_t)bs);
   for (int64_t b = 0; b < bs; b++) {
     const int64_t c = offs[b + 1] - offs[b];
-    out[(size_t)b] = py::make_tuple(correct.narrow(0, offs[b], c), conf.narrow(0, offs[b], c), pcls.narrow(0, offs[b], c));
+    out[(size_t)b] = py::make_tuple(view_of(correct, offs[b] * niou, {c, niou}, {niou, 1}), view_of(cc, offs[b] * 2, {c}, {2}), view_of(cc, offs[b] * 2 + 1, {c}, {2}));
   }
   if (!want_boxes) return std::move(out);
   return py::make_tuple(out, py::make_tuple(py::make_tuple(boxes[0], boxes[1], boxes[2], boxes[3]), offs));
@@ -540,6 +550,8 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
             "non_max_suppression_obb: utils/general.py:772-862; val_tail_batch: val.py:209-250)";
   m.def("init", &init, "bind the C ABI of the given libobb_hip.so (dlopen / dlsym)");
   m.def("library", &library);
+  m.def("_view_of", [](const at::Tensor& base, int64_t offset, std::vector<int64_t> sizes, std::vector<int64_t> strides) { return view_of(base, offset, sizes, strides); },
+        "the binding's direct view constructor (tests/test_cabi.py compares it with torch.as_strided)");
   m.def("nms_rotated", &nms_rotated, "NMS for rotated boxes", py::arg("dets"), py::arg("scores"), py::arg("iou_threshold"));
   m.def("nms_poly", &nms_poly, "NMS for quadrilaterals", py::arg("dets"), py::arg("iou_threshold"));
   m.def("nms_rotated_opts", &nms_rotated_opts, py::arg("dets"), py::arg("scores"), py::arg("iou_threshold"), py::arg("flags") = 0, py::arg("max_keep") = 0);
