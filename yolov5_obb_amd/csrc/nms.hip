@@ -14,6 +14,7 @@
 #include <stdio.h>
 #include <string.h>
 #include <hip/hip_fp16.h>
+#include "launch_once.h"
 #include "nms_core.h"
 #include "obb_hip.h"
 #include "psrs_sort.h"
@@ -535,11 +536,11 @@ constexpr size_t kPersistLdsMax = 159 * 1024;   // of the 160 KB per CU: exactly
 
 template <class G, bool GRID>
 static int launch_persist(const NmsArgs& a, unsigned nb, hipStream_t st) {   // nb <= number of CUs (nms_grid); static teams and plans are made for that grid
-  static bool attr_set = false;
-  if (!attr_set) {
+  static OncePerDevice attr;
+  if (attr.need()) {
     if (hipFuncSetAttribute((const void*)k_nms_persist<G, GRID>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPersistLdsMax) != hipSuccess)
       return OBB_ERR_LAUNCH;
-    attr_set = true;
+    attr.mark();
   }
   // every workgroup of the launch must be resident at once (team barriers): the grid is bounded by what the occupancy
   // calculation gives for this instantiation with its largest LDS footprint -- asked once, not assumed

@@ -1002,7 +1002,7 @@ __global__ __launch_bounds__(256) void k_gather_out(const float4* __restrict__ c
 struct SmallGather {
   struct Args {
     const float4* cand; const int* cnt; const int* tiny; const int* info;
-    int* ticket;               // [bs] segments of the image that are done, [bs] images that are done (zeroed by k_reset_state)
+    int* ticket;               // [bs] segments of the image that are done, then [1] images that are done (zeroed by k_reset_state or k_decode)
     float* out; int64_t* out_count; int64_t* status;
     long long cap_img, max_det;
     int bs;
@@ -1349,12 +1349,12 @@ static int run_nms_obb(const void* pred, const void* objcol, int dtype, int64_t 
   const int plan_nb = (bs * ncs > 1 && !small_nms) ? nms_grid(bs * ncs, bs * max_seg, cap_first()) : 0;
   if (lds_sort) {
     ProfScope ps(PROF_SEGSORT, st);
-    static bool attr_set = false;
+    static OncePerDevice attr;
     const size_t lds = (size_t)kSortLdsMax * 12;
-    if (!attr_set) {
+    if (attr.need()) {
       if (hipFuncSetAttribute((const void*)k_sort_prep_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return OBB_ERR_LAUNCH;
-      attr_set = true;
+      attr.mark();
     }
     const int parts = (class_ok && ncs >= 8) ? 4 : 1;           // class-segment images: four workgroups each take every fourth class
     k_sort_prep_lds<<<(unsigned)(bs * parts) + (plan_nb > 0 ? 1u : 0u), 1024, lds, st>>>(cv.cand, cv.keys_a, cv.vals_a, cv.keys_b, cv.vals_b, cv.cnt, cv.tiny, (int)bs, cap_img,
@@ -1427,13 +1427,13 @@ static int run_nms_obb(const void* pred, const void* objcol, int dtype, int64_t 
   const bool fused_out = small_nms && !out_packed && !no_fused_out;
   if (small_nms) {
     ProfScope ps(PROF_STEPS, st);
-    static bool attr_set = false;
+    static OncePerDevice attr;
     const size_t lds = small_lds_bytes<RotGeom>();
-    if (!attr_set) {
+    if (attr.need()) {
       if (hipFuncSetAttribute((const void*)k_nms_small<RotGeom, SmallNoTail>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
           hipFuncSetAttribute((const void*)k_nms_small<RotGeom, SmallGather>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return OBB_ERR_LAUNCH;
-      attr_set = true;
+      attr.mark();
     }
     SmallArgs sa{};
     sa.rec = nv.rec; sa.alive = nv.alive; sa.seg_begin = nv.seg_begin; sa.seg_end = nv.seg_end; sa.keep_cnt = nv.keep_cnt;

@@ -316,10 +316,10 @@ static inline void ps_carve_scratch(void* scratch, PsBuf* b) {
 }
 // launches 2 and 3 (the caller has launched its k_ps_local_* flavour over `runs` workgroups)
 static int ps_finish(const PsBuf& b, int runs, hipStream_t st) {
-  static bool attr_set = false;
-  if (!attr_set) {
+  static OncePerDevice attr;
+  if (attr.need()) {
     if (hipFuncSetAttribute((const void*)k_ps_bucket, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPsBucketLds) != hipSuccess) return OBB_ERR_LAUNCH;
-    attr_set = true;
+    attr.mark();
   }
   if (runs > 1) k_ps_split<<<(unsigned)runs, kPsRun, 0, st>>>(b);
   k_ps_bucket<<<(unsigned)runs, kPsRun, kPsBucketLds, st>>>(b);
