@@ -207,14 +207,21 @@ def test_small_grid_fallback_gives_the_same_result(dev, oracle_lib):
     pred = synth.s_pred(2, 4000, 15, seed=3)
     kw = dict(conf_thres=0.25, iou_thres=0.45, multi_label=True, max_det=300)
     want = pyref.non_max_suppression_obb(pred.clone(), **kw)
+    # ... and a list that falls apart into six independent slabs: with 8 workgroups every one of them scatters ten tiles of its
+    # block of positions (the one-tile form of k_slab_split's scatter is what the full grid runs)
+    dets6, _ = synth.with_classes(dets, 6, 5)
+    ref6 = oracle.nms_rotated(dets6.numpy(), scores.numpy(), 0.4, threads=8)
     L = _lib.lib()
     try:
         L.obb_nms_set_max_grid(8)
         got = nms_rotated_ext.nms_rotated(dets.to(dev), scores.to(dev), 0.4).cpu().numpy()
+        got6 = nms_rotated_ext.nms_rotated(dets6.to(dev), scores.to(dev), 0.4).cpu().numpy()
         out = non_max_suppression_obb(pred.to(dev), **kw)
     finally:
         L.obb_nms_set_max_grid(0)
     assert np.array_equal(ref, got)
+    assert np.array_equal(ref6, got6)
+    assert np.array_equal(ref6, nms_rotated_ext.nms_rotated(dets6.to(dev), scores.to(dev), 0.4).cpu().numpy())      # (full grid: one tile)
     assert all(torch.equal(g.cpu(), w) for g, w in zip(out, want))
 
 

@@ -1630,22 +1630,41 @@ __device__ __forceinline__ int slab_setup(const NmsArgs& a, float bin_x0, float 
   const int chunk = (((a.n + NB - 1) / NB) + 63) & ~63;
   const int p0 = wg * chunk < a.n ? wg * chunk : a.n, p1 = (p0 + chunk < a.n) ? p0 + chunk : a.n;
   if (tid < kMaxSlabs) { cnt[tid] = 0; run[tid] = 0; tot[tid] = 0; pre[tid] = 0; }
+  for (int k = tid; k < kNmsWaves * kMaxSlabs; k += kNmsThreads) wcnt[k] = 0;
   for (int k = wg * kNmsThreads + tid; k < a.alive2_words; k += NB * kNmsThreads) stg_agent(a.alive2 + k, 0ull);
   for (int k = wg * kNmsThreads + tid; k < a.kept_words; k += NB * kNmsThreads) stg_agent(a.kept_bits + k, 0ull);
   if (wg == 0 && tid < kMaxSlabs) stg_agent(a.slab_keep + tid, 0);
   __syncthreads();
+  // A block of at most one tile (every list of up to 131072 boxes on a full grid): the box's record, slab and place in its wave are
+  // kept in registers from this pass to the scatter behind the barrier -- which then only adds offsets and stores (round 5: the
+  // scatter re-read and re-ranked everything: 14 us of a 50 us kernel).
+  const bool one_tile = p1 - p0 <= kNmsThreads;                // (uniform over the grid)
+  int sl1 = -1, rank1 = 0;
+  uint32_t order1 = 0u;
+  float4 q1[G::RECQ];
   for (int pb = p0; pb < p1; pb += kNmsThreads) {
     const int p = pb + tid;
     int sl = -1;
-    if (p < p1 && ((a.alive[p >> 6] >> (p & 63)) & 1ull)) sl = slab_of(a.rec[(size_t)p * G::RECQ].x);
+    if (p < p1 && ((a.alive[p >> 6] >> (p & 63)) & 1ull)) {
+      if (one_tile) {
+#pragma unroll
+        for (int k = 0; k < G::RECQ; k++) q1[k] = a.rec[(size_t)p * G::RECQ + k];
+        order1 = a.order[p];
+        sl = slab_of(q1[0].x);
+      } else {
+        sl = slab_of(a.rec[(size_t)p * G::RECQ].x);
+      }
+    }
     u64 todo = __ballot(sl >= 0);
     while (todo) {                                             // one LDS atomic per (wave, slab present in it)
       const int l0 = __builtin_ctzll(todo);
       const int s0 = __shfl(sl, l0);
       const u64 m = __ballot(sl == s0);
-      if (lane == l0) atomicAdd(&cnt[s0], __popcll(m));
+      if (sl == s0) rank1 = __popcll(m & lanemask_lt());
+      if (lane == l0) { atomicAdd(&cnt[s0], __popcll(m)); if (one_tile) wcnt[wv * kMaxSlabs + s0] = __popcll(m); }
       todo &= ~m;
     }
+    sl1 = sl;
   }
   __syncthreads();
   // this workgroup's counts: its own row of the table, and -- one returning atomic each -- the slab totals and the totals of
@@ -1662,7 +1681,9 @@ __device__ __forceinline__ int slab_setup(const NmsArgs& a, float bin_x0, float 
   }
   slap(43);
   if (!team_barrier(gbar, s_flag)) return -1;
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  // (no acquire fence: what other workgroups of this launch wrote -- the count table and its totals -- is read with agent-scope
+  //  loads below; everything else this kernel reads comes from earlier launches.  Round 5: the fence, one cache invalidate per
+  //  wave of every workgroup, was most of the 14 us this step was charged with)
   slap(44);
   // ---- 3: totals and offsets: thread (slab, part) adds up its share of the group totals below this workgroup's group and
   // of the rows of its own group below itself
@@ -1673,14 +1694,13 @@ __device__ __forceinline__ int slab_setup(const NmsArgs& a, float bin_x0, float 
       // (at most two group totals and two rows per thread: all requested before the first is used -- the loop form waited
       //  for every load in turn, four round trips to lines other workgroups had just written: 14.5 us of the set-up)
       const int g2a = part, g2b = part + kNmsWaves, wa = (grp << 4) + part, wb = wa + kNmsWaves;
-      // (agent-scope loads instead of plain ones behind the fence were measured: no difference)
-      const int v0 = g2a < grp ? a.slab_tot[(size_t)(1 + g2a) * kMaxSlabs + s0] : 0;
-      const int v1 = g2b < grp ? a.slab_tot[(size_t)(1 + g2b) * kMaxSlabs + s0] : 0;
-      const int v2 = wa < wg ? a.slab_cnt[(size_t)wa * kMaxSlabs + s0] : 0;
-      const int v3 = wb < wg ? a.slab_cnt[(size_t)wb * kMaxSlabs + s0] : 0;
-      const int vt = part == 0 ? a.slab_tot[s0] : 0;
+      const int v0 = g2a < grp ? ldg_agent(a.slab_tot + (size_t)(1 + g2a) * kMaxSlabs + s0) : 0;
+      const int v1 = g2b < grp ? ldg_agent(a.slab_tot + (size_t)(1 + g2b) * kMaxSlabs + s0) : 0;
+      const int v2 = wa < wg ? ldg_agent(a.slab_cnt + (size_t)wa * kMaxSlabs + s0) : 0;
+      const int v3 = wb < wg ? ldg_agent(a.slab_cnt + (size_t)wb * kMaxSlabs + s0) : 0;
+      const int vt = part == 0 ? ldg_agent(a.slab_tot + s0) : 0;
       int below = v0 + v1 + v2 + v3;
-      for (int g2 = part + 2 * kNmsWaves; g2 < grp; g2 += kNmsWaves) below += a.slab_tot[(size_t)(1 + g2) * kMaxSlabs + s0];   // (grids beyond 256 workgroups)
+      for (int g2 = part + 2 * kNmsWaves; g2 < grp; g2 += kNmsWaves) below += ldg_agent(a.slab_tot + (size_t)(1 + g2) * kMaxSlabs + s0);   // (grids beyond 256 workgroups)
       if (below) atomicAdd(&pre[s0], below);
       if (part == 0) tot[s0] = vt;
     }
@@ -1693,7 +1713,17 @@ __device__ __forceinline__ int slab_setup(const NmsArgs& a, float bin_x0, float 
     for (int s0 = 0; s0 < S; s0++) { base[s0] = acc; acc += (tot[s0] + 63) & ~63; mx = mx > tot[s0] ? mx : tot[s0]; nonempty += tot[s0] > 0 ? 1 : 0; }
     // chunk capacity of a team: the single list's edge buffer shared out, cap (cap - 1) / 2 <= ecap / teams
     int c = 0;                                                 // largest multiple of 64 with c (c - 1) / 2 * teams <= ecap, at most capmax
-    while (c + 64 <= a.capmax && (long long)(c + 64) * (c + 63) / 2 * (nonempty > 0 ? nonempty : 1) <= a.ecap) c += 64;
+    {
+      const long long teams = nonempty > 0 ? nonempty : 1;
+      auto fits = [&](long long v) { return v <= a.capmax && v * (v - 1) / 2 * teams <= a.ecap; };
+      // (an estimate from the square root, then exact steps of 64 either way: the plain search from 0 took up to 128 dependent
+      //  64-bit multiplications on one thread with every other thread of every workgroup waiting)
+      long long est = (long long)sqrt(2.0 * (double)a.ecap / (double)teams);
+      est = (est > a.capmax ? a.capmax : est) & ~63ll;
+      while (est > 0 && !fits(est)) est -= 64;
+      while (fits(est + 64)) est += 64;
+      c = (int)est;
+    }
     if (a.slab_cap > 0 && c > a.slab_cap) c = a.slab_cap;      // (OBB_NMS_SLAB_CAP: measurements)
     misc[1] = (mx <= kSlabMaxSeg && nonempty >= 2 && nonempty <= NB && c >= 512) ? 1 : 0;
     misc[2] = nonempty; misc[3] = c;
@@ -1702,8 +1732,20 @@ __device__ __forceinline__ int slab_setup(const NmsArgs& a, float bin_x0, float 
   __syncthreads();
   slap(45);
   if (!misc[1]) return 0;                                      // (uniform: every workgroup read the same table)
-  // ---- 4: stable scatter, tile by tile
-  u64 seen = 0ull;
+  // ---- 4: stable scatter: from the registers of the counting pass, or tile by tile
+  if (one_tile) {
+    if (sl1 >= 0) {
+      int off = 0;
+      for (int w2 = 0; w2 < wv; w2++) off += wcnt[w2 * kMaxSlabs + sl1];
+      const int qn = base[sl1] + pre[sl1] + off + rank1;
+      float4* dst = a.rec2 + (size_t)qn * G::RECQ;
+#pragma unroll
+      for (int k = 0; k < G::RECQ; k++) dst[k] = q1[k];
+      a.order2[qn] = order1;
+      a.pos_old[qn] = (uint32_t)(p0 + tid);
+      __hip_atomic_fetch_or(a.alive2 + (qn >> 6), 1ull << (qn & 63), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  } else
   for (int pb = p0; pb < p1; pb += kNmsThreads) {
     const int p = pb + tid;
     int sl = -1;
@@ -1731,15 +1773,15 @@ __device__ __forceinline__ int slab_setup(const NmsArgs& a, float bin_x0, float 
       int off = run[sl];
       for (int w2 = 0; w2 < wv; w2++) off += wcnt[w2 * kMaxSlabs + sl];
       const int qn = base[sl] + pre[sl] + off + rank_in_wave;
-      u64* dst = reinterpret_cast<u64*>(a.rec2 + (size_t)qn * G::RECQ);
+      // (plain 16-byte stores: the copy is read by the NEXT launch -- as part of the persistent kernel, rounds 2-3, these were
+      //  write-through 8-byte stores followed by a grid barrier.  The alive bits stay atomics on words zeroed write-through in
+      //  front of this kernel's barrier: several workgroups share a word.)
+      float4* dst = a.rec2 + (size_t)qn * G::RECQ;
 #pragma unroll
-      for (int k = 0; k < G::RECQ; k++) {
-        stg_agent(dst + 2 * k, ((u64)__float_as_uint(q[k].y) << 32) | (u64)__float_as_uint(q[k].x));
-        stg_agent(dst + 2 * k + 1, ((u64)__float_as_uint(q[k].w) << 32) | (u64)__float_as_uint(q[k].z));
-      }
-      stg_agent(a.order2 + qn, a.order[p]);
-      stg_agent(a.pos_old + qn, (uint32_t)p);
-      seen ^= atomicOr(a.alive2 + (qn >> 6), 1ull << (qn & 63));             // (returning, consumed below: covered by the wave's vmcnt)
+      for (int k = 0; k < G::RECQ; k++) dst[k] = q[k];
+      a.order2[qn] = a.order[p];
+      a.pos_old[qn] = (uint32_t)p;
+      __hip_atomic_fetch_or(a.alive2 + (qn >> 6), 1ull << (qn & 63), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
     if (tid < kMaxSlabs) {
@@ -1748,7 +1790,6 @@ __device__ __forceinline__ int slab_setup(const NmsArgs& a, float bin_x0, float 
       run[tid] += add;
     }
   }
-  asm volatile("; alive bits set %0" ::"v"((unsigned)(seen >> 32) ^ (unsigned)seen));
   slap(50);
   // ---- the plan: one team per non-empty slab, the spare workgroups in proportion to the sizes (written by workgroup 0)
   __syncthreads();
