@@ -1583,7 +1583,8 @@ struct SlabPlan {
 //   4. STABLE scatter of records / original indices / original positions / alive bits: the order inside a slab is the
 //      score order of the list                                                                      -> team barrier
 template <class G>
-__device__ __forceinline__ int slab_setup(const NmsArgs& a, float bin_x0, float inv, unsigned char* smem, TeamBar& gbar, int* s_flag, SlabPlan& SL) {
+__device__ __forceinline__ int slab_setup(const NmsArgs& a, float bin_x0, float inv, unsigned char* smem, float4* st_rec, uint4* st_meta, TeamBar& gbar,
+                                          int* s_flag, SlabPlan& SL) {
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int NB = gridDim.x, wg = blockIdx.x;
   uint32_t* starts = reinterpret_cast<uint32_t*>(smem);       // [kSlabWords] bins where a run starts
@@ -1734,16 +1735,38 @@ __device__ __forceinline__ int slab_setup(const NmsArgs& a, float bin_x0, float 
   if (!misc[1]) return 0;                                      // (uniform: every workgroup read the same table)
   // ---- 4: stable scatter: from the registers of the counting pass, or tile by tile
   if (one_tile) {
+    // The boxes of this block go out slab by slab: in the copy the boxes a workgroup sends to one slab are neighbours (stable
+    // scatter), so they are first put into that order in LDS and then stored by consecutive lanes -- whole runs of 64-byte
+    // records instead of 4 x 64 scattered 16-byte pieces per store instruction (whose completion, ~10 us, the kernel's end waited for).
+    if (tid < 64) {                                             // this workgroup's own prefix over the slabs (kMaxSlabs = 64)
+      const int c = cnt[tid];
+      int incl = c;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(incl, d); if (lane >= d) incl += t; }
+      run[tid] = incl - c;                                       // (run[] is free in this form: first local index of the slab)
+      if (tid == 63) misc[0] = incl;
+    }
+    __syncthreads();
     if (sl1 >= 0) {
       int off = 0;
       for (int w2 = 0; w2 < wv; w2++) off += wcnt[w2 * kMaxSlabs + sl1];
+      const int li = run[sl1] + off + rank1;
       const int qn = base[sl1] + pre[sl1] + off + rank1;
-      float4* dst = a.rec2 + (size_t)qn * G::RECQ;
 #pragma unroll
-      for (int k = 0; k < G::RECQ; k++) dst[k] = q1[k];
-      a.order2[qn] = order1;
-      a.pos_old[qn] = (uint32_t)(p0 + tid);
-      __hip_atomic_fetch_or(a.alive2 + (qn >> 6), 1ull << (qn & 63), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      for (int k = 0; k < G::RECQ; k++) st_rec[li * G::RECQ + k] = q1[k];
+      st_meta[li] = make_uint4((uint32_t)qn, order1, (uint32_t)(p0 + tid), 0u);
+    }
+    __syncthreads();
+    const int total = misc[0];
+    for (int t = tid; t < total * G::RECQ; t += kNmsThreads) {
+      const int j = t / G::RECQ, k = t - j * G::RECQ;
+      a.rec2[(size_t)st_meta[j].x * G::RECQ + k] = st_rec[t];
+    }
+    for (int j = tid; j < total; j += kNmsThreads) {
+      const uint4 mt = st_meta[j];
+      a.order2[mt.x] = mt.y;
+      a.pos_old[mt.x] = mt.z;
+      __hip_atomic_fetch_or(a.alive2 + (mt.x >> 6), 1ull << (mt.x & 63), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   } else
   for (int pb = p0; pb < p1; pb += kNmsThreads) {
@@ -1839,12 +1862,14 @@ __device__ __forceinline__ int slab_setup(const NmsArgs& a, float bin_x0, float 
 template <class G>
 __global__ __launch_bounds__(kNmsThreads) void k_slab_split(NmsArgs a, SlabPlan* sp) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[(2 * kSlabWords + 6 * kMaxSlabs + kNmsWaves * kMaxSlabs + 8) * 4];
+  __shared__ float4 st_rec[kNmsThreads * G::RECQ];             // one tile of records in slab order (slab_setup, one-tile scatter)
+  __shared__ uint4 st_meta[kNmsThreads];                       // {place in the copy, original index, original position}
   __shared__ int s_flag;
   if (blockIdx.x == 0 && threadIdx.x == 0) sp->mode = 0;
   if (a.slab_flag[2] == 0) return;                             // the data is not wide enough to look for slabs (k_prep_rot / the sort's record tail)
   // the barrier line of team 1 (unused by a single-list call) and the second group-counter block
   TeamBar gbar{a.bar + 128, a.bar + 128 + 64, (int)gridDim.x, 0, a.abort_flag, gridDim.x > 32 ? a.bar_sub + kBarGroups * 64 : nullptr, (int)blockIdx.x};
-  const int st = slab_setup<G>(a, __int_as_float(a.slab_flag[4]), __int_as_float(a.slab_flag[5]), smem, gbar, &s_flag, *sp);
+  const int st = slab_setup<G>(a, __int_as_float(a.slab_flag[4]), __int_as_float(a.slab_flag[5]), smem, st_rec, st_meta, gbar, &s_flag, *sp);
   if (st == 1 && blockIdx.x == 0 && threadIdx.x == 0) sp->mode = 1;
 }
 
