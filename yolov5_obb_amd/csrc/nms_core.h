@@ -1555,7 +1555,11 @@ OBB_COLD_GRID int grid_build(const NmsArgs& a, const GridPlan& gp, int c0, int w
     }
   }
   if (!team_barrier(bar, s_flag)) return 1;
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  // ONE acquire per workgroup (the caches it invalidates are the CU's and the XCD's, not the wave's), as in serial_wait: with every
+  // wave of every workgroup issuing its own, 2048 invalidates queued up behind each other -- ~14 us in k_slab_split, where the
+  // timers showed it (round 5)
+  if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  __syncthreads();
   return 0;
 }
 
@@ -2139,7 +2143,8 @@ __global__ __launch_bounds__(kNmsThreads) __attribute__((amdgpu_waves_per_eu(1, 
     if (slab_mode) {                                   // every slab is done: the kept boxes meet again in score order
       lap(7);
       if (!team_barrier(gbar, &s_flag)) return;
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");       // (one per workgroup: see grid_build)
+      __syncthreads();
       slab_merge(a.kept_bits, n0, order0, keep_out0, keep_cnt0, s_i);
       lap(8);
     }
