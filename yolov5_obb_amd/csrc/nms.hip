@@ -16,6 +16,7 @@
 #include <hip/hip_fp16.h>
 #include "launch_once.h"
 #include "nms_core.h"
+#include "nms_mk.h"
 #include "obb_hip.h"
 #include "psrs_sort.h"
 #include "nms_small.h"
@@ -421,6 +422,8 @@ struct Carve {
   uint32_t *rows, *edges;
   long long ecap;
   GridDev grid;                        // spatial index (rotated boxes, single list); grid.meta == NULL: not carved
+  // the phase-kernel path of a long single list (nms_mk.h); mk_cidx == NULL: not carved.  Its control block is the head of `bar`.
+  uint32_t* mk_cidx; float4 *mk_ent_c, *mk_ent_r; uint16_t *mk_start_c, *mk_start_r; uint2* mk_pend1;
   size_t grid_zero_bytes;              // GridMeta + slot counters: one contiguous block, zeroed before every build
   size_t total;
 };
@@ -488,6 +491,7 @@ static int carve(void* base, int64_t n, int64_t nseg, int recq, int C, Carve* cv
   cv->ecap = (long long)C * (C - 1) / 2; if (cv->ecap < 1) cv->ecap = 1;
   cv->edges = (uint32_t*)take(nteams * (size_t)cv->ecap * 4);
   cv->grid = GridDev{}; cv->grid_zero_bytes = 0;
+  cv->mk_cidx = nullptr; cv->mk_ent_c = cv->mk_ent_r = nullptr; cv->mk_start_c = cv->mk_start_r = nullptr; cv->mk_pend1 = nullptr;
   if (recq == RotGeom::RECQ && nseg == 1 && n >= kGridMinN) {
     const uint32_t M = grid_slots(n);
     cv->grid.mask = M - 1;
@@ -518,6 +522,10 @@ static int carve(void* base, int64_t n, int64_t nseg, int recq, int C, Carve* cv
     cv->grid.kept_words = nn / 64 + 2;
     cv->grid.kept_bits = (u64*)take(cv->grid.kept_words * 8);
     cv->grid.slab_plan = (SlabPlan*)take(sizeof(SlabPlan));
+    cv->mk_cidx = (uint32_t*)take((size_t)kMkCapMax * 4);
+    cv->mk_ent_c = (float4*)take((size_t)kMkCapMax * 16); cv->mk_ent_r = (float4*)take((size_t)kMkCapMax * 16);
+    cv->mk_start_c = (uint16_t*)take((size_t)(kMkSlots + 8) * 2); cv->mk_start_r = (uint16_t*)take((size_t)(kMkSlots + 8) * 2);
+    cv->mk_pend1 = (uint2*)take((size_t)kMkPend1 * 8);
   }
   cv->total = off;
   return OBB_OK;
@@ -537,10 +545,10 @@ constexpr size_t kPersistLdsMax = 159 * 1024;   // of the 160 KB per CU: exactly
 template <class G, bool GRID>
 static int launch_persist(const NmsArgs& a, unsigned nb, hipStream_t st) {   // nb <= number of CUs (nms_grid); static teams and plans are made for that grid
   static OncePerDevice attr;
-  if (attr.need()) {
+  if (const int attr_dev = attr.need(); attr_dev != OncePerDevice::kDone) {
     if (hipFuncSetAttribute((const void*)k_nms_persist<G, GRID>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPersistLdsMax) != hipSuccess)
       return OBB_ERR_LAUNCH;
-    attr.mark();
+    attr.mark(attr_dev);
   }
   // every workgroup of the launch must be resident at once (team barriers): the grid is bounded by what the occupancy
   // calculation gives for this instantiation with its largest LDS footprint -- asked once, not assumed
@@ -632,6 +640,55 @@ static int nms_steps(int kind, NmsArgs& a, const Carve& cv, int64_t nseg, int64_
   return a.gmeta != nullptr ? launch_persist<RotGeom, true>(a, (unsigned)nb, st) : launch_persist<RotGeom, false>(a, (unsigned)nb, st);
 }
 
+// ---------------------------------------------------------------- the phase-kernel path of a long single list (nms_mk.h)
+// Steps are enqueued without knowing how many the data needs (stream-ordered: nothing is read back).  Every kernel of a step
+// returns at once when the control block says the call is complete, and whatever the enqueued steps leave undone is finished by
+// the one-workgroup tail kernel -- correct, slow, and rare: the device records the number of steps a call needed in a pinned word
+// of the calling thread (one per size class), and the thread's next call of that size enqueues that many + 1.
+constexpr int64_t kMkMinN = 16384;
+static int mk_enabled() { const char* e = getenv("OBB_NMS_MK"); return e ? atoi(e) : 1; }   // (read per call: tests switch between the two paths in one process)
+static int* mk_hint_slot(int64_t n) {
+  static thread_local int* base = nullptr;
+  if (!base) {
+    void* p = nullptr;
+    if (hipHostMalloc(&p, 64 * sizeof(int), hipHostMallocPortable) != hipSuccess) return nullptr;
+    base = (int*)p;
+    for (int i = 0; i < 64; i++) base[i] = -1;
+  }
+  int b = 0;
+  while ((n >> b) > 1 && b < 63) b++;
+  return base + b;
+}
+static int mk_steps(MkArgs& a, hipStream_t st) {
+  static OncePerDevice attr;
+  const size_t lds_tail = sizeof(MkLdsProbe<false, kMkWaves>) > kMkSerialLds ? sizeof(MkLdsProbe<false, kMkWaves>) : kMkSerialLds;
+  static_assert(sizeof(MkLdsSelect) <= kMkSerialLds && sizeof(MkLdsDecideWave) * kMkWaves <= kMkSerialLds, "serial-phase LDS");
+  if (const int attr_dev = attr.need(); attr_dev != OncePerDevice::kDone) {
+    if (hipFuncSetAttribute((const void*)k_mk_select, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMkSerialLds) != hipSuccess ||
+        hipFuncSetAttribute((const void*)k_mk_decide<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMkSerialLds) != hipSuccess ||
+        hipFuncSetAttribute((const void*)k_mk_decide<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMkSerialLds) != hipSuccess ||
+        hipFuncSetAttribute((const void*)k_mk_tail, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_tail) != hipSuccess)
+      return OBB_ERR_LAUNCH;
+    attr.mark(attr_dev);
+  }
+  static const int fixed_steps = [] { const char* e = getenv("OBB_NMS_MK_STEPS"); return e ? atoi(e) : 0; }();   // (measurement aid)
+  int steps = 7;
+  if (a.hint_host) { const int h = *(volatile int*)a.hint_host; if (h >= 0) steps = h + 1; }
+  if (fixed_steps > 0) steps = fixed_steps;
+  if (steps > 64) steps = 64;
+  const unsigned cus = (unsigned)hw_cu_count();
+  const unsigned gp = 5 * cus;
+  k_mk_select<<<1, kMkThreads, kMkSerialLds, st>>>(a);
+  for (int s = 0; s < steps; s++) {
+    k_mk_probe<false><<<gp, kMkProbeThreads, 0, st>>>(a);
+    k_mk_decide<false><<<cus, kMkThreads, kMkSerialLds, st>>>(a);      // ... + resolve in its last workgroup
+    k_mk_probe<true><<<gp, kMkProbeThreads, 0, st>>>(a);
+    k_mk_decide<true><<<cus, kMkThreads, kMkSerialLds, st>>>(a);       // ... + the next select in its last workgroup
+  }
+  k_mk_tail<<<1, kMkThreads, lds_tail, st>>>(a);
+  return hipGetLastError() == hipSuccess ? OBB_OK : OBB_ERR_LAUNCH;
+}
+
 // One list sorted by descending score, ties by ascending index (nms_rotated_cuda.cu:81-82 leaves the tie order to an
 // unstable sort; this is the documented rule here): sorted keys in cv.keys_b, order in cv.vals_b.  Up to kPsMaxN elements:
 // three launches (psrs_sort.h); longer lists: key kernel + LSD radix sort over the four score bytes (segsort.h).
@@ -685,13 +742,16 @@ static int run_nms(int kind, const float* boxes, int stride, const float* scores
   static const int no_grid = obb_dev_switch("OBB_NMS_NO_GRID", 0) != 0;          // A/B switch (development builds)
   const bool use_grid = !no_grid && kind == 0 && cv.grid.meta != nullptr && thr >= 0.f && n < (1ll << 24);
   static const int no_slabs = obb_dev_switch("OBB_NMS_NO_SLABS", 0) != 0;        // A/B switch (development builds)
-  const bool use_slabs = use_grid && !no_slabs && max_keep <= 0;   // (a limit on the kept boxes keeps the call one list: the windows are per list)
+  // long lists without a limit on the kept boxes: the phase-kernel path (nms_mk.h) -- no index of all boxes, no slab decomposition
+  const bool use_mk = use_grid && cv.mk_cidx != nullptr && n >= kMkMinN && max_keep <= 0 && mk_enabled() != 0;
+  const bool use_slabs = use_grid && !use_mk && !no_slabs && max_keep <= 0;   // (a limit on the kept boxes keeps the call one list: the windows are per list)
   {
     ProfScope ps(PROF_NMS_SORT, st);
     LocalExtras x{};
     x.seg_begin = cv.seg_begin; x.seg_end = cv.seg_end; x.keep_cnt = cv.keep_cnt;
     x.bar16 = reinterpret_cast<uint4*>(cv.bar); x.n_bar16 = (long long)(cv.bar_bytes / 16);
-    x.grid16 = reinterpret_cast<uint4*>(cv.grid.meta); x.n_grid16 = use_grid ? (long long)(cv.grid_zero_bytes / 16) : 0ll;
+    x.grid16 = reinterpret_cast<uint4*>(cv.grid.meta); x.n_grid16 = (use_grid && !use_mk) ? (long long)(cv.grid_zero_bytes / 16) : 0ll;
+    if (use_mk) x.n_bar16 = 64;   // the control block and its two counters: the first KB of the barrier block (no team barriers on this path)
     x.bbpart = (use_grid && kind == 0) ? cv.grid.bbpart : nullptr;
     rc = sort_single_list(scores, score_stride, kind == 0 ? boxes : nullptr, kind == 0 ? drop_small : 0, n, cv, x, &cv.grid.nparts, st);
     if (rc) return rc;
@@ -702,6 +762,27 @@ static int run_nms(int kind, const float* boxes, int stride, const float* scores
     if (kind == 0) k_prep_rot<<<gb, T, 0, st>>>(boxes, cv.vals_b, drop_small, (int)n, cv.rec, cv.alive, cv.grid.bbpart, cv.grid.nparts,
                                                 use_slabs ? cv.grid.slab_cover : nullptr, cv.grid.slab_flag);
     else k_prep_quad<<<gb, T, 0, st>>>(boxes, stride, cv.vals_b, (int)n, thr, quad_skip(), cv.rec, cv.alive);
+  }
+
+  if (use_mk) {
+    MkArgs m{};
+    m.rec = cv.rec; m.order = cv.vals_b; m.alive = cv.alive; m.n = (int)n;
+    m.ctl = reinterpret_cast<MkCtl*>(cv.bar);
+    m.cidx = cv.mk_cidx; m.ent_c = cv.mk_ent_c; m.start_c = cv.mk_start_c; m.ent_r = cv.mk_ent_r; m.start_r = cv.mk_start_r;
+    static_assert(sizeof(MkCtl) <= 256, "the control block shares the first KB of the barrier block with its counters");
+    m.edges = cv.edges; m.nedges = cv.bar + 64; m.ecap = cv.ecap;
+    m.rows = cv.rows; m.nrows = cv.bar + 128; m.keep_cnt = cv.keep_cnt; m.keep_out = keep_out;
+    m.bbpart = cv.grid.bbpart; m.nparts = cv.grid.nparts;
+    m.capmax = C < kMkCapMax ? C : kMkCapMax; m.cap_first = cap_first();
+    m.thr = thr;
+    m.pend1 = cv.mk_pend1; m.cap1 = kMkPend1; m.num_keep = num_keep;
+    m.hint_host = mk_hint_slot(n);
+    {
+      ProfScope ps(PROF_NMS_STEPS, st);
+      rc = mk_steps(m, st);
+      if (rc) return rc;
+    }
+    return OBB_OK;   // (the kernel that completes the call writes *num_keep: no finalize launch)
   }
 
   NmsArgs a{};

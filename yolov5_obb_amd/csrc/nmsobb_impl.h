@@ -1351,10 +1351,10 @@ static int run_nms_obb(const void* pred, const void* objcol, int dtype, int64_t 
     ProfScope ps(PROF_SEGSORT, st);
     static OncePerDevice attr;
     const size_t lds = (size_t)kSortLdsMax * 12;
-    if (attr.need()) {
+    if (const int attr_dev = attr.need(); attr_dev != OncePerDevice::kDone) {
       if (hipFuncSetAttribute((const void*)k_sort_prep_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return OBB_ERR_LAUNCH;
-      attr.mark();
+      attr.mark(attr_dev);
     }
     const int parts = (class_ok && ncs >= 8) ? 4 : 1;           // class-segment images: four workgroups each take every fourth class
     k_sort_prep_lds<<<(unsigned)(bs * parts) + (plan_nb > 0 ? 1u : 0u), 1024, lds, st>>>(cv.cand, cv.keys_a, cv.vals_a, cv.keys_b, cv.vals_b, cv.cnt, cv.tiny, (int)bs, cap_img,
@@ -1429,11 +1429,11 @@ static int run_nms_obb(const void* pred, const void* objcol, int dtype, int64_t 
     ProfScope ps(PROF_STEPS, st);
     static OncePerDevice attr;
     const size_t lds = small_lds_bytes<RotGeom>();
-    if (attr.need()) {
+    if (const int attr_dev = attr.need(); attr_dev != OncePerDevice::kDone) {
       if (hipFuncSetAttribute((const void*)k_nms_small<RotGeom, SmallNoTail>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
           hipFuncSetAttribute((const void*)k_nms_small<RotGeom, SmallGather>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return OBB_ERR_LAUNCH;
-      attr.mark();
+      attr.mark(attr_dev);
     }
     SmallArgs sa{};
     sa.rec = nv.rec; sa.alive = nv.alive; sa.seg_begin = nv.seg_begin; sa.seg_end = nv.seg_end; sa.keep_cnt = nv.keep_cnt;

@@ -317,9 +317,9 @@ static inline void ps_carve_scratch(void* scratch, PsBuf* b) {
 // launches 2 and 3 (the caller has launched its k_ps_local_* flavour over `runs` workgroups)
 static int ps_finish(const PsBuf& b, int runs, hipStream_t st) {
   static OncePerDevice attr;
-  if (attr.need()) {
+  if (const int attr_dev = attr.need(); attr_dev != OncePerDevice::kDone) {
     if (hipFuncSetAttribute((const void*)k_ps_bucket, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPsBucketLds) != hipSuccess) return OBB_ERR_LAUNCH;
-    attr.mark();
+    attr.mark(attr_dev);
   }
   if (runs > 1) k_ps_split<<<(unsigned)runs, kPsRun, 0, st>>>(b);
   k_ps_bucket<<<(unsigned)runs, kPsRun, kPsBucketLds, st>>>(b);
