@@ -17,7 +17,7 @@ from yolov5_obb_amd import nms_rotated_ext  # noqa: E402
 
 
 def run(d, s, thr, mk):
-    os.environ["OBB_NMS_MK"] = "1" if mk else "0"
+    os.environ["OBB_NMS_MK"] = str(int(mk))          # 0: persistent kernel, 1: phase kernels, 2: the library's own choice (feedback)
     return nms_rotated_ext.nms_rotated(d, s, thr)
 
 
@@ -91,19 +91,23 @@ def main():
     bad = 0
     for name, d, s, thr in cases(quick):
         dd, ss = d.to(dev), s.to(dev)
-        ref = run(dd, ss, thr, False).cpu().numpy()
+        ref = run(dd, ss, thr, 0).cpu().numpy()
         ok = True
         for rep in range(3):
-            got = run(dd, ss, thr, True).cpu().numpy()
+            got = run(dd, ss, thr, 1).cpu().numpy()
             if not np.array_equal(got, ref):
                 ok = False
                 common = int((got[: min(len(got), len(ref))] == ref[: min(len(got), len(ref))]).sum())
                 first = int(np.argmax(got[: min(len(got), len(ref))] != ref[: min(len(got), len(ref))])) if common < min(len(got), len(ref)) else -1
                 print(f"  MISMATCH {name} rep {rep}: kept {len(got)} vs {len(ref)}, first difference at {first}", flush=True)
         bad += 0 if ok else 1
-        t_old = timed(dd, ss, thr, False)
-        t_new = timed(dd, ss, thr, True)
-        print(f"{'ok ' if ok else 'BAD'} {name:28s} n {len(d):6d} kept {len(ref):6d}  persist {t_old[0]:7.3f} ms (min {t_old[1]:.3f})   phase kernels {t_new[0]:7.3f} ms (min {t_new[1]:.3f})",
+        t_old = timed(dd, ss, thr, 0)
+        t_new = timed(dd, ss, thr, 1)
+        for _ in range(3):
+            got = run(dd, ss, thr, 2).cpu().numpy()
+            ok = ok and np.array_equal(got, ref)
+        t_auto = timed(dd, ss, thr, 2)
+        print(f"{'ok ' if ok else 'BAD'} {name:28s} n {len(d):6d} kept {len(ref):6d}  persist {t_old[0]:7.3f} ms   phase kernels {t_new[0]:7.3f} ms   auto {t_auto[0]:7.3f} ms",
               flush=True)
     print("mismatching cases:", bad)
     return 1 if bad else 0

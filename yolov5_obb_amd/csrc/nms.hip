@@ -85,6 +85,7 @@ struct LocalExtras {
   int *seg_begin, *seg_end, *keep_cnt;
   uint4* bar16; long long n_bar16;
   uint4* grid16; long long n_grid16;
+  uint4* mk16; long long n_mk16;   // control block of the phase-kernel path (nms_mk.h)
   int* bbpart;                 // [runs][kBbInts] or NULL
 };
 __device__ __forceinline__ void local_extras(const LocalExtras& x, const float* __restrict__ dets5, int drop_small, int n, int i, bool in_range,
@@ -92,8 +93,10 @@ __device__ __forceinline__ void local_extras(const LocalExtras& x, const float* 
   if (i == 0) { x.seg_begin[0] = 0; x.seg_end[0] = n; x.keep_cnt[0] = 0; }
   for (long long k = i; k < x.n_bar16; k += (long long)gridDim.x * blockDim.x) x.bar16[k] = make_uint4(0u, 0u, 0u, 0u);
   for (long long k = i; k < x.n_grid16; k += (long long)gridDim.x * blockDim.x) x.grid16[k] = make_uint4(0u, 0u, 0u, 0u);   // GridMeta + slot counters
+  for (long long k = i; k < x.n_mk16; k += (long long)gridDim.x * blockDim.x) x.mk16[k] = make_uint4(0u, 0u, 0u, 0u);
   int bx0 = 0x7fffffff, by0 = 0x7fffffff, bx1 = (int)0x80000000, by1 = (int)0x80000000;
   int d2 = 0;                                          // largest w^2 + h^2 of the block, as float bits (>= 0: ordered like ints)
+  float rsum = 0.f; int rcnt = 0;
   if (in_range) {
     bool ok = true;
     float w = 0.f, h = 0.f;
@@ -109,16 +112,24 @@ __device__ __forceinline__ void local_extras(const LocalExtras& x, const float* 
       const float cx = dets5[(size_t)i * 5], cy = dets5[(size_t)i * 5 + 1];
       if ((cx - cx == 0.f) && (cy - cy == 0.f)) { bx0 = bx1 = grid_f2o(cx); by0 = by1 = grid_f2o(cy); }
       const float q = w * w + h * h;
-      if (q - q == 0.f) d2 = __float_as_int(q);
+      if (q - q == 0.f) { d2 = __float_as_int(q); rsum = sqrtf(q); rcnt = 1; }
     }
   }
   if (x.bbpart != nullptr) {
     int d2b = d2, dummy = d2;
     block_minmax4(bx0, by0, bx1, by1, s_red);
     { int lo0 = 0x7fffffff, lo1 = 0x7fffffff; block_minmax4(lo0, lo1, d2b, dummy, s_red); }
+    // (nms_mk.h: the mean diagonal of the finite boxes, for the radius limit of its tables -- a heuristic, any order of summation will do)
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { rsum += __shfl_xor(rsum, d); rcnt += __shfl_xor(rcnt, d); }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) { s_red[threadIdx.x >> 6][0] = __float_as_int(rsum); s_red[threadIdx.x >> 6][1] = rcnt; }
+    __syncthreads();
     if (threadIdx.x == 0) {
+      float rs = 0.f; int rc = 0;
+      for (int k = 0; k < (int)((blockDim.x + 63) >> 6); k++) { rs += __int_as_float(s_red[k][0]); rc += s_red[k][1]; }
       int* o = x.bbpart + (size_t)blockIdx.x * kBbInts;
-      o[0] = bx0; o[1] = by0; o[2] = bx1; o[3] = by1; o[4] = d2b; o[5] = o[6] = o[7] = 0;
+      o[0] = bx0; o[1] = by0; o[2] = bx1; o[3] = by1; o[4] = d2b; o[5] = __float_as_int(rs); o[6] = rc; o[7] = 0;
     }
   }
 }
@@ -375,14 +386,21 @@ __global__ void k_seg_from_offsets(const int32_t* __restrict__ seg_off, int nseg
 }
 
 // num_keep[g] = -1 when the persistent kernel gave up on a barrier (abort flag): the host layer raises
+// feedback != NULL (a long single list of rotated boxes): what the calling thread's NEXT call of this size class chooses its path
+// by (mk_choose below) -- the number of kept boxes and whether the list fell apart into independent slabs.
 __global__ void k_finalize(const int* __restrict__ keep_cnt, const int* __restrict__ seg_begin, int nseg, long long max_keep,
-                           const int* __restrict__ abort_flag, int64_t* __restrict__ num_keep, int64_t* __restrict__ seg_begin_out) {
+                           const int* __restrict__ abort_flag, int64_t* __restrict__ num_keep, int64_t* __restrict__ seg_begin_out,
+                           int* feedback = nullptr, const SlabPlan* slab_plan = nullptr) {
   int g = blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= nseg) return;
   if (seg_begin_out) seg_begin_out[g] = seg_begin[g];
   long long c = keep_cnt[g];
   if (max_keep > 0 && c > max_keep) c = max_keep;
   num_keep[g] = (abort_flag && *abort_flag) ? -1 : c;
+  if (feedback != nullptr && g == 0) {
+    __hip_atomic_store(feedback + 1, (int)c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(feedback + 2, (slab_plan != nullptr && slab_plan->mode == 1) ? 1 : 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
 }
 
 // ---------------------------------------------------------------- workspace
@@ -423,7 +441,7 @@ struct Carve {
   long long ecap;
   GridDev grid;                        // spatial index (rotated boxes, single list); grid.meta == NULL: not carved
   // the phase-kernel path of a long single list (nms_mk.h); mk_cidx == NULL: not carved.  Its control block is the head of `bar`.
-  uint32_t* mk_cidx; float4 *mk_ent_c, *mk_ent_r; uint16_t *mk_start_c, *mk_start_r; uint2* mk_pend1;
+  int* mk_ctl; uint32_t* mk_cidx; float4* mk_ent; uint16_t* mk_start; u64* mk_kbits; uint4* mk_pend1;   // mk_ctl: 1 KB (control block, edge counter at int 64)
   size_t grid_zero_bytes;              // GridMeta + slot counters: one contiguous block, zeroed before every build
   size_t total;
 };
@@ -491,7 +509,7 @@ static int carve(void* base, int64_t n, int64_t nseg, int recq, int C, Carve* cv
   cv->ecap = (long long)C * (C - 1) / 2; if (cv->ecap < 1) cv->ecap = 1;
   cv->edges = (uint32_t*)take(nteams * (size_t)cv->ecap * 4);
   cv->grid = GridDev{}; cv->grid_zero_bytes = 0;
-  cv->mk_cidx = nullptr; cv->mk_ent_c = cv->mk_ent_r = nullptr; cv->mk_start_c = cv->mk_start_r = nullptr; cv->mk_pend1 = nullptr;
+  cv->mk_ctl = nullptr; cv->mk_cidx = nullptr; cv->mk_ent = nullptr; cv->mk_start = nullptr; cv->mk_kbits = nullptr; cv->mk_pend1 = nullptr;
   if (recq == RotGeom::RECQ && nseg == 1 && n >= kGridMinN) {
     const uint32_t M = grid_slots(n);
     cv->grid.mask = M - 1;
@@ -522,10 +540,12 @@ static int carve(void* base, int64_t n, int64_t nseg, int recq, int C, Carve* cv
     cv->grid.kept_words = nn / 64 + 2;
     cv->grid.kept_bits = (u64*)take(cv->grid.kept_words * 8);
     cv->grid.slab_plan = (SlabPlan*)take(sizeof(SlabPlan));
+    cv->mk_ctl = (int*)take(1024);
     cv->mk_cidx = (uint32_t*)take((size_t)kMkCapMax * 4);
-    cv->mk_ent_c = (float4*)take((size_t)kMkCapMax * 16); cv->mk_ent_r = (float4*)take((size_t)kMkCapMax * 16);
-    cv->mk_start_c = (uint16_t*)take((size_t)(kMkSlots + 8) * 2); cv->mk_start_r = (uint16_t*)take((size_t)(kMkSlots + 8) * 2);
-    cv->mk_pend1 = (uint2*)take((size_t)kMkPend1 * 8);
+    cv->mk_ent = (float4*)take((size_t)kMkCapMax * 16);
+    cv->mk_start = (uint16_t*)take((size_t)(kMkSlots + 8) * 2);
+    cv->mk_kbits = (u64*)take((size_t)(kMkCapMax / 64) * 8);
+    cv->mk_pend1 = (uint4*)take((size_t)kMkPend1 * 16);
   }
   cv->total = off;
   return OBB_OK;
@@ -598,7 +618,7 @@ static int nms_steps(int kind, NmsArgs& a, const Carve& cv, int64_t nseg, int64_
   { static const int lpt = obb_dev_switch("OBB_NMS_LPT", 1) & 1; a.lpt = lpt; }      // A/B switch (development builds): rows of a chunk largest first
   static const int phase_prof = [] { const char* e = getenv("OBB_NMS_PHASE_PROF"); return (e && atoi(e)) ? 1 : 0; }();
   a.prof = nullptr;
-  if (phase_prof) {   // development aid: print the previous call's phase times (synchronises!)
+  if (phase_prof && a.resume == nullptr) {   // development aid: print the previous call's phase times (synchronises!)
     u64 h[56];
     if (hipMemcpy(h, cv.prof, sizeof h, hipMemcpyDeviceToHost) == hipSuccess && h[6] > 0 && h[6] < (1ull << 40)) {
       fprintf(stderr, "[nms phases, wg0, us] select %.1f pairs %.1f wait-resolve %.1f cross %.1f barrier %.1f steps %llu | resolve (any wg) %.1f rounds %llu [first round %.1f other rounds %.1f output %.1f]\n",
@@ -643,39 +663,66 @@ static int nms_steps(int kind, NmsArgs& a, const Carve& cv, int64_t nseg, int64_
 // ---------------------------------------------------------------- the phase-kernel path of a long single list (nms_mk.h)
 // Steps are enqueued without knowing how many the data needs (stream-ordered: nothing is read back).  Every kernel of a step
 // returns at once when the control block says the call is complete, and whatever the enqueued steps leave undone is finished by
-// the one-workgroup tail kernel -- correct, slow, and rare: the device records the number of steps a call needed in a pinned word
-// of the calling thread (one per size class), and the thread's next call of that size enqueues that many + 1.
+// the persistent kernel launched behind them (NmsResume) -- which returns at once when nothing is left.  The device records the
+// number of steps a call needed in a pinned word of the calling thread (one per size class); the thread's next call of that size
+// enqueues that many.
 constexpr int64_t kMkMinN = 16384;
-static int mk_enabled() { const char* e = getenv("OBB_NMS_MK"); return e ? atoi(e) : 1; }   // (read per call: tests switch between the two paths in one process)
-static int* mk_hint_slot(int64_t n) {
+constexpr int kMkMinKept = 1536;   // below this many kept boxes the persistent kernel's two or three steps are the shorter chain
+static int mk_enabled() { const char* e = getenv("OBB_NMS_MK"); return e ? atoi(e) : 2; }   // 0: never, 1: always, 2: by feedback (read per call: tests switch paths in one process)
+// Per calling thread and size class (floor(log2 n)): four pinned words the DEVICE writes when a call completes -- [0] the steps
+// the phase-kernel path needed, [1] the boxes the call kept, [2] whether the persistent kernel found independent slabs -- and
+// the host reads, without synchronising, when the thread's next call of that size is set up.  Nothing but the choice of path and
+// the number of enqueued steps depends on them; the result of a call does not.
+struct MkFeedback { int* words; unsigned calls; };
+static MkFeedback* mk_feedback(int64_t n) {
   static thread_local int* base = nullptr;
+  static thread_local MkFeedback fb[64];
   if (!base) {
     void* p = nullptr;
-    if (hipHostMalloc(&p, 64 * sizeof(int), hipHostMallocPortable) != hipSuccess) return nullptr;
+    if (hipHostMalloc(&p, 64 * 4 * sizeof(int), hipHostMallocPortable) != hipSuccess) return nullptr;
     base = (int*)p;
-    for (int i = 0; i < 64; i++) base[i] = -1;
+    for (int i = 0; i < 64 * 4; i++) base[i] = -1;
+    for (int i = 0; i < 64; i++) { fb[i].words = base + 4 * i; fb[i].calls = 0; }
   }
   int b = 0;
   while ((n >> b) > 1 && b < 63) b++;
-  return base + b;
+  return &fb[b];
+}
+// Which path the next call takes.  The phase kernels win where a chunk keeps many rows (thousands of objects, sparse data); the
+// persistent kernel wins where two or three steps with a few hundred kept rows each do it, and where the list falls apart into
+// independent slabs (class offsets: one team per slab steps concurrently).  Both report what the rule needs; the first call of a
+// size class, and every 64th after it, takes the persistent kernel (it is the one that can see slabs).
+static bool mk_choose(MkFeedback* f) {
+  const int mode = mk_enabled();
+  if (mode == 0) return false;
+  if (mode == 1 || f == nullptr) return mode == 1;
+  const unsigned k = f->calls++;
+  const int kept = *(volatile int*)(f->words + 1), slab = *(volatile int*)(f->words + 2);
+  if (kept < 0 || (k & 63u) == 0u) return false;
+  return slab != 1 && kept >= kMkMinKept;
 }
 static int mk_steps(MkArgs& a, hipStream_t st) {
   static OncePerDevice attr;
-  const size_t lds_tail = sizeof(MkLdsProbe<false, kMkWaves>) > kMkSerialLds ? sizeof(MkLdsProbe<false, kMkWaves>) : kMkSerialLds;
-  static_assert(sizeof(MkLdsSelect) <= kMkSerialLds && sizeof(MkLdsDecideWave) * kMkWaves <= kMkSerialLds, "serial-phase LDS");
+  static_assert(sizeof(MkLdsSelect) <= kMkSerialLds && (size_t)RotGeom::SCR * 64 * 4 * kMkWaves <= kMkSerialLds, "serial-phase LDS");
   if (const int attr_dev = attr.need(); attr_dev != OncePerDevice::kDone) {
     if (hipFuncSetAttribute((const void*)k_mk_select, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMkSerialLds) != hipSuccess ||
         hipFuncSetAttribute((const void*)k_mk_decide<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMkSerialLds) != hipSuccess ||
-        hipFuncSetAttribute((const void*)k_mk_decide<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMkSerialLds) != hipSuccess ||
-        hipFuncSetAttribute((const void*)k_mk_tail, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_tail) != hipSuccess)
+        hipFuncSetAttribute((const void*)k_mk_decide<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMkSerialLds) != hipSuccess)
       return OBB_ERR_LAUNCH;
     attr.mark(attr_dev);
   }
   static const int fixed_steps = [] { const char* e = getenv("OBB_NMS_MK_STEPS"); return e ? atoi(e) : 0; }();   // (measurement aid)
-  int steps = 7;
-  if (a.hint_host) { const int h = *(volatile int*)a.hint_host; if (h >= 0) steps = h + 1; }
+  // (-2: the previous call of this size class was finished by the persistent kernel behind its steps: twice as many this time)
+  int steps = 4;
+  if (a.hint_host) {
+    const int h = *(volatile int*)a.hint_host;
+    if (h >= 0) steps = h;
+    else if (h == -2) { const int last = *(volatile int*)(a.hint_host + 3); steps = last > 0 ? 2 * last : 8; }
+  }
   if (fixed_steps > 0) steps = fixed_steps;
-  if (steps > 64) steps = 64;
+  if (steps > 32) steps = 32;
+  if (steps < 1) steps = 1;
+  if (a.hint_host) { *(volatile int*)(a.hint_host + 3) = steps; }
   const unsigned cus = (unsigned)hw_cu_count();
   const unsigned gp = 5 * cus;
   k_mk_select<<<1, kMkThreads, kMkSerialLds, st>>>(a);
@@ -685,7 +732,6 @@ static int mk_steps(MkArgs& a, hipStream_t st) {
     k_mk_probe<true><<<gp, kMkProbeThreads, 0, st>>>(a);
     k_mk_decide<true><<<cus, kMkThreads, kMkSerialLds, st>>>(a);       // ... + the next select in its last workgroup
   }
-  k_mk_tail<<<1, kMkThreads, lds_tail, st>>>(a);
   return hipGetLastError() == hipSuccess ? OBB_OK : OBB_ERR_LAUNCH;
 }
 
@@ -743,15 +789,16 @@ static int run_nms(int kind, const float* boxes, int stride, const float* scores
   const bool use_grid = !no_grid && kind == 0 && cv.grid.meta != nullptr && thr >= 0.f && n < (1ll << 24);
   static const int no_slabs = obb_dev_switch("OBB_NMS_NO_SLABS", 0) != 0;        // A/B switch (development builds)
   // long lists without a limit on the kept boxes: the phase-kernel path (nms_mk.h) -- no index of all boxes, no slab decomposition
-  const bool use_mk = use_grid && cv.mk_cidx != nullptr && n >= kMkMinN && max_keep <= 0 && mk_enabled() != 0;
+  MkFeedback* const fbk = (use_grid && cv.mk_cidx != nullptr && n >= kMkMinN && max_keep <= 0) ? mk_feedback(n) : nullptr;
+  const bool use_mk = use_grid && cv.mk_cidx != nullptr && n >= kMkMinN && max_keep <= 0 && mk_choose(fbk);
   const bool use_slabs = use_grid && !use_mk && !no_slabs && max_keep <= 0;   // (a limit on the kept boxes keeps the call one list: the windows are per list)
   {
     ProfScope ps(PROF_NMS_SORT, st);
     LocalExtras x{};
     x.seg_begin = cv.seg_begin; x.seg_end = cv.seg_end; x.keep_cnt = cv.keep_cnt;
     x.bar16 = reinterpret_cast<uint4*>(cv.bar); x.n_bar16 = (long long)(cv.bar_bytes / 16);
-    x.grid16 = reinterpret_cast<uint4*>(cv.grid.meta); x.n_grid16 = (use_grid && !use_mk) ? (long long)(cv.grid_zero_bytes / 16) : 0ll;
-    if (use_mk) x.n_bar16 = 64;   // the control block and its two counters: the first KB of the barrier block (no team barriers on this path)
+    x.grid16 = reinterpret_cast<uint4*>(cv.grid.meta); x.n_grid16 = use_grid ? (long long)(cv.grid_zero_bytes / 16) : 0ll;
+    x.mk16 = reinterpret_cast<uint4*>(cv.mk_ctl); x.n_mk16 = use_mk ? 64 : 0;
     x.bbpart = (use_grid && kind == 0) ? cv.grid.bbpart : nullptr;
     rc = sort_single_list(scores, score_stride, kind == 0 ? boxes : nullptr, kind == 0 ? drop_small : 0, n, cv, x, &cv.grid.nparts, st);
     if (rc) return rc;
@@ -764,25 +811,34 @@ static int run_nms(int kind, const float* boxes, int stride, const float* scores
     else k_prep_quad<<<gb, T, 0, st>>>(boxes, stride, cv.vals_b, (int)n, thr, quad_skip(), cv.rec, cv.alive);
   }
 
+  MkArgs m{};
   if (use_mk) {
-    MkArgs m{};
+    static_assert(sizeof(MkCtl) <= 256, "the control block and its counters share one zeroed KB");
     m.rec = cv.rec; m.order = cv.vals_b; m.alive = cv.alive; m.n = (int)n;
-    m.ctl = reinterpret_cast<MkCtl*>(cv.bar);
-    m.cidx = cv.mk_cidx; m.ent_c = cv.mk_ent_c; m.start_c = cv.mk_start_c; m.ent_r = cv.mk_ent_r; m.start_r = cv.mk_start_r;
-    static_assert(sizeof(MkCtl) <= 256, "the control block shares the first KB of the barrier block with its counters");
-    m.edges = cv.edges; m.nedges = cv.bar + 64; m.ecap = cv.ecap;
-    m.rows = cv.rows; m.nrows = cv.bar + 128; m.keep_cnt = cv.keep_cnt; m.keep_out = keep_out;
+    m.ctl = reinterpret_cast<MkCtl*>(cv.mk_ctl);
+    m.cidx = cv.mk_cidx; m.ent = cv.mk_ent; m.start = cv.mk_start; m.kbits = cv.mk_kbits;
+    m.edges = cv.edges; m.nedges = cv.mk_ctl + 64; m.ecap = cv.ecap;
+    m.rows = cv.rows; m.nrows = cv.mk_ctl + 128; m.keep_cnt = cv.keep_cnt; m.keep_out = keep_out;
     m.bbpart = cv.grid.bbpart; m.nparts = cv.grid.nparts;
-    m.capmax = C < kMkCapMax ? C : kMkCapMax; m.cap_first = cap_first();
+    static const int mk_cap_first = [] { const char* e = getenv("OBB_NMS_MK_CHUNK"); const int v = e ? atoi(e) : 8192; return v < 64 ? 64 : (v > kMkCapMax ? kMkCapMax : v); }();   // (measurement aid)
+    m.capmax = kMkCapMax; m.cap_first = mk_cap_first;   // (this path is chosen for lists that keep thousands of boxes: a first chunk of 8192 holds a few boxes per object)
+    //   // (the edge list holds the worst case of kMkTile = C members; a larger chunk that outgrows it bails out)
+    static_assert(kMkTile == 8192, "cap_max(1)");
     m.thr = thr;
-    m.pend1 = cv.mk_pend1; m.cap1 = kMkPend1; m.num_keep = num_keep;
-    m.hint_host = mk_hint_slot(n);
-    {
-      ProfScope ps(PROF_NMS_STEPS, st);
-      rc = mk_steps(m, st);
-      if (rc) return rc;
+    m.pend1 = cv.mk_pend1; m.cap1 = kMkPend1; m.num_keep = nullptr;    // (k_finalize below writes the count)
+    m.hint_host = fbk ? fbk->words : nullptr;
+    static const int mk_prof = [] { const char* e = getenv("OBB_NMS_PHASE_PROF"); return (e && atoi(e)) ? 2 : 0; }();
+    if (mk_prof) {   // development aid: print the previous call's serial-phase times (synchronises!)
+      u64 h[56];
+      if (hipMemcpy(h, cv.prof, sizeof h, hipMemcpyDeviceToHost) == hipSuccess && h[37] > 0 && h[37] < (1ull << 20)) {
+        fprintf(stderr, "[mk phases, us, sums over %llu steps] pairs: decide+ticket %.1f (pending %llu) resolve %.1f [first round %.1f other rounds %.1f output %.1f; rounds %llu] | "
+                        "cross: decide+ticket %.1f (pending %llu) select %.1f chunk-table %.1f | edges %llu chunk members %llu kept %llu\n",
+                h[37], h[32] * 0.01, h[42], h[33] * 0.01, h[12] * 0.01, h[13] * 0.01, h[14] * 0.01, h[11], h[41] * 0.01, h[43], h[35] * 0.01, h[36] * 0.01, h[38], h[39], h[40]);
+        fprintf(stderr, "    chunk table: loads %.1f statistics %.1f counts %.1f scan %.1f scatter %.1f\n", h[44] * 0.01, h[45] * 0.01, h[46] * 0.01, h[47] * 0.01, h[48] * 0.01);
+      }
+      if (hipMemsetAsync(cv.prof, 0, 56 * 8, st) != hipSuccess) return OBB_ERR_LAUNCH;
+      m.prof = cv.prof;
     }
-    return OBB_OK;   // (the kernel that completes the call writes *num_keep: no finalize launch)
   }
 
   NmsArgs a{};
@@ -812,10 +868,16 @@ static int run_nms(int kind, const float* boxes, int stride, const float* scores
 
   {
     ProfScope ps(PROF_NMS_STEPS, st);
+    if (use_mk) {
+      rc = mk_steps(m, st);
+      if (rc) return rc;
+      a.resume = reinterpret_cast<const NmsResume*>(cv.mk_ctl);   // the persistent kernel behind them: returns at once when they completed the call
+    }
     rc = nms_steps(kind, a, cv, nseg, n, st, pre);
     if (rc) return rc;
   }
-  k_finalize<<<gseg, T, 0, st>>>(cv.keep_cnt, cv.seg_begin, (int)nseg, max_keep, cv.abort_flag, num_keep, nullptr);
+  k_finalize<<<gseg, T, 0, st>>>(cv.keep_cnt, cv.seg_begin, (int)nseg, max_keep, cv.abort_flag, num_keep, nullptr, fbk ? fbk->words : nullptr,
+                                 a.slab_plan);
   return hipGetLastError() == hipSuccess ? OBB_OK : OBB_ERR_LAUNCH;
 }
 

@@ -41,6 +41,17 @@ typedef unsigned long long u64;
 
 struct SlabPlan;
 
+// Where a single-list call stands when the persistent kernel is launched BEHIND the phase kernels of nms_mk.h (the head of their
+// control block): it returns at once when they completed the call, and otherwise carries on from their state -- the first step of a
+// call they handed over, the chunk they had selected, or the cross phase of a chunk whose rows are kept already.
+struct NmsResume {
+  int cur, kept, done, step;
+  int cn, cap, nrow, chunk_first;
+  float dmax2;
+  int stage;                 // 1: a chunk [chunk_first, cur) is selected but not resolved; 3: the rows of the last chunk are kept
+  int bail;                  // != 0 with stage 3: the cross phase of those rows is incomplete
+};
+
 struct NmsArgs {
   const float4* rec;         // [n][RECQ] AoS records in sorted order (read-only in this kernel)
   const uint32_t* order;     // sorted position -> original index (NULL: keep_out receives the sorted position itself)
@@ -97,6 +108,7 @@ struct NmsArgs {
   int slab_cap;               // > 0: upper limit of a slab team's chunk capacity
   int grow_sparse;            // chunk growth factor after a sparse chunk (<= 2: always double)
   int lpt;                    // 1: the resolver hands the kept rows of a chunk to the indexed cross phase LARGEST FIRST (nms_resolve)
+  const NmsResume* resume;    // optional (one list, no slabs): see NmsResume
 };
 
 // ---- cost model shared by the planner (k_plan_teams) and the workgroups that follow its plan
@@ -1936,6 +1948,7 @@ __global__ __launch_bounds__(kNmsThreads) __attribute__((amdgpu_waves_per_eu(1, 
   __shared__ int s_bb[kNmsWaves][4];
   const int tid = threadIdx.x, wv = tid >> 6;
   const int NB = gridDim.x;
+  if (a.resume != nullptr && a.resume->done != 0) return;     // (the phase kernels in front of this launch completed the call)
   // the extent of the data from the key kernel's per-workgroup partials (every workgroup reduces them itself)
   auto data_extent = [&]() -> GridPlan {
     int bx0 = 0x7fffffff, by0 = 0x7fffffff, bx1 = (int)0x80000000, by1 = (int)0x80000000;
@@ -2087,6 +2100,14 @@ __global__ __launch_bounds__(kNmsThreads) __attribute__((amdgpu_waves_per_eu(1, 
     // whose callers spill around the call): whoever needs one leaves a job, the head of the loop runs it.
     const uint32_t* jrows = nullptr;
     int jnr = 0, jc0 = 0, jc1 = 0;
+    if (a.resume != nullptr) {                            // carry on where the phase kernels stopped (every workgroup reads the same words)
+      const NmsResume& r = *a.resume;
+      kept = r.kept;
+      cur = (r.stage == 1) ? r.chunk_first : r.cur;
+      if (cur < sb) cur = sb;
+      if (r.cap > 0) cap = r.cap < a.capmax ? r.cap : a.capmax;
+      if (r.stage == 3 && r.bail != 0 && r.nrow > 0 && r.nrow <= kept && cur < wend) { jrows = a.rows + sb + (kept - r.nrow); jnr = r.nrow; jc0 = cur; jc1 = wend; }
+    }
     for (;;) {
       if (jnr > 0) {
         const u64 tcz = (a.prof && tid == 0) ? wall_clock64() : 0ull;
