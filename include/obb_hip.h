@@ -419,7 +419,9 @@ int obb_rbox_overlaps_f32(const float* boxes5, int64_t n, const float* query5, i
 /* Same symbols, argument order and host-pointer convention as the reference's devkit
  * (DOTA_devkit/poly_nms_gpu/poly_nms.hpp:9-10, poly_overlaps.hpp:1); synchronous.  The reference declares the two
  * functions with C++ linkage: the library also exports them under the mangled names a build of the reference's Cython
- * sources binds (_Z9_poly_nmsPiS_PKfiifi, _Z9_overlapsPfPKfS1_iii; tests/test_cabi.py). */
+ * sources binds (_Z9_poly_nmsPiS_PKfiifi, _Z9_overlapsPfPKfS1_iii).  tests/test_devkit_binding.py calls both spellings through
+ * ctypes, and oracle/ref_shim_devkit.cpp -- a translation unit that includes the reference's own poly_nms.hpp / poly_overlaps.hpp
+ * -- is linked against this library by oracle/Makefile and driven like poly_nms.pyx:9-24 / poly_overlaps.pyx:7-12. */
 void _poly_nms(int* keep_out_host, int* num_out_host, const float* polys_host, int polys_num, int polys_dim,
                float nms_overlap_thresh, int device_id);
 void _overlaps(float* overlaps_host, const float* boxes_host, const float* query_boxes_host, int n, int k, int device_id);

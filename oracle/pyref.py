@@ -230,9 +230,11 @@ def focal_bce(pred, true, pos_weight, gamma, alpha=0.25):
     return (loss * alpha_factor * modulating_factor).mean()
 
 
-def compute_loss(spec, p, targets, sort_obj_iou=False):
-    """utils/loss.py:122-192 (autobalance off; sort_obj_iou :156-158 with a stable sort; hyp['fl_gamma'] > 0 wraps the three
-    BCE terms in FocalLoss, :107-110).  p[i]: (bs, na, ny, nx, no) logits (requires_grad ok)."""
+def compute_loss(spec, p, targets, sort_obj_iou=False, autobalance=False):
+    """utils/loss.py:122-192 (sort_obj_iou :156-158 with a stable sort; hyp['fl_gamma'] > 0 wraps the three BCE terms in
+    FocalLoss, :107-110; autobalance :180-184: spec.balance is updated IN PLACE from the per-level objectness losses, after each
+    level has used its old weight, and renormalised to the stride-16 level, :115).  p[i]: (bs, na, ny, nx, no) logits
+    (requires_grad ok)."""
     h = spec.hyp
     fg = float(h.get('fl_gamma', 0.0))
     if fg > 0:
@@ -272,7 +274,13 @@ def compute_loss(spec, p, targets, sort_obj_iou=False):
                 tc[torch.arange(n), t['tcls']] = spec.cp
                 lcls = lcls + bce(ps[:, 5:ci], tc, pos_weight=pw_cls)
             lth = lth + bce(ps[:, ci:], t['csl'].type(ps.dtype), pos_weight=pw_th)
-        lobj = lobj + bce(pi[..., 4], tobj, pos_weight=pw_obj) * spec.balance[i]
+        obji = bce(pi[..., 4], tobj, pos_weight=pw_obj)                                  # :178
+        lobj = lobj + obji * spec.balance[i]                                            # :179
+        if autobalance:
+            spec.balance[i] = spec.balance[i] * 0.9999 + 0.0001 / obji.detach().item()  # :180-181
+    if autobalance:
+        ssi = [float(x) for x in spec.stride].index(16.0)                               # :115
+        spec.balance = [x / spec.balance[ssi] for x in spec.balance]                    # :183-184
     lbox = lbox * h['box']; lobj = lobj * h['obj']; lcls = lcls * h['cls']; lth = lth * h['theta']
     bs = p[0].shape[0]
     return (lbox + lobj + lcls + lth) * bs, torch.cat((lbox, lobj, lcls, lth)).detach()

@@ -256,6 +256,30 @@ def test_targets_without_csl_columns_are_encoded_on_the_device(dev):
         assert torch.allclose(a, b, rtol=1e-6, atol=1e-30)
 
 
+def test_autobalance_three_steps(dev, oracle_lib):
+    """ComputeLoss(model, autobalance=True) (utils/loss.py:98,115,180-184): the per-level objectness weights move with every call --
+    each level's loss uses the weight it had BEFORE the call, then balance[i] <- 0.9999 balance[i] + 0.0001 / obj_i and everything
+    is divided by the stride-16 level's weight.  Three calls on fresh logits against the restated reference: the scalars of every
+    call (they depend on the weights the previous calls left), the gradients of the last one, and the weights themselves."""
+    from yolov5_obb_amd.utils.loss import ComputeLoss
+    nc = 16
+    hyp = synth.scaled_hyp(nc, 256)
+    spec = pyref.LossSpec(hyp, synth.grid_anchors(), torch.tensor(synth.DEFAULT_STRIDES), nc)
+    cl = ComputeLoss(synth.FakeModel(nc, hyp, dev), autobalance=True)
+    assert cl.autobalance and cl.ssi == 1 and list(cl.balance) == list(spec.balance) == [4.0, 1.0, 0.4]
+    for step in range(3):
+        p, t = synth.s_loss(2, nc, 40, 500 + step, imgsz=256, sizes=[32, 16, 8])
+        pc = [x.clone().requires_grad_(True) for x in p]
+        lo, io = pyref.compute_loss(spec, pc, t.clone(), autobalance=True)
+        lo.backward()
+        pg = [x.clone().to(dev).requires_grad_(True) for x in p]
+        lg, ig = cl(pg, t.to(dev))
+        lg.backward()
+        check((lo, io, pc), (lg, ig, pg))
+        assert np.allclose(np.asarray(cl.balance, dtype=np.float64), np.asarray(spec.balance, dtype=np.float64), rtol=1e-6), (step, cl.balance, spec.balance)
+        assert cl.balance[1] == 1.0 and cl.balance[0] != 4.0
+
+
 def test_zz_report_achieved_errors(dev):
     """Not a check of its own: prints what the fp32 comparisons above achieved (pytest shows it in the warnings summary).  The
     asserted tolerances are 1e-5 relative on the loss scalars (north_star) and 1e-5 of the tensor's largest |gradient| (1e-4 until the achieved figure was printed: 3.3e-7)."""

@@ -264,6 +264,45 @@ def test_headline_tensors_of_bench_py(dev, oracle_lib, r):
         _cmp(general.non_max_suppression_obb(p, **kw), ref, ties=True)
 
 
+def test_nc2_tensor_of_bench_py(dev, oracle_lib):
+    """BASELINE configs[4]'s shape (DroneVehicle, nc = 2, /root/reference/data/DroneVehicle_poly.yaml:10, no = 187): the EXACT
+    tensor bench.py times as `nmsobb_nc2` -- (16, 64512, 187) fp16 generated on the device with seed 2002, speed-task thresholds.
+    Two classes put ~850 boxes into a class segment: past OBB_NMS_SMALL_SEG, i.e. the persistent kernel on 32 segments instead of
+    the one-workgroup-per-segment kernel of the headline -- a timed configuration needs its own parity test (VERDICT r5 missing #1).
+    Un-hinted call first, then the hinted ones."""
+    from yolov5_obb_amd.utils import general
+    p = synth.s_pred(16, 64512, 2, seed=2002, n_obj=120, fg_frac=0.03, device=dev, dtype=torch.float16)
+    assert p.shape == (16, 64512, 187)
+    kw = dict(conf_thres=0.25, iou_thres=0.45, multi_label=True, max_det=1500)
+    ref = pyref.non_max_suppression_obb(p.cpu().clone(), **kw)
+    assert sum(x.shape[0] for x in ref) > 1500
+    general.hints_clear()
+    for rep in range(3):
+        _cmp(general.non_max_suppression_obb(p, **kw), ref, ties=True)
+    general.hint_set(dev, 64512, 2, True, 0.25, cand=0)    # ... and the generic sort again behind a hint of 0
+    _cmp(general.non_max_suppression_obb(p, **kw), ref, ties=True)
+
+
+@pytest.mark.parametrize("half,multi", [(True, True), (False, True), (False, False)])
+def test_nc2_low_confidence_segments_of_thousands(dev, oracle_lib, half, multi):
+    """nc = 2 at conf 0.01 (the reference's val.py default conf_thres 0.001 regime, val.py:97): every image sends thousands of
+    candidates into each of its two class segments -- segments far above every in-LDS limit, a few images above max_nms' share --
+    with the multi-label expansion (two rows per anchor when both classes pass) and with the best-class rule."""
+    from yolov5_obb_amd.utils import general
+    p = synth.s_pred(4, 64512, 2, seed=2102, n_obj=300, fg_frac=0.12, dtype=torch.float16 if half else torch.float32)
+    if multi:
+        p[..., 5:7] = torch.maximum(p[..., 5:7], (p[..., 4:5] * 0.8).to(p.dtype))       # both classes above the threshold on the planted rows
+    kw = dict(conf_thres=0.01, iou_thres=0.4, multi_label=multi, max_det=1500)
+    ref = pyref.non_max_suppression_obb(p.clone(), **kw)
+    with torch.no_grad():
+        cand = int(((p[..., 4] > 0.01).sum(1)).min())
+    assert cand > 4000, cand
+    general.hints_clear()
+    pd = p.to(dev)
+    for rep in range(3):
+        _cmp(general.non_max_suppression_obb(pd, **kw), ref, ties=half)
+
+
 def test_tta_tensor_of_bench_py(dev, oracle_lib):
     """The TTA stress tensor bench.py times (`nmsobb_tta`): (1, 114627, 203) fp16, nc = 18, generated on the device with seed
     2001, conf 0.01 / iou 0.4 / multi-label (configs[3]): ~60k candidates, i.e. the top-30000 cut and the single-list path."""
