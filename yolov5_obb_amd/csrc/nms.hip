@@ -829,7 +829,9 @@ static int run_nms(int kind, const float* boxes, int stride, const float* scores
     m.capmax = kMkCapMax; m.cap_first = mk_cap_env >= 64 ? mk_cap_env : ((kept_prev >= 0 && (int64_t)kept_prev * 8 > n) ? 4096 : 2048);
     static_assert(kMkTile == 8192, "cap_max(1)");
     m.thr = thr;
-    m.pend1 = cv.mk_pend1; m.cap1 = kMkPend1; m.num_keep = nullptr;    // (k_finalize below writes the count)
+    // (OBB_NMS_MK_PEND: a smaller pending list, so that tests reach the overflow hand-over without two million undecided pairs)
+    static const int mk_pend_cap = [] { const char* e = getenv("OBB_NMS_MK_PEND"); const int v = e ? atoi(e) : 0; return (v > 0 && v < kMkPend1) ? v : kMkPend1; }();
+    m.pend1 = cv.mk_pend1; m.cap1 = mk_pend_cap; m.num_keep = nullptr;    // (k_finalize below writes the count)
     m.hint_host = fbk ? fbk->words : nullptr;
     static const int mk_prof = [] { const char* e = getenv("OBB_NMS_PHASE_PROF"); return (e && atoi(e)) ? 2 : 0; }();
     if (mk_prof) {   // development aid: print the previous call's serial-phase times (synchronises!)
