@@ -21,17 +21,25 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(d, s, thr, mode):
+def _run(d, s, thr, mode, xlds=None):
+    """mode: OBB_NMS_MK, read per call by the library: 0 persistent kernel, 1 phase kernels, 2 its own choice.
+    xlds: OBB_NMS_MK_XLDS, also read per call: 1 = the cross probe on a table of the kept rows in LDS (k_mk_cross_lds), 0 = on the
+    chunk's table in global memory (k_mk_probe<true>), None = the library's choice (by what the previous call kept)."""
     from yolov5_obb_amd import nms_rotated_ext
-    old = os.environ.get("OBB_NMS_MK")
-    os.environ["OBB_NMS_MK"] = str(mode)             # read per call by the library: 0 persistent kernel, 1 phase kernels, 2 its own choice
+    old = {k: os.environ.get(k) for k in ("OBB_NMS_MK", "OBB_NMS_MK_XLDS")}
+    os.environ["OBB_NMS_MK"] = str(mode)
+    if xlds is None:
+        os.environ.pop("OBB_NMS_MK_XLDS", None)
+    else:
+        os.environ["OBB_NMS_MK_XLDS"] = str(xlds)
     try:
         return nms_rotated_ext.nms_rotated(d, s, thr).cpu().numpy()
     finally:
-        if old is None:
-            os.environ.pop("OBB_NMS_MK", None)
-        else:
-            os.environ["OBB_NMS_MK"] = old
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
 
 
 @pytest.mark.parametrize("regime", ["clustered_k300", "clustered_k300_raw", "clustered_k300_18cls", "clustered_k3000", "uniform", "uniform_18cls"])
@@ -43,9 +51,9 @@ def test_full_size_100k_phase_kernels_equal_persistent_kernel(dev, regime):
     dets, scores = synth.regime_100k(regime)
     d, s = dets.to(dev), scores.to(dev)
     ref = _run(d, s, 0.4, 0)
-    for mode in (1, 1, 1, 2, 2, 2):
-        got = _run(d, s, 0.4, mode)
-        assert len(got) == len(ref) and np.array_equal(got, ref), (regime, mode, len(got), len(ref))
+    for mode, xlds in ((1, 0), (1, 0), (1, 1), (1, 1), (1, None), (2, None), (2, None), (2, None)):
+        got = _run(d, s, 0.4, mode, xlds)
+        assert len(got) == len(ref) and np.array_equal(got, ref), (regime, mode, xlds, len(got), len(ref))
 
 
 def _special_cases():
@@ -99,9 +107,9 @@ def test_special_inputs_against_the_oracle(dev, oracle_lib, name):
     d, s, thr = _SPECIAL[name]
     ref = oracle.nms_rotated(d.numpy(), s.numpy(), thr, threads=min(os.cpu_count() or 1, 32))
     dd, ss = d.to(dev), s.to(dev)
-    for mode in (1, 1, 0):
-        got = _run(dd, ss, thr, mode)
-        assert len(got) == len(ref) and np.array_equal(got, ref), (name, mode, len(got), len(ref))
+    for mode, xlds in ((1, 0), (1, 0), (1, 1), (1, 1), (0, None)):
+        got = _run(dd, ss, thr, mode, xlds)
+        assert len(got) == len(ref) and np.array_equal(got, ref), (name, mode, xlds, len(got), len(ref))
 
 
 _HANDOVER = r"""
@@ -117,7 +125,8 @@ for name in ("uniform", "clustered_k3000"):
     os.environ["OBB_NMS_MK"] = "0"
     ref = nms_rotated_ext.nms_rotated(d, s, 0.4).cpu().numpy()
     os.environ["OBB_NMS_MK"] = "1"
-    for rep in range(3):
+    for rep in range(4):
+        os.environ["OBB_NMS_MK_XLDS"] = str(rep & 1)
         got = nms_rotated_ext.nms_rotated(d, s, 0.4).cpu().numpy()
         assert np.array_equal(got, ref), (name, rep, len(got), len(ref))
 print("handover ok")

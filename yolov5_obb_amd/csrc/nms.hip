@@ -442,7 +442,7 @@ struct Carve {
   long long ecap;
   GridDev grid;                        // spatial index (rotated boxes, single list); grid.meta == NULL: not carved
   // the phase-kernel path of a long single list (nms_mk.h); mk_cidx == NULL: not carved.  Its control block is the head of `bar`.
-  int* mk_ctl; uint32_t* mk_cidx; float4* mk_ent; uint16_t* mk_start; u64* mk_kbits; uint4* mk_pend1;   // mk_ctl: 1 KB (control block, edge counter at int 64)
+  int* mk_ctl; uint32_t* mk_cidx; float4* mk_ent; uint16_t* mk_start; u64* mk_kbits; uint4* mk_pend1; uint8_t* mk_hasin;   // mk_ctl: 1 KB (control block, edge counter at int 64)
   size_t grid_zero_bytes;              // GridMeta + slot counters: one contiguous block, zeroed before every build
   size_t total;
 };
@@ -510,7 +510,7 @@ static int carve(void* base, int64_t n, int64_t nseg, int recq, int C, Carve* cv
   cv->ecap = (long long)C * (C - 1) / 2; if (cv->ecap < 1) cv->ecap = 1;
   cv->edges = (uint32_t*)take(nteams * (size_t)cv->ecap * 4);
   cv->grid = GridDev{}; cv->grid_zero_bytes = 0;
-  cv->mk_ctl = nullptr; cv->mk_cidx = nullptr; cv->mk_ent = nullptr; cv->mk_start = nullptr; cv->mk_kbits = nullptr; cv->mk_pend1 = nullptr;
+  cv->mk_ctl = nullptr; cv->mk_cidx = nullptr; cv->mk_ent = nullptr; cv->mk_start = nullptr; cv->mk_kbits = nullptr; cv->mk_pend1 = nullptr; cv->mk_hasin = nullptr;
   if (recq == RotGeom::RECQ && nseg == 1 && n >= kGridMinN) {
     const uint32_t M = grid_slots(n);
     cv->grid.mask = M - 1;
@@ -546,6 +546,7 @@ static int carve(void* base, int64_t n, int64_t nseg, int recq, int C, Carve* cv
     cv->mk_ent = (float4*)take((size_t)kMkCapMax * 16);
     cv->mk_start = (uint16_t*)take((size_t)(kMkSlots + 8) * 2);
     cv->mk_kbits = (u64*)take((size_t)(kMkCapMax / 64) * 8);
+    cv->mk_hasin = (uint8_t*)take((size_t)kMkCapMax);
     cv->mk_pend1 = (uint4*)take((size_t)kMkPend1 * 16);
   }
   cv->total = off;
@@ -702,13 +703,23 @@ static bool mk_choose(MkFeedback* f) {
   if (kept < 0 || (k & 63u) == 0u) return false;
   return slab != 1 && kept >= kMkMinKept;
 }
-static int mk_steps(MkArgs& a, hipStream_t st) {
+// Which cross probe: the table of the kept rows in every workgroup's LDS (k_mk_cross_lds) where a step keeps a few thousand rows
+// at most -- the previous call of the size class kept <= 2 passes' worth in all -- the chunk's table in global memory otherwise
+// (S-uniform keeps 36,000 of 100,000: six passes over the queries would cost more than the L2 round trips they save).
+// OBB_NMS_MK_XLDS = 0 / 1 pins the choice (read per call: tests run both on the same data).
+static bool mk_cross_in_lds(int kept_prev) {
+  const char* e = getenv("OBB_NMS_MK_XLDS");
+  if (e && (e[0] == '0' || e[0] == '1')) return e[0] == '1';
+  return kept_prev >= 0 && kept_prev <= 2 * kMkXRows;
+}
+static int mk_steps(MkArgs& a, int kept_prev, hipStream_t st) {
   static OncePerDevice attr;
   static_assert(sizeof(MkLdsSelect) <= kMkSerialLds && (size_t)RotGeom::SCR * 64 * 4 * kMkWaves <= kMkSerialLds, "serial-phase LDS");
   if (const int attr_dev = attr.need(); attr_dev != OncePerDevice::kDone) {
     if (hipFuncSetAttribute((const void*)k_mk_select, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMkSerialLds) != hipSuccess ||
         hipFuncSetAttribute((const void*)k_mk_decide<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMkSerialLds) != hipSuccess ||
-        hipFuncSetAttribute((const void*)k_mk_decide<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMkSerialLds) != hipSuccess)
+        hipFuncSetAttribute((const void*)k_mk_decide<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMkSerialLds) != hipSuccess ||
+        hipFuncSetAttribute((const void*)k_mk_cross_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(MkLdsCross)) != hipSuccess)
       return OBB_ERR_LAUNCH;
     attr.mark(attr_dev);
   }
@@ -726,11 +737,16 @@ static int mk_steps(MkArgs& a, hipStream_t st) {
   if (a.hint_host) { *(volatile int*)(a.hint_host + 3) = steps; }
   const unsigned cus = (unsigned)hw_cu_count();
   const unsigned gp = 5 * cus;
+  const bool xlds = mk_cross_in_lds(kept_prev);
   k_mk_select<<<1, kMkThreads, kMkSerialLds, st>>>(a);
   for (int s = 0; s < steps; s++) {
     k_mk_probe<false><<<gp, kMkProbeThreads, 0, st>>>(a);
     k_mk_decide<false><<<cus, kMkThreads, kMkSerialLds, st>>>(a);      // ... + resolve in its last workgroup
-    k_mk_probe<true><<<gp, kMkProbeThreads, 0, st>>>(a);
+    // (the step that completes a call has nothing behind its chunk: no cross half for the last enqueued step -- two empty launches,
+    //  ~10 us; a call that needs more steps than were enqueued goes on in the persistent kernel with this cross phase, NmsResume stage 3)
+    if (s == steps - 1) break;
+    if (xlds) k_mk_cross_lds<<<2 * cus, kMkXThreads, sizeof(MkLdsCross), st>>>(a);
+    else k_mk_probe<true><<<gp, kMkProbeThreads, 0, st>>>(a);
     k_mk_decide<true><<<cus, kMkThreads, kMkSerialLds, st>>>(a);       // ... + the next select in its last workgroup
   }
   return hipGetLastError() == hipSuccess ? OBB_OK : OBB_ERR_LAUNCH;
@@ -817,7 +833,7 @@ static int run_nms(int kind, const float* boxes, int stride, const float* scores
     static_assert(sizeof(MkCtl) <= 256, "the control block and its counters share one zeroed KB");
     m.rec = cv.rec; m.order = cv.vals_b; m.alive = cv.alive; m.n = (int)n;
     m.ctl = reinterpret_cast<MkCtl*>(cv.mk_ctl);
-    m.cidx = cv.mk_cidx; m.ent = cv.mk_ent; m.start = cv.mk_start; m.kbits = cv.mk_kbits;
+    m.cidx = cv.mk_cidx; m.ent = cv.mk_ent; m.start = cv.mk_start; m.kbits = cv.mk_kbits; m.hasin = cv.mk_hasin;
     m.edges = cv.edges; m.nedges = cv.mk_ctl + 64; m.ecap = cv.ecap;
     m.rows = cv.rows; m.nrows = cv.mk_ctl + 128; m.keep_cnt = cv.keep_cnt; m.keep_out = keep_out;
     m.bbpart = cv.grid.bbpart; m.nparts = cv.grid.nparts;
@@ -875,7 +891,7 @@ static int run_nms(int kind, const float* boxes, int stride, const float* scores
   {
     ProfScope ps(PROF_NMS_STEPS, st);
     if (use_mk) {
-      rc = mk_steps(m, st);
+      rc = mk_steps(m, fbk ? *(volatile int*)(fbk->words + 1) : -1, st);
       if (rc) return rc;
       a.resume = reinterpret_cast<const NmsResume*>(cv.mk_ctl);   // the persistent kernel behind them: returns at once when they completed the call
     }

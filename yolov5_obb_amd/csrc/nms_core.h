@@ -49,7 +49,9 @@ struct NmsResume {
   int cn, cap, nrow, chunk_first;
   float dmax2;
   int stage;                 // 1: a chunk [chunk_first, cur) is selected but not resolved; 3: the rows of the last chunk are kept
-  int bail;                  // != 0 with stage 3: the cross phase of those rows is incomplete
+  int bail;                  // != 0: the phase kernels stood back in the stage named (stage 3: somewhere in the cross phase).  Stage 3 means
+                             // "cross phase not known to be complete" either way -- the last enqueued step has no cross half -- and kills
+                             // are idempotent: the rows are crossed (again) before anything else
 };
 
 struct NmsArgs {
@@ -613,14 +615,28 @@ __device__ __forceinline__ void nms_pairs(const NmsArgs& a, int tm, int cn, cons
 // for the first rounds, until what is left of it fits.
 // LDS (aliasing the wave scratch): state[capmax] | blocked[capmax] | edges[...]
 // returns the number of kept boxes of the chunk (also published in nrows[g])
+// hasin (optional, [cn] bytes, nms_mk.h): != 0 where at least one edge points AT the member, set while the edges were written.  The
+// members nobody points at are kept before the first round instead of after it: the first pass over the list already kills and prunes.
 OBB_COLD_RESOLVE int nms_resolve(const NmsArgs& a, int g, int sb, int tm, int cn, int kept_before, const uint32_t* cidx, uint8_t* smem,
-                           size_t smem_bytes, int* s_i) {
+                           size_t smem_bytes, int* s_i, const uint8_t* hasin = nullptr) {
   const int tid = threadIdx.x;
   uint8_t* state = smem;              // 0 undecided, 1 kept, 2 dead
   uint8_t* blocked = smem + a.capmax;
   uint32_t* ledges = reinterpret_cast<uint32_t*>(smem + 2 * (size_t)a.capmax);
   const long long lcap = ((long long)smem_bytes - 2LL * a.capmax) / 4;
-  for (int j = tid; j < cn; j += kNmsThreads) { state[j] = 0; blocked[j] = 0; }
+  if (hasin != nullptr) {
+    // (four members per 32-bit word; the bytes behind cn stay inside the capmax-sized arrays and are never read)
+    for (int j4 = tid; j4 * 4 < cn; j4 += kNmsThreads) {
+      const uint32_t w = reinterpret_cast<const uint32_t*>(hasin)[j4];
+      uint32_t st = 0u;
+#pragma unroll
+      for (int c4 = 0; c4 < 4; c4++) st |= (((w >> (8 * c4)) & 0xffu) ? 0u : 1u) << (8 * c4);
+      reinterpret_cast<uint32_t*>(state)[j4] = st;
+      reinterpret_cast<uint32_t*>(blocked)[j4] = 0u;
+    }
+  } else {
+    for (int j = tid; j < cn; j += kNmsThreads) { state[j] = 0; blocked[j] = 0; }
+  }
   long long E = ldg_agent(a.nedges + tm);
   if (E > a.ecap) E = a.ecap;         // cannot happen: ecap is the worst case capmax*(capmax-1)/2
   const uint32_t* edges = a.edges + (size_t)tm * a.ecap;   // plain loads: acquired in serial_begin
@@ -659,9 +675,9 @@ OBB_COLD_RESOLVE int nms_resolve(const NmsArgs& a, int g, int sb, int tm, int cn
   // A list that does not fit is first streamed READ-ONLY from global memory (16-byte plain loads, 8 in flight: the
   // list was published write-through and acquired in serial_begin, nothing writes it during the serial section):
   // the rounds work exactly as below but nothing is pruned.  Each such round counts the edges that still have two
-  // undecided ends; these can only become fewer, so once every thread's count fits its LDS block the next round
-  // copies the survivors into LDS and the self-pruning rounds take over.
-  bool compact = false;
+  // undecided ends and copies them into the thread's LDS block as long as they fit (round 6: optimistically, in the same
+  // pass -- counting first and copying in the NEXT round cost a third 45 us pass over a 100,000-edge list); these can only
+  // become fewer, so once every thread's survivors fit the self-pruning rounds take over.
   // one edge (i < j) against the states read for it: true = both ends undecided, the edge stays and j waits for i
   auto decide = [&](uint32_t ed, uint8_t sj, uint8_t si) -> bool {
     if (sj != 0) return false;                       // target decided: the edge is done
@@ -693,7 +709,6 @@ OBB_COLD_RESOLVE int nms_resolve(const NmsArgs& a, int g, int sb, int tm, int cn
     } else {
       const uint4* e4 = reinterpret_cast<const uint4*>(edges);
       const long long nvec = (E + 3) >> 2;
-      int w = 0;
       for (long long v0 = tid; v0 < nvec; v0 += 8 * kNmsThreads) {
         uint4 v[8];
 #pragma unroll
@@ -713,13 +728,12 @@ OBB_COLD_RESOLVE int nms_resolve(const NmsArgs& a, int g, int sb, int tm, int cn
           for (int c = 0; c < 4; c++) {
             if (4 * k + c >= E) break;
             if (decide(e[c], sj[c], si[c])) {
+              if (remaining < per) mine_e[remaining] = e[c];
               remaining++;
-              if (compact) mine_e[w++] = e[c];
             }
           }
         }
       }
-      if (compact) mycnt = w;
     }
     // live edges of the whole list (LDS mode): two counters by round parity, the idle one is cleared for the next round
     int* live_cnt = &s_i[9 + (round & 1)];
@@ -736,8 +750,7 @@ OBB_COLD_RESOLVE int nms_resolve(const NmsArgs& a, int g, int sb, int tm, int cn
     const int any = __syncthreads_or(rem ? 1 : 0);     // barrier + "somebody is still undecided" in one
     if (!any) { if (a.prof && tid == 0) atomicAdd(a.prof + 11, (u64)(round + 1)); break; }
     if (!lds_mode) {
-      if (compact) lds_mode = true;                                        // the survivors are in LDS now
-      else compact = __syncthreads_or(remaining > per ? 1 : 0) == 0;       // block-uniform: next round copies them
+      if (__syncthreads_or(remaining > per ? 1 : 0) == 0) { lds_mode = true; mycnt = remaining; }   // block-uniform: the survivors are in LDS now
     } else if (*live_cnt <= kResolveTail && (long long)kNmsThreads * per + kResolveTail <= lcap) {
       // The tail: a few hundred live edges, a few dozen undecided boxes, and a dependency chain that still needs several
       // rounds (a round here decides one level of the chain: 9-10 rounds for the 1873-box chunk of S-clustered K=300, of
@@ -2106,7 +2119,7 @@ __global__ __launch_bounds__(kNmsThreads) __attribute__((amdgpu_waves_per_eu(1, 
       cur = (r.stage == 1) ? r.chunk_first : r.cur;
       if (cur < sb) cur = sb;
       if (r.cap > 0) cap = r.cap < a.capmax ? r.cap : a.capmax;
-      if (r.stage == 3 && r.bail != 0 && r.nrow > 0 && r.nrow <= kept && cur < wend) { jrows = a.rows + sb + (kept - r.nrow); jnr = r.nrow; jc0 = cur; jc1 = wend; }
+      if (r.stage == 3 && r.nrow > 0 && r.nrow <= kept && cur < wend) { jrows = a.rows + sb + (kept - r.nrow); jnr = r.nrow; jc0 = cur; jc1 = wend; }
     }
     for (;;) {
       if (jnr > 0) {

@@ -73,6 +73,8 @@ struct MkArgs {
   uint32_t* cidx;                         // [capmax] positions of the chunk members, ascending
   float4* ent; uint16_t* start;           // the chunk's table: entries {x, y, radius (rounded up to 16 bits) | chunk-local index, position}, slot starts [kMkSlots + 1]
   u64* kbits;                             // [capmax / 64] bit j: chunk member j was kept (written by resolve, read by the cross probe)
+  uint8_t* hasin;                         // [capmax] != 0: an edge points at chunk member j (cleared by select, set with every edge: resolve starts from
+                                          // the members nobody points at instead of finding them in a first pass over the edge list)
   uint32_t* edges; int* nedges; long long ecap;
   uint32_t* rows; int* nrows; int* keep_cnt; int64_t* keep_out;
   int64_t* num_keep;                      // written by whoever completes the call
@@ -396,6 +398,7 @@ __device__ void mk_select_phase(const MkArgs& a, MkLdsSelect& S, u64* t0) {
     return;
   }
   for (int k = tid; k < cn; k += kMkThreads) a.cidx[k] = S.list[k];
+  for (int k = tid; k * 16 < cn; k += kMkThreads) reinterpret_cast<uint4*>(a.hasin)[k] = make_uint4(0u, 0u, 0u, 0u);
   mk_build_table(a, a.rec, S.list, cn, D, &c->g, a.ent, a.start, S.b);
   mk_lap(a, 4, t0);
   if (tid == 0) {
@@ -450,6 +453,7 @@ __device__ __forceinline__ void mk_hit(const MkArgs& a, bool h, uint32_t qa) {
       if (h) {
         const long long p = (long long)base + __popcll(hm & lanemask_lt());
         if (p < a.ecap) stg_agent(a.edges + p, qa); else stg_agent(&a.ctl->bail, 1);   // (a chunk above kMkTile members can outgrow the list)
+        stg_agent(a.hasin + (qa & 0xffffu), (uint8_t)1);
       }
     }
   }
@@ -625,6 +629,206 @@ __device__ void mk_probe_phase(const MkArgs& a, MkLdsProbe<NW>& S, int wg, int n
   for (int i = tid; i < ne; i += NT) {
     const long long d = (long long)S.ebase + i;
     if (d < a.ecap) stg_agent(a.edges + d, S.ebuf[i]); else stg_agent(&c->bail, 1);
+    stg_agent(a.hasin + (S.ebuf[i] & 0xffffu), (uint8_t)1);
+  }
+}
+
+// ------------------------------------------------------------------ D': the cross probe on a table of the KEPT rows in LDS
+// The chunk's table holds every member, the cross phase needs the kept ones (300 of 2048 in S-clustered K=300), and its entries
+// sit in global memory: a query walks five or six cell-row ranges, every trip a dependent L2 round trip -- 61-67 us per step at
+// 100k in the clustered regimes, nearly all of it latency.  Here every workgroup builds its OWN table of the step's kept rows
+// (resolve left their positions in a.rows) in LDS: <= kMkXRows rows per pass (more rows: more passes over the queries), a
+// counting sort of a few thousand quads, ~5 us, after which a trip costs two LDS reads.  Same geometry rules, same exactness
+// rules as mk_build_table / mk_probe_phase: brute rows in front, a query that is not well conditioned reads everything.
+constexpr int kMkXThreads = 512;
+constexpr int kMkXWaves = kMkXThreads / 64;
+constexpr int kMkXRows = 3072;            // kept rows of a pass
+constexpr int kMkXPer = kMkXRows / kMkXThreads;
+constexpr int kMkXSlots = 4096;           // 64 table rows of 64 cells
+constexpr int kMkXTabPad = kMkXSlots / 32;
+constexpr int kMkXBruteCtr = kMkXSlots + kMkXTabPad + 8;
+__device__ __forceinline__ int mk_xtrow(int cy, int xb) { return (cy + 37 * xb) & 63; }
+__device__ __forceinline__ int mk_xslot(int cx, int cy) { return (cx & 63) + 64 * mk_xtrow(cy, cx >> 6); }
+struct MkLdsCross {
+  float4 ent[kMkXRows];                   // {x, y, radius rounded up to 16 bits, position}
+  uint16_t start[kMkXSlots + 8];
+  union {
+    int tab[kMkXSlots + kMkXTabPad + 40]; // the build's padded counters
+    struct { MkWaveLds w[kMkXWaves]; uint4 pbuf[kMkStagePend]; } q;   // the probe's queues and its staged appends
+  } u;
+  int redi[16];
+  int pcnt, pbase;
+};
+static_assert(sizeof(MkLdsCross) <= 80 * 1024, "two workgroups per CU");
+
+__device__ void mk_cross_lds_phase(const MkArgs& a, MkLdsCross& S, int wg, int nwg) {
+  constexpr int NT = kMkXThreads, NW = kMkXWaves;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  MkCtl* c = a.ctl;
+  const int cur = c->cur, n = a.n, nrow = c->nrow;
+  const uint32_t* __restrict__ rows = a.rows + (c->kept - nrow);
+  const float dmax2 = c->dmax2, thr = a.thr, rcap = c->drcap;
+  const float dx0 = c->dx0, dy0 = c->dy0, dxr = c->dxr, dyr = c->dyr, dmag = c->dmag;
+  const int w0 = cur >> 6;
+  const int nwords = cur < n ? ((n - 1) >> 6) - w0 + 1 : 0;
+  const int nitems = nwords * kMkQB;
+  auto rec_of = [&](uint32_t pos) -> const float4* { return a.rec + (size_t)pos * 4; };
+  for (int t0 = 0; t0 < nrow; t0 += kMkXRows) {
+    const int cnt = (nrow - t0) < kMkXRows ? (nrow - t0) : kMkXRows;
+    // ---- the pass's table
+    float4 q[kMkXPer]; uint32_t pos[kMkXPer]; int slot[kMkXPer];
+#pragma unroll
+    for (int u = 0; u < kMkXPer; u++) { const int k = tid + u * NT; pos[u] = k < cnt ? rows[t0 + k] : 0u; }
+#pragma unroll
+    for (int u = 0; u < kMkXPer; u++) { const int k = tid + u * NT; q[u] = k < cnt ? a.rec[(size_t)pos[u] * 4] : make_float4(0.f, 0.f, 0.f, 0.f); }
+    for (int s2 = tid; s2 < kMkXSlots + kMkXTabPad + 40; s2 += NT) S.u.tab[s2] = 0;
+    float gx0, gy0, ginv, grmax; int cxl, cyl;
+    {
+      const float area = fmaxf(dxr, rcap) * fmaxf(dyr, rcap);
+      const float expect = (float)cnt * (25.f * rcap * rcap) / area;                // rows in a (5 rcap)^2 window
+      float side = rcap * (expect < 16.f ? 2.0f : 0.75f);
+      const float ext = fmaxf(dxr, dyr);
+      if (!(side > ext * 1e-6f)) side = ext * 1e-6f;
+      if (!(side > 1e-30f)) side = 1.0f;
+      gx0 = dx0; gy0 = dy0; ginv = 1.0f / side; grmax = __uint_as_float(mk_rup(rcap));
+      const float fx = floorf(dxr * ginv), fy = floorf(dyr * ginv);
+      cxl = (fx < 1e9f) ? (int)fx : 1000000000; cyl = (fy < 1e9f) ? (int)fy : 1000000000;
+      if (!(fx >= 0.f)) cxl = 0;
+      if (!(fy >= 0.f)) cyl = 0;
+    }
+    auto brute = [&](const float4& v) -> bool { return !mk_finite3(v.x, v.y, v.z) || !(v.w >= kGridIllCond * dmax2) || (v.z > rcap); };
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < kMkXPer; u++) {
+      const int k = tid + u * NT;
+      slot[u] = -1;
+      if (k < cnt) {
+        const int s = brute(q[u]) ? kMkXBruteCtr : mk_xslot(mk_cell(q[u].x, gx0, ginv, cxl), mk_cell(q[u].y, gy0, ginv, cyl));
+        slot[u] = s == kMkXBruteCtr ? s : s + (s >> 5);
+        atomicAdd(&S.u.tab[slot[u]], 1);
+      }
+    }
+    __syncthreads();
+    const int nbrute = S.u.tab[kMkXBruteCtr];
+    {
+      constexpr int PER = kMkXSlots / NT;   // 8 consecutive slots per thread
+      int loc[PER]; int tsum = 0;
+#pragma unroll
+      for (int u = 0; u < PER; u++) { const int s = tid * PER + u; loc[u] = tsum; tsum += S.u.tab[s + (s >> 5)]; }
+      int incl = tsum;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) { const int v = __shfl_up(incl, d); if (lane >= d) incl += v; }
+      if (lane == 63) S.redi[wv] = incl;
+      __syncthreads();
+      int wpre = 0;
+#pragma unroll
+      for (int k = 0; k < NW; k++) if (k < wv) wpre += S.redi[k];
+      const int tbase = wpre + incl - tsum;
+#pragma unroll
+      for (int u = 0; u < PER; u++) {
+        const int s = tid * PER + u;
+        S.u.tab[s + (s >> 5)] = nbrute + tbase + loc[u];        // the running fill pointer of the slot
+        S.start[s] = (uint16_t)(tbase + loc[u]);
+      }
+      if (tid == 0) { S.start[kMkXSlots] = (uint16_t)(cnt - nbrute); S.u.tab[kMkXBruteCtr] = 0; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < kMkXPer; u++) {
+      if (slot[u] >= 0) {
+        const int e = atomicAdd(&S.u.tab[slot[u]], 1);
+        S.ent[e] = make_float4(q[u].x, q[u].y, __uint_as_float(mk_rup(q[u].z)), __uint_as_float(pos[u]));
+      }
+    }
+    __syncthreads();                         // the counters are dead: their memory serves the queues from here on
+    if (tid == 0) S.pcnt = 0;
+    __syncthreads();
+    // ---- the probe
+    MkWaveLds& L = S.u.q.w[wv];
+    MkQueue Q{L.qa, L.qb, L.qc, 0, 0};
+    auto drain = [&](int dcnt) {
+      wave_sync();
+      int res = 0; uint32_t qa = 0, qb = 0;
+      if (lane < dcnt) {
+        const int i = (Q.head + lane) & 127;
+        qa = L.qa[i]; qb = L.qb[i];
+        res = RotGeom::classify_quick(rec_of(qb), rec_of(qa), thr, true);
+      }
+      mk_hit<true>(a, res == 1, qa);
+      Q.head = (Q.head + dcnt) & 127; Q.count -= dcnt;
+      const uint4 v = make_uint4(qa, qb, qa, 0u);
+      mk_stage(res >= 2, v, S.u.q.pbuf, &S.pcnt, kMkStagePend, [&](bool ov) { mk_defer(a, c, ov, v); });
+      wave_sync();
+    };
+    // An item's two loads -- the alive word of its eight positions and their quads -- do not depend on each other (the quad of a
+    // dead position is simply not used), and the NEXT item's are requested before this one is walked: one exposed round trip per
+    // wave instead of two per item.
+    const int stride = nwg * NW;
+    auto request = [&](int it, u64& m, float4& q0) {
+      const int word = it / kMkQB, part = it - word * kMkQB;
+      const int w = w0 + word;
+      const long long p = (long long)w * 64 + part * kMkQB + (lane / kMkL);
+      m = ldg_agent(a.alive + w);
+      q0 = p < n ? a.rec[(size_t)p * 4] : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    u64 m_nx = 0ull; float4 q_nx = make_float4(0.f, 0.f, 0.f, 0.f);
+    int it = wg * NW + wv;
+    if (it < nitems) request(it, m_nx, q_nx);
+    for (; it < nitems; it += stride) {
+      const int word = it / kMkQB, part = it - word * kMkQB;
+      const int w = w0 + word, lo = w * 64;
+      u64 m = m_nx; const float4 q0 = q_nx;
+      if (it + stride < nitems) request(it + stride, m_nx, q_nx);
+      if (lo < cur) m &= ~((1ull << (cur - lo)) - 1ull);
+      if (lo + 64 > n) m &= (1ull << (n - lo)) - 1ull;
+      if (((m >> (part * kMkQB)) & ((1ull << kMkQB) - 1ull)) == 0ull) continue;
+      const int qlane = part * kMkQB + (lane / kMkL), k = lane & (kMkL - 1);
+      const bool valid = (m >> qlane) & 1ull;
+      const uint32_t qpos = (uint32_t)(lo + qlane);
+      const float qx = q0.x, qy = q0.y, qr = q0.z;
+      const bool qnever = !mk_finite3(qx, qy, qr) || !(q0.w >= kGridIllCond * dmax2);
+      const float R = (qr + grmax) * 1.0001f + (fabsf(qx) + fabsf(qy) + dmag) * 4e-7f;
+      const int cx0 = mk_cell(qx - R, gx0, ginv, cxl), cx1 = mk_cell(qx + R, gx0, ginv, cxl);
+      const int cy0 = mk_cell(qy - R, gy0, ginv, cyl), cy1 = mk_cell(qy + R, gy0, ginv, cyl);
+      const bool all = qnever || (cx1 - cx0 > 62) || (cy1 - cy0 > 62);
+      const int xb0 = cx0 >> 6, xb1 = cx1 >> 6;
+      int cy = cy0, xb = xb0;
+      int e = k, e1 = valid ? (all ? cnt : nbrute) : 0;
+      bool more = valid && !all && cnt > nbrute;
+      for (;;) {
+        bool act = e < e1;
+        if (!act && more) {
+          const int l0 = (cx0 > (xb << 6) ? cx0 : (xb << 6)) & 63, l1 = (cx1 < (xb << 6) + 63 ? cx1 : (xb << 6) + 63) & 63;
+          const int base = 64 * mk_xtrow(cy, xb);
+          e = nbrute + (int)S.start[base + l0] + k; e1 = nbrute + (int)S.start[base + l1 + 1];
+          if (++xb > xb1) { xb = xb0; if (++cy > cy1) more = false; }
+          act = e < e1;
+        }
+        if (__ballot(act || more) == 0ull) break;
+        bool pass = false; uint32_t ep = 0;
+        if (act) {
+          const float4 en = S.ent[e];
+          const float dx = qx - en.x, dy = qy - en.y, rs = en.z + qr;
+          pass = qnever || (e < nbrute) || !(dx * dx + dy * dy > rs * rs);
+          ep = __float_as_uint(en.w);
+          e += kMkL;
+        }
+        if (__ballot(pass)) {
+          Q.push(pass, qpos, ep, 0u);
+          if (Q.count >= 64) drain(64);
+        }
+      }
+    }
+    if (Q.count > 0) drain(Q.count);
+    __syncthreads();
+    const int np = S.pcnt < kMkStagePend ? S.pcnt : kMkStagePend;
+    if (tid == 0) S.pbase = np > 0 ? atomicAdd(&c->n1, np) : 0;
+    __syncthreads();
+    for (int i = tid; i < np; i += NT) {
+      const long long d = (long long)S.pbase + i;
+      if (d < a.cap1) a.pend1[d] = S.u.q.pbuf[i]; else stg_agent(&c->bail, 1);
+    }
+    __syncthreads();
   }
 }
 
@@ -645,7 +849,11 @@ __device__ __forceinline__ void mk_decide_phase(const MkArgs& a, float* scr_wave
     if (i < n1) {
       p = a.pend1[i];
       ra = a.rec + (size_t)p.y * 4; rb = a.rec + (size_t)p.x * 4;          // (the entry = the earlier box first)
-      res = RotGeom::classify_full(ra, rb, a.thr);
+      // (cross: a query that another row has removed meanwhile -- most have a quick hit from the row of their own object -- needs
+      //  no further decision)
+      bool open = true;
+      if constexpr (CROSS) open = (ldg_agent(a.alive + (p.z >> 6)) >> (p.z & 63)) & 1ull;
+      if (open) res = RotGeom::classify_full(ra, rb, a.thr);
     }
     bool h = res == 1;
     if (__ballot(res == 2)) {
@@ -665,7 +873,7 @@ __device__ void mk_resolve_phase(const MkArgs& a, uint8_t* smem, size_t smem_byt
   r.rec = a.rec; r.order = a.order; r.keep_cnt = a.keep_cnt; r.keep_out = a.keep_out; r.rows = a.rows; r.nrows = a.nrows;
   r.edges = a.edges; r.nedges = a.nedges; r.ecap = a.ecap; r.n = a.n; r.nseg = 1; r.capmax = a.capmax; r.max_keep = 0; r.lpt = 0; r.prof = a.prof;
   __syncthreads();
-  const int total = nms_resolve(r, 0, 0, 0, cn, kept_before, a.cidx, smem, smem_bytes, s_i);
+  const int total = nms_resolve(r, 0, 0, 0, cn, kept_before, a.cidx, smem, smem_bytes, s_i, a.hasin);
   // the kept bits of the chunk members for the cross probe (nms_resolve leaves the members' states at the head of its LDS block)
   const bool last = cur >= a.n;                         // nothing behind the chunk: no cross phase, the call is complete
   if (!last) {
@@ -710,6 +918,13 @@ __global__ __launch_bounds__(kMkProbeThreads, 5) void k_mk_probe(MkArgs a) {
   if (c->done || c->bail || c->stage != (CROSS ? 3 : 1)) return;
   if (CROSS && c->nrow == 0) return;
   mk_probe_phase<CROSS, kMkProbeWaves>(a, S, (int)blockIdx.x, (int)gridDim.x);
+}
+// the cross probe on a table of the kept rows in LDS (mk_cross_lds_phase): two workgroups per CU
+__global__ __launch_bounds__(kMkXThreads, 4) void k_mk_cross_lds(MkArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char mk_smem[];
+  const MkCtl* c = a.ctl;
+  if (c->done || c->bail || c->stage != 3 || c->nrow == 0) return;
+  mk_cross_lds_phase(a, *reinterpret_cast<MkLdsCross*>(mk_smem), (int)blockIdx.x, (int)gridDim.x);
 }
 // The decide kernel of a pair phase: the interval and the exact clip for the pairs its probe kernel left undecided, on every
 // workgroup; the workgroup that is through LAST then runs the serial phase behind it -- resolve after "pairs", select (+ the next

@@ -277,7 +277,28 @@ __global__ __launch_bounds__(kPsRun) void k_ps_bucket(PsBuf b) {
     const size_t src = (size_t)a0 * kPsRun + s_lo[a0] + (q - s_off[a0]);
     s_k[q] = b.run_k[src]; s_v[q] = b.run_v[src];
   }
-  if (m <= kPsSortMax) {
+  if (m > 1024 && m <= kPsSortMax) {
+    // A bucket just above 1024 elements (one in 196 at 100k: 1048 in S-clustered K=3000) padded to 2048 ran the four-per-thread
+    // network and the whole launch waited for it (31.8 us instead of 16.9).  Two blocks instead -- the first 1024 elements and the
+    // rest, padded to ITS power of two -- sorted one after the other and merged by rank on the way out (keys are unique).
+    const int mb = m - 1024;
+    int npb = 64;
+    while (npb < mb) npb <<= 1;
+    for (int q = m + tid; q < 1024 + npb; q += kPsRun) { s_k[q] = ~0ull; s_v[q] = 0u; }
+    __syncthreads();
+    sort_lds_regs<2>(s_k, s_v, 1024, tid);
+    if (npb <= 512) sort_lds_regs<1>(s_k + 1024, s_v + 1024, npb, tid);
+    else sort_lds_regs<2>(s_k + 1024, s_v + 1024, npb, tid);
+    for (int q = tid; q < m; q += kPsRun) {
+      const unsigned long long e = s_k[q];
+      const bool first = q < 1024;
+      int l2 = first ? 1024 : 0, h2 = first ? m : 1024;
+      const int l0 = l2;
+      while (l2 < h2) { const int mid = (l2 + h2) >> 1; if (s_k[mid] < e) l2 = mid + 1; else h2 = mid; }
+      const int rank = (first ? q : q - 1024) + (l2 - l0);
+      b.out_k[(size_t)base + rank] = e; b.out_v[(size_t)base + rank] = s_v[q];
+    }
+  } else if (m <= kPsSortMax) {
     int npad = 64;
     while (npad < m) npad <<= 1;
     for (int q = m + tid; q < npad; q += kPsRun) { s_k[q] = ~0ull; s_v[q] = 0u; }
