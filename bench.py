@@ -273,6 +273,7 @@ def dry_run(args):
 
 
 METRIC = "val.py img/s (hot path: non_max_suppression_obb, bs16) + NMS ms/img @100k cand, DOTAv1.5 1024^2, 1/2/4/8 GPU"
+WINDOWS = 5         # the timed window of K steps is repeated this many times; the median window is the reported one
 ROTATE = 4          # distinct prediction tensors rotated through the timed loop (4 x 415 MB: nothing stays Infinity-Cache-warm)
 
 
@@ -355,12 +356,17 @@ def main():
     barrier()
     # THE timed region: K steps with HIP events around the step's dominant kernel only (the persistent NMS kernel: two records per
     # step on the kernels' own stream; recording all five stages costs ten records = ~30 us of a 0.2 ms step)
+    # (one window of K x 0.14 ms is a 3 ms measurement -- one scheduler hiccup moves `value` by more than the
+    #  box-to-box spread.  The window of EXACTLY K steps, barrier + synchronize on both sides, is repeated WINDOWS times back to back;
+    #  `ms_per_step` / `value` are the MEDIAN window's, the others are reported next to it.)
     L.obb_profile_enable(2)
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        out = non_max_suppression_obb(preds[i % ROTATE], **kw)
-    barrier()
-    dt = time.perf_counter() - t0
+    win_dt = []
+    for _w in range(WINDOWS):
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            out = non_max_suppression_obb(preds[i % ROTATE], **kw)
+        barrier()
+        win_dt.append(time.perf_counter() - t0)
     ms_sum_t, cnts_t = collect_profile(L)
     L.obb_profile_enable(0)
     # the same K steps with events around every stage: the per-stage figures of `stages_ms` / `kernels` (the NMS kernel's own figure
@@ -394,8 +400,12 @@ def main():
     ms_warm = shard.max_over_ranks(time.perf_counter() - t0, device=dev) / args.steps * 1e3
     ms_sum_w, cnts_w = collect_profile(L)
     L.obb_profile_enable(0)
-    dt = shard.max_over_ranks(dt, device=dev)           # the job is as slow as its slowest rank
+    win_dt = [shard.max_over_ranks(w, device=dev) for w in win_dt]      # a window is as slow as its slowest rank
+    dt = sorted(win_dt)[len(win_dt) // 2]
     ms_per_step = dt / args.steps * 1e3
+    windows_obj = {"n": WINDOWS, "steps_each": args.steps, "ms_per_step": [round(w / args.steps * 1e3, 4) for w in win_dt],
+                   "median": round(ms_per_step, 4), "min": round(min(win_dt) / args.steps * 1e3, 4), "max": round(max(win_dt) / args.steps * 1e3, 4),
+                   "note": "every window: exactly `steps` steps between barrier + synchronize; value / ms_per_step = the median window"}
     value = world * bs * args.steps / dt
 
     # the step's kernels, measured with HIP events inside the timed region (cold: rotating tensors; warm: one tensor)
@@ -414,7 +424,7 @@ def main():
     nms_alg = int(sum(bytes_nms(int(c)) for c in cand))
     nms_ach = nms_alg / (nms_ms_step * 1e-3) / 1e9
     pmc = {}
-    for name in ("r5_pmc.json", "r4_pmc.json", "r3_pmc.json", "r2_pmc.json", "r1_pmc.json"):
+    for name in ("r6_pmc.json", "r5_pmc.json", "r4_pmc.json", "r3_pmc.json", "r2_pmc.json", "r1_pmc.json"):
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", name)))
             pmc["_file"] = "profiles/" + name
@@ -423,8 +433,11 @@ def main():
             continue
     sq = {}
     try:
-        sq = json.load(open(os.path.join(ROOT, "profiles", "r5_sq.json")))
-        sq["_file"] = "profiles/r5_sq.json"
+        for name in ("r6_sq.json", "r5_sq.json"):
+            if os.path.exists(os.path.join(ROOT, "profiles", name)):
+                sq = json.load(open(os.path.join(ROOT, "profiles", name)))
+                sq["_file"] = "profiles/" + name
+                break
     except Exception:
         pass
     # (through the compiled binding the step is three launches: "gather" -- k_gather_out -- reads 0, the output rows are written by the
@@ -439,7 +452,8 @@ def main():
     regimes = {}
     reps = 20
     for rname, label in (("clustered_k300_raw", "S-clustered(K=300)"), ("clustered_k300_18cls", "S-clustered(K=300) + 18 class offsets"),
-                         ("clustered_k3000", "S-clustered(K=3000)"), ("uniform", "S-uniform")):
+                         ("clustered_k3000", "S-clustered(K=3000)"), ("clustered_k3000_18cls", "S-clustered(K=3000) + 18 class offsets"),
+                         ("uniform", "S-uniform")):
         d100, s100 = synth.regime_100k(rname, n100)
         d100, s100 = d100.to(dev), s100.to(dev)
         for _ in range(3):
@@ -472,25 +486,35 @@ def main():
             "achieved_GBs": round(ach, 2), "frac": round(ach / HBM_PEAK_GBS, 4),
             "pair_tests_per_s": round(n100 * (n100 - 1) / 2 / (nms_ms * 1e-3), 1)}
         del d100, s100
-    worst = min(("clustered_k300_raw", "clustered_k300_18cls"), key=lambda r: regimes[r]["frac"])
+    # (the roofline object is the WORST of the regimes, not the friendliest; the real HBM rate sits next to the
+    #  notional one: real_hbm_frac = measured HBM bytes of the whole call / avg_call_ms / peak)
+    worst = min(regimes, key=lambda r: regimes[r]["frac"])
     wr = regimes[worst]
+    traffic = pmc.get("nms_100k_call_" + worst.replace("_raw", ""))
+    for r in regimes:
+        t_r = pmc.get("nms_100k_call_" + r.replace("_raw", ""))
+        regimes[r]["traffic"] = t_r
+        regimes[r]["real_hbm_frac"] = None if not t_r else round(t_r / (regimes[r]["ms_per_call"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
     nms_obj = {"regimes": regimes, "roofline_regime": worst,
-               "note": "fraction = SURVEY 8d bytes_nms(N) over the whole call; the roofline object reports the worse of the first two regimes"}
+               "note": "fraction = SURVEY 8d bytes_nms(N) over the whole call; the roofline object reports the WORST of the five regimes"}
     roofline = {"bound": "hbm", "achieved": wr["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": wr["frac"],
-                "traffic": pmc.get("k_nms_persist_100k_" + worst, pmc.get("k_nms_persist_100k")), "algorithmic_bytes": bytes_nms(n100),
-                "kernel": "obb::k_nms_persist<obb::RotGeom> (+ sort, prep) @ N = 100k", "regime": wr["distribution"],
+                "traffic": traffic, "real_hbm_frac": wr["real_hbm_frac"], "algorithmic_bytes": bytes_nms(n100),
+                "kernel": "single-list rotated NMS @ N = 100k, the whole call (k_ps_* sort, k_prep_rot, then the phase kernels k_mk_* of csrc/nms_mk.h or "
+                          "k_slab_split + k_nms_persist<obb::RotGeom, true>, by the library's own choice per regime)", "regime": wr["distribution"],
                 "avg_call_ms": wr["ms_per_call"], "avg_kernel_ms": wr["stages_ms"]["steps"], "pair_tests_per_s": wr["pair_tests_per_s"],
                 "frac_by_regime": {r: regimes[r]["frac"] for r in regimes},
+                "real_hbm_frac_by_regime": {r: regimes[r]["real_hbm_frac"] for r in regimes},
                 # the roofline that binds this kernel is not HBM (traffic << algorithmic bytes): SQ counters of k_nms_persist per regime --
                 # valu_frac = issued VALU cycles / (256 CUs x 4 SIMDs x kernel cycles), wait_frac = share of the waves' resident time spent
                 # parked (s_waitcnt, barrier spins), from profiles/r5_sq.md (rocprofv3 --pmc, separate passes; tools/rocpd_sq.py)
-                "sq": {r: sq.get("k_nms_persist_100k_" + r.replace("_raw", "")) for r in regimes}, "sq_source": sq.get("_file"),
-                "valu_frac": (sq.get("k_nms_persist_100k_" + worst.replace("_raw", "")) or {}).get("valu_frac"),
-                "note": "frac = SURVEY 8d bytes over avg_call_ms, the whole NMS call: three sort launches (k_ps_*), the record kernel, "
-                        "k_slab_split (52 us when the list falls apart into class slabs, 4 us otherwise) and k_nms_persist<RotGeom, true>; "
-                        "avg_kernel_ms = the HIP-event time of the last two together (the stage 'steps'); compare "
-                        "profiles/r4_hotpath_kernel_stats.md.  The kernel never builds the mask (traffic << algorithmic bytes): a time "
-                        "target, see pair_tests_per_s"}
+                "sq": {r: sq.get("nms_100k_" + r.replace("_raw", ""), sq.get("k_nms_persist_100k_" + r.replace("_raw", ""))) for r in regimes}, "sq_source": sq.get("_file"),
+                "valu_frac": (sq.get("nms_100k_" + worst.replace("_raw", ""), sq.get("k_nms_persist_100k_" + worst.replace("_raw", ""))) or {}).get("valu_frac"),
+                "note": "frac = SURVEY 8d bytes over avg_call_ms, the whole NMS call, for the WORST regime: three sort launches (k_ps_*), the "
+                        "record kernel, and either the phase kernels of csrc/nms_mk.h (select / probe / decide+resolve / cross / decide+select per "
+                        "step) or k_slab_split + k_nms_persist<RotGeom, true>; avg_kernel_ms = the HIP-event time of everything behind the "
+                        "records (the stage 'steps'); compare profiles/r6_nms100k_kernel_stats.md.  No path builds the mask: traffic << "
+                        "algorithmic bytes, `frac` is a time target in bytes' clothing -- real_hbm_frac is the HBM rate the call really "
+                        "reaches; what binds it is latency (profiles/r6_sq.md)"}
 
     # ---------------- measured copy ceiling next to the spec peak (256 MiB device-to-device, read + write)
     cbuf = torch.empty(256 << 20, dtype=torch.uint8, device=dev)
@@ -603,6 +627,32 @@ def main():
                     poly_obj["devkit_poly_gpu_nms_30000"] = {"ms_per_call_incl_host_sort_malloc_copies": round((time.perf_counter() - t0p) / 3 * 1e3, 3),
                                                               "kept": len(kh)}
                 del q9
+            # what rule B (the searched bounding-box skip of csrc/piou_device.h) buys: the same two calls with OBB_NMS_POLY_STRICT=1 (the
+            # proved cone rule only).  The library reads the switch once per process: a child process times them.
+            try:
+                import subprocess
+                code = ("import sys, json, torch; sys.path.insert(0, %r); from tests import synth; from yolov5_obb_amd import nms_rotated_ext\n"
+                        "dev = torch.device('cuda:%d'); e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True); out = {}\n"
+                        "for n in (30000, 100000):\n"
+                        "    d, s = synth.s_clustered(n, 300, seed=0)\n"
+                        "    q9 = torch.cat((synth.rbox_to_quad(d), s[:, None]), 1).contiguous().to(dev)\n"
+                        "    k = nms_rotated_ext.nms_poly(q9, 0.4); torch.cuda.synchronize(); ts = []\n"
+                        "    for _ in range(9):\n"
+                        "        e0.record(); k = nms_rotated_ext.nms_poly(q9, 0.4); e1.record(); torch.cuda.synchronize(); ts.append(e0.elapsed_time(e1))\n"
+                        "    ts.sort(); out['nms_poly_%%d' %% n] = {'ms_per_call': round(ts[4], 4), 'kept': int(k.numel())}\n"
+                        "print('STRICT ' + json.dumps(out))\n") % (ROOT, local_rank)
+                r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, OBB_NMS_POLY_STRICT="1"), capture_output=True, text=True, timeout=300)
+                got = [ln for ln in r.stdout.splitlines() if ln.startswith("STRICT ")]
+                strict = json.loads(got[-1][7:]) if got else {"error": (r.stderr or r.stdout)[-300:]}
+                for k_, v_ in strict.items():
+                    if k_ in poly_obj and isinstance(v_, dict):
+                        poly_obj[k_]["strict_ms_per_call"] = v_["ms_per_call"]
+                        poly_obj[k_]["strict_kept"] = v_["kept"]
+                        poly_obj[k_]["strict_over_default"] = round(v_["ms_per_call"] / max(poly_obj[k_]["ms_per_call"], 1e-9), 3)
+                    elif k_ == "error":
+                        poly_obj["strict_error"] = v_
+            except Exception as e:
+                poly_obj["strict_error"] = str(e)
             bo, _ = synth.s_uniform(10000, 3)
             qo, _ = synth.s_uniform(1000, 4)
             bod, qod = bo.to(dev), qo.to(dev)
@@ -899,7 +949,7 @@ def main():
             "metric": METRIC,
             "value": round(value, 2), "unit": "img/s", "n_gpus": dist.get_world_size() if dist is not None else 1, "rccl_ranks": rccl_ranks,
             "steps": args.steps, "warmup": args.warmup, "build": provenance(_lib, L),
-            "ms_per_step": round(ms_per_step, 4), "ms_per_step_with_all_stage_events": round(ms_all_events, 4), "ms_per_step_without_stage_events": round(ms_plain, 4),
+            "ms_per_step": round(ms_per_step, 4), "timed_windows": windows_obj, "ms_per_step_with_all_stage_events": round(ms_all_events, 4), "ms_per_step_without_stage_events": round(ms_plain, 4),
             "ms_per_step_one_tensor_warm": round(ms_warm, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f16", "data": "synthetic",
             "config": {"workload": f"DOTAv1.5 1024^2 bs16 (BASELINE metric; configs[1] thresholds): yolov5 OBB head output (16,64512,201) fp16, "

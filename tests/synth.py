@@ -52,7 +52,7 @@ def tie_free(scores):
 
 
 def regime_100k(name, n=100000):
-    """The four N = 100k regimes bench.py reports (SURVEY section 8d distributions; `raw` = the exact tensor bench.py times,
+    """The N = 100k regimes bench.py reports (SURVEY section 8d distributions; `raw` = the exact tensor bench.py times,
     scores not made tie-free: ties follow the documented rule, ascending original index)."""
     if name == "clustered_k300_raw":
         return s_clustered(n, 300, seed=0)
@@ -63,6 +63,9 @@ def regime_100k(name, n=100000):
         d, _ = with_classes(d, 18, 0)
     elif name == "clustered_k3000":
         d, s = s_clustered(n, 3000, seed=0)
+    elif name == "clustered_k3000_18cls":                   # thousands of objects x 18 classes (the realistic configs[3] shape)
+        d, s = s_clustered(n, 3000, seed=0)
+        d, _ = with_classes(d, 18, 0)
     elif name == "uniform":
         d, s = s_uniform(n, 0)
     elif name == "uniform_18cls":

@@ -442,12 +442,13 @@ def test_heavy_duplication_is_repeatable(dev, oracle_lib):
 regime_100k = synth.regime_100k
 
 
-@pytest.mark.parametrize("regime", ["clustered_k300", "clustered_k300_raw", "clustered_k300_18cls", "clustered_k3000", "uniform",
-                                    "uniform_18cls"])
+@pytest.mark.parametrize("regime", ["clustered_k300", "clustered_k300_raw", "clustered_k300_18cls", "clustered_k3000", "clustered_k3000_18cls",
+                                    "uniform", "uniform_18cls"])
 def test_full_size_100k_exact(dev, oracle_lib, regime):
     """BASELINE.json configs[3] size: the kept list of the HIP NMS at N = 100,000, iou 0.4, equals the oracle's -- same
-    indices, same order -- on every regime bench.py times; three device runs each (the kernel's work distribution depends
-    on timing, the result must not).  The oracle needs 2.3 s for S-clustered and about four minutes for S-uniform on one
+    indices, same order -- on every regime bench.py times; four device runs each (the kernels' work distribution depends
+    on timing, the result must not; the first call of a size class takes the persistent kernel, the later ones the path the
+    library chooses from what that call reported -- the phase kernels of csrc/nms_mk.h for K=3000 and S-uniform).  The oracle needs 2.3 s for S-clustered and about four minutes for S-uniform on one
     thread; its inner loop is split over the host's cores here (same result for any thread count)."""
     import os
     dets, scores = regime_100k(regime)
@@ -455,7 +456,7 @@ def test_full_size_100k_exact(dev, oracle_lib, regime):
     ref = oracle.nms_rotated(dets.numpy(), scores.numpy(), thr, threads=min(os.cpu_count() or 1, 64))
     d, s = dets.to(dev), scores.to(dev)
     from yolov5_obb_amd import nms_rotated_ext
-    for rep in range(3):
+    for rep in range(4):
         got = nms_rotated_ext.nms_rotated(d, s, thr).cpu().numpy()
         assert len(got) == len(ref), (regime, rep, len(got), len(ref))
         assert np.array_equal(ref, got), (regime, rep)

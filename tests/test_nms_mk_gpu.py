@@ -42,7 +42,8 @@ def _run(d, s, thr, mode, xlds=None):
                 os.environ[k] = v
 
 
-@pytest.mark.parametrize("regime", ["clustered_k300", "clustered_k300_raw", "clustered_k300_18cls", "clustered_k3000", "uniform", "uniform_18cls"])
+@pytest.mark.parametrize("regime", ["clustered_k300", "clustered_k300_raw", "clustered_k300_18cls", "clustered_k3000", "clustered_k3000_18cls", "uniform",
+                                    "uniform_18cls"])
 def test_full_size_100k_phase_kernels_equal_persistent_kernel(dev, regime):
     """BASELINE configs[3] size, the regimes bench.py times: three forced runs of the phase kernels (their step estimate comes
     from the previous run: the first run ends in the persistent kernel's hands or not, depending on the regime) and three runs

@@ -7,7 +7,7 @@ import torch
 from tests import synth
 from yolov5_obb_amd import nms_rotated_ext
 dev = torch.device("cuda:0")
-names = sys.argv[1:] or ["clustered_k300", "clustered_k300_18cls", "clustered_k3000", "uniform"]
+names = sys.argv[1:] or ["clustered_k300", "clustered_k300_18cls", "clustered_k3000", "clustered_k3000_18cls", "uniform"]
 for name in names:
     d, s = synth.regime_100k(name)
     d, s = d.to(dev), s.to(dev)

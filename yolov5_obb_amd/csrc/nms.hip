@@ -87,10 +87,11 @@ struct LocalExtras {
   uint4* grid16; long long n_grid16;
   uint4* mk16; long long n_mk16;   // control block of the phase-kernel path (nms_mk.h)
   int* bbpart;                 // [runs][kBbInts] or NULL
+  u64* tstart;                 // optional: the device's wall clock when the call's first kernel runs (k_finalize reports the call's duration)
 };
 __device__ __forceinline__ void local_extras(const LocalExtras& x, const float* __restrict__ dets5, int drop_small, int n, int i, bool in_range,
                                              int (*s_red)[4], uint32_t* key_out) {
-  if (i == 0) { x.seg_begin[0] = 0; x.seg_end[0] = n; x.keep_cnt[0] = 0; }
+  if (i == 0) { x.seg_begin[0] = 0; x.seg_end[0] = n; x.keep_cnt[0] = 0; if (x.tstart) *x.tstart = wall_clock64(); }
   for (long long k = i; k < x.n_bar16; k += (long long)gridDim.x * blockDim.x) x.bar16[k] = make_uint4(0u, 0u, 0u, 0u);
   for (long long k = i; k < x.n_grid16; k += (long long)gridDim.x * blockDim.x) x.grid16[k] = make_uint4(0u, 0u, 0u, 0u);   // GridMeta + slot counters
   for (long long k = i; k < x.n_mk16; k += (long long)gridDim.x * blockDim.x) x.mk16[k] = make_uint4(0u, 0u, 0u, 0u);
@@ -390,7 +391,7 @@ __global__ void k_seg_from_offsets(const int32_t* __restrict__ seg_off, int nseg
 // by (mk_choose below) -- the number of kept boxes and whether the list fell apart into independent slabs.
 __global__ void k_finalize(const int* __restrict__ keep_cnt, const int* __restrict__ seg_begin, int nseg, long long max_keep,
                            const int* __restrict__ abort_flag, int64_t* __restrict__ num_keep, int64_t* __restrict__ seg_begin_out,
-                           int* feedback = nullptr, const SlabPlan* slab_plan = nullptr, int feedback_slab = 0) {
+                           int* feedback = nullptr, const SlabPlan* slab_plan = nullptr, int feedback_slab = 0, const u64* tstart = nullptr) {
   int g = blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= nseg) return;
   if (seg_begin_out) seg_begin_out[g] = seg_begin[g];
@@ -401,6 +402,11 @@ __global__ void k_finalize(const int* __restrict__ keep_cnt, const int* __restri
     __hip_atomic_store(feedback + 1, (int)c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     // (only a call that looked for slabs reports on them: the phase-kernel path leaves the word alone)
     if (feedback_slab) __hip_atomic_store(feedback + 2, (slab_plan != nullptr && slab_plan->mode == 1) ? 1 : 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    // how long the call took on the device (10 ns ticks from its first kernel to this one) and which path it was: [4 + path]
+    if (tstart != nullptr) {
+      const u64 dtk = wall_clock64() - *tstart;
+      __hip_atomic_store(feedback + 4 + (feedback_slab ? 0 : 1), (int)(dtk > 0x3fffffffull ? 0x3fffffffull : dtk), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
   }
 }
 
@@ -442,7 +448,7 @@ struct Carve {
   long long ecap;
   GridDev grid;                        // spatial index (rotated boxes, single list); grid.meta == NULL: not carved
   // the phase-kernel path of a long single list (nms_mk.h); mk_cidx == NULL: not carved.  Its control block is the head of `bar`.
-  int* mk_ctl; uint32_t* mk_cidx; float4* mk_ent; uint16_t* mk_start; u64* mk_kbits; uint4* mk_pend1; uint8_t* mk_hasin;   // mk_ctl: 1 KB (control block, edge counter at int 64)
+  int* mk_ctl; uint32_t* mk_cidx; float4* mk_ent; uint16_t* mk_start; u64* mk_kbits; uint4* mk_pend1; uint8_t* mk_hasin; u64* tstart;   // mk_ctl: 1 KB (control block, edge counter at int 64)
   size_t grid_zero_bytes;              // GridMeta + slot counters: one contiguous block, zeroed before every build
   size_t total;
 };
@@ -501,6 +507,7 @@ static int carve(void* base, int64_t n, int64_t nseg, int recq, int C, Carve* cv
   cv->nrows = cv->abort_flag + 64;
   cv->nedges = cv->nrows + kMaxTeams;
   cv->prof = (u64*)take(56 * 8);
+  cv->tstart = (u64*)take(64);
   cv->plan = (int4*)take((size_t)kMaxTeams * 16);
   cv->seg_begin = (int*)take(ns * 4); cv->seg_end = (int*)take(ns * 4);
   cv->keep_cnt = (int*)take(ns * 4);
@@ -681,10 +688,10 @@ static MkFeedback* mk_feedback(int64_t n) {
   static thread_local MkFeedback fb[64];
   if (!base) {
     void* p = nullptr;
-    if (hipHostMalloc(&p, 64 * 4 * sizeof(int), hipHostMallocPortable) != hipSuccess) return nullptr;
+    if (hipHostMalloc(&p, 64 * 8 * sizeof(int), hipHostMallocPortable) != hipSuccess) return nullptr;
     base = (int*)p;
-    for (int i = 0; i < 64 * 4; i++) base[i] = -1;
-    for (int i = 0; i < 64; i++) { fb[i].words = base + 4 * i; fb[i].calls = 0; }
+    for (int i = 0; i < 64 * 8; i++) base[i] = -1;
+    for (int i = 0; i < 64; i++) { fb[i].words = base + 8 * i; fb[i].calls = 0; }
   }
   int b = 0;
   while ((n >> b) > 1 && b < 63) b++;
@@ -694,6 +701,10 @@ static MkFeedback* mk_feedback(int64_t n) {
 // persistent kernel wins where two or three steps with a few hundred kept rows each do it, and where the list falls apart into
 // independent slabs (class offsets: one team per slab steps concurrently).  Both report what the rule needs; the first call of a
 // size class, and every 64th after it, takes the persistent kernel (it is the one that can see slabs).
+// Round 6: the rule above only says where the phase kernels are WORTH TRYING.  Both paths report how long the call took on the device
+// ([4] persistent kernel, [5] phase kernels: 10 ns ticks between the call's first kernel and its k_finalize), and where both are
+// known the faster one is taken (S-clustered K=3000 + 18 class offsets keeps 40,000 boxes, finds no slabs -- and still runs 0.58 ms
+// on the persistent kernel against 0.67 ms here); the other one is measured again every 64th call, the data may have changed.
 static bool mk_choose(MkFeedback* f) {
   const int mode = mk_enabled();
   if (mode == 0) return false;
@@ -701,7 +712,11 @@ static bool mk_choose(MkFeedback* f) {
   const unsigned k = f->calls++;
   const int kept = *(volatile int*)(f->words + 1), slab = *(volatile int*)(f->words + 2);
   if (kept < 0 || (k & 63u) == 0u) return false;
-  return slab != 1 && kept >= kMkMinKept;
+  if (!(slab != 1 && kept >= kMkMinKept)) return false;
+  const int t_persist = *(volatile int*)(f->words + 4), t_mk = *(volatile int*)(f->words + 5);
+  if (t_persist <= 0 || t_mk <= 0) return true;        // (the phase kernels have not reported yet: try them)
+  if ((k & 63u) == 32u) return t_mk >= t_persist;      // the slower one's turn
+  return t_mk < t_persist;
 }
 // Which cross probe: the table of the kept rows in every workgroup's LDS (k_mk_cross_lds) where a step keeps a few thousand rows
 // at most -- the previous call of the size class kept <= 2 passes' worth in all -- the chunk's table in global memory otherwise
@@ -817,6 +832,7 @@ static int run_nms(int kind, const float* boxes, int stride, const float* scores
     x.grid16 = reinterpret_cast<uint4*>(cv.grid.meta); x.n_grid16 = use_grid ? (long long)(cv.grid_zero_bytes / 16) : 0ll;
     x.mk16 = reinterpret_cast<uint4*>(cv.mk_ctl); x.n_mk16 = use_mk ? 64 : 0;
     x.bbpart = (use_grid && kind == 0) ? cv.grid.bbpart : nullptr;
+    x.tstart = fbk ? cv.tstart : nullptr;
     rc = sort_single_list(scores, score_stride, kind == 0 ? boxes : nullptr, kind == 0 ? drop_small : 0, n, cv, x, &cv.grid.nparts, st);
     if (rc) return rc;
     pre = kNmsBarZeroed;
@@ -857,6 +873,8 @@ static int run_nms(int kind, const float* boxes, int stride, const float* scores
                         "cross: decide+ticket %.1f (pending %llu) select %.1f chunk-table %.1f | edges %llu chunk members %llu kept %llu\n",
                 h[37], h[32] * 0.01, h[42], h[33] * 0.01, h[12] * 0.01, h[13] * 0.01, h[14] * 0.01, h[11], h[41] * 0.01, h[43], h[35] * 0.01, h[36] * 0.01, h[38], h[39], h[40]);
         fprintf(stderr, "    chunk table: loads %.1f statistics %.1f counts %.1f scan %.1f scatter %.1f\n", h[44] * 0.01, h[45] * 0.01, h[46] * 0.01, h[47] * 0.01, h[48] * 0.01);
+        if (h[53]) fprintf(stderr, "    cross probe in LDS, per workgroup (%llu workgroup-steps): table %.1f (longest %.1f) wave 0's items %.1f (longest %.1f) whole %.1f (longest %.1f)\n",
+                           h[53], h[49] * 0.01 / h[53], h[54] * 0.01, h[50] * 0.01 / h[53], h[55] * 0.01, h[51] * 0.01 / h[53], h[52] * 0.01);
       }
       if (hipMemsetAsync(cv.prof, 0, 56 * 8, st) != hipSuccess) return OBB_ERR_LAUNCH;
       m.prof = cv.prof;
@@ -899,7 +917,7 @@ static int run_nms(int kind, const float* boxes, int stride, const float* scores
     if (rc) return rc;
   }
   k_finalize<<<gseg, T, 0, st>>>(cv.keep_cnt, cv.seg_begin, (int)nseg, max_keep, cv.abort_flag, num_keep, nullptr, fbk ? fbk->words : nullptr,
-                                 a.slab_plan, use_mk ? 0 : 1);
+                                 a.slab_plan, use_mk ? 0 : 1, fbk ? cv.tstart : nullptr);
   return hipGetLastError() == hipSuccess ? OBB_OK : OBB_ERR_LAUNCH;
 }
 

@@ -673,8 +673,11 @@ __device__ void mk_cross_lds_phase(const MkArgs& a, MkLdsCross& S, int wg, int n
   const int nwords = cur < n ? ((n - 1) >> 6) - w0 + 1 : 0;
   const int nitems = nwords * kMkQB;
   auto rec_of = [&](uint32_t pos) -> const float4* { return a.rec + (size_t)pos * 4; };
+  const bool xprof = a.prof != nullptr && tid == 0;
+  u64 tx0 = xprof ? wall_clock64() : 0ull, tx_build = 0ull, tx_items = 0ull;
   for (int t0 = 0; t0 < nrow; t0 += kMkXRows) {
     const int cnt = (nrow - t0) < kMkXRows ? (nrow - t0) : kMkXRows;
+    u64 txa = xprof ? wall_clock64() : 0ull;
     // ---- the pass's table
     float4 q[kMkXPer]; uint32_t pos[kMkXPer]; int slot[kMkXPer];
 #pragma unroll
@@ -743,6 +746,7 @@ __device__ void mk_cross_lds_phase(const MkArgs& a, MkLdsCross& S, int wg, int n
     __syncthreads();                         // the counters are dead: their memory serves the queues from here on
     if (tid == 0) S.pcnt = 0;
     __syncthreads();
+    if (xprof) { const u64 t = wall_clock64(); tx_build += t - txa; txa = t; }
     // ---- the probe
     MkWaveLds& L = S.u.q.w[wv];
     MkQueue Q{L.qa, L.qb, L.qc, 0, 0};
@@ -763,6 +767,8 @@ __device__ void mk_cross_lds_phase(const MkArgs& a, MkLdsCross& S, int wg, int n
     // An item's two loads -- the alive word of its eight positions and their quads -- do not depend on each other (the quad of a
     // dead position is simply not used), and the NEXT item's are requested before this one is walked: one exposed round trip per
     // wave instead of two per item.
+    // (measured and not kept: the workgroup's waves drawing their items from a counter in LDS instead of the fixed deal -- the mean
+    //  workgroup spends 16 of its 31 us in wave 0's items at S-clustered K=300, 3 in the table; 30.6 against 31.8 us, and 8 spilled registers)
     const int stride = nwg * NW;
     auto request = [&](int it, u64& m, float4& q0) {
       const int word = it / kMkQB, part = it - word * kMkQB;
@@ -820,6 +826,7 @@ __device__ void mk_cross_lds_phase(const MkArgs& a, MkLdsCross& S, int wg, int n
       }
     }
     if (Q.count > 0) drain(Q.count);
+    if (xprof) { const u64 t = wall_clock64(); tx_items += t - txa; txa = t; }      // (wave 0's own items)
     __syncthreads();
     const int np = S.pcnt < kMkStagePend ? S.pcnt : kMkStagePend;
     if (tid == 0) S.pbase = np > 0 ? atomicAdd(&c->n1, np) : 0;
@@ -829,6 +836,11 @@ __device__ void mk_cross_lds_phase(const MkArgs& a, MkLdsCross& S, int wg, int n
       if (d < a.cap1) a.pend1[d] = S.u.q.pbuf[i]; else stg_agent(&c->bail, 1);
     }
     __syncthreads();
+  }
+  if (xprof) {   // development aid (OBB_NMS_PHASE_PROF): per-workgroup times of this kernel, sums and maxima over workgroups and steps
+    const u64 tt = wall_clock64() - tx0;
+    atomicAdd(a.prof + 49, tx_build); atomicAdd(a.prof + 50, tx_items); atomicAdd(a.prof + 51, tt); atomicAdd(a.prof + 53, 1ull);
+    atomicMax(a.prof + 52, tt); atomicMax(a.prof + 54, tx_build); atomicMax(a.prof + 55, tx_items);
   }
 }
 
