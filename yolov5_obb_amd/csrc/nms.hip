@@ -676,7 +676,7 @@ static int nms_steps(int kind, NmsArgs& a, const Carve& cv, int64_t nseg, int64_
 // number of steps a call needed in a pinned word of the calling thread (one per size class); the thread's next call of that size
 // enqueues that many.
 constexpr int64_t kMkMinN = 16384;
-constexpr int kMkMinKept = 1536;   // below this many kept boxes the persistent kernel's two or three steps are the shorter chain
+constexpr int kMkMinKept = 256;    // below this many kept boxes (a handful of dense clusters: huge conflict lists per chunk) the phase kernels are not even tried
 static int mk_enabled() { const char* e = getenv("OBB_NMS_MK"); return e ? atoi(e) : 2; }   // 0: never, 1: always, 2: by feedback (read per call: tests switch paths in one process)
 // Per calling thread and size class (floor(log2 n)): four pinned words the DEVICE writes when a call completes -- [0] the steps
 // the phase-kernel path needed, [1] the boxes the call kept, [2] whether the persistent kernel found independent slabs -- and
@@ -751,7 +751,7 @@ static int mk_steps(MkArgs& a, int kept_prev, hipStream_t st) {
   if (steps < 1) steps = 1;
   if (a.hint_host) { *(volatile int*)(a.hint_host + 3) = steps; }
   const unsigned cus = (unsigned)hw_cu_count();
-  const unsigned gp = 5 * cus;
+  const unsigned gp = 4 * cus;                         // (k_mk_probe: four 256-thread workgroups per CU)
   const bool xlds = mk_cross_in_lds(kept_prev);
   k_mk_select<<<1, kMkThreads, kMkSerialLds, st>>>(a);
   for (int s = 0; s < steps; s++) {

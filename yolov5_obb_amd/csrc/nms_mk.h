@@ -34,6 +34,7 @@ constexpr int kMkWaves = kMkThreads / 64;
 constexpr int kMkSlots = 8192;            // table slots of a chunk's spatial hash: 128 table rows of 64 cells
 constexpr int kMkL = 8;                   // lanes per query
 constexpr int kMkQB = 64 / kMkL;          // queries of a wave in flight
+constexpr int kMkNE = 4;                  // entries a lane requests per trip of the global-table probes
 constexpr int kMkCapMax = 16384;          // largest chunk (chunk-local indices are 16-bit; the edge list holds the worst case of kMkTile members)
 constexpr int kMkTile = 8192;             // members a table build holds in registers at a time
 constexpr int kMkPer = kMkTile / kMkThreads;
@@ -540,7 +541,7 @@ __device__ void mk_probe_phase(const MkArgs& a, MkLdsProbe<NW>& S, int wg, int n
   const int nitems = nwords * kMkQB;
   // (measured and not kept: items drawn from a counter in LDS with the next item's words requested ahead -- the extra live
   //  registers spill at the 96 the five-waves-per-SIMD budget allows: uniform 0.94 -> 1.02 ms)
-  for (int it = wg * NW + wv; it < nitems; it += nwg * NW) {
+  for (int it = wv * nwg + wg; it < nitems; it += nwg * NW) {          // (a few hundred items -- a 2048-member chunk -- spread over all CUs)
     const int word = it / kMkQB, part = it - word * kMkQB;
     u64 m;
     int lo;
@@ -593,23 +594,26 @@ __device__ void mk_probe_phase(const MkArgs& a, MkLdsProbe<NW>& S, int wg, int n
         act = e < e1;
       }
       if (__ballot(act || more) == 0ull) break;
-      const bool act2 = e + kMkL < e1;
-      bool pass = false, pass2 = false; uint32_t qa1 = 0, qa2 = 0, ep1 = 0, ep2 = 0;
+      // kMkNE entries per lane and trip, requested together: a trip is a dependent L2 round trip whatever it carries, and a dense
+      // range (S-uniform: ~110 entries per cell row of a 16,384-member chunk) is walked in a quarter of the trips two entries took
+      bool pass[kMkNE]; uint32_t qa[kMkNE], ep[kMkNE];
+#pragma unroll
+      for (int u = 0; u < kMkNE; u++) { pass[u] = false; qa[u] = 0u; ep[u] = 0u; }
       if (act) {
-        const float4 en = ent[e];
-        float4 en2 = en;
-        if (act2) en2 = ent[e + kMkL];
-        pass = test(en, e < nbrute, qa1); ep1 = __float_as_uint(en.w);
-        if (act2) { pass2 = test(en2, e + kMkL < nbrute, qa2); ep2 = __float_as_uint(en2.w); }
-        e += 2 * kMkL;
+        float4 en[kMkNE];
+#pragma unroll
+        for (int u = 0; u < kMkNE; u++) en[u] = (e + u * kMkL < e1) ? ent[e + u * kMkL] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int u = 0; u < kMkNE; u++)
+          if (e + u * kMkL < e1) { pass[u] = test(en[u], e + u * kMkL < nbrute, qa[u]); ep[u] = __float_as_uint(en[u].w); }
+        e += kMkNE * kMkL;
       }
-      if (__ballot(pass)) {
-        Q.push(pass, qa1, ep1, qpos);
-        if (Q.count >= 64) drain(64);
-      }
-      if (__ballot(pass2)) {
-        Q.push(pass2, qa2, ep2, qpos);
-        if (Q.count >= 64) drain(64);
+#pragma unroll
+      for (int u = 0; u < kMkNE; u++) {
+        if (__ballot(pass[u])) {
+          Q.push(pass[u], qa[u], ep[u], qpos);
+          if (Q.count >= 64) drain(64);
+        }
       }
     }
   }
@@ -853,7 +857,9 @@ __device__ __forceinline__ void mk_decide_phase(const MkArgs& a, float* scr_wave
   MkCtl* c = a.ctl;
   const int lane = threadIdx.x & 63;
   int n1 = c->n1; if (n1 > a.cap1) n1 = a.cap1;
-  const int gw = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6), nw = (int)((gridDim.x * blockDim.x) >> 6);
+  // (wave w of workgroup b takes trips w * #workgroups + b, ...: a short list -- a third of the waves have a trip -- spreads over all
+  //  CUs, one or two waves each, instead of filling the first third of the workgroups with eight waves that share four SIMDs)
+  const int gw = (int)((threadIdx.x >> 6) * gridDim.x + blockIdx.x), nw = (int)((gridDim.x * blockDim.x) >> 6);
   for (int base = gw * 64; base < n1; base += nw * 64) {
     const int i = base + lane;
     int res = 0; uint4 p = make_uint4(0u, 0u, 0u, 0u);
@@ -924,7 +930,7 @@ __global__ __launch_bounds__(kMkThreads) void k_mk_select(MkArgs a) {
   mk_select_phase(a, *reinterpret_cast<MkLdsSelect*>(mk_smem), &t0);
 }
 template <bool CROSS>
-__global__ __launch_bounds__(kMkProbeThreads, 5) void k_mk_probe(MkArgs a) {
+__global__ __launch_bounds__(kMkProbeThreads, 4) void k_mk_probe(MkArgs a) {
   __shared__ MkLdsProbe<kMkProbeWaves> S;
   const MkCtl* c = a.ctl;
   if (c->done || c->bail || c->stage != (CROSS ? 3 : 1)) return;
