@@ -81,3 +81,26 @@ def test_native_rectangle_against_opencv_when_present():
         assert abs(w * h - nw * nh) <= 1e-3 * max(1.0, w * h)   # the same minimum area (float vs double implementation)
         if abs(w - h) > 1e-2 * max(w, h) and w * h > 1.0:
             assert abs(cx - nx) < 0.05 and abs(cy - ny) < 0.05
+
+
+def test_documented_opencv_convention_on_exact_shapes():
+    """cv2.minAreaRect since OpenCV 4.5.1 reports the angle in (0, 90] and the extent ALONG that direction as the width: an upright
+    w x h rectangle comes back as ((cx, cy), (h, w), 90), a square standing on a corner as (.., (a, a), 45), a rectangle turned by
+    t in (0, 90) degrees as (.., (w, h), t).  The native rectangle follows that convention on exact shapes (all four hull edges give
+    the same rectangle: no tie to break), and the reference's long-edge normalisation behind it (utils/rboxs_utils.py:61-70) lands
+    on theta = -pi/2 (angle label 0) for the upright square -- the value the CSL training labels are built from."""
+    (c, (w, h), a) = R._min_area_rect(np.float32([[0, 0], [10, 0], [10, 4], [0, 4]]))
+    assert np.allclose(c, (5, 2)) and np.allclose((w, h), (4, 10)) and a == 90.0
+    (c, (w, h), a) = R._min_area_rect(np.float32([[0, 5], [5, 0], [10, 5], [5, 10]]))
+    assert np.allclose(c, (5, 5)) and np.allclose((w, h), (50 ** 0.5, 50 ** 0.5)) and abs(a - 45.0) < 1e-9
+    for t in (10.0, 30.0, 60.0, 89.0):
+        r = np.deg2rad(t)
+        u, v = np.array([np.cos(r), np.sin(r)]), np.array([-np.sin(r), np.cos(r)])
+        quad = np.array([100 + 15 * u + 4 * v, 100 + 15 * u - 4 * v, 100 - 15 * u - 4 * v, 100 - 15 * u + 4 * v])
+        (c, (w, h), a) = R._min_area_rect(quad)
+        assert np.allclose(c, (100, 100), atol=1e-9) and abs(w - 30) < 1e-9 and abs(h - 8) < 1e-9 and abs(a - t) < 1e-9
+    # through poly2rbox: the upright square and the upright rectangles in both orientations
+    out = R.poly2rbox(np.float64([[0, 0, 10, 0, 10, 10, 0, 10], [0, 0, 10, 0, 10, 4, 0, 4], [0, 0, 4, 0, 4, 10, 0, 10]]), use_pi=True)
+    assert np.allclose(out[0], [5, 5, 10, 10, -R.pi / 2])
+    assert np.allclose(out[1, :4], [5, 2, 10, 4]) and abs(_ang_diff(out[1, 4], 0.0, R.pi)) < 1e-12
+    assert np.allclose(out[2, :4], [2, 5, 10, 4]) and abs(_ang_diff(out[2, 4], R.pi / 2, R.pi)) < 1e-12 and out[2, 4] < 0
