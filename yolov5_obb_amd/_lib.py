@@ -122,8 +122,23 @@ def compiled():
                 import importlib.util
                 loader = importlib.machinery.ExtensionFileLoader("nms_rotated_ext_c", EXT_PATH)
                 spec = importlib.util.spec_from_file_location("nms_rotated_ext_c", EXT_PATH, loader=loader)
-                mod = importlib.util.module_from_spec(spec)
-                loader.exec_module(mod)
+                try:
+                    mod = importlib.util.module_from_spec(spec)
+                    loader.exec_module(mod)
+                    lib()                          # the library must load (ImportError with build instructions otherwise)
+                    mod.init(LIB_PATH)
+                except (ImportError, RuntimeError, OSError) as e:
+                    # a stale artefact (built against another torch / ROCm) or a missing symbol: OBB_BINDING=compiled insists,
+                    # the default falls back to the ctypes binding of the same library -- once, with a warning
+                    if os.environ.get("OBB_BINDING", "auto").lower() == "compiled":
+                        raise
+                    import warnings
+                    warnings.warn(f"{EXT_PATH} did not load ({type(e).__name__}: {e}): yolov5_obb_amd uses its ctypes binding of "
+                                  "libobb_hip.so (same kernels, slower host side); rebuild with __graft_entry__.build()")
+                    mod = None
+                    lib()                          # (the library itself must load either way)
+                _ext, _ext_tried = mod, True
+                return _ext
             elif os.environ.get("OBB_BINDING", "auto").lower() == "compiled":
                 raise ImportError(f"{EXT_PATH} not found: run `python -c 'import __graft_entry__ as g; g.build()'`")
             else:
@@ -153,6 +168,15 @@ def checked_count(n, what):
     return n
 
 
+_abort_retries = [0]
+
+
+def abort_retries():
+    """Calls of this process that a barrier time-out of the persistent NMS kernel sent to the 8-workgroup grid (both bindings)."""
+    ext = compiled()
+    return _abort_retries[0] + (int(ext.abort_retries()) if ext is not None and hasattr(ext, "abort_retries") else 0)
+
+
 def retry_on_abort(run):
     """The persistent NMS kernel needs all its workgroups resident (include/obb_hip.h: obb_nms_set_max_grid).  When a call
     aborts on a barrier, run it once more with a grid of 8 workgroups -- resident under any CU mask -- before giving up."""
@@ -160,6 +184,7 @@ def retry_on_abort(run):
         return run()
     except NmsAborted:
         L = lib()
+        _abort_retries[0] += 1
         L.obb_nms_set_max_grid(8)
         try:
             return run()

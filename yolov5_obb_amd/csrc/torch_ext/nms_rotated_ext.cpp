@@ -143,9 +143,10 @@ void require_cuda(const at::Tensor& t, const char* name) {      // _lib.require_
     throw std::runtime_error(std::string(name) + " must be a CUDA/HIP tensor: yolov5_obb_amd is compiled for MI355X only (no CPU path, by design)");
 }
 
+std::atomic<long long> g_abort_retries{0};   // calls of this process that were repeated on the 8-workgroup grid (tests report it: abort_retries())
 struct AbortRetry {            // obb_nms_set_max_grid(8) for one retry of the calling thread, restored on every path
   bool capped = false;
-  void cap() { api.obb_nms_set_max_grid(8); capped = true; }
+  void cap() { api.obb_nms_set_max_grid(8); capped = true; g_abort_retries.fetch_add(1, std::memory_order_relaxed); }
   ~AbortRetry() { if (capped) api.obb_nms_set_max_grid(0); }
 };
 
@@ -558,6 +559,8 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("non_max_suppression_obb", &non_max_suppression_obb, py::arg("prediction"), py::arg("conf_thres") = 0.25, py::arg("iou_thres") = 0.45,
         py::arg("classes") = py::none(), py::arg("agnostic") = false, py::arg("multi_label") = false, py::arg("extra") = py::none(),
         py::arg("max_det") = 1500, py::arg("objcol") = py::none());
+  m.def("abort_retries", []() { return (long long)g_abort_retries.load(std::memory_order_relaxed); },
+        "calls of this process that a barrier time-out of the persistent NMS kernel sent to the 8-workgroup grid");
   m.def("hints_clear", &hints_clear, "forget the hint memo of the calling thread");
   m.def("hint_get", &hint_get, py::arg("device_index"), py::arg("A"), py::arg("nc"), py::arg("multi_label"), py::arg("conf_thres"));
   m.def("hint_set", &hint_set, py::arg("device_index"), py::arg("A"), py::arg("nc"), py::arg("multi_label"), py::arg("conf_thres"),

@@ -36,8 +36,14 @@ _SEG_SMALL = 384        # workgroup-per-segment kernel of csrc/nms_small.h takes
 _small_memo = {}        # same key -> the previous call met boxes with a sub-pixel side (status[1] bit 62): the next call runs k_tiny_cross
 
 
+_MEMO_LIMIT = 512       # keys (device, thread, shape, threshold): thread churn or a swept threshold must not grow the memos without bound
+
+
 def _key(dev_index, A, nc, multi, conf_thres):
     # per device, calling thread and confidence threshold: other callers' batches say nothing about this one's
+    if len(_cap_memo) > _MEMO_LIMIT:          # hints only: forgetting them costs the next call of every shape one generic pass
+        for d in (_cap_memo, _cand_memo, _seg_memo, _hold, _small_memo):
+            d.clear()
     return (dev_index, threading.get_ident(), int(A), int(nc), bool(multi), float(conf_thres))
 
 
