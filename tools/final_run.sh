@@ -1,11 +1,11 @@
 #!/bin/bash
 # Full measurement set of a round on the GPU box (run through gpurun from the repo root):
 #   bash tools/final_run.sh <tag> [round]   -> gpurun_out/<tag>/{pytest_gpu.log, smoke.log, bench.json, *_kernel_stats.md, pmc_*.md}
-# and, on the box, profiles/<round>_pmc.json + <round>_sq.{md,json} (default round: r5) so that the bench line of the same call reads this run's counters.
+# and, on the box, profiles/<round>_pmc.json + <round>_sq_step.{md,json} (default round: r6; the 100k NMS regimes: tools/r6_nms_prof.sh -> <round>_sq.{md,json}) so that the bench line of the same call reads this run's counters.
 # rocprofv3 writes rocpd SQLite databases (tens of MB): they stay in /tmp, only the markdown summaries come back.
 # SKIP_SQ=1: without the three SQ counter passes (profiles/<round>_sq.* stay as they are); SKIP_HIPTRACE=1: without the traced validation loop.
 TAG=${1:-run}
-RND=${2:-r5}
+RND=${2:-r6}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/$TAG
 mkdir -p $O
@@ -35,10 +35,13 @@ i=0; DBS=""
 done
 if [ -z "$SKIP_SQ" ]; then
 python tools/rocpd_sq.py "rocprofv3 --kernel-trace --pmc <8 SQ counters + GRBM_GUI_ACTIVE> -- python tools/prof_sq.py (three passes, SQ_REPS=3)" 3 $DBS > $O/sq.md 2> $O/sq.err
-python tools/sq_json.py $O/sq.md > $O/sq.json 2>> $O/sq.err && cp $O/sq.json profiles/${RND}_sq.json && cp $O/sq.md profiles/${RND}_sq.md
+python tools/sq_json.py $O/sq.md > $O/sq.json 2>> $O/sq.err && cp $O/sq.json profiles/${RND}_sq_step.json && cp $O/sq.md profiles/${RND}_sq_step.md
 fi
 # the counters feed bench.py's `traffic` fields: refresh the json before the bench line is produced
 python tools/pmc_json.py gpurun_out/$TAG/pmc_fetch.md gpurun_out/$TAG/pmc_write.md gpurun_out/$TAG/kernel_stats.md > $O/pmc.json 2> $O/pmc_json.err && cp $O/pmc.json profiles/${RND}_pmc.json
+# the single-list NMS at 100k, per regime: kernel traces, HBM bytes of the whole call, SQ counters (adds its keys to profiles/<round>_pmc.json)
+[ -n "$SKIP_NMS100K" ] || bash tools/r6_nms_prof.sh $TAG > $O/r6_nms_prof.log 2>&1
+cp profiles/${RND}_*.md profiles/${RND}_*.json $O/ 2>/dev/null
 # the HIP API timeline of the validation loop on the ctypes binding with torch's default thread count (the configuration that showed the
 # 70-88 ms stalls of rounds 2-4, before its val tail stopped issuing parallel CPU ops) next to the cgroup's throttle counters, and the same
 # loop on the compiled binding: profiles/r5_host_stall.md (the measurement that found the cause is gpurun_out/r5d/cgroup.txt, quoted there)
