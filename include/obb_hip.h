@@ -63,7 +63,15 @@ int obb_profile_collect(double* ms_sum_host, int64_t* count_host, int n_stages);
 /* Environment variables read by the library (once per process).  Every build:
  *   OBB_NMS_POLY_STRICT=1   quad NMS: only the proved skip rule (csrc/piou_device.h: the cone rule); =2: no rule at all, every pair
  *                           is clipped like the reference does (tests/test_nms_gpu.py::test_nms_poly_strict_equals_skip_100k)
- *   OBB_NMS_PHASE_PROF=1    in-kernel phase timers of the persistent NMS kernel, printed to stderr (synchronises; development aid)
+ *   OBB_NMS_PHASE_PROF=1    in-kernel phase timers of the single-list NMS (either path), printed to stderr (synchronises; development aid)
+ * Read per call (tests switch paths inside one process; nothing but speed depends on them -- the kept list is the same on every path):
+ *   OBB_NMS_MK=0 | 1 | 2    single-list rotated NMS of >= 16384 boxes: 0 the persistent kernel (csrc/nms_core.h), 1 the phase kernels
+ *                           (csrc/nms_mk.h), 2 = default: the library's choice from what the calling thread's previous calls of the size
+ *                           class reported (kept boxes, independent slabs, device time of either path)
+ *   OBB_NMS_MK_XLDS=0 | 1   phase kernels: the cross probe on the chunk's table in global memory (0) or on a table of the kept rows in
+ *                           every workgroup's LDS (1); default: 1 where the previous call kept <= 6144 boxes
+ * Read once per process, tests only: OBB_NMS_MK_STEPS (enqueued steps), OBB_NMS_MK_PEND (pending-list capacity), OBB_NMS_MK_CHUNK
+ * (first chunk): they force the hand-overs to the persistent kernel that tests/test_nms_mk_gpu.py checks.
  * Development builds only (make DEV=1; ignored otherwise): the A/B switches OBB_NMS_NO_GRID, OBB_NMS_NO_SLABS, OBB_NO_CLASS_SEG,
  * OBB_NO_LDS_SORT, OBB_NMS_GROUP_AFTER_CUT, OBB_NMS_CHUNK*, OBB_NMS_GROW, OBB_NMS_SLAB_CAP, OBB_GRID_FINE, OBB_LOSS_NT. */
 
@@ -86,6 +94,11 @@ size_t obb_nms_workspace_bytes(int64_t n, int64_t nseg, int kind);
  *   keep_out [n] int64: original indices of kept boxes in descending-score order
  *            (ties: ascending index; NaN scores first -- torch.sort's order)
  *   num_keep [1] int64 (device)
+ * Lists of >= 16384 boxes without max_keep: two implementations of the same lazy chunked greedy NMS sit behind this entry -- a chain
+ * of ordinary launches, one per phase (no co-residency needed), and one persistent kernel behind spin barriers (see
+ * obb_nms_set_max_grid) -- and the library takes the one that was faster for the calling thread's previous calls of the size class
+ * (four pinned words per size class that the device writes and the host reads without synchronising).  The persistent kernel is always
+ * launched last: it completes whatever the enqueued phases left undone and returns at once otherwise.
  */
 int obb_nms_rotated_f32(const float* dets5, const float* scores, int64_t n, float iou_thr, int flags, int64_t max_keep,
                         int64_t* keep_out, int64_t* num_keep, void* ws, size_t ws_bytes, void* stream);
@@ -228,7 +241,13 @@ int64_t obb_task1_format_rows(const char* text_host, const int32_t* name_off_hos
  *               held boxes with a sub-pixel short side -- hand these back as expected_cand of the next call of the shape; bit 61
  *               (informational, masked out of the hint): such an image kept its class segments in this call
  *               out_count and status are written with plain 8-byte stores by the last kernel of the call: they may live in
- *               device memory or in pinned host memory (hipHostMalloc) that the caller polls instead of copying back
+ *               device memory or in pinned host memory (hipHostMalloc) that the caller polls instead of copying back.
+ *               What a polled word publishes is the COUNT, nothing else: the kernel that writes out_count[b] / status may still be
+ *               storing rows of `out` (of image b and of the images in flight) and reading `ws` at that moment.  `out` is complete and
+ *               `ws` is reusable in STREAM ORDER only: a consumer on the call's stream needs nothing more; a consumer on another stream
+ *               or on the host records / waits for an event behind the call (or synchronises the stream) before it touches `out` or
+ *               hands `ws` to anybody else.  (The bindings of this repository return views of `out` to same-stream consumers and keep
+ *               `ws` in a per-stream cache.)
  * Score ties are ordered by ascending (anchor*nc + class): deterministic, where the reference inherits the order
  * of torch's unstable sort.
  */

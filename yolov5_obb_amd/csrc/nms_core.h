@@ -1582,8 +1582,19 @@ OBB_COLD_GRID int grid_build(const NmsArgs& a, const GridPlan& gp, int c0, int w
   if (!team_barrier(bar, s_flag)) return 1;
   // ONE acquire per workgroup (the caches it invalidates are the CU's and the XCD's, not the wave's), as in serial_wait: with every
   // wave of every workgroup issuing its own, 2048 invalidates queued up behind each other -- ~14 us in k_slab_split, where the
-  // timers showed it (round 5)
+  // timers showed it (round 5).
+  // What relies on it: everything another workgroup wrote before this barrier is read with PLAIN loads afterwards --
+  // gstart / gsorted / gslot / the unindexed list here, the slab-major records, order, old positions and alive2 behind slab_setup's
+  // barrier (which has no fence of its own: its readers use ldg_agent on slab_cnt / slab_tot), kept_bits behind slab_merge's.  The
+  // writers publish with write-through stores (stg_agent) or device atomics; a NEW plain read of such a buffer behind one of these
+  // barriers is only safe behind this fence + __syncthreads, a new read without them must be an ldg_agent.  A build with
+  // -DOBB_NMS_FULL_FENCE (make HIPCC="hipcc -DOBB_NMS_FULL_FENCE") issues the fence from every wave again: the A/B for a suspected
+  // stale read.
+#ifdef OBB_NMS_FULL_FENCE
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#else
   if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#endif
   __syncthreads();
   return 0;
 }
