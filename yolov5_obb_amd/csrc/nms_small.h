@@ -188,16 +188,32 @@ __device__ __forceinline__ void small_segment(const SmallArgs& a, unsigned char*
       const float4 cq = s_rec[(j < n ? j : 0) * G::RECQ];
       const int i0 = ti * 64 + quarter * 16;
       const u64 arow = s_alive[ti] >> (quarter * 16);
-#pragma unroll 4
-      for (int r = 0; r < 16; r++) {
-        const int i = i0 + r;
-        if (i >= n) break;                                       // (wave-uniform)
-        if (!((arow >> r) & 1ull)) continue;
-        const float4 rq = s_rec[i * G::RECQ];                    // (all lanes the same address: a broadcast)
-        const bool pass = jv && i < j && !G::cheap_reject(rq, cq);
-        if (__ballot(pass)) {
-          Q0.push(pass, ((uint32_t)i << 16) | (uint32_t)j);
-          if (Q0.count >= 64) drain0(64);
+      // Four rows per trip: their quads are requested together (broadcast reads of one address each), the four circle tests run
+      // back to back, then the pushes (round 6: 66.6 -> 65.3 us for the bs16 step's kernel).  What the per-segment stamps of that
+      // step say about the rest: the segments that set the kernel's time (200-250 boxes) spend 28-33 us in their slices -- ~4 us per
+      // slice and wave, of which 1 us is its quick-stage drain --, 17-20 us in the pooled leftovers (one clip drain = 10 us), 3 us in
+      // the scan and 6 us in the image's output stage; a wave of such a workgroup is bound by its own instruction stream (one
+      // instruction per 8 cycles with two waves per SIMD), not by memory.  Measured and not kept: running the interval stage and the
+      // clip lazily (rings drained only above 64 before a push, everything else left to the pooled passes): 66.6 -> 67.1 us.
+#pragma unroll 1
+      for (int r0 = 0; r0 < 16; r0 += 4) {
+        if (i0 + r0 >= n) break;                                 // (wave-uniform)
+        if (((arow >> r0) & 15ull) == 0ull) continue;            // none of the four rows takes part
+        float4 rq[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { const int i = i0 + r0 + u; rq[u] = s_rec[(i < n ? i : 0) * G::RECQ]; }   // (all lanes the same address: a broadcast)
+        bool pass[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const int i = i0 + r0 + u;
+          pass[u] = jv && i < n && ((arow >> (r0 + u)) & 1ull) && i < j && !G::cheap_reject(rq[u], cq);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          if (__ballot(pass[u])) {
+            Q0.push(pass[u], ((uint32_t)(i0 + r0 + u) << 16) | (uint32_t)j);
+            if (Q0.count >= 64) drain0(64);
+          }
         }
       }
     }
