@@ -157,37 +157,23 @@ constexpr int kMkBruteCtr = kMkSlots + kMkTabPad + 8;
 
 // ------------------------------------------------------------------ the table of a chunk (ONE workgroup of kMkThreads)
 // members k = 0 .. cnt-1 (cnt <= kMkCapMax) at positions list[k] (LDS, ascending).
-// Quad 0 of every member is fetched ONCE (kMkPer independent loads per thread) and stays in registers through the two passes of
-// the counting sort (counts, scatter): the passes cost LDS time, not a chain of memory round trips.
+// Quad 0 of every member is fetched ONCE (up to 2 x kMkPer independent loads per thread) and stays in registers through the two passes
+// of the counting sort (counts, scatter): the passes cost LDS time, not a chain of memory round trips.
 // A box above the data's radius limit (MkData::rcap) would widen every query's window; it becomes a "brute" entry like the boxes
 // that are not finite or not well conditioned for any partner inside the data's bounding box.
 __device__ void mk_build_table(const MkArgs& a, const float4* __restrict__ rec, const uint32_t* s_list, int cnt, const MkData& D, MkGrid* g_out,
                                float4* __restrict__ ent, uint16_t* __restrict__ start_g, MkLdsBuild& S) {
   const int tid = threadIdx.x;
   u64 tb = a.prof ? wall_clock64() : 0ull;
-  // a chunk above kMkTile members goes through the two passes tile by tile and fetches its quads once per pass
-  const int ntile = (cnt + kMkTile - 1) / kMkTile;
-  float4 q[kMkPer];
-  uint32_t pos[kMkPer];
-  auto load_tile = [&](int t) {
-#pragma unroll
-    for (int u = 0; u < kMkPer; u++) {
-      const int k = t * kMkTile + tid + u * kMkThreads;
-      pos[u] = k < cnt ? s_list[k] : 0u;
-    }
-#pragma unroll
-    for (int u = 0; u < kMkPer; u++) {
-      const int k = t * kMkTile + tid + u * kMkThreads;
-      q[u] = k < cnt ? rec[(size_t)pos[u] * 4] : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-  };
-  load_tile(0);
-  for (int s2 = tid; s2 < kMkSlots + kMkTabPad + 40; s2 += kMkThreads) S.tab[s2] = 0;
+  // A chunk has at most two tiles of kMkTile members.  BOTH stay in registers from their one fetch to the scatter -- x, y, radius,
+  // position and slot of 2 x kMkPer members per thread (round 6, second half: a chunk above kMkTile members went through the two
+  // passes tile by tile and fetched its quads once per pass: four dependent rounds of gathers instead of one, 24 us of the 27 us
+  // a 16,384-member table took one workgroup).
+  const bool two = cnt > kMkTile;                        // (workgroup-uniform)
   // the geometry: the data's bounding box and radius limit (fixed per call, MkData) and a cell side chosen by the density of THIS
   // chunk -- 3/4 of the radius limit when a query meets many entries (their number decides the work), twice the limit when it
   // meets a handful (then the number of cell rows a query walks decides it)
   const float rcap = D.rcap, dmax2 = D.dmax2;
-  auto brute = [&](const float4& v) -> bool { return !mk_finite3(v.x, v.y, v.z) || !(v.w >= kGridIllCond * dmax2) || (v.z > rcap); };
   MkGrid g;
   g.total = cnt; g.rmax = __uint_as_float(mk_rup(rcap));
   {
@@ -205,21 +191,41 @@ __device__ void mk_build_table(const MkArgs& a, const float4* __restrict__ rec, 
     if (!(fy >= 0.f)) g.cyl = 0;
   }
   for (int k = 0; k < 7; k++) g.pad[k] = 0;
-  __syncthreads();
-  if (a.prof) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); mk_lap(a, 12, &tb); }
-  // pass 1: counts per slot
   auto slot_of = [&](const float4& v) -> int {
-    return brute(v) ? kMkBruteCtr : mk_pad(mk_slot(mk_cell(v.x, g.x0, g.inv, g.cxl), mk_cell(v.y, g.y0, g.inv, g.cyl)));
+    const bool brute = !mk_finite3(v.x, v.y, v.z) || !(v.w >= kGridIllCond * dmax2) || (v.z > rcap);
+    return brute ? kMkBruteCtr : mk_pad(mk_slot(mk_cell(v.x, g.x0, g.inv, g.cxl), mk_cell(v.y, g.y0, g.inv, g.cyl)));
   };
-  int slot[kMkPer];
-  for (int t = 0; t < ntile; t++) {
-    if (t > 0) load_tile(t);
+  float ex[2][kMkPer], ey[2][kMkPer], ez[2][kMkPer];
+  uint32_t pos[2][kMkPer];
+  int slot[2][kMkPer];
+  // one fetch: the positions (LDS), then every quad (2 x kMkPer independent loads per thread), the slot computed as the quad arrives
+  auto fetch = [&](int t) {
+    float4 q[kMkPer];
+#pragma unroll
+    for (int u = 0; u < kMkPer; u++) { const int k = t * kMkTile + tid + u * kMkThreads; pos[t][u] = k < cnt ? s_list[k] : 0u; }
 #pragma unroll
     for (int u = 0; u < kMkPer; u++) {
       const int k = t * kMkTile + tid + u * kMkThreads;
-      slot[u] = -1;
-      if (k < cnt) { slot[u] = slot_of(q[u]); atomicAdd(&S.tab[slot[u]], 1); }
+      q[u] = k < cnt ? rec[(size_t)pos[t][u] * 4] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
+#pragma unroll
+    for (int u = 0; u < kMkPer; u++) {
+      const int k = t * kMkTile + tid + u * kMkThreads;
+      ex[t][u] = q[u].x; ey[t][u] = q[u].y; ez[t][u] = q[u].z;
+      slot[t][u] = k < cnt ? slot_of(q[u]) : -1;
+    }
+  };
+  for (int s2 = tid; s2 < kMkSlots + kMkTabPad + 40; s2 += kMkThreads) S.tab[s2] = 0;
+  fetch(0);
+  if (two) fetch(1);
+  __syncthreads();
+  if (a.prof) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); mk_lap(a, 12, &tb); }
+  // pass 1: counts per slot
+#pragma unroll
+  for (int u = 0; u < kMkPer; u++) if (slot[0][u] >= 0) atomicAdd(&S.tab[slot[0][u]], 1);
+  if (two) {
+#pragma unroll
+    for (int u = 0; u < kMkPer; u++) if (slot[1][u] >= 0) atomicAdd(&S.tab[slot[1][u]], 1);
   }
   __syncthreads();
   mk_lap(a, 14, &tb);
@@ -257,22 +263,24 @@ __device__ void mk_build_table(const MkArgs& a, const float4* __restrict__ rec, 
   __syncthreads();
   mk_lap(a, 15, &tb);
   // pass 2: scatter
-  for (int t = 0; t < ntile; t++) {
-    if (ntile > 1) load_tile(t);
+  auto scatter = [&](int t) {
 #pragma unroll
     for (int u = 0; u < kMkPer; u++) {
-      const int k = t * kMkTile + tid + u * kMkThreads;
-      if (k < cnt) {
-        const int e = atomicAdd(&S.tab[ntile > 1 ? slot_of(q[u]) : slot[u]], 1);
-        ent[e] = make_float4(q[u].x, q[u].y, __uint_as_float(mk_rup(q[u].z) | (uint32_t)k), __uint_as_float(pos[u]));
+      if (slot[t][u] >= 0) {
+        const int k = t * kMkTile + tid + u * kMkThreads;
+        const int e = atomicAdd(&S.tab[slot[t][u]], 1);
+        ent[e] = make_float4(ex[t][u], ey[t][u], __uint_as_float(mk_rup(ez[t][u]) | (uint32_t)k), __uint_as_float(pos[t][u]));
       }
     }
-  }
+  };
+  scatter(0);
+  if (two) scatter(1);
   if (tid == 0) *g_out = g;
   if (a.prof) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
   __syncthreads();
   mk_lap(a, 16, &tb);
 }
+static_assert(kMkCapMax == 2 * kMkTile, "mk_build_table holds a chunk as two tiles");
 static_assert(kMkSlots / kMkThreads == 16, "the slot starts are written as two 16-byte stores per thread");
 
 // The data as a whole from the key kernel's per-workgroup partials (nms.hip: local_extras): bounding box of the finite centres,
