@@ -391,7 +391,8 @@ __global__ void k_seg_from_offsets(const int32_t* __restrict__ seg_off, int nseg
 // by (mk_choose below) -- the number of kept boxes and whether the list fell apart into independent slabs.
 __global__ void k_finalize(const int* __restrict__ keep_cnt, const int* __restrict__ seg_begin, int nseg, long long max_keep,
                            const int* __restrict__ abort_flag, int64_t* __restrict__ num_keep, int64_t* __restrict__ seg_begin_out,
-                           int* feedback = nullptr, const SlabPlan* slab_plan = nullptr, int feedback_slab = 0, const u64* tstart = nullptr) {
+                           int* feedback = nullptr, const SlabPlan* slab_plan = nullptr, int feedback_slab = 0, const u64* tstart = nullptr,
+                           const NmsResume* mk_ctl = nullptr, int mk_enqueued = 0) {
   int g = blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= nseg) return;
   if (seg_begin_out) seg_begin_out[g] = seg_begin[g];
@@ -403,7 +404,11 @@ __global__ void k_finalize(const int* __restrict__ keep_cnt, const int* __restri
     // (only a call that looked for slabs reports on them: the phase-kernel path leaves the word alone)
     if (feedback_slab) __hip_atomic_store(feedback + 2, (slab_plan != nullptr && slab_plan->mode == 1) ? 1 : 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     // how long the call took on the device (10 ns ticks from its first kernel to this one) and which path it was: [4 + path]
-    if (tstart != nullptr) {
+    // (a phase-kernel call that merely ran out of enqueued steps -- a stale step count from other data of this size class -- and was
+    //  finished by the persistent kernel says nothing about the phase kernels' speed: its time is not recorded, the thread's next
+    //  call enqueues twice the steps (hint -2) and reports then.  A call that bailed out, or had 32 steps, does report.)
+    const bool starved = mk_ctl != nullptr && mk_ctl->done == 0 && mk_ctl->bail == 0 && mk_enqueued < 32;
+    if (tstart != nullptr && !starved) {
       const u64 dtk = wall_clock64() - *tstart;
       __hip_atomic_store(feedback + 4 + (feedback_slab ? 0 : 1), (int)(dtk > 0x3fffffffull ? 0x3fffffffull : dtk), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
@@ -917,7 +922,8 @@ static int run_nms(int kind, const float* boxes, int stride, const float* scores
     if (rc) return rc;
   }
   k_finalize<<<gseg, T, 0, st>>>(cv.keep_cnt, cv.seg_begin, (int)nseg, max_keep, cv.abort_flag, num_keep, nullptr, fbk ? fbk->words : nullptr,
-                                 a.slab_plan, use_mk ? 0 : 1, fbk ? cv.tstart : nullptr);
+                                 a.slab_plan, use_mk ? 0 : 1, fbk ? cv.tstart : nullptr,
+                                 use_mk ? reinterpret_cast<const NmsResume*>(cv.mk_ctl) : nullptr, (use_mk && fbk) ? *(volatile int*)(fbk->words + 3) : 0);
   return hipGetLastError() == hipSuccess ? OBB_OK : OBB_ERR_LAUNCH;
 }
 
@@ -1189,3 +1195,19 @@ int obb_device_info(int* cu_count, int* wave_size, char* arch_name, int arch_nam
 }
 
 }  // extern "C"
+
+#ifdef OBB_SMALL_TRACE
+// (development builds, tools/small_trace.sh) the stamps of the last k_nms_small launch; both buffers are cleared
+extern "C" int obb_debug_small_trace2(unsigned long long* words) {
+  return hipMemcpyFromSymbol(words, HIP_SYMBOL(obb::g_small_trace2), sizeof(obb::g_small_trace2)) == hipSuccess ? 0 : -1;
+}
+extern "C" int obb_debug_small_trace(unsigned long long* seg_words, unsigned long long* tail_words) {
+  if (hipDeviceSynchronize() != hipSuccess) return -1;
+  if (hipMemcpyFromSymbol(seg_words, HIP_SYMBOL(obb::g_small_trace), sizeof(obb::g_small_trace)) != hipSuccess) return -2;
+  if (hipMemcpyFromSymbol(tail_words, HIP_SYMBOL(obb::g_small_trace_tail), sizeof(obb::g_small_trace_tail)) != hipSuccess) return -3;
+  static unsigned long long zero[2048 * 16];
+  if (hipMemcpyToSymbol(HIP_SYMBOL(obb::g_small_trace), zero, sizeof(obb::g_small_trace)) != hipSuccess) return -4;
+  if (hipMemcpyToSymbol(HIP_SYMBOL(obb::g_small_trace_tail), zero, sizeof(obb::g_small_trace_tail)) != hipSuccess) return -5;
+  return 0;
+}
+#endif

@@ -24,6 +24,13 @@
 
 namespace obb {
 
+#ifdef OBB_SMALL_TRACE
+// (development builds, tools/small_trace.sh) 16 words per workgroup: block, seg | part << 24 | np << 28, n, kept, stamps..., drains
+__device__ unsigned long long g_small_trace[2048 * 16];
+__device__ unsigned long long g_small_trace_tail[2048 * 4];
+__device__ unsigned long long g_small_trace2[2048 * 8];
+#define STRACE(kind, ...) do { if (threadIdx.x == 0 && blockIdx.x < 2048) { const unsigned long long v_[] = {__VA_ARGS__}; unsigned long long* o_ = g_small_trace + blockIdx.x * 16; o_[0] = (kind); for (int z_ = 0; z_ < (int)(sizeof(v_) / 8) && z_ < 15; z_++) o_[1 + z_] = v_[z_]; } } while (0)
+#endif
 constexpr int kSmallMax = OBB_NMS_SMALL_SEG;        // boxes per segment (include/obb_hip.h)
 constexpr int kSmallWords = kSmallMax / 64;         // bit-matrix words per row
 constexpr int kSmallThreads = 512;
@@ -49,11 +56,32 @@ struct SmallArgs {
   unsigned long long* pub_key;             // [n_pos]
   uint32_t* pub_val;
   long long n_pos;
+  // A LARGE segment is shared by several workgroups (round 6, third part): the sort kernel, which knows every segment's size, gives a
+  // segment of more than kSmallSplit1 boxes np - 1 HELPER workgroups (small_parts) from a pool of `helpers` (the first blocks of
+  // the grid: they are dispatched before the segments' own workgroups) -- work[h] = segment | part << 24, seg_np[segment] =
+  // np | first helper << 8.  Part p takes every np-th slice of the pair triangle into its own LDS bit matrix, writes the matrix
+  // through to part_main (part 0: at the segment's positions) or part_help (helper h), and arrives on seg_ticket[segment]; the part
+  // that arrives LAST ors the others' matrices into its own and goes on with the scan, the output and the TAIL.  Nobody waits.
+  // helpers == 0: every segment is one workgroup's.
+  int helpers;
+  const int* help_cnt;                     // [1] helper slots handed out (may exceed `helpers`: the slots beyond were not)
+  const int* work;                         // [helpers]  (-1: a slot whose segment got no full set of helpers and stays whole)
+  const int* seg_np;                       // [nseg]
+  int* seg_ticket;                         // [nseg] zeroed by the sort kernel
+  u64* part_main;                          // [n_pos][kSmallWords]
+  u64* part_help;                          // [helpers][kSmallMax][kSmallWords]
 };
+// parts of a segment of n boxes: the work is the pairs that survive the circle test (~n^2), a part should hold what a 128-box
+// segment holds
+constexpr int kSmallSplit1 = 128;
+constexpr int kSmallHelpMax = 256;
+__host__ __device__ __forceinline__ int small_parts(int n) {
+  return n <= kSmallSplit1 ? 1 : (n <= 192 ? 2 : (n <= 256 ? 4 : (n <= 320 ? 6 : 8)));
+}
 // no output stage: the caller's next launch reads keep_out / keep_cnt
 struct SmallNoTail {
   struct Args {};
-  static __device__ __forceinline__ void run(const SmallArgs&, const Args&, unsigned char*) {}
+  static __device__ __forceinline__ void run(const SmallArgs&, const Args&, unsigned char*, int) {}
 };
 
 // The three decision stages are real functions here (one body each, called from the full drains and from the pooled
@@ -65,15 +93,43 @@ __device__ __attribute__((noinline)) int small_quick(const float4* ra, const flo
   return G::classify_quick(ra, rb, thr, true);
 }
 
+// The circle test of one 16-row x 64-column slice (round 6, third part).  Lane = column; the 16 row quads are fetched by lanes
+// 0..15 in ONE LDS read and handed round with v_readlane (scalar operands of the test), every row costs its ~11 VALU instructions
+// and nothing else -- no branch, no exec-mask change, no push -- and leaves ONE BIT in the lane's word; the caller turns the set
+// bits into queue entries, one push per bit PLANE instead of one per row.  (The loop this replaces tested, balloted and pushed row
+// by row with short-circuit conditions: the compiler made ~100 issue slots per row of it, half of them scalar spills through
+// v_readlane / v_writelane -- 4.2 us per slice, 25 of the 31 us a 249-box segment spent in its slices.)  The arithmetic is
+// RotGeom::cheap_reject's, operation for operation; a function of its own so that it gets a register allocation of its own.
+template <class G>
+__device__ __attribute__((noinline)) uint32_t small_slice_bits(const float4* s_rec, int i0, int n, uint32_t arow16, float4 cq, int j, bool jv) {
+  const int lane = threadIdx.x & 63;
+  const int ir = i0 + (lane & 15);
+  const float4 rq = s_rec[(ir < n ? ir : 0) * G::RECQ];
+  uint32_t bits = 0u;
+#pragma unroll
+  for (int r = 0; r < 16; r++) {
+    const float4 a = rdlane4(rq, r);                            // (wave-uniform: the row box)
+    const float dx = cq.x - a.x, dy = cq.y - a.y;
+    const float rs = a.z + cq.z;
+    const float d2 = dx * dx + dy * dy;
+    const bool apart = (d2 > rs * rs) & (fminf(a.w, cq.w) >= 2.34e-9f * d2);
+    const bool row_ok = ((arow16 >> r) & 1u) != 0u && i0 + r < n;   // (wave-uniform)
+    const bool pass = !apart & jv & (j > i0 + r) & row_ok;
+    bits |= pass ? (1u << r) : 0u;
+  }
+  return bits;
+}
+
 template <class G>
 struct SmallWave {                                  // per wave
   float scr[G::SCR * 64];                           // exact-clip scratch, one column per lane
   uint32_t q0[128], q1[128], q2[128];               // pending (i << 16 | j) pairs of the three stages
 };
 
+// returns the segment when this workgroup completed it (the TAIL follows), -1 when it has nothing (more) to do
 template <class G>
-__device__ __forceinline__ void small_segment(const SmallArgs& a, unsigned char* s_raw) {
-  __shared__ int s_next, s_nkept, s_qcnt[kSmallWaves], s_qhead[kSmallWaves], s_qcnt2[kSmallWaves];
+__device__ __forceinline__ int small_segment(const SmallArgs& a, unsigned char* s_raw) {
+  __shared__ int s_next, s_nkept, s_qcnt[kSmallWaves], s_qhead[kSmallWaves], s_qcnt2[kSmallWaves], s_last;
   __shared__ uint32_t s_kept[kSmallMax];
   __shared__ unsigned long long s_pk[kSmallMax];                 // (publishing) sort key and candidate slot of every position
   __shared__ uint32_t s_pv[kSmallMax];
@@ -81,12 +137,27 @@ __device__ __forceinline__ void small_segment(const SmallArgs& a, unsigned char*
   u64* s_mask = reinterpret_cast<u64*>(s_rec + (size_t)kSmallMax * G::RECQ);         // [kSmallMax][kSmallWords]
   u64* s_alive = s_mask + (size_t)kSmallMax * kSmallWords;                           // [kSmallWords] + pad
   SmallWave<G>* s_wave = reinterpret_cast<SmallWave<G>*>(s_alive + 8);
-  const int seg = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  int seg = (int)blockIdx.x - a.helpers, part = 0, np = 1, hbase = 0;
+  if (seg < 0) {                                                 // a helper (workgroup-uniform): which part of which segment, if any
+    const int h = (int)blockIdx.x;
+    if (h >= *a.help_cnt) {
+#ifdef OBB_SMALL_TRACE
+      STRACE(1ull, (unsigned long long)wall_clock64());
+#endif
+      return -1;
+    }
+    const int e = a.work[h];
+    if (e < 0) return -1;
+    seg = e & 0xffffff; part = e >> 24;
+  }
+  if (a.helpers > 0) { const int v = a.seg_np[seg]; if ((v & 255) > 1) { np = v & 255; hbase = v >> 8; } }
   const int sb = a.seg_begin[seg], n = a.seg_end[seg] - sb;
-  if (n <= 0) return;                                            // (keep_cnt is zero already)
-  if (n > kSmallMax) { if (tid == 0) atomicMax(a.too_big, n); return; }
+  if (n <= 0) return part == 0 ? seg : -1;                       // (keep_cnt is zero already)
+  if (n > kSmallMax) { if (tid == 0 && part == 0) atomicMax(a.too_big, n); return part == 0 ? seg : -1; }
 #ifdef OBB_SMALL_TRACE
   unsigned long long tt[8]; int ti_ = 0, nd0 = 0, nd1 = 0, nd2 = 0, nit = 0;
+  unsigned long long acc_d0 = 0, acc_d1 = 0, acc_d2 = 0, acc_draw = 0, acc_l0 = 0, acc_l1 = 0, acc_l2 = 0;
 #define SSTAMP() do { tt[ti_++] = wall_clock64(); } while (0)
 #else
 #define SSTAMP() do {} while (0)
@@ -173,8 +244,14 @@ __device__ __forceinline__ void small_segment(const SmallArgs& a, unsigned char*
     const int nitems = nb * (nb + 1) / 2 * 4;                    // upper-triangle tiles x four 16-row slices
     for (;;) {
       int it = 0;
+#ifdef OBB_SMALL_TRACE
+      const unsigned long long tdr_ = wall_clock64();
+#endif
       if (lane == 0) it = atomicAdd(&s_next, 1);
-      it = __builtin_amdgcn_readfirstlane(it);
+      it = __builtin_amdgcn_readfirstlane(it) * np + part;       // (a shared segment: every np-th slice is this part's)
+#ifdef OBB_SMALL_TRACE
+      acc_draw += wall_clock64() - tdr_;
+#endif
       if (it >= nitems) break;
 #ifdef OBB_SMALL_TRACE
       nit++;
@@ -187,34 +264,24 @@ __device__ __forceinline__ void small_segment(const SmallArgs& a, unsigned char*
       const bool jv = j < n && ((s_alive[tj] >> lane) & 1ull);
       const float4 cq = s_rec[(j < n ? j : 0) * G::RECQ];
       const int i0 = ti * 64 + quarter * 16;
-      const u64 arow = s_alive[ti] >> (quarter * 16);
-      // Four rows per trip: their quads are requested together (broadcast reads of one address each), the four circle tests run
-      // back to back, then the pushes (round 6: 66.6 -> 65.3 us for the bs16 step's kernel).  What the per-segment stamps of that
-      // step say about the rest: the segments that set the kernel's time (200-250 boxes) spend 28-33 us in their slices -- ~4 us per
-      // slice and wave, of which 1 us is its quick-stage drain --, 17-20 us in the pooled leftovers (one clip drain = 10 us), 3 us in
-      // the scan and 6 us in the image's output stage; a wave of such a workgroup is bound by its own instruction stream (one
-      // instruction per 8 cycles with two waves per SIMD), not by memory.  Measured and not kept: running the interval stage and the
-      // clip lazily (rings drained only above 64 before a push, everything else left to the pooled passes): 66.6 -> 67.1 us.
-#pragma unroll 1
-      for (int r0 = 0; r0 < 16; r0 += 4) {
-        if (i0 + r0 >= n) break;                                 // (wave-uniform)
-        if (((arow >> r0) & 15ull) == 0ull) continue;            // none of the four rows takes part
-        float4 rq[4];
-#pragma unroll
-        for (int u = 0; u < 4; u++) { const int i = i0 + r0 + u; rq[u] = s_rec[(i < n ? i : 0) * G::RECQ]; }   // (all lanes the same address: a broadcast)
-        bool pass[4];
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-          const int i = i0 + r0 + u;
-          pass[u] = jv && i < n && ((arow >> (r0 + u)) & 1ull) && i < j && !G::cheap_reject(rq[u], cq);
-        }
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-          if (__ballot(pass[u])) {
-            Q0.push(pass[u], ((uint32_t)(i0 + r0 + u) << 16) | (uint32_t)j);
-            if (Q0.count >= 64) drain0(64);
-          }
-        }
+      const uint32_t arow16 = (uint32_t)(s_alive[ti] >> (quarter * 16)) & 0xffffu;
+      if (i0 >= n || arow16 == 0u) continue;                     // (wave-uniform)
+      // the slice's circle tests leave a bit per (row, column) in the column's lane; a push per bit plane (small_slice_bits).
+      // What the per-segment stamps say about the rest (bs16 step, segments of 200-250 boxes): 17-20 us in the pooled leftovers
+      // (quick 3-7, interval 5.8, one clip drain 8 us), 3-4 us in the scan; a wave of such a workgroup is bound by its own
+      // instruction stream, not by memory.  Measured and not kept: running the interval stage and the clip lazily (rings
+      // drained only above 64 before a push, everything else left to the pooled passes): 66.6 -> 67.1 us.
+      uint32_t bits = small_slice_bits<G>(s_rec, i0, n, arow16, cq, j, jv);
+      while (__ballot(bits != 0u)) {                             // (wave-uniform)
+        const bool has = bits != 0u;
+        const int r = __builtin_ctz(bits | 0x10000u);
+        Q0.push(has, ((uint32_t)(i0 + r) << 16) | (uint32_t)j);
+        bits &= bits - 1u;
+#ifdef OBB_SMALL_TRACE
+        if (Q0.count >= 64) { const unsigned long long td_ = wall_clock64(); drain0(64); acc_d0 += wall_clock64() - td_; }
+#else
+        if (Q0.count >= 64) drain0(64);
+#endif
       }
     }
     SSTAMP();
@@ -223,6 +290,10 @@ __device__ __forceinline__ void small_segment(const SmallArgs& a, unsigned char*
     // read as one list, 64 entries per wave, by as few waves as it takes (what a wave decides goes to its own next ring).
     for (int stage = 0; stage < 3; stage++) {
       PairQueue& Q = stage == 0 ? Q0 : (stage == 1 ? Q1 : Q2);
+#ifdef OBB_SMALL_TRACE
+      const unsigned long long tl_ = wall_clock64();
+      struct LeftT { unsigned long long& a; unsigned long long t; __device__ ~LeftT() { a += wall_clock64() - t; } } lt_{stage == 0 ? acc_l0 : (stage == 1 ? acc_l1 : acc_l2), tl_};
+#endif
       for (;;) {                                                 // (one pass unless the rings hold more than 8 x 64 pairs)
         if (lane == 0) { s_qcnt[wv] = Q.count; s_qhead[wv] = Q.head; if (stage == 1) s_qcnt2[wv] = Q2.count; }
         __syncthreads();
@@ -292,6 +363,29 @@ __device__ __forceinline__ void small_segment(const SmallArgs& a, unsigned char*
   }
   SSTAMP();
   __syncthreads();
+  if (np > 1) {                                                  // (workgroup-uniform) a shared segment: publish, arrive, the last part merges
+    auto part_buf = [&](int p) -> u64* {
+      return p == 0 ? a.part_main + (size_t)sb * kSmallWords : a.part_help + (size_t)(hbase + p - 1) * kSmallMax * kSmallWords;
+    };
+    u64* mine = part_buf(part);
+    for (int t = tid; t < n * kSmallWords; t += kSmallThreads) stg_agent(mine + t, s_mask[t]);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // written through before the arrival
+    __syncthreads();
+    if (tid == 0) s_last = __hip_atomic_fetch_add(a.seg_ticket + seg, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == np - 1 ? 1 : 0;
+    __syncthreads();
+    if (!s_last) {
+#ifdef OBB_SMALL_TRACE
+      STRACE(2ull, (unsigned long long)seg | ((unsigned long long)part << 24) | ((unsigned long long)np << 28), (unsigned long long)n, 0ull, tt[0], tt[1], tt[2], tt[3], (unsigned long long)wall_clock64(), 0ull, 0ull, (unsigned long long)nit, (unsigned long long)nd0, (unsigned long long)nd1, (unsigned long long)nd2);
+#endif
+      return -1;
+    }
+    for (int p = 0; p < np; p++) {
+      if (p == part) continue;
+      const u64* src = part_buf(p);
+      for (int t = tid; t < n * kSmallWords; t += kSmallThreads) { const u64 v = ldg_agent(src + t); if (v) s_mask[t] |= v; }
+    }
+    __syncthreads();
+  }
   SSTAMP();
   // ---- 3. the scan (nms_rotated_cuda.cu:109-128): the lowest alive position is kept and removes what it overlaps
   if (wv == 0) {
@@ -332,9 +426,11 @@ __device__ __forceinline__ void small_segment(const SmallArgs& a, unsigned char*
   }
 #ifdef OBB_SMALL_TRACE
   SSTAMP();
-  if (lane == 0 && (seg % 41 == 0) && (wv == 0 || wv == 5)) printf("small seg %d n %d kept %d wave %d: load %llu items %llu leftovers %llu wait %llu scan %llu out %llu | items %d drains %d %d %d (x10 ns)\n", seg, n, nk, wv, tt[1]-tt[0], tt[2]-tt[1], tt[3]-tt[2], tt[4]-tt[3], tt[5]-tt[4], tt[6]-tt[5], nit, nd0, nd1, nd2);
+  STRACE(3ull, (unsigned long long)seg | ((unsigned long long)part << 24) | ((unsigned long long)np << 28), (unsigned long long)n, (unsigned long long)nk, tt[0], tt[1], tt[2], tt[3], tt[4], tt[5], tt[6], (unsigned long long)nit, (unsigned long long)nd0, (unsigned long long)nd1, (unsigned long long)nd2);
+  if (tid == 0 && blockIdx.x < 2048) { unsigned long long* o_ = g_small_trace2 + blockIdx.x * 8; o_[0] = acc_d0; o_[1] = acc_d1; o_[2] = acc_d2; o_[3] = acc_draw; o_[4] = acc_l0; o_[5] = acc_l1; o_[6] = acc_l2; }
 #endif
 #undef SSTAMP
+  return seg;
 }
 
 // TAIL::run follows the segment in every workgroup (also those of empty segments): the output stage of the fused driver counts
@@ -342,8 +438,9 @@ __device__ __forceinline__ void small_segment(const SmallArgs& a, unsigned char*
 template <class G, class TAIL>
 __global__ __launch_bounds__(kSmallThreads) void k_nms_small(SmallArgs a, typename TAIL::Args ta) {
   extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
-  small_segment<G>(a, s_raw);
-  TAIL::run(a, ta, s_raw);
+  const int seg = small_segment<G>(a, s_raw);
+  if (seg < 0) return;                                           // (workgroup-uniform)
+  TAIL::run(a, ta, s_raw, seg);
 }
 
 // (the whole segment state of one workgroup must fit the CU's 160 KB: records + bit matrix + alive words + eight wave blocks,

@@ -587,7 +587,8 @@ __global__ __launch_bounds__(1024) void k_sort_prep_lds(const float4* __restrict
                                                         int* sort_end, int* img_end, int* mode, int* grp_begin, int* grp_end,
                                                         int* __restrict__ seg_begin, int* __restrict__ seg_end, int* __restrict__ keep_cnt,
                                                         float4* __restrict__ rec, u64* __restrict__ alive, int* __restrict__ ticket,
-                                                        int plan_nb, int plan_chunk, int4* __restrict__ plan, int* __restrict__ seg_size, int P) {
+                                                        int plan_nb, int plan_chunk, int4* __restrict__ plan, int* __restrict__ seg_size, int P,
+                                                        int helpers, int* __restrict__ help_work, int* __restrict__ seg_np, int* __restrict__ seg_ticket) {
   extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
   __shared__ PlanLds s_plan;
   __shared__ int s_hist[256], s_cls_off[256], s_cls_cur[256], s_cls_task[257], s_cls_max, s_cls_ntask;
@@ -714,7 +715,10 @@ __global__ __launch_bounds__(1024) void k_sort_prep_lds(const float4* __restrict
   TSTAMP();
   if (!by_class) {
     if (q > 0) return;                               // (workgroup-uniform) the network orders the whole image in part 0
-    for (int sgm = tid; sgm < ncs; sgm += T) { seg_begin[g * ncs + sgm] = b0; seg_end[g * ncs + sgm] = b0; keep_cnt[g * ncs + sgm] = 0; }
+    for (int sgm = tid; sgm < ncs; sgm += T) {
+      seg_begin[g * ncs + sgm] = b0; seg_end[g * ncs + sgm] = b0; keep_cnt[g * ncs + sgm] = 0;
+      if (helpers > 0) seg_np[g * ncs + sgm] = 1;                // (segments of this path stay whole)
+    }
     __syncthreads();
   }
   if (by_class) {
@@ -722,6 +726,19 @@ __global__ __launch_bounds__(1024) void k_sort_prep_lds(const float4* __restrict
     for (int c = q + P * tid; c < ncs; c += P * T) {
       const int cc = s_hist[c], sb = cc ? b0 + s_cls_off[c] : b0;
       seg_begin[g * ncs + c] = sb; seg_end[g * ncs + c] = sb + cc; keep_cnt[g * ncs + c] = 0;
+      if (helpers > 0) {
+        // k_nms_small shares a large segment among several workgroups (nms_small.h: SmallArgs): the helpers are handed out here,
+        // where the sizes are known -- ticket[12] counts the slots; a segment that does not get its full set stays whole
+        int np = (cc <= kSmallMax) ? small_parts(cc) : 1, base = 0;
+        if (np > 1) {
+          base = atomicAdd(ticket + 12, np - 1);
+          const bool fits = base + np - 1 <= helpers;
+          for (int p = 1; p < np; p++) if (base + p - 1 < helpers) help_work[base + p - 1] = fits ? ((g * ncs + c) | (p << 24)) : -1;
+          if (!fits) np = 1;
+        }
+        seg_np[g * ncs + c] = np | (base << 8);
+        seg_ticket[g * ncs + c] = 0;
+      }
     }
     unsigned long long* s_keys2 = s_keys + kSortLdsMax / 2;
     uint32_t* s_vals2 = s_vals + kSortLdsMax / 2;
@@ -1010,9 +1027,9 @@ struct SmallGather {
   };
   static constexpr int kLds = kSortLdsMax;                       // entries staged in LDS: an image of the in-LDS sort has no more candidates
   static constexpr size_t kLdsBytes = 2064 + (size_t)kLds * 16;
-  static __device__ __forceinline__ void run(const SmallArgs& a, const Args& ga, unsigned char* s_raw) {
+  static __device__ __forceinline__ void run(const SmallArgs& a, const Args& ga, unsigned char* s_raw, int seg) {
     __shared__ int s_flag, s_maxc;
-    const int tid = threadIdx.x, lane = tid & 63, ncs = a.ncs, g = (int)blockIdx.x / ncs;
+    const int tid = threadIdx.x, lane = tid & 63, ncs = a.ncs, g = seg / ncs;
 #ifdef OBB_SMALL_TRACE
     unsigned long long tt[10]; int ti_ = 0;
 #define GSTAMP() do { tt[ti_++] = wall_clock64(); } while (0)
@@ -1198,7 +1215,7 @@ struct SmallGather {
     }
     GSTAMP();
 #ifdef OBB_SMALL_TRACE
-    if (tid == 0) printf("tail img %d total %d done before %d: ticket %llu counts+entries %llu stage %llu segof+issue %llu search %llu row wait %llu stores %llu (x10 ns) end %llu\n", g, total, t2, tt[1]-tt[0], tt[2]-tt[1], tt[3]-tt[2], tt[4]-tt[3], tt[5]-tt[4], tt[6]-tt[5], tt[7]-tt[6], tt[7]);
+    if (tid == 0 && blockIdx.x < 2048) { unsigned long long* o_ = g_small_trace_tail + blockIdx.x * 4; o_[0] = 1ull + (unsigned long long)g; o_[1] = (unsigned long long)total; o_[2] = tt[0]; o_[3] = tt[7]; }
 #endif
 #undef GSTAMP
     // ---- the call's status words, by the image that was done last (k_gather_out: workgroup 0; see there for their meaning)
@@ -1347,6 +1364,26 @@ static int run_nms_obb(const void* pred, const void* objcol, int dtype, int64_t 
   // (class segments, the in-LDS sort, thr >= 0: its first decision stage uses the conservative bounds); else the persistent kernel.
   const bool small_nms = lds_sort && class_ok && seg_hint > 0 && seg_hint <= kSmallMax && iou_thres >= 0.f && bs * ncs <= 65535;
   const int plan_nb = (bs * ncs > 1 && !small_nms) ? nms_grid(bs * ncs, bs * max_seg, cap_first()) : 0;
+  // k_nms_small's helper workgroups (nms_small.h: a large segment is shared).  Their lists and the parts' bit matrices live in the
+  // persistent kernel's edge lists, which this path does not use.  OBB_NMS_SMALL_HELPERS=0: every segment stays whole (A/B switch).
+  static const int helpers_env = [] { const char* e = getenv("OBB_NMS_SMALL_HELPERS"); const int v = e ? atoi(e) : 0; return v < 0 ? 0 : (v > kSmallHelpMax ? kSmallHelpMax : v); }();
+  int helpers = small_nms ? helpers_env : 0;
+  int *help_work = nullptr, *seg_np = nullptr, *seg_ticket = nullptr;
+  u64 *part_main = nullptr, *part_help = nullptr;
+  if (helpers > 0) {
+    const size_t nseg_b = align_up((size_t)(bs * ncs) * 4), work_b = align_up((size_t)helpers * 4);
+    const size_t main_b = align_up((size_t)bs * cap_img * kSmallWords * 8), help_b = align_up((size_t)helpers * kSmallMax * kSmallWords * 8);
+    const size_t have = (size_t)((bs * ncs < (int64_t)cu_count()) ? bs * ncs : (int64_t)cu_count()) * (size_t)nv.ecap * 4;   // (carve: nteams x ecap)
+    if (work_b + 2 * nseg_b + main_b + help_b > have) helpers = 0;
+    else {
+      char* p = reinterpret_cast<char*>(nv.edges);
+      help_work = (int*)p; p += work_b;
+      seg_np = (int*)p; p += nseg_b;
+      seg_ticket = (int*)p; p += nseg_b;
+      part_main = (u64*)p; p += main_b;
+      part_help = (u64*)p;
+    }
+  }
   if (lds_sort) {
     ProfScope ps(PROF_SEGSORT, st);
     static OncePerDevice attr;
@@ -1361,7 +1398,8 @@ static int run_nms_obb(const void* pred, const void* objcol, int dtype, int64_t 
                                                    max_nms, class_ok, A, nc, ncs, agnostic ? 0.f : max_wh, cv.sort_begin, cv.sort_end,
                                                    cv.img_end, cv.mode, cv.grp_begin, cv.grp_end, nv.seg_begin, nv.seg_end, nv.keep_cnt,
                                                    nv.rec, nv.alive, cv.ticket, plan_nb, plan_chunk, plan_nb > 0 ? nv.plan : nullptr,
-                                                   reinterpret_cast<int*>(cv.digit_base), parts);   // (digit_base: the class-bounds table of the other sort paths, free here)
+                                                   reinterpret_cast<int*>(cv.digit_base), parts,   // (digit_base: the class-bounds table of the other sort paths, free here)
+                                                   helpers, help_work, seg_np, seg_ticket);
   } else {
    {
     ProfScope ps(PROF_SEGSORT, st);
@@ -1439,6 +1477,9 @@ static int run_nms_obb(const void* pred, const void* objcol, int dtype, int64_t 
     sa.rec = nv.rec; sa.alive = nv.alive; sa.seg_begin = nv.seg_begin; sa.seg_end = nv.seg_end; sa.keep_cnt = nv.keep_cnt;
     sa.keep_out = cv.keep; sa.too_big = cv.ticket + 8; sa.thr = iou_thres; sa.max_keep = (int)max_det;
     sa.ncs = ncs; sa.mode = cv.mode;
+    sa.helpers = helpers; sa.help_cnt = cv.ticket + 12; sa.work = help_work; sa.seg_np = seg_np; sa.seg_ticket = seg_ticket;
+    sa.part_main = part_main; sa.part_help = part_help;
+    const unsigned gsmall = (unsigned)(bs * ncs + helpers);      // (the helpers are the FIRST blocks: dispatched before the segments' own workgroups)
     if (fused_out) {
       // (keys_a / vals_a, the sort's input, are free: they take what the segments publish)
       sa.keys_sorted = cv.keys_b; sa.vals_sorted = cv.vals_b; sa.pub_key = cv.keys_a; sa.pub_val = cv.vals_a; sa.n_pos = bs * cap_img;
@@ -1446,9 +1487,9 @@ static int run_nms_obb(const void* pred, const void* objcol, int dtype, int64_t 
       ga.cand = cv.cand; ga.cnt = cv.cnt; ga.tiny = cv.tiny; ga.info = cv.ticket; ga.ticket = cv.ticket + 16;
       ga.out = out; ga.out_count = out_count; ga.status = status; ga.cap_img = cap_img; ga.max_det = max_det; ga.bs = (int)bs;
       ga.clean_cnt = kept ? cv.cnt : nullptr; ga.clean_tiny = kept ? cv.tiny : nullptr;
-      k_nms_small<RotGeom, SmallGather><<<(unsigned)(bs * ncs), kSmallThreads, lds, st>>>(sa, ga);
+      k_nms_small<RotGeom, SmallGather><<<gsmall, kSmallThreads, lds, st>>>(sa, ga);
     } else {
-      k_nms_small<RotGeom, SmallNoTail><<<(unsigned)(bs * ncs), kSmallThreads, lds, st>>>(sa, SmallNoTail::Args{});
+      k_nms_small<RotGeom, SmallNoTail><<<gsmall, kSmallThreads, lds, st>>>(sa, SmallNoTail::Args{});
     }
   } else {
     ProfScope ps(PROF_STEPS, st);
