@@ -375,6 +375,45 @@ def test_small_segment_kernel_and_its_limits(dev, oracle_lib):
         _cmp(general.non_max_suppression_obb(base.to(dev), **kw4), pyref.non_max_suppression_obb(base.clone(), **kw4))
 
 
+def test_large_segments_shared_by_several_workgroups(dev, oracle_lib, monkeypatch):
+    """csrc/nms_small.h, SmallArgs::helpers: a segment above 128 boxes is cut into 2 / 4 / 6 / 8 parts (small_parts) when the sort
+    kernel can hand it helper workgroups; the parts' bit matrices are merged by whichever part arrives last.  Segments on either side
+    of every threshold, with no helper at all, with too few for everybody (some segments stay whole, their reserved slots are
+    marked), with the full pool and with the library's own choice -- all equal to the reference's single list."""
+    from yolov5_obb_amd.utils import general
+    nc, A = 4, 20000
+    pred = synth.s_pred(2, A, nc, seed=77, n_obj=40, fg_frac=0.01)
+    g = torch.Generator().manual_seed(5)
+    r0 = 3000
+    for img, cls, cnt in ((0, 0, 100), (0, 1, 150), (0, 2, 215), (0, 3, 270), (1, 0, 320), (1, 2, 180), (1, 3, 245)):
+        rows = torch.arange(r0, r0 + cnt)
+        r0 += cnt
+        k = max(1, cnt // 12)                                                # objects of ~12 overlapping candidates each
+        ctr = torch.rand(k, 2, generator=g) * 800 + 100
+        which = torch.randint(0, k, (cnt,), generator=g)
+        pred[img, rows, 0:2] = ctr[which] + torch.randn(cnt, 2, generator=g) * 6
+        pred[img, rows, 2:4] = torch.tensor([80.0, 28.0]) * (1 + 0.1 * torch.randn(cnt, 2, generator=g))
+        _set_class(pred, img, rows, cls, nc)
+        pred[img, rows, 4] = 0.5 + 0.45 * torch.rand(cnt, generator=g)
+        pred[img, rows, 5 + nc:] = 0.02
+        pred[img, rows, 5 + nc + torch.randint(0, 180, (cnt,), generator=g)] = 0.9
+    kw = dict(conf_thres=0.25, iou_thres=0.45, multi_label=True, max_det=1500)
+    ref = pyref.non_max_suppression_obb(pred.clone(), **kw)
+    shape = (dev, A, nc, True, 0.25)
+    for helpers in ("0", "3", "7", "256", None):
+        if helpers is None:
+            monkeypatch.delenv("OBB_NMS_SMALL_HELPERS", raising=False)
+        else:
+            monkeypatch.setenv("OBB_NMS_SMALL_HELPERS", helpers)
+        general.hints_clear()
+        for rep in range(3):
+            _cmp(general.non_max_suppression_obb(pred.to(dev), **kw), ref)
+        assert 256 < general.hint_get(*shape)["seg"] <= general._SEG_SMALL   # the small kernel ran (largest segment: 320 + the class's background)
+    for thr in (0.1, 0.8):
+        kw2 = dict(kw, iou_thres=thr)
+        _cmp(general.non_max_suppression_obb(pred.to(dev), **kw2), pyref.non_max_suppression_obb(pred.clone(), **kw2))
+
+
 def test_sort_prep_class_buckets_and_the_network_fallback(dev, oracle_lib):
     """The in-LDS sort kernel orders class buckets by rank counting on four workgroups per image; a bucket above 512 candidates
     (a dominant class) sends the image to the 16-wave network in one workgroup.  Both inside one batch, fp16 ties included."""

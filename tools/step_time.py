@@ -8,7 +8,7 @@ import torch
 from tests import synth
 from yolov5_obb_amd.utils.general import non_max_suppression_obb
 dev = torch.device("cuda:0")
-bs, A, nc = 16, 64512, 16
+bs, A, nc = int(os.environ.get("BS", "16")), 64512, 16
 kw = dict(conf_thres=0.25, iou_thres=0.45, multi_label=True, max_det=1500)
 preds = [synth.s_pred(bs, A, nc, seed=1000 + r, n_obj=120, fg_frac=0.03, device=dev, dtype=torch.float16) for r in range(4)]
 torch.cuda.synchronize()
@@ -31,4 +31,4 @@ for w in range(int(sys.argv[1]) if len(sys.argv) > 1 else 5):
     torch.cuda.synchronize()
     ws.append((time.perf_counter() - t0) / 200 * 1e3)
 print(f"step median {np.median(ws):.4f} ms  windows {[round(w, 4) for w in ws]}  rows {sum(int(o.shape[0]) for o in out)}  sha {h.hexdigest()[:16]}  "
-      f"[HELPERS={os.environ.get('OBB_NMS_SMALL_HELPERS', '-')}]", flush=True)
+      f"[HELPERS={os.environ.get('OBB_NMS_SMALL_HELPERS', '-')} BS={bs}]", flush=True)

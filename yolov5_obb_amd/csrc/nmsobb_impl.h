@@ -1364,10 +1364,17 @@ static int run_nms_obb(const void* pred, const void* objcol, int dtype, int64_t 
   // (class segments, the in-LDS sort, thr >= 0: its first decision stage uses the conservative bounds); else the persistent kernel.
   const bool small_nms = lds_sort && class_ok && seg_hint > 0 && seg_hint <= kSmallMax && iou_thres >= 0.f && bs * ncs <= 65535;
   const int plan_nb = (bs * ncs > 1 && !small_nms) ? nms_grid(bs * ncs, bs * max_seg, cap_first()) : 0;
-  // k_nms_small's helper workgroups (nms_small.h: a large segment is shared).  Their lists and the parts' bit matrices live in the
-  // persistent kernel's edge lists, which this path does not use.  OBB_NMS_SMALL_HELPERS=0: every segment stays whole (A/B switch).
-  static const int helpers_env = [] { const char* e = getenv("OBB_NMS_SMALL_HELPERS"); const int v = e ? atoi(e) : 0; return v < 0 ? 0 : (v > kSmallHelpMax ? kSmallHelpMax : v); }();
-  int helpers = small_nms ? helpers_env : 0;
+  // k_nms_small's helper workgroups (nms_small.h: a large segment is shared by several workgroups).  A workgroup takes a whole CU
+  // (160 KB of LDS), so helpers only run at once with the segments' own workgroups on the CUs the segments leave free: as many as
+  // that, none for the bs16 x 16-class step whose 256 segments fill the device (measured there with 256 helpers: 0.121 -> 0.132 ms,
+  // the helpers start when the first small segments are through).  Their lists and the parts' bit matrices live in the persistent
+  // kernel's edge lists, which this path does not use.  OBB_NMS_SMALL_HELPERS = n pins the number (0: every segment stays whole).
+  const int helpers_env = [] { const char* e = getenv("OBB_NMS_SMALL_HELPERS"); const int v = (e && *e) ? atoi(e) : -1; return v > kSmallHelpMax ? kSmallHelpMax : v; }();   // (read per call: tests switch in one process)
+  int helpers = 0;
+  if (small_nms) {
+    const int64_t free_cus = (int64_t)hw_cu_count() - bs * ncs;
+    helpers = helpers_env >= 0 ? helpers_env : (int)(free_cus < 0 ? 0 : (free_cus > kSmallHelpMax ? kSmallHelpMax : free_cus));
+  }
   int *help_work = nullptr, *seg_np = nullptr, *seg_ticket = nullptr;
   u64 *part_main = nullptr, *part_help = nullptr;
   if (helpers > 0) {
