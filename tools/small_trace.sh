@@ -6,7 +6,7 @@ D=$(cd "$(dirname "$0")/.." && pwd)
 if [ "$1" = build ]; then
   cd $D/yolov5_obb_amd/csrc && rm -rf /tmp/trace_objs; mkdir -p /tmp/trace_objs && for f in *.hip; do
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -fno-fast-math \
-      -Wno-unused-result -Wno-unused-value -Wno-format -DOBB_SMALL_TRACE -I../../include -I. -c $f -o /tmp/trace_objs/${f%.hip}.o & done; wait
+      -Wno-unused-result -Wno-unused-value -Wno-format -DOBB_SMALL_TRACE $TRACE_EXTRA -I../../include -I. -c $f -o /tmp/trace_objs/${f%.hip}.o & done; wait
   rm -f $D/yolov5_obb_amd/libobb_hip_trace.so; /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $D/yolov5_obb_amd/libobb_hip_trace.so /tmp/trace_objs/*.o && nm -D $D/yolov5_obb_amd/libobb_hip_trace.so | grep -q obb_debug_small_trace && echo built
   exit
 fi

@@ -42,9 +42,13 @@ for d in sorted(recs, key=lambda d: -d["end"])[:24]:
     print("  blk %4d seg %4d part %d/%d n %3d start %5.1f load %4.1f items %5.1f (%2d) leftovers %5.1f drains %d %d %d %s end %6.1f" % (
         d["blk"], d["seg"], d["part"], d["np"], d["n"], us(d["start"] - t0), us(t[1] - t[0]), us(t[2] - t[1]), d["nit"], us(t[3] - t[2]), d["d0"], d["d1"], d["d2"], tailtxt, us(d["end"] - t0)))
     x = d["x"]
-    print("        wave 0: in-item quick drains %.1f us, draws %.1f us | leftovers: quick %.1f interval %.1f clip %.1f us" % (us(x[0]), us(x[3]), us(x[4]), us(x[5]), us(x[6])))
+    print("        wave 0: in-item quick drains %.1f us, draws %.1f us | leftovers: quick %.1f interval %.1f clip %.1f us" % (us(x[0]), us(x[3]), us(x[4]), us(x[5]), us(x[6]))
+          + ("; waiting at the pooled interval pass: %d for the interval, %d for the clip" % ((x[7] - 1) & 0xfffff, (x[7] - 1) >> 20) if x[7] else ""))
 print("image tails (end us, image, rows, tail us):", [(round(us(e - t0), 1), g, n, round(us(e - s), 1)) for g, n, s, e in sorted(tails, key=lambda x: x[3])][-8:])
 big = sorted(set(d["n"] for d in recs if d["n"] > 128))
 print("segment sizes > 128:", big, " helpers wanted:", sum(d["np"] - 1 for d in recs if d["part"] == 0 and d["np"] > 1) if any(d["np"] > 1 for d in recs) else "-")
 ns = sorted(d["n"] for d in recs if d["part"] == 0)
 print("sizes: median %d p90 %d max %d; segments %d" % (ns[len(ns) // 2], ns[int(len(ns) * .9)], ns[-1], len(ns)))
+
+w1 = sorted(((d["x"][7] - 1) & 0xfffff) for d in recs if d["x"][7]); w2 = sorted(((d["x"][7] - 1) >> 20) for d in recs if d["x"][7])
+if w1: print("pairs waiting at the pooled interval pass, over %d segments: interval median %d p90 %d max %d; clip median %d p90 %d max %d" % (len(w1), w1[len(w1) // 2], w1[int(len(w1) * .9)], w1[-1], w2[len(w2) // 2], w2[int(len(w2) * .9)], w2[-1]))

@@ -1199,7 +1199,10 @@ int obb_device_info(int* cu_count, int* wave_size, char* arch_name, int arch_nam
 #ifdef OBB_SMALL_TRACE
 // (development builds, tools/small_trace.sh) the stamps of the last k_nms_small launch; both buffers are cleared
 extern "C" int obb_debug_small_trace2(unsigned long long* words) {
-  return hipMemcpyFromSymbol(words, HIP_SYMBOL(obb::g_small_trace2), sizeof(obb::g_small_trace2)) == hipSuccess ? 0 : -1;
+  static unsigned long long zero2[2048 * 8];
+  if (hipDeviceSynchronize() != hipSuccess) return -1;
+  if (hipMemcpyFromSymbol(words, HIP_SYMBOL(obb::g_small_trace2), sizeof(obb::g_small_trace2)) != hipSuccess) return -1;
+  return hipMemcpyToSymbol(HIP_SYMBOL(obb::g_small_trace2), zero2, sizeof(obb::g_small_trace2)) == hipSuccess ? 0 : -1;
 }
 extern "C" int obb_debug_small_trace(unsigned long long* seg_words, unsigned long long* tail_words) {
   if (hipDeviceSynchronize() != hipSuccess) return -1;

@@ -73,6 +73,7 @@ struct SmallArgs {
 };
 // parts of a segment of n boxes: the work is the pairs that survive the circle test (~n^2), a part should hold what a 128-box
 // segment holds
+constexpr int kSmallClipWaves = 4;                 // the waves of a workgroup sit on four SIMDs: up to this many clip drains run side by side at full speed
 constexpr int kSmallSplit1 = 128;
 constexpr int kSmallHelpMax = 256;
 __host__ __device__ __forceinline__ int small_parts(int n) {
@@ -295,21 +296,33 @@ __device__ __forceinline__ int small_segment(const SmallArgs& a, unsigned char* 
       struct LeftT { unsigned long long& a; unsigned long long t; __device__ ~LeftT() { a += wall_clock64() - t; } } lt_{stage == 0 ? acc_l0 : (stage == 1 ? acc_l1 : acc_l2), tl_};
 #endif
       for (;;) {                                                 // (one pass unless the rings hold more than 8 x 64 pairs)
+        // room for what this pass may add to the wave's next rings (64 each; a ring holds 128).  The first pass of a stage finds it
+        // (the slices leave every ring below 64); a full drain in front of a LATER pass is the rare case.  (Until round 6 the drains
+        // followed the pushes: one wave's interval or clip drain of 64 stood between the pooled quick pass and everybody else's next
+        // stage -- 3-5 us, 16 in a 73-box segment.)
+        if (stage <= 1 && Q2.count > 64) drain2(64);
+        if (stage == 0 && Q1.count > 64) drain1(64);
         if (lane == 0) { s_qcnt[wv] = Q.count; s_qhead[wv] = Q.head; if (stage == 1) s_qcnt2[wv] = Q2.count; }
         __syncthreads();
         if (stage == 1) {
-          // what is left for the interval stage and the exact clip together fits one wave: the interval stage (1700
-          // instructions to spare some pairs the clip) would only stand in front of a clip that runs anyway -- its pairs join
-          // the clip's ring and the stage is skipped
-          int t12 = 0;
+          // What is left for the interval stage and the exact clip together fits FOUR waves -- one per SIMD -- and every wave's two
+          // rings fit one: the interval stage (1700 instructions, 5.8 us, to spare some pairs the clip) would only stand in front of
+          // a clip drain (8 us) that runs anyway -- its pairs join the clip's rings and the stage is skipped.  (Round 6: the limit
+          // was one wave's worth; the bs16 step's segments bring 43 pairs to this point in the median, 230 at most, none of them
+          // bound for the clip yet: every segment paid both stages in a row.)
+          int t12 = 0, fit = 1;
 #pragma unroll
-          for (int w = 0; w < kSmallWaves; w++) t12 += s_qcnt[w] + s_qcnt2[w];
-          if (t12 <= 64) {                                       // (workgroup-uniform)
-            if (Q1.count > 0) {
+          for (int w = 0; w < kSmallWaves; w++) { t12 += s_qcnt[w] + s_qcnt2[w]; fit &= (s_qcnt[w] + s_qcnt2[w] <= 128) ? 1 : 0; }
+#ifdef OBB_SMALL_TRACE
+          { int t1_ = 0; for (int w = 0; w < kSmallWaves; w++) t1_ += s_qcnt[w]; if (tid == 0 && blockIdx.x < 2048 && g_small_trace2[blockIdx.x * 8 + 7] == 0ull) g_small_trace2[blockIdx.x * 8 + 7] = 1ull + (unsigned long long)t1_ + ((unsigned long long)(t12 - t1_) << 20); }
+#endif
+          if (t12 <= 64 * kSmallClipWaves && fit) {              // (workgroup-uniform)
+            while (Q1.count > 0) {
               wave_sync();
-              const bool mv = lane < Q1.count;
+              const int c1 = Q1.count < 64 ? Q1.count : 64;
+              const bool mv = lane < c1;
               const uint32_t e1 = mv ? W.q1[(Q1.head + lane) & 127] : 0u;
-              Q1.head = (Q1.head + Q1.count) & 127; Q1.count = 0;
+              Q1.head = (Q1.head + c1) & 127; Q1.count -= c1;
               Q2.push(mv, e1);
               wave_sync();
             }
@@ -354,8 +367,6 @@ __device__ __forceinline__ int small_segment(const SmallArgs& a, unsigned char* 
           if (stage == 0) { Q1.push(res == 3, e); Q2.push(res == 2, e); }
           else if (stage == 1) Q2.push(res == 2, e);
           wave_sync();
-          if (Q2.count >= 64) drain2(64);                        // (a ring holds 128: full drains stay with the wave)
-          if (stage == 0 && Q1.count >= 64) drain1(64);
         }
         __syncthreads();                                         // (s_qcnt is rewritten by the next pass)
       }
@@ -428,6 +439,7 @@ __device__ __forceinline__ int small_segment(const SmallArgs& a, unsigned char* 
   SSTAMP();
   STRACE(3ull, (unsigned long long)seg | ((unsigned long long)part << 24) | ((unsigned long long)np << 28), (unsigned long long)n, (unsigned long long)nk, tt[0], tt[1], tt[2], tt[3], tt[4], tt[5], tt[6], (unsigned long long)nit, (unsigned long long)nd0, (unsigned long long)nd1, (unsigned long long)nd2);
   if (tid == 0 && blockIdx.x < 2048) { unsigned long long* o_ = g_small_trace2 + blockIdx.x * 8; o_[0] = acc_d0; o_[1] = acc_d1; o_[2] = acc_d2; o_[3] = acc_draw; o_[4] = acc_l0; o_[5] = acc_l1; o_[6] = acc_l2; }
+  // (slot 7: the pairs waiting for the interval stage / the clip when the pooled interval pass starts, written there)
 #endif
 #undef SSTAMP
   return seg;
