@@ -403,6 +403,32 @@ def test_quad_iou_matrix_bit_exact(dev, oracle_lib):
     assert got[3, 7] == 1.0            # both degenerate: union == 0 -> (0+1)/(0+1)  (poly_nms_cuda.cu:136-137)
 
 
+@pytest.mark.parametrize("extent,na,nb,seed", [(1024.0, 300, 700, 21), (4096.0, 130, 520, 22), (60.0, 257, 65, 23), (30000.0, 64, 1000, 24)])
+def test_quad_iou_matrix_both_cone_rules_bit_exact(dev, oracle_lib, extent, na, nb, seed):
+    """k_quad_tile writes an exact +0 where either cone rule of piou_device.h fires (the column quad counter-clockwise of the row
+    quad as seen from the origin, or -- round 6, quad_cone2_skip -- clockwise of it) and clips the rest: every entry equals the
+    oracle's full clip bit for bit, on extents where nine pairs in ten are such zeros, across the 256-column blocks' edges, with
+    reversed rings, a quad around the origin, quads whose edge lines pass through the origin's neighbourhood and integer grids."""
+    from yolov5_obb_amd import ops
+    a, _ = synth.s_uniform(na, seed, extent=extent)
+    b, _ = synth.s_uniform(nb, seed + 100, extent=extent)
+    qa, qb = synth.rbox_to_quad(a), synth.rbox_to_quad(b)
+    qb[::5] = qb[::5].reshape(-1, 4, 2).flip(1).reshape(-1, 8)
+    qa[::7] = qa[::7].reshape(-1, 4, 2).flip(1).reshape(-1, 8)
+    qa[1::9] = qa[1::9].round(); qb[2::9] = qb[2::9].round()
+    qa[5] = torch.tensor([-3.0, -2.0, 40.0, -2.0, 40.0, 30.0, -3.0, 30.0])                       # around the origin: no cone
+    qb[6] = torch.tensor([10.0, 10.0, 500.0, 500.5, 499.0, 502.0, 9.0, 11.5])                    # edge lines through the origin's neighbourhood
+    qa[8] = torch.tensor([0.0, 50.0, 0.0, 90.0, -20.0, 90.0, -20.0, 50.0])                       # a vertex on the y axis, x <= 0
+    got = ops.quad_iou_matrix(qa.to(dev), qb.to(dev)).cpu().numpy()
+    ref = oracle.piou_matrix(qa.numpy(), qb.numpy())
+    same = (got.view(np.uint32) == ref.view(np.uint32)) | (np.isnan(got) & np.isnan(ref))
+    assert same.all(), (np.count_nonzero(~same), np.nanmax(np.abs(got - ref)))
+    # the devkit flavour (rboxes in, RotBox2Poly on the device) on the same boxes
+    gd = ops.rbox_overlaps(a.to(dev), b.to(dev)).cpu().numpy()
+    rd = oracle.devkit_overlaps(a.numpy(), b.numpy())
+    assert (gd.view(np.uint32) == rd.view(np.uint32)).mean() >= 0.999 and np.abs(gd - rd).max() <= 1e-5
+
+
 def test_devkit_overlaps_and_poly_gpu_nms(dev, oracle_lib):
     from yolov5_obb_amd.DOTA_devkit.poly_nms_gpu import poly_overlaps
     from yolov5_obb_amd.DOTA_devkit.poly_nms_gpu.nms_wrapper import poly_nms_gpu

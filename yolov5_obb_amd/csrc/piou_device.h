@@ -270,6 +270,83 @@ OBB_HD bool quad_cone_skip(uint32_t p, uint32_t q) {
   return plo <= phi && qlo <= qhi && phi < qlo && (qhi - plo) < 32768 - 4;
 }
 
+// ---- the second exact rule: the FIRST quad's cone lies counter-clockwise of the second's -----------------------------
+// PROVED under the conditions below for this file's contract, IEEE fp32 WITHOUT FMA contraction (DESIGN.md section 4.3 spells
+// the argument out; tests/native/host_check_quadcone.cpp searches for counter-examples on the rule's edges).  (With contraction
+// clip 3's s(Z) = fma(dx, dy, -fl(dx dy)) is a rounding residual instead of 0 and the statement does not hold; the first rule
+// holds either way.)  Notation as above: P = the first
+// argument, (a, b) an edge of P, (c, d) an edge of Q ordered so that the computed cross(c, d) > 1e-8, o the origin.  With every
+// vertex of P counter-clockwise of every vertex of Q:
+//   clip 1 (line o -> c): s(o) = 0 exactly, s(a), s(b) > 1e-8 (exact cross >= sin(margin) |c||a|, rounding <= 3 u |c||a|):
+//     the polygon stays [Z, a, b], Z = (+-0, +-0);
+//   clip 2 (line c -> d): s(Z) = cross(c, d) up to 4 u |d - c||c| -- safely positive when the edge's exact cross is
+//     >= 2^-16 max(|c|, |d|)^2 (edge condition); a, b fall on either side.  The clipped polygon's vertices are Z, a, b, the
+//     pinned (0, 0), and crossings: t a or t b with t = s(Z) / (s(Z) - s(.)) (on the rays o -> a, o -> b, no closer to the origin
+//     than 0.49 x the distance r of the line c-d from it), or lambda a + (1 - lambda) b computed from the two SIGNS-DIFFER
+//     values: lambda in (0, 1) when both lie outside +-1e-8, and within (-1, 2) when one of them lies inside (then
+//     |s(b) - s(a)| > 1e-8 >= |s(a)| bounds the extrapolation by one edge length on either side: the EXTENDED edge);
+//   clip 3 (line d -> o): s(v) = -cross(d, v) up to 3.1 u |d|(|v| + |d|); s(Z) = 0 exactly; for every other vertex v the exact
+//     value is <= -|d||v| sin(margin) and |v| >= 0.49 r >= M / 261 (M = the largest norm involved): s(v) < -1e-8.  Zero
+//     points are never emitted as vertices, a crossing between a zero point and a negative one is (+-0 - +-0) / s = +-0:
+//     the polygon is empty or the single point (0, 0), the shoelace sum +0.
+// So all 16 terms are exactly 0.  What the rule needs per quad (quad_cone2_bits): the cone of its four vertices AND of the
+// eight points 2 v_i - v_(i+-1) (the extended edges), the smallest distance r of an edge's LINE from the origin (rounded
+// down; it bounds every vertex, every point of an extended edge), the largest norm M of the twelve points (rounded up), the
+// edge condition on all four edges, M <= 2^30.  Per pair: the first quad's extended cone begins >= 5 units behind the end
+// of the second quad's cone (both widened by two units: >= 8.6e-4 rad between any two points), the whole span stays below
+// pi - 8 units, and max(M) <= 128 min(r): the crossings' directions move by <= 17 u M / (0.49 r) < 2.7e-4 rad, which leaves
+// sin(margin) >= 5.8e-4 against the 3.1 u (1 + 261) = 4.9e-5 needed.
+struct QuadCone2 {
+  uint32_t ext;   // cone of the twelve points, 16-bit fixed point lo | hi << 16 (kConeNone: no rule)
+  uint32_t rm;    // bf16 bits: r rounded down | M rounded up << 16
+};
+OBB_HD QuadCone2 quad_cone2_bits(const QuadFeat& q) {
+  QuadCone2 out; out.ext = kConeNone; out.rm = 0xffff0000u;
+  float lo = 4.f, hi = -4.f, m2 = 0.f, r = __builtin_huge_valf();
+  bool ok = quad_signed_area(q.x, q.y) != 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const int j = (i + 1) & 3;
+    const float ux = q.x[i], uy = q.y[i], wx = q.x[j], wy = q.y[j];
+    ok = ok && (ux - ux == 0.f) && (uy - uy == 0.f) && (fabsf(ux) + fabsf(uy) >= 1.5f);
+    const float cr = fabsf(ux * wy - wx * uy);
+    const float nu = ux * ux + uy * uy, nw = wx * wx + wy * wy;
+    // edge condition (computed cross >= 2^-15 max^2 covers the 3 u max^2 of its own roundings)
+    ok = ok && (cr >= fmaxf(nu, nw) * (1.f / 32768.f));
+    const float ex = wx - ux, ey = wy - uy;
+    const float len = sqrtf(ex * ex + ey * ey);
+    r = fminf(r, cr / len);
+    // the three points of this edge's line that can carry a vertex: u, 2u - w (behind u), 2w - u (beyond w)
+    const float px[3] = {ux, ux - ex, wx + ex}, py[3] = {uy, uy - ey, wy + ey};
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      const float t = atan2f(py[k], px[k]);
+      lo = fminf(lo, t); hi = fmaxf(hi, t);
+      m2 = fmaxf(m2, px[k] * px[k] + py[k] * py[k]);
+    }
+  }
+  const float M = sqrtf(m2) * 1.001f;
+  r *= 0.99f;
+  if (!ok || !(hi - lo < 3.1f) || !(M <= 1073741824.f) || !(r > 0.f)) return out;
+  const float sc = 65536.f / 6.2831855f;
+  float ulo = floorf((lo + 3.1415927f) * sc) - 2.f, uhi = ceilf((hi + 3.1415927f) * sc) + 2.f;
+  ulo = ulo < 0.f ? 0.f : ulo; uhi = uhi > 65535.f ? 65535.f : uhi;
+  out.ext = (uint32_t)ulo | ((uint32_t)uhi << 16);
+  const uint32_t rb = __builtin_bit_cast(uint32_t, r) >> 16;                       // truncation rounds a positive float down
+  const uint32_t mu = __builtin_bit_cast(uint32_t, M);
+  const uint32_t mb = (mu >> 16) + ((mu & 0xffffu) ? 1u : 0u);
+  out.rm = rb | (mb << 16);
+  return out;
+}
+// p_ext / p_rm: the FIRST argument's extended cone and (r, M); q_cone / q_rm: the second argument's plain cone and (r, M)
+OBB_HD bool quad_cone2_skip(uint32_t p_ext, uint32_t p_rm, uint32_t q_cone, uint32_t q_rm) {
+  const int plo = (int)(p_ext & 0xffffu), phi = (int)(p_ext >> 16), qlo = (int)(q_cone & 0xffffu), qhi = (int)(q_cone >> 16);
+  const uint32_t rmin = (p_rm & 0xffffu) < (q_rm & 0xffffu) ? (p_rm & 0xffffu) : (q_rm & 0xffffu);
+  const uint32_t mmax = (p_rm >> 16) > (q_rm >> 16) ? (p_rm >> 16) : (q_rm >> 16);
+  // bf16 bits of positive numbers order like the numbers; + (7 << 7) = x 128
+  return plo <= phi && qlo <= qhi && plo - qhi >= 5 && (phi - qlo) < 32768 - 8 && mmax <= rmin + (7u << 7);
+}
+
 struct QuadSkip {
   uint32_t lo;   // fp16 minx | fp16 miny << 16   (rounded down)
   uint32_t hi;   // fp16 maxx | fp16 maxy << 16   (rounded up)
