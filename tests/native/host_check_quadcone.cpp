@@ -39,6 +39,15 @@ static void rotate_quad(float* q, float a) {
   for (int k = 0; k < 4; k++) { const double x = q[2 * k], y = q[2 * k + 1]; q[2 * k] = (float)(c * x - s * y); q[2 * k + 1] = (float)(s * x + c * y); }
 }
 static const float kUnit = 6.2831855f / 65536.f;
+// the second rule as k_quad_strip applies it: tier 1 (extended cone) or tier 2 (plain cone + the pair check); *tier = which
+static long g_tier[3] = {0, 0, 0};
+static bool rule2_fires(const obb::QuadFeat& A, const obb::QuadFeat& B) {
+  const obb::QuadCone2 a2 = obb::quad_cone2_bits(A), b2 = obb::quad_cone2_bits(B);
+  const uint32_t cb = obb::quad_cone_bits(B);
+  if (obb::quad_cone2_skip(a2.ext, a2.rm, cb, b2.rm)) { g_tier[1]++; return true; }
+  if (obb::quad_cone2_skip(obb::quad_cone_bits(A), a2.rm, cb, b2.rm) && obb::quad_cone2_nofuzzy(A, B)) { g_tier[2]++; return true; }
+  return false;
+}
 
 // Families aimed at the SECOND rule (the first argument counter-clockwise of the second):
 //   0: two rectangles, the gap between the first one's extended cone and the second one's cone set to -3 .. 12 units around the
@@ -96,10 +105,24 @@ static bool family2_pair(long i, float* p, float* q, float* gap_units) {
   for (int it = 0; it < 3; it++) {
     const obb::QuadCone2 c2 = obb::quad_cone2_bits(obb::quad_make_feat(p));
     if (c2.ext == obb::kConeNone || cq == obb::kConeNone) return false;
-    const float want = -3.f + 15.f * U();
-    const float have = (float)(int)(c2.ext & 0xffffu) - (float)(int)(cq >> 16);
+    // the gap the rule asks for grows with max(M) / min(r): aim at -3 .. +12 units around it, for the extended cone (tier 1) or
+    // the plain one (tier 2)
+    const obb::QuadFeat Pf = obb::quad_make_feat(p);
+    const obb::QuadCone2 q2 = obb::quad_cone2_bits(Q);
+    const bool plain = (i / 8) % 2;
+    const uint32_t pc = plain ? obb::quad_cone_bits(Pf) : c2.ext;
+    if (pc == obb::kConeNone) return false;
+    int need = 5;
+    for (int gq = 5; gq < 300; gq++) {                      // the smallest gap quad_cone2_skip accepts for this pair's (r, M)
+      const uint32_t fake_p = 40000u | (40100u << 16), fake_q = (uint32_t)(40000 - gq - 50) | ((uint32_t)(40000 - gq) << 16);
+      if (obb::quad_cone2_skip(fake_p, c2.rm, fake_q, q2.rm)) { need = gq; break; }
+      need = 300;
+    }
+    if (need >= 300) return false;
+    const float want = (float)need - 8.f + 15.f * U();
+    const float have = (float)(int)(pc & 0xffffu) - (float)(int)(cq >> 16);
     rotate_quad(p, (want - have) * kUnit);
-    *gap_units = want;
+    *gap_units = want - (float)need + 5.f;
   }
   return true;
 }
@@ -126,8 +149,7 @@ int main(int argc, char** argv) {
     for (int role = 0; rule2 && role < 2; role++) {
       // the second rule (first argument counter-clockwise of the second): same statement, exact +0
       const obb::QuadFeat& A = role ? Q : P; const obb::QuadFeat& B = role ? P : Q;
-      const obb::QuadCone2 a2 = obb::quad_cone2_bits(A), b2 = obb::quad_cone2_bits(B);
-      if (!obb::quad_cone2_skip(a2.ext, a2.rm, obb::quad_cone_bits(B), b2.rm)) continue;
+      if (!rule2_fires(A, B)) continue;
       fired2++;
       if (gap < 1.2e-3f) near_edge2++;
       const float v = obb::quad_iou<1>(A, B, s0, s1, s2, s3);
@@ -149,15 +171,14 @@ int main(int argc, char** argv) {
     float p[8], q[8], gu = 100.f;
     if (!family2_pair(i, p, q, &gu)) continue;
     const obb::QuadFeat P = obb::quad_make_feat(p), Q = obb::quad_make_feat(q);
-    const obb::QuadCone2 p2 = obb::quad_cone2_bits(P), q2 = obb::quad_cone2_bits(Q);
-    if (!obb::quad_cone2_skip(p2.ext, p2.rm, obb::quad_cone_bits(Q), q2.rm)) continue;
+    if (!rule2_fires(P, Q)) continue;
     fired2++; fam_fired[i % 4]++;
     if (gu < 8.f) edge2++;
     const float v = obb::quad_iou<1>(P, Q, s0, s1, s2, s3);
     uint32_t vb; memcpy(&vb, &v, 4);
     if (vb != 0u) { wrong2++; if (wrong2 < 5) fprintf(stderr, "counter-example (rule 2, family %ld): iou bits %08x\n", i % 4, vb); }
   }
-  printf("family2_fired=%ld,%ld,%ld,%ld at_edge2=%ld ", fam_fired[0], fam_fired[1], fam_fired[2], fam_fired[3], edge2);
+  printf("family2_fired=%ld,%ld,%ld,%ld at_edge2=%ld tier1=%ld tier2=%ld ", fam_fired[0], fam_fired[1], fam_fired[2], fam_fired[3], edge2, g_tier[1], g_tier[2]);
   printf("pairs=%ld fired=%ld near_edge=%ld wrong=%ld fired2=%ld near_edge2=%ld wrong2=%ld\n", n, fired, near_edge, wrong, fired2, near_edge2, wrong2);
   return (wrong || wrong2) ? 1 : 0;
 }

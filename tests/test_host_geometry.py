@@ -60,15 +60,24 @@ def test_quad_cone_rule_gives_exactly_zero(tmp_path, fma):
     lies counter-clockwise of the first's, every one of the 16 terms of the reference's sum is exactly zero and the IoU is
     +0 -- checked on pairs generated to sit on the rule's edges (smallest resolvable gaps, spans up to pi, vertices at the minimum
     distance, coordinates 2 .. 1e7, bow ties, clockwise rings), in a build without and in a build WITH FMA contraction
-    (nvcc's default for the reference's .cu files)."""
+    (nvcc's default for the reference's .cu files).
+    Round 6: the SECOND proved rule (quad_cone2_skip / quad_cone2_nofuzzy: the first quad counter-clockwise of the second; tier 1
+    on the extended-edge cone, tier 2 on the plain cone plus the pair check) in the build without contraction -- this project's
+    arithmetic contract, the one the rule is stated for -- on the same pairs and on four families of its own: rectangles with
+    the gap set around the smallest one the rule accepts for the pair's M / r, edges of one quad lying on an edge line of the other
+    (0 .. 3 ulps off, 1e-9 .. 1e-3 off, and on lines next to an axis where clip 2's sign values land within +-2e-8: the
+    extrapolated crossing), integer grids."""
     out = tmp_path / ("hc_cone_fma" if fma else "hc_cone")
     flags = ["-march=native", "-ffp-contract=fast"] if fma else ["-ffp-contract=off"]
     subprocess.run(["g++", "-O2", "-std=c++17", *flags, f"-I{ROOT}/yolov5_obb_amd/csrc",
                     f"{ROOT}/tests/native/host_check_quadcone.cpp", "-o", str(out), "-lm"], check=True)
-    r = subprocess.run([str(out), "3000000", "5"], capture_output=True, text=True)
-    assert r.returncode == 0 and " wrong=0" in r.stdout, r.stdout + r.stderr
+    r = subprocess.run([str(out), "3000000", "5", "0" if fma else "1"], capture_output=True, text=True)
+    assert r.returncode == 0 and " wrong=0" in r.stdout and " wrong2=0" in r.stdout, r.stdout + r.stderr
     vals = dict(kv.split("=") for kv in r.stdout.split())
     assert int(vals["fired"]) > 1500000 and int(vals["near_edge"]) > 500000, r.stdout
+    if not fma:
+        assert int(vals["fired2"]) > 1000000 and int(vals["tier1"]) > 300000 and int(vals["tier2"]) > 300000, r.stdout
+        assert int(vals["at_edge2"]) > 200000 and min(int(v) for v in vals["family2_fired"].split(",")) > 30000, r.stdout
 
 
 def test_fast_iou_interval_contains_the_reference_value(oracle_lib, tmp_path):

@@ -405,7 +405,7 @@ def test_quad_iou_matrix_bit_exact(dev, oracle_lib):
 
 @pytest.mark.parametrize("extent,na,nb,seed", [(1024.0, 300, 700, 21), (4096.0, 130, 520, 22), (60.0, 257, 65, 23), (30000.0, 64, 1000, 24)])
 def test_quad_iou_matrix_both_cone_rules_bit_exact(dev, oracle_lib, extent, na, nb, seed):
-    """k_quad_tile writes an exact +0 where either cone rule of piou_device.h fires (the column quad counter-clockwise of the row
+    """k_quad_strip writes an exact +0 where either cone rule of piou_device.h fires (the column quad counter-clockwise of the row
     quad as seen from the origin, or -- round 6, quad_cone2_skip -- clockwise of it) and clips the rest: every entry equals the
     oracle's full clip bit for bit, on extents where nine pairs in ten are such zeros, across the 256-column blocks' edges, with
     reversed rings, a quad around the origin, quads whose edge lines pass through the origin's neighbourhood and integer grids."""

@@ -2,8 +2,8 @@
 // rbox overlaps (DOTA_devkit/poly_nms_gpu/poly_overlaps_kernel.cu:280-353).
 //
 // Layout: rotated IoU: a 64 x 64 output tile per one-wave workgroup, lanes own COLUMNS (each store instruction writes 64
-// consecutive floats of one output row), the row box is wave-uniform and read from LDS as a broadcast.  Quad IoU: 64 x 256 per
-// workgroup of four waves, 16 rows each, exact zeros written at once and the clips run from a compacted queue (k_quad_tile).  The <= 24 / 20
+// consecutive floats of one output row), the row box is wave-uniform and read from LDS as a broadcast.  Quad IoU: 16 rows x a chunk of
+// columns per one-wave workgroup, exact zeros written at once and the clips run from a compacted queue (k_quad_strip).  The <= 24 / 20
 // clip points of each lane live in an LDS column (bank == lane).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -70,24 +70,27 @@ __device__ __forceinline__ void rbox_to_quad_devkit(const float* d, float* qx, f
   qy[3] = (float)(y + ss * (-w / 2.0) + cs * (-h / 2.0));
 }
 
-// Dense quad IoU: 64 rows x (up to) 256 columns per workgroup of four waves (devPolyIoU, utils/nms_rotated/src/poly_nms_cuda.cu:122-142;
+// Dense quad IoU: one WAVE per unit of 16 rows x `chunk` columns (devPolyIoU, utils/nms_rotated/src/poly_nms_cuda.cu:122-142;
 // DEVKIT: the rows / columns are rboxes turned into quads by RotBox2Poly, DOTA_devkit/poly_nms_gpu/poly_overlaps_kernel.cu:280-353).
-// A wave walks its 16 rows over the column tiles of 64, writes the exact zeros of the pairs one of the two PROVED cone rules
-// (piou_device.h: the column quad counter-clockwise of the row quad as seen from the origin, or clockwise of it) vouches for
-// and pushes the others into a ring queue in LDS; the clip (48 half-plane cuts, ~10^4 instructions) only ever runs on 64 queued
-// pairs at a time, whatever tile they come from -- on S-uniform rboxes over 1024 px nine pairs in ten are exact zeros, so a
-// wave drains five or six full queues per 16 x 256 block instead of 1.4 per 16 x 64 tile.
-constexpr int kQtWaves = 4;
-constexpr int kQtCols = 256;
+// The wave walks its 16 rows over the column tiles of 64 (a column per lane), writes the exact zeros of the pairs one of the two
+// PROVED cone rules vouches for (piou_device.h: the column quad counter-clockwise of the row quad as seen from the origin, or
+// clockwise of it -- tier 1 on the row's extended cone, tier 2 on its plain cone plus the pair check) and pushes the others
+// into a ring queue in LDS; the clip (48 half-plane cuts, ~2.5 x 10^4 instructions per wave) only ever runs on 64 queued pairs at
+// a time, whatever tile they come from.  On S-uniform rboxes over 1024 px nine pairs in ten are exact zeros.  One-wave
+// workgroups of 11 KB LDS: 14 per CU, handed out by the dispatcher as they finish (the units' clip counts differ), no
+// workgroup barrier anywhere; the row records live in the first 16 lanes' registers (v_readlane per row), the queued pair's
+// column quad is read again from global memory when its clip runs.
+constexpr int kQsRows = 16;
 template <bool DEVKIT>
-__global__ __launch_bounds__(64 * kQtWaves) void k_quad_tile(const float* __restrict__ a, long long sa, long long n, const float* __restrict__ b,
-                                                             long long sb, long long k, float* __restrict__ out) {
-  __shared__ float4 rowq[64 * 2], colq[kQtCols * 2];
-  __shared__ uint32_t rowcone[64], rowext[64], rowrm[64], colcone[kQtCols], colrm[kQtCols];
-  __shared__ uint32_t queue[kQtWaves][128];
-  __shared__ float scr[kQtWaves][QuadGeom::SCR * 64];
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const long long i0 = (long long)blockIdx.y * 64, j0 = (long long)blockIdx.x * kQtCols;
+__global__ __launch_bounds__(64) void k_quad_strip(const float* __restrict__ a, long long sa, long long n, const float* __restrict__ b,
+                                                   long long sb, long long k, float* __restrict__ out, int chunk, int nchunks) {
+  __shared__ float4 rowq[kQsRows * 2];
+  __shared__ uint32_t queue[128];
+  __shared__ float scr[QuadGeom::SCR * 64];
+  const int lane = threadIdx.x;
+  const long long strip = blockIdx.x / (unsigned)nchunks, ch = blockIdx.x % (unsigned)nchunks;
+  const long long i0 = strip * kQsRows, j0 = ch * chunk;
+  const long long j1 = (k - j0) < chunk ? k : j0 + chunk;
   auto load_quad = [&](const float* src, long long st, long long idx) {
     QuadFeat q = {};
     if (DEVKIT) rbox_to_quad_devkit(src + idx * 5, q.x, q.y);
@@ -97,60 +100,68 @@ __global__ __launch_bounds__(64 * kQtWaves) void k_quad_tile(const float* __rest
     }
     return q;
   };
-  {                                                      // every thread stages a column, the first wave the rows as well
-    const long long j = j0 + tid;
+  uint32_t rc = kConeNone, re = kConeNone, rr = kRmNone;      // lane r < 16: row r's plain cone, extended cone, (r, M)
+  if (lane < kQsRows) {
     QuadFeat q = {};
-    const bool v = j < k;
-    if (v) q = load_quad(b, sb, j);
-    colq[tid * 2] = make_float4(q.x[0], q.y[0], q.x[1], q.y[1]);
-    colq[tid * 2 + 1] = make_float4(q.x[2], q.y[2], q.x[3], q.y[3]);
-    colcone[tid] = v ? quad_cone_bits(q) : kConeNone;
-    colrm[tid] = v ? quad_cone2_bits(q).rm : 0xffff0000u;
+    if (i0 + lane < n) {
+      q = load_quad(a, sa, i0 + lane);
+      rc = quad_cone_bits(q);
+      const QuadCone2 c2 = quad_cone2_bits(q);
+      re = c2.ext; rr = c2.rm;
+    }
+    rowq[lane * 2] = make_float4(q.x[0], q.y[0], q.x[1], q.y[1]);
+    rowq[lane * 2 + 1] = make_float4(q.x[2], q.y[2], q.x[3], q.y[3]);
   }
-  if (tid < 64) {
-    const long long i = i0 + tid;
-    QuadFeat q = {};
-    const bool v = i < n;
-    if (v) q = load_quad(a, sa, i);
-    rowq[tid * 2] = make_float4(q.x[0], q.y[0], q.x[1], q.y[1]);
-    rowq[tid * 2 + 1] = make_float4(q.x[2], q.y[2], q.x[3], q.y[3]);
-    QuadCone2 c2; c2.ext = kConeNone; c2.rm = 0xffff0000u;
-    if (v) c2 = quad_cone2_bits(q);
-    rowcone[tid] = v ? quad_cone_bits(q) : kConeNone;
-    rowext[tid] = c2.ext; rowrm[tid] = c2.rm;
-  }
-  __syncthreads();
-  uint32_t* q = queue[wv];
+  __builtin_amdgcn_wave_barrier();
   int head = 0, count = 0;                               // wave-uniform
   auto drain = [&](int cnt) {
     __builtin_amdgcn_wave_barrier();
     if (lane < cnt) {
-      const uint32_t e = q[(head + lane) & 127];
-      const int r = (int)(e >> 8), c = (int)(e & 255u);
-      const QuadFeat A = QuadGeom::unpack(rowq[r * 2], rowq[r * 2 + 1]), B = QuadGeom::unpack(colq[c * 2], colq[c * 2 + 1]);
-      out[(i0 + r) * k + j0 + c] = QuadGeom::iou(A, B, scr[wv] + lane);
+      const uint32_t e = queue[(head + lane) & 127];
+      const int r = (int)(e >> 28);
+      const long long j = j0 + (long long)(e & 0x0fffffffu);
+      const QuadFeat A = QuadGeom::unpack(rowq[r * 2], rowq[r * 2 + 1]), B = load_quad(b, sb, j);
+      out[(i0 + r) * k + j] = QuadGeom::iou(A, B, scr + lane);
     }
     head = (head + cnt) & 127; count -= cnt;
     __builtin_amdgcn_wave_barrier();
   };
-  const int nr = (int)((n - i0) < 64 ? (n - i0) : 64);
-  const int nct = (int)((((k - j0) < kQtCols ? (k - j0) : kQtCols) + 63) / 64);
-  for (int ct = 0; ct < nct; ct++) {
-    const int c = ct * 64 + lane;
-    const bool cvalid = j0 + c < k;
-    const uint32_t cone_b = colcone[c], rm_b = colrm[c];
-    for (int r = wv * 16; r < wv * 16 + 16 && r < nr; r++) {
+  const int nr = (int)((n - i0) < kQsRows ? (n - i0) : kQsRows);
+  for (long long jt = j0; jt < j1; jt += 64) {
+    const long long j = jt + lane;
+    const bool cvalid = j < j1;
+    QuadFeat B = {};
+    uint32_t cone_b = kConeNone, rm_b = kRmNone;
+    if (cvalid) { B = load_quad(b, sb, j); cone_b = quad_cone_bits(B); rm_b = quad_cone2_bits(B).rm; }
+    for (int r = 0; r < nr; r++) {
+      const uint32_t prc = (uint32_t)__builtin_amdgcn_readlane((int)rc, r), pre = (uint32_t)__builtin_amdgcn_readlane((int)re, r),
+                     prr = (uint32_t)__builtin_amdgcn_readlane((int)rr, r);
       // either cone rule: all 16 terms of the reference's sum are exactly zero -> IoU = +0, no clip
-      const bool skip = quad_cone_skip(rowcone[r], cone_b) || quad_cone2_skip(rowext[r], rowrm[r], cone_b, rm_b);
-      if (cvalid && skip) out[(i0 + r) * k + j0 + c] = 0.f;
+      bool skip = quad_cone_skip(prc, cone_b) || quad_cone2_skip(pre, prr, cone_b, rm_b);
+      if (!skip && quad_cone2_skip(prc, prr, cone_b, rm_b))
+        skip = quad_cone2_nofuzzy(QuadGeom::unpack(rowq[r * 2], rowq[r * 2 + 1]), B);
+      if (cvalid && skip) out[(i0 + r) * k + j] = 0.f;
       const bool work = cvalid && !skip;
       const unsigned long long m = __ballot(work);
-      if (work) q[(head + count + __popcll(m & ((1ull << lane) - 1ull))) & 127] = ((uint32_t)r << 8) | (uint32_t)c;
+      if (work) queue[(head + count + __popcll(m & ((1ull << lane) - 1ull))) & 127] = ((uint32_t)r << 28) | (uint32_t)(j - j0);
       count += __popcll(m);
       if (count >= 64) drain(64);
     }
   }
   if (count > 0) drain(count);
+}
+
+// units of 16 rows x chunk columns, chunk a multiple of 64 chosen for >= ~3 units per wave slot of the device (256 CUs x 14)
+static int quad_strip_launch(bool devkit, const float* a, long long sa, long long n, const float* b, long long sb, long long k, float* out,
+                             hipStream_t st) {
+  const long long strips = (n + kQsRows - 1) / kQsRows;
+  long long chunk = strips * k / 10752 / 64 * 64;
+  chunk = chunk < 64 ? 64 : (chunk > 1024 ? 1024 : chunk);
+  const long long nchunks = (k + chunk - 1) / chunk;
+  if (strips * nchunks > 0x7fffffffLL || nchunks > 0x7fffffffLL) return OBB_ERR_BAD_ARG;
+  if (devkit) k_quad_strip<true><<<(unsigned)(strips * nchunks), 64, 0, st>>>(a, sa, n, b, sb, k, out, (int)chunk, (int)nchunks);
+  else k_quad_strip<false><<<(unsigned)(strips * nchunks), 64, 0, st>>>(a, sa, n, b, sb, k, out, (int)chunk, (int)nchunks);
+  return hipGetLastError() == hipSuccess ? OBB_OK : OBB_ERR_LAUNCH;
 }
 
 // DOTA Task-1 evaluation, the det x GT part of voc_eval (DOTA_devkit/dota_evaluation_task1.py:168-223): for every
@@ -253,19 +264,13 @@ int obb_quad_iou_matrix_f32(const float* a, int64_t a_stride, int64_t n, const f
                             float* out, void* stream) {
   if (n < 0 || k < 0 || a_stride < 8 || b_stride < 8 || (n > 0 && k > 0 && (!a || !b || !out))) return OBB_ERR_BAD_ARG;
   if (n == 0 || k == 0) return OBB_OK;
-  dim3 g((unsigned)((k + kQtCols - 1) / kQtCols), (unsigned)((n + 63) / 64));
-  if (g.y > 65535) return OBB_ERR_BAD_ARG;
-  k_quad_tile<false><<<g, 64 * kQtWaves, 0, (hipStream_t)stream>>>(a, a_stride, n, b, b_stride, k, out);
-  return OBB_CHECK_LAUNCH();
+  return quad_strip_launch(false, a, a_stride, n, b, b_stride, k, out, (hipStream_t)stream);
 }
 
 int obb_rbox_overlaps_f32(const float* boxes5, int64_t n, const float* query5, int64_t k, float* out, void* stream) {
   if (n < 0 || k < 0 || (n > 0 && k > 0 && (!boxes5 || !query5 || !out))) return OBB_ERR_BAD_ARG;
   if (n == 0 || k == 0) return OBB_OK;
-  dim3 g((unsigned)((k + kQtCols - 1) / kQtCols), (unsigned)((n + 63) / 64));
-  if (g.y > 65535) return OBB_ERR_BAD_ARG;
-  k_quad_tile<true><<<g, 64 * kQtWaves, 0, (hipStream_t)stream>>>(boxes5, 5, n, query5, 5, k, out);
-  return OBB_CHECK_LAUNCH();
+  return quad_strip_launch(true, boxes5, 5, n, query5, 5, k, out, (hipStream_t)stream);
 }
 
 

@@ -286,22 +286,29 @@ OBB_HD bool quad_cone_skip(uint32_t p, uint32_t q) {
 //     values: lambda in (0, 1) when both lie outside +-1e-8, and within (-1, 2) when one of them lies inside (then
 //     |s(b) - s(a)| > 1e-8 >= |s(a)| bounds the extrapolation by one edge length on either side: the EXTENDED edge);
 //   clip 3 (line d -> o): s(v) = -cross(d, v) up to 3.1 u |d|(|v| + |d|); s(Z) = 0 exactly; for every other vertex v the exact
-//     value is <= -|d||v| sin(margin) and |v| >= 0.49 r >= M / 261 (M = the largest norm involved): s(v) < -1e-8.  Zero
+//     value is <= -|d||v| sin(margin) and |v| >= 0.49 r (M = the largest norm involved; M / r is bounded): s(v) < -1e-8.  Zero
 //     points are never emitted as vertices, a crossing between a zero point and a negative one is (+-0 - +-0) / s = +-0:
 //     the polygon is empty or the single point (0, 0), the shoelace sum +0.
-// So all 16 terms are exactly 0.  What the rule needs per quad (quad_cone2_bits): the cone of its four vertices AND of the
-// eight points 2 v_i - v_(i+-1) (the extended edges), the smallest distance r of an edge's LINE from the origin (rounded
-// down; it bounds every vertex, every point of an extended edge), the largest norm M of the twelve points (rounded up), the
-// edge condition on all four edges, M <= 2^30.  Per pair: the first quad's extended cone begins >= 5 units behind the end
-// of the second quad's cone (both widened by two units: >= 8.6e-4 rad between any two points), the whole span stays below
-// pi - 8 units, and max(M) <= 128 min(r): the crossings' directions move by <= 17 u M / (0.49 r) < 2.7e-4 rad, which leaves
-// sin(margin) >= 5.8e-4 against the 3.1 u (1 + 261) = 4.9e-5 needed.
+// So all 16 terms are exactly 0.  What the rule needs per quad (quad_cone2_bits): the smallest distance r of an edge's LINE from
+// the origin (rounded down; it bounds every vertex and every point of an extended edge from below), the largest norm M of
+// the twelve points v_i, 2 v_i - v_(i+-1) (rounded up), the edge condition on all four edges, M <= 2^30; the cone of the four
+// vertices (quad_cone_bits) and the cone of the twelve points.  Per pair, with k = max(M) / min(r) <= 4096:
+//   * how far apart the cones must be: a crossing's direction moves by <= 17 u M / (0.49 r) = 2.1e-6 k rad, clip 3's sign needs
+//     sin(angle) > 3.1 u (1 + M / (0.49 r)) = 3.8e-7 k: 0.026 k units of 2 pi / 65536 in all.  Asked for: 5 + k / 16 units between
+//     the cones, both widened by two units (9 + k / 16 between any two points: k = 128: 17 against 3.5 needed, k = 4096: 265
+//     against 112);
+//   * the whole span stays below pi - 8 units;
+//   * tier 1: the first quad's EXTENDED cone is used -- nothing else to check;
+//   * tier 2: the first quad's plain cone is used and quad_cone2_nofuzzy vouches that none of clip 2's sixteen possible sign
+//     values (a vertex of the first quad against an edge line of the second) lies within +-1e-8: every crossing on an edge
+//     (a, b) is then a proper convex combination and stays inside the plain cone.
 struct QuadCone2 {
-  uint32_t ext;   // cone of the twelve points, 16-bit fixed point lo | hi << 16 (kConeNone: no rule)
-  uint32_t rm;    // bf16 bits: r rounded down | M rounded up << 16
+  uint32_t ext;   // cone of the twelve points, 16-bit fixed point lo | hi << 16 (kConeNone: no tier 1)
+  uint32_t rm;    // bf16 bits: r rounded down | M rounded up << 16   (0xffff0000: the quad takes no part in the rule)
 };
+constexpr uint32_t kRmNone = 0xffff0000u;
 OBB_HD QuadCone2 quad_cone2_bits(const QuadFeat& q) {
-  QuadCone2 out; out.ext = kConeNone; out.rm = 0xffff0000u;
+  QuadCone2 out; out.ext = kConeNone; out.rm = kRmNone;
   float lo = 4.f, hi = -4.f, m2 = 0.f, r = __builtin_huge_valf();
   bool ok = quad_signed_area(q.x, q.y) != 0.f;
 #pragma unroll
@@ -327,24 +334,51 @@ OBB_HD QuadCone2 quad_cone2_bits(const QuadFeat& q) {
   }
   const float M = sqrtf(m2) * 1.001f;
   r *= 0.99f;
-  if (!ok || !(hi - lo < 3.1f) || !(M <= 1073741824.f) || !(r > 0.f)) return out;
-  const float sc = 65536.f / 6.2831855f;
-  float ulo = floorf((lo + 3.1415927f) * sc) - 2.f, uhi = ceilf((hi + 3.1415927f) * sc) + 2.f;
-  ulo = ulo < 0.f ? 0.f : ulo; uhi = uhi > 65535.f ? 65535.f : uhi;
-  out.ext = (uint32_t)ulo | ((uint32_t)uhi << 16);
+  if (!ok || !(M <= 1073741824.f) || !(r > 0.f)) return out;
   const uint32_t rb = __builtin_bit_cast(uint32_t, r) >> 16;                       // truncation rounds a positive float down
   const uint32_t mu = __builtin_bit_cast(uint32_t, M);
   const uint32_t mb = (mu >> 16) + ((mu & 0xffffu) ? 1u : 0u);
   out.rm = rb | (mb << 16);
+  if (!(hi - lo < 3.1f)) return out;
+  const float sc = 65536.f / 6.2831855f;
+  float ulo = floorf((lo + 3.1415927f) * sc) - 2.f, uhi = ceilf((hi + 3.1415927f) * sc) + 2.f;
+  ulo = ulo < 0.f ? 0.f : ulo; uhi = uhi > 65535.f ? 65535.f : uhi;
+  out.ext = (uint32_t)ulo | ((uint32_t)uhi << 16);
   return out;
 }
-// p_ext / p_rm: the FIRST argument's extended cone and (r, M); q_cone / q_rm: the second argument's plain cone and (r, M)
-OBB_HD bool quad_cone2_skip(uint32_t p_ext, uint32_t p_rm, uint32_t q_cone, uint32_t q_rm) {
-  const int plo = (int)(p_ext & 0xffffu), phi = (int)(p_ext >> 16), qlo = (int)(q_cone & 0xffffu), qhi = (int)(q_cone >> 16);
-  const uint32_t rmin = (p_rm & 0xffffu) < (q_rm & 0xffffu) ? (p_rm & 0xffffu) : (q_rm & 0xffffu);
-  const uint32_t mmax = (p_rm >> 16) > (q_rm >> 16) ? (p_rm >> 16) : (q_rm >> 16);
-  // bf16 bits of positive numbers order like the numbers; + (7 << 7) = x 128
-  return plo <= phi && qlo <= qhi && plo - qhi >= 5 && (phi - qlo) < 32768 - 8 && mmax <= rmin + (7u << 7);
+// p_cone: the FIRST argument's extended cone (tier 1) or plain cone (tier 2, with quad_cone2_nofuzzy); q_cone: the second
+// argument's plain cone; p_rm / q_rm: their (r, M)
+OBB_HD bool quad_cone2_skip(uint32_t p_cone, uint32_t p_rm, uint32_t q_cone, uint32_t q_rm) {
+  const int plo = (int)(p_cone & 0xffffu), phi = (int)(p_cone >> 16), qlo = (int)(q_cone & 0xffffu), qhi = (int)(q_cone >> 16);
+  const int rmin = (int)((p_rm & 0xffffu) < (q_rm & 0xffffu) ? (p_rm & 0xffffu) : (q_rm & 0xffffu));
+  const int mmax = (int)((p_rm >> 16) > (q_rm >> 16) ? (p_rm >> 16) : (q_rm >> 16));
+  // bf16 bits of positive numbers order like the numbers; 128 bits per octave, the mantissa's piecewise-linear logarithm is
+  // off by < 0.09 octaves: k is taken as the next power of two above the bits' difference (a true ratio <= 1.07 k)
+  const int d = mmax - rmin;
+  if (d > 12 * 128) return false;
+  const int kexp = d <= 0 ? 0 : (d + 127) >> 7;
+  const int gap = 5 + (((1 << kexp) + 15) >> 4);
+  return plo <= phi && qlo <= qhi && plo - qhi >= gap && (phi - qlo) < 32768 - 8;
+}
+// Tier 2's pair check: t = cross(w - u, v - u) for every edge (u, w) of Q and vertex v of P, in one orientation; clip 2 computes
+// the same quantity from either end of the edge with <= 4 u (|ex| + |ey|)(|v - c|_1) of rounding.  Asked for:
+// |t| > 2 x 2^-20 L + 2e-8, L = (|ex| + |ey|)(|v - u|_1 + |e|_1): four times the roundings of t and of the clip's own value.
+OBB_HD bool quad_cone2_nofuzzy(const QuadFeat& P, const QuadFeat& Q) {
+  bool ok = true;
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const int j1 = (j + 1) & 3;
+    const float ux = Q.x[j], uy = Q.y[j], ex = Q.x[j1] - ux, ey = Q.y[j1] - uy;
+    const float e1 = fabsf(ex) + fabsf(ey);
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const float vx = P.x[i] - ux, vy = P.y[i] - uy;
+      const float t = ex * vy - vx * ey;
+      const float L = e1 * (fabsf(vx) + fabsf(vy) + e1);
+      ok = ok && (fabsf(t) > L * (1.f / 524288.f) + 2e-8f);
+    }
+  }
+  return ok;
 }
 
 struct QuadSkip {
