@@ -146,6 +146,74 @@ struct QuadGeom {
   static __device__ __forceinline__ bool hit_exact(const float4* ra, const float4* rb, float thr, float* scr) {
     return iou(unpack(ra[1], ra[2]), unpack(rb[1], rb[2]), scr) > thr;
   }
+  // The same decision for FEW pairs per wave, sixteen lanes per pair: the 16 terms of the reference's sum (a triangle of the
+  // first ring against a triangle of the second, poly_nms_cuda.cu:88-105) are independent, a lane computes one of them in its
+  // own scratch column, the group's first lane adds them in the reference's order (t = 4 i + j, from +0) and decides.  Four
+  // pairs per pass: a wave holding a dozen undecided pairs is through in three term times instead of sixteen.  Every lane of
+  // the wave calls; `want` lanes hold a pair and get its decision.  scr_wave: the wave's scratch (lane columns).
+  static constexpr bool HAS_COOP = true;
+  static constexpr int kCoopMax = 40;            // above this many pairs the lane-per-pair form is as fast
+  static __device__ __forceinline__ bool hit_exact_coop(bool want, const float4* ra, const float4* rb, float thr, float* scr_wave) {
+    float v[16];
+    if (want) {
+      const float4 a1 = ra[1], a2 = ra[2], b1 = rb[1], b2 = rb[2];
+      v[0] = a1.x; v[1] = a1.y; v[2] = a1.z; v[3] = a1.w; v[4] = a2.x; v[5] = a2.y; v[6] = a2.z; v[7] = a2.w;
+      v[8] = b1.x; v[9] = b1.y; v[10] = b1.z; v[11] = b1.w; v[12] = b2.x; v[13] = b2.y; v[14] = b2.z; v[15] = b2.w;
+    } else {
+#pragma unroll
+      for (int k = 0; k < 16; k++) v[k] = 0.f;
+    }
+    return iou_coop(want, v, scr_wave) > thr;       // (lanes without a pair: NaN > thr is false)
+  }
+  // v: the lane's pair as x0 y0 .. x3 y3 of the first quad, then of the second; returns the pair's IoU to its lane (NaN to the others)
+  static __device__ __forceinline__ float iou_coop(bool want, const float (&v)[16], float* scr_wave) {
+    const int lane = threadIdx.x & 63;
+    const unsigned long long m = __ballot(want);
+    const int np = __popcll(m);
+    const unsigned long long below = (1ull << lane) - 1ull;
+    // lane k learns which lane holds the pair of rank k (the others fill the permutation behind the np pairs)
+    const int rank = want ? __popcll(m & below) : np + __popcll(~m & below);
+    const int holder = __builtin_amdgcn_ds_permute(rank << 2, lane);
+    const int sub = lane >> 4, t = lane & 15, ti = t >> 2, tj = t & 3;
+    float mine = __builtin_nanf("");
+    for (int p = 0; p * 4 < np; p++) {
+      const int kk = p * 4 + sub;
+      const int src = __shfl(holder, kk < np ? kk : 0);
+      float w[16];
+#pragma unroll
+      for (int k = 0; k < 16; k++) w[k] = __shfl(v[k], src);
+      // the rings as the reference orients them (reversed when the signed area is negative, poly_nms_cuda.cu:108-109)
+      float px_[4] = {w[0], w[2], w[4], w[6]}, py_[4] = {w[1], w[3], w[5], w[7]};
+      float qx_[4] = {w[8], w[10], w[12], w[14]}, qy_[4] = {w[9], w[11], w[13], w[15]};
+      const float s1 = quad_signed_area(px_, py_), s2 = quad_signed_area(qx_, qy_);
+      float ax[4], ay[4], bx[4], by[4];
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        ax[i] = (s1 < 0) ? px_[3 - i] : px_[i]; ay[i] = (s1 < 0) ? py_[3 - i] : py_[i];
+        bx[i] = (s2 < 0) ? qx_[3 - i] : qx_[i]; by[i] = (s2 < 0) ? qy_[3 - i] : qy_[i];
+      }
+      const int i1 = (ti + 1) & 3, j1 = (tj + 1) & 3;
+      const float pax = ti == 0 ? ax[0] : ti == 1 ? ax[1] : ti == 2 ? ax[2] : ax[3];
+      const float pay = ti == 0 ? ay[0] : ti == 1 ? ay[1] : ti == 2 ? ay[2] : ay[3];
+      const float pbx = i1 == 0 ? ax[0] : i1 == 1 ? ax[1] : i1 == 2 ? ax[2] : ax[3];
+      const float pby = i1 == 0 ? ay[0] : i1 == 1 ? ay[1] : i1 == 2 ? ay[2] : ay[3];
+      const float qcx = tj == 0 ? bx[0] : tj == 1 ? bx[1] : tj == 2 ? bx[2] : bx[3];
+      const float qcy = tj == 0 ? by[0] : tj == 1 ? by[1] : tj == 2 ? by[2] : by[3];
+      const float qdx = j1 == 0 ? bx[0] : j1 == 1 ? bx[1] : j1 == 2 ? bx[2] : bx[3];
+      const float qdy = j1 == 0 ? by[0] : j1 == 1 ? by[1] : j1 == 2 ? by[2] : by[3];
+      float term = 0.f;
+      float* c0 = scr_wave + lane;
+      if (kk < np) term = ptri_tri<64>(pax, pay, pbx, pby, qcx, qcy, qdx, qdy, c0, c0 + 10 * 64, c0 + 20 * 64, c0 + 30 * 64);
+      float inter = 0.f;
+#pragma unroll
+      for (int k = 0; k < 16; k++) inter += __shfl(term, (lane & 48) + k);
+      const float ua = pabs(quad_signed_area(ax, ay)) + pabs(quad_signed_area(bx, by)) - inter;
+      const float iouv = (ua == 0.f) ? (inter + 1.f) / (ua + 1.f) : inter / ua;     // :136-137
+      const float got = __shfl(iouv, (rank & 3) << 4);
+      if (want && (rank >> 2) == p) mine = got;
+    }
+    return mine;
+  }
 };
 
 // Double-precision quads for the tile -> full-image merge (DOTA_devkit/ResultMerge_multi_process.py:62-123,

@@ -291,6 +291,34 @@ __device__ __forceinline__ bool stage_exact(const float4* ra, const float4* rb, 
   else return G::hit_exact(ra, rb, thr, scr);
 }
 
+// Wave-level form of the exact stage: every lane of the wave calls, `want` lanes hold a pair.  A geometry whose exact stage
+// splits into independent parts (QuadGeom: the 16 terms of the reference's sum) decides a FEW pairs with several lanes per
+// pair (geom.h: hit_exact_coop) -- a leftover drain of a dozen quad pairs costs three term times instead of sixteen.
+template <class G> struct has_coop { template <class T> static constexpr bool f(decltype(T::HAS_COOP)*) { return T::HAS_COOP; } template <class T> static constexpr bool f(...) { return false; } static constexpr bool value = f<G>(nullptr); };
+template <class G, class TH>
+__device__ OBB_STAGE_ATTR bool nms_stage_exact_coop(bool want, const float4* ra, const float4* rb, TH thr, float* scr_wave) {
+  if constexpr (has_coop<G>::value) return G::hit_exact_coop(want, ra, rb, thr, scr_wave);
+  else return false;
+}
+template <class G, bool FN, class TH>
+__device__ __forceinline__ bool stage_exact_wave(bool want, const float4* ra, const float4* rb, TH thr, float* scr_wave) {
+  if constexpr (has_coop<G>::value) {
+    if (__popcll(__ballot(want)) <= G::kCoopMax) return nms_stage_exact_coop<G>(want, ra, rb, thr, scr_wave);
+  }
+  bool hit = false;
+  if (want) hit = stage_exact<G, FN>(ra, rb, thr, scr_wave + (threadIdx.x & 63));
+  return hit;
+}
+// how many pooled leftover pairs a wave takes per trip: 64, or -- where few pairs are decided faster by several lanes each --
+// an even share of the pool (a multiple of four: four pairs per pass)
+template <class G>
+__device__ __forceinline__ int exact_pool_share(int total) {
+  if constexpr (has_coop<G>::value) {
+    if (total <= kNmsWaves * G::kCoopMax) { const int s = ((total + kNmsWaves - 1) / kNmsWaves + 3) & ~3; return s < 4 ? 4 : s; }
+  }
+  return 64;
+}
+
 // Ring queue of pending (row, col) pairs in LDS; all bookkeeping is wave-uniform.
 struct PairQueue {
   uint32_t* q;  // LDS, 128 entries
@@ -384,13 +412,13 @@ __device__ __forceinline__ void nms_pairs(const NmsArgs& a, int tm, int cn, cons
   // stage 2: exact clip; entries are chunk-local (i << 16 | j), so the queue lives across tiles
   auto drain2 = [&](int cnt) {
     wave_sync();
-    bool hit = false;
     uint32_t packed = 0;
+    uint32_t pi = 0, pj = 0;
     if (lane < cnt) {
       packed = L.qbuf2[(Q2.head + lane) & 127];
-      const uint32_t pi = cidx[packed >> 16], pj = cidx[packed & 0xffff];
-      hit = stage_exact<G, FN>(a.rec + (size_t)pi * G::RECQ, a.rec + (size_t)pj * G::RECQ, G::thr_of(a), L.scr + lane);
+      pi = cidx[packed >> 16]; pj = cidx[packed & 0xffff];
     }
+    const bool hit = stage_exact_wave<G, FN>(lane < cnt, a.rec + (size_t)pi * G::RECQ, a.rec + (size_t)pj * G::RECQ, G::thr_of(a), L.scr);
     const u64 hm = __ballot(hit);
     if (hm) {
       int base = 0;
@@ -586,15 +614,16 @@ __device__ __forceinline__ void nms_pairs(const NmsArgs& a, int tm, int cn, cons
     Q2.count = 0;
     __syncthreads();
     const int total = *s_pool;
-    for (int c0 = (threadIdx.x >> 6) * 64; c0 < total; c0 += kNmsWaves * 64) {
-      const int cnt = min(64, total - c0);
-      bool hit = false;
+    const int share = exact_pool_share<G>(total);
+    for (int c0 = (threadIdx.x >> 6) * share; c0 < total; c0 += kNmsWaves * share) {
+      const int cnt = min(share, total - c0);
       uint32_t packed = 0;
+      uint32_t pi = 0, pj = 0;
       if (lane < cnt) {
         packed = pool_at(c0 + lane);
-        const uint32_t pi = cidx[packed >> 16], pj = cidx[packed & 0xffff];
-        hit = stage_exact<G, FN>(a.rec + (size_t)pi * G::RECQ, a.rec + (size_t)pj * G::RECQ, G::thr_of(a), L.scr + lane);
+        pi = cidx[packed >> 16]; pj = cidx[packed & 0xffff];
       }
+      const bool hit = stage_exact_wave<G, FN>(lane < cnt, a.rec + (size_t)pi * G::RECQ, a.rec + (size_t)pj * G::RECQ, G::thr_of(a), L.scr);
       emit(hit, packed);
       p_n2++;
     }
@@ -1021,13 +1050,18 @@ __device__ __forceinline__ void nms_cross(const NmsArgs& a, const uint32_t* rows
     L.colpos[lane] = c;
     auto drain2 = [&](int cnt) {                   // stage 2: exact clip; entries carry the row position itself
       wave_sync();
-      if (lane < cnt) {
-        const int slot = (Q2.head + lane) & 127;
-        const uint32_t rowp = L.qbuf2[slot];
-        const int cc = L.q2col[slot];
-        if (!L.cdead[cc]) {
-          if (stage_exact<G, FN>(a.rec + (size_t)rowp * G::RECQ, a.rec + (size_t)L.colpos[cc] * G::RECQ, G::thr_of(a), L.scr + lane)) L.cdead[cc] = 1;
+      {
+        uint32_t rowp = 0, colp = 0;
+        int cc = 0;
+        bool want = false;
+        if (lane < cnt) {
+          const int slot = (Q2.head + lane) & 127;
+          rowp = L.qbuf2[slot];
+          cc = L.q2col[slot];
+          want = !L.cdead[cc];
+          colp = L.colpos[cc];
         }
+        if (stage_exact_wave<G, FN>(want, a.rec + (size_t)rowp * G::RECQ, a.rec + (size_t)colp * G::RECQ, G::thr_of(a), L.scr)) L.cdead[cc] = 1;
       }
       Q2.head = (Q2.head + cnt) & 127;
       Q2.count -= cnt;
@@ -1245,14 +1279,15 @@ __device__ __forceinline__ void nms_cross_grid(const NmsArgs& a, const GridPlan&
   };
   auto drain2 = [&](int cnt) {                     // stage 2: exact clip
     wave_sync();
-    bool hit = false;
-    uint32_t cp = 0;
+    uint32_t cp = 0, rowp = 0;
+    bool want = false;
     if (lane < cnt) {
       const int slot = (Q2.head + lane) & 127;
-      const uint32_t rowp = L.qbuf2[slot];
+      rowp = L.qbuf2[slot];
       cp = L.qcol2[slot];
-      if (col_alive(cp)) hit = nms_stage_exact<G>(a.rec + (size_t)rowp * G::RECQ, a.rec + (size_t)cp * G::RECQ, G::thr_of(a), L.scr + lane);
+      want = col_alive(cp);
     }
+    const bool hit = stage_exact_wave<G, true>(want, a.rec + (size_t)rowp * G::RECQ, a.rec + (size_t)cp * G::RECQ, G::thr_of(a), L.scr);
     kill(hit, cp);
     Q2.head = (Q2.head + cnt) & 127;
     Q2.count -= cnt;

@@ -116,11 +116,21 @@ __global__ __launch_bounds__(64) void k_quad_strip(const float* __restrict__ a, 
   int head = 0, count = 0;                               // wave-uniform
   auto drain = [&](int cnt) {
     __builtin_amdgcn_wave_barrier();
-    if (lane < cnt) {
+    const bool want = lane < cnt;
+    int r = 0;
+    long long j = 0;
+    QuadFeat A = {}, B = {};
+    if (want) {
       const uint32_t e = queue[(head + lane) & 127];
-      const int r = (int)(e >> 28);
-      const long long j = j0 + (long long)(e & 0x0fffffffu);
-      const QuadFeat A = QuadGeom::unpack(rowq[r * 2], rowq[r * 2 + 1]), B = load_quad(b, sb, j);
+      r = (int)(e >> 28);
+      j = j0 + (long long)(e & 0x0fffffffu);
+      A = QuadGeom::unpack(rowq[r * 2], rowq[r * 2 + 1]); B = load_quad(b, sb, j);
+    }
+    if (cnt <= QuadGeom::kCoopMax) {                      // a partial queue: sixteen lanes per pair (geom.h), same bits
+      const float v[16] = {A.x[0], A.y[0], A.x[1], A.y[1], A.x[2], A.y[2], A.x[3], A.y[3], B.x[0], B.y[0], B.x[1], B.y[1], B.x[2], B.y[2], B.x[3], B.y[3]};
+      const float val = QuadGeom::iou_coop(want, v, scr);
+      if (want) out[(i0 + r) * k + j] = val;
+    } else if (want) {
       out[(i0 + r) * k + j] = QuadGeom::iou(A, B, scr + lane);
     }
     head = (head + cnt) & 127; count -= cnt;
