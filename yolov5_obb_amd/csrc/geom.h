@@ -110,9 +110,10 @@ struct RotGeom {
 };
 
 struct QuadGeom {
-  static constexpr int RECQ = 3;
+  static constexpr int RECQ = 4;               // q3 = {extended cone, (r, M), -, -}: the second cone rule (classify_quick)
   static constexpr int SCR = 40;  // 2 x 10 points x (x,y) per lane
   // q0 = {fp16 minx | miny, fp16 maxx | maxy (rounded outward), budget f, cone (piou_device.h: quad_cone_bits)}   q1 = {x0, y0, x1, y1}   q2 = {x2, y2, x3, y3}
+  //      (f = -inf: the first two words are the extended cone and (r, M) of piou_device.h's second cone rule instead)
   // The reference's quad IoU sums signed triangle areas taken from the coordinate origin; for disjoint quads the terms
   // cancel only up to rounding noise that grows with the square of the coordinates, so "IoU == 0" cannot be predicted
   // from a bounding-box test alone.  Two rules (piou_device.h): a pair is skipped when the column box's cone lies
@@ -125,7 +126,11 @@ struct QuadGeom {
     QuadSkip A, B;
     A.lo = __builtin_bit_cast(uint32_t, a.x); A.hi = __builtin_bit_cast(uint32_t, a.y); A.f = a.z;
     B.lo = __builtin_bit_cast(uint32_t, b.x); B.hi = __builtin_bit_cast(uint32_t, b.y); B.f = b.z;
-    return quad_cone_skip(__builtin_bit_cast(uint32_t, a.w), __builtin_bit_cast(uint32_t, b.w)) || quad_skip_pair(A, B);
+    if (quad_cone_skip(__builtin_bit_cast(uint32_t, a.w), __builtin_bit_cast(uint32_t, b.w)) || quad_skip_pair(A, B)) return true;
+    // two quads without a budget (f = -inf: OBB_NMS_POLY_STRICT=1, thr <= 0, outside the searched envelope) carry the second
+    // proved rule's words in place of their boxes (k_prep_quad): the row quad's extended cone counter-clockwise of the column quad's cone
+    const float ninf = -__builtin_huge_valf();
+    return a.z == ninf && b.z == ninf && quad_cone2_skip(A.lo, A.hi, __builtin_bit_cast(uint32_t, b.w), B.hi);
   }
   static constexpr bool PACKED = false;
   static OBB_HD QuadFeat unpack(const float4& q0, const float4& q1) {
@@ -141,7 +146,18 @@ struct QuadGeom {
   static constexpr bool HAS_FAST = false;      // every pair that is not skipped is clipped: no value bounds for this formulation
   static constexpr bool HAS_GRID = false;
   template <class A> static __device__ __forceinline__ float thr_of(const A& a) { return a.thr; }
-  static __device__ __forceinline__ int classify_quick(const float4*, const float4*, float, bool) { return 2; }
+  // The second PROVED cone rule (piou_device.h: the row quad counter-clockwise of the column quad as seen from the origin): tier 1 on
+  // the row's extended cone, tier 2 on its plain cone + the pair check on the coordinates.  IoU = +0 exactly: not a hit for thr >= 0.
+  static __device__ __forceinline__ int classify_quick(const float4* ra, const float4* rb, float thr, bool cull) {
+    if (!cull || !(thr >= 0.f)) return 2;
+    const float4 a3 = ra[3], b3 = rb[3];
+    const uint32_t a_rm = __builtin_bit_cast(uint32_t, a3.y), b_rm = __builtin_bit_cast(uint32_t, b3.y);
+    const uint32_t cb = __builtin_bit_cast(uint32_t, rb[0].w);
+    if (quad_cone2_skip(__builtin_bit_cast(uint32_t, a3.x), a_rm, cb, b_rm)) return 0;
+    if (quad_cone2_skip(__builtin_bit_cast(uint32_t, ra[0].w), a_rm, cb, b_rm) &&
+        quad_cone2_nofuzzy(unpack(ra[1], ra[2]), unpack(rb[1], rb[2]))) return 0;
+    return 2;
+  }
   static __device__ __forceinline__ int classify_full(const float4*, const float4*, float) { return 2; }
   static __device__ __forceinline__ bool hit_exact(const float4* ra, const float4* rb, float thr, float* scr) {
     return iou(unpack(ra[1], ra[2]), unpack(rb[1], rb[2]), scr) > thr;

@@ -318,9 +318,19 @@ __global__ void k_prep_quad(const float* __restrict__ polys, int stride, const u
     const QuadFeat qf = quad_make_feat(c);
     const QuadSkip sk = quad_skip_record(qf, (skip & 2) ? thr : 0.f);
     const uint32_t cone = (skip & 1) ? quad_cone_bits(qf) : kConeNone;
-    rec[(size_t)p * 3 + 0] = make_float4(__builtin_bit_cast(float, sk.lo), __builtin_bit_cast(float, sk.hi), sk.f, __builtin_bit_cast(float, cone));
-    rec[(size_t)p * 3 + 1] = make_float4(c[0], c[1], c[2], c[3]);
-    rec[(size_t)p * 3 + 2] = make_float4(c[4], c[5], c[6], c[7]);
+    uint32_t w0 = sk.lo, w1 = sk.hi;
+    QuadCone2 c2w; c2w.ext = kConeNone; c2w.rm = kRmNone;
+    if (skip & 1) c2w = quad_cone2_bits(qf);
+    if ((skip & 1) && sk.f == -__builtin_huge_valf()) {
+      // a quad without a budget takes no part in the bounding-box rule: its two box words carry what the SECOND proved rule
+      // needs instead (piou_device.h: the extended cone and (r, M); QuadGeom::cheap_reject reads them when both budgets are -inf)
+      w0 = c2w.ext; w1 = c2w.rm;
+    }
+    float4* r = rec + (size_t)p * QuadGeom::RECQ;
+    r[0] = make_float4(__builtin_bit_cast(float, w0), __builtin_bit_cast(float, w1), sk.f, __builtin_bit_cast(float, cone));
+    r[1] = make_float4(c[0], c[1], c[2], c[3]);
+    r[2] = make_float4(c[4], c[5], c[6], c[7]);
+    r[3] = make_float4(__builtin_bit_cast(float, c2w.ext), __builtin_bit_cast(float, c2w.rm), 0.f, 0.f);     // the second cone rule's words (QuadGeom::classify_quick)
   }
   const u64 m = __ballot(p < n);
   if ((threadIdx.x & 63) == 0 && (p & ~63) < n) alive[p >> 6] = m;
@@ -461,7 +471,7 @@ struct Carve {
 // table slots of the spatial index (power of two, multiple of 4096)
 // cells of side 2 R_L / 2^fine (grid.h): 1 measured best at 100k (K=3000: 716 -> 648 us, uniform 2361 -> 2138; 2: no further gain)
 static int grid_fine() { static const int f = [] { const int v = obb_dev_switch("OBB_GRID_FINE", 1); return (v < 0 || v > 2) ? 1 : v; }(); return f; }
-// Skip rules of the quad NMS (piou_device.h): bit 0 = the exact cone rule (proved), bit 1 = the bounding-box rule (measured noise
+// Skip rules of the quad NMS (piou_device.h): bit 0 = the two exact cone rules (proved), bit 1 = the bounding-box rule (measured noise
 // bound).  OBB_NMS_POLY_STRICT=1: cone rule only (every other pair is clipped); =2: no rule at all, every pair is clipped.
 static int quad_skip() {
   static const int f = [] { const char* e = getenv("OBB_NMS_POLY_STRICT"); const int v = e ? atoi(e) : 0; return v == 1 ? 1 : (v >= 2 ? 0 : 3); }();
