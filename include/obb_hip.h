@@ -61,7 +61,7 @@ int obb_profile_enable(int on);
 int obb_profile_collect(double* ms_sum_host, int64_t* count_host, int n_stages);
 
 /* Environment variables read by the library (once per process).  Every build:
- *   OBB_NMS_POLY_STRICT=1   quad NMS: only the proved skip rule (csrc/piou_device.h: the cone rule); =2: no rule at all, every pair
+ *   OBB_NMS_POLY_STRICT=1   quad NMS: only the proved skip rules (csrc/piou_device.h: the two cone rules); =2: no rule at all, every pair
  *                           is clipped like the reference does (tests/test_nms_gpu.py::test_nms_poly_strict_equals_skip_100k)
  *   OBB_NMS_PHASE_PROF=1    in-kernel phase timers of the single-list NMS (either path), printed to stderr (synchronises; development aid)
  * Read per call (tests switch paths inside one process; nothing but speed depends on them -- the kept list is the same on every path):
@@ -119,9 +119,10 @@ int obb_nms_rotated_f64(const double* dets5, const double* scores, int64_t n, fl
  * bounding boxes are disjoint AND whose areas outweigh the rounding noise of the reference's origin-based sum (a bound of
  * 1024 * 2^-24 * M^2 per box, M = its largest |coordinate|) are not clipped.  That bound is backed by search
  * (2.8 * 10^10 skip decisions, none wrong), not by proof, and is only applied inside the envelope the search covered: a quad with
- * every |coordinate| <= 70,000 and a bounding box of at most 600 x 600; any other quad is decided by the proved rule (the second
- * quad's cone counter-clockwise of the first's: all 16 terms exactly zero) or clipped like the reference does.
- * OBB_NMS_POLY_STRICT=1 keeps only the proved rule, =2 clips every pair.
+ * every |coordinate| <= 70,000 and a bounding box of at most 600 x 600; any other quad is decided by the two PROVED rules (the two
+ * quads' cones, as seen from the coordinate origin, apart by a margin in either order: all 16 terms exactly zero -- csrc/piou_device.h:
+ * quad_cone_skip, quad_cone2_skip / quad_cone2_nofuzzy) or clipped like the reference does.
+ * OBB_NMS_POLY_STRICT=1 keeps only the proved rules (4.5x the default's time at 30,000 quads), =2 clips every pair.
  */
 int obb_nms_poly_f32(const float* polys, int64_t row_stride, int64_t n, float iou_thr, int64_t max_keep, int64_t* keep_out,
                      int64_t* num_keep, void* ws, size_t ws_bytes, void* stream);
@@ -426,7 +427,8 @@ int obb_process_batch_f32(const float* det6, int64_t n, const float* lab5, int64
 int obb_rotated_iou_pairs_f32(const float* a5, const float* b5, int64_t n, float* out, void* stream);
 /* out[i*k + j] = IoU(a5[i], b5[j]) */
 int obb_rotated_iou_matrix_f32(const float* a5, int64_t n, const float* b5, int64_t k, float* out, void* stream);
-/* out[i*k + j] = quad IoU of rows (first 8 floats used) -- devPolyIoU, utils/nms_rotated/src/poly_nms_cuda.cu:122-142 */
+/* out[i*k + j] = quad IoU of rows (first 8 floats used) -- devPolyIoU, utils/nms_rotated/src/poly_nms_cuda.cu:122-142.
+ * Entries the two proved cone rules of csrc/piou_device.h vouch for are written as the exact +0 the clip would return. */
 int obb_quad_iou_matrix_f32(const float* a, int64_t a_stride, int64_t n, const float* b, int64_t b_stride, int64_t k,
                             float* out, void* stream);
 /* Dense IoU matrix of rboxes through RotBox2Poly + devPolyIoU: the overlaps_kernel of
