@@ -295,6 +295,29 @@ def test_nms_poly_skip_rule(dev, oracle_lib, thr):
     assert np.array_equal(ref, got)
 
 
+@pytest.mark.parametrize("extent,thr", [(4096.0, 0.1), (4096.0, 0.4), (30000.0, 0.3), (200.0, 0.0)])
+def test_nms_poly_second_cone_rule_large_extents(dev, oracle_lib, extent, thr):
+    """Round 6: the second proved cone rule inside the NMS kernels (QuadGeom::classify_quick: tier 1 on the extended cone, tier 2 on
+    the plain cone + the pair check; QuadGeom::cheap_reject for budget-less quads).  On large extents rule B has no budget (its noise
+    bound grows with the square of the coordinates) and the two cone rules decide almost every pair: 4,000 clustered + uniform quads
+    incl. clockwise rings and integer coordinates against the oracle, which clips every pair; thr = 0 on a small extent (no rule B at
+    thr <= 0: every quad is budget-less and carries the rule's words in its hot-loop record)."""
+    from yolov5_obb_amd import nms_rotated_ext
+    d0, s0 = synth.s_clustered(3000, 150, seed=31, extent=extent)
+    d1, s1 = synth.s_uniform(1000, 32, extent=extent)
+    dets = torch.cat([d0, d1])
+    scores = synth.tie_free(torch.cat([s0, s1]))
+    quads = synth.rbox_to_quad(dets)
+    quads[3::11] = quads[3::11].reshape(-1, 4, 2).flip(1).reshape(-1, 8)
+    quads[4::13] = quads[4::13].round()
+    polys = torch.cat([quads, scores[:, None]], 1).contiguous()
+    ref = oracle.nms_poly(polys.numpy(), thr)
+    for _ in range(2):
+        got = nms_rotated_ext.nms_poly(polys.to(dev), thr).cpu().numpy()
+        assert np.array_equal(ref, got)
+    assert 10 < len(ref) < 4000
+
+
 def test_nms_poly_strict_equals_skip_100k(dev, tmp_path):
     """The skip rule of the quad NMS (csrc/piou_device.h) against the same library with the rule switched off
     (OBB_NMS_POLY_STRICT=1: every pair is clipped, as the reference does) at N = 100,000 quads in three layouts -- a 1024 px

@@ -421,6 +421,8 @@ __global__ void k_finalize(const int* __restrict__ keep_cnt, const int* __restri
     if (tstart != nullptr && !starved) {
       const u64 dtk = wall_clock64() - *tstart;
       __hip_atomic_store(feedback + 4 + (feedback_slab ? 0 : 1), (int)(dtk > 0x3fffffffull ? 0x3fffffffull : dtk), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      // ... and on how many kept boxes: a time measured on other data of the size class is not compared (mk_choose)
+      __hip_atomic_store(feedback + 6 + (feedback_slab ? 0 : 1), (int)c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
   }
 }
@@ -729,7 +731,13 @@ static bool mk_choose(MkFeedback* f) {
   if (kept < 0 || (k & 63u) == 0u) return false;
   if (!(slab != 1 && kept >= kMkMinKept)) return false;
   const int t_persist = *(volatile int*)(f->words + 4), t_mk = *(volatile int*)(f->words + 5);
-  if (t_persist <= 0 || t_mk <= 0) return true;        // (the phase kernels have not reported yet: try them)
+  // a time only counts for data like the data it was measured on: the kept count it came with ([6], [7]) within a quarter of the
+  // previous call's.  (bench.py switches regimes of one size class every 24 calls: K=3000 + 18 class offsets inherited "phase
+  // kernels are faster" from K=3000 and stayed on them at 0.62 ms against the persistent kernel's 0.51 until the 64th call.)
+  const int k_persist = *(volatile int*)(f->words + 6), k_mk = *(volatile int*)(f->words + 7);
+  auto stale = [&](int kk) { const int d = kk > kept ? kk - kept : kept - kk; return kk < 0 || d > kept / 4 + 16; };
+  if (t_mk <= 0 || stale(k_mk)) return true;           // (the phase kernels have not reported on such data yet: try them)
+  if (t_persist <= 0 || stale(k_persist)) return false;
   if ((k & 63u) == 32u) return t_mk >= t_persist;      // the slower one's turn
   return t_mk < t_persist;
 }

@@ -8,7 +8,7 @@
 // (oracle/piou_impl.inc) restates.  The reference's per-thread arrays sized by
 // `maxn` (10 / 51 / 510 float2 depending on the copy) are replaced by a
 // 2 x 10-point scratch with a compile-time lane stride (an LDS column per lane
-// on the GPU).  One pinning of undefined behaviour: the one
+// on the GPU); the clip ping-pongs between the two halves.  One pinning of undefined behaviour: the one
 // indeterminate read of the reference (lineCross leaving pp[m] unwritten): that
 // vertex is defined as (0,0) here and in the oracle.
 #pragma once
@@ -49,38 +49,48 @@ OBB_HD T ptri(T ox, T oy, T ax, T ay, T bx, T by) {
   return (ax - ox) * (by - oy) - (bx - ox) * (ay - oy);
 }
 
-// keep the part of polygon p (n vertices, scratch stride STRIDE) left of a->b
+// keep the part of polygon p (n vertices, scratch stride STRIDE) left of a->b; the result goes to q (the caller swaps the two
+// scratch halves between clips).  The reference (poly_nms_cuda.cu:46-72, cut) writes the raw crossings / kept vertices to a second
+// array, copies them back dropping every point within 1e-8 of its RAW predecessor, then drops trailing points within 1e-8 of the
+// first.  Same points, same arithmetic, one pass: a point is compared with its raw predecessor (held in registers) as it is
+// produced and stored only when it stays; the closing edge reads vertex 0 again instead of a sentinel copy behind the last one.
 template <int STRIDE, typename T>
-OBB_HD int pclip(T* px, T* py, int n, T ax, T ay, T bx, T by, T* qx, T* qy) {
-  int m = 0;
-  px[n * STRIDE] = px[0]; py[n * STRIDE] = py[0];
+OBB_HD int pclip(const T* px, const T* py, int n, T ax, T ay, T bx, T by, T* qx, T* qy) {
   T cx = px[0], cy = py[0];
   T s1 = ptri(ax, ay, bx, by, cx, cy);
   int g1 = psgn(s1);
+  int k = 0;
+  bool first = true;
+  T lx = 0, ly = 0, fx = 0, fy = 0;          // the raw predecessor; the first stored point
   for (int i = 0; i < n; i++) {
-    T dx = px[(i + 1) * STRIDE], dy = py[(i + 1) * STRIDE];
+    const int nx = (i + 1 == n) ? 0 : i + 1;
+    T dx = px[nx * STRIDE], dy = py[nx * STRIDE];
     T s2 = ptri(ax, ay, bx, by, dx, dy);
     int g2 = psgn(s2);
-    if (g1 > 0) { qx[m * STRIDE] = cx; qy[m * STRIDE] = cy; m++; }
+    if (g1 > 0) {
+      if (first || !(psgn(cx - lx) == 0 && psgn(cy - ly) == 0)) {
+        qx[k * STRIDE] = cx; qy[k * STRIDE] = cy;
+        if (k == 0) { fx = cx; fy = cy; }
+        k++;
+      }
+      lx = cx; ly = cy; first = false;
+    }
     if (g1 != g2) {
       T den = s2 - s1;
       bool ok = psgn(den) != 0;   // (both-zero cannot occur here: the signs differ)
       // unwritten in the reference when !ok (indeterminate); pinned to (0,0) here and in the oracle
-      qx[m * STRIDE] = ok ? (cx * s2 - dx * s1) / den : T(0);
-      qy[m * STRIDE] = ok ? (cy * s2 - dy * s1) / den : T(0);
-      m++;
+      const T ix = ok ? (cx * s2 - dx * s1) / den : T(0);
+      const T iy = ok ? (cy * s2 - dy * s1) / den : T(0);
+      if (first || !(psgn(ix - lx) == 0 && psgn(iy - ly) == 0)) {
+        qx[k * STRIDE] = ix; qy[k * STRIDE] = iy;
+        if (k == 0) { fx = ix; fy = iy; }
+        k++;
+      }
+      lx = ix; ly = iy; first = false;
     }
     cx = dx; cy = dy; s1 = s2; g1 = g2;
   }
-  int k = 0;
-  T lx = 0, ly = 0;
-  for (int i = 0; i < m; i++) {
-    T x = qx[i * STRIDE], y = qy[i * STRIDE];
-    if (i == 0 || !(psgn(x - lx) == 0 && psgn(y - ly) == 0)) { px[k * STRIDE] = x; py[k * STRIDE] = y; k++; }
-    lx = x; ly = y;
-  }
-  T fx = px[0], fy = py[0];
-  while (k > 1 && psgn(px[(k - 1) * STRIDE] - fx) == 0 && psgn(py[(k - 1) * STRIDE] - fy) == 0) k--;
+  while (k > 1 && psgn(qx[(k - 1) * STRIDE] - fx) == 0 && psgn(qy[(k - 1) * STRIDE] - fy) == 0) k--;
   return k;
 }
 
@@ -98,14 +108,14 @@ OBB_HD T ptri_tri(T ax, T ay, T bx, T by, T cx, T cy, T dx, T dy, T* px, T* py, 
   px[2 * STRIDE] = bx; py[2 * STRIDE] = by;
   int n = 3;
   n = pclip<STRIDE>(px, py, n, z, z, cx, cy, qx, qy);
-  n = pclip<STRIDE>(px, py, n, cx, cy, dx, dy, qx, qy);
+  n = pclip<STRIDE>(qx, qy, n, cx, cy, dx, dy, px, py);
   n = pclip<STRIDE>(px, py, n, dx, dy, z, z, qx, qy);
-  // shoelace
-  px[n * STRIDE] = px[0]; py[n * STRIDE] = py[0];
+  // shoelace (the polygon sits in q; the closing edge returns to vertex 0)
   T acc = 0;
-  T x0 = px[0], y0 = py[0];
+  T x0 = qx[0], y0 = qy[0];
   for (int i = 0; i < n; i++) {
-    T x1 = px[(i + 1) * STRIDE], y1 = py[(i + 1) * STRIDE];
+    const int nx = (i + 1 == n) ? 0 : i + 1;
+    T x1 = qx[nx * STRIDE], y1 = qy[nx * STRIDE];
     acc += x0 * y1 - y0 * x1;
     x0 = x1; y0 = y1;
   }
