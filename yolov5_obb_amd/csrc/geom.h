@@ -168,7 +168,10 @@ struct QuadGeom {
   // pairs per pass: a wave holding a dozen undecided pairs is through in three term times instead of sixteen.  Every lane of
   // the wave calls; `want` lanes hold a pair and get its decision.  scr_wave: the wave's scratch (lane columns).
   static constexpr bool HAS_COOP = true;
-  static constexpr int kCoopMax = 40;            // above this many pairs the lane-per-pair form is as fast
+#ifndef OBB_QUAD_COOP_MAX
+#define OBB_QUAD_COOP_MAX 40
+#endif
+  static constexpr int kCoopMax = OBB_QUAD_COOP_MAX;            // above this many pairs the lane-per-pair form is as fast
   static __device__ __forceinline__ bool hit_exact_coop(bool want, const float4* ra, const float4* rb, float thr, float* scr_wave) {
     float v[16];
     if (want) {

@@ -80,7 +80,10 @@ __device__ __forceinline__ void rbox_to_quad_devkit(const float* d, float* qx, f
 // workgroups of 11 KB LDS: 14 per CU, handed out by the dispatcher as they finish (the units' clip counts differ), no
 // workgroup barrier anywhere; the row records live in the first 16 lanes' registers (v_readlane per row), the queued pair's
 // column quad is read again from global memory when its clip runs.
-constexpr int kQsRows = 16;
+#ifndef OBB_QS_ROWS
+#define OBB_QS_ROWS 16
+#endif
+constexpr int kQsRows = OBB_QS_ROWS;      // <= 16 (four bits of a queue entry)
 template <bool DEVKIT>
 __global__ __launch_bounds__(64) void k_quad_strip(const float* __restrict__ a, long long sa, long long n, const float* __restrict__ b,
                                                    long long sb, long long k, float* __restrict__ out, int chunk, int nchunks) {
