@@ -430,3 +430,82 @@ def test_sort_prep_class_buckets_and_the_network_fallback(dev, oracle_lib):
         general.hints_clear()
         for rep in range(3):
             _cmp(general.non_max_suppression_obb(p.to(dev), **kw), ref, ties=half)
+
+
+def _stage_counts(L):
+    import ctypes as C
+    ms = (C.c_double * 8)()
+    cnt = (C.c_int64 * 8)()
+    assert L.obb_profile_collect(C.cast(ms, C.c_void_p), C.cast(cnt, C.c_void_p), 8) == 0
+    return list(cnt)
+
+
+def test_self_sorting_segments_equal_the_sort_kernel(dev, oracle_lib, monkeypatch):
+    """csrc/nmsobb_impl.h, SmallSelfSort: no sort launch in front of k_nms_small -- every (image, class) workgroup picks its class
+    out of the image's candidate keys, orders it by rank counting and builds its records in LDS.  Same rows as the reference's
+    single list on every path (OBB_NMS_SELF_SORT = 0: sort kernel, 1: self-sorting where no helpers run, 2: wherever possible), with
+    the cases the sort kernel distinguishes inside one batch: class segments, an empty image, an image on the single list (an
+    oversized box) that fits one segment, one that does not (the call is repeated on the persistent kernel), label rows, a class
+    filter, fp16 ties, more than 4096 candidates in an image.  The library's stage counters say which path ran (stage 1 = sort)."""
+    from yolov5_obb_amd import _lib
+    from yolov5_obb_amd.utils import general
+    L = _lib.lib()
+    nc, A = 16, 30000
+    kw = dict(conf_thres=0.25, iou_thres=0.45, multi_label=True, max_det=1500)
+    base = synth.s_pred(5, A, nc, seed=91, n_obj=70, fg_frac=0.03)
+    base[1, :, 4] = 0.0                                                      # image 1: empty
+    base[2, :, 4] *= 0.02                                                    # image 2: a handful of candidates ...
+    rows = torch.arange(500, 620)
+    _set_class(base, 2, rows[:60], 3, nc, conf=0.9)
+    _set_class(base, 2, rows[60:], 11, nc, conf=0.8)
+    base[2, 500, 2] = 5000.0                                                 # ... one of them oversized: single list, 120 boxes -> segment 0
+    base[3, 700, 2] = 5000.0; base[3, 700, 4] = 0.9                          # image 3: single list of ~900 boxes -> too big for a segment
+    cases = []
+    cases.append(("mixed", base[:3].clone(), kw))
+    cases.append(("single list too big", base.clone(), kw))
+    cases.append(("fp16", base[:3].to(torch.float16), kw))
+    cases.append(("class filter", base[:3].clone(), dict(kw, classes=[2, 3, 11])))
+    cases.append(("best class only", base[:3].clone(), dict(kw, multi_label=False)))
+    cases.append(("max_det 25", base[:3].clone(), dict(kw, max_det=25)))
+    labels = [torch.tensor([[3, 100., 120., 60., 20.], [7, 500., 400., 80., 30.], [3, 104., 121., 58., 21.]]), torch.zeros((0, 5)), torch.tensor([[11, 50., 60., 30., 10.]])]
+    cases.append(("label rows", base[:3].clone(), dict(kw, labels=labels)))
+    many = synth.s_pred(2, A, 40, seed=92, n_obj=300, fg_frac=0.2)           # > 4096 candidates per image, every class below 384
+    cases.append(("many candidates", many, dict(kw, conf_thres=0.3)))
+    for name, pred, k in cases:
+        half = pred.dtype == torch.float16
+        ncls = pred.shape[2] - 185
+        ref = pyref.non_max_suppression_obb(pred.clone(), **k)
+        assert sum(r.shape[0] for r in ref) > 10, name
+        p = pred.to(dev)
+        for mode in ("0", "1", "2", None):
+            if mode is None:
+                monkeypatch.delenv("OBB_NMS_SELF_SORT", raising=False)
+            else:
+                monkeypatch.setenv("OBB_NMS_SELF_SORT", mode)
+            for helpers in ("0", None):
+                if helpers is None:
+                    monkeypatch.delenv("OBB_NMS_SMALL_HELPERS", raising=False)
+                else:
+                    monkeypatch.setenv("OBB_NMS_SMALL_HELPERS", helpers)
+                general.hints_clear()
+                for rep in range(3):
+                    L.obb_profile_enable(1)
+                    try:
+                        got = general.non_max_suppression_obb(p, **k)
+                    finally:
+                        cnt = _stage_counts(L)
+                        L.obb_profile_enable(0)
+                    _cmp(got, ref, ties=half)
+                    if rep == 2 and name in ("mixed", "fp16", "class filter", "label rows", "many candidates"):
+                        # the third call of the shape runs on the previous call's hints: the small-segment kernel, with or without the sort in front
+                        seg = general.hint_get(dev, A, ncls, bool(k["multi_label"]), k["conf_thres"])["seg"]
+                        self_ran = cnt[0] > 0 and cnt[1] == 0
+                        want_self = mode != "0" and (helpers == "0" or mode in ("2", None))
+                        if name == "many candidates" and not want_self:
+                            # (the sort kernel orders an image of more than 4096 candidates as ONE list and reports its size as the
+                            #  largest segment: the next call takes the persistent kernel; self-sorting segments report the largest class)
+                            assert seg > general._SEG_SMALL and cnt[1] > 0, (name, mode, helpers, seg, cnt)
+                            continue
+                        assert 0 < seg <= general._SEG_SMALL, (name, mode, seg)
+                        assert self_ran == want_self, (name, mode, helpers, cnt)
+    assert min(int(((many[b, :, 5:45] * many[b, :, 4:5] > 0.3) & (many[b, :, 4:5] > 0.3)).sum()) for b in range(2)) > 4096

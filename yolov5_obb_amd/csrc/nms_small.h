@@ -70,7 +70,20 @@ struct SmallArgs {
   int* seg_ticket;                         // [nseg] zeroed by the sort kernel
   u64* part_main;                          // [n_pos][kSmallWords]
   u64* part_help;                          // [helpers][kSmallMax][kSmallWords]
+  // SELF-SORTING segments (round 6, fourth part; the FRONT of nmsobb_impl.h: SmallSelfSort): no sort launch in front of this kernel --
+  // the workgroup of (image, class) reads the image's candidate keys as the filter kernel left them, keeps its class, orders it by
+  // rank counting and builds records, alive words and publishing keys in LDS.  rec / alive / seg_begin / seg_end / keys_sorted /
+  // vals_sorted / mode are not read; segment (g, c) publishes at g * cap_img + c * kSmallMax.  keys_in == nullptr: segments from the sort.
+  const unsigned long long* keys_in;       // [images * cap_img] (score_desc << 32 | row * nc + class), slot order
+  const float4* cand;                      // [images * cap_img][2]
+  const int* cnt;                          // [images * kCntPad] candidates per image
+  const int* tiny;                         // [images] flags (kImg*)
+  long long cap_img, max_nms, A;
+  int nc;
+  float class_offset;
+  int* seg_max;                            // [1] the call's largest segment (feedback, status[1])
 };
+struct SmallFromSort { static constexpr bool kSelf = false; };   // FRONT of k_nms_small: segments as the sort kernel left them
 // parts of a segment of n boxes: the work is the pairs that survive the circle test (~n^2), a part should hold what a 128-box
 // segment holds
 constexpr int kSmallClipWaves = 4;                 // the waves of a workgroup sit on four SIMDs: up to this many clip drains run side by side at full speed
@@ -128,7 +141,7 @@ struct SmallWave {                                  // per wave
 };
 
 // returns the segment when this workgroup completed it (the TAIL follows), -1 when it has nothing (more) to do
-template <class G>
+template <class G, class FRONT>
 __device__ __forceinline__ int small_segment(const SmallArgs& a, unsigned char* s_raw) {
   __shared__ int s_next, s_nkept, s_qcnt[kSmallWaves], s_qhead[kSmallWaves], s_qcnt2[kSmallWaves], s_last;
   __shared__ uint32_t s_kept[kSmallMax];
@@ -153,9 +166,22 @@ __device__ __forceinline__ int small_segment(const SmallArgs& a, unsigned char* 
     seg = e & 0xffffff; part = e >> 24;
   }
   if (a.helpers > 0) { const int v = a.seg_np[seg]; if ((v & 255) > 1) { np = v & 255; hbase = v >> 8; } }
-  const int sb = a.seg_begin[seg], n = a.seg_end[seg] - sb;
-  if (n <= 0) return part == 0 ? seg : -1;                       // (keep_cnt is zero already)
-  if (n > kSmallMax) { if (tid == 0 && part == 0) atomicMax(a.too_big, n); return part == 0 ? seg : -1; }
+  int sb, n, md_self = 0;
+  if constexpr (FRONT::kSelf) {
+    // (no helpers in this mode: part == 0)  records, alive words, publishing keys and the zeroed bit matrix are in LDS when load() returns
+    const int r = FRONT::template load<G>(a, seg, reinterpret_cast<float4*>(s_raw),
+                                          reinterpret_cast<u64*>(reinterpret_cast<float4*>(s_raw) + (size_t)kSmallMax * G::RECQ), s_pk, s_pv, &s_next);
+    n = r & 0xffff; md_self = r >> 16;
+    sb = (int)((long long)(seg / a.ncs) * a.cap_img) + (seg % a.ncs) * kSmallMax;
+    if (n <= 0 || n > kSmallMax) {                               // (workgroup-uniform) nobody zeroed keep_cnt in this mode
+      if (tid == 0) { stg_agent(a.keep_cnt + seg, 0); if (n > kSmallMax) atomicMax(a.too_big, n); }
+      return seg;
+    }
+  } else {
+    sb = a.seg_begin[seg]; n = a.seg_end[seg] - sb;
+    if (n <= 0) return part == 0 ? seg : -1;                     // (keep_cnt is zero already)
+    if (n > kSmallMax) { if (tid == 0 && part == 0) atomicMax(a.too_big, n); return part == 0 ? seg : -1; }
+  }
 #ifdef OBB_SMALL_TRACE
   unsigned long long tt[8]; int ti_ = 0, nd0 = 0, nd1 = 0, nd2 = 0, nit = 0;
   unsigned long long acc_d0 = 0, acc_d1 = 0, acc_d2 = 0, acc_draw = 0, acc_l0 = 0, acc_l1 = 0, acc_l2 = 0;
@@ -165,18 +191,20 @@ __device__ __forceinline__ int small_segment(const SmallArgs& a, unsigned char* 
 #endif
   SSTAMP();
   // ---- 1. the segment -> LDS
-  for (int t = tid; t < n * G::RECQ; t += kSmallThreads) s_rec[t] = a.rec[(size_t)sb * G::RECQ + t];
-  for (int t = tid; t < n * kSmallWords; t += kSmallThreads) s_mask[t] = 0ull;
   const bool pub = a.pub_key != nullptr;                         // (kernel-uniform)
-  if (pub)                                                       // requested with the records: no latency of its own
-    for (int t = tid; t < n; t += kSmallThreads) { s_pk[t] = a.keys_sorted[(size_t)sb + t]; s_pv[t] = a.vals_sorted[(size_t)sb + t]; }
-  if (tid < kSmallWords) {
-    const int w0 = (sb >> 6) + tid, sh = sb & 63;
-    u64 v = a.alive[w0] >> sh;
-    if (sh) v |= a.alive[w0 + 1] << (64 - sh);
-    const int left = n - tid * 64;                               // positions of this word that belong to the segment
-    if (left <= 0) v = 0ull; else if (left < 64) v &= (1ull << left) - 1ull;
-    s_alive[tid] = v;
+  if constexpr (!FRONT::kSelf) {
+    for (int t = tid; t < n * G::RECQ; t += kSmallThreads) s_rec[t] = a.rec[(size_t)sb * G::RECQ + t];
+    for (int t = tid; t < n * kSmallWords; t += kSmallThreads) s_mask[t] = 0ull;
+    if (pub)                                                     // requested with the records: no latency of its own
+      for (int t = tid; t < n; t += kSmallThreads) { s_pk[t] = a.keys_sorted[(size_t)sb + t]; s_pv[t] = a.vals_sorted[(size_t)sb + t]; }
+    if (tid < kSmallWords) {
+      const int w0 = (sb >> 6) + tid, sh = sb & 63;
+      u64 v = a.alive[w0] >> sh;
+      if (sh) v |= a.alive[w0 + 1] << (64 - sh);
+      const int left = n - tid * 64;                             // positions of this word that belong to the segment
+      if (left <= 0) v = 0ull; else if (left < 64) v &= (1ull << left) - 1ull;
+      s_alive[tid] = v;
+    }
   }
   if (tid == 0) s_next = 0;
   __syncthreads();
@@ -423,7 +451,7 @@ __device__ __forceinline__ int small_segment(const SmallArgs& a, unsigned char* 
   const int nk = s_nkept;
   if (pub) {
     // write-through stores: the output stage of the image runs in whichever workgroup finishes last, on any XCD
-    const int md = a.mode[seg / a.ncs];
+    const int md = FRONT::kSelf ? md_self : a.mode[seg / a.ncs];
     for (int k = tid; k < nk; k += kSmallThreads) {
       const int i = (int)s_kept[k];
       const unsigned long long key = s_pk[i];
@@ -447,10 +475,10 @@ __device__ __forceinline__ int small_segment(const SmallArgs& a, unsigned char* 
 
 // TAIL::run follows the segment in every workgroup (also those of empty segments): the output stage of the fused driver counts
 // the segments of an image there and runs in the one that arrives last.
-template <class G, class TAIL>
+template <class G, class TAIL, class FRONT = SmallFromSort>
 __global__ __launch_bounds__(kSmallThreads) void k_nms_small(SmallArgs a, typename TAIL::Args ta) {
   extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
-  const int seg = small_segment<G>(a, s_raw);
+  const int seg = small_segment<G, FRONT>(a, s_raw);
   if (seg < 0) return;                                           // (workgroup-uniform)
   TAIL::run(a, ta, s_raw, seg);
 }

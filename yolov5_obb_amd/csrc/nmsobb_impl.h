@@ -1011,6 +1011,106 @@ __global__ __launch_bounds__(256) void k_gather_out(const float4* __restrict__ c
   }
 }
 
+// The FRONT of k_nms_small without a sort launch (round 6, fourth part).  At the reference's default thresholds an image holds a few
+// thousand candidates in ~16 classes: k_sort_prep_lds spent 17 us (+ its launch) on four workgroups per image ordering what the 256
+// segment workgroups of the NMS launch can order themselves -- every workgroup reads its image's keys (8 bytes per candidate, from
+// L2), keeps the candidates of ITS class (the class is the key's tie word modulo nc; label rows carry it in their record), ranks
+// them by counting (keys are unique: the rank is the place; <= 384 members, the keys broadcast from LDS two at a time) and builds
+// records, alive bits (nms_rotated_wrapper.py:32) and publishing keys where the pair phase wants them: in LDS.  Same keys, same
+// order, same records as the sort kernel's (k_sort_prep_lds: "by_class"); an image that keeps ONE list (img_single_list, more than
+// max_nms candidates) is segment 0's if it fits.  What does not fit a segment raises too_big like a segment of the sort's: the caller
+// repeats the call on the persistent kernel.
+struct SmallSelfSort {
+  static constexpr bool kSelf = true;
+  // an image's candidate count, its top-max_nms cut and its mode exactly as k_sort_prep_lds decides them (class_ok holds: the
+  // small-segment kernel is only chosen with it)
+  static __device__ __forceinline__ int image_mode(long long c, int tf, long long cap_img, long long max_nms, int& n, int& e) {
+    const bool over_cap = c > cap_img;
+    if (over_cap) c = cap_img;
+    if (c > kSortLdsMax) c = 0;                                  // not this path's regime: reported through status[1]
+    const bool over_nms = max_nms > 0 && c > max_nms;
+    e = (int)(over_nms ? max_nms : c);                           // :845-846
+    n = (int)c;
+    return (!over_cap && !img_single_list(tf) && !over_nms) ? 1 : 0;
+  }
+  // returns boxes of the segment (> kSmallMax: too many, nothing was built) | mode of the image << 16
+  template <class G>
+  static __device__ __forceinline__ int load(const SmallArgs& a, int seg, float4* s_rec, u64* s_mask, unsigned long long* s_pk,
+                                                       uint32_t* s_pv, int* s_n) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int g = seg / a.ncs, c = seg - g * a.ncs;
+    int n, e;
+    const int m = image_mode(a.cnt[g * kCntPad], a.tiny[g], a.cap_img, a.max_nms, n, e);
+    if (n == 0 || (m == 0 && c != 0)) return m << 16;            // (workgroup-uniform)
+    u64* s_alive = s_mask + (size_t)kSmallMax * kSmallWords;
+    unsigned long long* st_key = reinterpret_cast<unsigned long long*>(s_mask);        // staged members: the bit matrix is not in use yet
+    uint32_t* st_slot = reinterpret_cast<uint32_t*>(st_key + kSmallMax);
+    if (tid == 0) *s_n = 0;
+    if (tid < 8) s_alive[tid] = 0ull;
+    __syncthreads();
+    const size_t b0 = (size_t)g * (size_t)a.cap_img;
+    const uint32_t nc = (uint32_t)a.nc, lim = (uint32_t)((unsigned long long)a.A * nc);   // (A * nc + label rows < 2^32: checked by the launcher)
+    for (int i0 = 0; i0 < n; i0 += 4 * kSmallThreads) {          // (workgroup-uniform trip count: ballots inside)
+      unsigned long long k[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) { const int i = i0 + u * kSmallThreads + tid; k[u] = i < n ? a.keys_in[b0 + i] : 0ull; }
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int i = i0 + u * kSmallThreads + tid;
+        bool mine = false;
+        unsigned long long nk = k[u];
+        if (i < n) {
+          if (m == 1) {                                          // k_rekey: (cls << 56 | score_desc << 24 | anchor)
+            const uint32_t tie = (uint32_t)k[u];
+            uint32_t cls, anchor;
+            if (tie < lim) { anchor = tie / nc; cls = tie - anchor * nc; }
+            else { cls = (uint32_t)(int)a.cand[(b0 + i) * 2 + 1].z; anchor = (uint32_t)a.A + (tie - lim); }     // (an apriori label row)
+            mine = cls == (uint32_t)c;
+            nk = ((unsigned long long)cls << 56) | ((k[u] >> 32) << 24) | (unsigned long long)(anchor & 0xffffffu);
+          } else mine = true;
+        }
+        const u64 mk = __ballot(mine);
+        if (mk) {                                                // (wave-uniform)
+          int base = 0;
+          if (lane == 0) base = atomicAdd(s_n, __popcll(mk));
+          base = __shfl(base, 0);
+          const int at = base + __popcll(mk & lanemask_lt());
+          if (mine && at < kSmallMax) { st_key[at] = nk; st_slot[at] = (uint32_t)i; }
+        }
+      }
+    }
+    __syncthreads();
+    const int nm = *s_n;
+    if (nm > kSmallMax) return (nm > 0xffff ? 0xffff : nm) | (m << 16);
+    const int ec = (m == 1 || nm < e) ? nm : e;                  // one list: the first max_nms by key
+    if (tid == 0 && nm > 0) atomicMax(a.seg_max, ec);
+    if (tid < nm) {
+      const unsigned long long mine = st_key[tid];
+      const uint32_t slot = st_slot[tid];
+      const size_t ci = b0 + slot;
+      const float4 c0 = a.cand[ci * 2], c1 = a.cand[ci * 2 + 1]; // under way during the count
+      int rank = 0, j = 0;
+      const ulonglong2* p2 = reinterpret_cast<const ulonglong2*>(st_key);
+      for (; j + 2 <= nm; j += 2) { const ulonglong2 v = p2[j >> 1]; rank += (v.x < mine ? 1 : 0) + (v.y < mine ? 1 : 0); }
+      if (j < nm) rank += st_key[j] < mine ? 1 : 0;
+      if (rank < ec) {
+        s_pk[rank] = mine; s_pv[rank] = slot;
+        const float coff = c1.z * a.class_offset;                // :849
+        const RBoxFeat f = rbox_make_feat(c0.x + coff, c0.y + coff, c0.z, c0.w, c1.x);
+        float4 rq[4];
+        G::pack(f, rq);
+#pragma unroll
+        for (int u = 0; u < 4; u++) s_rec[rank * G::RECQ + u] = rq[u];
+        const float mn = (c0.w < c0.z) ? c0.w : c0.z;
+        if (!(mn < 0.001f)) atomicOr(&s_alive[rank >> 6], 1ull << (rank & 63));        // nms_rotated_wrapper.py:32
+      }
+    }
+    __syncthreads();                                             // the staged members are read: their place becomes the bit matrix
+    for (int t = tid; t < ec * kSmallWords; t += kSmallThreads) s_mask[t] = 0ull;
+    return ec | (m << 16);
+  }
+};
+
 // The same output stage INSIDE k_nms_small (its TAIL): the segments of an image count themselves on a ticket and the workgroup
 // that arrives last merges the image's kept lists and writes its rows -- the launch of k_gather_out, its start-up and two of its
 // four dependent round trips (kept positions -> keys / slots: the segments publish merge keys and slots themselves) are gone
@@ -1047,7 +1147,12 @@ struct SmallGather {
     while (spec * 2 * ncs <= kSmallThreads) spec <<= 1;          // (ncs <= 256)
     const int myc = tid / spec, myk = tid - myc * spec;
     const bool mine = myc < ncs;
-    const int sb_c = mine ? a.seg_begin[g * ncs + myc] : 0;
+    const bool self = a.keys_in != nullptr;                      // (kernel-uniform) self-sorting segments publish at fixed places
+    // (the image's mode: from its counter, read BEFORE this workgroup arrives -- the image that is done last zeroes the counters)
+    int single_self = 0;
+    if (self) { int n_, e_; single_self = SmallSelfSort::image_mode(ga.cnt[g * kCntPad], ga.tiny[g], ga.cap_img, a.max_nms, n_, e_) == 0 ? 1 : 0; }
+    asm volatile("" : "+v"(single_self));
+    const int sb_c = !mine ? 0 : (self ? (int)((long long)g * ga.cap_img) + myc * kSmallMax : a.seg_begin[g * ncs + myc]);
     int t2 = -1;                                                 // (thread 0) images that were done before this one
     if (tid == 0) {
       const int last = __hip_atomic_fetch_add(ga.ticket + g, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == ncs - 1 ? 1 : 0;
@@ -1112,7 +1217,7 @@ struct SmallGather {
     const int total = s_pre[ncs], maxc = s_maxc;
     GSTAMP();
     if (tid == 0) ga.out_count[g] = (max_det > 0 && total > max_det) ? max_det : (long long)total;
-    const bool single = a.mode[g] == 0;
+    const bool single = self ? single_self != 0 : a.mode[g] == 0;
     const bool in_lds = total <= kLds;
     auto seg_of = [&](int e) -> int {                            // the segment c with s_pre[c] <= e < s_pre[c + 1]
       int lo = 0, hi = ncs - 1;
@@ -1228,7 +1333,7 @@ struct SmallGather {
     if (ga.clean_cnt != nullptr)
       for (int b2 = lane; b2 < ga.bs; b2 += 64) { ga.clean_cnt[b2 * kCntPad] = 0; ga.clean_tiny[b2] = 0; }
     if (lane == 0) {
-      const int seg4 = ga.info[4];
+      const int seg4 = ldg_agent(ga.info + 4);                  // (self-sorting segments raise it in this launch)
       ga.status[0] = big ? -1 : (mx > ga.cap_img ? mx : 0);
       const long long small_seen = ((tf & kImgSmall) ? (1ll << 62) : 0ll) | ((tf & 16) ? (1ll << 61) : 0ll);
       ga.status[1] = mx | (((long long)(big > seg4 ? big : seg4) & 0x1fffffffll) << 32) | small_seen;
@@ -1370,8 +1475,13 @@ static int run_nms_obb(const void* pred, const void* objcol, int dtype, int64_t 
   // the helpers start when the first small segments are through).  Their lists and the parts' bit matrices live in the persistent
   // kernel's edge lists, which this path does not use.  OBB_NMS_SMALL_HELPERS = n pins the number (0: every segment stays whole).
   const int helpers_env = [] { const char* e = getenv("OBB_NMS_SMALL_HELPERS"); const int v = (e && *e) ? atoi(e) : -1; return v > kSmallHelpMax ? kSmallHelpMax : v; }();   // (read per call: tests switch in one process)
+  static const int no_fused_out = obb_dev_switch("OBB_NO_FUSED_OUT", 0) != 0;    // A/B switch (development builds)
+  // OBB_NMS_SELF_SORT (read per call): 0 = always the sort kernel, 1 = self-sorting segments where no helpers would run, 2 = default:
+  // self-sorting segments wherever they are possible (no helpers then: the sort kernel is what hands them out)
+  const int self_env = [] { const char* e = getenv("OBB_NMS_SELF_SORT"); return (e && *e >= '0' && *e <= '2') ? *e - '0' : 2; }();
+  const bool self_possible = small_nms && !out_packed && !no_fused_out && (int64_t)ncs * kSmallMax <= cap_img && self_env != 0;
   int helpers = 0;
-  if (small_nms) {
+  if (small_nms && !(self_possible && self_env == 2 && helpers_env < 0)) {
     const int64_t free_cus = (int64_t)hw_cu_count() - bs * ncs;
     helpers = helpers_env >= 0 ? helpers_env : (int)(free_cus < 0 ? 0 : (free_cus > kSmallHelpMax ? kSmallHelpMax : free_cus));
   }
@@ -1391,7 +1501,11 @@ static int run_nms_obb(const void* pred, const void* objcol, int dtype, int64_t 
       part_help = (u64*)p;
     }
   }
-  if (lds_sort) {
+  // Self-sorting segments (SmallSelfSort): no sort launch when the small-segment kernel writes the rows itself and every segment is
+  // one workgroup's.  OBB_NMS_SELF_SORT=0 keeps the sort kernel (read per call: tests compare the two in one process).
+  const bool self_sort = self_possible && helpers == 0;
+  if (self_sort) {
+  } else if (lds_sort) {
     ProfScope ps(PROF_SEGSORT, st);
     static OncePerDevice attr;
     const size_t lds = (size_t)kSortLdsMax * 12;
@@ -1468,7 +1582,6 @@ static int run_nms_obb(const void* pred, const void* objcol, int dtype, int64_t 
   a.ecap = nv.ecap; a.n = (int)(bs * cap_img); a.capmax = cap_max(bs * ncs);
   a.max_keep = (int)max_det; a.window = nms_window(max_det); a.thr = iou_thres; a.cull = (iou_thres >= 0.f) ? 1 : 0;
   // the output stage runs inside k_nms_small unless the caller wants packed rows (SmallGather)
-  static const int no_fused_out = obb_dev_switch("OBB_NO_FUSED_OUT", 0) != 0;    // A/B switch (development builds)
   const bool fused_out = small_nms && !out_packed && !no_fused_out;
   if (small_nms) {
     ProfScope ps(PROF_STEPS, st);
@@ -1476,7 +1589,8 @@ static int run_nms_obb(const void* pred, const void* objcol, int dtype, int64_t 
     const size_t lds = small_lds_bytes<RotGeom>();
     if (const int attr_dev = attr.need(); attr_dev != OncePerDevice::kDone) {
       if (hipFuncSetAttribute((const void*)k_nms_small<RotGeom, SmallNoTail>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
-          hipFuncSetAttribute((const void*)k_nms_small<RotGeom, SmallGather>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+          hipFuncSetAttribute((const void*)k_nms_small<RotGeom, SmallGather>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+          hipFuncSetAttribute((const void*)k_nms_small<RotGeom, SmallGather, SmallSelfSort>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return OBB_ERR_LAUNCH;
       attr.mark(attr_dev);
     }
@@ -1494,6 +1608,13 @@ static int run_nms_obb(const void* pred, const void* objcol, int dtype, int64_t 
       ga.cand = cv.cand; ga.cnt = cv.cnt; ga.tiny = cv.tiny; ga.info = cv.ticket; ga.ticket = cv.ticket + 16;
       ga.out = out; ga.out_count = out_count; ga.status = status; ga.cap_img = cap_img; ga.max_det = max_det; ga.bs = (int)bs;
       ga.clean_cnt = kept ? cv.cnt : nullptr; ga.clean_tiny = kept ? cv.tiny : nullptr;
+      if (self_sort) {
+        // (the segments read keys_a, the filter kernel's output, while others publish: keys_b / vals_b, the sort's output places, are free)
+        sa.pub_key = cv.keys_b; sa.pub_val = cv.vals_b; sa.keys_sorted = nullptr; sa.vals_sorted = nullptr;
+        sa.keys_in = cv.keys_a; sa.cand = cv.cand; sa.cnt = cv.cnt; sa.tiny = cv.tiny; sa.cap_img = cap_img; sa.max_nms = max_nms; sa.A = A; sa.nc = nc;
+        sa.class_offset = max_wh; sa.seg_max = cv.ticket + 4;
+        k_nms_small<RotGeom, SmallGather, SmallSelfSort><<<gsmall, kSmallThreads, lds, st>>>(sa, ga);
+      } else
       k_nms_small<RotGeom, SmallGather><<<gsmall, kSmallThreads, lds, st>>>(sa, ga);
     } else {
       k_nms_small<RotGeom, SmallNoTail><<<gsmall, kSmallThreads, lds, st>>>(sa, SmallNoTail::Args{});
