@@ -70,6 +70,13 @@ int obb_profile_collect(double* ms_sum_host, int64_t* count_host, int n_stages);
  *                           class reported (kept boxes, independent slabs, device time of either path)
  *   OBB_NMS_MK_XLDS=0 | 1   phase kernels: the cross probe on the chunk's table in global memory (0) or on a table of the kept rows in
  *                           every workgroup's LDS (1); default: 1 where the previous call kept <= 6144 boxes
+ *   OBB_NMS_MK_NOFULL=0     phase kernels: the decide kernels run the IoU-interval stage in front of the exact clip again (default: the
+ *                           pending pairs go straight to the clip)
+ *   OBB_NMS_SELF_SORT=0|1|2 obb_non_max_suppression_obb* with the small-segment NMS kernel (expected_cand bits 32..60) and out_packed = 0:
+ *                           0 = the per-image sort kernel in front of it, 1 = self-sorting segments (csrc/nmsobb_impl.h: SmallSelfSort --
+ *                           no sort launch, two launches per call) where the sort kernel would hand out no helper workgroups,
+ *                           2 = default: self-sorting segments wherever they are possible
+ *   OBB_NMS_SMALL_HELPERS=n small-segment NMS kernel behind the sort kernel: helper workgroups that share large segments (0: none)
  * Read once per process, tests only: OBB_NMS_MK_STEPS (enqueued steps), OBB_NMS_MK_PEND (pending-list capacity), OBB_NMS_MK_CHUNK
  * (first chunk): they force the hand-overs to the persistent kernel that tests/test_nms_mk_gpu.py checks.
  * Development builds only (make DEV=1; ignored otherwise): the A/B switches OBB_NMS_NO_GRID, OBB_NMS_NO_SLABS, OBB_NO_CLASS_SEG,
@@ -276,8 +283,9 @@ int obb_non_max_suppression_obb_col(const void* pred, const void* objcol, int dt
  * bytes of device memory (256-byte aligned), zeroed ONCE by the caller (hipMemset) and then handed to every call with this bs
  * that is ordered on one stream.  Each call finds it zeroed and leaves it zeroed (its last kernel does that), so the call has no
  * reset launch of its own; the filter kernel zeroes the state of the later launches on its way.  At the reference's default
- * thresholds with out_packed = 0 the whole of non_max_suppression_obb is then THREE launches (filter + CSL decode, sort, NMS +
- * output rows).  A call that returns an error may leave the buffer dirty: zero it again.  Two calls that are not ordered on one
+ * thresholds with out_packed = 0 the whole of non_max_suppression_obb is then TWO launches (filter + CSL decode; NMS whose
+ * (image, class) workgroups order their own class and write the output rows -- round 6, OBB_NMS_SELF_SORT above; three with the sort
+ * kernel between them).  A call that returns an error may leave the buffer dirty: zero it again.  Two calls that are not ordered on one
  * stream need a buffer each.  Everything else as obb_non_max_suppression_obb_col (objcol may be NULL). */
 size_t obb_nms_obb_state_bytes(int64_t bs);
 int obb_non_max_suppression_obb_st(const void* pred, const void* objcol, int dtype, int64_t bs, int64_t A, int64_t no,

@@ -81,6 +81,7 @@ struct MkArgs {
   int64_t* num_keep;                      // written by whoever completes the call
   const int* bbpart; int nparts;
   int capmax, cap_first;
+  int skip_full;                          // decide kernels: 1 = every open pending pair goes straight to the exact clip (see mk_decide_phase)
   float thr;
   uint4* pend1; int cap1;                 // {query position, entry position, entry index << 16 | query index (pairs), -} the quick tests left undecided
   int* hint_host;                         // pinned words: [0] steps the call needed, [1] boxes it kept (read by the NEXT call of this thread; may be NULL)
@@ -879,7 +880,7 @@ __device__ __forceinline__ void mk_decide_phase(const MkArgs& a, float* scr_wave
       //  no further decision)
       bool open = true;
       if constexpr (CROSS) open = (ldg_agent(a.alive + (p.z >> 6)) >> (p.z & 63)) & 1ull;
-      if (open) res = RotGeom::classify_full(ra, rb, a.thr);
+      if (open) res = a.skip_full ? 2 : RotGeom::classify_full(ra, rb, a.thr);
     }
     bool h = res == 1;
     if (__ballot(res == 2)) {

@@ -166,6 +166,14 @@ __device__ __forceinline__ int small_segment(const SmallArgs& a, unsigned char* 
     seg = e & 0xffffff; part = e >> 24;
   }
   if (a.helpers > 0) { const int v = a.seg_np[seg]; if ((v & 255) > 1) { np = v & 255; hbase = v >> 8; } }
+#ifdef OBB_SMALL_TRACE
+  unsigned long long tt[8]; int ti_ = 0, nd0 = 0, nd1 = 0, nd2 = 0, nit = 0;
+  unsigned long long acc_d0 = 0, acc_d1 = 0, acc_d2 = 0, acc_draw = 0, acc_l0 = 0, acc_l1 = 0, acc_l2 = 0;
+#define SSTAMP() do { tt[ti_++] = wall_clock64(); } while (0)
+#else
+#define SSTAMP() do {} while (0)
+#endif
+  SSTAMP();                                                      // (self-sorting segments: the front end counts as "load")
   int sb, n, md_self = 0;
   if constexpr (FRONT::kSelf) {
     // (no helpers in this mode: part == 0)  records, alive words, publishing keys and the zeroed bit matrix are in LDS when load() returns
@@ -182,14 +190,6 @@ __device__ __forceinline__ int small_segment(const SmallArgs& a, unsigned char* 
     if (n <= 0) return part == 0 ? seg : -1;                     // (keep_cnt is zero already)
     if (n > kSmallMax) { if (tid == 0 && part == 0) atomicMax(a.too_big, n); return part == 0 ? seg : -1; }
   }
-#ifdef OBB_SMALL_TRACE
-  unsigned long long tt[8]; int ti_ = 0, nd0 = 0, nd1 = 0, nd2 = 0, nit = 0;
-  unsigned long long acc_d0 = 0, acc_d1 = 0, acc_d2 = 0, acc_draw = 0, acc_l0 = 0, acc_l1 = 0, acc_l2 = 0;
-#define SSTAMP() do { tt[ti_++] = wall_clock64(); } while (0)
-#else
-#define SSTAMP() do {} while (0)
-#endif
-  SSTAMP();
   // ---- 1. the segment -> LDS
   const bool pub = a.pub_key != nullptr;                         // (kernel-uniform)
   if constexpr (!FRONT::kSelf) {
