@@ -964,11 +964,11 @@ def main():
             "hbm_copy": hbm_copy,
             "val_buckets": val_obj,
             "kernels": {
-                "obb::k_nms_small<obb::RotGeom, obb::SmallGather> (bs16 step)": {
+                "obb::k_nms_small<obb::RotGeom, obb::SmallGather, obb::SmallSelfSort> (bs16 step)": {
                     "bound": "hbm", "achieved": round(nms_ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(nms_ach / HBM_PEAK_GBS, 5), "traffic": pmc.get("k_nms_persist_bs16"), "algorithmic_bytes": nms_alg,
                     "avg_kernel_ms": round(nms_ms_step, 5), "candidates_per_image": [int(c) for c in cand],
-                    "note": "largest share of the step; one workgroup per (image, class) segment of ~100 boxes held in LDS (csrc/nms_small.h; round 3: the persistent kernel, 0.073 ms): VALU bound by the decision stages, not HBM bound.  Since round 5 the time includes the output rows: the workgroup that finishes an image merges its kept lists and writes them (csrc/nmsobb_impl.h SmallGather; the stage 'gather' is 0), and the call is three launches (filter, sort, this kernel)"},
+                    "note": "largest share of the step; one workgroup per (image, class) segment of ~100 boxes held in LDS (csrc/nms_small.h; round 3: the persistent kernel, 0.073 ms): VALU bound by the decision stages, not HBM bound.  Since round 5 the time includes the output rows: the workgroup that finishes an image merges its kept lists and writes them (csrc/nmsobb_impl.h SmallGather; the stage 'gather' is 0).  Since round 6 it also includes the per-class ordering: every workgroup picks its class out of the image's candidate keys and ranks it in LDS (SmallSelfSort; the stage 'segsort' is 0) -- the call is two launches (filter, this kernel)"},
                 "obb::k_decode<__half>": {
                     "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "avg_kernel_ms": round(dec_ms, 5), "avg_kernel_ms_one_tensor_warm": round(dec_ms_warm, 5),

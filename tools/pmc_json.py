@@ -62,7 +62,8 @@ def main():
     # the bs16 step's NMS kernel: round 4's small-segment kernel (the first call of the shape may still run the persistent one)
     try:
         fb, wb = find(f, "obb::k_nms_small<obb::RotGeom"), find(w, "obb::k_nms_small<obb::RotGeom")      # (round 5: <RotGeom, SmallGather>)
-        out["k_nms_bs16_kernel"] = "obb::k_nms_small<obb::RotGeom, obb::SmallGather>" if any("SmallGather" in k and "k_nms_small" in k for k in f) else "obb::k_nms_small<obb::RotGeom>"
+        out["k_nms_bs16_kernel"] = ("obb::k_nms_small<obb::RotGeom, obb::SmallGather, obb::SmallSelfSort>" if any("SmallSelfSort" in k and "k_nms_small" in k for k in f) else
+                                    "obb::k_nms_small<obb::RotGeom, obb::SmallGather>" if any("SmallGather" in k and "k_nms_small" in k for k in f) else "obb::k_nms_small<obb::RotGeom>")
     except KeyError:
         fb, wb = find(f, "obb::k_nms_persist<obb::RotGeom, false>"), find(w, "obb::k_nms_persist<obb::RotGeom, false>")
         out["k_nms_bs16_kernel"] = "obb::k_nms_persist<obb::RotGeom, false>"

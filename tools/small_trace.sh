@@ -12,5 +12,5 @@ if [ "$1" = build ]; then
 fi
 O=${2:-gpurun_out/trace}; mkdir -p $O
 for h in ${HELPERS:-0 256}; do
-OBB_NMS_SMALL_HELPERS=$h OBB_HIP_LIB=$D/yolov5_obb_amd/libobb_hip_trace.so OBB_BINDING=ctypes python tools/small_trace_report.py 2>&1 | grep -v amdgpu.ids | tee $O/report_h$h.txt
+OBB_NMS_SMALL_HELPERS=$h OBB_HIP_LIB=$D/yolov5_obb_amd/libobb_hip_trace.so OBB_BINDING=${BINDING:-ctypes} python tools/small_trace_report.py 2>&1 | grep -v amdgpu.ids | tee $O/report_h$h.txt
 done

@@ -27,7 +27,7 @@ def main():
                 continue
             r = dict(zip(hdr, c))
             rows.setdefault((sec, r["workload"]), []).append(r)
-    short = {"k_nms_persist<RotGeom, true>": "k_nms_persist_100k", "k_nms_small<RotGeom>": "k_nms_small_bs16", "k_nms_small<RotGeom, SmallGather>": "k_nms_small_bs16", "k_quad_strip<true>": "k_quad_strip",
+    short = {"k_nms_persist<RotGeom, true>": "k_nms_persist_100k", "k_nms_small<RotGeom>": "k_nms_small_bs16", "k_nms_small<RotGeom, SmallGather>": "k_nms_small_bs16", "k_nms_small<RotGeom, SmallGather, SmallSelfSort>": "k_nms_small_bs16", "k_nms_small<RotGeom, SmallGather, SmallFromSort>": "k_nms_small_bs16", "k_quad_strip<true>": "k_quad_strip",
              "k_decode<__half>": "k_decode", "k_sort_prep_lds": "k_sort_prep_lds", "k_gather_out": "k_gather_out",
              "k_nms_persist<QuadGeom, false>": "k_nms_persist_quad_30k", "k_ps_local_scores": "k_ps_local_scores", "k_ps_split": "k_ps_split",
              "k_ps_bucket": "k_ps_bucket", "k_prep_rot": "k_prep_rot", "k_slab_split<RotGeom>": "k_slab_split"}

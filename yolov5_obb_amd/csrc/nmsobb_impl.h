@@ -1039,6 +1039,23 @@ struct SmallSelfSort {
                                                        uint32_t* s_pv, int* s_n) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int g = seg / a.ncs, c = seg - g * a.ncs;
+#ifndef OBB_SELF_KPT
+#define OBB_SELF_KPT 8
+#endif
+#ifndef OBB_SELF_SPEC
+#define OBB_SELF_SPEC 1
+#endif
+#ifndef OBB_SELF_RU
+#define OBB_SELF_RU 1
+#endif
+    constexpr int KPT = OBB_SELF_KPT;                            // keys per thread and trip
+    const size_t b0 = (size_t)g * (size_t)a.cap_img;
+    // the first trip's keys are requested TOGETHER with the image's counter (slots behind the count hold stale keys of the
+    // workspace: read, never used) -- one round trip less in front of every segment
+    const int spec = !OBB_SELF_SPEC ? 0 : (a.cap_img < (long long)KPT * kSmallThreads ? (int)a.cap_img : KPT * kSmallThreads);
+    unsigned long long k[KPT];
+#pragma unroll
+    for (int u = 0; u < KPT; u++) { const int i = u * kSmallThreads + tid; k[u] = i < spec ? a.keys_in[b0 + i] : 0ull; }
     int n, e;
     const int m = image_mode(a.cnt[g * kCntPad], a.tiny[g], a.cap_img, a.max_nms, n, e);
     if (n == 0 || (m == 0 && c != 0)) return m << 16;            // (workgroup-uniform)
@@ -1048,15 +1065,16 @@ struct SmallSelfSort {
     if (tid == 0) *s_n = 0;
     if (tid < 8) s_alive[tid] = 0ull;
     __syncthreads();
-    const size_t b0 = (size_t)g * (size_t)a.cap_img;
     const uint32_t nc = (uint32_t)a.nc, lim = (uint32_t)((unsigned long long)a.A * nc);   // (A * nc + label rows < 2^32: checked by the launcher)
-    for (int i0 = 0; i0 < n; i0 += 4 * kSmallThreads) {          // (workgroup-uniform trip count: ballots inside)
-      unsigned long long k[4];
+    for (int i0 = 0; i0 < n; i0 += KPT * kSmallThreads) {        // (workgroup-uniform trip count: ballots inside)
+      if (i0 > 0 || !OBB_SELF_SPEC) {
 #pragma unroll
-      for (int u = 0; u < 4; u++) { const int i = i0 + u * kSmallThreads + tid; k[u] = i < n ? a.keys_in[b0 + i] : 0ull; }
+        for (int u = 0; u < KPT; u++) { const int i = i0 + u * kSmallThreads + tid; k[u] = i < n ? a.keys_in[b0 + i] : 0ull; }
+      }
 #pragma unroll
-      for (int u = 0; u < 4; u++) {
+      for (int u = 0; u < KPT; u++) {
         const int i = i0 + u * kSmallThreads + tid;
+        if (i0 + u * kSmallThreads >= n) break;                  // (workgroup-uniform)
         bool mine = false;
         unsigned long long nk = k[u];
         if (i < n) {
@@ -1091,6 +1109,13 @@ struct SmallSelfSort {
       const float4 c0 = a.cand[ci * 2], c1 = a.cand[ci * 2 + 1]; // under way during the count
       int rank = 0, j = 0;
       const ulonglong2* p2 = reinterpret_cast<const ulonglong2*>(st_key);
+      for (; OBB_SELF_RU && j + 16 <= nm; j += 16) {                            // eight 16-byte broadcast reads in flight (one at a time: 64 cycles each)
+        ulonglong2 v[8];
+#pragma unroll
+        for (int z = 0; z < 8; z++) v[z] = p2[(j >> 1) + z];
+#pragma unroll
+        for (int z = 0; z < 8; z++) rank += (v[z].x < mine ? 1 : 0) + (v[z].y < mine ? 1 : 0);
+      }
       for (; j + 2 <= nm; j += 2) { const ulonglong2 v = p2[j >> 1]; rank += (v.x < mine ? 1 : 0) + (v.y < mine ? 1 : 0); }
       if (j < nm) rank += st_key[j] < mine ? 1 : 0;
       if (rank < ec) {
