@@ -363,6 +363,9 @@ __global__ void k_append_extra(const float* __restrict__ extra8, int m, long lon
   const float* e = extra8 + (size_t)i * 8;
   const int b = (int)e[0];
   if (b < 0 || b >= a.bs) return;
+  // a label row is a candidate like any other (:807-813 append it in front of the filters): conf = 1 > conf_thres (:827 / :831) and
+  // the class filter (:835) apply to it -- until round 6 the class filter did not (found by tools/self_fuzz.py: `labels` + `classes`)
+  if (!(e[6] > a.conf_thres) || !class_allowed(a.cm, (int)e[7])) return;
   const int slot = atomicAdd(&a.cnt[b * kCntPad], 1);
   { const int fl = cand_flags(e[1], e[3], e[4], a.win_lo, a.win_hi); if (fl) atomicOr(&a.tiny[b], fl); }
   if (slot >= a.cap_img) return;
