@@ -1,0 +1,69 @@
+"""Random differential check of the single-list NMS entry points against the C oracle (development aid):
+nms_rotated f32 / f64 and nms_poly over random sizes (every size class: small, persistent kernel, phase kernels), distributions,
+thresholds, duplicates, degenerate boxes, exact score ties."""
+import os, sys, random, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+import oracle
+from tests import synth
+from yolov5_obb_amd import nms_rotated_ext
+dev = torch.device("cuda:0")
+seed = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+N = int(sys.argv[2]) if len(sys.argv) > 2 else 60
+rng = random.Random(seed)
+bad = 0
+t_end = time.time() + float(os.environ.get("FUZZ_SECONDS", "600"))
+for it in range(N):
+    if time.time() > t_end: print("time box reached at", it); break
+    kind = rng.choice(["rot32", "rot32", "rot64", "poly"])
+    dist = rng.choice(["clustered", "clustered", "uniform", "classes"])
+    n = rng.choice([0, 1, 2, 63, 64, 65, 500, 3000, 16383, 16384, 20000, 40000]) if dist != "uniform" else rng.choice([1, 70, 900, 5000, 17000])
+    if kind == "poly": n = min(n, 20000)
+    if kind == "rot64": n = min(n, 20000)
+    thr = rng.choice([0.0, 0.05, 0.3, 0.4, 0.5, 0.75, 0.95, 1.0])
+    k = rng.choice([3, 50, 300, 3000])
+    ext = rng.choice([64.0, 1024.0, 1024.0, 8192.0])
+    if n == 0:
+        d, s = torch.zeros((0, 5)), torch.zeros((0,))
+    elif dist == "uniform":
+        d, s = synth.s_uniform(n, seed=seed * 1000 + it, extent=ext)
+    else:
+        d, s = synth.s_clustered(n, k, seed=seed * 1000 + it, extent=ext)
+        if dist == "classes": d = synth.with_classes(d, rng.choice([2, 18]), seed=it)[0]
+    g = torch.Generator().manual_seed(it)
+    if n > 4:
+        mode = rng.choice(["plain", "dups", "ties", "degenerate", "mixed"])
+        if mode in ("dups", "mixed"):
+            m = max(1, n // rng.choice([2, 10, 100])); src = torch.randint(0, n, (m,), generator=g); dst = torch.randint(0, n, (m,), generator=g)
+            d[dst] = d[src]
+        if mode in ("ties", "mixed"):
+            s = (s * rng.choice([4, 50, 1000])).round() / 1000.0
+        else:
+            s = synth.tie_free(s)
+        if mode in ("degenerate", "mixed"):
+            m = max(1, n // 50); idx = torch.randint(0, n, (m,), generator=g)
+            d[idx[: m // 3], 2] = 0.0                                   # zero width
+            d[idx[m // 3: 2 * m // 3], 3] = 1e-4                        # sub-pixel
+            d[idx[2 * m // 3:], 2:4] = torch.tensor([3000.0, 2.0])      # very long and thin
+    else:
+        mode = "plain"
+    try:
+        if kind == "rot32":
+            got = nms_rotated_ext.nms_rotated(d.to(dev), s.to(dev), thr).cpu().numpy()
+            ref = oracle.nms_rotated(d.numpy(), s.numpy(), thr)
+        elif kind == "rot64":
+            d64, s64 = d.double(), s.double()
+            got = nms_rotated_ext.nms_rotated(d64.to(dev), s64.to(dev), thr).cpu().numpy()
+            ref = oracle.nms_rotated(d64.numpy(), s64.numpy(), thr)
+        else:
+            q9 = torch.cat((synth.rbox_to_quad(d), s[:, None]), 1).contiguous() if n else torch.zeros((0, 9))
+            got = nms_rotated_ext.nms_poly(q9.to(dev), thr).cpu().numpy()
+            ref = oracle.nms_poly(q9.numpy(), thr)
+        ok = np.array_equal(got, ref)
+    except Exception as e:
+        ok = False; print("EXC", repr(e)[:200])
+    if not ok:
+        bad += 1
+        print("MISMATCH", it, dict(kind=kind, dist=dist, n=n, thr=thr, k=k, ext=ext, mode=mode), "got", len(got) if ok is False and 'got' in dir() else None, "ref", len(ref) if 'ref' in dir() else None, flush=True)
+print(f"nms_fuzz seed {seed}: {it + 1} cases, {bad} mismatches", flush=True)

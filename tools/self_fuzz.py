@@ -25,28 +25,35 @@ for it in range(N):
     kw = dict(conf_thres=conf, iou_thres=iou, multi_label=multi, max_det=md)
     if rng.random() < 0.25:
         kw["classes"] = sorted(rng.sample(range(nc), max(1, nc // 3)))
+    if rng.random() < 0.15:
+        kw["agnostic"] = True
     if rng.random() < 0.2:
         kw["labels"] = [torch.tensor([[rng.randrange(nc), 100., 120., 60., 20.], [rng.randrange(nc), 101., 121., 58., 21.]]) if (b % 2 == 0) else torch.zeros((0, 5)) for b in range(bs)]
     p = pred.to(dev)
     outs = {}
-    for mode in ("0", "2"):
+    MODES = os.environ.get("FUZZ_MODES", "0 2").split()
+    for mode in MODES:
         os.environ["OBB_NMS_SELF_SORT"] = mode
         general.hints_clear()
         rs = [general.non_max_suppression_obb(p, **kw) for _ in range(3)]
         for r in rs[1:]:
             assert all(torch.equal(a, b) for a, b in zip(rs[0], r)), ("call-to-call difference", it, mode)
         outs[mode] = [o.cpu() for o in rs[0]]
-    same = all(torch.equal(a, b) for a, b in zip(outs["0"], outs["2"]))
+    same = all(torch.equal(a, b) for a, b in zip(outs[MODES[0]], outs[MODES[-1]]))
     ref_ok = True
-    if it % 4 == 0 and not half:
+    if it % int(os.environ.get("FUZZ_ORACLE_EVERY", "4")) == 0:
         ref = pyref.non_max_suppression_obb(pred.clone(), **kw)
-        ref_ok = all(torch.equal(a, torch.as_tensor(b)) for a, b in zip(outs["2"], ref))
+        if half:     # equal-confidence groups: the reference's sort is unstable, rows are compared as sets inside them (tests/_cmp ties=True)
+            ref_ok = all(a.shape == torch.as_tensor(b).shape and torch.equal(a[:, 5], torch.as_tensor(b)[:, 5]) and
+                         __import__("numpy").array_equal(synth.canon_rows(a), synth.canon_rows(torch.as_tensor(b))) for a, b in zip(outs[MODES[-1]], ref))
+        else:
+            ref_ok = all(torch.equal(a, torch.as_tensor(b)) for a, b in zip(outs[MODES[-1]], ref))
     if not (same and ref_ok):
         bad += 1
         os.makedirs("gpurun_out/fuzz", exist_ok=True)
-        torch.save({"pred": pred, "kw": kw, "gpu": outs["2"], "gpu0": outs["0"]}, f"gpurun_out/fuzz/case_{sys.argv[1] if len(sys.argv) > 1 else 0}_{it}.pt")
+        torch.save({"pred": pred, "kw": kw, "gpu": outs[MODES[-1]], "gpu0": outs[MODES[0]]}, f"gpurun_out/fuzz/case_{sys.argv[1] if len(sys.argv) > 1 else 0}_{it}.pt")
         if not ref_ok:
-            for b, (a_, r_) in enumerate(zip(outs["2"], ref)):
+            for b, (a_, r_) in enumerate(zip(outs[MODES[-1]], ref)):
                 r_ = torch.as_tensor(r_)
                 if a_.shape != r_.shape or not torch.equal(a_, r_):
                     print("   image", b, "gpu rows", tuple(a_.shape), "ref rows", tuple(r_.shape), "labels" in kw, flush=True)
