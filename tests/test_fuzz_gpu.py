@@ -29,3 +29,10 @@ def test_fused_driver_on_random_shapes(dev, oracle_lib):
 def test_single_list_nms_on_random_inputs(dev, oracle_lib):
     out, tail = _run("nms_fuzz.py", "21", "20", env={"FUZZ_SECONDS": "80"})
     assert ", 0 mismatches" in out and "nms_fuzz seed 21" in out, tail
+
+
+def test_pairwise_iou_on_random_inputs(dev, oracle_lib):
+    """tools/iou_fuzz.py: rotated and quad IoU matrices on random sizes / extents up to 60000 / shapes (identical boxes, zero areas,
+    reversed rings): quads bit for bit (the proved and the searched skip rules included), rotated within the documented last-bit bar."""
+    out, tail = _run("iou_fuzz.py", "21", "40")
+    assert "iou_fuzz seed 21: 40 cases, 0 mismatches" in out, tail
