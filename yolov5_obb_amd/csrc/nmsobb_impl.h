@@ -1023,6 +1023,17 @@ __global__ __launch_bounds__(256) void k_gather_out(const float4* __restrict__ c
 // order, same records as the sort kernel's (k_sort_prep_lds: "by_class"); an image that keeps ONE list (img_single_list, more than
 // max_nms candidates) is segment 0's if it fits.  What does not fit a segment raises too_big like a segment of the sort's: the caller
 // repeats the call on the persistent kernel.
+// (compile-time switches of the front end, measured within 1 us of each other on the bs16 step: keys per thread and trip, the first
+//  trip requested together with the image's counter, the rank count with eight reads in flight)
+#ifndef OBB_SELF_KPT
+#define OBB_SELF_KPT 8
+#endif
+#ifndef OBB_SELF_SPEC
+#define OBB_SELF_SPEC 1
+#endif
+#ifndef OBB_SELF_RU
+#define OBB_SELF_RU 1
+#endif
 struct SmallSelfSort {
   static constexpr bool kSelf = true;
   // an image's candidate count, its top-max_nms cut and its mode exactly as k_sort_prep_lds decides them (class_ok holds: the
@@ -1042,15 +1053,6 @@ struct SmallSelfSort {
                                                        uint32_t* s_pv, int* s_n) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int g = seg / a.ncs, c = seg - g * a.ncs;
-#ifndef OBB_SELF_KPT
-#define OBB_SELF_KPT 8
-#endif
-#ifndef OBB_SELF_SPEC
-#define OBB_SELF_SPEC 1
-#endif
-#ifndef OBB_SELF_RU
-#define OBB_SELF_RU 1
-#endif
     constexpr int KPT = OBB_SELF_KPT;                            // keys per thread and trip
     const size_t b0 = (size_t)g * (size_t)a.cap_img;
     // the first trip's keys are requested TOGETHER with the image's counter (slots behind the count hold stale keys of the
