@@ -7,7 +7,7 @@ from tests import synth
 from yolov5_obb_amd import _lib
 from yolov5_obb_amd.utils.general import non_max_suppression_obb
 dev = torch.device("cuda:0")
-pred = synth.s_pred(16, 64512, 16, seed=1000, n_obj=120, fg_frac=0.03, device=dev, dtype=torch.float16)
+pred = synth.s_pred(16, 64512, 16, seed=int(os.environ.get("SEED", "1000")), n_obj=int(os.environ.get("N_OBJ", "120")), fg_frac=float(os.environ.get("FG_FRAC", "0.03")), device=dev, dtype=torch.float16)
 kw = dict(conf_thres=0.25, iou_thres=0.45, multi_label=True, max_det=1500)
 L = C.CDLL(_lib.LIB_PATH)
 seg = np.zeros(2048 * 16, dtype=np.uint64); tail = np.zeros(2048 * 4, dtype=np.uint64)
