@@ -229,6 +229,10 @@ int64_t obb_task1_format_rows(const char* text_host, const int32_t* name_off_hos
  *               in-LDS sort and iou_thres >= 0 selects the one-workgroup-per-segment NMS kernel (csrc/nms_small.h); a call that
  *               meets a larger segment there sets status[0] = -1: NOTHING of its output is valid, call again with the
  *               segment size status[1] reports (the Python layer does).  0 or larger: the persistent kernel.
+ *               With out_packed = 0 that kernel's (image, class) workgroups also ORDER their class themselves (round 6: no sort
+ *               launch; OBB_NMS_SELF_SORT above) and the reported size is the largest class of any image of up to
+ *               OBB_NMS_SORT_LDS_MAX candidates; behind the sort kernel an image above OBB_NMS_SORT_LDS_MAX / 2 candidates is
+ *               ordered as one list and reported with its whole size.
  *               bit 62      the previous call met boxes with a short side in [0.001, 1) px (status[1] bit 62).  The reference's fp32
  *               clip is ill conditioned for such a box against a partner tens of thousands of pixels away, i.e. across its
  *               cls * max_wh offsets (utils/general.py:849-851), so an image holding one may only keep its per-class NMS segments if

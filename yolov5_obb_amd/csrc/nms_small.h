@@ -7,7 +7,9 @@
 // set, team barriers, a planner in front: for a 100-box segment its workgroup spends 7 us selecting, 12 us resolving and every
 // record it touches is a global round trip (busiest workgroup 69 us, mean 47).  Here a segment lives in LDS from its first
 // load to its last store:
-//   1. records (64 bytes per box) and the segment's slice of the alive bitmap -> LDS;
+//   1. records (64 bytes per box) and the segment's slice of the alive bitmap -> LDS -- as the sort kernel left them (FRONT =
+//      SmallFromSort), or built here from the image's candidate keys with no sort launch in front of the kernel (FRONT =
+//      SmallSelfSort of nmsobb_impl.h, round 6: the fused driver's default);
 //   2. pairs: 64 x 16 slices of the upper triangle, drawn by the eight waves from an LDS counter; the circle test of
 //      RotGeom::cheap_reject on quad 0, then the same three decision stages as everywhere else (classify_quick, classify_full,
 //      hit_exact -- the decisions ARE the reference's), each with its own LDS queue so that a stage always runs on a full wave;
