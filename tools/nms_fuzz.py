@@ -22,6 +22,11 @@ for it in range(N):
     if kind == "poly": n = min(n, 20000)
     if kind == "rot64": n = min(n, 20000)
     thr = rng.choice([0.0, 0.05, 0.3, 0.4, 0.5, 0.75, 0.95, 1.0])
+    if kind == "rot64" and thr == 1.0:
+        # float64 IoU of EXACT duplicates is 1 +- an ulp, and which side it falls on depends on the last bit of the platform's double
+        # sin / cos (ocml here, glibc under the oracle; CUDA's libm under the reference): "IoU > 1.0" is not pinned by any CPU oracle
+        # (seed 9, case 84 of this tool: boxes 29 / 42 identical, the oracle drops 42, the device keeps it).  DESIGN 2.
+        thr = 0.95
     k = rng.choice([3, 50, 300, 3000])
     ext = rng.choice([64.0, 1024.0, 1024.0, 8192.0])
     if n == 0:
